@@ -1,0 +1,193 @@
+/*
+ * vidsitu_hip.h -- C-ABI of libvidsitu_hip.so (gfx950 / MI355X only).
+ *
+ * The reference (TheShadow29/VidSitu) has no FFI of its own: every FLOP of its
+ * hot path is reached through torch.nn modules of un-vendored packages
+ * (SURVEY.md section 2.2).  Each entry point below therefore cites the
+ * reference call site whose arithmetic it replaces.
+ *
+ * Conventions (all entry points):
+ *   - raw DEVICE pointers, POD descriptors, caller's hipStream_t (as void*);
+ *   - never allocates, never synchronises, never throws; returns 0 or a
+ *     negative vs_status; vs_last_error_string() explains the last failure of
+ *     the calling thread;
+ *   - activations are dense channels-last "NDHWC" bf16 (a torch tensor of
+ *     logical shape [N,C,T,H,W] in torch.channels_last_3d memory format), with
+ *     an explicit row pitch `ld` (elements between consecutive positions) so a
+ *     channel concat is a pointer offset into a wider buffer;
+ *   - conv weights are [Cout][kT][kH][kW][Cin] bf16 (the channels_last_3d image
+ *     of the reference's [Cout,Cin,kT,kH,kW] parameter);
+ *   - statistics, affine parameters, gradients of parameters: fp32.
+ */
+#ifndef VIDSITU_HIP_H
+#define VIDSITU_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum vs_status {
+  VS_OK = 0,
+  VS_ERR_BAD_ARG = -1,
+  VS_ERR_UNSUPPORTED = -2,
+  VS_ERR_WORKSPACE = -3,
+  VS_ERR_LAUNCH = -4
+} vs_status;
+
+/* conv epilogue / mode flags */
+#define VS_CONV_AFFINE 1   /* y = acc*scale[c] + shift[c]   (eval-mode BN folded) */
+#define VS_CONV_RESIDUAL 2 /* y += residual                 (ResBlock add)        */
+#define VS_CONV_RELU 4     /* y = max(y, 0)                                        */
+#define VS_CONV_STATS 8    /* per-block per-channel sum / sum-of-squares partials  */
+#define VS_CONV_NAIVE 16   /* debug: one-thread-per-output direct kernel           */
+#define VS_CONV_APRO 32    /* a = relu?(a*in_scale[c]+in_shift[c]) applied to the  \
+                              gathered input (train-mode BN of the producer fused  \
+                              into this consumer); padding stays zero              */
+#define VS_CONV_APRO_RELU 64
+
+/* Geometry of one Conv3d (bias-free, groups 1, dilation 1).
+ * Replaces nn.Conv3d reached from vidsitu_code/mdl_sf_base.py:22-33 (s1..s5,
+ * s*_fuse of slowfast.models.video_model_builder). */
+typedef struct vs_conv_desc {
+  int32_t N, Ti, Hi, Wi, Cin;
+  int32_t To, Ho, Wo, Cout;
+  int32_t kT, kH, kW;
+  int32_t sT, sH, sW;
+  int32_t pT, pH, pW;
+  int32_t x_ld;   /* input row pitch  (elements, >= Cin)  */
+  int32_t y_ld;   /* output row pitch (elements, >= Cout) */
+  int32_t res_ld; /* residual row pitch                   */
+  int32_t flags;
+} vs_conv_desc;
+
+const char* vs_last_error_string(void);
+int vs_version(void);
+
+/* NCDHW (f32 or bf16) -> NDHWC bf16 with channels zero-padded to Cpad.
+ * Replaces the implicit layout of the A0 batch contract
+ * (vidsitu_code/dat_loader.py:454-501 -> mdl_sf_base.py:169-180). */
+int vs_pack_input(const void* x, int x_is_bf16, void* y, int N, int C, int T, int H, int W,
+                  int Cpad, void* stream);
+
+/* Forward conv as implicit GEMM on bf16 MFMA, fp32 accumulate.
+ *   stats_partial: [vs_conv_stats_rows(desc)][2][Cout] fp32 when VS_CONV_STATS.
+ *   in_scale/in_shift: [Cin] fp32 when VS_CONV_APRO. */
+int vs_conv_fwd(const void* x, const void* w, void* y, const vs_conv_desc* d, const float* scale,
+                const float* shift, const void* residual, float* stats_partial,
+                const float* in_scale, const float* in_shift, void* stream);
+int vs_conv_stats_rows(const vs_conv_desc* d);
+
+/* Data gradient: dx[N,Ti,Hi,Wi,Cin] = conv_transpose(dy, w).  wt is the
+ * [Cin][kT][kH][kW][Cout] bf16 image made by vs_weight_transpose.
+ * Replaces autograd's cudnn_convolution_backward_input for the same layers. */
+int vs_conv_dgrad(const void* dy, const void* wt, void* dx, const vs_conv_desc* d, void* stream);
+int vs_weight_transpose(const void* w, void* wt, int Cout, int taps, int Cin, void* stream);
+
+/* Weight gradient: dw[Cout][taps][Cin] fp32 = sum_p dy[p][co] * x[p@tap][ci].
+ * workspace: vs_conv_wgrad_workspace_bytes(desc) bytes of fp32 split-K slabs.
+ * in_scale/in_shift (+relu flag via desc.flags APRO) re-apply the producer's BN
+ * to x on load. */
+size_t vs_conv_wgrad_workspace_bytes(const vs_conv_desc* d);
+int vs_conv_wgrad(const void* dy, const void* x, float* dw, const vs_conv_desc* d,
+                  const float* in_scale, const float* in_shift, void* workspace, size_t ws_bytes,
+                  void* stream);
+
+/* BatchNorm3d (mdl_sf_base.py:22-33 via slowfast BN modules; eps 1e-5, mom 0.1).
+ * finalize: reduce conv-epilogue partials -> batch mean / biased var ->
+ *   scale = gamma*rsqrt(var+eps), shift = beta - mean*scale; updates running
+ *   stats with the unbiased variance (training) -- or, with nparts == 0, folds
+ *   the running stats (eval). */
+int vs_bn_finalize(const float* partials, int nparts, double count, const float* gamma,
+                   const float* beta, float* running_mean, float* running_var, float momentum,
+                   float eps, float* scale, float* shift, float* mean, float* invstd, int C,
+                   void* stream);
+/* out = relu?(y*scale[c] + shift[c] (+ residual)), bf16 rows of C channels. */
+int vs_bn_apply(const void* y, const float* scale, const float* shift, const void* residual,
+                void* out, int64_t rows, int C, int y_ld, int res_ld, int out_ld, int relu,
+                void* stream);
+/* Backward of z = relu?(bn(y) (+res)):  g = dz * [z>0];
+ *   pass 1 (reduce): partial[blk][2][C] = (sum g, sum g*xhat), xhat=(y-mean)*invstd
+ *   pass 2 (apply):  dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M); dres = g. */
+int vs_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* mean,
+                     const float* invstd, float* partial, int64_t rows, int C, int dz_ld, int z_ld,
+                     int y_ld, int relu, void* stream);
+int vs_bn_bwd_reduce_rows(int64_t rows, int C);
+int vs_bn_bwd_finalize(const float* partial, int nparts, float* dgamma, float* dbeta, int C,
+                       void* stream);
+int vs_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* mean,
+                    const float* invstd, const float* gamma, const float* dgamma,
+                    const float* dbeta, void* dy, void* dres, int64_t rows, int C, int dz_ld,
+                    int z_ld, int y_ld, int dy_ld, int dres_ld, int relu, void* stream);
+
+/* MaxPool3d([1,3,3], s[1,2,2], p[0,1,1]) of the stems (slowfast stem_helper via
+ * mdl_sf_base.py:22).  idx: uint8 argmax tap (first max in (kh,kw) scan order,
+ * as torch) per output element, used by the backward. */
+int vs_maxpool_hw3s2_fwd(const void* x, void* y, uint8_t* idx, int N, int T, int H, int W, int C,
+                         int x_ld, int y_ld, void* stream);
+int vs_maxpool_hw3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int T, int H, int W,
+                         int C, int dy_ld, int dx_ld, void* stream);
+/* MaxPool3d k=s=[kt,1,1] (pathway0_pool of c2d / i3d, mdl_sf_base.py:49-51). */
+int vs_maxpool_t_fwd(const void* x, void* y, uint8_t* idx, int N, int T, int HW, int C, int kt,
+                     void* stream);
+int vs_maxpool_t_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int T, int HW, int C,
+                     int kt, void* stream);
+
+/* AdaptiveAvgPool3d((1,1,1)) + channel concat (mdl_sf_base.py:97-113):
+ * out[n][c_off + c] = mean over `rows_per_clip` positions, fp32 out. */
+int vs_avgpool_fwd(const void* x, float* out, int N, int64_t rows_per_clip, int C, int x_ld,
+                   int out_ld, int c_off, void* stream);
+int vs_avgpool_bwd(const float* dout, void* dx, int N, int64_t rows_per_clip, int C, int dx_ld,
+                   int dout_ld, int c_off, void* stream);
+
+/* fp32 Linear for M <= 64*k rows: y[M,N] = act(x[M,K] @ W[N,K]^T + b).
+ * Replaces nn.Linear of proj_head / vid_feat_encoder (mdl_sf_base.py:161-167,
+ * 767-769) and of utils/transformer_code.py:51-79 (wq/wk/wv/wo, linear1/2). */
+int vs_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K,
+                  int relu, void* stream);
+/* dx[M,K] = dy[M,N] @ W[N,K], given wt = W^T [K,N] from vs_transpose_f32;
+ * dw[N,K] = dy^T x;  db[N] = sum_m dy. */
+int vs_transpose_f32(const float* w, float* wt, int R, int C, void* stream);
+int vs_linear_bwd_data(const float* dy, const float* wt, float* dx, int M, int N, int K,
+                       void* stream);
+int vs_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, int M, int N,
+                         int K, void* stream);
+
+/* softmax(Q_h K_h^T / scale) V_h for short sequences (L <= 16), per head.
+ * q,k,v,o: [B, L, H*dh] fp32.  utils/transformer_code.py:33-48,60-68 --
+ * scale is sqrt(d_model) there, passed explicitly. */
+int vs_attn_small_fwd(const float* q, const float* k, const float* v, float* o, float* probs,
+                      int B, int L, int H, int dh, float scale, void* stream);
+int vs_attn_small_bwd(const float* q, const float* k, const float* v, const float* probs,
+                      const float* dout, float* dq, float* dk, float* dv, int B, int L, int H,
+                      int dh, float scale, void* stream);
+
+/* y = LayerNorm(x + r) (utils/transformer_code.py:21-30), fp32, eps given. */
+int vs_add_layernorm_fwd(const float* x, const float* r, const float* gamma, const float* beta,
+                         float* y, float* mean, float* rstd, int rows, int D, float eps,
+                         void* stream);
+int vs_add_layernorm_bwd(const float* dy, const float* x, const float* r, const float* gamma,
+                         const float* mean, const float* rstd, float* dx, float* dgamma_partial,
+                         float* dbeta_partial, int rows, int D, void* stream);
+
+/* Fused cross-entropy (mean) fwd + dlogits (mdl_sf_base.py:226-231) and the
+ * softmax -> descending sort -> top-k verb indices of EvalB
+ * (vidsitu_code/evl_vsitu.py:39-42). */
+int vs_softmax_xent(const float* logits, const int64_t* labels, float* loss, float* dlogits,
+                    int rows, int V, void* stream);
+int vs_softmax_topk(const float* logits, float* probs_out, int64_t* idx_out, int rows, int V,
+                    int k, void* stream);
+
+/* Adam (main_dist.py:50: betas (0.9, 0.99), eps 1e-8, no weight decay) on a flat
+ * fp32 parameter / gradient arena; grad_scale folds the DDP 1/world_size. */
+int vs_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                 float beta2, float eps, int step, float grad_scale, void* stream);
+/* fp32 -> bf16 cast of the parameter arena (weights used by the conv kernels). */
+int vs_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIDSITU_HIP_H */

@@ -1,0 +1,123 @@
+"""ctypes binding of libvidsitu_hip.so (the C-ABI in include/vidsitu_hip.h).
+
+The product path has NO CPU fallback: if the shared object is missing or a
+symbol is absent this module raises at first use, loudly.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvidsitu_hip.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+VS_CONV_AFFINE = 1
+VS_CONV_RESIDUAL = 2
+VS_CONV_RELU = 4
+VS_CONV_STATS = 8
+VS_CONV_NAIVE = 16
+VS_CONV_APRO = 32
+VS_CONV_APRO_RELU = 64
+
+
+class ConvDesc(C.Structure):
+    """vs_conv_desc (include/vidsitu_hip.h)."""
+
+    _fields_ = [
+        (n, C.c_int32)
+        for n in (
+            "N Ti Hi Wi Cin To Ho Wo Cout kT kH kW sT sH sW pT pH pW x_ld y_ld res_ld flags"
+        ).split()
+    ]
+
+
+_p, _i, _i64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
+_dp = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); mirrors include/vidsitu_hip.h one to one
+SIGNATURES = {
+    "vs_last_error_string": (C.c_char_p, []),
+    "vs_version": (_i, []),
+    "vs_pack_input": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "vs_conv_fwd": (_i, [_p, _p, _p, _dp, _p, _p, _p, _p, _p, _p, _p]),
+    "vs_conv_stats_rows": (_i, [_dp]),
+    "vs_conv_dgrad": (_i, [_p, _p, _p, _dp, _p]),
+    "vs_weight_transpose": (_i, [_p, _p, _i, _i, _i, _p]),
+    "vs_conv_wgrad_workspace_bytes": (_sz, [_dp]),
+    "vs_conv_wgrad": (_i, [_p, _p, _p, _dp, _p, _p, _p, _sz, _p]),
+    "vs_bn_finalize": (_i, [_p, _i, _d, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i, _p]),
+    "vs_bn_apply": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p]),
+    "vs_bn_bwd_reduce": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p]),
+    "vs_bn_bwd_reduce_rows": (_i, [_i64, _i]),
+    "vs_bn_bwd_finalize": (_i, [_p, _i, _p, _p, _i, _p]),
+    "vs_bn_bwd_apply": (
+        _i,
+        [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _p],
+    ),
+    "vs_maxpool_hw3s2_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "vs_maxpool_hw3s2_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "vs_maxpool_t_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vs_maxpool_t_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vs_avgpool_fwd": (_i, [_p, _p, _i, _i64, _i, _i, _i, _i, _p]),
+    "vs_avgpool_bwd": (_i, [_p, _p, _i, _i64, _i, _i, _i, _i, _p]),
+    "vs_linear_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "vs_transpose_f32": (_i, [_p, _p, _i, _i, _p]),
+    "vs_linear_bwd_data": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "vs_linear_bwd_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "vs_attn_small_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "vs_attn_small_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "vs_add_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
+    "vs_add_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
+    "vs_softmax_xent": (_i, [_p, _p, _p, _p, _i, _i, _p]),
+    "vs_softmax_topk": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "vs_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _i, _f, _p]),
+    "vs_cast_f32_to_bf16": (_i, [_p, _p, _i64, _p]),
+}
+
+
+class VsError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def build_library(force=False):
+    """Compile csrc/*.hip for gfx950 into libvidsitu_hip.so (hipcc cross-compiles
+    without a GPU)."""
+    args = ["make", "-C", CSRC_DIR, "-j4"]
+    if force:
+        subprocess.check_call(["make", "-C", CSRC_DIR, "clean"])
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+def load():
+    """dlopen the library and bind every symbol the header declares."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VsError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the HIP path)"
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().vs_last_error_string()
+        raise VsError(f"{what} failed with vs_status {rc}: {msg.decode() if msg else ''}")
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    check(rc, name)

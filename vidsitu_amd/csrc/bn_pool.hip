@@ -1,0 +1,632 @@
+// BatchNorm3d (train + eval), stem max-pools, global average pool and the input
+// pack for the channels-last bf16 trunk.  All HBM-bound: 16-byte vectors of 8
+// consecutive channels per lane, fp32 math, wave-shuffle / LDS reductions.
+// Reference call sites: vidsitu_code/mdl_sf_base.py:22-33 (trunk modules),
+// :97-113 (AdaptiveAvgPool3d + cat), dat_loader.py:454-501 (input contract).
+#include "common.h"
+
+// ----------------------------------------------------------------------------
+// NCDHW (f32 | bf16) -> NDHWC bf16, channels zero-padded to Cpad (multiple of 8)
+// ----------------------------------------------------------------------------
+template <bool IN_BF16>
+__global__ void pack_input_kernel(const void* xin, uint16_t* y, int N, int C, long long THW,
+                                  int Cpad) {
+  const long long pos = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // n*THW + s
+  if (pos >= (long long)N * THW) return;
+  const long long n = pos / THW, s = pos - n * THW;
+  for (int c0 = 0; c0 < Cpad; c0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c0 + e;
+      float f = 0.f;
+      if (c < C) {
+        const long long off = (n * C + c) * THW + s;
+        f = IN_BF16 ? bf16_to_f32(((const uint16_t*)xin)[off]) : ((const float*)xin)[off];
+      }
+      v[e] = f;
+    }
+    *(uint4*)(y + pos * Cpad + c0) = pack8_bf16(v);
+  }
+}
+
+extern "C" int vs_pack_input(const void* x, int x_is_bf16, void* y, int N, int C, int T, int H,
+                             int W, int Cpad, void* stream) {
+  VS_CHECK_ARG(x && y, "null tensor");
+  VS_CHECK_ARG(Cpad % 8 == 0 && Cpad >= C, "Cpad must be a multiple of 8 and >= C");
+  const long long THW = (long long)T * H * W, total = THW * N;
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (x_is_bf16)
+    hipLaunchKernelGGL(pack_input_kernel<true>, grid, block, 0, (hipStream_t)stream, x,
+                       (uint16_t*)y, N, C, THW, Cpad);
+  else
+    hipLaunchKernelGGL(pack_input_kernel<false>, grid, block, 0, (hipStream_t)stream, x,
+                       (uint16_t*)y, N, C, THW, Cpad);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// ----------------------------------------------------------------------------
+// BN finalize: partial[nparts][2][C] -> mean / biased var -> scale, shift
+// block = 32 channels x 32 slices; fp64 cross-partial accumulation.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(
+    const float* partials, int nparts, double count, const float* gamma, const float* beta,
+    float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
+    float* mean_out, float* invstd_out, int C) {
+  __shared__ double sh_s[32][33];
+  __shared__ double sh_q[32][33];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s = 0.0, q = 0.0;
+  if (c < C) {
+    for (int p = sl; p < nparts; p += 32) {
+      s += (double)partials[(long long)p * 2 * C + c];
+      q += (double)partials[(long long)p * 2 * C + C + c];
+    }
+  }
+  sh_s[sl][cl] = s;
+  sh_q[sl][cl] = q;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    float sc, sf;
+    if (nparts > 0) {
+      double ts = 0.0, tq = 0.0;
+      for (int i = 0; i < 32; ++i) {
+        ts += sh_s[i][cl];
+        tq += sh_q[i][cl];
+      }
+      const double mean = ts / count;
+      double var = tq / count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+      sc = gamma[c] * invstd;
+      sf = beta[c] - (float)mean * sc;
+      if (mean_out) mean_out[c] = (float)mean;
+      if (invstd_out) invstd_out[c] = invstd;
+      if (running_mean) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+      }
+    } else {  // eval: fold the running statistics
+      const float invstd = 1.0f / sqrtf(running_var[c] + eps);
+      sc = gamma[c] * invstd;
+      sf = beta[c] - running_mean[c] * sc;
+      if (mean_out) mean_out[c] = running_mean[c];
+      if (invstd_out) invstd_out[c] = invstd;
+    }
+    scale[c] = sc;
+    shift[c] = sf;
+  }
+}
+
+extern "C" int vs_bn_finalize(const float* partials, int nparts, double count, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var,
+                              float momentum, float eps, float* scale, float* shift, float* mean,
+                              float* invstd, int C, void* stream) {
+  VS_CHECK_ARG(gamma && beta && scale && shift && C > 0, "bad args");
+  VS_CHECK_ARG(nparts == 0 || (partials && count > 0), "train mode needs partials and count");
+  VS_CHECK_ARG(nparts > 0 || (running_mean && running_var), "eval mode needs running stats");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream,
+                     partials, nparts, count, gamma, beta, running_mean, running_var, momentum, eps,
+                     scale, shift, mean, invstd, C);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// ----------------------------------------------------------------------------
+// out = relu?(y*scale + shift (+res)), rows x C bf16 with row pitches
+// ----------------------------------------------------------------------------
+__global__ void bn_apply_kernel(const uint16_t* y, const float* scale, const float* shift,
+                                const uint16_t* res, uint16_t* out, long long rows, int C, int y_ld,
+                                int res_ld, int out_ld, int relu) {
+  const int cpr = C >> 3;
+  const long long total = rows * cpr;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const long long row = idx / cpr;
+    const int c = (int)(idx - row * cpr) * 8;
+    float v[8], r[8];
+    unpack8_bf16(*(const uint4*)(y + row * y_ld + c), v);
+    const float4 s0 = *(const float4*)(scale + c), s1 = *(const float4*)(scale + c + 4);
+    const float4 h0 = *(const float4*)(shift + c), h1 = *(const float4*)(shift + c + 4);
+    v[0] = v[0] * s0.x + h0.x; v[1] = v[1] * s0.y + h0.y;
+    v[2] = v[2] * s0.z + h0.z; v[3] = v[3] * s0.w + h0.w;
+    v[4] = v[4] * s1.x + h1.x; v[5] = v[5] * s1.y + h1.y;
+    v[6] = v[6] * s1.z + h1.z; v[7] = v[7] * s1.w + h1.w;
+    if (res) {
+      unpack8_bf16(*(const uint4*)(res + row * res_ld + c), r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += r[e];
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    *(uint4*)(out + row * out_ld + c) = pack8_bf16(v);
+  }
+}
+
+static inline int ew_grid(long long total) {
+  long long g = (total + 255) / 256;
+  if (g > 256 * 8) g = 256 * 8;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" int vs_bn_apply(const void* y, const float* scale, const float* shift,
+                           const void* residual, void* out, int64_t rows, int C, int y_ld,
+                           int res_ld, int out_ld, int relu, void* stream) {
+  VS_CHECK_ARG(y && scale && shift && out, "null tensor");
+  VS_CHECK_ARG(C % 8 == 0 && y_ld % 8 == 0 && out_ld % 8 == 0 && (!residual || res_ld % 8 == 0),
+               "channels / pitches must be multiples of 8");
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(rows * (C / 8))), dim3(256), 0,
+                     (hipStream_t)stream, (const uint16_t*)y, scale, shift,
+                     (const uint16_t*)residual, (uint16_t*)out, (long long)rows, C, y_ld, res_ld,
+                     out_ld, relu);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// ----------------------------------------------------------------------------
+// BN backward.  g = dz * [z > 0] (relu) ; xhat = (y - mean) * invstd
+//   reduce : partial[blk][2][C] = (sum g, sum g*xhat) over the block's row slab
+//   apply  : dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M) ; dres = g
+// block = 256 threads = cpr chunk-columns x (256/cpr) row lanes, cpr = C/8 | 256
+// ----------------------------------------------------------------------------
+#define BNB_ROWS_PER_LANE 16
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const uint16_t* dz, const uint16_t* z, const uint16_t* y, const float* mean,
+    const float* invstd, float* partial, long long rows, int C, int dz_ld, int z_ld, int y_ld,
+    int relu) {
+  __shared__ float red[256 * 16];
+  const int cpr = C >> 3;
+  const int ncol = cpr < 256 ? cpr : 256;  // chunk columns handled per pass
+  const int rl = 256 / ncol;               // row lanes
+  const int col = threadIdx.x % ncol, lane_r = threadIdx.x / ncol;
+  const long long rows_per_blk = (long long)rl * BNB_ROWS_PER_LANE;
+  const long long r0 = (long long)blockIdx.x * rows_per_blk;
+  for (int cb = col; cb < cpr; cb += ncol) {
+    const int c = cb * 8;
+    float mu[8], is[8], sg[8], sx[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      mu[e] = mean[c + e];
+      is[e] = invstd[c + e];
+      sg[e] = 0.f;
+      sx[e] = 0.f;
+    }
+    for (int it = 0; it < BNB_ROWS_PER_LANE; ++it) {
+      const long long row = r0 + (long long)it * rl + lane_r;
+      if (row < rows) {
+        float g[8], yv[8];
+        unpack8_bf16(*(const uint4*)(dz + row * dz_ld + c), g);
+        unpack8_bf16(*(const uint4*)(y + row * y_ld + c), yv);
+        if (relu) {
+          float zv[8];
+          unpack8_bf16(*(const uint4*)(z + row * z_ld + c), zv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) g[e] = zv[e] > 0.f ? g[e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          sg[e] += g[e];
+          sx[e] += g[e] * (yv[e] - mu[e]) * is[e];
+        }
+      }
+    }
+    // reduce over the rl row lanes through LDS
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[threadIdx.x * 16 + e] = sg[e];
+      red[threadIdx.x * 16 + 8 + e] = sx[e];
+    }
+    __syncthreads();
+    if (lane_r == 0) {
+      for (int r = 1; r < rl; ++r) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          sg[e] += red[(r * ncol + col) * 16 + e];
+          sx[e] += red[(r * ncol + col) * 16 + 8 + e];
+        }
+      }
+      float* dst = partial + (long long)blockIdx.x * 2 * C;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        dst[c + e] = sg[e];
+        dst[C + c + e] = sx[e];
+      }
+    }
+  }
+}
+
+static int bnb_check(int C) {
+  const int cpr = C / 8;
+  if (C % 8 != 0 || (cpr & (cpr - 1)) != 0) return 0;
+  return 1;
+}
+
+extern "C" int vs_bn_bwd_reduce_rows(int64_t rows, int C) {
+  if (!bnb_check(C)) return -1;
+  const int cpr = C / 8;
+  const int ncol = cpr < 256 ? cpr : 256;
+  const long long rpb = (long long)(256 / ncol) * BNB_ROWS_PER_LANE;
+  return (int)((rows + rpb - 1) / rpb);
+}
+
+extern "C" int vs_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* mean,
+                                const float* invstd, float* partial, int64_t rows, int C, int dz_ld,
+                                int z_ld, int y_ld, int relu, void* stream) {
+  VS_CHECK_ARG(dz && y && mean && invstd && partial, "null tensor");
+  VS_CHECK_ARG(!relu || z, "relu needs z");
+  VS_CHECK_ARG(bnb_check(C), "C/8 must be a power of two");
+  const int nblk = vs_bn_bwd_reduce_rows(rows, C);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)dz, (const uint16_t*)z, (const uint16_t*)y, mean, invstd,
+                     partial, (long long)rows, C, dz_ld, z_ld, y_ld, relu);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* partial, int nparts,
+                                                              float* dgamma, float* dbeta, int C) {
+  __shared__ double sh_s[32][33];
+  __shared__ double sh_q[32][33];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s = 0.0, q = 0.0;
+  if (c < C) {
+    for (int p = sl; p < nparts; p += 32) {
+      s += (double)partial[(long long)p * 2 * C + c];
+      q += (double)partial[(long long)p * 2 * C + C + c];
+    }
+  }
+  sh_s[sl][cl] = s;
+  sh_q[sl][cl] = q;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    double ts = 0.0, tq = 0.0;
+    for (int i = 0; i < 32; ++i) {
+      ts += sh_s[i][cl];
+      tq += sh_q[i][cl];
+    }
+    dbeta[c] = (float)ts;
+    dgamma[c] = (float)tq;
+  }
+}
+
+extern "C" int vs_bn_bwd_finalize(const float* partial, int nparts, float* dgamma, float* dbeta,
+                                  int C, void* stream) {
+  VS_CHECK_ARG(partial && dgamma && dbeta && nparts > 0, "bad args");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0,
+                     (hipStream_t)stream, partial, nparts, dgamma, dbeta, C);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+__global__ void bn_bwd_apply_kernel(const uint16_t* dz, const uint16_t* z, const uint16_t* y,
+                                    const float* mean, const float* invstd, const float* gamma,
+                                    const float* dgamma, const float* dbeta, uint16_t* dy,
+                                    uint16_t* dres, long long rows, int C, int dz_ld, int z_ld,
+                                    int y_ld, int dy_ld, int dres_ld, int relu) {
+  const int cpr = C >> 3;
+  const long long total = rows * cpr;
+  const float invM = 1.0f / (float)rows;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const long long row = idx / cpr;
+    const int c = (int)(idx - row * cpr) * 8;
+    float g[8], yv[8], o[8];
+    unpack8_bf16(*(const uint4*)(dz + row * dz_ld + c), g);
+    unpack8_bf16(*(const uint4*)(y + row * y_ld + c), yv);
+    if (relu) {
+      float zv[8];
+      unpack8_bf16(*(const uint4*)(z + row * z_ld + c), zv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = zv[e] > 0.f ? g[e] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float is = invstd[c + e];
+      const float xh = (yv[e] - mean[c + e]) * is;
+      o[e] = gamma[c + e] * is * (g[e] - dbeta[c + e] * invM - xh * dgamma[c + e] * invM);
+    }
+    *(uint4*)(dy + row * dy_ld + c) = pack8_bf16(o);
+    if (dres) *(uint4*)(dres + row * dres_ld + c) = pack8_bf16(g);
+  }
+}
+
+extern "C" int vs_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* mean,
+                               const float* invstd, const float* gamma, const float* dgamma,
+                               const float* dbeta, void* dy, void* dres, int64_t rows, int C,
+                               int dz_ld, int z_ld, int y_ld, int dy_ld, int dres_ld, int relu,
+                               void* stream) {
+  VS_CHECK_ARG(dz && y && mean && invstd && gamma && dgamma && dbeta && dy, "null tensor");
+  VS_CHECK_ARG(!relu || z, "relu needs z");
+  VS_CHECK_ARG(C % 8 == 0, "C must be a multiple of 8");
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * (C / 8))), dim3(256), 0,
+                     (hipStream_t)stream, (const uint16_t*)dz, (const uint16_t*)z,
+                     (const uint16_t*)y, mean, invstd, gamma, dgamma, dbeta, (uint16_t*)dy,
+                     (uint16_t*)dres, (long long)rows, C, dz_ld, z_ld, y_ld, dy_ld, dres_ld, relu);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// ----------------------------------------------------------------------------
+// MaxPool3d([1,3,3], s[1,2,2], p[0,1,1]); idx = first max in (kh,kw) scan order
+// ----------------------------------------------------------------------------
+__global__ void maxpool_hw_fwd_kernel(const uint16_t* x, uint16_t* y, uint8_t* idx, int NT, int H,
+                                      int W, int Ho, int Wo, int C, int x_ld, int y_ld) {
+  const int cpr = C >> 3;
+  const long long total = (long long)NT * Ho * Wo * cpr;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpr) * 8;
+    long long pos = i / cpr;
+    const int wo = (int)(pos % Wo);
+    pos /= Wo;
+    const int ho = (int)(pos % Ho);
+    const long long nt = pos / Ho;
+    float best[8];
+    int bi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      best[e] = -INFINITY;
+      bi[e] = 0;
+    }
+    for (int dh = 0; dh < 3; ++dh) {
+      const int h = 2 * ho - 1 + dh;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int dw = 0; dw < 3; ++dw) {
+        const int w = 2 * wo - 1 + dw;
+        if ((unsigned)w >= (unsigned)W) continue;
+        float v[8];
+        unpack8_bf16(*(const uint4*)(x + ((nt * H + h) * W + w) * x_ld + c), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (v[e] > best[e] || (v[e] != v[e] && best[e] == best[e])) {  // NaN propagates as torch
+            best[e] = v[e];
+            bi[e] = dh * 3 + dw;
+          }
+      }
+    }
+    const long long opos = (nt * Ho + ho) * Wo + wo;
+    *(uint4*)(y + opos * y_ld + c) = pack8_bf16(best);
+    if (idx) {
+      uint2 pk;
+      pk.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+      pk.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+      *(uint2*)(idx + opos * C + c) = pk;
+    }
+  }
+}
+
+extern "C" int vs_maxpool_hw3s2_fwd(const void* x, void* y, uint8_t* idx, int N, int T, int H,
+                                    int W, int C, int x_ld, int y_ld, void* stream) {
+  VS_CHECK_ARG(x && y, "null tensor");
+  VS_CHECK_ARG(C % 8 == 0 && x_ld % 8 == 0 && y_ld % 8 == 0, "C / pitches multiple of 8");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long long total = (long long)N * T * Ho * Wo * (C / 8);
+  hipLaunchKernelGGL(maxpool_hw_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0,
+                     (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, idx, N * T, H, W, Ho,
+                     Wo, C, x_ld, y_ld);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// gather form: every input element sums dy of the (<= 4) windows whose argmax it is
+__global__ void maxpool_hw_bwd_kernel(const uint16_t* dy, const uint8_t* idx, uint16_t* dx, int NT,
+                                      int H, int W, int Ho, int Wo, int C, int dy_ld, int dx_ld) {
+  const int cpr = C >> 3;
+  const long long total = (long long)NT * H * W * cpr;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpr) * 8;
+    long long pos = i / cpr;
+    const int w = (int)(pos % W);
+    pos /= W;
+    const int h = (int)(pos % H);
+    const long long nt = pos / H;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    // windows ho with 2ho-1 <= h <= 2ho+1
+    const int ho_lo = h >> 1, ho_hi = (h + 1) >> 1;
+    const int wo_lo = w >> 1, wo_hi = (w + 1) >> 1;
+    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+      if (ho >= Ho) continue;
+      const int dh = h - (2 * ho - 1);
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        if (wo >= Wo) continue;
+        const int dw = w - (2 * wo - 1);
+        const int tap = dh * 3 + dw;
+        const long long opos = (nt * Ho + ho) * Wo + wo;
+        const uint2 pk = *(const uint2*)(idx + opos * C + c);
+        float g[8];
+        unpack8_bf16(*(const uint4*)(dy + opos * dy_ld + c), g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const unsigned b = ((e < 4 ? pk.x : pk.y) >> ((e & 3) * 8)) & 0xff;
+          if ((int)b == tap) acc[e] += g[e];
+        }
+      }
+    }
+    *(uint4*)(dx + ((nt * H + h) * W + w) * dx_ld + c) = pack8_bf16(acc);
+  }
+}
+
+extern "C" int vs_maxpool_hw3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int T,
+                                    int H, int W, int C, int dy_ld, int dx_ld, void* stream) {
+  VS_CHECK_ARG(dy && idx && dx, "null tensor");
+  VS_CHECK_ARG(C % 8 == 0 && dy_ld % 8 == 0 && dx_ld % 8 == 0, "C / pitches multiple of 8");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long long total = (long long)N * T * H * W * (C / 8);
+  hipLaunchKernelGGL(maxpool_hw_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0,
+                     (hipStream_t)stream, (const uint16_t*)dy, idx, (uint16_t*)dx, N * T, H, W, Ho,
+                     Wo, C, dy_ld, dx_ld);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// MaxPool3d k = s = [kt,1,1]  (dense tensors, T % kt == 0)
+__global__ void maxpool_t_fwd_kernel(const uint16_t* x, uint16_t* y, uint8_t* idx, int N, int T,
+                                     long long HW, int C, int kt) {
+  const int cpr = C >> 3, To = T / kt;
+  const long long total = (long long)N * To * HW * cpr;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpr) * 8;
+    long long pos = i / cpr;
+    const long long s = pos % HW;
+    pos /= HW;
+    const int to = (int)(pos % To);
+    const long long n = pos / To;
+    float best[8];
+    int bi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      best[e] = -INFINITY;
+      bi[e] = 0;
+    }
+    for (int d = 0; d < kt; ++d) {
+      float v[8];
+      unpack8_bf16(*(const uint4*)(x + (((n * T + to * kt + d) * HW) + s) * C + c), v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (v[e] > best[e] || (v[e] != v[e] && best[e] == best[e])) {
+          best[e] = v[e];
+          bi[e] = d;
+        }
+    }
+    const long long opos = (n * To + to) * HW + s;
+    *(uint4*)(y + opos * C + c) = pack8_bf16(best);
+    if (idx) {
+      uint2 pk;
+      pk.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+      pk.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+      *(uint2*)(idx + opos * C + c) = pk;
+    }
+  }
+}
+
+extern "C" int vs_maxpool_t_fwd(const void* x, void* y, uint8_t* idx, int N, int T, int HW, int C,
+                                int kt, void* stream) {
+  VS_CHECK_ARG(x && y && C % 8 == 0 && kt > 0 && T % kt == 0, "bad args");
+  const long long total = (long long)N * (T / kt) * HW * (C / 8);
+  hipLaunchKernelGGL(maxpool_t_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)x, (uint16_t*)y, idx, N, T, (long long)HW, C, kt);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+__global__ void maxpool_t_bwd_kernel(const uint16_t* dy, const uint8_t* idx, uint16_t* dx, int N,
+                                     int T, long long HW, int C, int kt) {
+  const int cpr = C >> 3, To = T / kt;
+  const long long total = (long long)N * T * HW * cpr;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpr) * 8;
+    long long pos = i / cpr;
+    const long long s = pos % HW;
+    pos /= HW;
+    const int t = (int)(pos % T);
+    const long long n = pos / T;
+    const int to = t / kt, d = t - to * kt;
+    const long long opos = (n * To + to) * HW + s;
+    const uint2 pk = *(const uint2*)(idx + opos * C + c);
+    float g[8], o[8];
+    unpack8_bf16(*(const uint4*)(dy + opos * C + c), g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned b = ((e < 4 ? pk.x : pk.y) >> ((e & 3) * 8)) & 0xff;
+      o[e] = ((int)b == d) ? g[e] : 0.f;
+    }
+    *(uint4*)(dx + ((n * T + t) * HW + s) * C + c) = pack8_bf16(o);
+  }
+}
+
+extern "C" int vs_maxpool_t_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int T, int HW,
+                                int C, int kt, void* stream) {
+  VS_CHECK_ARG(dy && idx && dx && C % 8 == 0 && kt > 0 && T % kt == 0, "bad args");
+  const long long total = (long long)N * T * HW * (C / 8);
+  hipLaunchKernelGGL(maxpool_t_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)dy, idx, (uint16_t*)dx, N, T, (long long)HW, C, kt);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// ----------------------------------------------------------------------------
+// AdaptiveAvgPool3d(1) + concat: out[n][c_off+c] = mean_rows x[n,row,c]  (fp32 out)
+// block = 32 chunk-columns x 8 row lanes ; grid = (ceil(cpr/32), N)
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const uint16_t* x, float* out,
+                                                          long long rows, int C, int x_ld,
+                                                          int out_ld, int c_off) {
+  __shared__ float red[8][32][8];
+  const int cpr = C >> 3;
+  const int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int cb = blockIdx.x * 32 + col;
+  const long long n = blockIdx.y;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  if (cb < cpr) {
+    for (long long r = rl; r < rows; r += 8) {
+      float v[8];
+      unpack8_bf16(*(const uint4*)(x + (n * rows + r) * x_ld + cb * 8), v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][col][e] = acc[e];
+  __syncthreads();
+  if (rl == 0 && cb < cpr) {
+    const float inv = 1.0f / (float)rows;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float s = 0.f;
+      for (int r = 0; r < 8; ++r) s += red[r][col][e];
+      out[n * out_ld + c_off + cb * 8 + e] = s * inv;
+    }
+  }
+}
+
+extern "C" int vs_avgpool_fwd(const void* x, float* out, int N, int64_t rows_per_clip, int C,
+                              int x_ld, int out_ld, int c_off, void* stream) {
+  VS_CHECK_ARG(x && out && C % 8 == 0 && x_ld % 8 == 0, "bad args");
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3((C / 8 + 31) / 32, N), dim3(256), 0,
+                     (hipStream_t)stream, (const uint16_t*)x, out, (long long)rows_per_clip, C,
+                     x_ld, out_ld, c_off);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+__global__ void avgpool_bwd_kernel(const float* dout, uint16_t* dx, long long rows, int C,
+                                   int dx_ld, int dout_ld, int c_off, long long total) {
+  const int cpr = C >> 3;
+  const float inv = 1.0f / (float)rows;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpr) * 8;
+    const long long pos = i / cpr;
+    const long long n = pos / rows;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = dout[n * dout_ld + c_off + c + e] * inv;
+    *(uint4*)(dx + pos * dx_ld + c) = pack8_bf16(v);
+  }
+}
+
+extern "C" int vs_avgpool_bwd(const float* dout, void* dx, int N, int64_t rows_per_clip, int C,
+                              int dx_ld, int dout_ld, int c_off, void* stream) {
+  VS_CHECK_ARG(dout && dx && C % 8 == 0 && dx_ld % 8 == 0, "bad args");
+  const long long total = (long long)N * rows_per_clip * (C / 8);
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                     dout, (uint16_t*)dx, (long long)rows_per_clip, C, dx_ld, dout_ld, c_off, total);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}

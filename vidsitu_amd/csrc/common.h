@@ -1,0 +1,74 @@
+// Shared device/host helpers for libvidsitu_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "vidsitu_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+void vs_set_error(const char* fmt, ...);
+
+#define VS_CHECK_ARG(cond, msg)                   \
+  do {                                            \
+    if (!(cond)) {                                \
+      vs_set_error("%s: %s", __func__, msg);      \
+      return VS_ERR_BAD_ARG;                      \
+    }                                             \
+  } while (0)
+
+#define VS_CHECK_LAUNCH()                                                   \
+  do {                                                                      \
+    hipError_t e__ = hipGetLastError();                                     \
+    if (e__ != hipSuccess) {                                                \
+      vs_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__)); \
+      return VS_ERR_LAUNCH;                                                 \
+    }                                                                       \
+  } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) {
+  return __uint_as_float(((uint32_t)h) << 16);
+}
+// round-to-nearest-even; a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and
+// keeps NaN a NaN (MI355X_MICROARCH.md, correctness boundaries).
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ void unpack8_bf16(const uint4& v, float* f) {
+  f[0] = __uint_as_float(v.x << 16);
+  f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16);
+  f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16);
+  f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16);
+  f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8_bf16(const float* f) {
+  uint4 v;
+  v.x = pack2_bf16(f[0], f[1]);
+  v.y = pack2_bf16(f[2], f[3]);
+  v.z = pack2_bf16(f[4], f[5]);
+  v.w = pack2_bf16(f[6], f[7]);
+  return v;
+}
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,545 @@
+// Implicit-GEMM Conv3d forward / data-gradient on bf16 MFMA (gfx950).
+//
+// Replaces nn.Conv3d (cuDNN fwd / bwd-data) of the SlowFast trunk reached from
+// vidsitu_code/mdl_sf_base.py:22-33.  GEMM view (channels-last activations):
+//   rows    m = (n, to, ho, wo)           output positions      (fwd)
+//   cols    n = cout
+//   K       k = (dt, dh, dw, cin)         gathered on the fly from x
+//   A[m][k] = x[n, to*s-p+dt, ..][cin]    16-byte units = 8 consecutive channels
+//   B[n][k] = w[cout][dt][dh][dw][cin]    K-contiguous ("B^T" layout)
+// dgrad is the same kernel with the gather transposed (rows = input positions,
+// gathered tensor = dy, stride becomes a divisibility test).
+//
+// Tile: BM x BN x 64, 256 threads (4 waves, WM x WN), v_mfma_f32_16x16x32_bf16,
+// register-staged global->LDS double buffering (loads of tile k+1 are issued
+// before the MFMAs of tile k and written to LDS after them), XOR-swizzled
+// 128-byte LDS rows (conflict-free ds_read_b128 fragment reads), fp32 epilogue
+// staged through LDS so stores are whole 16-byte channel vectors.
+#include "common.h"
+
+struct ConvP {
+  const uint16_t* x;
+  const uint16_t* w;
+  uint16_t* y;
+  const float* scale;
+  const float* shift;
+  const uint16_t* res;
+  float* stats;
+  int M, Ncols, K, Cg, g_ld;
+  int Rt, Rh, Rw;  // row space per clip
+  int Gt, Gh, Gw;  // gathered tensor dims per clip
+  int kT, kH, kW;
+  int mulT, mulH, mulW;
+  int offT, offH, offW;
+  int tmul;
+  int shT, shH, shW;  // log2(stride) for the transposed gather
+  int y_ld, res_ld, flags;
+  int tilesM, tilesN;
+};
+
+template <int BM, int BN>
+struct ConvSmem {
+  static constexpr int STAGE = (BM + BN) * 128;
+  static constexpr int EPI = BM * BN * 4;
+  static constexpr int MAIN = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
+};
+
+template <int BM, int BN, int WM, int WN, int MODE>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int AI = BM / 32;
+  constexpr int BJ = (BN + 31) / 32;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MR = TM / 16, NR = TN / 16;
+  constexpr int STAGE = ConvSmem<BM, BN>::STAGE;
+  constexpr int MAIN = ConvSmem<BM, BN>::MAIN;
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile");
+
+  const int tid = threadIdx.x;
+  // XCD-aware remap: blocks b, b+8, ... share an XCD (speed only); give each
+  // XCD a contiguous run of tiles so neighbouring N-tiles re-read A from its L2.
+  int swz;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tn = swz % p.tilesN, tm = swz / p.tilesN;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kc = tid & 7, lrow = tid >> 3;
+  const int K8 = p.K >> 3;
+
+  float* statbuf = (float*)(smem + MAIN);               // [2][WM][BN]
+  int2* ktab = (int2*)(smem + MAIN + 2 * WM * BN * 4);  // [K8]
+
+  if (MODE != 0) {
+    const int C8 = p.Cg >> 3;
+    for (int k8 = tid; k8 < K8; k8 += 256) {
+      const int tap = k8 / C8, c8 = k8 - tap * C8;
+      const int dw = tap % p.kW, t2 = tap / p.kW;
+      const int dh = t2 % p.kH, dt = t2 / p.kH;
+      ktab[k8] = make_int2(dt | (dh << 8) | (dw << 16), c8 * 8);
+    }
+  }
+
+  // ---- per-thread row state (this thread always loads 16-byte unit kc of rows lrow+32i)
+  int rT[AI], rH[AI], rW[AI];
+  long long rbase[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int m = m0 + lrow + 32 * i;
+    if (m < p.M) {
+      int rw = m % p.Rw, t1 = m / p.Rw;
+      int rh = t1 % p.Rh, t2 = t1 / p.Rh;
+      int rt = t2 % p.Rt, n = t2 / p.Rt;
+      if (MODE == 0) {
+        const long long pos =
+            ((long long)(n * p.Gt + rt * p.mulT) * p.Gh + rh * p.mulH) * p.Gw + rw * p.mulW;
+        rbase[i] = pos * p.g_ld;
+        rT[i] = rH[i] = rW[i] = 0;
+      } else {
+        rbase[i] = (long long)n * p.Gt * p.Gh * p.Gw;
+        rT[i] = rt * p.mulT + p.offT;
+        rH[i] = rh * p.mulH + p.offH;
+        rW[i] = rw * p.mulW + p.offW;
+      }
+    } else {
+      rbase[i] = -1;
+      rT[i] = rH[i] = rW[i] = -(1 << 20);
+    }
+  }
+
+  u32x4 ra[AI], rb[BJ];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  auto gload = [&](int kt) __attribute__((always_inline)) {
+    const int k8 = kt * 8 + kc;
+    const bool kval = k8 < K8;
+    if (MODE == 0) {
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        ra[i] = zero4;
+        if (kval && rbase[i] >= 0) ra[i] = *(const u32x4*)(p.x + rbase[i] + k8 * 8);
+      }
+    } else {
+      int2 e = make_int2(0, 0);
+      if (kval) e = ktab[k8];
+      const int dt = (e.x & 0xff) * p.tmul, dh = ((e.x >> 8) & 0xff) * p.tmul,
+                dw = ((e.x >> 16) & 0xff) * p.tmul;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        int ti = rT[i] + dt, hi = rH[i] + dh, wi = rW[i] + dw;
+        bool ok = kval;
+        if (MODE == 2) {
+          ok = ok && (((ti & ((1 << p.shT) - 1)) | (hi & ((1 << p.shH) - 1)) |
+                       (wi & ((1 << p.shW) - 1))) == 0);
+          ti >>= p.shT;
+          hi >>= p.shH;
+          wi >>= p.shW;
+        }
+        ok = ok && ((unsigned)ti < (unsigned)p.Gt) && ((unsigned)hi < (unsigned)p.Gh) &&
+             ((unsigned)wi < (unsigned)p.Gw);
+        ra[i] = zero4;
+        if (ok) {
+          const long long pos = rbase[i] + (long long)((ti * p.Gh + hi) * p.Gw + wi);
+          ra[i] = *(const u32x4*)(p.x + pos * p.g_ld + e.y);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      const int row = lrow + 32 * j;
+      const int n = n0 + row;
+      rb[j] = zero4;
+      if (kval && row < BN && n < p.Ncols) rb[j] = *(const u32x4*)(p.w + (long long)n * p.K + k8 * 8);
+    }
+  };
+
+  auto sstore = [&](int buf) __attribute__((always_inline)) {
+    char* A = smem + buf * STAGE;
+    char* B = A + BM * 128;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int row = lrow + 32 * i;
+      *(u32x4*)(A + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4)) = ra[i];
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      const int row = lrow + 32 * j;
+      if (row < BN) *(u32x4*)(B + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4)) = rb[j];
+    }
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane & 15, lq = lane >> 4;
+
+  f32x4 acc[MR][NR];
+#pragma unroll
+  for (int a = 0; a < MR; ++a)
+#pragma unroll
+    for (int b = 0; b < NR; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int buf, int kt) __attribute__((always_inline)) {
+    const char* A = smem + buf * STAGE;
+    const char* B = A + BM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (ks == 1 && kt * 64 + 32 >= p.K) break;  // K tail: nothing but zeros left
+      bf16x8 af[MR], bfr[NR];
+      const int ch = ks * 4 + lq;
+#pragma unroll
+      for (int a = 0; a < MR; ++a) {
+        const int row = wm * TM + a * 16 + lr;
+        af[a] = *(const bf16x8*)(A + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int b = 0; b < NR; ++b) {
+        const int row = wn * TN + b * 16 + lr;
+        bfr[b] = *(const bf16x8*)(B + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int a = 0; a < MR; ++a)
+#pragma unroll
+        for (int b = 0; b < NR; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+    }
+  };
+
+  const int nk = (p.K + 63) >> 6;
+  __syncthreads();  // ktab visible
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    compute(cur, kt);
+    if (kt + 1 < nk) sstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---------------- epilogue ----------------
+  // (1) BN batch-statistic partials from the fp32 accumulators (tail rows are
+  //     zero-filled, so they add nothing).
+  if (p.flags & VS_CONV_STATS) {
+#pragma unroll
+    for (int b = 0; b < NR; ++b) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int a = 0; a < MR; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[a][b][r];
+          s += v;
+          q += v * v;
+        }
+      s += __shfl_xor(s, 16, 64);
+      q += __shfl_xor(q, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 32, 64);
+      if (lq == 0) {
+        const int col = wn * TN + b * 16 + lr;
+        statbuf[wm * BN + col] = s;
+        statbuf[WM * BN + wm * BN + col] = q;
+      }
+    }
+  }
+  // (2) accumulators -> fp32 LDS tile (with the per-channel affine)
+  float* E = (float*)smem;
+#pragma unroll
+  for (int b = 0; b < NR; ++b) {
+    const int col = wn * TN + b * 16 + lr;
+    float sc = 1.f, sh = 0.f;
+    if ((p.flags & VS_CONV_AFFINE) && (n0 + col < p.Ncols)) {
+      sc = p.scale[n0 + col];
+      sh = p.shift[n0 + col];
+    }
+#pragma unroll
+    for (int a = 0; a < MR; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wm * TM + a * 16 + lq * 4 + r;
+        E[row * BN + col] = acc[a][b][r] * sc + sh;
+      }
+  }
+  __syncthreads();
+  if ((p.flags & VS_CONV_STATS) && tid < BN && n0 + tid < p.Ncols) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) {
+      s += statbuf[w * BN + tid];
+      q += statbuf[WM * BN + w * BN + tid];
+    }
+    float* dst = p.stats + (long long)tm * 2 * p.Ncols;
+    dst[n0 + tid] = s;
+    dst[p.Ncols + n0 + tid] = q;
+  }
+  // (3) whole 16-byte channel vectors: residual add, ReLU, bf16, store
+  constexpr int CPR = BN / 8;
+  for (int idx = tid; idx < BM * CPR; idx += 256) {
+    const int row = idx / CPR, c8 = idx - row * CPR;
+    const int m = m0 + row, n = n0 + c8 * 8;
+    if (m < p.M && n < p.Ncols) {
+      float v[8];
+      const float4 v0 = *(const float4*)(E + row * BN + c8 * 8);
+      const float4 v1 = *(const float4*)(E + row * BN + c8 * 8 + 4);
+      v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
+      v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+      if (p.flags & VS_CONV_RESIDUAL) {
+        const uint4 rv = *(const uint4*)(p.res + (long long)m * p.res_ld + n);
+        float rf[8];
+        unpack8_bf16(rv, rf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rf[e];
+      }
+      if (p.flags & VS_CONV_RELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      *(uint4*)(p.y + (long long)m * p.y_ld + n) = pack8_bf16(v);
+    }
+  }
+}
+
+// ---- debug / cross-check kernel: one thread per output element, same gather ---
+__global__ void conv_naive_kernel(ConvP p, int transposed) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)p.M * p.Ncols) return;
+  const int n = (int)(idx % p.Ncols);
+  const int m = (int)(idx / p.Ncols);
+  int rw = m % p.Rw, t1 = m / p.Rw;
+  int rh = t1 % p.Rh, t2 = t1 / p.Rh;
+  int rt = t2 % p.Rt, cn = t2 / p.Rt;
+  float acc = 0.f;
+  for (int dt = 0; dt < p.kT; ++dt)
+    for (int dh = 0; dh < p.kH; ++dh)
+      for (int dw = 0; dw < p.kW; ++dw) {
+        int ti = rt * p.mulT + p.offT + p.tmul * dt;
+        int hi = rh * p.mulH + p.offH + p.tmul * dh;
+        int wi = rw * p.mulW + p.offW + p.tmul * dw;
+        if (transposed) {
+          if ((ti & ((1 << p.shT) - 1)) | (hi & ((1 << p.shH) - 1)) | (wi & ((1 << p.shW) - 1)))
+            continue;
+          ti >>= p.shT;
+          hi >>= p.shH;
+          wi >>= p.shW;
+        }
+        if ((unsigned)ti >= (unsigned)p.Gt || (unsigned)hi >= (unsigned)p.Gh ||
+            (unsigned)wi >= (unsigned)p.Gw)
+          continue;
+        const long long pos = ((long long)(cn * p.Gt + ti) * p.Gh + hi) * p.Gw + wi;
+        const uint16_t* xp = p.x + pos * p.g_ld;
+        const int tap = (dt * p.kH + dh) * p.kW + dw;
+        const uint16_t* wp = p.w + (long long)n * p.K + tap * p.Cg;
+        for (int c = 0; c < p.Cg; ++c) acc += bf16_to_f32(xp[c]) * bf16_to_f32(wp[c]);
+      }
+  float v = acc;
+  if (p.flags & VS_CONV_AFFINE) v = v * p.scale[n] + p.shift[n];
+  if (p.flags & VS_CONV_RESIDUAL) v += bf16_to_f32(p.res[(long long)m * p.res_ld + n]);
+  if (p.flags & VS_CONV_RELU) v = fmaxf(v, 0.f);
+  p.y[(long long)m * p.y_ld + n] = f32_to_bf16(v);
+}
+
+// ------------------------------ host side ------------------------------------
+struct TileCfg {
+  int bm, bn;
+};
+
+static TileCfg pick_tile(long long M, int Ncols) {
+  TileCfg c;
+  if (Ncols >= 128) {
+    c.bn = 128;
+    const long long t = ((M + 127) / 128) * ((Ncols + 127) / 128);
+    c.bm = (t >= 512) ? 128 : 64;
+  } else if (Ncols >= 64) {
+    c.bn = 64;
+    const long long t = (M + 127) / 128;
+    c.bm = (t >= 512) ? 128 : 64;
+  } else if (Ncols >= 32) {
+    c.bn = 32;
+    c.bm = 256;
+  } else {
+    c.bn = 16;
+    c.bm = 256;
+  }
+  return c;
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(const ConvP& p, int mode, hipStream_t st) {
+  const size_t smem =
+      (size_t)ConvSmem<BM, BN>::MAIN + 2 * WM * BN * 4 + (mode ? (size_t)(p.K >> 3) * 8 : 0);
+  const int grid = p.tilesM * p.tilesN;
+  // dynamic LDS above 64 KiB needs an explicit opt-in, once per kernel
+  static bool attr_done = false;
+  if (!attr_done) {
+    const int max_smem = 160 * 1024;
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, 0>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max_smem);
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, 1>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max_smem);
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, 2>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max_smem);
+    attr_done = true;
+  }
+  if (mode == 0)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 0>), dim3(grid), dim3(256), smem, st, p);
+  else if (mode == 1)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1>), dim3(grid), dim3(256), smem, st, p);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 2>), dim3(grid), dim3(256), smem, st, p);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+static int launch_conv(ConvP& p, int mode, int naive, hipStream_t st) {
+  if (naive) {
+    const long long total = (long long)p.M * p.Ncols;
+    hipLaunchKernelGGL(conv_naive_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       p, mode == 2 ? 1 : 0);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+  }
+  const TileCfg c = pick_tile(p.M, p.Ncols);
+  p.tilesM = (p.M + c.bm - 1) / c.bm;
+  p.tilesN = (p.Ncols + c.bn - 1) / c.bn;
+  if (c.bm == 128 && c.bn == 128) return launch_cfg<128, 128, 2, 2>(p, mode, st);
+  if (c.bm == 64 && c.bn == 128) return launch_cfg<64, 128, 1, 4>(p, mode, st);
+  if (c.bm == 128 && c.bn == 64) return launch_cfg<128, 64, 2, 2>(p, mode, st);
+  if (c.bm == 64 && c.bn == 64) return launch_cfg<64, 64, 2, 2>(p, mode, st);
+  if (c.bm == 256 && c.bn == 32) return launch_cfg<256, 32, 4, 1>(p, mode, st);
+  return launch_cfg<256, 16, 4, 1>(p, mode, st);
+}
+
+static int ilog2_exact(int v) {
+  int s = 0;
+  while ((1 << s) < v) ++s;
+  return ((1 << s) == v) ? s : -1;
+}
+
+static int check_desc(const vs_conv_desc* d) {
+  VS_CHECK_ARG(d != nullptr, "null desc");
+  VS_CHECK_ARG(d->Cin % 8 == 0 && d->Cout % 8 == 0, "Cin and Cout must be multiples of 8");
+  VS_CHECK_ARG(d->x_ld % 8 == 0 && d->y_ld % 8 == 0, "row pitches must be multiples of 8");
+  VS_CHECK_ARG(d->x_ld >= d->Cin && d->y_ld >= d->Cout, "row pitch smaller than channels");
+  VS_CHECK_ARG(d->kT <= 7 && d->kH <= 7 && d->kW <= 7, "kernel extent > 7");
+  VS_CHECK_ARG(d->To == (d->Ti + 2 * d->pT - d->kT) / d->sT + 1, "To inconsistent");
+  VS_CHECK_ARG(d->Ho == (d->Hi + 2 * d->pH - d->kH) / d->sH + 1, "Ho inconsistent");
+  VS_CHECK_ARG(d->Wo == (d->Wi + 2 * d->pW - d->kW) / d->sW + 1, "Wo inconsistent");
+  VS_CHECK_ARG((long long)d->N * d->Ti * d->Hi * d->Wi < (1ll << 31), "too many positions");
+  VS_CHECK_ARG((long long)d->kT * d->kH * d->kW * (d->Cin > d->Cout ? d->Cin : d->Cout) <= 8 * 2048,
+               "K too large for the LDS tap table");
+  return VS_OK;
+}
+
+extern "C" int vs_conv_stats_rows(const vs_conv_desc* d) {
+  const long long M = (long long)d->N * d->To * d->Ho * d->Wo;
+  const TileCfg c = pick_tile(M, d->Cout);
+  return (int)((M + c.bm - 1) / c.bm);
+}
+
+extern "C" int vs_conv_fwd(const void* x, const void* w, void* y, const vs_conv_desc* d,
+                           const float* scale, const float* shift, const void* residual,
+                           float* stats_partial, const float* in_scale, const float* in_shift,
+                           void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  VS_CHECK_ARG(x && w && y, "null tensor");
+  VS_CHECK_ARG(!(d->flags & VS_CONV_AFFINE) || (scale && shift), "AFFINE needs scale/shift");
+  VS_CHECK_ARG(!(d->flags & VS_CONV_RESIDUAL) || residual, "RESIDUAL needs residual");
+  VS_CHECK_ARG(!(d->flags & VS_CONV_STATS) || stats_partial, "STATS needs stats_partial");
+  if (d->flags & VS_CONV_APRO) {
+    (void)in_scale;
+    (void)in_shift;
+    vs_set_error("vs_conv_fwd: VS_CONV_APRO not implemented yet");
+    return VS_ERR_UNSUPPORTED;
+  }
+  ConvP p;
+  p.x = (const uint16_t*)x;
+  p.w = (const uint16_t*)w;
+  p.y = (uint16_t*)y;
+  p.scale = scale;
+  p.shift = shift;
+  p.res = (const uint16_t*)residual;
+  p.stats = stats_partial;
+  p.M = d->N * d->To * d->Ho * d->Wo;
+  p.Ncols = d->Cout;
+  p.K = d->kT * d->kH * d->kW * d->Cin;
+  p.Cg = d->Cin;
+  p.g_ld = d->x_ld;
+  p.Rt = d->To; p.Rh = d->Ho; p.Rw = d->Wo;
+  p.Gt = d->Ti; p.Gh = d->Hi; p.Gw = d->Wi;
+  p.kT = d->kT; p.kH = d->kH; p.kW = d->kW;
+  p.mulT = d->sT; p.mulH = d->sH; p.mulW = d->sW;
+  p.offT = -d->pT; p.offH = -d->pH; p.offW = -d->pW;
+  p.tmul = 1;
+  p.shT = p.shH = p.shW = 0;
+  p.y_ld = d->y_ld;
+  p.res_ld = d->res_ld;
+  p.flags = d->flags;
+  p.tilesM = p.tilesN = 0;
+  const bool pointwise = (d->kT * d->kH * d->kW == 1) && d->pT == 0 && d->pH == 0 && d->pW == 0;
+  return launch_conv(p, pointwise ? 0 : 1, (d->flags & VS_CONV_NAIVE) != 0, (hipStream_t)stream);
+}
+
+extern "C" int vs_conv_dgrad(const void* dy, const void* wt, void* dx, const vs_conv_desc* d,
+                             void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  VS_CHECK_ARG(dy && wt && dx, "null tensor");
+  const int shT = ilog2_exact(d->sT), shH = ilog2_exact(d->sH), shW = ilog2_exact(d->sW);
+  VS_CHECK_ARG(shT >= 0 && shH >= 0 && shW >= 0, "strides must be powers of two");
+  ConvP p;
+  p.x = (const uint16_t*)dy;
+  p.w = (const uint16_t*)wt;
+  p.y = (uint16_t*)dx;
+  p.scale = p.shift = nullptr;
+  p.res = nullptr;
+  p.stats = nullptr;
+  p.M = d->N * d->Ti * d->Hi * d->Wi;
+  p.Ncols = d->Cin;
+  p.K = d->kT * d->kH * d->kW * d->Cout;
+  p.Cg = d->Cout;
+  p.g_ld = d->y_ld;
+  p.Rt = d->Ti; p.Rh = d->Hi; p.Rw = d->Wi;
+  p.Gt = d->To; p.Gh = d->Ho; p.Gw = d->Wo;
+  p.kT = d->kT; p.kH = d->kH; p.kW = d->kW;
+  p.mulT = p.mulH = p.mulW = 1;
+  p.offT = d->pT; p.offH = d->pH; p.offW = d->pW;
+  p.tmul = -1;
+  p.shT = shT; p.shH = shH; p.shW = shW;
+  p.y_ld = d->x_ld;
+  p.res_ld = 0;
+  p.flags = d->flags & VS_CONV_NAIVE;
+  p.tilesM = p.tilesN = 0;
+  const bool unit_stride = d->sT == 1 && d->sH == 1 && d->sW == 1;
+  const bool pointwise =
+      unit_stride && (d->kT * d->kH * d->kW == 1) && d->pT == 0 && d->pH == 0 && d->pW == 0;
+  const int mode = pointwise ? 0 : (unit_stride ? 1 : 2);
+  return launch_conv(p, mode, (d->flags & VS_CONV_NAIVE) != 0, (hipStream_t)stream);
+}
+
+// w [Cout][taps][Cin] -> wt [Cin][taps][Cout]
+__global__ void weight_transpose_kernel(const uint16_t* w, uint16_t* wt, int Cout, int taps,
+                                        int Cin) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)Cout * taps * Cin;
+  if (idx >= total) return;
+  const int co = (int)(idx % Cout);
+  const long long r = idx / Cout;
+  const int tap = (int)(r % taps);
+  const int ci = (int)(r / taps);
+  wt[idx] = w[((long long)co * taps + tap) * Cin + ci];
+}
+
+extern "C" int vs_weight_transpose(const void* w, void* wt, int Cout, int taps, int Cin,
+                                   void* stream) {
+  VS_CHECK_ARG(w && wt && Cout > 0 && taps > 0 && Cin > 0, "bad args");
+  const long long total = (long long)Cout * taps * Cin;
+  hipLaunchKernelGGL(weight_transpose_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const uint16_t*)w, (uint16_t*)wt, Cout, taps, Cin);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}

@@ -1,0 +1,347 @@
+// Conv3d weight gradient on bf16 MFMA (gfx950).
+//
+// Replaces autograd's cudnn_convolution_backward_weight for the trunk convs
+// (vidsitu_code/mdl_sf_base.py:22-33).  GEMM view:
+//   dW[co][k'] = sum_p dY[p][co] * Xg[p][k'],   k' = (dt,dh,dw,ci),
+//   M = Cout, N = taps*Cin, K = output positions p (split over blocks).
+// Both operands are stored position-major (channels contiguous), i.e. the
+// reduction index is the strided one, so tiles are staged [64 positions][128 ch]
+// in LDS exactly as loaded (coalesced 16-byte channel vectors) and MFMA
+// fragments are fetched with the gfx950 transposing read ds_read_b64_tr_b16
+// (4 positions x 16 channels per 16-lane group).  256-byte LDS rows with an XOR
+// on the 8-byte unit index keep those reads conflict free:
+//   unit' = unit ^ ((row & 3) << 2) ^ (((row >> 3) & 1) << 4).
+// Split-K partials go to fp32 slabs [S][Cout][K'] and are summed in a fixed
+// order by a second kernel (bitwise reproducible; no atomics).
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+struct WgradP {
+  const uint16_t* dy;
+  const uint16_t* x;
+  float* out;  // slabs [S][Cout][Kp]
+  int P;       // total output positions
+  int Cout, Kp, Cin, x_ld, dy_ld;
+  int To, Ho, Wo, Ti, Hi, Wi;
+  int kT, kH, kW, sT, sH, sW, pT, pH, pW;
+  int tilesM, tilesN, S, rows_per_split;
+};
+
+#define WG_ROWTAB 1024  // positions decoded per refill (16 steps of 64)
+
+__device__ __forceinline__ int wg_swz_chunk(int row) {
+  // 16-byte chunk XOR equivalent of the 8-byte unit swizzle above
+  return ((row & 3) << 1) | (((row >> 3) & 1) << 3);
+}
+
+template <int BM, int BN, int WM, int WN, int MODE>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MR = TM / 16, NR = TN / 16;
+  constexpr int CM = BM / 8, CN = BN / 8;            // 16-byte chunks per row
+  constexpr int RPM = 256 / CM, RPN = 256 / CN;      // rows per load pass
+  constexpr int IM = (64 + RPM - 1) / RPM, IN = (64 + RPN - 1) / RPN;
+  constexpr int IMG = 64 * 256;                      // one image: 64 rows x 256 B
+  constexpr int STAGE = 2 * IMG;
+  static_assert(WM * WN == 4, "4 waves");
+
+  const int tid = threadIdx.x;
+  int bid = blockIdx.x;
+  const int s = bid % p.S;
+  bid /= p.S;
+  const int tn = bid % p.tilesN, tm = bid / p.tilesN;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int pbeg = s * p.rows_per_split;
+  const int pend = min(p.P, pbeg + p.rows_per_split);
+
+  int4* rowtab = (int4*)(smem + 2 * STAGE);
+
+  // fixed per-thread column chunks
+  const int ccm = tid % CM, rm = tid / CM;
+  const int ccn = tid % CN, rn = tid / CN;
+  const bool mcol_ok = (m0 + ccm * 8) < p.Cout;
+  const int ncol = n0 + ccn * 8;
+  const bool ncol_ok = ncol < p.Kp;
+  int dt = 0, dh = 0, dw = 0, c0 = 0;
+  if (MODE == 1 && ncol_ok) {
+    const int tap = ncol / p.Cin;
+    c0 = ncol - tap * p.Cin;
+    dw = tap % p.kW;
+    const int t2 = tap / p.kW;
+    dh = t2 % p.kH;
+    dt = t2 / p.kH;
+  }
+
+  u32x4 ra[IM], rb[IN];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  auto gload = [&](int pstep, int chunk0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < IM; ++i) {
+      const int r = rm + RPM * i;
+      const int pp = pstep + r;
+      ra[i] = zero4;
+      if (r < 64 && mcol_ok && pp < pend)
+        ra[i] = *(const u32x4*)(p.dy + (long long)pp * p.dy_ld + m0 + ccm * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < IN; ++i) {
+      const int r = rn + RPN * i;
+      const int pp = pstep + r;
+      rb[i] = zero4;
+      if (r < 64 && ncol_ok && pp < pend) {
+        if (MODE == 0) {
+          rb[i] = *(const u32x4*)(p.x + (long long)pp * p.x_ld + ncol);
+        } else {
+          const int4 e = rowtab[pp - chunk0];
+          const int ti = e.y + dt, hi = e.z + dh, wi = e.w + dw;
+          if ((unsigned)ti < (unsigned)p.Ti && (unsigned)hi < (unsigned)p.Hi &&
+              (unsigned)wi < (unsigned)p.Wi) {
+            const long long pos = (long long)e.x + (long long)((ti * p.Hi + hi) * p.Wi + wi);
+            rb[i] = *(const u32x4*)(p.x + pos * p.x_ld + c0);
+          }
+        }
+      }
+    }
+  };
+
+  auto sstore = [&](int buf) __attribute__((always_inline)) {
+    char* A = smem + buf * STAGE;
+    char* B = A + IMG;
+#pragma unroll
+    for (int i = 0; i < IM; ++i) {
+      const int r = rm + RPM * i;
+      if (r < 64) *(u32x4*)(A + r * 256 + ((ccm ^ wg_swz_chunk(r)) << 4)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < IN; ++i) {
+      const int r = rn + RPN * i;
+      if (r < 64) *(u32x4*)(B + r * 256 + ((ccn ^ wg_swz_chunk(r)) << 4)) = rb[i];
+    }
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / WN, wn = wave % WN;
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, pp4 = li & 3;
+
+  f32x4 acc[MR][NR];
+#pragma unroll
+  for (int a = 0; a < MR; ++a)
+#pragma unroll
+    for (int b = 0; b < NR; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int buf) __attribute__((always_inline)) {
+    const char* A = smem + buf * STAGE;
+    const char* B = A + IMG;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int row = ks * 32 + 8 * g + q;  // this lane supplies row `row` (and row+4)
+      const int swz = ((row & 3) << 2) | (((row >> 3) & 1) << 4);
+      bf16x8 af[MR], bfr[NR];
+#pragma unroll
+      for (int a = 0; a < MR; ++a) {
+        const int unit = ((wm * TM + a * 16) >> 2) + pp4;
+        const lds_s16x4* ptr = (const lds_s16x4*)(A + row * 256 + ((unit ^ swz) << 3));
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)ptr);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ptr + 128));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        af[a] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int b = 0; b < NR; ++b) {
+        const int unit = ((wn * TN + b * 16) >> 2) + pp4;
+        const lds_s16x4* ptr = (const lds_s16x4*)(B + row * 256 + ((unit ^ swz) << 3));
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)ptr);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ptr + 128));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        bfr[b] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int a = 0; a < MR; ++a)
+#pragma unroll
+        for (int b = 0; b < NR; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+    }
+  };
+
+  // positions are processed in chunks of WG_ROWTAB rows; the pipeline restarts
+  // at each chunk so the row table can be rebuilt behind a barrier.
+  for (int chunk0 = pbeg; chunk0 < pend; chunk0 += WG_ROWTAB) {
+    const int cend = min(pend, chunk0 + WG_ROWTAB);
+    if (MODE == 1) {
+      __syncthreads();  // previous chunk's readers are done
+      for (int i = tid; i < WG_ROWTAB; i += 256) {
+        const int pp = chunk0 + i;
+        int4 e = make_int4(0, -(1 << 20), -(1 << 20), -(1 << 20));
+        if (pp < cend) {
+          const int wo = pp % p.Wo, t1 = pp / p.Wo;
+          const int ho = t1 % p.Ho, t2 = t1 / p.Ho;
+          const int to = t2 % p.To, n = t2 / p.To;
+          e.x = n * p.Ti * p.Hi * p.Wi;
+          e.y = to * p.sT - p.pT;
+          e.z = ho * p.sH - p.pH;
+          e.w = wo * p.sW - p.pW;
+        }
+        rowtab[i] = e;
+      }
+      __syncthreads();
+    }
+    const int nsteps = (cend - chunk0 + 63) >> 6;
+    gload(chunk0, chunk0);
+    __syncthreads();  // all waves finished computing on both buffers (previous chunk)
+    sstore(0);
+    __syncthreads();
+    for (int st = 0; st < nsteps; ++st) {
+      const int cur = st & 1;
+      if (st + 1 < nsteps) gload(chunk0 + (st + 1) * 64, chunk0);
+      compute(cur);
+      if (st + 1 < nsteps) sstore(cur ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // D[m][n]: row = g*4 + reg (cout), col = li (k' column)
+  float* dst = p.out + (long long)s * p.Cout * p.Kp;
+#pragma unroll
+  for (int a = 0; a < MR; ++a)
+#pragma unroll
+    for (int b = 0; b < NR; ++b) {
+      const int col = n0 + wn * TN + b * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * TM + a * 16 + g * 4 + r;
+        if (row < p.Cout && col < p.Kp) dst[(long long)row * p.Kp + col] = acc[a][b][r];
+      }
+    }
+}
+
+// dw[i] = sum_s slab[s][i]  (fixed order)
+__global__ void wgrad_reduce_kernel(const float* slabs, float* dw, long long n, int S) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += slabs[(long long)s * n + i];
+    dw[i] = acc;
+  }
+}
+
+// ------------------------------ host side ------------------------------------
+struct WgCfg {
+  int bm, bn, S, rows_per_split, tilesM, tilesN;
+};
+
+static WgCfg wg_pick(const vs_conv_desc* d) {
+  WgCfg c;
+  const int Kp = d->kT * d->kH * d->kW * d->Cin;
+  const long long P = (long long)d->N * d->To * d->Ho * d->Wo;
+  c.bm = d->Cout >= 128 ? 128 : (d->Cout >= 64 ? 64 : (d->Cout >= 32 ? 32 : 16));
+  c.bn = Kp >= 128 ? 128 : 64;
+  c.tilesM = (d->Cout + c.bm - 1) / c.bm;
+  c.tilesN = (Kp + c.bn - 1) / c.bn;
+  const long long tiles = (long long)c.tilesM * c.tilesN;
+  // aim for ~1024 blocks, at least 4 steps (256 positions) per block
+  long long S = (1024 + tiles - 1) / tiles;
+  const long long maxS = (P + 255) / 256;
+  if (S > maxS) S = maxS;
+  if (S < 1) S = 1;
+  long long rps = (P + S - 1) / S;
+  rps = (rps + 63) / 64 * 64;
+  S = (P + rps - 1) / rps;
+  c.S = (int)S;
+  c.rows_per_split = (int)rps;
+  return c;
+}
+
+extern "C" size_t vs_conv_wgrad_workspace_bytes(const vs_conv_desc* d) {
+  const WgCfg c = wg_pick(d);
+  if (c.S <= 1) return 0;
+  return (size_t)c.S * d->Cout * d->kT * d->kH * d->kW * d->Cin * sizeof(float);
+}
+
+template <int BM, int BN, int WM, int WN>
+static int wg_launch(const WgradP& p, int mode, hipStream_t st) {
+  const size_t smem = 2 * 2 * 64 * 256 + (mode ? WG_ROWTAB * sizeof(int4) : 0);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<BM, BN, WM, WN, 0>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<BM, BN, WM, WN, 1>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const int grid = p.tilesM * p.tilesN * p.S;
+  if (mode == 0)
+    hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, 0>), dim3(grid), dim3(256), smem, st, p);
+  else
+    hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, 1>), dim3(grid), dim3(256), smem, st, p);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+extern "C" int vs_conv_wgrad(const void* dy, const void* x, float* dw, const vs_conv_desc* d,
+                             const float* in_scale, const float* in_shift, void* workspace,
+                             size_t ws_bytes, void* stream) {
+  VS_CHECK_ARG(d && dy && x && dw, "null argument");
+  VS_CHECK_ARG(d->Cin % 8 == 0 && d->Cout % 8 == 0, "Cin and Cout must be multiples of 8");
+  VS_CHECK_ARG(d->x_ld % 8 == 0 && d->y_ld % 8 == 0, "row pitches must be multiples of 8");
+  VS_CHECK_ARG((long long)d->N * d->Ti * d->Hi * d->Wi < (1ll << 31), "too many positions");
+  if (d->flags & VS_CONV_APRO) {
+    (void)in_scale;
+    (void)in_shift;
+    vs_set_error("vs_conv_wgrad: VS_CONV_APRO not implemented yet");
+    return VS_ERR_UNSUPPORTED;
+  }
+  const WgCfg c = wg_pick(d);
+  const size_t need = vs_conv_wgrad_workspace_bytes(d);
+  if (need > 0 && (workspace == nullptr || ws_bytes < need)) {
+    vs_set_error("vs_conv_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
+    return VS_ERR_WORKSPACE;
+  }
+  WgradP p;
+  p.dy = (const uint16_t*)dy;
+  p.x = (const uint16_t*)x;
+  p.out = c.S > 1 ? (float*)workspace : dw;
+  p.P = d->N * d->To * d->Ho * d->Wo;
+  p.Cout = d->Cout;
+  p.Cin = d->Cin;
+  p.Kp = d->kT * d->kH * d->kW * d->Cin;
+  p.x_ld = d->x_ld;
+  p.dy_ld = d->y_ld;
+  p.To = d->To; p.Ho = d->Ho; p.Wo = d->Wo;
+  p.Ti = d->Ti; p.Hi = d->Hi; p.Wi = d->Wi;
+  p.kT = d->kT; p.kH = d->kH; p.kW = d->kW;
+  p.sT = d->sT; p.sH = d->sH; p.sW = d->sW;
+  p.pT = d->pT; p.pH = d->pH; p.pW = d->pW;
+  p.tilesM = c.tilesM;
+  p.tilesN = c.tilesN;
+  p.S = c.S;
+  p.rows_per_split = c.rows_per_split;
+  const bool dense = (d->kT * d->kH * d->kW == 1) && d->sT == 1 && d->sH == 1 && d->sW == 1 &&
+                     d->pT == 0 && d->pH == 0 && d->pW == 0;
+  const int mode = dense ? 0 : 1;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (c.bm == 128 && c.bn == 128) rc = wg_launch<128, 128, 2, 2>(p, mode, st);
+  else if (c.bm == 128) rc = wg_launch<128, 64, 2, 2>(p, mode, st);
+  else if (c.bm == 64 && c.bn == 128) rc = wg_launch<64, 128, 2, 2>(p, mode, st);
+  else if (c.bm == 64) rc = wg_launch<64, 64, 2, 2>(p, mode, st);
+  else if (c.bm == 32 && c.bn == 128) rc = wg_launch<32, 128, 1, 4>(p, mode, st);
+  else if (c.bm == 32) rc = wg_launch<32, 64, 1, 4>(p, mode, st);
+  else if (c.bn == 128) rc = wg_launch<16, 128, 1, 4>(p, mode, st);
+  else rc = wg_launch<16, 64, 1, 4>(p, mode, st);
+  if (rc) return rc;
+  if (c.S > 1) {
+    const long long n = (long long)d->Cout * p.Kp;
+    long long grid = (n + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, st,
+                       (const float*)workspace, dw, n, c.S);
+    VS_CHECK_LAUNCH();
+  }
+  return VS_OK;
+}

@@ -1,0 +1,601 @@
+// fp32 kernels for the 5-token transformer encoder and the small heads.
+//
+// Replaces (reference call sites): nn.Linear of utils/transformer_code.py:51-79
+// (wq/wk/wv/wo, linear1/linear2), the per-head softmax attention :33-48, the
+// post-LN residual block :21-30, proj_head / vid_feat_encoder of
+// vidsitu_code/mdl_sf_base.py:161-167,767-769, F.cross_entropy :226-231 and the
+// softmax->sort->top-5 of vidsitu_code/evl_vsitu.py:39-42.
+//
+// Everything here is weight-bandwidth / latency bound (M = 5*B <= 64 rows), so
+// it stays in exact fp32 on the VALU: each weight row is streamed once per
+// 64-row slab, activations are staged in LDS, reductions are wave shuffles.
+#include "common.h"
+
+// ----------------------------------------------------------------------------
+// y[M,N] = act(x[M,K] @ W[N,K]^T + b).   One wave per output column; lanes split
+// K in float4 units; x chunk [MT][256] staged in LDS and shared by the 4 waves.
+// grid = (ceil(N/4), ceil(M/MT))
+// ----------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ w,
+                                                         const float* __restrict__ b, float* y,
+                                                         int M, int N, int K, int relu) {
+  __shared__ float4 xs[MT][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + wave;
+  const int mbase = blockIdx.y * MT;
+  float acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+  const bool vec_ok = (K & 3) == 0;
+  for (int k0 = 0; k0 < K; k0 += 256) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < MT * 64; i += 256) {
+      const int m = i >> 6, l = i & 63;
+      const int k = k0 + l * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (mbase + m < M) {
+        const float* src = x + (long long)(mbase + m) * K + k;
+        if (vec_ok && k + 3 < K) {
+          v = *(const float4*)src;
+        } else {
+          if (k < K) v.x = src[0];
+          if (k + 1 < K) v.y = src[1];
+          if (k + 2 < K) v.z = src[2];
+          if (k + 3 < K) v.w = src[3];
+        }
+      }
+      xs[m][l] = v;
+    }
+    __syncthreads();
+    if (n < N) {
+      const int k = k0 + lane * 4;
+      float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float* src = w + (long long)n * K + k;
+      if (vec_ok && k + 3 < K) {
+        wv = *(const float4*)src;
+      } else {
+        if (k < K) wv.x = src[0];
+        if (k + 1 < K) wv.y = src[1];
+        if (k + 2 < K) wv.z = src[2];
+        if (k + 3 < K) wv.w = src[3];
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const float4 xv = xs[m][lane];
+        acc[m] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+      }
+    }
+  }
+  if (n < N) {
+    const float bias = b ? b[n] : 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float s = wave_reduce_sum(acc[m]);
+      if (lane == 0 && mbase + m < M) {
+        s += bias;
+        if (relu) s = fmaxf(s, 0.f);
+        y[(long long)(mbase + m) * N + n] = s;
+      }
+    }
+  }
+}
+
+extern "C" int vs_linear_fwd(const float* x, const float* w, const float* b, float* y, int M,
+                             int N, int K, int relu, void* stream) {
+  VS_CHECK_ARG(x && w && y && M > 0 && N > 0 && K > 0, "bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const int gx = (N + 3) / 4;
+  if (M <= 8)
+    hipLaunchKernelGGL(linear_fwd_kernel<8>, dim3(gx, 1), dim3(256), 0, st, x, w, b, y, M, N, K, relu);
+  else if (M <= 16)
+    hipLaunchKernelGGL(linear_fwd_kernel<16>, dim3(gx, 1), dim3(256), 0, st, x, w, b, y, M, N, K, relu);
+  else if (M <= 32)
+    hipLaunchKernelGGL(linear_fwd_kernel<32>, dim3(gx, 1), dim3(256), 0, st, x, w, b, y, M, N, K, relu);
+  else if (M <= 48)
+    hipLaunchKernelGGL(linear_fwd_kernel<48>, dim3(gx, 1), dim3(256), 0, st, x, w, b, y, M, N, K, relu);
+  else
+    hipLaunchKernelGGL(linear_fwd_kernel<64>, dim3(gx, (M + 63) / 64), dim3(256), 0, st, x, w, b, y,
+                       M, N, K, relu);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// dx[M,K] = dy[M,N] @ W[N,K] is the forward kernel on the transposed weight
+// wT[K,N] (made once per step by vs_transpose_f32): every weight row is again
+// streamed exactly once and N/4.. blocks keep the chip busy.
+__global__ void transpose_f32_kernel(const float* __restrict__ w, float* __restrict__ wt, int R,
+                                     int C) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    tile[i][threadIdx.x] = (r < R && c < C) ? w[(long long)r * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (r < R && c < C) wt[(long long)c * R + r] = tile[threadIdx.x][i];
+  }
+}
+
+extern "C" int vs_transpose_f32(const float* w, float* wt, int R, int C, void* stream) {
+  VS_CHECK_ARG(w && wt && R > 0 && C > 0, "bad args");
+  hipLaunchKernelGGL(transpose_f32_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(32, 8), 0,
+                     (hipStream_t)stream, w, wt, R, C);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+extern "C" int vs_linear_bwd_data(const float* dy, const float* wt, float* dx, int M, int N, int K,
+                                  void* stream) {
+  return vs_linear_fwd(dy, wt, nullptr, dx, M, K, N, 0, stream);
+}
+
+// dw[N,K] = dy^T x ; db[N] = sum_m dy.  thread per (n, 4 k's), loop over M rows.
+__global__ void linear_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                         float* dw, float* db, int M, int N, int K) {
+  const int K4 = (K + 3) / 4;
+  const long long total = (long long)N * K4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / K4);
+    const int k = (int)(i - (long long)n * K4) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float bsum = 0.f;
+    const bool vec_ok = (K & 3) == 0;
+    for (int m = 0; m < M; ++m) {
+      const float d = dy[(long long)m * N + n];
+      const float* src = x + (long long)m * K + k;
+      float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (vec_ok) {
+        xv = *(const float4*)src;
+      } else {
+        xv.x = src[0];
+        if (k + 1 < K) xv.y = src[1];
+        if (k + 2 < K) xv.z = src[2];
+        if (k + 3 < K) xv.w = src[3];
+      }
+      acc.x += d * xv.x;
+      acc.y += d * xv.y;
+      acc.z += d * xv.z;
+      acc.w += d * xv.w;
+      bsum += d;
+    }
+    float* dst = dw + (long long)n * K + k;
+    dst[0] = acc.x;
+    if (k + 1 < K) dst[1] = acc.y;
+    if (k + 2 < K) dst[2] = acc.z;
+    if (k + 3 < K) dst[3] = acc.w;
+    if (db && k == 0) db[n] = bsum;
+  }
+}
+
+extern "C" int vs_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, int M,
+                                    int N, int K, void* stream) {
+  VS_CHECK_ARG(dy && x && dw && M > 0 && N > 0 && K > 0, "bad args");
+  const long long total = (long long)N * ((K + 3) / 4);
+  long long g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(linear_bwd_weight_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+                     dy, x, dw, db, M, N, K);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// ----------------------------------------------------------------------------
+// Attention for L <= 16: one 256-thread block per (batch, head); q/k/v of the head
+// live in LDS (L*dh*3 floats), scores and probabilities in LDS [L][L].
+// probs saved as [B][H][L][L] for the backward.
+// ----------------------------------------------------------------------------
+#define ATT_MAXL 16
+
+__global__ __launch_bounds__(256) void attn_small_fwd_kernel(const float* q, const float* k,
+                                                             const float* v, float* o, float* probs,
+                                                             int L, int H, int dh, float inv_scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem_att[];
+  float* qs = (float*)smem_att;  // [L][dh]
+  float* ks = qs + L * dh;
+  float* vs = ks + L * dh;
+  float* ps = vs + L * dh;  // [L][L]
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int D = H * dh;
+  for (int i = threadIdx.x; i < L * dh; i += 256) {
+    const int r = i / dh, d = i - r * dh;
+    const long long off = ((long long)b * L + r) * D + h * dh + d;
+    qs[i] = q[off];
+    ks[i] = k[off];
+    vs[i] = v[off];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < L * L; e += 256) {
+    const int i = e / L, j = e - i * L;
+    float s = 0.f;
+    for (int d = 0; d < dh; ++d) s += qs[i * dh + d] * ks[j * dh + d];
+    ps[e] = s * inv_scale;
+  }
+  __syncthreads();
+  if (threadIdx.x < L) {
+    const int i = threadIdx.x;
+    float mx = -INFINITY;
+    for (int j = 0; j < L; ++j) mx = fmaxf(mx, ps[i * L + j]);
+    float den = 0.f;
+    for (int j = 0; j < L; ++j) {
+      const float ev = expf(ps[i * L + j] - mx);
+      ps[i * L + j] = ev;
+      den += ev;
+    }
+    const float inv = 1.0f / den;
+    for (int j = 0; j < L; ++j) {
+      const float pj = ps[i * L + j] * inv;
+      ps[i * L + j] = pj;
+      if (probs) probs[(((long long)b * H + h) * L + i) * L + j] = pj;
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < L * dh; e += 256) {
+    const int i = e / dh, d = e - i * dh;
+    float acc = 0.f;
+    for (int j = 0; j < L; ++j) acc += ps[i * L + j] * vs[j * dh + d];
+    o[((long long)b * L + i) * D + h * dh + d] = acc;
+  }
+}
+
+extern "C" int vs_attn_small_fwd(const float* q, const float* k, const float* v, float* o,
+                                 float* probs, int B, int L, int H, int dh, float scale,
+                                 void* stream) {
+  VS_CHECK_ARG(q && k && v && o, "null tensor");
+  VS_CHECK_ARG(L >= 1 && L <= ATT_MAXL && dh >= 1 && dh <= 512, "L <= 16, dh <= 512");
+  const size_t smem = (size_t)(3 * L * dh + L * L) * sizeof(float);
+  hipLaunchKernelGGL(attn_small_fwd_kernel, dim3(B * H), dim3(256), smem, (hipStream_t)stream, q, k,
+                     v, o, probs, L, H, dh, 1.0f / scale);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+__global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* q, const float* k,
+                                                             const float* v, const float* probs,
+                                                             const float* dout, float* dq, float* dk,
+                                                             float* dv, int L, int H, int dh,
+                                                             float inv_scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem_att[];
+  float* qs = (float*)smem_att;  // [L][dh]
+  float* ks = qs + L * dh;
+  float* vs = ks + L * dh;
+  float* dos = vs + L * dh;
+  float* ps = dos + L * dh;  // [L][L]
+  float* dss = ps + L * L;   // [L][L]
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int D = H * dh;
+  for (int i = threadIdx.x; i < L * dh; i += 256) {
+    const int r = i / dh, d = i - r * dh;
+    const long long off = ((long long)b * L + r) * D + h * dh + d;
+    qs[i] = q[off];
+    ks[i] = k[off];
+    vs[i] = v[off];
+    dos[i] = dout[off];
+  }
+  for (int e = threadIdx.x; e < L * L; e += 256)
+    ps[e] = probs[((long long)b * H + h) * L * L + e];
+  __syncthreads();
+  // dP[i][j] = dO[i] . V[j]
+  for (int e = threadIdx.x; e < L * L; e += 256) {
+    const int i = e / L, j = e - i * L;
+    float s = 0.f;
+    for (int d = 0; d < dh; ++d) s += dos[i * dh + d] * vs[j * dh + d];
+    dss[e] = s;
+  }
+  __syncthreads();
+  // dS = P * (dP - sum_j dP*P) / scale
+  if (threadIdx.x < L) {
+    const int i = threadIdx.x;
+    float dot = 0.f;
+    for (int j = 0; j < L; ++j) dot += dss[i * L + j] * ps[i * L + j];
+    for (int j = 0; j < L; ++j) dss[i * L + j] = ps[i * L + j] * (dss[i * L + j] - dot) * inv_scale;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < L * dh; e += 256) {
+    const int r = e / dh, d = e - r * dh;
+    float aq = 0.f, ak = 0.f, av = 0.f;
+    for (int j = 0; j < L; ++j) {
+      aq += dss[r * L + j] * ks[j * dh + d];   // dQ[r] = sum_j dS[r][j] K[j]
+      ak += dss[j * L + r] * qs[j * dh + d];   // dK[r] = sum_i dS[i][r] Q[i]
+      av += ps[j * L + r] * dos[j * dh + d];   // dV[r] = sum_i P[i][r] dO[i]
+    }
+    const long long off = ((long long)b * L + r) * D + h * dh + d;
+    dq[off] = aq;
+    dk[off] = ak;
+    dv[off] = av;
+  }
+}
+
+extern "C" int vs_attn_small_bwd(const float* q, const float* k, const float* v,
+                                 const float* probs, const float* dout, float* dq, float* dk,
+                                 float* dv, int B, int L, int H, int dh, float scale,
+                                 void* stream) {
+  VS_CHECK_ARG(q && k && v && probs && dout && dq && dk && dv, "null tensor");
+  VS_CHECK_ARG(L >= 1 && L <= ATT_MAXL && dh >= 1 && dh <= 512, "L <= 16, dh <= 512");
+  const size_t smem = (size_t)(4 * L * dh + 2 * L * L) * sizeof(float);
+  hipLaunchKernelGGL(attn_small_bwd_kernel, dim3(B * H), dim3(256), smem, (hipStream_t)stream, q, k,
+                     v, probs, dout, dq, dk, dv, L, H, dh, 1.0f / scale);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// ----------------------------------------------------------------------------
+// y = LayerNorm(x + r): one wave per row, two-pass mean / centred variance.
+// ----------------------------------------------------------------------------
+#define LN_MAXE 32  // elements per lane (D <= 2048)
+
+__global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* x, const float* r,
+                                                                const float* gamma,
+                                                                const float* beta, float* y,
+                                                                float* mean, float* rstd, int rows,
+                                                                int D, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float v[LN_MAXE];
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < LN_MAXE; ++e) {
+    const int d = lane + 64 * e;
+    v[e] = 0.f;
+    if (d < D) {
+      v[e] = x[(long long)row * D + d] + (r ? r[(long long)row * D + d] : 0.f);
+      s += v[e];
+    }
+  }
+  const float mu = wave_reduce_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < LN_MAXE; ++e) {
+    const int d = lane + 64 * e;
+    if (d < D) {
+      const float c = v[e] - mu;
+      q += c * c;
+    }
+  }
+  const float rs = rsqrtf(wave_reduce_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int e = 0; e < LN_MAXE; ++e) {
+    const int d = lane + 64 * e;
+    if (d < D) y[(long long)row * D + d] = (v[e] - mu) * rs * gamma[d] + beta[d];
+  }
+  if (lane == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = rs;
+  }
+}
+
+extern "C" int vs_add_layernorm_fwd(const float* x, const float* r, const float* gamma,
+                                    const float* beta, float* y, float* mean, float* rstd,
+                                    int rows, int D, float eps, void* stream) {
+  VS_CHECK_ARG(x && gamma && beta && y && rows > 0, "bad args");
+  VS_CHECK_ARG(D >= 1 && D <= 64 * LN_MAXE, "D <= 2048");
+  hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0,
+                     (hipStream_t)stream, x, r, gamma, beta, y, mean, rstd, rows, D, eps);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// dx = rstd * (g - mean(g) - xhat*mean(g*xhat)), g = gamma*dy ; per-row wave
+__global__ __launch_bounds__(256) void add_layernorm_bwd_dx_kernel(
+    const float* dy, const float* x, const float* r, const float* gamma, const float* mean,
+    const float* rstd, float* dx, int rows, int D) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float mu = mean[row], rs = rstd[row];
+  float g[LN_MAXE], xh[LN_MAXE];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int e = 0; e < LN_MAXE; ++e) {
+    const int d = lane + 64 * e;
+    g[e] = 0.f;
+    xh[e] = 0.f;
+    if (d < D) {
+      const float v = x[(long long)row * D + d] + (r ? r[(long long)row * D + d] : 0.f);
+      xh[e] = (v - mu) * rs;
+      g[e] = gamma[d] * dy[(long long)row * D + d];
+      s1 += g[e];
+      s2 += g[e] * xh[e];
+    }
+  }
+  const float m1 = wave_reduce_sum(s1) / (float)D, m2 = wave_reduce_sum(s2) / (float)D;
+#pragma unroll
+  for (int e = 0; e < LN_MAXE; ++e) {
+    const int d = lane + 64 * e;
+    if (d < D) dx[(long long)row * D + d] = rs * (g[e] - m1 - xh[e] * m2);
+  }
+}
+
+// dgamma[d] = sum_rows dy*xhat ; dbeta[d] = sum_rows dy   (thread per column)
+__global__ void add_layernorm_bwd_param_kernel(const float* dy, const float* x, const float* r,
+                                               const float* mean, const float* rstd, float* dgamma,
+                                               float* dbeta, int rows, int D) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  float sg = 0.f, sb = 0.f;
+  for (int row = 0; row < rows; ++row) {
+    const float v = x[(long long)row * D + d] + (r ? r[(long long)row * D + d] : 0.f);
+    const float g = dy[(long long)row * D + d];
+    sg += g * (v - mean[row]) * rstd[row];
+    sb += g;
+  }
+  dgamma[d] = sg;
+  dbeta[d] = sb;
+}
+
+extern "C" int vs_add_layernorm_bwd(const float* dy, const float* x, const float* r,
+                                    const float* gamma, const float* mean, const float* rstd,
+                                    float* dx, float* dgamma, float* dbeta, int rows, int D,
+                                    void* stream) {
+  VS_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "null tensor");
+  VS_CHECK_ARG(D >= 1 && D <= 64 * LN_MAXE, "D <= 2048");
+  hipLaunchKernelGGL(add_layernorm_bwd_dx_kernel, dim3((rows + 3) / 4), dim3(256), 0,
+                     (hipStream_t)stream, dy, x, r, gamma, mean, rstd, dx, rows, D);
+  hipLaunchKernelGGL(add_layernorm_bwd_param_kernel, dim3((D + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, dy, x, r, mean, rstd, dgamma, dbeta, rows, D);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// ----------------------------------------------------------------------------
+// mean cross-entropy + dlogits.  One block; waves take rows round-robin and the
+// per-wave loss sums are combined in a fixed order (bitwise reproducible).
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_xent_kernel(const float* logits,
+                                                           const int64_t* labels, float* loss,
+                                                           float* dlogits, int rows, int V) {
+  __shared__ float wsum[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float lsum = 0.f;
+  const float invR = 1.0f / (float)rows;
+  for (int row = wave; row < rows; row += 4) {
+    const float* lg = logits + (long long)row * V;
+    float mx = -INFINITY;
+    for (int j = lane; j < V; j += 64) mx = fmaxf(mx, lg[j]);
+    mx = wave_reduce_max(mx);
+    float den = 0.f;
+    for (int j = lane; j < V; j += 64) den += expf(lg[j] - mx);
+    den = wave_reduce_sum(den);
+    const int lab = (int)labels[row];
+    const float lse = mx + logf(den);
+    lsum += lse - lg[lab];
+    if (dlogits) {
+      const float inv = 1.0f / den;
+      for (int j = lane; j < V; j += 64) {
+        const float pj = expf(lg[j] - mx) * inv;
+        dlogits[(long long)row * V + j] = (pj - (j == lab ? 1.f : 0.f)) * invR;
+      }
+    }
+  }
+  if (lane == 0) wsum[wave] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) *loss = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * invR;
+}
+
+extern "C" int vs_softmax_xent(const float* logits, const int64_t* labels, float* loss,
+                               float* dlogits, int rows, int V, void* stream) {
+  VS_CHECK_ARG(logits && labels && loss && rows > 0 && V > 0, "bad args");
+  hipLaunchKernelGGL(softmax_xent_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, labels,
+                     loss, dlogits, rows, V);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// softmax -> k largest (descending; ties -> lowest index).  One wave per row.
+__global__ __launch_bounds__(64) void softmax_topk_kernel(const float* logits, float* probs_out,
+                                                          int64_t* idx_out, int V, int k) {
+  const int row = blockIdx.x, lane = threadIdx.x;
+  const float* lg = logits + (long long)row * V;
+  float mx = -INFINITY;
+  for (int j = lane; j < V; j += 64) mx = fmaxf(mx, lg[j]);
+  mx = wave_reduce_max(mx);
+  float den = 0.f;
+  for (int j = lane; j < V; j += 64) den += expf(lg[j] - mx);
+  den = wave_reduce_sum(den);
+  float prev_v = INFINITY;
+  int prev_i = -1;
+  for (int t = 0; t < k; ++t) {
+    // best (value, index) strictly after (prev_v, prev_i) in (desc value, asc index) order
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = lane; j < V; j += 64) {
+      const float v = lg[j];
+      const bool after = (v < prev_v) || (v == prev_v && j > prev_i);
+      if (after && (v > bv || (v == bv && j < bi))) {
+        bv = v;
+        bi = j;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+    if (lane == 0) {
+      probs_out[(long long)row * k + t] = expf(bv - mx) / den;
+      idx_out[(long long)row * k + t] = bi;
+    }
+    prev_v = bv;
+    prev_i = bi;
+  }
+}
+
+extern "C" int vs_softmax_topk(const float* logits, float* probs_out, int64_t* idx_out, int rows,
+                               int V, int k, void* stream) {
+  VS_CHECK_ARG(logits && probs_out && idx_out && rows > 0 && V > 0 && k > 0 && k <= V, "bad args");
+  hipLaunchKernelGGL(softmax_topk_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, logits,
+                     probs_out, idx_out, V, k);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// ----------------------------------------------------------------------------
+// Adam on a flat fp32 arena (torch.optim.Adam semantics, main_dist.py:50) and the
+// fp32 -> bf16 weight cast.
+// ----------------------------------------------------------------------------
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, long long n, float lr,
+                            float b1, float b2, float eps, float bc1, float bc2_sqrt,
+                            float grad_scale) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * grad_scale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+  }
+}
+
+extern "C" int vs_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                            float beta1, float beta2, float eps, int step, float grad_scale,
+                            void* stream) {
+  VS_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "bad args");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = 1.f - powf(beta2, (float)step);
+  long long grid = (n + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m,
+                     v, (long long)n, lr, beta1, beta2, eps, bc1, sqrtf(bc2), grad_scale);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+__global__ void cast_f32_bf16_kernel(const float* x, uint16_t* y, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    y[i] = f32_to_bf16(x[i]);
+}
+
+extern "C" int vs_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {
+  VS_CHECK_ARG(x && y && n > 0, "bad args");
+  long long grid = (n + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
+                     x, (uint16_t*)y, (long long)n);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// ------------------------------ error plumbing --------------------------------
+#include <stdarg.h>
+static thread_local char g_err[512] = "";
+
+void vs_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* vs_last_error_string(void) { return g_err; }
+extern "C" int vs_version(void) { return 1; }
