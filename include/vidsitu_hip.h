@@ -80,10 +80,13 @@ int vs_conv_fwd(const void* x, const void* w, void* y, const vs_conv_desc* d, co
                 const float* in_scale, const float* in_shift, void* stream);
 int vs_conv_stats_rows(const vs_conv_desc* d);
 
-/* Data gradient: dx[N,Ti,Hi,Wi,Cin] = conv_transpose(dy, w).  wt is the
+/* Data gradient: dx[N,Ti,Hi,Wi,Cin] = conv_transpose(dy, w) (+ residual when
+ * desc.flags has VS_CONV_RESIDUAL: the gradient arriving over the other branch
+ * of a fan-out, pitch desc.res_ld; may alias dx).  wt is the
  * [Cin][kT][kH][kW][Cout] bf16 image made by vs_weight_transpose.
  * Replaces autograd's cudnn_convolution_backward_input for the same layers. */
-int vs_conv_dgrad(const void* dy, const void* wt, void* dx, const vs_conv_desc* d, void* stream);
+int vs_conv_dgrad(const void* dy, const void* wt, void* dx, const vs_conv_desc* d,
+                  const void* residual, void* stream);
 int vs_weight_transpose(const void* w, void* wt, int Cout, int taps, int Cin, void* stream);
 
 /* Weight gradient: dw[Cout][taps][Cin] fp32 = sum_p dy[p][co] * x[p@tap][ci].

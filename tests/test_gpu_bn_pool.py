@@ -1,0 +1,134 @@
+"""BatchNorm (train / eval / backward), stem max-pools and the global average pool vs
+fp32 torch on the same bf16-rounded operands."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_utils import assert_close, rb, to_act, to_w
+
+pytestmark = pytest.mark.gpu
+
+
+def _conv_case(seed, n=2, cin=16, cout=32, t=4, hw=12):
+    g = torch.Generator().manual_seed(seed)
+    x = rb(torch.randn(n, cin, t, hw, hw, generator=g))
+    w = rb(torch.randn(cout, cin, 1, 3, 3, generator=g) / 12.0)
+    return x, w
+
+
+@pytest.mark.parametrize("cout,hw", [(8, 20), (32, 12), (128, 9), (512, 5)])
+def test_bn_train_forward_matches_torch(cout, hw, dev):
+    from vidsitu_amd import ops
+
+    x, w = _conv_case(1, cout=cout, hw=hw)
+    g = torch.Generator().manual_seed(2)
+    gamma, beta = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+    rm, rv = torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5
+    yref = F.conv3d(x, w, padding=(0, 1, 1))
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    zref = F.relu(F.batch_norm(yref, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5))
+    y, partials = ops.conv_fwd(to_act(x, dev), to_w(w, dev), (1, 3, 3), (1, 1, 1), (0, 1, 1), stats=True)
+    rm_d, rv_d = rm.to(dev), rv.to(dev)
+    scale, shift, mean, invstd = ops.bn_finalize(partials, ops.act_rows(y), gamma.to(dev),
+                                                 beta.to(dev), rm_d, rv_d, 0.1, 1e-5, train=True)
+    z = ops.bn_apply(y, scale, shift, None, True)
+    assert_close(mean, yref.mean(dim=(0, 2, 3, 4)), 2e-3, "batch mean")
+    assert_close(1.0 / invstd ** 2, yref.var(dim=(0, 2, 3, 4), unbiased=False) + 1e-5, 5e-3, "var")
+    assert_close(rm_d, rm_ref, 2e-3, "running_mean")
+    assert_close(rv_d, rv_ref, 5e-3, "running_var (unbiased)")
+    assert_close(z, zref, 2e-2, "bn+relu output")
+
+
+def test_bn_eval_fold(dev):
+    from vidsitu_amd import ops
+
+    c = 64
+    g = torch.Generator().manual_seed(3)
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    rm, rv = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5
+    scale, shift, _, _ = ops.bn_finalize(None, 0, gamma.to(dev), beta.to(dev), rm.to(dev),
+                                         rv.to(dev), 0.1, 1e-5, train=False)
+    sref = gamma / torch.sqrt(rv + 1e-5)
+    assert_close(scale, sref, 1e-6, "scale")
+    assert_close(shift, beta - rm * sref, 1e-5, "shift")
+
+
+@pytest.mark.parametrize("c,hw,relu,res", [(8, 20, True, False), (32, 12, True, True),
+                                           (256, 6, False, False), (2048, 3, True, True)])
+def test_bn_backward_matches_autograd(c, hw, relu, res, dev):
+    from vidsitu_amd import ops
+
+    g = torch.Generator().manual_seed(4)
+    n, t = 2, 3
+    y = rb(torch.randn(n, c, t, hw, hw, generator=g) * 1.5 + 0.3).requires_grad_()
+    r = rb(torch.randn(n, c, t, hw, hw, generator=g)).requires_grad_()
+    gamma = (torch.rand(c, generator=g) + 0.5).requires_grad_()
+    beta = (torch.randn(c, generator=g) * 0.2).requires_grad_()
+    zr = F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5)
+    if res:
+        zr = zr + r
+    if relu:
+        zr = F.relu(zr)
+    dz = rb(torch.randn(zr.shape, generator=g))
+    grads = torch.autograd.grad(zr, [y, gamma, beta] + ([r] if res else []), dz)
+    # device side: stats from y itself (fp32), then apply, then backward
+    yd = to_act(y.detach(), dev)
+    yf = y.detach()
+    mean = yf.mean(dim=(0, 2, 3, 4))
+    invstd = 1.0 / torch.sqrt(yf.var(dim=(0, 2, 3, 4), unbiased=False) + 1e-5)
+    scale = gamma.detach() * invstd
+    shift = beta.detach() - mean * scale
+    z = ops.bn_apply(yd, scale.to(dev), shift.to(dev), to_act(r.detach(), dev) if res else None, relu)
+    dy, dres, dgamma, dbeta = ops.bn_bwd(to_act(dz, dev), z, yd, mean.to(dev), invstd.to(dev),
+                                         gamma.detach().to(dev), relu, want_dres=res)
+    # the ReLU mask is taken from the bf16-rounded z, so elements within rounding of 0 may flip
+    assert_close(dy, grads[0], 3e-2, "dy")
+    assert_close(dgamma, grads[1], 2e-2, "dgamma")
+    assert_close(dbeta, grads[2], 2e-2, "dbeta")
+    if res:
+        assert_close(dres, grads[3], 2e-2, "dres")
+
+
+@pytest.mark.parametrize("c,t,h,w", [(8, 2, 16, 16), (64, 2, 14, 18), (16, 1, 7, 9)])
+def test_maxpool_hw_fwd_bwd(c, t, h, w, dev):
+    from vidsitu_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    x = F.relu(rb(torch.randn(2, c, t, h, w, generator=g))).requires_grad_()  # many exact ties at 0
+    yr = F.max_pool3d(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    dy = rb(torch.randn(yr.shape, generator=g))
+    (dxr,) = torch.autograd.grad(yr, x, dy)
+    y, idx = ops.maxpool_hw(to_act(x.detach(), dev), want_idx=True)
+    assert torch.equal(y.float().cpu(), yr.detach())
+    dx = ops.maxpool_hw_bwd(to_act(dy, dev), idx, tuple(x.shape))
+    assert_close(dx, dxr, 1e-2, "maxpool bwd (first-max tie rule, bf16 sum)")
+
+
+def test_maxpool_t_fwd_bwd(dev):
+    from vidsitu_amd import ops
+
+    g = torch.Generator().manual_seed(6)
+    x = rb(torch.randn(2, 32, 8, 5, 5, generator=g)).requires_grad_()
+    yr = F.max_pool3d(x, (2, 1, 1), (2, 1, 1))
+    dy = rb(torch.randn(yr.shape, generator=g))
+    (dxr,) = torch.autograd.grad(yr, x, dy)
+    y, idx = ops.maxpool_t(to_act(x.detach(), dev), 2, want_idx=True)
+    assert torch.equal(y.float().cpu(), yr.detach())
+    dx = ops.maxpool_t_bwd(to_act(dy, dev), idx, tuple(x.shape), 2)
+    assert torch.equal(dx.float().cpu(), dxr)
+
+
+def test_avgpool_cat_fwd_bwd(dev):
+    from vidsitu_amd import ops
+
+    g = torch.Generator().manual_seed(7)
+    a = rb(torch.randn(3, 2048, 2, 3, 3, generator=g))
+    b = rb(torch.randn(3, 256, 8, 3, 3, generator=g))
+    out = ops.avgpool_cat([to_act(a, dev), to_act(b, dev)])
+    ref = torch.cat([a.mean(dim=(2, 3, 4)), b.mean(dim=(2, 3, 4))], 1)
+    assert tuple(out.shape) == (3, 2304)
+    assert_close(out, ref, 1e-5, "avgpool+cat")
+    dout = torch.randn(3, 2304, generator=g)
+    da, db = ops.avgpool_cat_bwd(dout.to(dev), [tuple(a.shape), tuple(b.shape)])
+    assert_close(da, (dout[:, :2048] / 18.0).view(3, 2048, 1, 1, 1).expand_as(a), 5e-3, "da")
+    assert_close(db, (dout[:, 2048:] / 72.0).view(3, 256, 1, 1, 1).expand_as(b), 5e-3, "db")

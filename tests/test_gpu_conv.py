@@ -1,0 +1,171 @@
+"""Parity of the HIP conv kernels (through the C-ABI) with fp32 torch conv3d on the same
+bf16-rounded operands.  Tolerance: outputs are rounded to bf16 once (2^-9 relative) and
+accumulated in fp32 in a different order, so 1e-2 of the tensor's max magnitude.
+Covers every kernel family of SlowFast-R50, every tile config of
+pick_tile(), K / M / N tails, strides, padding, the fused epilogue and the BN partials."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_utils import assert_close, rb, to_act, to_w
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-2
+
+# name, N, Cin, T, H, W, Cout, k, s, p
+CASES = [
+    ("pw_64_256", 2, 64, 4, 14, 14, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("pw_k80_tail", 2, 80, 2, 12, 12, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("pw_8_32_fast", 1, 8, 4, 18, 18, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("pw_32_8", 1, 32, 4, 18, 18, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("pw_stride2", 2, 64, 2, 14, 14, 128, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
+    ("pw_320_512_s2", 1, 320, 2, 14, 14, 512, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
+    ("pw_bigM_128x128", 2, 16, 8, 64, 64, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("pw_bigM_128x64", 2, 16, 8, 64, 64, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("t3_32_8", 2, 32, 8, 8, 8, 8, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ("t3_256_64", 1, 256, 4, 7, 7, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ("t3_640_256", 1, 640, 3, 6, 6, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ("s3_64_64", 2, 64, 2, 14, 14, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("s3_16_16_s2", 2, 16, 4, 14, 14, 16, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ("s3_8_8", 1, 8, 4, 20, 20, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("s3_128_128", 1, 128, 2, 7, 7, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("s3_odd_hw", 1, 32, 3, 9, 11, 32, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ("fuse_7x1x1_s4", 2, 8, 32, 6, 6, 16, (7, 1, 1), (4, 1, 1), (3, 0, 0)),
+    ("fuse_32_64", 1, 32, 16, 5, 5, 64, (7, 1, 1), (4, 1, 1), (3, 0, 0)),
+    ("stem_slow", 1, 8, 2, 32, 32, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3)),
+    ("stem_fast", 1, 8, 8, 32, 32, 8, (5, 7, 7), (1, 2, 2), (2, 3, 3)),
+]
+
+
+def _mk(case, seed=0):
+    name, n, cin, t, h, w, cout, k, s, p = case
+    g = torch.Generator().manual_seed(seed)
+    x = rb(torch.randn(n, cin, t, h, w, generator=g))
+    wt = rb(torch.randn(cout, cin, *k, generator=g) / (cin * k[0] * k[1] * k[2]) ** 0.5)
+    return x, wt, k, s, p
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_fwd_matches_torch(case, dev):
+    from vidsitu_amd import ops
+
+    x, w, k, s, p = _mk(case)
+    ref = F.conv3d(x, w, stride=s, padding=p)
+    y, _ = ops.conv_fwd(to_act(x, dev), to_w(w, dev), k, s, p)
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert_close(y, ref, TOL, case[0])
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[4], CASES[9], CASES[12], CASES[16], CASES[19]],
+                         ids=lambda c: c[0])
+def test_mfma_kernel_matches_naive_hip_kernel(case, dev):
+    """Two independent HIP implementations of the same gather agree (isolates MFMA/LDS bugs)."""
+    from vidsitu_amd import ops
+
+    x, w, k, s, p = _mk(case, seed=3)
+    xa, wa = to_act(x, dev), to_w(w, dev)
+    y1, _ = ops.conv_fwd(xa, wa, k, s, p)
+    y2, _ = ops.conv_fwd(xa, wa, k, s, p, naive=True)
+    assert_close(y1, y2.float(), 8e-3, case[0])
+
+
+def test_conv_fused_epilogue_and_concat_write(dev):
+    """scale/shift + residual + ReLU, written into a channel slice of a wider buffer and
+    read from one (the FuseFastToSlow in-place concat)."""
+    from vidsitu_amd import ops
+
+    g = torch.Generator().manual_seed(1)
+    n, cin, cout, t, h, w = 2, 64, 64, 2, 10, 10
+    xfull = rb(torch.randn(n, cin + 16, t, h, w, generator=g))
+    wt = rb(torch.randn(cout, cin, 1, 3, 3, generator=g) / 24.0)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    res = rb(torch.randn(n, cout, t, h, w, generator=g))
+    ref = F.relu(F.conv3d(xfull[:, 16:], wt, padding=(0, 1, 1)) * scale.view(1, -1, 1, 1, 1)
+                 + shift.view(1, -1, 1, 1, 1) + res)
+    xa = to_act(xfull, dev)[:, 16:]
+    buf = ops.new_act(n, cout + 32, t, h, w, dev, zero=True)
+    out = buf[:, 32:]
+    ops.conv_fwd(xa, to_w(wt, dev), (1, 3, 3), (1, 1, 1), (0, 1, 1), out=out,
+                 scale=scale.to(dev), shift=shift.to(dev), residual=to_act(res, dev), relu=True)
+    assert_close(buf[:, 32:], ref, TOL, "fused epilogue")
+    assert float(buf[:, :32].float().abs().max()) == 0.0  # neighbours untouched
+
+
+@pytest.mark.parametrize("case", [CASES[1], CASES[7], CASES[11], CASES[13], CASES[17]],
+                         ids=lambda c: c[0])
+def test_conv_bn_stat_partials(case, dev):
+    from vidsitu_amd import ops
+
+    x, w, k, s, p = _mk(case, seed=5)
+    ref = F.conv3d(x, w, stride=s, padding=p)
+    y, partials = ops.conv_fwd(to_act(x, dev), to_w(w, dev), k, s, p, stats=True)
+    tot = partials.double().sum(0).cpu()
+    rsum = ref.double().sum(dim=(0, 2, 3, 4))
+    rsq = (ref.double() ** 2).sum(dim=(0, 2, 3, 4))
+    assert torch.allclose(tot[0], rsum, rtol=1e-3, atol=1e-3 * float(ref.abs().max()) * 10)
+    assert torch.allclose(tot[1], rsq, rtol=1e-3, atol=1e-3)
+
+
+DG_CASES = [CASES[i] for i in (0, 1, 3, 4, 5, 8, 9, 11, 12, 14, 15, 16, 17)]
+
+
+@pytest.mark.parametrize("case", DG_CASES, ids=[c[0] for c in DG_CASES])
+def test_conv_dgrad_matches_autograd(case, dev):
+    from vidsitu_amd import ops
+
+    x, w, k, s, p = _mk(case, seed=7)
+    x.requires_grad_()
+    y = F.conv3d(x, w, stride=s, padding=p)
+    dy = rb(torch.randn(y.shape, generator=torch.Generator().manual_seed(9)))
+    (dx_ref,) = torch.autograd.grad(y, x, dy)
+    wt = ops.weight_transpose(to_w(w, dev))
+    dx = ops.conv_dgrad(to_act(dy, dev), wt, tuple(x.shape), k, s, p)
+    assert_close(dx, dx_ref, TOL, case[0])
+    dxn = ops.conv_dgrad(to_act(dy, dev), wt, tuple(x.shape), k, s, p, naive=True)
+    assert_close(dxn, dx_ref, TOL, case[0] + " naive")
+    # fan-out accumulation: dx = dgrad + residual (may alias the output)
+    r = rb(torch.randn(x.shape, generator=torch.Generator().manual_seed(11)))
+    ra = to_act(r, dev)
+    ops.conv_dgrad(to_act(dy, dev), wt, tuple(x.shape), k, s, p, out=ra, residual=ra)
+    assert_close(ra, dx_ref + r, TOL, case[0] + " +residual in place")
+
+
+WG_CASES = [CASES[i] for i in (0, 1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 19)]
+
+
+@pytest.mark.parametrize("case", WG_CASES, ids=[c[0] for c in WG_CASES])
+def test_conv_wgrad_matches_autograd(case, dev):
+    from vidsitu_amd import ops
+
+    x, w, k, s, p = _mk(case, seed=13)
+    w.requires_grad_()
+    y = F.conv3d(x, w, stride=s, padding=p)
+    dy = rb(torch.randn(y.shape, generator=torch.Generator().manual_seed(15)))
+    (dw_ref,) = torch.autograd.grad(y, w, dy)
+    dw = ops.conv_wgrad(to_act(dy, dev), to_act(x, dev), k, s, p)
+    assert tuple(dw.shape) == tuple(dw_ref.shape)
+    assert_close(dw, dw_ref, 5e-3, case[0])  # fp32 output, only operand rounding differs
+
+
+def test_wgrad_is_bitwise_reproducible(dev):
+    from vidsitu_amd import ops
+
+    x, w, k, s, p = _mk(CASES[6], seed=2)
+    dy = rb(torch.randn(F.conv3d(x, w, stride=s, padding=p).shape))
+    a = ops.conv_wgrad(to_act(dy, dev), to_act(x, dev), k, s, p)
+    b = ops.conv_wgrad(to_act(dy, dev), to_act(x, dev), k, s, p)
+    assert torch.equal(a, b)
+
+
+def test_pack_input_layout(dev):
+    from vidsitu_amd import ops
+
+    x = torch.randn(2, 3, 4, 6, 10)
+    y = ops.pack_input(x.to(dev))
+    assert tuple(y.shape) == (2, 8, 4, 6, 10)
+    assert torch.equal(y[:, :3].float().cpu(), rb(x))
+    assert float(y[:, 3:].float().abs().max()) == 0.0
+    y2 = ops.pack_input(x.to(dev).to(torch.bfloat16))
+    assert torch.equal(y2.float(), y.float())

@@ -1,0 +1,168 @@
+"""End-to-end parity of the HIP trunk / SFBase with the CPU fp32 oracle restatement
+(oracle/slowfast_ref.py) on identical weights and inputs, at sizes the oracle finishes in
+seconds.  bf16 activations between ~50 stacked layers: tolerances are on the relative L2
+error of whole tensors (written next to each assert), stage by stage so a failure localises."""
+import pytest
+import torch
+
+from gpu_utils import rel_err, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(arch, depth, width, frames, dev, seed=0):
+    from oracle.slowfast_ref import VideoTrunk as RefTrunk, default_sf_cfg, randomize_bn
+    from vidsitu_amd.trunk import VideoTrunk
+
+    torch.manual_seed(seed)
+    cfg = default_sf_cfg(arch, depth, width, frames)
+    ref = RefTrunk(cfg)
+    randomize_bn(ref, seed)
+    ours = VideoTrunk(cfg)
+    ours.load_state_dict(ref.state_dict(), strict=True)
+    return cfg, ref, ours.to(dev)
+
+
+def _ref_taps(ref, xs):
+    taps = {}
+    x = ref.s1(list(xs))
+    if ref.multi:
+        x = ref.s1_fuse(x)
+    taps["s1"] = [t.clone() for t in x]
+    for k in range(2, 6):
+        x = getattr(ref, f"s{k}")(x)
+        if ref.multi and k < 5:
+            x = getattr(ref, f"s{k}_fuse")(x)
+        if k == 2:
+            x = [getattr(ref, f"pathway{p}_pool")(x[p]) for p in range(ref.num_pathways)]
+        taps[f"s{k}"] = [t.clone() for t in x]
+    return x, taps
+
+
+def _inputs(cfg, n, hw, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    t = cfg.DATA.NUM_FRAMES
+    fast = torch.randn(n, 3, t, hw, hw, generator=g)
+    if cfg.MODEL.ARCH == "slowfast":
+        from oracle.slowfast_ref import slow_index
+
+        return [fast.index_select(2, slow_index(t, cfg.SLOWFAST.ALPHA)), fast]
+    return [fast]
+
+
+@pytest.mark.parametrize("arch,depth,width,frames,n,hw", [
+    ("i3d", "tiny", 8, 8, 2, 32),
+    ("i3d", 50, 64, 8, 1, 64),
+    ("slowfast", 50, 64, 32, 2, 64),
+])
+def test_trunk_eval_matches_oracle(arch, depth, width, frames, n, hw, dev):
+    cfg, ref, ours = _pair(arch, depth, width, frames, dev)
+    xs = _inputs(cfg, n, hw)
+    ref.eval()
+    ours.eval()
+    with torch.no_grad():
+        fr, taps_r = _ref_taps(ref, xs)
+        ours.debug_taps = {}
+        fo = ours.forward_features([x.to(dev) for x in xs])
+    report = []
+    for k in ["s1", "s2", "s3", "s4", "s5"]:
+        for p, (a, b) in enumerate(zip(ours.debug_taps[k], taps_r[k])):
+            assert tuple(a.shape) == tuple(b.shape), (k, p, a.shape, b.shape)
+            report.append((k, p, rel_l2(a, b), rel_err(a, b)))
+    print("\n".join(f"{k} pathway{p}: rel_l2 {l2:.3e} max {mx:.3e}" for k, p, l2, mx in report))
+    for k, p, l2, mx in report:
+        assert l2 < 3e-2, f"{k} pathway{p} rel_l2 {l2:.3e}"  # bf16 chain through <= 53 convs
+    for a, b in zip(fo, fr):
+        assert tuple(a.shape) == tuple(b.shape)  # logical NCDHW kept
+
+
+@pytest.mark.parametrize("arch,depth,width,frames,n,hw", [
+    ("i3d", "tiny", 8, 8, 2, 32),
+    ("slowfast", 50, 64, 32, 2, 64),
+])
+def test_trunk_train_step_matches_oracle(arch, depth, width, frames, n, hw, dev):
+    """Train-mode forward (batch statistics, running-stat update) and the hand-written
+    backward (parameter gradients) vs autograd on the oracle."""
+    cfg, ref, ours = _pair(arch, depth, width, frames, dev, seed=3)
+    xs = _inputs(cfg, n, hw, seed=4)
+    ref.train()
+    ours.train()
+    fr = ref.forward_features(xs)
+    g = torch.Generator().manual_seed(5)
+    dfeat = [torch.randn(f.shape, generator=g) / f.numel() ** 0.5 for f in fr]
+    sum((f * d).sum() for f, d in zip(fr, dfeat)).backward()
+    fo = ours.forward_features([x.to(dev) for x in xs])
+    for p, (a, b) in enumerate(zip(fo, fr)):
+        l2 = rel_l2(a, b)
+        print(f"train fwd pathway{p}: rel_l2 {l2:.3e}")
+        assert l2 < 3e-2
+    sum((f.float() * d.to(dev)).sum() for f, d in zip(fo, dfeat)).backward()
+    # running statistics (fp32 partial sums of fp32 accumulators)
+    sd_r, sd_o = ref.state_dict(), ours.state_dict()
+    worst = 0.0
+    for k in sd_r:
+        if "running" in k:
+            worst = max(worst, rel_err(sd_o[k], sd_r[k]))
+        if "num_batches_tracked" in k:
+            assert int(sd_o[k]) == int(sd_r[k]) == 1
+    print(f"running stats worst max-normalised err {worst:.3e}")
+    assert worst < 2e-2
+    # parameter gradients
+    pr, po = dict(ref.named_parameters()), dict(ours.named_parameters())
+    rows = []
+    for k in pr:
+        assert po[k].grad is not None, f"no gradient for {k}"
+        rows.append((rel_l2(po[k].grad, pr[k].grad), k))
+    rows.sort(reverse=True)
+    print("worst parameter-gradient rel_l2:\n" + "\n".join(f"  {e:.3e} {k}" for e, k in rows[:12]))
+    med = sorted(e for e, _ in rows)[len(rows) // 2]
+    print(f"median {med:.3e}")
+    assert med < 5e-2, "median parameter-gradient error (bf16 backward chain)"
+    assert rows[0][0] < 2.5e-1, f"worst parameter gradient {rows[0]}"
+
+
+def test_sfbase_logits_and_top5_indices(dev):
+    """SFBase end to end (mdl_sf_base.py:213-216) + EvalB top-5 (evl_vsitu.py:39-42): logits
+    within tolerance of the oracle and verb indices bit-exact wherever the oracle's own
+    top-5 margins exceed that tolerance (otherwise index equality is ill-posed)."""
+    from oracle.slowfast_ref import SFBaseRef, randomize_bn
+    from vidsitu_amd import synth_data
+    from vidsitu_amd.evl_vsitu import EvalB
+    from vidsitu_amd.extended_config import get_cfg
+    from vidsitu_amd.mdl_selector import get_mdl_loss_eval
+
+    cfg = get_cfg({"mdl.sf_mdl_name": "i3d_tiny", "synth.num_verbs": 97})
+    comm = synth_data.make_comm(cfg)
+    torch.manual_seed(0)
+    sel = get_mdl_loss_eval(cfg)
+    mdl = sel["mdl"](cfg=cfg, comm=comm)
+    ref = SFBaseRef(cfg.sf_mdl, 97)
+    randomize_bn(ref, 1)
+    with torch.no_grad():
+        for lin in (ref.proj_head[0], ref.proj_head[2]):
+            lin.weight.normal_(0, 0.2)
+    mdl.load_state_dict(ref.state_dict(), strict=True)
+    mdl = mdl.to(dev).eval()
+    ref.eval()
+    batch = synth_data.synth_batch(cfg, comm, bs=2, n_ev=5, crop=32)
+    with torch.no_grad():
+        lr = ref([batch["frms_ev_fast_tensor"].flatten(0, 1)]).view(2, 5, -1)
+        gbatch = {k: v.to(dev) for k, v in batch.items()}
+        lo = mdl(gbatch)["mdl_out"]
+    assert tuple(lo.shape) == (2, 5, 97)
+    err = float((lo.cpu() - lr).abs().max())
+    print(f"logits max abs err {err:.3e} (max |logit| {float(lr.abs().max()):.3f})")
+    assert err < 2e-2 * float(lr.abs().max())
+    out = EvalB(cfg, comm, dev).forward_one_batch(mdl, gbatch)
+    srt, ix = lr.sort(dim=-1, descending=True)
+    for b in range(2):
+        for e in range(5):
+            margins = (srt[b, e, :5] - srt[b, e, 1:6])
+            if float(margins.min()) > 2.5 * err:
+                assert out[b]["pred_ixs_ev"][e] == ix[b, e, :5].tolist()
+    # the loss / backward path of the plugin surface runs end to end
+    mdl.train()
+    loss = sel["loss"](cfg, comm)(mdl(gbatch), gbatch)["loss"]
+    loss.backward()
+    assert torch.isfinite(loss) and mdl.proj_head[0].weight.grad is not None
+    assert mdl.sf_mdl.s1.pathway0_stem.conv.weight.grad is not None

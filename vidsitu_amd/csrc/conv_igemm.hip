@@ -485,10 +485,11 @@ extern "C" int vs_conv_fwd(const void* x, const void* w, void* y, const vs_conv_
 }
 
 extern "C" int vs_conv_dgrad(const void* dy, const void* wt, void* dx, const vs_conv_desc* d,
-                             void* stream) {
+                             const void* residual, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   VS_CHECK_ARG(dy && wt && dx, "null tensor");
+  VS_CHECK_ARG(!(d->flags & VS_CONV_RESIDUAL) || residual, "RESIDUAL needs residual");
   const int shT = ilog2_exact(d->sT), shH = ilog2_exact(d->sH), shW = ilog2_exact(d->sW);
   VS_CHECK_ARG(shT >= 0 && shH >= 0 && shW >= 0, "strides must be powers of two");
   ConvP p;
@@ -496,7 +497,7 @@ extern "C" int vs_conv_dgrad(const void* dy, const void* wt, void* dx, const vs_
   p.w = (const uint16_t*)wt;
   p.y = (uint16_t*)dx;
   p.scale = p.shift = nullptr;
-  p.res = nullptr;
+  p.res = (const uint16_t*)residual;
   p.stats = nullptr;
   p.M = d->N * d->Ti * d->Hi * d->Wi;
   p.Ncols = d->Cin;
@@ -511,8 +512,8 @@ extern "C" int vs_conv_dgrad(const void* dy, const void* wt, void* dx, const vs_
   p.tmul = -1;
   p.shT = shT; p.shH = shH; p.shW = shW;
   p.y_ld = d->x_ld;
-  p.res_ld = 0;
-  p.flags = d->flags & VS_CONV_NAIVE;
+  p.res_ld = d->res_ld;
+  p.flags = d->flags & (VS_CONV_NAIVE | VS_CONV_RESIDUAL);
   p.tilesM = p.tilesN = 0;
   const bool unit_stride = d->sT == 1 && d->sH == 1 && d->sW == 1;
   const bool pointwise =

@@ -1,0 +1,59 @@
+"""Verb-prediction evaluation step: softmax -> descending sort -> top-5.
+
+Mirrors `EvalB.forward_one_batch` (`vidsitu_code/evl_vsitu.py:39-75`): this is the
+output BASELINE calls "bit-exact event/verb indices".  The softmax + top-k runs in
+one HIP kernel (`vs_softmax_topk`; ties resolve to the lowest index); the
+per-rank pickle merge and text metrics of the reference are out of scope.
+"""
+import torch
+from torch import nn
+
+from . import ops
+
+
+class EvalB(nn.Module):
+    def __init__(self, cfg, comm, device=None):
+        super().__init__()
+        self.cfg = cfg
+        self.full_cfg = cfg
+        self.comm = comm
+        self.device = device
+        self.met_keys = ["Per_Ev_Top_1", "Per_Ev_Top_5"]
+        self.topk_save = 5
+
+    @torch.no_grad()
+    def forward_one_batch(self, mdl, inp):
+        mdl_out = mdl(inp)["mdl_out"]  # [B, E, V]
+        B, E, V = mdl_out.shape
+        probs, idx = ops.softmax_topk(mdl_out.reshape(B * E, V).float(), self.topk_save)
+        probs = probs.view(B, E, -1).tolist()
+        idx = idx.view(B, E, -1).tolist()
+        symbols = getattr(self.comm.vb_id_vocab, "symbols", self.comm.vb_id_vocab)
+        out = []
+        for b, ann_idx in enumerate(inp["vseg_idx"].tolist()):
+            out.append({
+                "pred_vbs_ev": [[symbols[i] for i in ev] for ev in idx[b]],
+                "pred_scores_ev": probs[b],
+                "pred_ixs_ev": idx[b],
+                "ann_idx": ann_idx,
+            })
+        return out
+
+    @torch.no_grad()
+    def forward(self, model, loss_fn, dl, dl_name="valid", rank=0, pred_path=None, mb=None):
+        """Top-1 / top-5 per-event accuracy + mean loss over `dl` (a list of batches)."""
+        model.eval()
+        n, c1, c5, loss_sum, nb = 0, 0, 0, 0.0, 0
+        for batch in dl:
+            out = model(batch)
+            loss_sum += float(loss_fn(out, batch)["loss"])
+            nb += 1
+            B, E, V = out["mdl_out"].shape
+            _, idx = ops.softmax_topk(out["mdl_out"].reshape(B * E, V).float(), self.topk_save)
+            lab = batch["label_tensor"].reshape(-1, 1)
+            hit = idx == lab
+            n += lab.numel()
+            c1 += int(hit[:, 0].sum())
+            c5 += int(hit.any(dim=1).sum())
+        return ({"loss": loss_sum / max(nb, 1)},
+                {"Per_Ev_Top_1": c1 / max(n, 1), "Per_Ev_Top_5": c5 / max(n, 1)})

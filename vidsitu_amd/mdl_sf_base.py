@@ -1,0 +1,304 @@
+"""Host-side mirror of `vidsitu_code/mdl_sf_base.py` for the hot path, on the HIP
+kernels: `SlowFast_FeatModel` / `ResNet_FeatModel` (:20-62), `ResNetBasicHead_Trimmed`
+(:65-113), `SFBase` (:116-216), `LossB` (:219-231), `LossLambda` (:234-243),
+`TxEncoderNew` / `TxEncoder()` (:341-432), `get_head_dim` (:751-760) and the
+encoder half of `SFPreFeats_TxEncDec` (:793-832).
+
+Same constructor contracts (`mdl(cfg=cfg, comm=comm)`, `loss(cfg, comm)`), same
+attribute names (`sf_mdl`, `head`, `proj_head`, `vid_feat_encoder`,
+`vid_feat_txenc`), same state_dict keys, same input dict
+(`frms_ev_fast_tensor`, `frms_ev_slow_tensor`, `vseg_idx`, `label_tensor`).
+The one deliberate generalisation: the number of events per video is read from
+the input tensor's second axis instead of the literal 5 (`:209`), so the
+BASELINE "8 clips" batch is expressible.
+"""
+from collections import namedtuple
+from typing import Dict
+
+import torch
+from torch import nn
+
+from . import ops
+from .trunk import VideoTrunk
+from .transformer_code import Transformer as TxCodeEnc, LinearFn
+
+EncoderOut = namedtuple(
+    "EncoderOut",
+    ["encoder_out", "encoder_padding_mask", "encoder_embedding", "encoder_states", "src_tokens",
+     "src_lengths"],
+)
+
+
+def combine_first_ax(t, keepdim=False):
+    """`utils/misc_utils.py:1-5`."""
+    s = t.shape
+    if keepdim:
+        return t.view(1, s[0] * s[1], *s[2:])
+    return t.view(s[0] * s[1], *s[2:])
+
+
+class SlowFast_FeatModel(VideoTrunk):
+    """mdl_sf_base.py:20-42 (two pathways)."""
+
+
+class ResNet_FeatModel(VideoTrunk):
+    """mdl_sf_base.py:45-62 (c2d / i3d / slow)."""
+
+
+class _AvgPoolCatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *feats):
+        ctx.shapes = [tuple(f.shape) for f in feats]
+        return ops.avgpool_cat(list(feats))
+
+    @staticmethod
+    def backward(ctx, dout):
+        return tuple(ops.avgpool_cat_bwd(dout.float(), ctx.shapes))
+
+
+class ResNetBasicHead_Trimmed(nn.Module):
+    """AdaptiveAvgPool3d((1,1,1)) per pathway + channel concat (mdl_sf_base.py:65-113)."""
+
+    def __init__(self, dim_in, pool_size):
+        super().__init__()
+        assert len({len(pool_size), len(dim_in)}) == 1, "pathway dimensions are not consistent."
+        assert all(p is None for p in pool_size), "only the adaptive (None) pool is on the hot path"
+        self.num_pathways = len(pool_size)
+        self.dim_in = dim_in
+
+    def forward(self, inputs):
+        assert len(inputs) == self.num_pathways, \
+            "Input tensor does not contain {} pathway".format(self.num_pathways)
+        feats = [ops_act(f) for f in inputs]
+        out = _AvgPoolCatFn.apply(*feats)  # [N, sum C] fp32
+        return out.view(out.shape[0], out.shape[1], 1, 1, 1)
+
+
+def ops_act(t):
+    from .trunk import ops_ensure_act
+    return ops_ensure_act(t)
+
+
+class HipMLP(nn.Sequential):
+    """nn.Sequential(Linear, ReLU, Linear) parameter layout (keys `0.*`, `2.*`), HIP compute."""
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.Linear):
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                x = LinearFn.apply(x, m.weight, m.bias, relu)
+                i += 2 if relu else 1
+            else:
+                raise NotImplementedError(type(m))
+        return x
+
+
+class _XentFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        loss, dlogits = ops.softmax_xent(logits, labels, want_grad=True)
+        ctx.save_for_backward(dlogits)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * dloss, None
+
+
+def hip_cross_entropy(logits, labels):
+    """mean F.cross_entropy (mdl_sf_base.py:230) on vs_softmax_xent."""
+    return _XentFn.apply(logits.float().contiguous(), labels)
+
+
+class SFBase(nn.Module):
+    def __init__(self, cfg, comm):
+        super().__init__()
+        self.full_cfg = cfg
+        self.sf_cfg = cfg.sf_mdl
+        self.cfg = cfg.mdl
+        self.comm = comm
+        self.build_model()
+
+    def build_model(self):
+        self.build_sf_model(self.sf_cfg)
+        self.build_head(self.sf_cfg)
+        self.build_projection_head(self.sf_cfg)
+
+    def build_sf_model(self, cfg):
+        mdl_name = cfg.MODEL.MODEL_NAME
+        if mdl_name == "SlowFast":
+            mdl = SlowFast_FeatModel(cfg)
+        elif mdl_name == "ResNet":
+            mdl = ResNet_FeatModel(cfg)
+        else:
+            raise NotImplementedError
+        self.sf_mdl = mdl
+
+    def build_head(self, cfg):
+        dims = self.sf_mdl.dim_out
+        if self.comm.path_type == "multi":
+            assert dims == [cfg.RESNET.WIDTH_PER_GROUP * 32,
+                            cfg.RESNET.WIDTH_PER_GROUP * 32 // cfg.SLOWFAST.BETA_INV]
+            self.head = ResNetBasicHead_Trimmed(dim_in=dims, pool_size=[None, None])
+        elif self.comm.path_type == "single":
+            self.head = ResNetBasicHead_Trimmed(dim_in=dims, pool_size=[None])
+
+    def build_projection_head(self, cfg, out_dim=None):
+        if out_dim is None:
+            out_dim = len(self.comm.vb_id_vocab)
+        din = sum(self.head.dim_in)
+        self.proj_head = HipMLP(nn.Linear(din, din // 2), nn.ReLU(), nn.Linear(din // 2, out_dim))
+
+    def get_feats(self, inp):
+        if self.comm.path_type == "multi":
+            return [combine_first_ax(inp["frms_ev_slow_tensor"]),
+                    combine_first_ax(inp["frms_ev_fast_tensor"])]
+        elif self.comm.path_type == "single":
+            return [combine_first_ax(inp["frms_ev_fast_tensor"])]
+        raise NotImplementedError
+
+    def forward_encoder(self, inp):
+        feats_used = self.get_feats(inp)
+        feat_out = self.sf_mdl.forward_features(feats_used)
+        assert len(feat_out) == len(feats_used)
+        return feat_out
+
+    def forward_decoder(self, enc_out, inp):
+        head_out = self.head(enc_out)
+        head_out = head_out.permute((0, 2, 3, 4, 1))  # (B, C, T, H, W) -> (B, T, H, W, C)
+        proj_out = self.proj_head(head_out)
+        B = len(inp["vseg_idx"])
+        n_ev = inp["frms_ev_fast_tensor"].shape[1]
+        out = proj_out.view(B, n_ev, -1)
+        assert out.size(-1) == len(self.comm.vb_id_vocab)
+        return out
+
+    def forward(self, inp: Dict):
+        feat_out = self.forward_encoder(inp)
+        mdl_out = self.forward_decoder(feat_out, inp)
+        return {"mdl_out": mdl_out}
+
+
+class LossB(nn.Module):
+    def __init__(self, cfg, comm):
+        super().__init__()
+        self.cfg = cfg
+        self.comm = comm
+        self.loss_keys = ["loss"]
+
+    def forward(self, mdl_out, inp):
+        labels_c1 = combine_first_ax(inp["label_tensor"])
+        mdl_preds_c1 = combine_first_ax(mdl_out["mdl_out"])
+        return {"loss": hip_cross_entropy(mdl_preds_c1, labels_c1)}
+
+
+class LossLambda(nn.Module):
+    def __init__(self, cfg, comm):
+        super().__init__()
+        self.cfg = cfg
+        self.comm = comm
+        self.loss_keys = ["loss"]
+
+    def forward(self, mdl_out, inp):
+        assert "loss" in mdl_out
+        return {"loss": mdl_out["loss"]}
+
+
+class TxEncoderNew(TxCodeEnc):
+    """mdl_sf_base.py:341-381."""
+
+    def __init__(self, cfg, comm):
+        self.full_cfg = cfg
+        self.comm = comm
+        args = cfg.tx_dec
+        super().__init__(d_model=1024, n_vocab_src=0, vocab_trg=0, d_hidden=1024,
+                         n_layers=args.encoder_layers, n_heads=args.encoder_attention_heads,
+                         drop_ratio=args.dropout, pe=False)
+
+    def forward(self, src_tokens=None, src_lengths=None, return_all_hiddens=False,
+                token_embeddings=None):
+        assert token_embeddings is not None
+        enc_out = self.encoder(token_embeddings)[-1]
+        return EncoderOut(encoder_out=enc_out.transpose(0, 1).contiguous(),
+                          encoder_padding_mask=None, encoder_embedding=None, encoder_states=None,
+                          src_tokens=None, src_lengths=None)
+
+
+def TxEncoder(cfg, comm):
+    if cfg.mdl.tx_enc_type == "new":
+        return TxEncoderNew(cfg, comm)
+    # "old" / "new_conc" are the fairseq TransformerEncoder
+    raise NotImplementedError(f"tx_enc_type={cfg.mdl.tx_enc_type} is outside the hot path")
+
+
+def get_head_dim(full_cfg) -> int:
+    d = full_cfg.ds.vsitu.vsit_frm_feats_dir
+    if "i3d" in d:
+        return 2048
+    elif ("slow_fast" in d) or ("sfast" in d):
+        return 2304
+    raise NotImplementedError
+
+
+class SFPreFeats_TxEncDec(nn.Module):
+    """Encoder half (mdl_sf_base.py:793-832): pre-extracted [B,5,2304] features ->
+    vid_feat_encoder -> TxEncoderNew -> EncoderOut [1, 5B, 1024].  The fairseq / GPT-2
+    decoder half is SURVEY.md section 8(f) rows f2/f3 (not built yet)."""
+
+    def __init__(self, cfg, comm):
+        super().__init__()
+        self.full_cfg = cfg
+        self.cfg = cfg.mdl
+        self.comm = comm
+        head_dim = get_head_dim(self.full_cfg)
+        self.vid_feat_encoder = HipMLP(nn.Linear(head_dim, 1024), nn.ReLU(), nn.Linear(1024, 1024))
+        self.use_encoder = True
+        self.vid_feat_txenc = TxEncoder(self.full_cfg, self.comm)
+
+    def forward_encoder(self, inp):
+        frm_feats = inp["frm_feats"]
+        B = inp["vseg_idx"].size(0)
+        n_ev = frm_feats.size(1)
+        out = self.vid_feat_encoder(frm_feats.float())
+        out = out.view(B, n_ev, -1)
+        tx_out = self.vid_feat_txenc(src_tokens=out[..., 0], src_lengths=None,
+                                     return_all_hiddens=True, token_embeddings=out)
+        enc_out_batch1 = tx_out.encoder_out.transpose(0, 1).contiguous()
+        enc_out3 = enc_out_batch1.view(B * n_ev, 1, -1).transpose(0, 1).contiguous()
+        return EncoderOut(encoder_out=enc_out3, encoder_padding_mask=None, encoder_embedding=None,
+                          encoder_states=None, src_tokens=None, src_lengths=None)
+
+    def forward(self, inp):
+        raise NotImplementedError("decoder half: SURVEY.md section 8(f) f2/f3")
+
+
+class SFBase_TxEnc(SFBase):
+    """BASELINE config 3 ("SlowFast-R50 + 6-layer TxEnc verb-pred"), a composition the
+    reference does not hold as one class: SFBase trunk + head ->
+    `vid_feat_encoder` (SFPreFeats_TxEncDec, :798-800) -> `TxEncoderNew` over the events of
+    each video -> per-event Linear(1024, V).  Every piece is parity-tested on its own."""
+
+    def build_projection_head(self, cfg, out_dim=None):
+        if out_dim is None:
+            out_dim = len(self.comm.vb_id_vocab)
+        din = sum(self.head.dim_in)
+        self.vid_feat_encoder = HipMLP(nn.Linear(din, 1024), nn.ReLU(), nn.Linear(1024, 1024))
+        self.vid_feat_txenc = TxEncoder(self.full_cfg, self.comm)
+        self.proj_head = HipMLP(nn.Linear(1024, out_dim))
+
+    def forward_decoder(self, enc_out, inp):
+        head_out = self.head(enc_out)  # [N, C, 1, 1, 1]
+        B = len(inp["vseg_idx"])
+        n_ev = inp["frms_ev_fast_tensor"].shape[1]
+        feats = head_out.view(B, n_ev, -1)
+        tok = self.vid_feat_encoder(feats)
+        tx = self.vid_feat_txenc(src_tokens=tok[..., 0], src_lengths=None,
+                                 return_all_hiddens=True, token_embeddings=tok)
+        ev = tx.encoder_out.transpose(0, 1)  # [B, n_ev, 1024]
+        out = self.proj_head(ev.contiguous())
+        assert out.size(-1) == len(self.comm.vb_id_vocab)
+        return out

@@ -1,0 +1,417 @@
+"""Tensor-level wrappers over the C-ABI (include/vidsitu_hip.h).
+
+PyTorch is used for device memory and streams only; every function here ends in
+a HIP kernel of libvidsitu_hip.so and raises if the library or a GPU tensor is
+missing -- there is no CPU / eager fallback on the product path.
+
+Activations: bf16 tensors of logical shape [N, C, T, H, W] whose memory is
+channels-last (NDHWC), optionally a channel slice of a wider buffer (row pitch
+`ld` = the buffer's channel count), which is how the slow/fast lateral concat
+(`FuseFastToSlow`) is done without a copy.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (  # noqa: F401  (re-exported flags)
+    VS_CONV_AFFINE,
+    VS_CONV_NAIVE,
+    VS_CONV_RELU,
+    VS_CONV_RESIDUAL,
+    VS_CONV_STATS,
+    ConvDesc,
+)
+
+BF16 = torch.bfloat16
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.VsError("HIP op called with a non-GPU tensor (no CPU fallback exists)")
+    return C.c_void_p(t.data_ptr())
+
+
+# ----------------------------------------------------------------------------
+# activation helpers
+# ----------------------------------------------------------------------------
+def new_act(n, c, t, h, w, device, ctot=None, c_off=0, dtype=BF16, zero=False):
+    """[n,c,t,h,w] channels-last activation; with ctot, a slice of a wider buffer."""
+    ctot = c if ctot is None else ctot
+    alloc = torch.zeros if zero else torch.empty
+    buf = alloc((n, t, h, w, ctot), dtype=dtype, device=device)
+    return buf.permute(0, 4, 1, 2, 3)[:, c_off : c_off + c]
+
+
+def channel_slice(x, c_off, c):
+    return x[:, c_off : c_off + c]
+
+
+def act_ld(x):
+    """Row pitch (elements) of a channels-last activation; validates the layout."""
+    n, c, t, h, w = x.shape
+    s = x.stride()
+    ld = s[4] if w > 1 else (s[3] if h > 1 else (s[2] if t > 1 else s[0]))
+    ok = (c == 1 or s[1] == 1) and ld >= c
+    ok = ok and (w == 1 or s[4] == ld) and (h == 1 or s[3] == w * ld)
+    ok = ok and (t == 1 or s[2] == h * w * ld) and (n == 1 or s[0] == t * h * w * ld)
+    if not ok or x.dtype != BF16:
+        raise _lib.VsError(f"not a bf16 channels-last activation: shape {tuple(x.shape)} stride {s}")
+    if ld % 8 or (x.storage_offset() % 8):
+        raise _lib.VsError("activation pitch / channel offset must be multiples of 8")
+    return ld
+
+
+def act_rows(x):
+    n, c, t, h, w = x.shape
+    return n * t * h * w
+
+
+def pack_input(x, cpad=8):
+    """NCDHW f32/bf16 (any strides are made dense first) -> NDHWC bf16, C padded."""
+    x = x.contiguous()
+    n, c, t, h, w = x.shape
+    y = new_act(n, cpad, t, h, w, x.device)
+    _lib.call(
+        "vs_pack_input", _ptr(x), int(x.dtype == BF16), _ptr(y), n, c, t, h, w, cpad, _stream()
+    )
+    return y
+
+
+# ----------------------------------------------------------------------------
+# convolution
+# ----------------------------------------------------------------------------
+def conv_out_shape(xs, cout, k, s, p):
+    n, _, t, h, w = xs
+    return (
+        n,
+        cout,
+        (t + 2 * p[0] - k[0]) // s[0] + 1,
+        (h + 2 * p[1] - k[1]) // s[1] + 1,
+        (w + 2 * p[2] - k[2]) // s[2] + 1,
+    )
+
+
+def make_desc(xs, x_ld, ys, y_ld, k, s, p, flags=0, res_ld=0):
+    d = ConvDesc()
+    d.N, d.Cin, d.Ti, d.Hi, d.Wi = xs[0], xs[1], xs[2], xs[3], xs[4]
+    d.Cout, d.To, d.Ho, d.Wo = ys[1], ys[2], ys[3], ys[4]
+    d.kT, d.kH, d.kW = k
+    d.sT, d.sH, d.sW = s
+    d.pT, d.pH, d.pW = p
+    d.x_ld, d.y_ld, d.res_ld, d.flags = x_ld, y_ld, res_ld, flags
+    return d
+
+
+def check_weight(w, cout, cin, k):
+    """w: bf16 [Cout,Cin,kT,kH,kW] whose memory is [Cout][kT][kH][kW][Cin]."""
+    if tuple(w.shape) != (cout, cin, *k) or w.dtype != BF16:
+        raise _lib.VsError(f"weight shape/dtype mismatch {tuple(w.shape)} {w.dtype}")
+    if not w.permute(0, 2, 3, 4, 1).is_contiguous():
+        raise _lib.VsError("conv weight must be channels-last ([Cout][taps][Cin] in memory)")
+
+
+def conv_fwd(x, w, k, s, p, out=None, scale=None, shift=None, residual=None, relu=False,
+             stats=False, naive=False):
+    """y = conv3d(x, w) [*scale+shift] [+residual] [relu]; optional BN-stat partials.
+    Returns (y, partials|None)."""
+    cout = w.shape[0]
+    ys = conv_out_shape(x.shape, cout, k, s, p)
+    if out is None:
+        out = new_act(*ys, device=x.device)
+    elif tuple(out.shape) != ys:
+        raise _lib.VsError(f"conv out shape {tuple(out.shape)} != {ys}")
+    check_weight(w, cout, x.shape[1], k)
+    flags = 0
+    if scale is not None:
+        flags |= VS_CONV_AFFINE
+    if residual is not None:
+        flags |= VS_CONV_RESIDUAL
+        if tuple(residual.shape) != ys:
+            raise _lib.VsError("residual shape mismatch")
+    if relu:
+        flags |= VS_CONV_RELU
+    if stats:
+        flags |= VS_CONV_STATS
+    if naive:
+        flags |= VS_CONV_NAIVE
+    d = make_desc(x.shape, act_ld(x), ys, act_ld(out), k, s, p, flags,
+                  act_ld(residual) if residual is not None else 0)
+    partials = None
+    if stats:
+        rows = _lib.load().vs_conv_stats_rows(C.byref(d))
+        partials = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
+    _lib.call("vs_conv_fwd", _ptr(x), _ptr(w), _ptr(out), C.byref(d), _ptr(scale), _ptr(shift),
+              _ptr(residual), _ptr(partials), None, None, _stream())
+    return out, partials
+
+
+def weight_transpose(w):
+    """[Cout][taps][Cin] -> [Cin][taps][Cout] bf16 (logical [Cin,Cout,kT,kH,kW])."""
+    cout, cin, kt, kh, kw = w.shape
+    wt = torch.empty((cin, kt, kh, kw, cout), dtype=BF16, device=w.device).permute(0, 4, 1, 2, 3)
+    _lib.call("vs_weight_transpose", _ptr(w), _ptr(wt), cout, kt * kh * kw, cin, _stream())
+    return wt
+
+
+def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False):
+    """dx[xs] = conv_transpose(dy, w) (+ residual).  wt from weight_transpose."""
+    if out is None:
+        out = new_act(*xs, device=dy.device)
+    flags = (VS_CONV_NAIVE if naive else 0) | (VS_CONV_RESIDUAL if residual is not None else 0)
+    d = make_desc(xs, act_ld(out), dy.shape, act_ld(dy), k, s, p, flags,
+                  act_ld(residual) if residual is not None else 0)
+    _lib.call("vs_conv_dgrad", _ptr(dy), _ptr(wt), _ptr(out), C.byref(d), _ptr(residual), _stream())
+    return out
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def conv_wgrad(dy, x, k, s, p, out=None):
+    """dw fp32, logical [Cout,Cin,kT,kH,kW], memory [Cout][taps][Cin]."""
+    cout, cin = dy.shape[1], x.shape[1]
+    if out is None:
+        out = torch.empty((cout, *k, cin), dtype=torch.float32, device=x.device).permute(0, 4, 1, 2, 3)
+    d = make_desc(x.shape, act_ld(x), dy.shape, act_ld(dy), k, s, p)
+    need = _lib.load().vs_conv_wgrad_workspace_bytes(C.byref(d))
+    ws = _workspace(need, x.device) if need else None
+    _lib.call("vs_conv_wgrad", _ptr(dy), _ptr(x), _ptr(out), C.byref(d), None, None, _ptr(ws),
+              C.c_size_t(ws.numel() if ws is not None else 0), _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------
+# batch norm
+# ----------------------------------------------------------------------------
+def bn_finalize(partials, count, gamma, beta, running_mean, running_var, momentum, eps, train):
+    c = gamma.numel()
+    dev = gamma.device
+    scale = torch.empty(c, dtype=torch.float32, device=dev)
+    shift = torch.empty(c, dtype=torch.float32, device=dev)
+    mean = torch.empty(c, dtype=torch.float32, device=dev)
+    invstd = torch.empty(c, dtype=torch.float32, device=dev)
+    nparts = partials.shape[0] if train else 0
+    _lib.call("vs_bn_finalize", _ptr(partials) if train else None, nparts, float(count),
+              _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), float(momentum),
+              float(eps), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), c, _stream())
+    return scale, shift, mean, invstd
+
+
+def bn_apply(y, scale, shift, residual=None, relu=True, out=None):
+    if out is None:
+        out = new_act(*y.shape, device=y.device)
+    _lib.call("vs_bn_apply", _ptr(y), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out),
+              act_rows(y), y.shape[1], act_ld(y), act_ld(residual) if residual is not None else 0,
+              act_ld(out), int(relu), _stream())
+    return out
+
+
+def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres, dy_out=None):
+    """Returns (dy, dres|None, dgamma, dbeta)."""
+    rows, c = act_rows(y), y.shape[1]
+    dev = y.device
+    nblk = _lib.load().vs_bn_bwd_reduce_rows(rows, c)
+    if nblk <= 0:
+        raise _lib.VsError("bn_bwd: unsupported channel count")
+    partial = torch.empty((nblk, 2, c), dtype=torch.float32, device=dev)
+    zz = z if relu else None
+    _lib.call("vs_bn_bwd_reduce", _ptr(dz), _ptr(zz), _ptr(y), _ptr(mean), _ptr(invstd),
+              _ptr(partial), rows, c, act_ld(dz), act_ld(z) if relu else 0, act_ld(y), int(relu),
+              _stream())
+    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+    _lib.call("vs_bn_bwd_finalize", _ptr(partial), nblk, _ptr(dgamma), _ptr(dbeta), c, _stream())
+    dy = new_act(*y.shape, device=dev) if dy_out is None else dy_out
+    dres = new_act(*y.shape, device=dev) if want_dres else None
+    _lib.call("vs_bn_bwd_apply", _ptr(dz), _ptr(zz), _ptr(y), _ptr(mean), _ptr(invstd),
+              _ptr(gamma), _ptr(dgamma), _ptr(dbeta), _ptr(dy), _ptr(dres), rows, c, act_ld(dz),
+              act_ld(z) if relu else 0, act_ld(y), act_ld(dy), act_ld(dres) if want_dres else 0,
+              int(relu), _stream())
+    return dy, dres, dgamma, dbeta
+
+
+# ----------------------------------------------------------------------------
+# pooling
+# ----------------------------------------------------------------------------
+def maxpool_hw(x, out=None, want_idx=False):
+    n, c, t, h, w = x.shape
+    ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    if out is None:
+        out = new_act(n, c, t, ho, wo, x.device)
+    idx = torch.empty((n, t, ho, wo, c), dtype=torch.uint8, device=x.device) if want_idx else None
+    _lib.call("vs_maxpool_hw3s2_fwd", _ptr(x), _ptr(out), _ptr(idx), n, t, h, w, c, act_ld(x),
+              act_ld(out), _stream())
+    return out, idx
+
+
+def maxpool_hw_bwd(dy, idx, xs):
+    n, c, t, h, w = xs
+    dx = new_act(n, c, t, h, w, dy.device)
+    _lib.call("vs_maxpool_hw3s2_bwd", _ptr(dy), _ptr(idx), _ptr(dx), n, t, h, w, c, act_ld(dy),
+              act_ld(dx), _stream())
+    return dx
+
+
+def maxpool_t(x, kt, want_idx=False):
+    n, c, t, h, w = x.shape
+    if act_ld(x) != c:
+        raise _lib.VsError("maxpool_t needs a dense activation")
+    out = new_act(n, c, t // kt, h, w, x.device)
+    idx = torch.empty((n, t // kt, h, w, c), dtype=torch.uint8, device=x.device) if want_idx else None
+    _lib.call("vs_maxpool_t_fwd", _ptr(x), _ptr(out), _ptr(idx), n, t, h * w, c, kt, _stream())
+    return out, idx
+
+
+def maxpool_t_bwd(dy, idx, xs, kt):
+    n, c, t, h, w = xs
+    dx = new_act(n, c, t, h, w, dy.device)
+    _lib.call("vs_maxpool_t_bwd", _ptr(dy), _ptr(idx), _ptr(dx), n, t, h * w, c, kt, _stream())
+    return dx
+
+
+def avgpool_cat(feats):
+    """AdaptiveAvgPool3d(1) per pathway + channel concat -> fp32 [N, sum C]."""
+    n = feats[0].shape[0]
+    ctot = sum(f.shape[1] for f in feats)
+    out = torch.empty((n, ctot), dtype=torch.float32, device=feats[0].device)
+    off = 0
+    for f in feats:
+        _, c, t, h, w = f.shape
+        _lib.call("vs_avgpool_fwd", _ptr(f), _ptr(out), n, t * h * w, c, act_ld(f), ctot, off,
+                  _stream())
+        off += c
+    return out
+
+
+def avgpool_cat_bwd(dout, shapes):
+    """dout fp32 [N, sum C] -> list of bf16 activations of `shapes`."""
+    outs, off = [], 0
+    dout = dout.contiguous()
+    for (n, c, t, h, w) in shapes:
+        dx = new_act(n, c, t, h, w, dout.device)
+        _lib.call("vs_avgpool_bwd", _ptr(dout), _ptr(dx), n, t * h * w, c, act_ld(dx),
+                  dout.shape[1], off, _stream())
+        outs.append(dx)
+        off += c
+    return outs
+
+
+# ----------------------------------------------------------------------------
+# fp32 small ops (TxEncoder, heads, loss, optimizer)
+# ----------------------------------------------------------------------------
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise _lib.VsError("fp32 tensor expected")
+    return t.contiguous()
+
+
+def linear_fwd(x, w, b=None, relu=False):
+    x, w = _f32c(x), _f32c(w)
+    m, k = x.shape
+    n = w.shape[0]
+    y = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    _lib.call("vs_linear_fwd", _ptr(x), _ptr(w), _ptr(b), _ptr(y), m, n, k, int(relu), _stream())
+    return y
+
+
+def linear_bwd(dy, x, w, need_dx=True, has_bias=True):
+    dy, x, w = _f32c(dy), _f32c(x), _f32c(w)
+    m, n = dy.shape
+    k = x.shape[1]
+    dx = None
+    if need_dx:
+        wt = torch.empty((k, n), dtype=torch.float32, device=x.device)
+        _lib.call("vs_transpose_f32", _ptr(w), _ptr(wt), n, k, _stream())
+        dx = torch.empty((m, k), dtype=torch.float32, device=x.device)
+        _lib.call("vs_linear_bwd_data", _ptr(dy), _ptr(wt), _ptr(dx), m, n, k, _stream())
+    dw = torch.empty((n, k), dtype=torch.float32, device=x.device)
+    db = torch.empty(n, dtype=torch.float32, device=x.device) if has_bias else None
+    _lib.call("vs_linear_bwd_weight", _ptr(dy), _ptr(x), _ptr(dw), _ptr(db), m, n, k, _stream())
+    return dx, dw, db
+
+
+def attn_small_fwd(q, k, v, n_heads, scale):
+    q, k, v = _f32c(q), _f32c(k), _f32c(v)
+    b, l, d = q.shape
+    o = torch.empty_like(q)
+    probs = torch.empty((b, n_heads, l, l), dtype=torch.float32, device=q.device)
+    _lib.call("vs_attn_small_fwd", _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(probs), b, l, n_heads,
+              d // n_heads, float(scale), _stream())
+    return o, probs
+
+
+def attn_small_bwd(q, k, v, probs, do, n_heads, scale):
+    do = _f32c(do)
+    b, l, d = q.shape
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    _lib.call("vs_attn_small_bwd", _ptr(q), _ptr(k), _ptr(v), _ptr(probs), _ptr(do), _ptr(dq),
+              _ptr(dk), _ptr(dv), b, l, n_heads, d // n_heads, float(scale), _stream())
+    return dq, dk, dv
+
+
+def add_layernorm_fwd(x, r, gamma, beta, eps=1e-5):
+    x = _f32c(x)
+    r = _f32c(r) if r is not None else None
+    rows, d = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _lib.call("vs_add_layernorm_fwd", _ptr(x), _ptr(r), _ptr(gamma), _ptr(beta), _ptr(y),
+              _ptr(mean), _ptr(rstd), rows, d, float(eps), _stream())
+    return y, mean, rstd
+
+
+def add_layernorm_bwd(dy, x, r, gamma, mean, rstd):
+    dy = _f32c(dy)
+    rows, d = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.empty(d, dtype=torch.float32, device=x.device)
+    db = torch.empty(d, dtype=torch.float32, device=x.device)
+    _lib.call("vs_add_layernorm_bwd", _ptr(dy), _ptr(x), _ptr(r), _ptr(gamma), _ptr(mean),
+              _ptr(rstd), _ptr(dx), _ptr(dg), _ptr(db), rows, d, _stream())
+    return dx, dg, db
+
+
+def softmax_xent(logits, labels, want_grad=True):
+    logits = _f32c(logits)
+    labels = labels.contiguous()
+    rows, v = logits.shape
+    loss = torch.empty((), dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty_like(logits) if want_grad else None
+    _lib.call("vs_softmax_xent", _ptr(logits), _ptr(labels), _ptr(loss), _ptr(dlogits), rows, v,
+              _stream())
+    return loss, dlogits
+
+
+def softmax_topk(logits, k=5):
+    logits = _f32c(logits)
+    rows, v = logits.shape
+    probs = torch.empty((rows, k), dtype=torch.float32, device=logits.device)
+    idx = torch.empty((rows, k), dtype=torch.int64, device=logits.device)
+    _lib.call("vs_softmax_topk", _ptr(logits), _ptr(probs), _ptr(idx), rows, v, k, _stream())
+    return probs, idx
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    _lib.call("vs_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr),
+              float(beta1), float(beta2), float(eps), int(step), float(grad_scale), _stream())
+
+
+def cast_bf16(src_f32, dst_bf16):
+    _lib.call("vs_cast_f32_to_bf16", _ptr(src_f32), _ptr(dst_bf16), src_f32.numel(), _stream())

@@ -1,0 +1,91 @@
+"""Flat-arena parameters, gradients and Adam for the data-parallel step.
+
+The reference wraps the model in torch DDP (`main_dist.py:68-79`: bucketed fp32
+all-reduce of ~39 M gradient elements, plus a BN-buffer broadcast and
+`find_unused_parameters`) and steps `torch.optim.Adam(betas=(0.9, 0.99))`
+(`main_dist.py:50`).  Here every parameter and every gradient is a view into ONE
+fp32 buffer each, so a step is: zero the gradient arena (one memset) ->
+forward/backward (HIP kernels write gradients in place) -> ONE all-reduce over
+RCCL (`torch.distributed`, backend "nccl") -> ONE fused Adam launch
+(`vs_adam_step`, the 1/world_size averaging folded in) -> refresh the bf16
+kernel-layout weight copies.  No unused parameters exist (the upstream 2304->400
+head is never built) and BN running statistics are not re-broadcast (SURVEY.md
+section 5: rank 0's are the ones checkpointed).
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+def _dense_view(buf, off, p):
+    """A view of buf[off: off+n] with p's shape AND p's memory order."""
+    n = p.numel()
+    flat = buf[off : off + n]
+    if p.dim() == 5 and not p.is_contiguous():  # channels-last conv weight
+        co, ci, kt, kh, kw = p.shape
+        return flat.view(co, kt, kh, kw, ci).permute(0, 4, 1, 2, 3)
+    return flat.view(p.shape)
+
+
+class ParamArena:
+    def __init__(self, model):
+        self.model = model
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        dev = self.params[0].device
+        sizes = [(p.numel() + 3) // 4 * 4 for p in self.params]  # keep 16-byte alignment
+        self.offsets = [0]
+        for s in sizes:
+            self.offsets.append(self.offsets[-1] + s)
+        total = self.offsets[-1]
+        self.data = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, off in zip(self.params, self.offsets):
+                v = _dense_view(self.data, off, p)
+                v.copy_(p.detach())
+                p.data = v
+                p.grad = _dense_view(self.grad, off, p)
+        self.numel = total
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, off in zip(self.params, self.offsets):  # re-attach if something replaced .grad
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
+                p.grad = _dense_view(self.grad, off, p)
+
+    def all_reduce(self):
+        """Sum gradients over ranks (averaging happens inside the Adam kernel)."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
+            return dist.get_world_size()
+        return 1
+
+    def broadcast_params(self, src=0):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.broadcast(self.data, src=src)
+            self.refresh()
+
+    def refresh(self):
+        for m in self.model.modules():
+            if hasattr(m, "refresh_weights"):
+                m.refresh_weights()
+
+
+class ArenaAdam:
+    """torch.optim.Adam semantics (lr, betas, eps; no weight decay) on the arena."""
+
+    def __init__(self, arena, lr=1e-4, betas=(0.9, 0.99), eps=1e-8):
+        self.arena, self.lr, self.betas, self.eps = arena, lr, betas, eps
+        self.m = torch.zeros_like(arena.data)
+        self.v = torch.zeros_like(arena.data)
+        self.t = 0
+
+    def zero_grad(self):
+        self.arena.zero_grad()
+
+    def step(self, world=1):
+        self.t += 1
+        ops.adam_step(self.arena.data, self.arena.grad, self.m, self.v, self.lr, self.betas[0],
+                      self.betas[1], self.eps, self.t, grad_scale=1.0 / world)
+        self.arena.refresh()

@@ -1,0 +1,185 @@
+"""Host-side mirror of the reference's `utils/transformer_code.py` (post-LN
+transformer encoder, lines 21-124 and 261-284) on the HIP kernels.
+
+Same class names, constructor arguments, attribute names and state_dict keys
+(`encoder.layers.{i}.selfattn.layer.wq.weight`, ...), so a reference checkpoint
+loads unchanged; `forward` never calls torch.nn.functional -- every matmul,
+softmax and LayerNorm is a kernel of libvidsitu_hip.so (fp32, exact-order
+reductions).  Parity trap kept: the softmax scale is sqrt(d_model), not
+sqrt(head_dim) (`utils/transformer_code.py:36,54`).
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x @ W^T + b) on vs_linear_*  (x: [..., K] fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        y = ops.linear_fwd(x2, w, b, relu)
+        ctx.save_for_backward(x2, w, y if relu else None)
+        ctx.has_bias, ctx.relu, ctx.shp = b is not None, relu, shp
+        return y.reshape(*shp[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        dy2 = dy.reshape(-1, w.shape[0])
+        if ctx.relu:
+            dy2 = dy2 * (y > 0).to(dy2.dtype)
+        dx, dw, db = ops.linear_bwd(dy2.contiguous(), x2, w, need_dx=ctx.needs_input_grad[0],
+                                    has_bias=ctx.has_bias)
+        return (dx.reshape(ctx.shp) if dx is not None else None), dw, db, None
+
+
+class AttnSmallFn(torch.autograd.Function):
+    """concat_h softmax(Q_h K_h^T / scale) V_h for L <= 16 (vs_attn_small_*)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, n_heads, scale):
+        o, probs = ops.attn_small_fwd(q, k, v, n_heads, scale)
+        ctx.save_for_backward(q, k, v, probs)
+        ctx.n_heads, ctx.scale = n_heads, scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, probs = ctx.saved_tensors
+        dq, dk, dv = ops.attn_small_bwd(q.contiguous(), k.contiguous(), v.contiguous(), probs, do,
+                                        ctx.n_heads, ctx.scale)
+        return dq, dk, dv, None, None
+
+
+class AddLayerNormFn(torch.autograd.Function):
+    """LayerNorm(x + r) (vs_add_layernorm_*)."""
+
+    @staticmethod
+    def forward(ctx, x, r, gamma, beta, eps):
+        shp = x.shape
+        x2, r2 = x.reshape(-1, shp[-1]).contiguous(), r.reshape(-1, shp[-1]).contiguous()
+        y, mean, rstd = ops.add_layernorm_fwd(x2, r2, gamma, beta, eps)
+        ctx.save_for_backward(x2, r2, gamma, mean, rstd)
+        ctx.shp = shp
+        return y.reshape(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, r2, gamma, mean, rstd = ctx.saved_tensors
+        dx, dg, db = ops.add_layernorm_bwd(dy.reshape(x2.shape), x2, r2, gamma, mean, rstd)
+        dx = dx.reshape(ctx.shp)
+        return dx, dx, dg, db, None
+
+
+def hip_linear(mod, x, relu=False):
+    return LinearFn.apply(x, mod.weight, mod.bias, relu)
+
+
+class Attention(nn.Module):
+    def __init__(self, d_key, drop_ratio, causal):
+        super().__init__()
+        self.scale = math.sqrt(d_key)
+        self.dropout = nn.Dropout(drop_ratio)
+        self.causal = causal
+        if causal:
+            raise NotImplementedError("causal attention is not on the VidSitu hot path")
+
+
+class MultiHead(nn.Module):
+    def __init__(self, d_key, d_value, n_heads, drop_ratio, causal=False):
+        super().__init__()
+        self.attention = Attention(d_key, drop_ratio, causal=causal)
+        self.wq = nn.Linear(d_key, d_key, bias=False)
+        self.wk = nn.Linear(d_key, d_key, bias=False)
+        self.wv = nn.Linear(d_value, d_value, bias=False)
+        self.wo = nn.Linear(d_value, d_key, bias=False)
+        self.n_heads = n_heads
+
+    def forward(self, query, key, value):
+        if self.training and self.attention.dropout.p > 0:
+            raise NotImplementedError(
+                "attention-probability dropout in training mode: set tx_dec.dropout=0 "
+                "(the eval path and the dropout-free training path run on HIP)")
+        q, k, v = hip_linear(self.wq, query), hip_linear(self.wk, key), hip_linear(self.wv, value)
+        o = AttnSmallFn.apply(q, k, v, self.n_heads, self.attention.scale)
+        return hip_linear(self.wo, o)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, d_model, d_hidden):
+        super().__init__()
+        self.linear1 = nn.Linear(d_model, d_hidden)
+        self.linear2 = nn.Linear(d_hidden, d_model)
+
+    def forward(self, x):
+        return hip_linear(self.linear2, hip_linear(self.linear1, x, relu=True))
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, layer, d_model, drop_ratio):
+        super().__init__()
+        self.layer = layer
+        self.dropout = nn.Dropout(drop_ratio)
+        self.layernorm = nn.LayerNorm(d_model)
+
+    def forward(self, *x):
+        branch = self.layer(*x)
+        if self.training and self.dropout.p > 0:
+            raise NotImplementedError("residual dropout in training mode: set tx_dec.dropout=0")
+        return AddLayerNormFn.apply(x[0], branch, self.layernorm.weight, self.layernorm.bias,
+                                    self.layernorm.eps)
+
+
+class EncoderLayer(nn.Module):
+    def __init__(self, d_model, d_hidden, n_heads, drop_ratio):
+        super().__init__()
+        self.selfattn = ResidualBlock(MultiHead(d_model, d_model, n_heads, drop_ratio), d_model,
+                                      drop_ratio)
+        self.feedforward = ResidualBlock(FeedForward(d_model, d_hidden), d_model, drop_ratio)
+
+    def forward(self, x):
+        return self.feedforward(self.selfattn(x, x, x))
+
+
+class Encoder(nn.Module):
+    def __init__(self, d_model, d_hidden, n_vocab, n_layers, n_heads, drop_ratio, pe):
+        super().__init__()
+        self.layers = nn.ModuleList(
+            [EncoderLayer(d_model, d_hidden, n_heads, drop_ratio) for _ in range(n_layers)])
+        self.dropout = nn.Dropout(drop_ratio)
+        self.pe = pe
+
+    def forward(self, x, mask=None):
+        if self.pe:
+            raise NotImplementedError
+        if not x.is_cuda:
+            raise ops._lib.VsError("the TxEncoder runs on the HIP kernels only (GPU tensor required)")
+        x = x.float().contiguous()
+        if mask is not None:
+            x = x * mask
+        encoding = [x]
+        for layer in self.layers:
+            x = layer(x)
+            if mask is not None:
+                x = x * mask
+            encoding.append(x)
+        return encoding
+
+
+class Transformer(nn.Module):
+    def __init__(self, d_model, n_vocab_src, vocab_trg, d_hidden=2048, n_layers=6, n_heads=8,
+                 drop_ratio=0.1, pe=False):
+        super().__init__()
+        self.encoder = Encoder(d_model, d_hidden, n_vocab_src, n_layers, n_heads, drop_ratio, pe)
+
+    def forward(self, x):
+        return self.encoder(x)[-1]
+
+    def all_outputs(self, x):
+        return self.encoder(x)

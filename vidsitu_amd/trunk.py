@@ -1,0 +1,465 @@
+"""SlowFast / ResNet video trunk on the HIP kernels.
+
+Host-side mirror of the module tree the reference reaches through
+`slowfast.models.video_model_builder.{SlowFast,ResNet}` and subclasses in
+`vidsitu_code/mdl_sf_base.py:20-62` (`SlowFast_FeatModel`, `ResNet_FeatModel`):
+same attribute names (`s1, s1_fuse, s2, ... s5, pathway{p}_pool`), same
+state_dict keys, same `forward_features(list) -> list`.
+
+Compute never touches torch.nn.functional: every layer is a launch of
+libvidsitu_hip.so through `ops`.  Activations are bf16 channels-last; the
+tensors handed back keep the reference's logical NCDHW shape.
+
+  eval : conv epilogue applies the folded BN (+residual, +ReLU)   -> 1 launch / conv
+  train: conv emits raw bf16 + fp32 batch-stat partials -> finalize -> apply
+         (+residual, +ReLU); the backward is hand written (BN reduce/apply,
+         conv dgrad / wgrad) and writes parameter gradients straight into
+         `param.grad` (one fp32 arena), so DDP-style averaging is one all-reduce.
+"""
+import torch
+from torch import nn
+
+from . import ops
+
+STAGE_DEPTH = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), "tiny": (1, 0, 0, 1)}
+TEMPORAL_KERNEL_BASIS = {
+    "c2d": [[[1]], [[1]], [[1]], [[1]], [[1]]],
+    "i3d": [[[5]], [[3]], [[3, 1]], [[3, 1]], [[1, 3]]],
+    "slow": [[[1]], [[1]], [[1]], [[3]], [[3]]],
+    "slowfast": [[[1], [5]], [[1], [3]], [[1], [3]], [[3], [3]], [[3], [3]]],
+}
+POOL1 = {
+    "c2d": [[2, 1, 1]],
+    "i3d": [[2, 1, 1]],
+    "slow": [[1, 1, 1]],
+    "slowfast": [[1, 1, 1], [1, 1, 1]],
+}
+
+
+# ----------------------------------------------------------------------------
+# parameter holders (names = upstream names)
+# ----------------------------------------------------------------------------
+class Conv3dP(nn.Module):
+    """Bias-free Conv3d parameters.  `weight` is the fp32 master in the reference's
+    logical shape [Cout,Cin,kT,kH,kW] with channels-last memory."""
+
+    def __init__(self, cin, cout, k, s=(1, 1, 1), p=(0, 0, 0)):
+        super().__init__()
+        self.cin, self.cout = cin, cout
+        self.k, self.s, self.p = tuple(k), tuple(s), tuple(p)
+        self.cin_pad = (cin + 7) // 8 * 8
+        w = torch.empty(cout, *self.k, cin).permute(0, 4, 1, 2, 3)
+        fan_out = cout * k[0] * k[1] * k[2]
+        w.normal_(0.0, (2.0 / fan_out) ** 0.5)  # c2_msra_fill
+        self.weight = nn.Parameter(w)
+        self.w_bf16 = None  # [Cout, cin_pad, k] channels-last, refreshed by the trunk
+        self.wt_bf16 = None  # transposed image for dgrad
+
+    def refresh(self):
+        w = self.weight.detach()
+        if self.w_bf16 is None or self.w_bf16.device != w.device:
+            self.w_bf16 = torch.zeros(
+                (self.cout, *self.k, self.cin_pad), dtype=ops.BF16, device=w.device
+            ).permute(0, 4, 1, 2, 3)
+        if self.cin_pad == self.cin:
+            ops.cast_bf16(w, self.w_bf16)  # identical memory order
+        else:
+            self.w_bf16[:, : self.cin].copy_(w)
+        self.wt_bf16 = None
+
+    def wt(self):
+        if self.wt_bf16 is None:
+            self.wt_bf16 = ops.weight_transpose(self.w_bf16)
+        return self.wt_bf16
+
+
+class BN3dP(nn.Module):
+    def __init__(self, c, eps=1e-5, momentum=0.1, zero_init=False):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = c, eps, momentum
+        self.weight = nn.Parameter(torch.zeros(c) if zero_init else torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+def _set_grad(param, g):
+    """Write a gradient produced by a HIP kernel (overwrite semantics)."""
+    if param.grad is None:
+        param.grad = g if g.shape == param.shape else g.reshape(param.shape)
+    else:
+        param.grad.copy_(g)
+
+
+class _Unit:
+    """conv -> BN (-> +residual) (-> ReLU) executed on the HIP kernels."""
+
+    @staticmethod
+    def fwd(conv, bn, x, relu, residual=None, out=None, train=False, saved=None):
+        if not train:
+            scale, shift, _, _ = ops.bn_finalize(
+                None, 0, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum,
+                bn.eps, train=False)
+            y, _ = ops.conv_fwd(x, conv.w_bf16, conv.k, conv.s, conv.p, out=out, scale=scale,
+                                shift=shift, residual=residual, relu=relu)
+            return y
+        y, partials = ops.conv_fwd(x, conv.w_bf16, conv.k, conv.s, conv.p, stats=True)
+        scale, shift, mean, invstd = ops.bn_finalize(
+            partials, ops.act_rows(y), bn.weight, bn.bias, bn.running_mean, bn.running_var,
+            bn.momentum, bn.eps, train=True)
+        z = ops.bn_apply(y, scale, shift, residual, relu, out=out)
+        saved.append(dict(conv=conv, bn=bn, x=x, y=y, z=z, mean=mean, invstd=invstd, relu=relu))
+        return z
+
+    @staticmethod
+    def bwd(rec, dz, need_dx=True, want_dres=False, dx_residual=None, masked=False):
+        """Returns (dx|None, dres|None).  `masked`: dz already carries the ReLU mask."""
+        conv, bn = rec["conv"], rec["bn"]
+        relu = rec["relu"] and not masked
+        dy, dres, dgamma, dbeta = ops.bn_bwd(
+            dz, rec["z"], rec["y"], rec["mean"], rec["invstd"], bn.weight, relu, want_dres)
+        _set_grad(bn.weight, dgamma)
+        _set_grad(bn.bias, dbeta)
+        x = rec["x"]
+        if conv.cin_pad == conv.cin:
+            if conv.weight.grad is None:
+                conv.weight.grad = torch.empty_like(conv.weight)
+            ops.conv_wgrad(dy, x, conv.k, conv.s, conv.p, out=conv.weight.grad)
+        else:
+            dwp = ops.conv_wgrad(dy, x, conv.k, conv.s, conv.p)
+            _set_grad(conv.weight, dwp[:, : conv.cin])
+        dx = None
+        if need_dx:
+            dx = ops.conv_dgrad(dy, conv.wt(), tuple(x.shape), conv.k, conv.s, conv.p,
+                                residual=dx_residual)
+        return dx, dres
+
+
+class ResNetBasicStem(nn.Module):
+    def __init__(self, cin, cout, kt, eps, mom):
+        super().__init__()
+        self.conv = Conv3dP(cin, cout, (kt, 7, 7), (1, 2, 2), (kt // 2, 3, 3))
+        self.bn = BN3dP(cout, eps, mom)
+
+    def fwd(self, x, out, train, saved):
+        z = _Unit.fwd(self.conv, self.bn, x, True, train=train, saved=saved)
+        y, idx = ops.maxpool_hw(z, out=out, want_idx=train)
+        if train:
+            saved.append(dict(pool_idx=idx, pool_in=tuple(z.shape)))
+        return y
+
+    def bwd(self, saved, dy):
+        rec = saved.pop()
+        dz = ops.maxpool_hw_bwd(dy, rec["pool_idx"], rec["pool_in"])
+        _Unit.bwd(saved.pop(), dz, need_dx=False)
+
+
+class VideoModelStem(nn.Module):
+    def __init__(self, cins, couts, kts, eps, mom):
+        super().__init__()
+        self.num_pathways = len(cins)
+        for p in range(self.num_pathways):
+            self.add_module(f"pathway{p}_stem", ResNetBasicStem(cins[p], couts[p], kts[p], eps, mom))
+
+
+class FuseFastToSlow(nn.Module):
+    def __init__(self, cfast, ratio, ksz, alpha, eps, mom):
+        super().__init__()
+        self.conv_f2s = Conv3dP(cfast, cfast * ratio, (ksz, 1, 1), (alpha, 1, 1), (ksz // 2, 0, 0))
+        self.bn = BN3dP(cfast * ratio, eps, mom)
+
+
+class BottleneckTransform(nn.Module):
+    def __init__(self, cin, cout, cinner, tk, stride, eps, mom, zero_final):
+        super().__init__()
+        self.a = Conv3dP(cin, cinner, (tk, 1, 1), (1, 1, 1), (tk // 2, 0, 0))
+        self.a_bn = BN3dP(cinner, eps, mom)
+        self.b = Conv3dP(cinner, cinner, (1, 3, 3), (1, stride, stride), (0, 1, 1))
+        self.b_bn = BN3dP(cinner, eps, mom)
+        self.c = Conv3dP(cinner, cout, (1, 1, 1))
+        self.c_bn = BN3dP(cout, eps, mom, zero_init=zero_final)
+
+
+class ResBlock(nn.Module):
+    def __init__(self, cin, cout, cinner, tk, stride, eps, mom, zero_final):
+        super().__init__()
+        self.has_sc = cin != cout or stride != 1
+        if self.has_sc:
+            self.branch1 = Conv3dP(cin, cout, (1, 1, 1), (1, stride, stride))
+            self.branch1_bn = BN3dP(cout, eps, mom)
+        self.branch2 = BottleneckTransform(cin, cout, cinner, tk, stride, eps, mom, zero_final)
+
+    def fwd(self, x, out, train, saved):
+        b2 = self.branch2
+        sc = x
+        if self.has_sc:
+            sc = _Unit.fwd(self.branch1, self.branch1_bn, x, False, train=train, saved=saved)
+        a = _Unit.fwd(b2.a, b2.a_bn, x, True, train=train, saved=saved)
+        b = _Unit.fwd(b2.b, b2.b_bn, a, True, train=train, saved=saved)
+        return _Unit.fwd(b2.c, b2.c_bn, b, True, residual=sc, out=out, train=train, saved=saved)
+
+    def bwd(self, saved, dout):
+        rc, rb, ra = saved.pop(), saved.pop(), saved.pop()
+        db, g = _Unit.bwd(rc, dout, want_dres=True)
+        da, _ = _Unit.bwd(rb, db)
+        if self.has_sc:
+            dx1, _ = _Unit.bwd(saved.pop(), g, masked=True)
+            dx, _ = _Unit.bwd(ra, da, dx_residual=dx1)
+        else:
+            dx, _ = _Unit.bwd(ra, da, dx_residual=g)
+        return dx
+
+
+class ResStage(nn.Module):
+    def __init__(self, cins, couts, cinners, tks, strides, nblocks, nblk_tk, eps, mom, zero_final):
+        super().__init__()
+        self.num_pathways = len(cins)
+        self.num_blocks = list(nblocks)
+        self.couts = list(couts)
+        for p in range(self.num_pathways):
+            n = nblocks[p]
+            tk_list = (tks[p] * n)[: nblk_tk[p]] + [1] * (n - nblk_tk[p])
+            for i in range(n):
+                self.add_module(
+                    f"pathway{p}_res{i}",
+                    ResBlock(cins[p] if i == 0 else couts[p], couts[p], cinners[p], tk_list[i],
+                             strides[p] if i == 0 else 1, eps, mom, zero_final))
+
+    def blocks(self, p):
+        return [getattr(self, f"pathway{p}_res{i}") for i in range(self.num_blocks[p])]
+
+
+class PathwayPool(nn.Module):
+    """`pathway{p}_pool` = MaxPool3d(k = s = [kt,1,1]) (mdl_sf_base.py:26-28, 49-51);
+    identity for slowfast / slow (kt = 1)."""
+
+    def __init__(self, kt):
+        super().__init__()
+        self.kt = kt
+
+    def forward(self, x):
+        return x if self.kt == 1 else ops.maxpool_t(x, self.kt)[0]
+
+
+class _TrunkFn(torch.autograd.Function):
+    """One autograd node for the whole trunk (manual HIP backward)."""
+
+    @staticmethod
+    def forward(ctx, trunk, _tick, *inputs):
+        feats, saved = trunk._run(inputs, train=True)
+        ctx.trunk, ctx.saved = trunk, saved
+        ctx.n_in = len(inputs)
+        return tuple(feats)
+
+    @staticmethod
+    def backward(ctx, *dfeats):
+        ctx.trunk._backward(ctx.saved, [ops_ensure_act(d) for d in dfeats])
+        ctx.saved = None
+        return (None, None) + (None,) * ctx.n_in
+
+
+def ops_ensure_act(t):
+    """Gradients normally arrive as our own channels-last bf16 tensors; anything
+    else (a torch op in between) is re-laid-out here."""
+    if t.dtype != ops.BF16:
+        t = t.to(ops.BF16)
+    n, c, tt, h, w = t.shape
+    if not t.permute(0, 2, 3, 4, 1).is_contiguous():
+        t = t.contiguous(memory_format=torch.channels_last_3d)
+        if not t.permute(0, 2, 3, 4, 1).is_contiguous():  # size-1 dims confuse the format
+            t = t.permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3)
+    return t
+
+
+class VideoTrunk(nn.Module):
+    """`SlowFast_FeatModel` / `ResNet_FeatModel` (mdl_sf_base.py:20-62)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        arch = cfg.MODEL.ARCH
+        self.arch = arch
+        self.multi = arch in cfg.MODEL.MULTI_PATHWAY_ARCH
+        self.num_pathways = 2 if self.multi else 1
+        self.enable_detection = False
+        eps, mom = cfg.BN.EPSILON, cfg.BN.MOMENTUM
+        zf = bool(cfg.RESNET.ZERO_INIT_FINAL_BN)
+        w = cfg.RESNET.WIDTH_PER_GROUP
+        inner = cfg.RESNET.NUM_GROUPS * w
+        depths = STAGE_DEPTH[cfg.RESNET.DEPTH]
+        tk = TEMPORAL_KERNEL_BASIS[arch]
+        nbt = cfg.RESNET.NUM_BLOCK_TEMP_KERNEL
+        ss = cfg.RESNET.SPATIAL_STRIDES
+        self.pool1 = POOL1[arch]
+        if self.multi:
+            binv = cfg.SLOWFAST.BETA_INV
+            ratio = cfg.SLOWFAST.FUSION_CONV_CHANNEL_RATIO
+            odr = binv // ratio
+            fk, alpha = cfg.SLOWFAST.FUSION_KERNEL_SZ, cfg.SLOWFAST.ALPHA
+            self.s1 = VideoModelStem(cfg.DATA.INPUT_CHANNEL_NUM, [w, w // binv],
+                                     [tk[0][0][0], tk[0][1][0]], eps, mom)
+            self.s1_fuse = FuseFastToSlow(w // binv, ratio, fk, alpha, eps, mom)
+            cin_s, cin_f = w + w // odr, w // binv
+            for k in range(4):
+                mult = 4 * (2 ** k)
+                cout_s, cout_f = w * mult, w * mult // binv
+                setattr(self, f"s{k + 2}", ResStage(
+                    [cin_s, cin_f], [cout_s, cout_f],
+                    [inner * (2 ** k), inner * (2 ** k) // binv], tk[k + 1], ss[k],
+                    [depths[k]] * 2, nbt[k], eps, mom, zf))
+                if k < 3:
+                    setattr(self, f"s{k + 2}_fuse",
+                            FuseFastToSlow(cout_f, ratio, fk, alpha, eps, mom))
+                cin_s, cin_f = cout_s + cout_s // odr, cout_f
+            self.dim_out = [w * 32, w * 32 // binv]
+        else:
+            self.s1 = VideoModelStem(cfg.DATA.INPUT_CHANNEL_NUM, [w], [tk[0][0][0]], eps, mom)
+            cin = w
+            for k in range(4):
+                cout = w * 4 * (2 ** k) if depths[k] > 0 else cin
+                setattr(self, f"s{k + 2}", ResStage(
+                    [cin], [cout], [inner * (2 ** k)], tk[k + 1], ss[k], [depths[k]], nbt[k],
+                    eps, mom, zf))
+                cin = cout
+            self.dim_out = [cin]
+        for p in range(self.num_pathways):
+            self.add_module(f"pathway{p}_pool", PathwayPool(self.pool1[p][0]))
+        self._weights_version = None
+        self.debug_taps = None  # set to a dict to record the activations after every stage
+
+    # ---- weights ----------------------------------------------------------------
+    def _convs(self):
+        return [m for m in self.modules() if isinstance(m, Conv3dP)]
+
+    def refresh_weights(self):
+        """(Re)build the bf16 kernel-layout copies of every conv weight.  Call after
+        an optimizer step or a state_dict load; `forward_features` calls it
+        lazily when the parameters' version counters moved."""
+        for c in self._convs():
+            c.refresh()
+        self._weights_version = self._version_key()
+
+    def _version_key(self):
+        return tuple((c.weight._version, c.weight.data_ptr()) for c in self._convs())
+
+    # ---- forward ------------------------------------------------------------------
+    def forward_features(self, x):
+        """x: list of NCDHW tensors ([slow, fast] or [fast]) -> list of feature maps
+        (bf16, logical NCDHW, channels-last memory)."""
+        if not x[0].is_cuda:
+            raise ops._lib.VsError("VideoTrunk runs on the HIP kernels only (GPU tensors required)")
+        if self._weights_version != self._version_key():
+            self.refresh_weights()
+        if self.training and torch.is_grad_enabled():
+            tick = torch.zeros(1, device=x[0].device, requires_grad=True)
+            return list(_TrunkFn.apply(self, tick, *x))
+        feats, _ = self._run(x, train=self.training)
+        return feats
+
+    def forward(self, x, bboxes=None):
+        return self.forward_features(x)
+
+    def _run(self, inputs, train):
+        saved = [] if train else None
+        P = self.num_pathways
+        xin = [ops.pack_input(t) for t in inputs]
+        dev = xin[0].device
+        if train:
+            bns = [m.num_batches_tracked for m in self.modules() if isinstance(m, BN3dP)]
+            torch._foreach_add_(bns, 1)
+        # ---- s1 (+ fuse): stems write straight into the concat buffer of the slow path
+        cur = []
+        for p in range(P):
+            stem = getattr(self.s1, f"pathway{p}_stem")
+            n, _, t, h, w = xin[p].shape
+            ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+            hp, wp = (ho + 2 - 3) // 2 + 1, (wo + 2 - 3) // 2 + 1
+            c = stem.conv.cout
+            if self.multi and p == 0:
+                cf = self.s1_fuse.conv_f2s.cout
+                buf = ops.new_act(n, c + cf, t, hp, wp, dev)
+                out = ops.channel_slice(buf, 0, c)
+            else:
+                buf = out = ops.new_act(n, c, t, hp, wp, dev)
+            stem.fwd(xin[p], out, train, saved)
+            cur.append(buf)
+        if self.multi:
+            self._fuse_fwd(self.s1_fuse, cur, train, saved)
+        if self.debug_taps is not None:
+            self.debug_taps["s1"] = [c.float().cpu() for c in cur]
+        for k in range(2, 6):
+            stage = getattr(self, f"s{k}")
+            fuse = getattr(self, f"s{k}_fuse", None) if self.multi else None
+            nxt = []
+            for p in range(P):
+                x = cur[p]
+                blocks = stage.blocks(p)
+                for i, blk in enumerate(blocks):
+                    last = i == len(blocks) - 1
+                    out = None
+                    if last and fuse is not None and p == 0:
+                        ys = ops.conv_out_shape(x.shape, stage.couts[0], (1, 1, 1),
+                                                (1, blk.branch2.b.s[1], blk.branch2.b.s[2]),
+                                                (0, 0, 0))
+                        cf = fuse.conv_f2s.cout
+                        buf = ops.new_act(ys[0], ys[1] + cf, ys[2], ys[3], ys[4], dev)
+                        out = ops.channel_slice(buf, 0, ys[1])
+                        blk.fwd(x, out, train, saved)
+                        x = buf
+                    else:
+                        x = blk.fwd(x, None, train, saved)
+                nxt.append(x)
+            cur = nxt
+            if fuse is not None:
+                self._fuse_fwd(fuse, cur, train, saved)
+            if k == 2:
+                for p in range(P):
+                    kt = self.pool1[p][0]
+                    if kt > 1:
+                        y, idx = ops.maxpool_t(cur[p], kt, want_idx=train)
+                        if train:
+                            saved.append(dict(tpool_idx=idx, tpool_in=tuple(cur[p].shape), kt=kt))
+                        cur[p] = y
+            if self.debug_taps is not None:
+                self.debug_taps[f"s{k}"] = [c.float().cpu() for c in cur]
+        return cur, saved
+
+    def _fuse_fwd(self, fuse, cur, train, saved):
+        slow_buf, fast = cur
+        cf = fuse.conv_f2s.cout
+        cs = slow_buf.shape[1] - cf
+        _Unit.fwd(fuse.conv_f2s, fuse.bn, fast, True, out=ops.channel_slice(slow_buf, cs, cf),
+                  train=train, saved=saved)
+
+    # ---- backward (mirror of _run, popping `saved`) ----------------------------------
+    def _backward(self, saved, dfeats):
+        P = self.num_pathways
+        d = list(dfeats)
+        for k in range(5, 1, -1):
+            stage = getattr(self, f"s{k}")
+            fuse = getattr(self, f"s{k}_fuse", None) if self.multi else None
+            if k == 2:
+                for p in reversed(range(P)):
+                    if self.pool1[p][0] > 1:
+                        rec = saved.pop()
+                        d[p] = ops.maxpool_t_bwd(d[p], rec["tpool_idx"], rec["tpool_in"], rec["kt"])
+            if fuse is not None:
+                d = self._fuse_bwd(saved, d)
+            for p in reversed(range(P)):
+                g = d[p]
+                for blk in reversed(stage.blocks(p)):
+                    g = blk.bwd(saved, g)
+                d[p] = g
+        if self.multi:
+            d = self._fuse_bwd(saved, d)
+        for p in reversed(range(P)):
+            getattr(self.s1, f"pathway{p}_stem").bwd(saved, d[p])
+        assert not saved, "trunk backward did not consume every saved record"
+
+    def _fuse_bwd(self, saved, d):
+        d_cat, d_fast = d
+        rec = saved.pop()
+        cf = rec["conv"].cout
+        cs = d_cat.shape[1] - cf
+        d_fast_tot, _ = _Unit.bwd(rec, ops.channel_slice(d_cat, cs, cf), dx_residual=d_fast)
+        return [ops.channel_slice(d_cat, 0, cs), d_fast_tot]
