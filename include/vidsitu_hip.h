@@ -88,6 +88,10 @@ int vs_conv_stats_rows(const vs_conv_desc* d);
 int vs_conv_dgrad(const void* dy, const void* wt, void* dx, const vs_conv_desc* d,
                   const void* residual, void* stream);
 int vs_weight_transpose(const void* w, void* wt, int Cout, int taps, int Cin, void* stream);
+/* Every dgrad weight image of a model in one launch: src/dst are bf16 arenas with equal
+ * element offsets; table[i] = {offset, Cout, taps, Cin, first flat index} (int64 x 5). */
+int vs_weight_transpose_batched(const void* src, void* dst, const int64_t* table, int n,
+                                int64_t total, void* stream);
 
 /* Weight gradient: dw[Cout][taps][Cin] fp32 = sum_p dy[p][co] * x[p@tap][ci].
  * workspace: vs_conv_wgrad_workspace_bytes(desc) bytes of fp32 split-K slabs.
@@ -107,6 +111,10 @@ int vs_bn_finalize(const float* partials, int nparts, double count, const float*
                    const float* beta, float* running_mean, float* running_var, float momentum,
                    float eps, float* scale, float* shift, float* mean, float* invstd, int C,
                    void* stream);
+/* Level-1 reduction of the conv-epilogue partials when there are thousands of rows:
+ * out[G][2][C] (then passed to vs_bn_finalize with nparts = G). */
+int vs_bn_partials_reduce(const float* partials, int nparts, float* out, int C, int G,
+                          void* stream);
 /* out = relu?(y*scale[c] + shift[c] (+ residual)), bf16 rows of C channels. */
 int vs_bn_apply(const void* y, const float* scale, const float* shift, const void* residual,
                 void* out, int64_t rows, int C, int y_ld, int res_ld, int out_ld, int relu,

@@ -43,9 +43,11 @@ SIGNATURES = {
     "vs_conv_stats_rows": (_i, [_dp]),
     "vs_conv_dgrad": (_i, [_p, _p, _p, _dp, _p, _p]),
     "vs_weight_transpose": (_i, [_p, _p, _i, _i, _i, _p]),
+    "vs_weight_transpose_batched": (_i, [_p, _p, _p, _i, _i64, _p]),
     "vs_conv_wgrad_workspace_bytes": (_sz, [_dp]),
     "vs_conv_wgrad": (_i, [_p, _p, _p, _dp, _p, _p, _p, _sz, _p]),
     "vs_bn_finalize": (_i, [_p, _i, _d, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i, _p]),
+    "vs_bn_partials_reduce": (_i, [_p, _i, _p, _i, _i, _p]),
     "vs_bn_apply": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p]),
     "vs_bn_bwd_reduce": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p]),
     "vs_bn_bwd_reduce_rows": (_i, [_i64, _i]),
@@ -97,6 +99,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64; it must be in the process first so that this
+    # library binds to the same HIP runtime (two runtimes => "no ROCm-capable device").
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise VsError(
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -101,6 +101,48 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
   }
 }
 
+// Level-1 reduction of many per-tile partials: out[g][2][C] = sum over the g-th slice of
+// parts (fp64 accumulation, fixed order).  Keeps bn_finalize short when a small-channel
+// layer produced thousands of partial rows.
+__global__ __launch_bounds__(1024) void bn_partials_reduce_kernel(const float* partials, int nparts,
+                                                                 float* out, int C, int G) {
+  __shared__ double sh_s[32][33];
+  __shared__ double sh_q[32][33];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const int g = blockIdx.y;
+  const int per = (nparts + G - 1) / G;
+  const int p0 = g * per, p1 = min(nparts, p0 + per);
+  double s = 0.0, q = 0.0;
+  if (c < C) {
+    for (int p = p0 + sl; p < p1; p += 32) {
+      s += (double)partials[(long long)p * 2 * C + c];
+      q += (double)partials[(long long)p * 2 * C + C + c];
+    }
+  }
+  sh_s[sl][cl] = s;
+  sh_q[sl][cl] = q;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    double ts = 0.0, tq = 0.0;
+    for (int i = 0; i < 32; ++i) {
+      ts += sh_s[i][cl];
+      tq += sh_q[i][cl];
+    }
+    out[(long long)g * 2 * C + c] = (float)ts;
+    out[(long long)g * 2 * C + C + c] = (float)tq;
+  }
+}
+
+extern "C" int vs_bn_partials_reduce(const float* partials, int nparts, float* out, int C, int G,
+                                     void* stream) {
+  VS_CHECK_ARG(partials && out && nparts > 0 && C > 0 && G > 0, "bad args");
+  hipLaunchKernelGGL(bn_partials_reduce_kernel, dim3((C + 31) / 32, G), dim3(1024), 0,
+                     (hipStream_t)stream, partials, nparts, out, C, G);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
 extern "C" int vs_bn_finalize(const float* partials, int nparts, double count, const float* gamma,
                               const float* beta, float* running_mean, float* running_var,
                               float momentum, float eps, float* scale, float* shift, float* mean,

@@ -544,3 +544,37 @@ extern "C" int vs_weight_transpose(const void* w, void* wt, int Cout, int taps, 
   VS_CHECK_LAUNCH();
   return VS_OK;
 }
+
+// All dgrad weight images of a model in ONE launch.  table[i] = {element offset (same in
+// src and dst arenas), Cout, taps, Cin, first flat index}; entries sorted by first index.
+__global__ void weight_transpose_batched_kernel(const uint16_t* src, uint16_t* dst,
+                                                const long long* table, int n, long long total) {
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (table[mid * 5 + 4] <= idx) lo = mid; else hi = mid - 1;
+    }
+    const long long off = table[lo * 5 + 0];
+    const int Cout = (int)table[lo * 5 + 1], taps = (int)table[lo * 5 + 2], Cin = (int)table[lo * 5 + 3];
+    const long long e = idx - table[lo * 5 + 4];
+    const int co = (int)(e % Cout);
+    const long long r = e / Cout;
+    const int tap = (int)(r % taps);
+    const int ci = (int)(r / taps);
+    dst[off + e] = src[off + ((long long)co * taps + tap) * Cin + ci];
+  }
+}
+
+extern "C" int vs_weight_transpose_batched(const void* src, void* dst, const int64_t* table, int n,
+                                           int64_t total, void* stream) {
+  VS_CHECK_ARG(src && dst && table && n > 0 && total > 0, "bad args");
+  long long grid = (total + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(weight_transpose_batched_kernel, dim3((unsigned)grid), dim3(256), 0,
+                     (hipStream_t)stream, (const uint16_t*)src, (uint16_t*)dst,
+                     (const long long*)table, n, (long long)total);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}

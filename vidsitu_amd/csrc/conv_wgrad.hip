@@ -220,13 +220,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     }
 }
 
-// dw[i] = sum_s slab[s][i]  (fixed order)
+// dw[i] = sum_s slab[s][i]  (fixed order; n is a multiple of 4)
 __global__ void wgrad_reduce_kernel(const float* slabs, float* dw, long long n, int S) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
        i += (long long)gridDim.x * blockDim.x) {
-    float acc = 0.f;
-    for (int s = 0; s < S; ++s) acc += slabs[(long long)s * n + i];
-    dw[i] = acc;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < S; ++s) {
+      const float4 v = *(const float4*)(slabs + (long long)s * n + i * 4);
+      acc.x += v.x;
+      acc.y += v.y;
+      acc.z += v.z;
+      acc.w += v.w;
+    }
+    *(float4*)(dw + i * 4) = acc;
   }
 }
 
@@ -244,10 +251,12 @@ static WgCfg wg_pick(const vs_conv_desc* d) {
   c.tilesM = (d->Cout + c.bm - 1) / c.bm;
   c.tilesN = (Kp + c.bn - 1) / c.bn;
   const long long tiles = (long long)c.tilesM * c.tilesN;
-  // aim for ~1024 blocks, at least 4 steps (256 positions) per block
-  long long S = (1024 + tiles - 1) / tiles;
-  const long long maxS = (P + 255) / 256;
+  // ~512 blocks (2 per CU); every block keeps >= 8 steps (512 positions) so the slab
+  // traffic (S x |dW| fp32, written and re-read) stays small next to the operand reads
+  long long S = (512 + tiles - 1) / tiles;
+  const long long maxS = (P + 511) / 512;
   if (S > maxS) S = maxS;
+  if (S > 64) S = 64;
   if (S < 1) S = 1;
   long long rps = (P + S - 1) / S;
   rps = (rps + 63) / 64 * 64;
@@ -337,8 +346,8 @@ extern "C" int vs_conv_wgrad(const void* dy, const void* x, float* dw, const vs_
   if (rc) return rc;
   if (c.S > 1) {
     const long long n = (long long)d->Cout * p.Kp;
-    long long grid = (n + 255) / 256;
-    if (grid > 2048) grid = 2048;
+    long long grid = (n / 4 + 255) / 256;
+    if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, st,
                        (const float*)workspace, dw, n, c.S);
     VS_CHECK_LAUNCH();

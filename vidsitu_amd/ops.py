@@ -152,12 +152,18 @@ def conv_fwd(x, w, k, s, p, out=None, scale=None, shift=None, residual=None, rel
     return out, partials
 
 
-def weight_transpose(w):
+def weight_transpose(w, out=None):
     """[Cout][taps][Cin] -> [Cin][taps][Cout] bf16 (logical [Cin,Cout,kT,kH,kW])."""
     cout, cin, kt, kh, kw = w.shape
-    wt = torch.empty((cin, kt, kh, kw, cout), dtype=BF16, device=w.device).permute(0, 4, 1, 2, 3)
+    wt = out if out is not None else torch.empty(
+        (cin, kt, kh, kw, cout), dtype=BF16, device=w.device).permute(0, 4, 1, 2, 3)
     _lib.call("vs_weight_transpose", _ptr(w), _ptr(wt), cout, kt * kh * kw, cin, _stream())
     return wt
+
+
+def weight_transpose_batched(src_arena, dst_arena, table, total):
+    _lib.call("vs_weight_transpose_batched", _ptr(src_arena), _ptr(dst_arena), _ptr(table),
+              table.shape[0], int(total), _stream())
 
 
 def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False):
@@ -188,6 +194,8 @@ def conv_wgrad(dy, x, k, s, p, out=None):
     cout, cin = dy.shape[1], x.shape[1]
     if out is None:
         out = torch.empty((cout, *k, cin), dtype=torch.float32, device=x.device).permute(0, 4, 1, 2, 3)
+    elif not out.permute(0, 2, 3, 4, 1).is_contiguous() or out.dtype != torch.float32:
+        raise _lib.VsError("conv_wgrad out must be fp32 with [Cout][taps][Cin] memory")
     d = make_desc(x.shape, act_ld(x), dy.shape, act_ld(dy), k, s, p)
     need = _lib.load().vs_conv_wgrad_workspace_bytes(C.byref(d))
     ws = _workspace(need, x.device) if need else None
@@ -207,6 +215,10 @@ def bn_finalize(partials, count, gamma, beta, running_mean, running_var, momentu
     mean = torch.empty(c, dtype=torch.float32, device=dev)
     invstd = torch.empty(c, dtype=torch.float32, device=dev)
     nparts = partials.shape[0] if train else 0
+    if train and nparts > 512:  # two-level reduction keeps the finalize launch short
+        lvl1 = torch.empty((32, 2, c), dtype=torch.float32, device=dev)
+        _lib.call("vs_bn_partials_reduce", _ptr(partials), nparts, _ptr(lvl1), c, 32, _stream())
+        partials, nparts = lvl1, 32
     _lib.call("vs_bn_finalize", _ptr(partials) if train else None, nparts, float(count),
               _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), float(momentum),
               float(eps), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), c, _stream())
@@ -222,8 +234,8 @@ def bn_apply(y, scale, shift, residual=None, relu=True, out=None):
     return out
 
 
-def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres, dy_out=None):
-    """Returns (dy, dres|None, dgamma, dbeta)."""
+def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres, dy_out=None, dgamma=None, dbeta=None):
+    """Returns (dy, dres|None, dgamma, dbeta); dgamma / dbeta may be given (param.grad views)."""
     rows, c = act_rows(y), y.shape[1]
     dev = y.device
     nblk = _lib.load().vs_bn_bwd_reduce_rows(rows, c)
@@ -234,8 +246,10 @@ def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres, dy_out=None):
     _lib.call("vs_bn_bwd_reduce", _ptr(dz), _ptr(zz), _ptr(y), _ptr(mean), _ptr(invstd),
               _ptr(partial), rows, c, act_ld(dz), act_ld(z) if relu else 0, act_ld(y), int(relu),
               _stream())
-    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
-    dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+    if dgamma is None:
+        dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+    if dbeta is None:
+        dbeta = torch.empty(c, dtype=torch.float32, device=dev)
     _lib.call("vs_bn_bwd_finalize", _ptr(partial), nblk, _ptr(dgamma), _ptr(dbeta), c, _stream())
     dy = new_act(*y.shape, device=dev) if dy_out is None else dy_out
     dres = new_act(*y.shape, device=dev) if want_dres else None

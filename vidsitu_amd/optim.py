@@ -47,6 +47,36 @@ class ParamArena:
                 p.data = v
                 p.grad = _dense_view(self.grad, off, p)
         self.numel = total
+        self._adopt_conv_weights(dev)
+
+    def _adopt_conv_weights(self, dev):
+        """bf16 kernel-layout weights and their transposed dgrad images become views into two
+        bf16 arenas with the fp32 arena's offsets: one cast launch + one batched transpose
+        launch refresh every conv of the model."""
+        from .trunk import Conv3dP
+
+        self.data_bf16 = torch.zeros(self.numel, dtype=ops.BF16, device=dev)
+        self.wt_bf16 = torch.zeros(self.numel, dtype=ops.BF16, device=dev)
+        off_of = {id(p): off for p, off in zip(self.params, self.offsets)}
+        rows, first = [], 0
+        self._loose_convs = []
+        for m in self.model.modules():
+            if not isinstance(m, Conv3dP):
+                continue
+            off = off_of.get(id(m.weight))
+            if off is None or m.cin_pad != m.cin:
+                self._loose_convs.append(m)  # stems (Cin 3 -> 8 padding) keep their own copy
+                continue
+            n = m.weight.numel()
+            kt, kh, kw = m.k
+            m.w_bf16 = self.data_bf16[off : off + n].view(m.cout, kt, kh, kw, m.cin).permute(0, 4, 1, 2, 3)
+            m.wt_bf16 = self.wt_bf16[off : off + n].view(m.cin, kt, kh, kw, m.cout).permute(0, 4, 1, 2, 3)
+            m.arena_managed = True
+            rows.append([off, m.cout, kt * kh * kw, m.cin, first])
+            first += n
+        self._tr_total = first
+        self._tr_table = torch.tensor(rows, dtype=torch.int64, device=dev) if rows else None
+        self.refresh()
 
     def zero_grad(self):
         self.grad.zero_()
@@ -67,9 +97,16 @@ class ParamArena:
             self.refresh()
 
     def refresh(self):
+        """After the fp32 arena changed (optimizer step, broadcast, load): one cast, one
+        batched transpose, the two padded stems, and the trunks are marked up to date."""
+        ops.cast_bf16(self.data, self.data_bf16)
+        if self._tr_table is not None:
+            ops.weight_transpose_batched(self.data_bf16, self.wt_bf16, self._tr_table, self._tr_total)
+        for m in self._loose_convs:
+            m.refresh()
         for m in self.model.modules():
-            if hasattr(m, "refresh_weights"):
-                m.refresh_weights()
+            if hasattr(m, "_version_key") and hasattr(m, "_weights_version"):
+                m._weights_version = m._version_key()
 
 
 class ArenaAdam:

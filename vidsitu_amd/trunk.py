@@ -56,16 +56,22 @@ class Conv3dP(nn.Module):
         self.wt_bf16 = None  # transposed image for dgrad
 
     def refresh(self):
+        """Rebuild the bf16 kernel-layout copy (and, when its storage is managed by a
+        ParamArena, the transposed dgrad image) of this conv's weight."""
         w = self.weight.detach()
         if self.w_bf16 is None or self.w_bf16.device != w.device:
             self.w_bf16 = torch.zeros(
                 (self.cout, *self.k, self.cin_pad), dtype=ops.BF16, device=w.device
             ).permute(0, 4, 1, 2, 3)
+            self.arena_managed = False
         if self.cin_pad == self.cin:
             ops.cast_bf16(w, self.w_bf16)  # identical memory order
         else:
             self.w_bf16[:, : self.cin].copy_(w)
-        self.wt_bf16 = None
+        if getattr(self, "arena_managed", False):
+            ops.weight_transpose(self.w_bf16, out=self.wt_bf16)
+        else:
+            self.wt_bf16 = None
 
     def wt(self):
         if self.wt_bf16 is None:
@@ -82,6 +88,7 @@ class BN3dP(nn.Module):
         self.register_buffer("running_mean", torch.zeros(c))
         self.register_buffer("running_var", torch.ones(c))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.fold = None  # eval-mode (scale, shift), cached by the trunk
 
 
 def _set_grad(param, g):
@@ -95,12 +102,12 @@ def _set_grad(param, g):
 class _Unit:
     """conv -> BN (-> +residual) (-> ReLU) executed on the HIP kernels."""
 
+    trace = None  # debugging: set to a list to record (conv, y, z, mean, invstd) per unit
+
     @staticmethod
     def fwd(conv, bn, x, relu, residual=None, out=None, train=False, saved=None):
         if not train:
-            scale, shift, _, _ = ops.bn_finalize(
-                None, 0, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum,
-                bn.eps, train=False)
+            scale, shift = bn.fold
             y, _ = ops.conv_fwd(x, conv.w_bf16, conv.k, conv.s, conv.p, out=out, scale=scale,
                                 shift=shift, residual=residual, relu=relu)
             return y
@@ -109,6 +116,8 @@ class _Unit:
             partials, ops.act_rows(y), bn.weight, bn.bias, bn.running_mean, bn.running_var,
             bn.momentum, bn.eps, train=True)
         z = ops.bn_apply(y, scale, shift, residual, relu, out=out)
+        if _Unit.trace is not None:
+            _Unit.trace.append((conv, y.float().cpu(), z.float().cpu(), mean.cpu(), invstd.cpu()))
         saved.append(dict(conv=conv, bn=bn, x=x, y=y, z=z, mean=mean, invstd=invstd, relu=relu))
         return z
 
@@ -117,10 +126,13 @@ class _Unit:
         """Returns (dx|None, dres|None).  `masked`: dz already carries the ReLU mask."""
         conv, bn = rec["conv"], rec["bn"]
         relu = rec["relu"] and not masked
-        dy, dres, dgamma, dbeta = ops.bn_bwd(
-            dz, rec["z"], rec["y"], rec["mean"], rec["invstd"], bn.weight, relu, want_dres)
-        _set_grad(bn.weight, dgamma)
-        _set_grad(bn.bias, dbeta)
+        if bn.weight.grad is None:
+            bn.weight.grad = torch.zeros_like(bn.weight)
+        if bn.bias.grad is None:
+            bn.bias.grad = torch.zeros_like(bn.bias)
+        dy, dres, _, _ = ops.bn_bwd(
+            dz, rec["z"], rec["y"], rec["mean"], rec["invstd"], bn.weight, relu, want_dres,
+            dgamma=bn.weight.grad, dbeta=bn.bias.grad)
         x = rec["x"]
         if conv.cin_pad == conv.cin:
             if conv.weight.grad is None:
@@ -325,6 +337,8 @@ class VideoTrunk(nn.Module):
         for p in range(self.num_pathways):
             self.add_module(f"pathway{p}_pool", PathwayPool(self.pool1[p][0]))
         self._weights_version = None
+        self._folds_version = None
+        self._stats_epoch = 0  # bumped whenever a train-mode pass rewrites running stats
         self.debug_taps = None  # set to a dict to record the activations after every stage
 
     # ---- weights ----------------------------------------------------------------
@@ -341,6 +355,25 @@ class VideoTrunk(nn.Module):
 
     def _version_key(self):
         return tuple((c.weight._version, c.weight.data_ptr()) for c in self._convs())
+
+    def _bns(self):
+        return [m for m in self.modules() if isinstance(m, BN3dP)]
+
+    def _fold_key(self):
+        return (self._stats_epoch,) + tuple(
+            (b.weight._version, b.bias._version, b.running_mean._version, b.running_var._version,
+             b.weight.data_ptr()) for b in self._bns())
+
+    def _ensure_folds(self):
+        """Eval mode: BN folds to a per-channel (scale, shift) applied in the conv epilogue;
+        recomputed only when parameters / running statistics changed."""
+        key = self._fold_key()
+        if self._folds_version != key:
+            for b in self._bns():
+                sc, sh, _, _ = ops.bn_finalize(None, 0, b.weight, b.bias, b.running_mean,
+                                               b.running_var, b.momentum, b.eps, train=False)
+                b.fold = (sc, sh)
+            self._folds_version = key
 
     # ---- forward ------------------------------------------------------------------
     def forward_features(self, x):
@@ -367,6 +400,9 @@ class VideoTrunk(nn.Module):
         if train:
             bns = [m.num_batches_tracked for m in self.modules() if isinstance(m, BN3dP)]
             torch._foreach_add_(bns, 1)
+            self._stats_epoch += 1
+        else:
+            self._ensure_folds()
         # ---- s1 (+ fuse): stems write straight into the concat buffer of the slow path
         cur = []
         for p in range(P):
