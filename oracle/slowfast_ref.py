@@ -31,7 +31,7 @@ import torch
 from torch import nn
 
 # ---- published structure constants of the upstream network ------------------
-STAGE_DEPTH = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), "tiny": (1, 0, 0, 1)}
+STAGE_DEPTH = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), "tiny": (1, 0, 0, 1), "mini": (1, 1, 1, 1)}
 
 # temporal kernel of conv1 / res2 .. res5, per pathway
 TEMPORAL_KERNEL_BASIS = {

@@ -29,7 +29,9 @@ def _dense_view(buf, off, p):
 
 
 class ParamArena:
-    def __init__(self, model):
+    def __init__(self, model, adopt_conv=True):
+        """adopt_conv=False keeps only the flat fp32 parameter / gradient bookkeeping (what the
+        CPU gloo tests exercise); True also moves the bf16 kernel weights into arenas (GPU)."""
         self.model = model
         self.params = [p for p in model.parameters() if p.requires_grad]
         dev = self.params[0].device
@@ -47,7 +49,9 @@ class ParamArena:
                 p.data = v
                 p.grad = _dense_view(self.grad, off, p)
         self.numel = total
-        self._adopt_conv_weights(dev)
+        self._tr_table, self._loose_convs, self.data_bf16 = None, [], None
+        if adopt_conv:
+            self._adopt_conv_weights(dev)
 
     def _adopt_conv_weights(self, dev):
         """bf16 kernel-layout weights and their transposed dgrad images become views into two
@@ -99,6 +103,8 @@ class ParamArena:
     def refresh(self):
         """After the fp32 arena changed (optimizer step, broadcast, load): one cast, one
         batched transpose, the two padded stems, and the trunks are marked up to date."""
+        if self.data_bf16 is None:
+            return
         ops.cast_bf16(self.data, self.data_bf16)
         if self._tr_table is not None:
             ops.weight_transpose_batched(self.data_bf16, self.wt_bf16, self._tr_table, self._tr_total)

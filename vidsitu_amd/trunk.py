@@ -21,7 +21,7 @@ from torch import nn
 
 from . import ops
 
-STAGE_DEPTH = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), "tiny": (1, 0, 0, 1)}
+STAGE_DEPTH = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), "tiny": (1, 0, 0, 1), "mini": (1, 1, 1, 1)}
 TEMPORAL_KERNEL_BASIS = {
     "c2d": [[[1]], [[1]], [[1]], [[1]], [[1]]],
     "i3d": [[[5]], [[3]], [[3, 1]], [[3, 1]], [[1, 3]]],
