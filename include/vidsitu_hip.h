@@ -169,19 +169,23 @@ int vs_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, 
 /* softmax(Q_h K_h^T / scale) V_h for short sequences (L <= 16), per head.
  * q,k,v,o: [B, L, H*dh] fp32.  utils/transformer_code.py:33-48,60-68 --
  * scale is sqrt(d_model) there, passed explicitly. */
+/* drop_mask (nullable): [B,H,L,L] fp32 holding 0 or 1/(1-p), the train-mode dropout of the
+ * attention probabilities (transformer_code.py:48); probs keeps the pre-dropout softmax. */
 int vs_attn_small_fwd(const float* q, const float* k, const float* v, float* o, float* probs,
-                      int B, int L, int H, int dh, float scale, void* stream);
+                      const float* drop_mask, int B, int L, int H, int dh, float scale,
+                      void* stream);
 int vs_attn_small_bwd(const float* q, const float* k, const float* v, const float* probs,
-                      const float* dout, float* dq, float* dk, float* dv, int B, int L, int H,
-                      int dh, float scale, void* stream);
+                      const float* dout, float* dq, float* dk, float* dv, const float* drop_mask,
+                      int B, int L, int H, int dh, float scale, void* stream);
 
-/* y = LayerNorm(x + r) (utils/transformer_code.py:21-30), fp32, eps given. */
-int vs_add_layernorm_fwd(const float* x, const float* r, const float* gamma, const float* beta,
-                         float* y, float* mean, float* rstd, int rows, int D, float eps,
-                         void* stream);
-int vs_add_layernorm_bwd(const float* dy, const float* x, const float* r, const float* gamma,
-                         const float* mean, const float* rstd, float* dx, float* dgamma_partial,
-                         float* dbeta_partial, int rows, int D, void* stream);
+/* y = LayerNorm(x + r*rmask) (utils/transformer_code.py:21-30: x + dropout(layer(x))), fp32.
+ * rmask (nullable): [rows,D] holding 0 or 1/(1-p).  bwd: dx = d(x), dr = dx*rmask. */
+int vs_add_layernorm_fwd(const float* x, const float* r, const float* rmask, const float* gamma,
+                         const float* beta, float* y, float* mean, float* rstd, int rows, int D,
+                         float eps, void* stream);
+int vs_add_layernorm_bwd(const float* dy, const float* x, const float* r, const float* rmask,
+                         const float* gamma, const float* mean, const float* rstd, float* dx,
+                         float* dr, float* dgamma, float* dbeta, int rows, int D, void* stream);
 
 /* Fused cross-entropy (mean) fwd + dlogits (mdl_sf_base.py:226-231) and the
  * softmax -> descending sort -> top-k verb indices of EvalB

@@ -113,11 +113,79 @@ def test_add_layernorm(rows, D, dev):
     assert_close(y, ref, TOL, "layernorm")
     dy = torch.randn(rows, D, generator=g)
     gx, gr, gg, gb = torch.autograd.grad(ref, [x, r, gamma, beta], dy)
-    dx, dg, db = ops.add_layernorm_bwd(dy.to(dev), x.detach().to(dev), r.detach().to(dev),
-                                       gamma.detach().to(dev), mean, rstd)
+    dx, dr, dg, db = ops.add_layernorm_bwd(dy.to(dev), x.detach().to(dev), r.detach().to(dev),
+                                           gamma.detach().to(dev), mean, rstd)
     assert_close(dx, gx, TOL, "dx")
+    assert_close(dr, gr, TOL, "dr")
     assert_close(dg, gg, TOL, "dgamma")
     assert_close(db, gb, TOL, "dbeta")
+
+
+def test_dropout_masks_in_attention_and_residual(dev):
+    """Train-mode dropout sites of transformer_code.py (:48 on the attention probabilities,
+    :30 on the residual branch) with explicit masks vs the same masks applied in torch."""
+    from vidsitu_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    B, L, H, dh, p = 2, 5, 4, 16, 0.25
+    q, k, v = [torch.randn(B, L, H * dh, generator=g).requires_grad_() for _ in range(3)]
+    mask = (torch.rand(B, H, L, L, generator=g) >= p).float() / (1 - p)
+    scale = (H * dh) ** 0.5
+    outs = []
+    for h in range(H):
+        sl = slice(h * dh, (h + 1) * dh)
+        pr = F.softmax(q[..., sl] @ k[..., sl].transpose(1, 2) / scale, -1) * mask[:, h]
+        outs.append(pr @ v[..., sl])
+    ref = torch.cat(outs, -1)
+    o, probs = ops.attn_small_fwd(q.detach().to(dev), k.detach().to(dev), v.detach().to(dev), H, scale,
+                                  mask.to(dev))
+    assert_close(o, ref, TOL, "attention with dropout")
+    do = torch.randn(ref.shape, generator=g)
+    gq, gk, gv = torch.autograd.grad(ref, [q, k, v], do)
+    dq, dk, dv = ops.attn_small_bwd(q.detach().to(dev), k.detach().to(dev), v.detach().to(dev), probs,
+                                    do.to(dev), H, scale, mask.to(dev))
+    assert_close(dq, gq, TOL, "dq")
+    assert_close(dk, gk, TOL, "dk")
+    assert_close(dv, gv, TOL, "dv")
+    rows, D = 10, 64
+    x, r = torch.randn(rows, D, generator=g).requires_grad_(), torch.randn(rows, D, generator=g).requires_grad_()
+    gamma, beta = (torch.rand(D, generator=g) + 0.5), torch.randn(D, generator=g)
+    rmask = (torch.rand(rows, D, generator=g) >= p).float() / (1 - p)
+    ref = F.layer_norm(x + r * rmask, (D,), gamma, beta, 1e-5)
+    y, mean, rstd = ops.add_layernorm_fwd(x.detach().to(dev), r.detach().to(dev), gamma.to(dev),
+                                          beta.to(dev), 1e-5, rmask.to(dev))
+    assert_close(y, ref, TOL, "LN(x + dropout(r))")
+    dy = torch.randn(rows, D, generator=g)
+    gx, gr = torch.autograd.grad(ref, [x, r], dy)
+    dx, dr, _, _ = ops.add_layernorm_bwd(dy.to(dev), x.detach().to(dev), r.detach().to(dev), gamma.to(dev),
+                                         mean, rstd, rmask.to(dev))
+    assert_close(dx, gx, TOL, "dx")
+    assert_close(dr, gr, TOL, "dr (masked)")
+
+
+def test_txenc_train_mode_dropout_statistics(dev):
+    """Encoder in train mode: runs end to end with dropout 0.1, is stochastic, differentiable,
+    and equals the eval output when the masks are forced to one."""
+    from vidsitu_amd import ops
+    from vidsitu_amd.transformer_code import Transformer
+
+    torch.manual_seed(0)
+    mdl = Transformer(d_model=64, n_vocab_src=0, vocab_trg=0, d_hidden=64, n_layers=2, n_heads=8,
+                      drop_ratio=0.1).to(dev)
+    x = torch.randn(3, 5, 64, device=dev, requires_grad=True)
+    mdl.train()
+    a, b = mdl(x), mdl(x)
+    assert float((a - b).abs().max()) > 1e-3  # different masks
+    a.sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
+    keep = ops.dropout_mask
+    try:
+        ops.dropout_mask = lambda shape, p, device: torch.ones(shape, device=device)
+        c = mdl(x)
+    finally:
+        ops.dropout_mask = keep
+    mdl.eval()
+    assert_close(c, mdl(x), 1e-6, "train mode with unit masks == eval")
 
 
 def test_softmax_xent_and_topk(dev):

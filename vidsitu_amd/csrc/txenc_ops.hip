@@ -193,7 +193,8 @@ extern "C" int vs_linear_bwd_weight(const float* dy, const float* x, float* dw, 
 
 __global__ __launch_bounds__(256) void attn_small_fwd_kernel(const float* q, const float* k,
                                                              const float* v, float* o, float* probs,
-                                                             int L, int H, int dh, float inv_scale) {
+                                                             const float* drop_mask, int L, int H,
+                                                             int dh, float inv_scale) {
   extern __shared__ __attribute__((aligned(16))) char smem_att[];
   float* qs = (float*)smem_att;  // [L][dh]
   float* ks = qs + L * dh;
@@ -229,8 +230,9 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(const float* q, con
     const float inv = 1.0f / den;
     for (int j = 0; j < L; ++j) {
       const float pj = ps[i * L + j] * inv;
-      ps[i * L + j] = pj;
-      if (probs) probs[(((long long)b * H + h) * L + i) * L + j] = pj;
+      const long long pidx = (((long long)b * H + h) * L + i) * L + j;
+      if (probs) probs[pidx] = pj;  // pre-dropout probabilities (softmax backward needs them)
+      ps[i * L + j] = drop_mask ? pj * drop_mask[pidx] : pj;
     }
   }
   __syncthreads();
@@ -243,13 +245,13 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(const float* q, con
 }
 
 extern "C" int vs_attn_small_fwd(const float* q, const float* k, const float* v, float* o,
-                                 float* probs, int B, int L, int H, int dh, float scale,
-                                 void* stream) {
+                                 float* probs, const float* drop_mask, int B, int L, int H, int dh,
+                                 float scale, void* stream) {
   VS_CHECK_ARG(q && k && v && o, "null tensor");
   VS_CHECK_ARG(L >= 1 && L <= ATT_MAXL && dh >= 1 && dh <= 512, "L <= 16, dh <= 512");
   const size_t smem = (size_t)(3 * L * dh + L * L) * sizeof(float);
   hipLaunchKernelGGL(attn_small_fwd_kernel, dim3(B * H), dim3(256), smem, (hipStream_t)stream, q, k,
-                     v, o, probs, L, H, dh, 1.0f / scale);
+                     v, o, probs, drop_mask, L, H, dh, 1.0f / scale);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }
@@ -257,15 +259,16 @@ extern "C" int vs_attn_small_fwd(const float* q, const float* k, const float* v,
 __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* q, const float* k,
                                                              const float* v, const float* probs,
                                                              const float* dout, float* dq, float* dk,
-                                                             float* dv, int L, int H, int dh,
-                                                             float inv_scale) {
+                                                             float* dv, const float* drop_mask,
+                                                             int L, int H, int dh, float inv_scale) {
   extern __shared__ __attribute__((aligned(16))) char smem_att[];
   float* qs = (float*)smem_att;  // [L][dh]
   float* ks = qs + L * dh;
   float* vs = ks + L * dh;
   float* dos = vs + L * dh;
-  float* ps = dos + L * dh;  // [L][L]
+  float* ps = dos + L * dh;  // [L][L]  pre-dropout probabilities
   float* dss = ps + L * L;   // [L][L]
+  float* ms = dss + L * L;   // [L][L]  dropout mask (1 when absent)
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const int D = H * dh;
   for (int i = threadIdx.x; i < L * dh; i += 256) {
@@ -276,15 +279,17 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* q, con
     vs[i] = v[off];
     dos[i] = dout[off];
   }
-  for (int e = threadIdx.x; e < L * L; e += 256)
+  for (int e = threadIdx.x; e < L * L; e += 256) {
     ps[e] = probs[((long long)b * H + h) * L * L + e];
+    ms[e] = drop_mask ? drop_mask[((long long)b * H + h) * L * L + e] : 1.f;
+  }
   __syncthreads();
-  // dP[i][j] = dO[i] . V[j]
+  // dP[i][j] = mask * (dO[i] . V[j])
   for (int e = threadIdx.x; e < L * L; e += 256) {
     const int i = e / L, j = e - i * L;
     float s = 0.f;
     for (int d = 0; d < dh; ++d) s += dos[i * dh + d] * vs[j * dh + d];
-    dss[e] = s;
+    dss[e] = s * ms[e];
   }
   __syncthreads();
   // dS = P * (dP - sum_j dP*P) / scale
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* q, con
     for (int j = 0; j < L; ++j) {
       aq += dss[r * L + j] * ks[j * dh + d];   // dQ[r] = sum_j dS[r][j] K[j]
       ak += dss[j * L + r] * qs[j * dh + d];   // dK[r] = sum_i dS[i][r] Q[i]
-      av += ps[j * L + r] * dos[j * dh + d];   // dV[r] = sum_i P[i][r] dO[i]
+      av += ps[j * L + r] * ms[j * L + r] * dos[j * dh + d];  // dV[r] = sum_i P'[i][r] dO[i]
     }
     const long long off = ((long long)b * L + r) * D + h * dh + d;
     dq[off] = aq;
@@ -312,13 +317,13 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* q, con
 
 extern "C" int vs_attn_small_bwd(const float* q, const float* k, const float* v,
                                  const float* probs, const float* dout, float* dq, float* dk,
-                                 float* dv, int B, int L, int H, int dh, float scale,
-                                 void* stream) {
+                                 float* dv, const float* drop_mask, int B, int L, int H, int dh,
+                                 float scale, void* stream) {
   VS_CHECK_ARG(q && k && v && probs && dout && dq && dk && dv, "null tensor");
   VS_CHECK_ARG(L >= 1 && L <= ATT_MAXL && dh >= 1 && dh <= 512, "L <= 16, dh <= 512");
-  const size_t smem = (size_t)(4 * L * dh + 2 * L * L) * sizeof(float);
+  const size_t smem = (size_t)(4 * L * dh + 3 * L * L) * sizeof(float);
   hipLaunchKernelGGL(attn_small_bwd_kernel, dim3(B * H), dim3(256), smem, (hipStream_t)stream, q, k,
-                     v, probs, dout, dq, dk, dv, L, H, dh, 1.0f / scale);
+                     v, probs, dout, dq, dk, dv, drop_mask, L, H, dh, 1.0f / scale);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }
@@ -328,7 +333,15 @@ extern "C" int vs_attn_small_bwd(const float* q, const float* k, const float* v,
 // ----------------------------------------------------------------------------
 #define LN_MAXE 32  // elements per lane (D <= 2048)
 
+__device__ __forceinline__ float ln_input(const float* x, const float* r, const float* rmask,
+                                          long long i) {
+  float v = x[i];
+  if (r) v += rmask ? r[i] * rmask[i] : r[i];
+  return v;
+}
+
 __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* x, const float* r,
+                                                                const float* rmask,
                                                                 const float* gamma,
                                                                 const float* beta, float* y,
                                                                 float* mean, float* rstd, int rows,
@@ -343,7 +356,7 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* x, 
     const int d = lane + 64 * e;
     v[e] = 0.f;
     if (d < D) {
-      v[e] = x[(long long)row * D + d] + (r ? r[(long long)row * D + d] : 0.f);
+      v[e] = ln_input(x, r, rmask, (long long)row * D + d);
       s += v[e];
     }
   }
@@ -369,21 +382,21 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* x, 
   }
 }
 
-extern "C" int vs_add_layernorm_fwd(const float* x, const float* r, const float* gamma,
-                                    const float* beta, float* y, float* mean, float* rstd,
-                                    int rows, int D, float eps, void* stream) {
+extern "C" int vs_add_layernorm_fwd(const float* x, const float* r, const float* rmask,
+                                    const float* gamma, const float* beta, float* y, float* mean,
+                                    float* rstd, int rows, int D, float eps, void* stream) {
   VS_CHECK_ARG(x && gamma && beta && y && rows > 0, "bad args");
   VS_CHECK_ARG(D >= 1 && D <= 64 * LN_MAXE, "D <= 2048");
   hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0,
-                     (hipStream_t)stream, x, r, gamma, beta, y, mean, rstd, rows, D, eps);
+                     (hipStream_t)stream, x, r, rmask, gamma, beta, y, mean, rstd, rows, D, eps);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }
 
 // dx = rstd * (g - mean(g) - xhat*mean(g*xhat)), g = gamma*dy ; per-row wave
 __global__ __launch_bounds__(256) void add_layernorm_bwd_dx_kernel(
-    const float* dy, const float* x, const float* r, const float* gamma, const float* mean,
-    const float* rstd, float* dx, int rows, int D) {
+    const float* dy, const float* x, const float* r, const float* rmask, const float* gamma,
+    const float* mean, const float* rstd, float* dx, float* dr, int rows, int D) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -396,7 +409,7 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_dx_kernel(
     g[e] = 0.f;
     xh[e] = 0.f;
     if (d < D) {
-      const float v = x[(long long)row * D + d] + (r ? r[(long long)row * D + d] : 0.f);
+      const float v = ln_input(x, r, rmask, (long long)row * D + d);
       xh[e] = (v - mu) * rs;
       g[e] = gamma[d] * dy[(long long)row * D + d];
       s1 += g[e];
@@ -407,19 +420,24 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_dx_kernel(
 #pragma unroll
   for (int e = 0; e < LN_MAXE; ++e) {
     const int d = lane + 64 * e;
-    if (d < D) dx[(long long)row * D + d] = rs * (g[e] - m1 - xh[e] * m2);
+    if (d < D) {
+      const float dv = rs * (g[e] - m1 - xh[e] * m2);
+      dx[(long long)row * D + d] = dv;
+      if (dr) dr[(long long)row * D + d] = rmask ? dv * rmask[(long long)row * D + d] : dv;
+    }
   }
 }
 
 // dgamma[d] = sum_rows dy*xhat ; dbeta[d] = sum_rows dy   (thread per column)
 __global__ void add_layernorm_bwd_param_kernel(const float* dy, const float* x, const float* r,
-                                               const float* mean, const float* rstd, float* dgamma,
-                                               float* dbeta, int rows, int D) {
+                                               const float* rmask, const float* mean,
+                                               const float* rstd, float* dgamma, float* dbeta,
+                                               int rows, int D) {
   const int d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= D) return;
   float sg = 0.f, sb = 0.f;
   for (int row = 0; row < rows; ++row) {
-    const float v = x[(long long)row * D + d] + (r ? r[(long long)row * D + d] : 0.f);
+    const float v = ln_input(x, r, rmask, (long long)row * D + d);
     const float g = dy[(long long)row * D + d];
     sg += g * (v - mean[row]) * rstd[row];
     sb += g;
@@ -429,15 +447,15 @@ __global__ void add_layernorm_bwd_param_kernel(const float* dy, const float* x, 
 }
 
 extern "C" int vs_add_layernorm_bwd(const float* dy, const float* x, const float* r,
-                                    const float* gamma, const float* mean, const float* rstd,
-                                    float* dx, float* dgamma, float* dbeta, int rows, int D,
-                                    void* stream) {
+                                    const float* rmask, const float* gamma, const float* mean,
+                                    const float* rstd, float* dx, float* dr, float* dgamma,
+                                    float* dbeta, int rows, int D, void* stream) {
   VS_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "null tensor");
   VS_CHECK_ARG(D >= 1 && D <= 64 * LN_MAXE, "D <= 2048");
   hipLaunchKernelGGL(add_layernorm_bwd_dx_kernel, dim3((rows + 3) / 4), dim3(256), 0,
-                     (hipStream_t)stream, dy, x, r, gamma, mean, rstd, dx, rows, D);
+                     (hipStream_t)stream, dy, x, r, rmask, gamma, mean, rstd, dx, dr, rows, D);
   hipLaunchKernelGGL(add_layernorm_bwd_param_kernel, dim3((D + 255) / 256), dim3(256), 0,
-                     (hipStream_t)stream, dy, x, r, mean, rstd, dgamma, dbeta, rows, D);
+                     (hipStream_t)stream, dy, x, r, rmask, mean, rstd, dgamma, dbeta, rows, D);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }

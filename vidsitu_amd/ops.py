@@ -360,46 +360,54 @@ def linear_bwd(dy, x, w, need_dx=True, has_bias=True):
     return dx, dw, db
 
 
-def attn_small_fwd(q, k, v, n_heads, scale):
+def dropout_mask(shape, p, device):
+    """0 or 1/(1-p) per element, from torch's (hipGraph-safe) generator."""
+    return (torch.rand(shape, device=device) >= p).to(torch.float32).mul_(1.0 / (1.0 - p))
+
+
+def attn_small_fwd(q, k, v, n_heads, scale, drop_mask=None):
     q, k, v = _f32c(q), _f32c(k), _f32c(v)
     b, l, d = q.shape
     o = torch.empty_like(q)
     probs = torch.empty((b, n_heads, l, l), dtype=torch.float32, device=q.device)
-    _lib.call("vs_attn_small_fwd", _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(probs), b, l, n_heads,
-              d // n_heads, float(scale), _stream())
+    _lib.call("vs_attn_small_fwd", _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(probs),
+              _ptr(drop_mask), b, l, n_heads, d // n_heads, float(scale), _stream())
     return o, probs
 
 
-def attn_small_bwd(q, k, v, probs, do, n_heads, scale):
+def attn_small_bwd(q, k, v, probs, do, n_heads, scale, drop_mask=None):
     do = _f32c(do)
     b, l, d = q.shape
     dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
     _lib.call("vs_attn_small_bwd", _ptr(q), _ptr(k), _ptr(v), _ptr(probs), _ptr(do), _ptr(dq),
-              _ptr(dk), _ptr(dv), b, l, n_heads, d // n_heads, float(scale), _stream())
+              _ptr(dk), _ptr(dv), _ptr(drop_mask), b, l, n_heads, d // n_heads, float(scale),
+              _stream())
     return dq, dk, dv
 
 
-def add_layernorm_fwd(x, r, gamma, beta, eps=1e-5):
+def add_layernorm_fwd(x, r, gamma, beta, eps=1e-5, rmask=None):
     x = _f32c(x)
     r = _f32c(r) if r is not None else None
     rows, d = x.shape
     y = torch.empty_like(x)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-    _lib.call("vs_add_layernorm_fwd", _ptr(x), _ptr(r), _ptr(gamma), _ptr(beta), _ptr(y),
-              _ptr(mean), _ptr(rstd), rows, d, float(eps), _stream())
+    _lib.call("vs_add_layernorm_fwd", _ptr(x), _ptr(r), _ptr(rmask), _ptr(gamma), _ptr(beta),
+              _ptr(y), _ptr(mean), _ptr(rstd), rows, d, float(eps), _stream())
     return y, mean, rstd
 
 
-def add_layernorm_bwd(dy, x, r, gamma, mean, rstd):
+def add_layernorm_bwd(dy, x, r, gamma, mean, rstd, rmask=None):
+    """Returns (dx, dr, dgamma, dbeta); dr = dx * rmask."""
     dy = _f32c(dy)
     rows, d = x.shape
     dx = torch.empty_like(x)
+    dr = torch.empty_like(x) if rmask is not None else None
     dg = torch.empty(d, dtype=torch.float32, device=x.device)
     db = torch.empty(d, dtype=torch.float32, device=x.device)
-    _lib.call("vs_add_layernorm_bwd", _ptr(dy), _ptr(x), _ptr(r), _ptr(gamma), _ptr(mean),
-              _ptr(rstd), _ptr(dx), _ptr(dg), _ptr(db), rows, d, _stream())
-    return dx, dg, db
+    _lib.call("vs_add_layernorm_bwd", _ptr(dy), _ptr(x), _ptr(r), _ptr(rmask), _ptr(gamma),
+              _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dr), _ptr(dg), _ptr(db), rows, d, _stream())
+    return dx, (dr if dr is not None else dx), dg, db
 
 
 def softmax_xent(logits, labels, want_grad=True):

@@ -43,38 +43,37 @@ class AttnSmallFn(torch.autograd.Function):
     """concat_h softmax(Q_h K_h^T / scale) V_h for L <= 16 (vs_attn_small_*)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, n_heads, scale):
-        o, probs = ops.attn_small_fwd(q, k, v, n_heads, scale)
-        ctx.save_for_backward(q, k, v, probs)
+    def forward(ctx, q, k, v, n_heads, scale, drop_mask):
+        o, probs = ops.attn_small_fwd(q, k, v, n_heads, scale, drop_mask)
+        ctx.save_for_backward(q, k, v, probs, drop_mask)
         ctx.n_heads, ctx.scale = n_heads, scale
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, probs = ctx.saved_tensors
+        q, k, v, probs, drop_mask = ctx.saved_tensors
         dq, dk, dv = ops.attn_small_bwd(q.contiguous(), k.contiguous(), v.contiguous(), probs, do,
-                                        ctx.n_heads, ctx.scale)
-        return dq, dk, dv, None, None
+                                        ctx.n_heads, ctx.scale, drop_mask)
+        return dq, dk, dv, None, None, None
 
 
 class AddLayerNormFn(torch.autograd.Function):
-    """LayerNorm(x + r) (vs_add_layernorm_*)."""
+    """LayerNorm(x + r * rmask) (vs_add_layernorm_*); rmask = residual-dropout mask or None."""
 
     @staticmethod
-    def forward(ctx, x, r, gamma, beta, eps):
+    def forward(ctx, x, r, gamma, beta, eps, rmask):
         shp = x.shape
         x2, r2 = x.reshape(-1, shp[-1]).contiguous(), r.reshape(-1, shp[-1]).contiguous()
-        y, mean, rstd = ops.add_layernorm_fwd(x2, r2, gamma, beta, eps)
-        ctx.save_for_backward(x2, r2, gamma, mean, rstd)
+        y, mean, rstd = ops.add_layernorm_fwd(x2, r2, gamma, beta, eps, rmask)
+        ctx.save_for_backward(x2, r2, gamma, mean, rstd, rmask)
         ctx.shp = shp
         return y.reshape(shp)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, r2, gamma, mean, rstd = ctx.saved_tensors
-        dx, dg, db = ops.add_layernorm_bwd(dy.reshape(x2.shape), x2, r2, gamma, mean, rstd)
-        dx = dx.reshape(ctx.shp)
-        return dx, dx, dg, db, None
+        x2, r2, gamma, mean, rstd, rmask = ctx.saved_tensors
+        dx, dr, dg, db = ops.add_layernorm_bwd(dy.reshape(x2.shape), x2, r2, gamma, mean, rstd, rmask)
+        return dx.reshape(ctx.shp), dr.reshape(ctx.shp), dg, db, None, None
 
 
 def hip_linear(mod, x, relu=False):
@@ -102,12 +101,13 @@ class MultiHead(nn.Module):
         self.n_heads = n_heads
 
     def forward(self, query, key, value):
-        if self.training and self.attention.dropout.p > 0:
-            raise NotImplementedError(
-                "attention-probability dropout in training mode: set tx_dec.dropout=0 "
-                "(the eval path and the dropout-free training path run on HIP)")
         q, k, v = hip_linear(self.wq, query), hip_linear(self.wk, key), hip_linear(self.wv, value)
-        o = AttnSmallFn.apply(q, k, v, self.n_heads, self.attention.scale)
+        mask = None
+        p = self.attention.dropout.p
+        if self.training and p > 0:  # transformer_code.py:48 dropout(softmax(...))
+            b, l, _ = q.shape
+            mask = ops.dropout_mask((b, self.n_heads, l, l), p, q.device)
+        o = AttnSmallFn.apply(q, k, v, self.n_heads, self.attention.scale, mask)
         return hip_linear(self.wo, o)
 
 
@@ -130,10 +130,12 @@ class ResidualBlock(nn.Module):
 
     def forward(self, *x):
         branch = self.layer(*x)
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError("residual dropout in training mode: set tx_dec.dropout=0")
+        rmask = None
+        if self.training and self.dropout.p > 0:  # transformer_code.py:30 x + dropout(layer(x))
+            rmask = ops.dropout_mask((branch.numel() // branch.shape[-1], branch.shape[-1]),
+                                     self.dropout.p, branch.device)
         return AddLayerNormFn.apply(x[0], branch, self.layernorm.weight, self.layernorm.bias,
-                                    self.layernorm.eps)
+                                    self.layernorm.eps, rmask)
 
 
 class EncoderLayer(nn.Module):
