@@ -72,6 +72,15 @@ int vs_version(void);
 int vs_pack_input(const void* x, int x_is_bf16, void* y, int N, int C, int T, int H, int W,
                   int Cpad, void* stream);
 
+/* Stem convolution Conv3d(3 -> Cout, [kT,7,7], stride [1,2,2], pad [kT/2,3,3]) (the two
+ * `pathway{p}_stem.conv` of s1).  x4: NDHWC bf16 with C padded to 4 (vs_pack_input, Cpad = 4);
+ * wp: bf16 [ceil16(Cout)][kT][7][8][4] (kw 7 -> 8 and Cin 3 -> 4 zero-padded);
+ * flags: VS_CONV_AFFINE | RELU | STATS; stats_partial: [vs_stem_stats_rows][2][Cout]. */
+int vs_stem_conv_fwd(const void* x4, const void* wp, void* y, int N, int T, int H, int W, int Cout,
+                     int kT, int y_ld, int flags, const float* scale, const float* shift,
+                     float* stats_partial, void* stream);
+int vs_stem_stats_rows(int N, int T, int H, int W);
+
 /* Forward conv as implicit GEMM on bf16 MFMA, fp32 accumulate.
  *   stats_partial: [vs_conv_stats_rows(desc)][2][Cout] fp32 when VS_CONV_STATS.
  *   in_scale/in_shift: [Cin] fp32 when VS_CONV_APRO. */
@@ -199,6 +208,11 @@ int vs_softmax_topk(const float* logits, float* probs_out, int64_t* idx_out, int
  * fp32 parameter / gradient arena; grad_scale folds the DDP 1/world_size. */
 int vs_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                  float beta2, float eps, int step, float grad_scale, void* stream);
+/* Same, with the step count kept in device memory (incremented by the call): safe to capture
+ * in a hipGraph and replay. */
+int vs_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                     float beta1, float beta2, float eps, int* step_counter, float grad_scale,
+                     void* stream);
 /* fp32 -> bf16 cast of the parameter arena (weights used by the conv kernels). */
 int vs_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 

@@ -169,3 +169,29 @@ def test_pack_input_layout(dev):
     assert float(y[:, 3:].float().abs().max()) == 0.0
     y2 = ops.pack_input(x.to(dev).to(torch.bfloat16))
     assert torch.equal(y2.float(), y.float())
+
+
+@pytest.mark.parametrize("cout,kt,t,h,w", [(64, 1, 2, 32, 32), (8, 5, 6, 32, 32), (64, 1, 1, 36, 44),
+                                           (8, 5, 3, 20, 52), (32, 3, 4, 64, 64)])
+def test_stem_kernel_matches_torch(cout, kt, t, h, w, dev):
+    """Dedicated Cin=3 stem kernel (conv_stem.hip): patch-in-LDS implicit GEMM, incl. tile tails,
+    temporal padding, fused affine+ReLU and the BN partials."""
+    from vidsitu_amd import ops
+
+    g = torch.Generator().manual_seed(cout + kt)
+    x = rb(torch.randn(2, 3, t, h, w, generator=g))
+    wt = rb(torch.randn(cout, 3, kt, 7, 7, generator=g) / (147 * kt) ** 0.5)
+    ref = F.conv3d(x, wt, stride=(1, 2, 2), padding=(kt // 2, 3, 3))
+    x4 = ops.pack_input(x.to(dev), 4)
+    assert tuple(x4.shape) == (2, 4, t, h, w)
+    wp = ops.pack_stem_weight(wt.to(dev))
+    y, partials = ops.stem_conv_fwd(x4, wp, cout, kt, stats=True)
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert_close(y, ref, TOL, "stem conv")
+    tot = partials.double().sum(0).cpu()
+    assert torch.allclose(tot[0], ref.double().sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=1e-2)
+    assert torch.allclose(tot[1], (ref.double() ** 2).sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=1e-2)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    y2, _ = ops.stem_conv_fwd(x4, wp, cout, kt, scale=scale.to(dev), shift=shift.to(dev), relu=True)
+    assert_close(y2, F.relu(ref * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)), TOL,
+                 "stem conv + affine + relu")

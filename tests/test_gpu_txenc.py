@@ -226,3 +226,12 @@ def test_adam_matches_torch(dev):
         opt.step()
         ops.adam_step(p, gr.to(dev), m, v, 1e-3, 0.9, 0.99, 1e-8, step)
     assert_close(p, pr.detach(), 1e-6, "adam params after 3 steps")
+    # device-side step counter variant (what a captured hipGraph replays)
+    p2 = p0.to(dev)
+    m2, v2, cnt = torch.zeros_like(p2), torch.zeros_like(p2), torch.zeros(1, dtype=torch.int32, device=dev)
+    g2 = torch.Generator().manual_seed(1)
+    torch.randn(10007, generator=g2)
+    for _ in range(3):
+        ops.adam_step_dev(p2, torch.randn(10007, generator=g2).to(dev), m2, v2, 1e-3, 0.9, 0.99, 1e-8, cnt)
+    assert int(cnt) == 3
+    assert_close(p2, pr.detach(), 1e-6, "adam (device step counter)")

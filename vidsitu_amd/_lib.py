@@ -39,6 +39,8 @@ SIGNATURES = {
     "vs_last_error_string": (C.c_char_p, []),
     "vs_version": (_i, []),
     "vs_pack_input": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "vs_stem_conv_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "vs_stem_stats_rows": (_i, [_i, _i, _i, _i]),
     "vs_conv_fwd": (_i, [_p, _p, _p, _dp, _p, _p, _p, _p, _p, _p, _p]),
     "vs_conv_stats_rows": (_i, [_dp]),
     "vs_conv_dgrad": (_i, [_p, _p, _p, _dp, _p, _p]),
@@ -73,6 +75,7 @@ SIGNATURES = {
     "vs_softmax_xent": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "vs_softmax_topk": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "vs_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _i, _f, _p]),
+    "vs_adam_step_dev": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _p, _f, _p]),
     "vs_cast_f32_to_bf16": (_i, [_p, _p, _i64, _p]),
 }
 

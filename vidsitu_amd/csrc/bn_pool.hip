@@ -14,6 +14,15 @@ __global__ void pack_input_kernel(const void* xin, uint16_t* y, int N, int C, lo
   const long long pos = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // n*THW + s
   if (pos >= (long long)N * THW) return;
   const long long n = pos / THW, s = pos - n * THW;
+  if (Cpad == 4) {  // stem layout: 8 bytes per pixel
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C && c < 4; ++c) {
+      const long long off = (n * C + c) * THW + s;
+      v[c] = IN_BF16 ? bf16_to_f32(((const uint16_t*)xin)[off]) : ((const float*)xin)[off];
+    }
+    *(uint2*)(y + pos * 4) = make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
+    return;
+  }
   for (int c0 = 0; c0 < Cpad; c0 += 8) {
     float v[8];
 #pragma unroll
@@ -33,7 +42,7 @@ __global__ void pack_input_kernel(const void* xin, uint16_t* y, int N, int C, lo
 extern "C" int vs_pack_input(const void* x, int x_is_bf16, void* y, int N, int C, int T, int H,
                              int W, int Cpad, void* stream) {
   VS_CHECK_ARG(x && y, "null tensor");
-  VS_CHECK_ARG(Cpad % 8 == 0 && Cpad >= C, "Cpad must be a multiple of 8 and >= C");
+  VS_CHECK_ARG((Cpad % 8 == 0 || Cpad == 4) && Cpad >= C, "Cpad must be 4 or a multiple of 8, >= C");
   const long long THW = (long long)T * H * W, total = THW * N;
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   if (x_is_bf16)

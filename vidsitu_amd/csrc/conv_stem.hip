@@ -1,0 +1,250 @@
+// Stem convolutions of the SlowFast trunk: Conv3d(3 -> Cout, [kT,7,7], stride [1,2,2],
+// pad [kT/2,3,3]) -- slowfast stem_helper via vidsitu_code/mdl_sf_base.py:22 (s1).
+//
+// Cin = 3 does not fit the 8-channel units of the generic implicit GEMM (padding to 8
+// made the gather move 12.6 GB through L2 per step).  Here the input is NDHWC with C padded
+// to 4 (8 bytes / pixel) and one kernel ROW (dt, dh) is one k = 32 MFMA step: kw padded 7 -> 8,
+// so k = (dw, c) = 8 x 4 and a lane's 8 consecutive k are 2 adjacent pixels = 16 contiguous
+// bytes.  Per 8 x 16 output tile the block stages the input patch (kT x 21 x 38 pixels) in
+// LDS once; A fragments are ds_read_b128 straight from the patch (stride-2 windows are 16-byte
+// aligned because 2*wo + dw0 is even), B fragments come from the whole packed weight
+// [Cout][kT][7][8][4], resident in LDS across a persistent loop over tiles.
+#include "common.h"
+
+#define ST_TH 8
+#define ST_TW 16
+#define ST_PH 21                // 2*8 + 5 input rows
+#define ST_PW 40                // 2*16 + 5 = 37 input pixels, padded to 40
+#define ST_ROWB (ST_PW * 8)     // 320 bytes per patch row
+#define ST_FRAMEB (ST_PH * ST_ROWB)
+
+struct StemP {
+  const uint16_t* x;  // [N][T][H][W][4] bf16
+  const uint16_t* w;  // [CP][kT][7][8][4] bf16
+  uint16_t* y;        // [N][T][Ho][Wo] rows of y_ld
+  const float* scale;
+  const float* shift;
+  float* stats;       // [tiles][2][Cout]
+  int N, T, H, W, Ho, Wo, Cout, kT, y_ld, flags;
+  int tilesH, tilesW, ntiles;
+};
+
+template <int NT>  // NT = padded Cout / 16
+__global__ __launch_bounds__(256) void stem_conv_kernel(StemP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CP = NT * 16;
+  const int K = p.kT * 7 * 32;
+  const int wpitch = K * 2 + 16;
+  char* wlds = smem;                                   // [CP][wpitch]
+  char* patch = smem + ((CP * wpitch + 15) & ~15);     // [kT][21][40] x 8 B
+  const int patch_bytes = p.kT * ST_FRAMEB;
+  float* E = (float*)(patch + ((patch_bytes + 15) & ~15));  // [128][CP] fp32
+  float* statbuf = E + 128 * CP;                        // [2][4][CP]
+
+  const int tid = threadIdx.x;
+  // weights: resident for the whole persistent loop
+  {
+    const int chunks_per_row = K / 8;  // 16-byte chunks
+    for (int i = tid; i < CP * chunks_per_row; i += 256) {
+      const int r = i / chunks_per_row, c = i - r * chunks_per_row;
+      *(u32x4*)(wlds + r * wpitch + c * 16) = *(const u32x4*)(p.w + (long long)r * K + c * 8);
+    }
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int ksteps = p.kT * 7;
+  const int pT = p.kT >> 1;
+
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    int t = tile;
+    const int tw = t % p.tilesW;
+    t /= p.tilesW;
+    const int th = t % p.tilesH;
+    t /= p.tilesH;
+    const int to = t % p.T, n = t / p.T;
+    const int ho0 = th * ST_TH, wo0 = tw * ST_TW;
+    const int hi0 = 2 * ho0 - 3, wi0 = 2 * wo0 - 3;
+
+    __syncthreads();  // previous tile's epilogue / this block's weight fill are done
+    // ---- stage the input patch (zero outside the image / clip) ----
+    for (int i = tid; i < p.kT * ST_PH * ST_PW; i += 256) {
+      const int c = i % ST_PW;
+      int r = i / ST_PW;
+      const int dt = r / ST_PH;
+      r -= dt * ST_PH;
+      const int ti = to - pT + dt, hi = hi0 + r, wi = wi0 + c;
+      uint2 v = make_uint2(0u, 0u);
+      if ((unsigned)ti < (unsigned)p.T && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+        v = *(const uint2*)(p.x + ((((long long)n * p.T + ti) * p.H + hi) * p.W + wi) * 4);
+      *(uint2*)(patch + dt * ST_FRAMEB + r * ST_ROWB + c * 8) = v;
+    }
+    __syncthreads();
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int ks = 0; ks < ksteps; ++ks) {
+      const int dt = ks / 7, dh = ks - dt * 7;
+      bf16x8 af[2], bfr[NT];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int hol = wave * 2 + a;  // one output row per 16-position MFMA row tile
+        af[a] = *(const bf16x8*)(patch + dt * ST_FRAMEB + (2 * hol + dh) * ST_ROWB +
+                                 (2 * lr + 2 * lq) * 8);
+      }
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+        bfr[b] = *(const bf16x8*)(wlds + (b * 16 + lr) * wpitch + (ks * 32 + lq * 8) * 2);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+    }
+
+    // ---- epilogue: D[row = lq*4 + r -> wo_l][col = lr -> cout] ----
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int ho = ho0 + wave * 2 + a;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int wo = wo0 + lq * 4 + r;
+        if (ho >= p.Ho || wo >= p.Wo) {
+#pragma unroll
+          for (int b = 0; b < NT; ++b) acc[a][b][r] = 0.f;  // tile tail: keep out of the stats
+        }
+      }
+    }
+    if (p.flags & VS_CONV_STATS) {
+#pragma unroll
+      for (int b = 0; b < NT; ++b) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = acc[a][b][r];
+            s += v;
+            q += v * v;
+          }
+        s += __shfl_xor(s, 16, 64);
+        q += __shfl_xor(q, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        q += __shfl_xor(q, 32, 64);
+        if (lq == 0) {
+          statbuf[wave * CP + b * 16 + lr] = s;
+          statbuf[4 * CP + wave * CP + b * 16 + lr] = q;
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      const int col = b * 16 + lr;
+      float sc = 1.f, sh = 0.f;
+      if ((p.flags & VS_CONV_AFFINE) && col < p.Cout) {
+        sc = p.scale[col];
+        sh = p.shift[col];
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = (wave * 2 + a) * 16 + lq * 4 + r;  // = hol*16 + wo_l
+          E[row * CP + col] = acc[a][b][r] * sc + sh;
+        }
+    }
+    __syncthreads();
+    if ((p.flags & VS_CONV_STATS) && tid < p.Cout) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        s += statbuf[w * CP + tid];
+        q += statbuf[4 * CP + w * CP + tid];
+      }
+      float* dst = p.stats + (long long)tile * 2 * p.Cout;
+      dst[tid] = s;
+      dst[p.Cout + tid] = q;
+    }
+    const int cpr = p.Cout >> 3;  // real 16-byte chunks per output row
+    for (int idx = tid; idx < 128 * cpr; idx += 256) {
+      const int row = idx / cpr, c8 = idx - row * cpr;
+      const int ho = ho0 + (row >> 4), wo = wo0 + (row & 15);
+      if (ho < p.Ho && wo < p.Wo) {
+        float v[8];
+        const float4 v0 = *(const float4*)(E + row * CP + c8 * 8);
+        const float4 v1 = *(const float4*)(E + row * CP + c8 * 8 + 4);
+        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
+        v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+        if (p.flags & VS_CONV_RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        const long long pos = (((long long)n * p.T + to) * p.Ho + ho) * p.Wo + wo;
+        *(uint4*)(p.y + pos * p.y_ld + c8 * 8) = pack8_bf16(v);
+      }
+    }
+  }
+}
+
+static size_t stem_smem(int CP, int kT) {
+  const int K = kT * 7 * 32;
+  const size_t w = ((size_t)CP * (K * 2 + 16) + 15) & ~(size_t)15;
+  const size_t patch = ((size_t)kT * ST_FRAMEB + 15) & ~(size_t)15;
+  return w + patch + (size_t)128 * CP * 4 + (size_t)2 * 4 * CP * 4;
+}
+
+extern "C" int vs_stem_stats_rows(int N, int T, int H, int W) {
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  return N * T * ((Ho + ST_TH - 1) / ST_TH) * ((Wo + ST_TW - 1) / ST_TW);
+}
+
+extern "C" int vs_stem_conv_fwd(const void* x4, const void* wp, void* y, int N, int T, int H, int W,
+                                int Cout, int kT, int y_ld, int flags, const float* scale,
+                                const float* shift, float* stats_partial, void* stream) {
+  VS_CHECK_ARG(x4 && wp && y, "null tensor");
+  VS_CHECK_ARG(Cout % 8 == 0 && Cout <= 64 && y_ld % 8 == 0 && y_ld >= Cout, "Cout in {8..64}, pitch % 8");
+  VS_CHECK_ARG(kT == 1 || kT == 3 || kT == 5, "kT in {1,3,5}");
+  VS_CHECK_ARG(!(flags & VS_CONV_AFFINE) || (scale && shift), "AFFINE needs scale/shift");
+  VS_CHECK_ARG(!(flags & VS_CONV_STATS) || stats_partial, "STATS needs stats_partial");
+  VS_CHECK_ARG(!(flags & VS_CONV_RESIDUAL), "no residual on a stem");
+  StemP p;
+  p.x = (const uint16_t*)x4;
+  p.w = (const uint16_t*)wp;
+  p.y = (uint16_t*)y;
+  p.scale = scale;
+  p.shift = shift;
+  p.stats = stats_partial;
+  p.N = N; p.T = T; p.H = H; p.W = W;
+  p.Ho = (H + 6 - 7) / 2 + 1;
+  p.Wo = (W + 6 - 7) / 2 + 1;
+  p.Cout = Cout; p.kT = kT; p.y_ld = y_ld; p.flags = flags;
+  p.tilesH = (p.Ho + ST_TH - 1) / ST_TH;
+  p.tilesW = (p.Wo + ST_TW - 1) / ST_TW;
+  p.ntiles = N * T * p.tilesH * p.tilesW;
+  const int CP = (Cout + 15) / 16 * 16;
+  const size_t smem = stem_smem(CP, kT);
+  int grid = p.ntiles < 512 ? p.ntiles : 512;  // 2 persistent blocks per CU
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_STEM(NT_)                                                                         \
+  do {                                                                                           \
+    static bool attr_done = false;                                                               \
+    if (!attr_done) {                                                                            \
+      (void)hipFuncSetAttribute((const void*)stem_conv_kernel<NT_>,                              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);         \
+      attr_done = true;                                                                          \
+    }                                                                                            \
+    hipLaunchKernelGGL((stem_conv_kernel<NT_>), dim3(grid), dim3(256), smem, st, p);             \
+  } while (0)
+  switch (CP / 16) {
+    case 1: LAUNCH_STEM(1); break;
+    case 2: LAUNCH_STEM(2); break;
+    case 3: LAUNCH_STEM(3); break;
+    default: LAUNCH_STEM(4); break;
+  }
+#undef LAUNCH_STEM
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}

@@ -589,6 +589,40 @@ extern "C" int vs_adam_step(float* p, const float* g, float* m, float* v, int64_
   return VS_OK;
 }
 
+// hipGraph-safe variant: the step count lives in device memory (a captured launch would
+// otherwise replay the bias correction of the step it was captured at).
+__global__ void adam_tick_kernel(int* step) { step[0] += 1; }
+
+__global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, long long n, float lr,
+                                float b1, float b2, float eps, const int* step, float grad_scale) {
+  const float t = (float)step[0];
+  const float bc1 = 1.f - powf(b1, t);
+  const float bc2_sqrt = sqrtf(1.f - powf(b2, t));
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * grad_scale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+  }
+}
+
+extern "C" int vs_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                                float beta1, float beta2, float eps, int* step_counter,
+                                float grad_scale, void* stream) {
+  VS_CHECK_ARG(p && g && m && v && n > 0 && step_counter, "bad args");
+  long long grid = (n + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_counter);
+  hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m,
+                     v, (long long)n, lr, beta1, beta2, eps, (const int*)step_counter, grad_scale);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
 __global__ void cast_f32_bf16_kernel(const float* x, uint16_t* y, long long n) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x)

@@ -74,7 +74,8 @@ def act_rows(x):
 
 
 def pack_input(x, cpad=8):
-    """NCDHW f32/bf16 (any strides are made dense first) -> NDHWC bf16, C padded."""
+    """NCDHW f32/bf16 (any strides are made dense first) -> NDHWC bf16, C padded (4: stem
+    kernel layout, 8: generic implicit-GEMM layout)."""
     x = x.contiguous()
     n, c, t, h, w = x.shape
     y = new_act(n, cpad, t, h, w, x.device)
@@ -150,6 +151,44 @@ def conv_fwd(x, w, k, s, p, out=None, scale=None, shift=None, residual=None, rel
     _lib.call("vs_conv_fwd", _ptr(x), _ptr(w), _ptr(out), C.byref(d), _ptr(scale), _ptr(shift),
               _ptr(residual), _ptr(partials), None, None, _stream())
     return out, partials
+
+
+def pack_stem_weight(w, out=None):
+    """fp32 [Cout,3,kT,7,7] -> bf16 [ceil16(Cout)][kT][7][8][4] (zero padded) for the stem kernel."""
+    cout, cin, kt, kh, kw = w.shape
+    cp = (cout + 15) // 16 * 16
+    if out is None:
+        out = torch.zeros((cp, kt, 7, 8, 4), dtype=BF16, device=w.device)
+    out[:cout, :, :, :7, :cin].copy_(w.detach().permute(0, 2, 3, 4, 1))
+    return out
+
+
+def stem_conv_fwd(x4, wp, cout, kt, out=None, scale=None, shift=None, relu=False, stats=False):
+    """Conv3d(3->cout,[kt,7,7],s[1,2,2],p[kt//2,3,3]) on the C=4 packed input.
+    Returns (y, partials|None)."""
+    n, c, t, h, w = x4.shape
+    if c != 4 or act_ld4(x4) != 4:
+        raise _lib.VsError("stem input must be the dense C=4 packed activation")
+    ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+    if out is None:
+        out = new_act(n, cout, t, ho, wo, x4.device)
+    flags = (VS_CONV_AFFINE if scale is not None else 0) | (VS_CONV_RELU if relu else 0) | \
+        (VS_CONV_STATS if stats else 0)
+    partials = None
+    if stats:
+        rows = _lib.load().vs_stem_stats_rows(n, t, h, w)
+        partials = torch.empty((rows, 2, cout), dtype=torch.float32, device=x4.device)
+    _lib.call("vs_stem_conv_fwd", _ptr(x4), _ptr(wp), _ptr(out), n, t, h, w, cout, kt, act_ld(out),
+              flags, _ptr(scale), _ptr(shift), _ptr(partials), _stream())
+    return out, partials
+
+
+def act_ld4(x):
+    n, c, t, h, w = x.shape
+    ok = x.dtype == BF16 and x.permute(0, 2, 3, 4, 1).is_contiguous()
+    if not ok:
+        raise _lib.VsError("not a dense channels-last activation")
+    return c
 
 
 def weight_transpose(w, out=None):
@@ -433,6 +472,12 @@ def softmax_topk(logits, k=5):
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     _lib.call("vs_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr),
               float(beta1), float(beta2), float(eps), int(step), float(grad_scale), _stream())
+
+
+def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, step_counter, grad_scale=1.0):
+    """Adam with the step count in device memory (int32 tensor, incremented here)."""
+    _lib.call("vs_adam_step_dev", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr),
+              float(beta1), float(beta2), float(eps), _ptr(step_counter), float(grad_scale), _stream())
 
 
 def cast_bf16(src_f32, dst_bf16):

@@ -122,13 +122,12 @@ class ArenaAdam:
         self.arena, self.lr, self.betas, self.eps = arena, lr, betas, eps
         self.m = torch.zeros_like(arena.data)
         self.v = torch.zeros_like(arena.data)
-        self.t = 0
+        self.t = torch.zeros(1, dtype=torch.int32, device=arena.data.device)  # device-side: graph safe
 
     def zero_grad(self):
         self.arena.zero_grad()
 
     def step(self, world=1):
-        self.t += 1
-        ops.adam_step(self.arena.data, self.arena.grad, self.m, self.v, self.lr, self.betas[0],
-                      self.betas[1], self.eps, self.t, grad_scale=1.0 / world)
+        ops.adam_step_dev(self.arena.data, self.arena.grad, self.m, self.v, self.lr, self.betas[0],
+                          self.betas[1], self.eps, self.t, grad_scale=1.0 / world)
         self.arena.refresh()

@@ -54,6 +54,10 @@ class Conv3dP(nn.Module):
         self.weight = nn.Parameter(w)
         self.w_bf16 = None  # [Cout, cin_pad, k] channels-last, refreshed by the trunk
         self.wt_bf16 = None  # transposed image for dgrad
+        # the two stems (Cin = 3, [kT,7,7], stride [1,2,2]) run on the dedicated kernel
+        self.is_stem = (cin == 3 and self.k[1:] == (7, 7) and self.s == (1, 2, 2)
+                        and self.p == (self.k[0] // 2, 3, 3) and cout <= 64)
+        self.w_stem = None
 
     def refresh(self):
         """Rebuild the bf16 kernel-layout copy (and, when its storage is managed by a
@@ -68,6 +72,9 @@ class Conv3dP(nn.Module):
             ops.cast_bf16(w, self.w_bf16)  # identical memory order
         else:
             self.w_bf16[:, : self.cin].copy_(w)
+        if self.is_stem:
+            self.w_stem = ops.pack_stem_weight(w, out=self.w_stem if self.w_stem is not None and
+                                               self.w_stem.device == w.device else None)
         if getattr(self, "arena_managed", False):
             ops.weight_transpose(self.w_bf16, out=self.wt_bf16)
         else:
@@ -108,10 +115,18 @@ class _Unit:
     def fwd(conv, bn, x, relu, residual=None, out=None, train=False, saved=None):
         if not train:
             scale, shift = bn.fold
+            if conv.is_stem:
+                y, _ = ops.stem_conv_fwd(x[0], conv.w_stem, conv.cout, conv.k[0], out=out,
+                                         scale=scale, shift=shift, relu=relu)
+                return y
             y, _ = ops.conv_fwd(x, conv.w_bf16, conv.k, conv.s, conv.p, out=out, scale=scale,
                                 shift=shift, residual=residual, relu=relu)
             return y
-        y, partials = ops.conv_fwd(x, conv.w_bf16, conv.k, conv.s, conv.p, stats=True)
+        if conv.is_stem:
+            y, partials = ops.stem_conv_fwd(x[0], conv.w_stem, conv.cout, conv.k[0], stats=True)
+            x = x[1]  # the C=8 packed copy feeds the generic wgrad kernel
+        else:
+            y, partials = ops.conv_fwd(x, conv.w_bf16, conv.k, conv.s, conv.p, stats=True)
         scale, shift, mean, invstd = ops.bn_finalize(
             partials, ops.act_rows(y), bn.weight, bn.bias, bn.running_mean, bn.running_var,
             bn.momentum, bn.eps, train=True)
@@ -395,8 +410,13 @@ class VideoTrunk(nn.Module):
     def _run(self, inputs, train):
         saved = [] if train else None
         P = self.num_pathways
-        xin = [ops.pack_input(t) for t in inputs]
-        dev = xin[0].device
+        if self.s1.pathway0_stem.conv.is_stem:
+            xin = [(ops.pack_input(t, 4), ops.pack_input(t, 8) if train else None) for t in inputs]
+            shapes = [tuple(x[0].shape) for x in xin]
+        else:
+            xin = [ops.pack_input(t) for t in inputs]
+            shapes = [tuple(x.shape) for x in xin]
+        dev = inputs[0].device
         if train:
             bns = [m.num_batches_tracked for m in self.modules() if isinstance(m, BN3dP)]
             torch._foreach_add_(bns, 1)
@@ -407,7 +427,7 @@ class VideoTrunk(nn.Module):
         cur = []
         for p in range(P):
             stem = getattr(self.s1, f"pathway{p}_stem")
-            n, _, t, h, w = xin[p].shape
+            n, _, t, h, w = shapes[p]
             ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
             hp, wp = (ho + 2 - 3) // 2 + 1, (wo + 2 - 3) // 2 + 1
             c = stem.conv.cout
