@@ -47,6 +47,9 @@ typedef enum vs_status {
                               gathered input (train-mode BN of the producer fused  \
                               into this consumer); padding stays zero              */
 #define VS_CONV_APRO_RELU 64
+/* bits 8..11: forced tile config id + 1 (0 = built-in heuristic); ids index
+ * {128x128, 64x128, 128x64, 64x64, 256x32, 256x16, 256x128, 128x256} (BM x BN). */
+#define VS_CONV_TILE(id) (((id) + 1) << 8)
 
 /* Geometry of one Conv3d (bias-free, groups 1, dilation 1).
  * Replaces nn.Conv3d reached from vidsitu_code/mdl_sf_base.py:22-33 (s1..s5,

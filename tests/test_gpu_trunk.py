@@ -153,15 +153,13 @@ def test_trunk_train_step_matches_oracle(arch, depth, width, frames, n, hw, dev)
     med = sorted(e for e, _ in rows)[len(rows) // 2]
     print(f"median {med:.3e}   (for scale: emulation vs fp32 oracle median "
           f"{sorted(rows32)[len(rows32) // 2]:.3e}, max {max(rows32):.3e})")
-    if depth == 50:
-        # 53 convs deep with batch-of-2 batch norm the backward is chaotic: the emulation
-        # itself sits ~0.33 (median) from the fp32 oracle.  Only require that the HIP gradients
-        # are at least as close to the emulation as fp32 is, i.e. that nothing is garbage; the
-        # shallow nets above and the per-kernel tests carry the tight bounds.
-        assert med < 1.2 * sorted(rows32)[len(rows32) // 2] + 2e-2
-    else:
-        assert med < 8e-2, "median parameter-gradient error"
-        assert rows[0][0] < 3.5e-1, f"worst parameter gradient {rows[0]}"
+    # Criterion: the HIP gradients sit inside the bf16-rounding noise band, i.e. closer to the
+    # bf16-emulating oracle than that oracle is to plain fp32 (with batch-of-2 batch norm the
+    # backward is chaotic: emulation vs fp32 is 0.13 / 0.18 / 0.33 median for the three nets).
+    # The per-kernel tests (conv dgrad / wgrad, BN backward, pools) carry the tight bounds.
+    med32 = sorted(rows32)[len(rows32) // 2]
+    assert med < max(8e-2, 0.9 * med32), f"median parameter-gradient error {med:.3e} vs band {med32:.3e}"
+    assert rows[0][0] < max(3.5e-1, 1.2 * max(rows32)), f"worst parameter gradient {rows[0]}"
 
 
 def test_sfbase_logits_and_top5_indices(dev):

@@ -1,0 +1,102 @@
+"""Measure every tile config on every distinct conv GEMM shape of the bench step (fwd + dgrad)
+on the GPU box and write vidsitu_amd/conv_tune.json (shape key -> tile id).  Run through gpurun:
+    python tools/autotune_conv.py && cp vidsitu_amd/conv_tune.json gpurun_out/
+"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from vidsitu_amd import ops, synth_data
+from vidsitu_amd.extended_config import get_cfg
+from vidsitu_amd.mdl_selector import get_mdl_loss_eval
+
+dev = torch.device("cuda:0")
+cfg = get_cfg({"mdl.mdl_name": "sf_base"})
+comm = synth_data.make_comm(cfg)
+torch.manual_seed(0)
+sel = get_mdl_loss_eval(cfg)
+mdl = sel["mdl"](cfg=cfg, comm=comm).to(dev).train()
+batch = synth_data.synth_batch(cfg, comm, bs=2, n_ev=4, device=dev, dtype=torch.bfloat16)
+
+shapes = {}
+orig_f, orig_d = ops.conv_fwd, ops.conv_dgrad
+
+
+def rec_f(x, w, k, s, p, **kw):
+    ys = ops.conv_out_shape(x.shape, w.shape[0], k, s, p)
+    key = f"f:{ys[0]*ys[2]*ys[3]*ys[4]}:{ys[1]}:{x.shape[1]*k[0]*k[1]*k[2]}:{k[0]}{k[1]}{k[2]}:{s[0]}{s[1]}{s[2]}"
+    shapes.setdefault(key, ("f", tuple(x.shape), ops.act_ld(x), tuple(w.shape), k, s, p))
+    return orig_f(x, w, k, s, p, **kw)
+
+
+def rec_d(dy, wt, xs, k, s, p, **kw):
+    key = f"d:{xs[0]*xs[2]*xs[3]*xs[4]}:{xs[1]}:{dy.shape[1]*k[0]*k[1]*k[2]}:{k[0]}{k[1]}{k[2]}:{s[0]}{s[1]}{s[2]}"
+    shapes.setdefault(key, ("d", tuple(dy.shape), ops.act_ld(dy), tuple(xs), k, s, p))
+    return orig_d(dy, wt, xs, k, s, p, **kw)
+
+
+ops.conv_fwd, ops.conv_dgrad = rec_f, rec_d
+loss = sel["loss"](cfg, comm)(mdl(batch), batch)["loss"]
+loss.backward()
+ops.conv_fwd, ops.conv_dgrad = orig_f, orig_d
+torch.cuda.synchronize()
+print(f"{len(shapes)} distinct GEMM shapes")
+
+
+def timeit(fn, reps=5):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+table, report = {}, []
+for key, spec in sorted(shapes.items()):
+    kind = spec[0]
+    M, ncols = int(key.split(":")[1]), int(key.split(":")[2])
+    cands = [i for i, (bm, bn) in enumerate(ops.TILE_CFGS)
+             if bn <= max(16, 2 * ncols) and (bn >= min(ncols, 128) or bn >= ncols) and bm <= max(64, 2 * M)]
+    if kind == "f":
+        _, xs, xld, ws, k, s, p = spec
+        x = ops.new_act(*xs, device=dev, ctot=xld)
+        x.normal_()
+        w = torch.randn((ws[0], *k, ws[1]), device=dev).to(ops.BF16).permute(0, 4, 1, 2, 3)
+        fn_of = lambda t: (lambda: ops.conv_fwd(x, w, k, s, p, stats=True, tile=t))
+    else:
+        _, dys, dyld, xs, k, s, p = spec
+        dy = ops.new_act(*dys, device=dev, ctot=dyld)
+        dy.normal_()
+        wt = torch.randn((xs[1], *k, dys[1]), device=dev).to(ops.BF16).permute(0, 4, 1, 2, 3)
+        fn_of = lambda t: (lambda: ops.conv_dgrad(dy, wt, xs, k, s, p, tile=t))
+    times = {}
+    for t in cands:
+        try:
+            times[t] = timeit(fn_of(t))
+        except Exception as e:  # a config that cannot launch for this shape
+            times[t] = float("inf")
+    heur = timeit(fn_of(None))
+    best = min(times, key=times.get)
+    table[key] = best
+    report.append((key, heur, times[best], ops.TILE_CFGS[best], {ops.TILE_CFGS[t]: round(v, 4) for t, v in times.items()}))
+
+tot_h = sum(r[1] for r in report)
+tot_b = sum(r[2] for r in report)
+for r in sorted(report, key=lambda r: -(r[1] - r[2])):
+    print(f"{r[0]:40s} heuristic {r[1]*1e3:8.1f} us  best {r[2]*1e3:8.1f} us {r[3]}  {r[4]}")
+print(f"sum over distinct shapes: heuristic {tot_h:.3f} ms -> tuned {tot_b:.3f} ms")
+out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vidsitu_amd", "conv_tune.json")
+with open(out, "w") as f:
+    json.dump(table, f, indent=0, sort_keys=True)
+os.makedirs("gpurun_out", exist_ok=True)
+with open("gpurun_out/conv_tune.json", "w") as f:
+    json.dump(table, f, indent=0, sort_keys=True)
+print("wrote", out)

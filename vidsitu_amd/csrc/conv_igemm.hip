@@ -394,7 +394,18 @@ static int launch_cfg(const ConvP& p, int mode, hipStream_t st) {
   return VS_OK;
 }
 
-static int launch_conv(ConvP& p, int mode, int naive, hipStream_t st) {
+// tile configs addressable through vs_conv_desc.flags bits 8..11 (value = id + 1; 0 = heuristic)
+static const TileCfg kTileTable[] = {{128, 128}, {64, 128}, {128, 64}, {64, 64},
+                                     {256, 32},  {256, 16}, {256, 128}, {128, 256}};
+static const int kNumTileCfgs = 8;
+
+static TileCfg resolve_tile(long long M, int Ncols, int flags) {
+  const int forced = (flags >> 8) & 0xf;
+  if (forced >= 1 && forced <= kNumTileCfgs) return kTileTable[forced - 1];
+  return pick_tile(M, Ncols);
+}
+
+static int launch_conv(ConvP& p, int mode, int naive, int flags, hipStream_t st) {
   if (naive) {
     const long long total = (long long)p.M * p.Ncols;
     hipLaunchKernelGGL(conv_naive_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
@@ -402,7 +413,7 @@ static int launch_conv(ConvP& p, int mode, int naive, hipStream_t st) {
     VS_CHECK_LAUNCH();
     return VS_OK;
   }
-  const TileCfg c = pick_tile(p.M, p.Ncols);
+  const TileCfg c = resolve_tile(p.M, p.Ncols, flags);
   p.tilesM = (p.M + c.bm - 1) / c.bm;
   p.tilesN = (p.Ncols + c.bn - 1) / c.bn;
   if (c.bm == 128 && c.bn == 128) return launch_cfg<128, 128, 2, 2>(p, mode, st);
@@ -410,6 +421,8 @@ static int launch_conv(ConvP& p, int mode, int naive, hipStream_t st) {
   if (c.bm == 128 && c.bn == 64) return launch_cfg<128, 64, 2, 2>(p, mode, st);
   if (c.bm == 64 && c.bn == 64) return launch_cfg<64, 64, 2, 2>(p, mode, st);
   if (c.bm == 256 && c.bn == 32) return launch_cfg<256, 32, 4, 1>(p, mode, st);
+  if (c.bm == 256 && c.bn == 128) return launch_cfg<256, 128, 4, 1>(p, mode, st);
+  if (c.bm == 128 && c.bn == 256) return launch_cfg<128, 256, 1, 4>(p, mode, st);
   return launch_cfg<256, 16, 4, 1>(p, mode, st);
 }
 
@@ -436,7 +449,7 @@ static int check_desc(const vs_conv_desc* d) {
 
 extern "C" int vs_conv_stats_rows(const vs_conv_desc* d) {
   const long long M = (long long)d->N * d->To * d->Ho * d->Wo;
-  const TileCfg c = pick_tile(M, d->Cout);
+  const TileCfg c = resolve_tile(M, d->Cout, d->flags);
   return (int)((M + c.bm - 1) / c.bm);
 }
 
@@ -478,10 +491,11 @@ extern "C" int vs_conv_fwd(const void* x, const void* w, void* y, const vs_conv_
   p.shT = p.shH = p.shW = 0;
   p.y_ld = d->y_ld;
   p.res_ld = d->res_ld;
-  p.flags = d->flags;
+  p.flags = d->flags & 0xff;
   p.tilesM = p.tilesN = 0;
   const bool pointwise = (d->kT * d->kH * d->kW == 1) && d->pT == 0 && d->pH == 0 && d->pW == 0;
-  return launch_conv(p, pointwise ? 0 : 1, (d->flags & VS_CONV_NAIVE) != 0, (hipStream_t)stream);
+  return launch_conv(p, pointwise ? 0 : 1, (d->flags & VS_CONV_NAIVE) != 0, d->flags,
+                     (hipStream_t)stream);
 }
 
 extern "C" int vs_conv_dgrad(const void* dy, const void* wt, void* dx, const vs_conv_desc* d,
@@ -519,7 +533,7 @@ extern "C" int vs_conv_dgrad(const void* dy, const void* wt, void* dx, const vs_
   const bool pointwise =
       unit_stride && (d->kT * d->kH * d->kW == 1) && d->pT == 0 && d->pH == 0 && d->pW == 0;
   const int mode = pointwise ? 0 : (unit_stride ? 1 : 2);
-  return launch_conv(p, mode, (d->flags & VS_CONV_NAIVE) != 0, (hipStream_t)stream);
+  return launch_conv(p, mode, (d->flags & VS_CONV_NAIVE) != 0, d->flags, (hipStream_t)stream);
 }
 
 // w [Cout][taps][Cin] -> wt [Cin][taps][Cout]

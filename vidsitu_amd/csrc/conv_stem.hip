@@ -17,6 +17,7 @@
 #define ST_PW 40                // 2*16 + 5 = 37 input pixels, padded to 40
 #define ST_ROWB (ST_PW * 8)     // 320 bytes per patch row
 #define ST_FRAMEB (ST_PH * ST_ROWB)
+#define ST_TC 4                 // consecutive output frames per work item (frame ring reuse)
 
 struct StemP {
   const uint16_t* x;  // [N][T][H][W][4] bf16
@@ -26,7 +27,7 @@ struct StemP {
   const float* shift;
   float* stats;       // [tiles][2][Cout]
   int N, T, H, W, Ho, Wo, Cout, kT, y_ld, flags;
-  int tilesH, tilesW, ntiles;
+  int tilesH, tilesW, tchunks, ntiles;  // ntiles = number of work items
 };
 
 template <int NT>  // NT = padded Cout / 16
@@ -55,28 +56,49 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemP p) {
   const int ksteps = p.kT * 7;
   const int pT = p.kT >> 1;
 
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-    int t = tile;
+  // Work item = (clip, spatial tile, chunk of ST_TC consecutive output frames).  Inside an item
+  // the kT input frames live in a ring (slot = frame mod kT): only ONE new frame is staged per
+  // output frame after the first, instead of kT.
+  auto stage_frame = [&](int n, int ti, int hi0, int wi0) __attribute__((always_inline)) {
+    const int slot = ((ti % p.kT) + p.kT) % p.kT;
+    char* dst = patch + slot * ST_FRAMEB;
+    const bool tin = (unsigned)ti < (unsigned)p.T;
+    const uint16_t* src = p.x + (((long long)n * p.T + (tin ? ti : 0)) * p.H) * (long long)p.W * 4;
+    uint2 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // 21*40 = 840 pixels: 4 per thread, loads issued together
+      const int i = tid + u * 256;
+      const int r = i / ST_PW, c = i - r * ST_PW;
+      const int hi = hi0 + r, wi = wi0 + c;
+      v[u] = make_uint2(0u, 0u);
+      if (i < ST_PH * ST_PW && tin && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+        v[u] = *(const uint2*)(src + ((long long)hi * p.W + wi) * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + u * 256;
+      if (i < ST_PH * ST_PW) *(uint2*)(dst + i * 8) = v[u];
+    }
+  };
+
+  for (int item = blockIdx.x; item < p.ntiles; item += gridDim.x) {
+    int t = item;
+    const int tc = t % p.tchunks;
+    t /= p.tchunks;
     const int tw = t % p.tilesW;
     t /= p.tilesW;
     const int th = t % p.tilesH;
-    t /= p.tilesH;
-    const int to = t % p.T, n = t / p.T;
+    const int n = t / p.tilesH;
     const int ho0 = th * ST_TH, wo0 = tw * ST_TW;
     const int hi0 = 2 * ho0 - 3, wi0 = 2 * wo0 - 3;
-
-    __syncthreads();  // previous tile's epilogue / this block's weight fill are done
-    // ---- stage the input patch (zero outside the image / clip) ----
-    for (int i = tid; i < p.kT * ST_PH * ST_PW; i += 256) {
-      const int c = i % ST_PW;
-      int r = i / ST_PW;
-      const int dt = r / ST_PH;
-      r -= dt * ST_PH;
-      const int ti = to - pT + dt, hi = hi0 + r, wi = wi0 + c;
-      uint2 v = make_uint2(0u, 0u);
-      if ((unsigned)ti < (unsigned)p.T && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-        v = *(const uint2*)(p.x + ((((long long)n * p.T + ti) * p.H + hi) * p.W + wi) * 4);
-      *(uint2*)(patch + dt * ST_FRAMEB + r * ST_ROWB + c * 8) = v;
+    const int to_beg = tc * ST_TC, to_end = min(p.T, to_beg + ST_TC);
+   for (int to = to_beg; to < to_end; ++to) {
+    const int tile = ((n * p.T + to) * p.tilesH + th) * p.tilesW + tw;  // stats row
+    __syncthreads();  // previous epilogue / weight fill done; ring slot about to be reused
+    if (to == to_beg) {
+      for (int dt = 0; dt < p.kT; ++dt) stage_frame(n, to - pT + dt, hi0, wi0);
+    } else {
+      stage_frame(n, to + pT, hi0, wi0);
     }
     __syncthreads();
 
@@ -88,11 +110,13 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemP p) {
 
     for (int ks = 0; ks < ksteps; ++ks) {
       const int dt = ks / 7, dh = ks - dt * 7;
+      const int ti = to - pT + dt;
+      const int slot = ((ti % p.kT) + p.kT) % p.kT;
       bf16x8 af[2], bfr[NT];
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         const int hol = wave * 2 + a;  // one output row per 16-position MFMA row tile
-        af[a] = *(const bf16x8*)(patch + dt * ST_FRAMEB + (2 * hol + dh) * ST_ROWB +
+        af[a] = *(const bf16x8*)(patch + slot * ST_FRAMEB + (2 * hol + dh) * ST_ROWB +
                                  (2 * lr + 2 * lq) * 8);
       }
 #pragma unroll
@@ -186,7 +210,8 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemP p) {
         *(uint4*)(p.y + pos * p.y_ld + c8 * 8) = pack8_bf16(v);
       }
     }
-  }
+   }  // to
+  }    // item
 }
 
 static size_t stem_smem(int CP, int kT) {
@@ -223,7 +248,8 @@ extern "C" int vs_stem_conv_fwd(const void* x4, const void* wp, void* y, int N, 
   p.Cout = Cout; p.kT = kT; p.y_ld = y_ld; p.flags = flags;
   p.tilesH = (p.Ho + ST_TH - 1) / ST_TH;
   p.tilesW = (p.Wo + ST_TW - 1) / ST_TW;
-  p.ntiles = N * T * p.tilesH * p.tilesW;
+  p.tchunks = (T + ST_TC - 1) / ST_TC;
+  p.ntiles = N * p.tilesH * p.tilesW * p.tchunks;
   const int CP = (Cout + 15) / 16 * 16;
   const size_t smem = stem_smem(CP, kT);
   int grid = p.ntiles < 512 ? p.ntiles : 512;  // 2 persistent blocks per CU

@@ -253,10 +253,15 @@ static WgCfg wg_pick(const vs_conv_desc* d) {
   const long long tiles = (long long)c.tilesM * c.tilesN;
   // ~512 blocks (2 per CU); every block keeps >= 8 steps (512 positions) so the slab
   // traffic (S x |dW| fp32, written and re-read) stays small next to the operand reads
-  long long S = (512 + tiles - 1) / tiles;
+  // Skinny outputs (fast pathway, stems: a handful of tiles, 10^5..10^6 positions) are
+  // latency bound per 64-position step, so they get up to 2048 blocks.
+  const long long target = (d->Cout <= 32) ? 2048 : 512;
+  long long S = (target + tiles - 1) / tiles;
   const long long maxS = (P + 511) / 512;
   if (S > maxS) S = maxS;
-  if (S > 64) S = 64;
+  const long long slab_cap = (64ll << 20) / ((long long)d->Cout * Kp * 4);  // <= 64 MB of slabs
+  if (S > slab_cap) S = slab_cap;
+  if (S > 1024) S = 1024;
   if (S < 1) S = 1;
   long long rps = (P + S - 1) / S;
   rps = (rps + 63) / 64 * 64;

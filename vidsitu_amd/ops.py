@@ -118,8 +118,36 @@ def check_weight(w, cout, cin, k):
         raise _lib.VsError("conv weight must be channels-last ([Cout][taps][Cin] in memory)")
 
 
+TILE_CFGS = [(128, 128), (64, 128), (128, 64), (64, 64), (256, 32), (256, 16), (256, 128), (128, 256)]
+_tune = None
+
+
+def _tune_table():
+    """Per-shape tile choices measured on MI355X by tools/autotune_conv.py (optional)."""
+    global _tune
+    if _tune is None:
+        import json
+        import os
+
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_tune.json")
+        _tune = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                _tune = json.load(f)
+    return _tune
+
+
+def tile_flag(kind, M, ncols, K, k, s, force=None):
+    """flags bits 8..11 for this GEMM shape: forced id, tuned id, or 0 (C-side heuristic)."""
+    if force is not None:
+        return (force + 1) << 8
+    key = f"{kind}:{M}:{ncols}:{K}:{k[0]}{k[1]}{k[2]}:{s[0]}{s[1]}{s[2]}"
+    tid = _tune_table().get(key)
+    return ((tid + 1) << 8) if tid is not None else 0
+
+
 def conv_fwd(x, w, k, s, p, out=None, scale=None, shift=None, residual=None, relu=False,
-             stats=False, naive=False):
+             stats=False, naive=False, tile=None):
     """y = conv3d(x, w) [*scale+shift] [+residual] [relu]; optional BN-stat partials.
     Returns (y, partials|None)."""
     cout = w.shape[0]
@@ -142,6 +170,8 @@ def conv_fwd(x, w, k, s, p, out=None, scale=None, shift=None, residual=None, rel
         flags |= VS_CONV_STATS
     if naive:
         flags |= VS_CONV_NAIVE
+    flags |= tile_flag("f", ys[0] * ys[2] * ys[3] * ys[4], cout, x.shape[1] * k[0] * k[1] * k[2], k, s,
+                       tile)
     d = make_desc(x.shape, act_ld(x), ys, act_ld(out), k, s, p, flags,
                   act_ld(residual) if residual is not None else 0)
     partials = None
@@ -205,11 +235,13 @@ def weight_transpose_batched(src_arena, dst_arena, table, total):
               table.shape[0], int(total), _stream())
 
 
-def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False):
+def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=None):
     """dx[xs] = conv_transpose(dy, w) (+ residual).  wt from weight_transpose."""
     if out is None:
         out = new_act(*xs, device=dy.device)
     flags = (VS_CONV_NAIVE if naive else 0) | (VS_CONV_RESIDUAL if residual is not None else 0)
+    flags |= tile_flag("d", xs[0] * xs[2] * xs[3] * xs[4], xs[1], dy.shape[1] * k[0] * k[1] * k[2], k, s,
+                       tile)
     d = make_desc(xs, act_ld(out), dy.shape, act_ld(dy), k, s, p, flags,
                   act_ld(residual) if residual is not None else 0)
     _lib.call("vs_conv_dgrad", _ptr(dy), _ptr(wt), _ptr(out), C.byref(d), _ptr(residual), _stream())

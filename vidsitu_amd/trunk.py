@@ -55,8 +55,11 @@ class Conv3dP(nn.Module):
         self.w_bf16 = None  # [Cout, cin_pad, k] channels-last, refreshed by the trunk
         self.wt_bf16 = None  # transposed image for dgrad
         # the two stems (Cin = 3, [kT,7,7], stride [1,2,2]) run on the dedicated kernel
+        cp = (cout + 15) // 16 * 16
+        stem_lds = cp * (self.k[0] * 7 * 64 + 16) + self.k[0] * 21 * 320 + 128 * cp * 4 + 32 * cp
         self.is_stem = (cin == 3 and self.k[1:] == (7, 7) and self.s == (1, 2, 2)
-                        and self.p == (self.k[0] // 2, 3, 3) and cout <= 64)
+                        and self.p == (self.k[0] // 2, 3, 3) and cout <= 64
+                        and stem_lds <= 150 * 1024)  # whole packed weight must sit in LDS
         self.w_stem = None
 
     def refresh(self):
@@ -410,12 +413,13 @@ class VideoTrunk(nn.Module):
     def _run(self, inputs, train):
         saved = [] if train else None
         P = self.num_pathways
-        if self.s1.pathway0_stem.conv.is_stem:
-            xin = [(ops.pack_input(t, 4), ops.pack_input(t, 8) if train else None) for t in inputs]
-            shapes = [tuple(x[0].shape) for x in xin]
-        else:
-            xin = [ops.pack_input(t) for t in inputs]
-            shapes = [tuple(x.shape) for x in xin]
+        xin, shapes = [], []
+        for p, t in enumerate(inputs):
+            if getattr(self.s1, f"pathway{p}_stem").conv.is_stem:
+                xin.append((ops.pack_input(t, 4), ops.pack_input(t, 8) if train else None))
+            else:
+                xin.append(ops.pack_input(t))
+            shapes.append(tuple(t.shape))
         dev = inputs[0].device
         if train:
             bns = [m.num_batches_tracked for m in self.modules() if isinstance(m, BN3dP)]
