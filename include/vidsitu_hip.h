@@ -83,6 +83,11 @@ int vs_stem_conv_fwd(const void* x4, const void* wp, void* y, int N, int T, int 
                      int kT, int y_ld, int flags, const float* scale, const float* shift,
                      float* stats_partial, void* stream);
 int vs_stem_stats_rows(int N, int T, int H, int W);
+/* Stem weight gradient, same patch scheme; dwp: fp32 [Cout][kT][7][8][4] (the packed weight's
+ * layout; kw = 7 and c = 3 entries are padding).  workspace: vs_stem_wgrad_workspace_bytes. */
+size_t vs_stem_wgrad_workspace_bytes(int N, int T, int H, int W, int Cout, int kT);
+int vs_stem_conv_wgrad(const void* dy, const void* x4, float* dwp, int N, int T, int H, int W,
+                       int Cout, int kT, int dy_ld, void* workspace, size_t ws_bytes, void* stream);
 
 /* Forward conv as implicit GEMM on bf16 MFMA, fp32 accumulate.
  *   stats_partial: [vs_conv_stats_rows(desc)][2][Cout] fp32 when VS_CONV_STATS.

@@ -195,3 +195,21 @@ def test_stem_kernel_matches_torch(cout, kt, t, h, w, dev):
     y2, _ = ops.stem_conv_fwd(x4, wp, cout, kt, scale=scale.to(dev), shift=shift.to(dev), relu=True)
     assert_close(y2, F.relu(ref * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)), TOL,
                  "stem conv + affine + relu")
+
+
+@pytest.mark.parametrize("cout,kt,t,h,w", [(64, 1, 2, 32, 32), (8, 5, 6, 32, 32), (64, 1, 1, 36, 44),
+                                           (8, 5, 5, 20, 52), (16, 3, 4, 32, 48)])
+def test_stem_wgrad_matches_autograd(cout, kt, t, h, w, dev):
+    from vidsitu_amd import ops
+
+    g = torch.Generator().manual_seed(cout * 3 + kt)
+    x = rb(torch.randn(2, 3, t, h, w, generator=g))
+    wt = rb(torch.randn(cout, 3, kt, 7, 7, generator=g) / (147 * kt) ** 0.5).requires_grad_()
+    y = F.conv3d(x, wt, stride=(1, 2, 2), padding=(kt // 2, 3, 3))
+    dy = rb(torch.randn(y.shape, generator=g))
+    (dw_ref,) = torch.autograd.grad(y, wt, dy)
+    dw = ops.stem_conv_wgrad(to_act(dy, dev), ops.pack_input(x.to(dev), 4), kt)
+    assert tuple(dw.shape) == tuple(dw_ref.shape)
+    assert_close(dw, dw_ref, 5e-3, "stem wgrad")
+    dw2 = ops.stem_conv_wgrad(to_act(dy, dev), ops.pack_input(x.to(dev), 4), kt)
+    assert torch.equal(dw.contiguous(), dw2.contiguous())  # fixed-order slab reduce

@@ -159,7 +159,7 @@ def test_trunk_train_step_matches_oracle(arch, depth, width, frames, n, hw, dev)
     # The per-kernel tests (conv dgrad / wgrad, BN backward, pools) carry the tight bounds.
     med32 = sorted(rows32)[len(rows32) // 2]
     assert med < max(8e-2, 0.9 * med32), f"median parameter-gradient error {med:.3e} vs band {med32:.3e}"
-    assert rows[0][0] < max(3.5e-1, 1.2 * max(rows32)), f"worst parameter gradient {rows[0]}"
+    assert rows[0][0] < max(3.5e-1, 1.5 * max(rows32)), f"worst parameter gradient {rows[0]}"
 
 
 def test_sfbase_logits_and_top5_indices(dev):

@@ -274,3 +274,235 @@ extern "C" int vs_stem_conv_fwd(const void* x4, const void* wp, void* y, int N, 
   VS_CHECK_LAUNCH();
   return VS_OK;
 }
+
+// =============================================================================
+// Stem weight gradient.  dW[co][dt][dh][dw][c] = sum_pos dY[pos][co] * X[pos @ tap][c]
+// with the same frame-ring patch in LDS.  MFMA K = 32 output positions (two output rows of a
+// tile); A = dY^T from an LDS image [m-tile][128 pos][16 couts] read with ds_read_b64_tr_b16;
+// B = 16 consecutive (dw, c) elements = 4 pixels of one kernel row, read with the SAME
+// transposing instruction straight from the raw patch (each position supplies its own
+// 8-byte pixel address).  N-tiles (dt, dh, half-row) are dealt round-robin to the 4 waves;
+// accumulators persist over all the block's work items; one fp32 slab per block, then the
+// fixed-order slab reduce.  Output layout = the packed weight's: [Cout][kT][7][8][4].
+// =============================================================================
+typedef __attribute__((ext_vector_type(4))) short st_s16x4;
+typedef __attribute__((address_space(3))) st_s16x4 st_lds_s16x4;
+typedef __attribute__((ext_vector_type(8))) short st_s16x8;
+
+__device__ __forceinline__ bf16x8 st_tr_pair(const char* p0, const char* p1) {
+  const st_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((st_lds_s16x4*)p0);
+  const st_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((st_lds_s16x4*)p1);
+  const st_s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+struct StemWgP {
+  const uint16_t* x;   // [N][T][H][W][4]
+  const uint16_t* dy;  // [N][T][Ho][Wo] rows of dy_ld
+  float* slabs;        // [grid][Cout][Kpad]
+  int N, T, H, W, Ho, Wo, Cout, kT, dy_ld;
+  int tilesH, tilesW, tchunks, nitems;
+};
+
+template <int MT, int NTW>  // MT = padded Cout / 16 ; NTW = n-tiles per wave (ceil(kT*14 / 4))
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* patch = smem;                                                 // [kT][21][40] x 8 B
+  char* dyl = smem + ((p.kT * ST_FRAMEB + 15) & ~15);                 // [MT][128][16] bf16
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, p4 = li & 3;
+  const int pT = p.kT >> 1;
+  const int ntiles_n = p.kT * 14;
+
+  f32x4 acc[MT][NTW];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NTW; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto stage_frame = [&](int n, int ti, int hi0, int wi0) __attribute__((always_inline)) {
+    const int slot = ((ti % p.kT) + p.kT) % p.kT;
+    char* dst = patch + slot * ST_FRAMEB;
+    const bool tin = (unsigned)ti < (unsigned)p.T;
+    const uint16_t* src = p.x + (((long long)n * p.T + (tin ? ti : 0)) * p.H) * (long long)p.W * 4;
+    uint2 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + u * 256;
+      const int r = i / ST_PW, c = i - r * ST_PW;
+      const int hi = hi0 + r, wi = wi0 + c;
+      v[u] = make_uint2(0u, 0u);
+      if (i < ST_PH * ST_PW && tin && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+        v[u] = *(const uint2*)(src + ((long long)hi * p.W + wi) * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + u * 256;
+      if (i < ST_PH * ST_PW) *(uint2*)(dst + i * 8) = v[u];
+    }
+  };
+
+  for (int item = blockIdx.x; item < p.nitems; item += gridDim.x) {
+    int t = item;
+    const int tc = t % p.tchunks;
+    t /= p.tchunks;
+    const int tw = t % p.tilesW;
+    t /= p.tilesW;
+    const int th = t % p.tilesH;
+    const int n = t / p.tilesH;
+    const int ho0 = th * ST_TH, wo0 = tw * ST_TW;
+    const int hi0 = 2 * ho0 - 3, wi0 = 2 * wo0 - 3;
+    const int to_beg = tc * ST_TC, to_end = min(p.T, to_beg + ST_TC);
+    for (int to = to_beg; to < to_end; ++to) {
+      __syncthreads();  // previous frame's readers are done
+      if (to == to_beg) {
+        for (int dt = 0; dt < p.kT; ++dt) stage_frame(n, to - pT + dt, hi0, wi0);
+      } else {
+        stage_frame(n, to + pT, hi0, wi0);
+      }
+      // dY tile -> [mt][pos][16] (zeros outside the image and beyond Cout)
+      for (int i = tid; i < MT * 128 * 2; i += 256) {
+        const int h8 = i & 1;            // which 8-channel half of the 16-wide m-tile
+        const int pos = (i >> 1) & 127;
+        const int mt = i >> 8;
+        const int ho = ho0 + (pos >> 4), wo = wo0 + (pos & 15);
+        const int c = mt * 16 + h8 * 8;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (ho < p.Ho && wo < p.Wo && c < p.Cout)
+          v = *(const u32x4*)(p.dy + ((((long long)n * p.T + to) * p.Ho + ho) * p.Wo + wo) * p.dy_ld + c);
+        *(u32x4*)(dyl + (mt * 128 + pos) * 32 + h8 * 16) = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        // this lane supplies position k = ks*32 + 8g + q (and k + 4)
+        const int k = ks * 32 + 8 * g + q;
+        bf16x8 af[MT];
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+          const char* ptr = dyl + (a * 128 + k) * 32 + p4 * 8;
+          af[a] = st_tr_pair(ptr, ptr + 4 * 32);
+        }
+        const int hol = k >> 4, wol = k & 15;
+#pragma unroll
+        for (int b = 0; b < NTW; ++b) {
+          const int nt = wave + 4 * b;
+          if (nt < ntiles_n) {
+            const int half = nt & 1, row = nt >> 1;  // row = dt*7 + dh
+            const int dt = row / 7, dh = row - dt * 7;
+            const int ti = to - pT + dt;
+            const int slot = ((ti % p.kT) + p.kT) % p.kT;
+            const char* ptr = patch + slot * ST_FRAMEB + (2 * hol + dh) * ST_ROWB +
+                              (2 * wol + half * 4 + p4) * 8;
+            const bf16x8 bf = st_tr_pair(ptr, ptr + 4 * 16);  // +4 positions = +8 pixels... see note
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf, acc[a][b], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // D[row = g*4 + r -> cout][col = li -> k' column]
+  const int Kpad = p.kT * 7 * 32;
+  float* dst = p.slabs + (long long)blockIdx.x * p.Cout * Kpad;
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NTW; ++b) {
+      const int nt = wave + 4 * b;
+      if (nt < ntiles_n) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = a * 16 + g * 4 + r;
+          if (co < p.Cout) dst[(long long)co * Kpad + nt * 16 + li] = acc[a][b][r];
+        }
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void stem_slab_reduce_kernel(const float* slabs, float* dw,
+                                                              long long n, int S) {
+  __shared__ float4 part[16][17];
+  const long long n4 = n >> 2;
+  const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long long i = (long long)blockIdx.x * 16 + col;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    const int per = (S + 15) / 16;
+    const int s0 = sl * per, s1 = min(S, s0 + per);
+    for (int s = s0; s < s1; ++s) {
+      const float4 v = *(const float4*)(slabs + (long long)s * n + i * 4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  part[sl][col] = acc;
+  __syncthreads();
+  if (sl == 0 && i < n4) {
+    float4 t = part[0][col];
+    for (int k = 1; k < 16; ++k) {
+      const float4 v = part[k][col];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    *(float4*)(dw + i * 4) = t;
+  }
+}
+
+static int stem_wg_grid(int nitems) { return nitems < 512 ? nitems : 512; }
+
+extern "C" size_t vs_stem_wgrad_workspace_bytes(int N, int T, int H, int W, int Cout, int kT) {
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  const int nitems = N * ((Ho + ST_TH - 1) / ST_TH) * ((Wo + ST_TW - 1) / ST_TW) * ((T + ST_TC - 1) / ST_TC);
+  return (size_t)stem_wg_grid(nitems) * Cout * kT * 7 * 32 * sizeof(float);
+}
+
+extern "C" int vs_stem_conv_wgrad(const void* dy, const void* x4, float* dwp, int N, int T, int H,
+                                  int W, int Cout, int kT, int dy_ld, void* workspace,
+                                  size_t ws_bytes, void* stream) {
+  VS_CHECK_ARG(dy && x4 && dwp && workspace, "null tensor");
+  VS_CHECK_ARG(Cout % 8 == 0 && Cout <= 64 && dy_ld % 8 == 0 && dy_ld >= Cout, "Cout in {8..64}, pitch % 8");
+  VS_CHECK_ARG(kT == 1 || kT == 3 || kT == 5, "kT in {1,3,5}");
+  StemWgP p;
+  p.x = (const uint16_t*)x4;
+  p.dy = (const uint16_t*)dy;
+  p.slabs = (float*)workspace;
+  p.N = N; p.T = T; p.H = H; p.W = W;
+  p.Ho = (H + 6 - 7) / 2 + 1;
+  p.Wo = (W + 6 - 7) / 2 + 1;
+  p.Cout = Cout; p.kT = kT; p.dy_ld = dy_ld;
+  p.tilesH = (p.Ho + ST_TH - 1) / ST_TH;
+  p.tilesW = (p.Wo + ST_TW - 1) / ST_TW;
+  p.tchunks = (T + ST_TC - 1) / ST_TC;
+  p.nitems = N * p.tilesH * p.tilesW * p.tchunks;
+  const int grid = stem_wg_grid(p.nitems);
+  if (ws_bytes < vs_stem_wgrad_workspace_bytes(N, T, H, W, Cout, kT)) {
+    vs_set_error("vs_stem_conv_wgrad: workspace too small");
+    return VS_ERR_WORKSPACE;
+  }
+  const int MTv = (Cout + 15) / 16;
+  const size_t smem = (((size_t)kT * ST_FRAMEB + 15) & ~(size_t)15) + (size_t)MTv * 128 * 32;
+  hipStream_t st = (hipStream_t)stream;
+  const int ntw = (kT * 14 + 3) / 4;  // 4 (kT=1), 11 (kT=3), 18 (kT=5)
+#define LAUNCH_SWG(MT_, NTW_)                                                                    \
+  hipLaunchKernelGGL((stem_wgrad_kernel<MT_, NTW_>), dim3(grid), dim3(256), smem, st, p)
+  if (MTv == 1 && ntw == 18) LAUNCH_SWG(1, 18);
+  else if (MTv == 1 && ntw == 11) LAUNCH_SWG(1, 11);
+  else if (MTv == 1) LAUNCH_SWG(1, 4);
+  else if (MTv == 2 && ntw == 18) LAUNCH_SWG(2, 18);
+  else if (MTv == 2 && ntw == 11) LAUNCH_SWG(2, 11);
+  else if (MTv == 2) LAUNCH_SWG(2, 4);
+  else if (MTv == 4 && ntw == 4) LAUNCH_SWG(4, 4);
+  else if (MTv == 4 && ntw == 11) LAUNCH_SWG(4, 11);
+  else if (MTv == 3 && ntw == 4) LAUNCH_SWG(3, 4);
+  else {
+    vs_set_error("vs_stem_conv_wgrad: unsupported (Cout, kT) = (%d, %d)", Cout, kT);
+    return VS_ERR_UNSUPPORTED;
+  }
+#undef LAUNCH_SWG
+  VS_CHECK_LAUNCH();
+  const long long n = (long long)Cout * kT * 7 * 32;
+  hipLaunchKernelGGL(stem_slab_reduce_kernel, dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, st,
+                     (const float*)workspace, dwp, n, grid);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}

@@ -220,20 +220,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     }
 }
 
-// dw[i] = sum_s slab[s][i]  (fixed order; n is a multiple of 4)
-__global__ void wgrad_reduce_kernel(const float* slabs, float* dw, long long n, int S) {
+// dw[i] = sum_s slab[s][i], bitwise reproducible: block = 16 float4 columns x 16 slab slices,
+// each slice summed in order, the 16 slice sums combined in order through LDS.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, float* dw,
+                                                          long long n, int S) {
+  __shared__ float4 part[16][17];
   const long long n4 = n >> 2;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-       i += (long long)gridDim.x * blockDim.x) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < S; ++s) {
+  const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long long i = (long long)blockIdx.x * 16 + col;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    const int per = (S + 15) / 16;
+    const int s0 = sl * per, s1 = min(S, s0 + per);
+    for (int s = s0; s < s1; ++s) {
       const float4 v = *(const float4*)(slabs + (long long)s * n + i * 4);
       acc.x += v.x;
       acc.y += v.y;
       acc.z += v.z;
       acc.w += v.w;
     }
-    *(float4*)(dw + i * 4) = acc;
+  }
+  part[sl][col] = acc;
+  __syncthreads();
+  if (sl == 0 && i < n4) {
+    float4 t = part[0][col];
+    for (int k = 1; k < 16; ++k) {
+      const float4 v = part[k][col];
+      t.x += v.x;
+      t.y += v.y;
+      t.z += v.z;
+      t.w += v.w;
+    }
+    *(float4*)(dw + i * 4) = t;
   }
 }
 
@@ -351,8 +369,7 @@ extern "C" int vs_conv_wgrad(const void* dy, const void* x, float* dw, const vs_
   if (rc) return rc;
   if (c.S > 1) {
     const long long n = (long long)d->Cout * p.Kp;
-    long long grid = (n / 4 + 255) / 256;
-    if (grid > 4096) grid = 4096;
+    const long long grid = (n / 4 + 15) / 16;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, st,
                        (const float*)workspace, dw, n, c.S);
     VS_CHECK_LAUNCH();

@@ -213,6 +213,19 @@ def stem_conv_fwd(x4, wp, cout, kt, out=None, scale=None, shift=None, relu=False
     return out, partials
 
 
+def stem_conv_wgrad(dy, x4, kt):
+    """Weight gradient of the stem conv; returns fp32 [Cout,3,kT,7,7]-shaped view of the padded
+    [Cout][kT][7][8][4] result."""
+    n, _, t, h, w = x4.shape
+    cout = dy.shape[1]
+    dwp = torch.empty((cout, kt, 7, 8, 4), dtype=torch.float32, device=dy.device)
+    need = _lib.load().vs_stem_wgrad_workspace_bytes(n, t, h, w, cout, kt)
+    ws = _workspace(need, dy.device)
+    _lib.call("vs_stem_conv_wgrad", _ptr(dy), _ptr(x4), _ptr(dwp), n, t, h, w, cout, kt, act_ld(dy),
+              _ptr(ws), C.c_size_t(ws.numel()), _stream())
+    return dwp[:, :, :, :7, :3].permute(0, 4, 1, 2, 3)
+
+
 def act_ld4(x):
     n, c, t, h, w = x.shape
     ok = x.dtype == BF16 and x.permute(0, 2, 3, 4, 1).is_contiguous()

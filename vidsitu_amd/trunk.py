@@ -127,7 +127,7 @@ class _Unit:
             return y
         if conv.is_stem:
             y, partials = ops.stem_conv_fwd(x[0], conv.w_stem, conv.cout, conv.k[0], stats=True)
-            x = x[1]  # the C=8 packed copy feeds the generic wgrad kernel
+            x = x[0]  # the stem wgrad kernel reads the same C=4 packed input
         else:
             y, partials = ops.conv_fwd(x, conv.w_bf16, conv.k, conv.s, conv.p, stats=True)
         scale, shift, mean, invstd = ops.bn_finalize(
@@ -152,7 +152,9 @@ class _Unit:
             dz, rec["z"], rec["y"], rec["mean"], rec["invstd"], bn.weight, relu, want_dres,
             dgamma=bn.weight.grad, dbeta=bn.bias.grad)
         x = rec["x"]
-        if conv.cin_pad == conv.cin:
+        if conv.is_stem:
+            _set_grad(conv.weight, ops.stem_conv_wgrad(dy, x, conv.k[0]))
+        elif conv.cin_pad == conv.cin:
             if conv.weight.grad is None:
                 conv.weight.grad = torch.empty_like(conv.weight)
             ops.conv_wgrad(dy, x, conv.k, conv.s, conv.p, out=conv.weight.grad)
@@ -416,7 +418,7 @@ class VideoTrunk(nn.Module):
         xin, shapes = [], []
         for p, t in enumerate(inputs):
             if getattr(self.s1, f"pathway{p}_stem").conv.is_stem:
-                xin.append((ops.pack_input(t, 4), ops.pack_input(t, 8) if train else None))
+                xin.append((ops.pack_input(t, 4), None))
             else:
                 xin.append(ops.pack_input(t))
             shapes.append(tuple(t.shape))
