@@ -35,6 +35,7 @@ struct ConvP {
   int shT, shH, shW;  // log2(stride) for the transposed gather
   int y_ld, res_ld, flags;
   int tilesM, tilesN;
+  unsigned x_bytes, w_bytes;  // extents for the buffer resources (FAST path)
 };
 
 template <int BM, int BN>
@@ -44,7 +45,14 @@ struct ConvSmem {
   static constexpr int MAIN = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
 };
 
-template <int BM, int BN, int WM, int WN, int MODE>
+#define VS_OOB 0x80000000u  // byte offset beyond any tensor: buffer_load returns zeros
+
+// FAST (taps <= 32, every conv of the trunk but the Cin-padded stems): per row a bitmask of
+// valid taps and a base byte offset are computed ONCE; per k-step a load is
+// `valid ? base + delta[k] : OOB` through a buffer resource whose bounds check supplies the
+// zero padding -- no branches, no 64-bit address math in the loop.
+// !FAST: generic per-load coordinate tests (any tap count).
+template <int BM, int BN, int WM, int WN, int MODE, bool FAST>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int AI = BM / 32;
@@ -75,20 +83,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 
   if (MODE != 0) {
     const int C8 = p.Cg >> 3;
-    for (int k8 = tid; k8 < K8; k8 += 256) {
+    const int K8pad = ((p.K + 63) >> 6) << 3;
+    for (int k8 = tid; k8 < K8pad; k8 += 256) {
+      if (k8 >= K8) {  // K tail: tap 31 is never valid (FAST requires <= 31 taps)
+        ktab[k8] = FAST ? make_int2(31, 0) : make_int2(0, 0);
+        continue;
+      }
       const int tap = k8 / C8, c8 = k8 - tap * C8;
       const int dw = tap % p.kW, t2 = tap / p.kW;
       const int dh = t2 % p.kH, dt = t2 / p.kH;
-      ktab[k8] = make_int2(dt | (dh << 8) | (dw << 16), c8 * 8);
+      if (FAST) {
+        long long dpos;
+        if (MODE == 1) dpos = ((long long)dt * p.Gh + dh) * p.Gw + dw;
+        else dpos = -(((long long)(dt >> p.shT) * p.Gh + (dh >> p.shH)) * p.Gw + (dw >> p.shW));
+        ktab[k8] = make_int2(tap, (int)((dpos * p.g_ld + c8 * 8) * 2));
+      } else {
+        ktab[k8] = make_int2(dt | (dh << 8) | (dw << 16), c8 * 8);
+      }
     }
   }
 
   // ---- per-thread row state (this thread always loads 16-byte unit kc of rows lrow+32i)
   int rT[AI], rH[AI], rW[AI];
   long long rbase[AI];
+  unsigned roff[AI], vmask[AI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
     const int m = m0 + lrow + 32 * i;
+    rT[i] = rH[i] = rW[i] = -(1 << 20);
+    rbase[i] = -1;
+    roff[i] = VS_OOB;
+    vmask[i] = 0u;
     if (m < p.M) {
       int rw = m % p.Rw, t1 = m / p.Rw;
       int rh = t1 % p.Rh, t2 = t1 / p.Rh;
@@ -97,18 +122,53 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         const long long pos =
             ((long long)(n * p.Gt + rt * p.mulT) * p.Gh + rh * p.mulH) * p.Gw + rw * p.mulW;
         rbase[i] = pos * p.g_ld;
-        rT[i] = rH[i] = rW[i] = 0;
+        roff[i] = (unsigned)(pos * p.g_ld * 2);
+        vmask[i] = 1u;
       } else {
+        const int ct = rt * p.mulT + p.offT, ch = rh * p.mulH + p.offH, cw = rw * p.mulW + p.offW;
         rbase[i] = (long long)n * p.Gt * p.Gh * p.Gw;
-        rT[i] = rt * p.mulT + p.offT;
-        rH[i] = rh * p.mulH + p.offH;
-        rW[i] = rw * p.mulW + p.offW;
+        rT[i] = ct;
+        rH[i] = ch;
+        rW[i] = cw;
+        if (FAST) {
+          long long pos0;
+          if (MODE == 1) pos0 = rbase[i] + ((long long)ct * p.Gh + ch) * p.Gw + cw;
+          else pos0 = rbase[i] + ((long long)(ct >> p.shT) * p.Gh + (ch >> p.shH)) * p.Gw + (cw >> p.shW);
+          roff[i] = (unsigned)(pos0 * p.g_ld * 2);  // exact modulo 2^32 whenever the tap is valid
+          unsigned mk = 0u;
+          int tap = 0;
+          for (int dt = 0; dt < p.kT; ++dt)
+            for (int dh = 0; dh < p.kH; ++dh)
+              for (int dw = 0; dw < p.kW; ++dw, ++tap) {
+                int ti = ct + p.tmul * dt, hi = ch + p.tmul * dh, wi = cw + p.tmul * dw;
+                bool ok = true;
+                if (MODE == 2) {
+                  ok = (((ti & ((1 << p.shT) - 1)) | (hi & ((1 << p.shH) - 1)) |
+                         (wi & ((1 << p.shW) - 1))) == 0);
+                  ti >>= p.shT;
+                  hi >>= p.shH;
+                  wi >>= p.shW;
+                }
+                ok = ok && ((unsigned)ti < (unsigned)p.Gt) && ((unsigned)hi < (unsigned)p.Gh) &&
+                     ((unsigned)wi < (unsigned)p.Gw);
+                mk |= (ok ? 1u : 0u) << tap;
+              }
+          vmask[i] = mk;
+        }
       }
-    } else {
-      rbase[i] = -1;
-      rT[i] = rH[i] = rW[i] = -(1 << 20);
     }
   }
+  // weight rows of this thread (byte offsets; OOB beyond Ncols)
+  unsigned boff[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int row = lrow + 32 * j, n = n0 + row;
+    boff[j] = (row < BN && n < p.Ncols) ? (unsigned)((long long)n * p.K * 2) : VS_OOB;
+  }
+  const __amdgpu_buffer_rsrc_t xsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
 
   u32x4 ra[AI], rb[BJ];
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -116,6 +176,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   auto gload = [&](int kt) __attribute__((always_inline)) {
     const int k8 = kt * 8 + kc;
     const bool kval = k8 < K8;
+    if (FAST) {
+      // branch-free: every predicate is folded into the byte offset (OOB -> zeros)
+      int2 e = make_int2(0, k8 * 16);
+      if (MODE != 0) e = ktab[k8];  // table is padded to whole k-steps (tap 31 = never valid)
+      const unsigned kbit = (MODE == 0) ? (unsigned)kval : 1u;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const unsigned ok = kbit & (vmask[i] >> e.x) & 1u;
+        const unsigned off = ok ? roff[i] + (unsigned)e.y : VS_OOB;
+        ra[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0));
+      }
+#pragma unroll
+      for (int j = 0; j < BJ; ++j) {
+        const unsigned ok = (unsigned)kval & (unsigned)(boff[j] != VS_OOB);
+        const unsigned off = ok ? boff[j] + (unsigned)(k8 * 16) : VS_OOB;
+        rb[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wsrc, off, 0, 0));
+      }
+      return;
+    }
     if (MODE == 0) {
 #pragma unroll
       for (int i = 0; i < AI; ++i) {
@@ -181,12 +260,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
     for (int b = 0; b < NR; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  auto compute = [&](int buf, int kt) __attribute__((always_inline)) {
+  // straight-line MFMA chains (no conditional exit: a branch here makes the compiler shuttle
+  // every accumulator between AGPRs and VGPRs each k-step); a K tail multiplies staged zeros.
+  auto compute = [&](int buf) __attribute__((always_inline)) {
     const char* A = smem + buf * STAGE;
     const char* B = A + BM * 128;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      if (ks == 1 && kt * 64 + 32 >= p.K) break;  // K tail: nothing but zeros left
       bf16x8 af[MR], bfr[NR];
       const int ch = ks * 4 + lq;
 #pragma unroll
@@ -212,13 +292,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   gload(0);
   sstore(0);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
+  // loop body without control flow (the last k-step is peeled): keeps the accumulators in
+  // place instead of being copied between register files around every branch
+  for (int kt = 0; kt < nk - 1; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
-    compute(cur, kt);
-    if (kt + 1 < nk) sstore(cur ^ 1);
+    gload(kt + 1);
+    compute(cur);
+    sstore(cur ^ 1);
     __syncthreads();
   }
+  compute((nk - 1) & 1);
+  __syncthreads();
 
   // ---------------- epilogue ----------------
   // (1) BN batch-statistic partials from the fp32 accumulators (tail rows are
@@ -246,25 +330,80 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
       }
     }
   }
-  // (2) accumulators -> fp32 LDS tile (with the per-channel affine)
-  float* E = (float*)smem;
+  constexpr int CPR = BN / 8;
+  const bool has_res = (p.flags & VS_CONV_RESIDUAL) != 0;
+  if (!has_res) {
+    // (2a) no residual: affine + ReLU in registers, bf16 straight into an LDS tile, then
+    //      whole 16-byte channel vectors are copied out (no unpack / repack pass).
+    uint16_t* Eh = (uint16_t*)smem;
+    const bool relu = (p.flags & VS_CONV_RELU) != 0;
 #pragma unroll
-  for (int b = 0; b < NR; ++b) {
-    const int col = wn * TN + b * 16 + lr;
-    float sc = 1.f, sh = 0.f;
-    if ((p.flags & VS_CONV_AFFINE) && (n0 + col < p.Ncols)) {
-      sc = p.scale[n0 + col];
-      sh = p.shift[n0 + col];
-    }
-#pragma unroll
-    for (int a = 0; a < MR; ++a)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = wm * TM + a * 16 + lq * 4 + r;
-        E[row * BN + col] = acc[a][b][r] * sc + sh;
+    for (int b = 0; b < NR; ++b) {
+      const int col = wn * TN + b * 16 + lr;
+      float sc = 1.f, sh = 0.f;
+      if ((p.flags & VS_CONV_AFFINE) && (n0 + col < p.Ncols)) {
+        sc = p.scale[n0 + col];
+        sh = p.shift[n0 + col];
       }
+#pragma unroll
+      for (int a = 0; a < MR; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wm * TM + a * 16 + lq * 4 + r;
+          float v = acc[a][b][r] * sc + sh;
+          if (relu) v = fmaxf(v, 0.f);
+          Eh[row * BN + col] = f32_to_bf16(v);
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < BM * CPR; idx += 256) {
+      const int row = idx / CPR, c8 = idx - row * CPR;
+      const int m = m0 + row, n = n0 + c8 * 8;
+      if (m < p.M && n < p.Ncols)
+        *(uint4*)(p.y + (long long)m * p.y_ld + n) = *(const uint4*)(Eh + row * BN + c8 * 8);
+    }
+  } else {
+    // (2b) residual add: fp32 tile through LDS, residual read as 16-byte vectors
+    float* E = (float*)smem;
+#pragma unroll
+    for (int b = 0; b < NR; ++b) {
+      const int col = wn * TN + b * 16 + lr;
+      float sc = 1.f, sh = 0.f;
+      if ((p.flags & VS_CONV_AFFINE) && (n0 + col < p.Ncols)) {
+        sc = p.scale[n0 + col];
+        sh = p.shift[n0 + col];
+      }
+#pragma unroll
+      for (int a = 0; a < MR; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wm * TM + a * 16 + lq * 4 + r;
+          E[row * BN + col] = acc[a][b][r] * sc + sh;
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < BM * CPR; idx += 256) {
+      const int row = idx / CPR, c8 = idx - row * CPR;
+      const int m = m0 + row, n = n0 + c8 * 8;
+      if (m < p.M && n < p.Ncols) {
+        float v[8];
+        const float4 v0 = *(const float4*)(E + row * BN + c8 * 8);
+        const float4 v1 = *(const float4*)(E + row * BN + c8 * 8 + 4);
+        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
+        v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+        const uint4 rv = *(const uint4*)(p.res + (long long)m * p.res_ld + n);
+        float rf[8];
+        unpack8_bf16(rv, rf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rf[e];
+        if (p.flags & VS_CONV_RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        *(uint4*)(p.y + (long long)m * p.y_ld + n) = pack8_bf16(v);
+      }
+    }
   }
-  __syncthreads();
   if ((p.flags & VS_CONV_STATS) && tid < BN && n0 + tid < p.Ncols) {
     float s = 0.f, q = 0.f;
 #pragma unroll
@@ -275,31 +414,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     float* dst = p.stats + (long long)tm * 2 * p.Ncols;
     dst[n0 + tid] = s;
     dst[p.Ncols + n0 + tid] = q;
-  }
-  // (3) whole 16-byte channel vectors: residual add, ReLU, bf16, store
-  constexpr int CPR = BN / 8;
-  for (int idx = tid; idx < BM * CPR; idx += 256) {
-    const int row = idx / CPR, c8 = idx - row * CPR;
-    const int m = m0 + row, n = n0 + c8 * 8;
-    if (m < p.M && n < p.Ncols) {
-      float v[8];
-      const float4 v0 = *(const float4*)(E + row * BN + c8 * 8);
-      const float4 v1 = *(const float4*)(E + row * BN + c8 * 8 + 4);
-      v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
-      v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-      if (p.flags & VS_CONV_RESIDUAL) {
-        const uint4 rv = *(const uint4*)(p.res + (long long)m * p.res_ld + n);
-        float rf[8];
-        unpack8_bf16(rv, rf);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += rf[e];
-      }
-      if (p.flags & VS_CONV_RELU) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-      }
-      *(uint4*)(p.y + (long long)m * p.y_ld + n) = pack8_bf16(v);
-    }
   }
 }
 
@@ -370,26 +484,36 @@ static TileCfg pick_tile(long long M, int Ncols) {
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const ConvP& p, int mode, hipStream_t st) {
   const size_t smem =
-      (size_t)ConvSmem<BM, BN>::MAIN + 2 * WM * BN * 4 + (mode ? (size_t)(p.K >> 3) * 8 : 0);
+      (size_t)ConvSmem<BM, BN>::MAIN + 2 * WM * BN * 4 + (mode ? (size_t)((p.K + 63) >> 6) * 64 : 0);
   const int grid = p.tilesM * p.tilesN;
+  const bool fast = p.kT * p.kH * p.kW <= 31;
   // dynamic LDS above 64 KiB needs an explicit opt-in, once per kernel
   static bool attr_done = false;
   if (!attr_done) {
     const int max_smem = 160 * 1024;
-    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, 0>,
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, 0, true>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_smem);
-    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, 1>,
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, 1, true>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_smem);
-    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, 2>,
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, 2, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, max_smem);
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, 1, false>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_smem);
     attr_done = true;
   }
-  if (mode == 0)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 0>), dim3(grid), dim3(256), smem, st, p);
+  if (!fast) {  // > 32 taps: only the Cin-padded stems of configurations without a stem kernel
+    if (mode != 1) {
+      vs_set_error("conv: more than 31 taps is only supported for the forward gather");
+      return VS_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, false>), dim3(grid), dim3(256), smem,
+                       st, p);
+  } else if (mode == 0)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 0, true>), dim3(grid), dim3(256), smem, st, p);
   else if (mode == 1)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1>), dim3(grid), dim3(256), smem, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, true>), dim3(grid), dim3(256), smem, st, p);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 2>), dim3(grid), dim3(256), smem, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 2, true>), dim3(grid), dim3(256), smem, st, p);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }
@@ -489,6 +613,13 @@ extern "C" int vs_conv_fwd(const void* x, const void* w, void* y, const vs_conv_
   p.offT = -d->pT; p.offH = -d->pH; p.offW = -d->pW;
   p.tmul = 1;
   p.shT = p.shH = p.shW = 0;
+  {
+    const long long xb = (long long)d->N * d->Ti * d->Hi * d->Wi * d->x_ld * 2;
+    const long long wb = (long long)d->Cout * p.K * 2;
+    VS_CHECK_ARG(xb < (1ll << 31) && wb < (1ll << 31), "tensor larger than 2 GiB");
+    p.x_bytes = (unsigned)xb;
+    p.w_bytes = (unsigned)wb;
+  }
   p.y_ld = d->y_ld;
   p.res_ld = d->res_ld;
   p.flags = d->flags & 0xff;
@@ -525,6 +656,13 @@ extern "C" int vs_conv_dgrad(const void* dy, const void* wt, void* dx, const vs_
   p.offT = d->pT; p.offH = d->pH; p.offW = d->pW;
   p.tmul = -1;
   p.shT = shT; p.shH = shH; p.shW = shW;
+  {
+    const long long xb = (long long)d->N * d->To * d->Ho * d->Wo * d->y_ld * 2;
+    const long long wb = (long long)d->Cin * p.K * 2;
+    VS_CHECK_ARG(xb < (1ll << 31) && wb < (1ll << 31), "tensor larger than 2 GiB");
+    p.x_bytes = (unsigned)xb;
+    p.w_bytes = (unsigned)wb;
+  }
   p.y_ld = d->x_ld;
   p.res_ld = d->res_ld;
   p.flags = d->flags & (VS_CONV_NAIVE | VS_CONV_RESIDUAL);
