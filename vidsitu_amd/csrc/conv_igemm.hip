@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
       const int dh = t2 % p.kH, dt = t2 / p.kH;
       if (FAST) {
         long long dpos;
-        if (MODE == 1) dpos = ((long long)dt * p.Gh + dh) * p.Gw + dw;
+        if (MODE == 1) dpos = (((long long)dt * p.Gh + dh) * p.Gw + dw) * p.tmul;
         else dpos = -(((long long)(dt >> p.shT) * p.Gh + (dh >> p.shH)) * p.Gw + (dw >> p.shW));
         ktab[k8] = make_int2(tap, (int)((dpos * p.g_ld + c8 * 8) * 2));
       } else {
@@ -135,24 +135,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
           if (MODE == 1) pos0 = rbase[i] + ((long long)ct * p.Gh + ch) * p.Gw + cw;
           else pos0 = rbase[i] + ((long long)(ct >> p.shT) * p.Gh + (ch >> p.shH)) * p.Gw + (cw >> p.shW);
           roff[i] = (unsigned)(pos0 * p.g_ld * 2);  // exact modulo 2^32 whenever the tap is valid
+          // per-axis validity first (kT + kH + kW tests), then one AND per tap
+          auto axis_mask = [&](int c, int kk, int sh, int G) {
+            unsigned mm = 0u;
+            for (int dd = 0; dd < kk; ++dd) {
+              int v = c + p.tmul * dd;
+              bool ok = true;
+              if (MODE == 2) {
+                ok = (v & ((1 << sh) - 1)) == 0;
+                v >>= sh;
+              }
+              ok = ok && ((unsigned)v < (unsigned)G);
+              mm |= (ok ? 1u : 0u) << dd;
+            }
+            return mm;
+          };
+          const unsigned mt = axis_mask(ct, p.kT, p.shT, p.Gt), mh = axis_mask(ch, p.kH, p.shH, p.Gh),
+                         mw = axis_mask(cw, p.kW, p.shW, p.Gw);
           unsigned mk = 0u;
           int tap = 0;
           for (int dt = 0; dt < p.kT; ++dt)
-            for (int dh = 0; dh < p.kH; ++dh)
-              for (int dw = 0; dw < p.kW; ++dw, ++tap) {
-                int ti = ct + p.tmul * dt, hi = ch + p.tmul * dh, wi = cw + p.tmul * dw;
-                bool ok = true;
-                if (MODE == 2) {
-                  ok = (((ti & ((1 << p.shT) - 1)) | (hi & ((1 << p.shH) - 1)) |
-                         (wi & ((1 << p.shW) - 1))) == 0);
-                  ti >>= p.shT;
-                  hi >>= p.shH;
-                  wi >>= p.shW;
-                }
-                ok = ok && ((unsigned)ti < (unsigned)p.Gt) && ((unsigned)hi < (unsigned)p.Gh) &&
-                     ((unsigned)wi < (unsigned)p.Gw);
-                mk |= (ok ? 1u : 0u) << tap;
-              }
+            for (int dh = 0; dh < p.kH; ++dh) {
+              const unsigned th = (mt >> dt) & (mh >> dh) & 1u;
+              mk |= (th ? mw : 0u) << tap;
+              tap += p.kW;
+            }
           vmask[i] = mk;
         }
       }
@@ -296,8 +303,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   // place instead of being copied between register files around every branch
   for (int kt = 0; kt < nk - 1; ++kt) {
     const int cur = kt & 1;
-    gload(kt + 1);
-    compute(cur);
+    gload(kt + 1);                        // issue the next tile's loads first ...
+    __builtin_amdgcn_sched_barrier(0);    // (the scheduler otherwise sinks them below the MFMAs)
+    compute(cur);                         // ... so their latency hides under this tile's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
     sstore(cur ^ 1);
     __syncthreads();
   }

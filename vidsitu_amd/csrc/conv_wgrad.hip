@@ -199,7 +199,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     for (int st = 0; st < nsteps; ++st) {
       const int cur = st & 1;
       if (st + 1 < nsteps) gload(chunk0 + (st + 1) * 64, chunk0);
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs
       compute(cur);
+      __builtin_amdgcn_sched_barrier(0);
       if (st + 1 < nsteps) sstore(cur ^ 1);
       __syncthreads();
     }
