@@ -139,16 +139,19 @@ int vs_bn_apply(const void* y, const float* scale, const float* shift, const voi
 /* Backward of z = relu?(bn(y) (+res)):  g = dz * [z>0];
  *   pass 1 (reduce): partial[blk][2][C] = (sum g, sum g*xhat), xhat=(y-mean)*invstd
  *   pass 2 (apply):  dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M); dres = g. */
+/* z may be NULL when relu is set and the unit has no residual input: the mask is then
+ * recomputed from y as gamma*xhat + beta > 0 (one read less per pass). */
 int vs_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* mean,
-                     const float* invstd, float* partial, int64_t rows, int C, int dz_ld, int z_ld,
-                     int y_ld, int relu, void* stream);
+                     const float* invstd, const float* gamma, const float* beta, float* partial,
+                     int64_t rows, int C, int dz_ld, int z_ld, int y_ld, int relu, void* stream);
 int vs_bn_bwd_reduce_rows(int64_t rows, int C);
 int vs_bn_bwd_finalize(const float* partial, int nparts, float* dgamma, float* dbeta, int C,
                        void* stream);
 int vs_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* mean,
-                    const float* invstd, const float* gamma, const float* dgamma,
-                    const float* dbeta, void* dy, void* dres, int64_t rows, int C, int dz_ld,
-                    int z_ld, int y_ld, int dy_ld, int dres_ld, int relu, void* stream);
+                    const float* invstd, const float* gamma, const float* beta,
+                    const float* dgamma, const float* dbeta, void* dy, void* dres, int64_t rows,
+                    int C, int dz_ld, int z_ld, int y_ld, int dy_ld, int dres_ld, int relu,
+                    void* stream);
 
 /* MaxPool3d([1,3,3], s[1,2,2], p[0,1,1]) of the stems (slowfast stem_helper via
  * mdl_sf_base.py:22).  idx: uint8 argmax tap (first max in (kh,kw) scan order,

@@ -87,6 +87,13 @@ def test_bn_backward_matches_autograd(c, hw, relu, res, dev):
     assert_close(dbeta, grads[2], 2e-2, "dbeta")
     if res:
         assert_close(dres, grads[3], 2e-2, "dres")
+    elif relu:  # same backward with the ReLU mask recomputed from y instead of read from z
+        dy2, _, dg2, db2 = ops.bn_bwd(to_act(dz, dev), None, yd, mean.to(dev), invstd.to(dev),
+                                      gamma.detach().to(dev), True, want_dres=False,
+                                      beta=beta.detach().to(dev))
+        assert_close(dy2, grads[0], 3e-2, "dy (mask from y)")
+        assert_close(dg2, grads[1], 2e-2, "dgamma (mask from y)")
+        assert_close(db2, grads[2], 2e-2, "dbeta (mask from y)")
 
 
 @pytest.mark.parametrize("c,t,h,w", [(8, 2, 16, 16), (64, 2, 14, 18), (16, 1, 7, 9)])

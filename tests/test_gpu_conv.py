@@ -33,6 +33,12 @@ CASES = [
     ("s3_odd_hw", 1, 32, 3, 9, 11, 32, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
     ("fuse_7x1x1_s4", 2, 8, 32, 6, 6, 16, (7, 1, 1), (4, 1, 1), (3, 0, 0)),
     ("fuse_32_64", 1, 32, 16, 5, 5, 64, (7, 1, 1), (4, 1, 1), (3, 0, 0)),
+    # small-channel layers of the fast pathway -> direct (register-resident weights) kernel
+    ("dir_8_8_3x3_big", 2, 8, 8, 40, 40, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("dir_32_8_t3", 1, 32, 16, 24, 24, 8, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ("dir_8_32_pw", 2, 8, 8, 36, 36, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("dir_16_16_s2", 2, 16, 6, 30, 26, 16, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ("dir_8_32_pw_s2", 1, 8, 4, 30, 30, 32, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
     ("stem_slow", 1, 8, 2, 32, 32, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3)),
     ("stem_fast", 1, 8, 8, 32, 32, 8, (5, 7, 7), (1, 2, 2), (2, 3, 3)),
 ]
@@ -57,7 +63,7 @@ def test_conv_fwd_matches_torch(case, dev):
     assert_close(y, ref, TOL, case[0])
 
 
-@pytest.mark.parametrize("case", [CASES[0], CASES[4], CASES[9], CASES[12], CASES[16], CASES[19]],
+@pytest.mark.parametrize("case", [CASES[0], CASES[4], CASES[9], CASES[12], CASES[16], CASES[18], CASES[24]],
                          ids=lambda c: c[0])
 def test_mfma_kernel_matches_naive_hip_kernel(case, dev):
     """Two independent HIP implementations of the same gather agree (isolates MFMA/LDS bugs)."""
@@ -93,8 +99,8 @@ def test_conv_fused_epilogue_and_concat_write(dev):
     assert float(buf[:, :32].float().abs().max()) == 0.0  # neighbours untouched
 
 
-@pytest.mark.parametrize("case", [CASES[1], CASES[7], CASES[11], CASES[13], CASES[17]],
-                         ids=lambda c: c[0])
+@pytest.mark.parametrize("case", [CASES[1], CASES[7], CASES[11], CASES[13], CASES[17], CASES[18], CASES[20],
+                                  CASES[21]], ids=lambda c: c[0])
 def test_conv_bn_stat_partials(case, dev):
     from vidsitu_amd import ops
 
@@ -108,7 +114,7 @@ def test_conv_bn_stat_partials(case, dev):
     assert torch.allclose(tot[1], rsq, rtol=1e-3, atol=1e-3)
 
 
-DG_CASES = [CASES[i] for i in (0, 1, 3, 4, 5, 8, 9, 11, 12, 14, 15, 16, 17)]
+DG_CASES = [CASES[i] for i in (0, 1, 3, 4, 5, 8, 9, 11, 12, 14, 15, 16, 17, 18, 19, 20, 21, 22)]
 
 
 @pytest.mark.parametrize("case", DG_CASES, ids=[c[0] for c in DG_CASES])
@@ -132,7 +138,7 @@ def test_conv_dgrad_matches_autograd(case, dev):
     assert_close(ra, dx_ref + r, TOL, case[0] + " +residual in place")
 
 
-WG_CASES = [CASES[i] for i in (0, 1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 19)]
+WG_CASES = [CASES[i] for i in (0, 1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 19, 21, 23, 24)]
 
 
 @pytest.mark.parametrize("case", WG_CASES, ids=[c[0] for c in WG_CASES])
@@ -147,6 +153,27 @@ def test_conv_wgrad_matches_autograd(case, dev):
     dw = ops.conv_wgrad(to_act(dy, dev), to_act(x, dev), k, s, p)
     assert tuple(dw.shape) == tuple(dw_ref.shape)
     assert_close(dw, dw_ref, 5e-3, case[0])  # fp32 output, only operand rounding differs
+
+
+def test_direct_kernel_epilogue_and_residual(dev):
+    """The register-resident small-channel kernel: affine + ReLU, residual add (dgrad fan-out),
+    forced tiled kernel gives the same answer."""
+    from vidsitu_amd import ops
+
+    x, w, k, s, p = _mk(CASES[18], seed=21)
+    g = torch.Generator().manual_seed(22)
+    cout = w.shape[0]
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ref0 = F.conv3d(x, w, stride=s, padding=p)
+    res = rb(torch.randn(ref0.shape, generator=g))
+    ref = F.relu(ref0 * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1) + res)
+    xa, wa = to_act(x, dev), to_w(w, dev)
+    y, _ = ops.conv_fwd(xa, wa, k, s, p, scale=scale.to(dev), shift=shift.to(dev),
+                        residual=to_act(res, dev), relu=True)
+    assert_close(y, ref, TOL, "direct kernel: affine + residual + relu")
+    y_tiled, _ = ops.conv_fwd(xa, wa, k, s, p, scale=scale.to(dev), shift=shift.to(dev),
+                              residual=to_act(res, dev), relu=True, tile=5)
+    assert_close(y, y_tiled.float(), 8e-3, "direct vs tiled kernel")
 
 
 def test_wgrad_is_bitwise_reproducible(dev):

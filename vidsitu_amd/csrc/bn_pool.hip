@@ -228,10 +228,12 @@ extern "C" int vs_bn_apply(const void* y, const float* scale, const float* shift
 // ----------------------------------------------------------------------------
 #define BNB_ROWS_PER_LANE 16
 
+// relu with z == nullptr: the mask is recomputed as gamma*xhat + beta > 0 (units without a
+// residual input), which drops one of the three reads of each pass.
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const uint16_t* dz, const uint16_t* z, const uint16_t* y, const float* mean,
-    const float* invstd, float* partial, long long rows, int C, int dz_ld, int z_ld, int y_ld,
-    int relu) {
+    const float* invstd, const float* gamma, const float* beta, float* partial, long long rows,
+    int C, int dz_ld, int z_ld, int y_ld, int relu) {
   __shared__ float red[256 * 16];
   const int cpr = C >> 3;
   const int ncol = cpr < 256 ? cpr : 256;  // chunk columns handled per pass
@@ -241,11 +243,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
   const long long r0 = (long long)blockIdx.x * rows_per_blk;
   for (int cb = col; cb < cpr; cb += ncol) {
     const int c = cb * 8;
-    float mu[8], is[8], sg[8], sx[8];
+    float mu[8], is[8], sg[8], sx[8], ga[8], be[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       mu[e] = mean[c + e];
       is[e] = invstd[c + e];
+      ga[e] = (relu && !z) ? gamma[c + e] : 0.f;
+      be[e] = (relu && !z) ? beta[c + e] : 0.f;
       sg[e] = 0.f;
       sx[e] = 0.f;
     }
@@ -255,11 +259,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
         float g[8], yv[8];
         unpack8_bf16(*(const uint4*)(dz + row * dz_ld + c), g);
         unpack8_bf16(*(const uint4*)(y + row * y_ld + c), yv);
-        if (relu) {
+        if (relu && z) {
           float zv[8];
           unpack8_bf16(*(const uint4*)(z + row * z_ld + c), zv);
 #pragma unroll
           for (int e = 0; e < 8; ++e) g[e] = zv[e] > 0.f ? g[e] : 0.f;
+        } else if (relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            g[e] = ((yv[e] - mu[e]) * is[e] * ga[e] + be[e]) > 0.f ? g[e] : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -309,15 +317,16 @@ extern "C" int vs_bn_bwd_reduce_rows(int64_t rows, int C) {
 }
 
 extern "C" int vs_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* mean,
-                                const float* invstd, float* partial, int64_t rows, int C, int dz_ld,
-                                int z_ld, int y_ld, int relu, void* stream) {
+                                const float* invstd, const float* gamma, const float* beta,
+                                float* partial, int64_t rows, int C, int dz_ld, int z_ld, int y_ld,
+                                int relu, void* stream) {
   VS_CHECK_ARG(dz && y && mean && invstd && partial, "null tensor");
-  VS_CHECK_ARG(!relu || z, "relu needs z");
+  VS_CHECK_ARG(!relu || z || (gamma && beta), "relu needs z, or gamma/beta to recompute the mask");
   VS_CHECK_ARG(bnb_check(C), "C/8 must be a power of two");
   const int nblk = vs_bn_bwd_reduce_rows(rows, C);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream,
-                     (const uint16_t*)dz, (const uint16_t*)z, (const uint16_t*)y, mean, invstd,
-                     partial, (long long)rows, C, dz_ld, z_ld, y_ld, relu);
+                     (const uint16_t*)dz, (const uint16_t*)z, (const uint16_t*)y, mean, invstd, gamma,
+                     beta, partial, (long long)rows, C, dz_ld, z_ld, y_ld, relu);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }
@@ -360,7 +369,8 @@ extern "C" int vs_bn_bwd_finalize(const float* partial, int nparts, float* dgamm
 
 __global__ void bn_bwd_apply_kernel(const uint16_t* dz, const uint16_t* z, const uint16_t* y,
                                     const float* mean, const float* invstd, const float* gamma,
-                                    const float* dgamma, const float* dbeta, uint16_t* dy,
+                                    const float* beta, const float* dgamma, const float* dbeta,
+                                    uint16_t* dy,
                                     uint16_t* dres, long long rows, int C, int dz_ld, int z_ld,
                                     int y_ld, int dy_ld, int dres_ld, int relu) {
   const int cpr = C >> 3;
@@ -373,7 +383,7 @@ __global__ void bn_bwd_apply_kernel(const uint16_t* dz, const uint16_t* z, const
     float g[8], yv[8], o[8];
     unpack8_bf16(*(const uint4*)(dz + row * dz_ld + c), g);
     unpack8_bf16(*(const uint4*)(y + row * y_ld + c), yv);
-    if (relu) {
+    if (relu && z) {
       float zv[8];
       unpack8_bf16(*(const uint4*)(z + row * z_ld + c), zv);
 #pragma unroll
@@ -383,6 +393,7 @@ __global__ void bn_bwd_apply_kernel(const uint16_t* dz, const uint16_t* z, const
     for (int e = 0; e < 8; ++e) {
       const float is = invstd[c + e];
       const float xh = (yv[e] - mean[c + e]) * is;
+      if (relu && !z) g[e] = (xh * gamma[c + e] + beta[c + e]) > 0.f ? g[e] : 0.f;
       o[e] = gamma[c + e] * is * (g[e] - dbeta[c + e] * invM - xh * dgamma[c + e] * invM);
     }
     *(uint4*)(dy + row * dy_ld + c) = pack8_bf16(o);
@@ -391,16 +402,16 @@ __global__ void bn_bwd_apply_kernel(const uint16_t* dz, const uint16_t* z, const
 }
 
 extern "C" int vs_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* mean,
-                               const float* invstd, const float* gamma, const float* dgamma,
-                               const float* dbeta, void* dy, void* dres, int64_t rows, int C,
-                               int dz_ld, int z_ld, int y_ld, int dy_ld, int dres_ld, int relu,
-                               void* stream) {
+                               const float* invstd, const float* gamma, const float* beta,
+                               const float* dgamma, const float* dbeta, void* dy, void* dres,
+                               int64_t rows, int C, int dz_ld, int z_ld, int y_ld, int dy_ld,
+                               int dres_ld, int relu, void* stream) {
   VS_CHECK_ARG(dz && y && mean && invstd && gamma && dgamma && dbeta && dy, "null tensor");
-  VS_CHECK_ARG(!relu || z, "relu needs z");
+  VS_CHECK_ARG(!relu || z || beta, "relu needs z, or beta to recompute the mask");
   VS_CHECK_ARG(C % 8 == 0, "C must be a multiple of 8");
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * (C / 8))), dim3(256), 0,
                      (hipStream_t)stream, (const uint16_t*)dz, (const uint16_t*)z,
-                     (const uint16_t*)y, mean, invstd, gamma, dgamma, dbeta, (uint16_t*)dy,
+                     (const uint16_t*)y, mean, invstd, gamma, beta, dgamma, dbeta, (uint16_t*)dy,
                      (uint16_t*)dres, (long long)rows, C, dz_ld, z_ld, y_ld, dy_ld, dres_ld, relu);
   VS_CHECK_LAUNCH();
   return VS_OK;

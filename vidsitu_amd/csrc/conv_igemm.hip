@@ -426,6 +426,236 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   }
 }
 
+// =============================================================================
+// Direct kernel for small-channel layers (fast pathway: N <= 32, K <= 160, taps <= 31).
+// Those GEMMs are a few MFMAs per 16 rows, so the tiled kernel above is all prologue /
+// barrier / epilogue.  Here there is no block-level cooperation at all: the whole weight
+// matrix sits in registers as B fragments, every lane fetches its A fragment (16 bytes =
+// 8 channels of one tap of its row) straight into the MFMA operand with a bounds-checked
+// buffer_load, each wave streams `tiles_per_wave` consecutive 16-row tiles, and the only
+// LDS use is a 512-byte per-wave transpose so that stores are whole channel vectors.
+// =============================================================================
+__device__ __forceinline__ void fast_divmod(int x, int d, float rcp, int& q, int& r) {
+  q = (int)((float)x * rcp);
+  r = x - q * d;
+  if (r < 0) { r += d; --q; }
+  if (r >= d) { r -= d; ++q; }
+}
+
+template <int NT, int KS, int MODE>
+__global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p, int tiles_per_wave) {
+  __shared__ __attribute__((aligned(16))) uint16_t tbuf[4][16 * 16 * NT];
+  __shared__ float sstat[2][4][16 * NT];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int K8 = p.K >> 3, C8 = p.Cg >> 3;
+  const __amdgpu_buffer_rsrc_t xsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+
+  // B fragments: B[k = ks*32 + 8*lq + j][n = nt*16 + lr], resident for the whole kernel
+  bf16x8 bfr[KS][NT];
+  int ktap[KS], kdel[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int k8 = ks * 4 + lq;
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      const int n = b * 16 + lr;
+      const unsigned off = (k8 < K8 && n < p.Ncols) ? (unsigned)((n * p.K + k8 * 8) * 2) : VS_OOB;
+      bfr[ks][b] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wsrc, off, 0, 0));
+    }
+    ktap[ks] = 31;  // never valid
+    kdel[ks] = 0;
+    if (k8 < K8) {
+      if (MODE == 0) {
+        ktap[ks] = 0;
+        kdel[ks] = k8 * 16;
+      } else {
+        const int tap = k8 / C8, c8 = k8 - tap * C8;
+        const int dw = tap % p.kW, t2 = tap / p.kW;
+        const int dh = t2 % p.kH, dt = t2 / p.kH;
+        long long dpos;
+        if (MODE == 1) dpos = (((long long)dt * p.Gh + dh) * p.Gw + dw) * p.tmul;
+        else dpos = -(((long long)(dt >> p.shT) * p.Gh + (dh >> p.shH)) * p.Gw + (dw >> p.shW));
+        ktap[ks] = tap;
+        kdel[ks] = (int)((dpos * p.g_ld + c8 * 8) * 2);
+      }
+    }
+  }
+  const float rcpW = 1.0f / (float)p.Rw, rcpH = 1.0f / (float)p.Rh, rcpT = 1.0f / (float)p.Rt;
+  float ssum[NT], ssq[NT];
+#pragma unroll
+  for (int b = 0; b < NT; ++b) ssum[b] = ssq[b] = 0.f;
+  float sc[NT], sh[NT];
+#pragma unroll
+  for (int b = 0; b < NT; ++b) {
+    const int col = b * 16 + lr;
+    sc[b] = 1.f;
+    sh[b] = 0.f;
+    if ((p.flags & VS_CONV_AFFINE) && col < p.Ncols) {
+      sc[b] = p.scale[col];
+      sh[b] = p.shift[col];
+    }
+  }
+  const bool relu = (p.flags & VS_CONV_RELU) != 0, has_res = (p.flags & VS_CONV_RESIDUAL) != 0;
+  uint16_t* tb = tbuf[wave];
+  const int tile0 = (blockIdx.x * 4 + wave) * tiles_per_wave;
+
+  for (int it = 0; it < tiles_per_wave; ++it) {
+    const int m0 = (tile0 + it) * 16;
+    if (m0 >= p.M) break;
+    const int m = m0 + lr;
+    unsigned roff = VS_OOB, vmask = 0u;
+    if (m < p.M) {
+      int rw, t1, rh, t2, rt, n;
+      fast_divmod(m, p.Rw, rcpW, t1, rw);
+      fast_divmod(t1, p.Rh, rcpH, t2, rh);
+      fast_divmod(t2, p.Rt, rcpT, n, rt);
+      if (MODE == 0) {
+        const long long pos =
+            ((long long)(n * p.Gt + rt * p.mulT) * p.Gh + rh * p.mulH) * p.Gw + rw * p.mulW;
+        roff = (unsigned)(pos * p.g_ld * 2);
+        vmask = 1u;
+      } else {
+        const int ct = rt * p.mulT + p.offT, ch = rh * p.mulH + p.offH, cw = rw * p.mulW + p.offW;
+        long long pos0 = (long long)n * p.Gt * p.Gh * p.Gw;
+        if (MODE == 1) pos0 += ((long long)ct * p.Gh + ch) * p.Gw + cw;
+        else pos0 += ((long long)(ct >> p.shT) * p.Gh + (ch >> p.shH)) * p.Gw + (cw >> p.shW);
+        roff = (unsigned)(pos0 * p.g_ld * 2);
+        auto axis_mask = [&](int c, int kk, int shf, int G) {
+          unsigned mm = 0u;
+          for (int dd = 0; dd < kk; ++dd) {
+            int v = c + p.tmul * dd;
+            bool ok = true;
+            if (MODE == 2) {
+              ok = (v & ((1 << shf) - 1)) == 0;
+              v >>= shf;
+            }
+            ok = ok && ((unsigned)v < (unsigned)G);
+            mm |= (ok ? 1u : 0u) << dd;
+          }
+          return mm;
+        };
+        const unsigned mt = axis_mask(ct, p.kT, p.shT, p.Gt), mh = axis_mask(ch, p.kH, p.shH, p.Gh),
+                       mw = axis_mask(cw, p.kW, p.shW, p.Gw);
+        int tap = 0;
+        for (int dt = 0; dt < p.kT; ++dt)
+          for (int dh = 0; dh < p.kH; ++dh) {
+            const unsigned th = (mt >> dt) & (mh >> dh) & 1u;
+            vmask |= (th ? mw : 0u) << tap;
+            tap += p.kW;
+          }
+      }
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const unsigned ok = (vmask >> ktap[ks]) & 1u;
+      const unsigned off = ok ? roff + (unsigned)kdel[ks] : VS_OOB;
+      const bf16x8 af =
+          __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0));
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[ks][b], acc[b], 0, 0, 0);
+    }
+    // D[row = lq*4 + r][col = lr]; rows beyond M were zero-filled
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = acc[b][r];
+        ssum[b] += a;
+        ssq[b] += a * a;
+        float v = a * sc[b] + sh[b];
+        if (relu && !has_res) v = fmaxf(v, 0.f);
+        tb[(lq * 4 + r) * (16 * NT) + b * 16 + lr] = f32_to_bf16(v);
+      }
+    }
+    // the wave's own 16 x (16*NT) bf16 tile -> 16-byte channel vectors (wave-local LDS hand-off)
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's ds_writes have landed
+    __builtin_amdgcn_wave_barrier();
+    constexpr int CPRW = 2 * NT;  // chunks per row
+    for (int c = lane; c < 16 * CPRW; c += 64) {
+      const int row = c / CPRW, c8 = c - row * CPRW;
+      const int mm = m0 + row, n = c8 * 8;
+      if (mm < p.M && n < p.Ncols) {
+        uint4 v = *(const uint4*)(tb + row * (16 * NT) + c8 * 8);
+        if (has_res) {
+          float f[8], g[8];
+          unpack8_bf16(v, f);
+          unpack8_bf16(*(const uint4*)(p.res + (long long)mm * p.res_ld + n), g);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            f[e] += g[e];
+            if (relu) f[e] = fmaxf(f[e], 0.f);
+          }
+          v = pack8_bf16(f);
+        }
+        *(uint4*)(p.y + (long long)mm * p.y_ld + n) = v;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();  // reads done before the next tile overwrites tb
+  }
+  if (p.flags & VS_CONV_STATS) {
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      float s = ssum[b], q = ssq[b];
+      s += __shfl_xor(s, 16, 64);
+      q += __shfl_xor(q, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 32, 64);
+      if (lq == 0) {
+        sstat[0][wave][b * 16 + lr] = s;
+        sstat[1][wave][b * 16 + lr] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < p.Ncols) {
+      float* dst = p.stats + (long long)blockIdx.x * 2 * p.Ncols;
+      dst[tid] = sstat[0][0][tid] + sstat[0][1][tid] + sstat[0][2][tid] + sstat[0][3][tid];
+      dst[p.Ncols + tid] = sstat[1][0][tid] + sstat[1][1][tid] + sstat[1][2][tid] + sstat[1][3][tid];
+    }
+  }
+}
+
+#define VS_DIRECT_TPW 8  // 16-row tiles per wave -> 512 rows per block
+
+static bool direct_eligible(const ConvP& p) {
+  return p.Ncols <= 32 && p.K <= 160 && p.kT * p.kH * p.kW <= 31 && p.M >= 64;
+}
+static int direct_blocks(long long M) {
+  return (int)((M + 16 * 4 * VS_DIRECT_TPW - 1) / (16 * 4 * VS_DIRECT_TPW));
+}
+
+template <int NT, int KS>
+static int launch_direct_ks(const ConvP& p, int mode, hipStream_t st) {
+  const int grid = direct_blocks(p.M);
+  if (mode == 0)
+    hipLaunchKernelGGL((conv_direct_kernel<NT, KS, 0>), dim3(grid), dim3(256), 0, st, p, VS_DIRECT_TPW);
+  else if (mode == 1)
+    hipLaunchKernelGGL((conv_direct_kernel<NT, KS, 1>), dim3(grid), dim3(256), 0, st, p, VS_DIRECT_TPW);
+  else
+    hipLaunchKernelGGL((conv_direct_kernel<NT, KS, 2>), dim3(grid), dim3(256), 0, st, p, VS_DIRECT_TPW);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+template <int NT>
+static int launch_direct(const ConvP& p, int mode, hipStream_t st) {
+  switch ((p.K + 31) / 32) {
+    case 1: return launch_direct_ks<NT, 1>(p, mode, st);
+    case 2: return launch_direct_ks<NT, 2>(p, mode, st);
+    case 3: return launch_direct_ks<NT, 3>(p, mode, st);
+    case 4: return launch_direct_ks<NT, 4>(p, mode, st);
+    default: return launch_direct_ks<NT, 5>(p, mode, st);
+  }
+}
+
 // ---- debug / cross-check kernel: one thread per output element, same gather ---
 __global__ void conv_naive_kernel(ConvP p, int transposed) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -546,6 +776,8 @@ static int launch_conv(ConvP& p, int mode, int naive, int flags, hipStream_t st)
     VS_CHECK_LAUNCH();
     return VS_OK;
   }
+  if (direct_eligible(p) && ((flags >> 8) & 0xf) == 0)
+    return p.Ncols <= 16 ? launch_direct<1>(p, mode, st) : launch_direct<2>(p, mode, st);
   const TileCfg c = resolve_tile(p.M, p.Ncols, flags);
   p.tilesM = (p.M + c.bm - 1) / c.bm;
   p.tilesN = (p.Ncols + c.bn - 1) / c.bn;
@@ -582,6 +814,12 @@ static int check_desc(const vs_conv_desc* d) {
 
 extern "C" int vs_conv_stats_rows(const vs_conv_desc* d) {
   const long long M = (long long)d->N * d->To * d->Ho * d->Wo;
+  ConvP q;
+  q.M = (int)M;
+  q.Ncols = d->Cout;
+  q.K = d->kT * d->kH * d->kW * d->Cin;
+  q.kT = d->kT; q.kH = d->kH; q.kW = d->kW;
+  if (direct_eligible(q) && ((d->flags >> 8) & 0xf) == 0) return direct_blocks(M);
   const TileCfg c = resolve_tile(M, d->Cout, d->flags);
   return (int)((M + c.bm - 1) / c.bm);
 }

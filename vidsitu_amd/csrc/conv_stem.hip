@@ -53,7 +53,6 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemP p) {
   }
   const int wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 15, lq = lane >> 4;
-  const int ksteps = p.kT * 7;
   const int pT = p.kT >> 1;
 
   // Work item = (clip, spatial tile, chunk of ST_TC consecutive output frames).  Inside an item
@@ -108,25 +107,29 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemP p) {
 #pragma unroll
       for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int ks = 0; ks < ksteps; ++ks) {
-      const int dt = ks / 7, dh = ks - dt * 7;
-      const int ti = to - pT + dt;
-      const int slot = ((ti % p.kT) + p.kT) % p.kT;
-      bf16x8 af[2], bfr[NT];
+    // ring slot of frame (to - pT + dt): incremental, no division in the loop
+    int slot = (to - pT) % p.kT;
+    if (slot < 0) slot += p.kT;
+    int ks = 0;
+    for (int dt = 0; dt < p.kT; ++dt) {
+      const char* fbase = patch + slot * ST_FRAMEB + (2 * lr + 2 * lq) * 8;
+      for (int dh = 0; dh < 7; ++dh, ++ks) {
+        bf16x8 af[2], bfr[NT];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const int hol = wave * 2 + a;  // one output row per 16-position MFMA row tile
-        af[a] = *(const bf16x8*)(patch + slot * ST_FRAMEB + (2 * hol + dh) * ST_ROWB +
-                                 (2 * lr + 2 * lq) * 8);
-      }
-#pragma unroll
-      for (int b = 0; b < NT; ++b)
-        bfr[b] = *(const bf16x8*)(wlds + (b * 16 + lr) * wpitch + (ks * 32 + lq * 8) * 2);
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a) {
+          const int hol = wave * 2 + a;  // one output row per 16-position MFMA row tile
+          af[a] = *(const bf16x8*)(fbase + (2 * hol + dh) * ST_ROWB);
+        }
 #pragma unroll
         for (int b = 0; b < NT; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+          bfr[b] = *(const bf16x8*)(wlds + (b * 16 + lr) * wpitch + (ks * 32 + lq * 8) * 2);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < NT; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+      }
+      if (++slot == p.kT) slot = 0;
     }
 
     // ---- epilogue: D[row = lq*4 + r -> wo_l][col = lr -> cout] ----
@@ -315,10 +318,16 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgP p) {
   const int ntiles_n = p.kT * 14;
 
   f32x4 acc[MT][NTW];
+  int nt_dt[NTW], nt_off[NTW];  // per n-tile (dt, dh, half): frame index and byte offset in a frame
 #pragma unroll
-  for (int a = 0; a < MT; ++a)
+  for (int b = 0; b < NTW; ++b) {
 #pragma unroll
-    for (int b = 0; b < NTW; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < MT; ++a) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nt = wave + 4 * b;
+    const int half = nt & 1, row = nt >> 1;
+    nt_dt[b] = row / 7;
+    nt_off[b] = (row - nt_dt[b] * 7) * ST_ROWB + (half * 4 + p4) * 8;
+  }
 
   auto stage_frame = [&](int n, int ti, int hi0, int wi0) __attribute__((always_inline)) {
     const int slot = ((ti % p.kT) + p.kT) % p.kT;
@@ -373,6 +382,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgP p) {
         *(u32x4*)(dyl + (mt * 128 + pos) * 32 + h8 * 16) = v;
       }
       __syncthreads();
+      int slot0 = (to - pT) % p.kT;
+      if (slot0 < 0) slot0 += p.kT;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         // this lane supplies position k = ks*32 + 8g + q (and k + 4)
@@ -383,18 +394,14 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgP p) {
           const char* ptr = dyl + (a * 128 + k) * 32 + p4 * 8;
           af[a] = st_tr_pair(ptr, ptr + 4 * 32);
         }
-        const int hol = k >> 4, wol = k & 15;
+        const int rowk = (2 * (k >> 4)) * ST_ROWB + (2 * (k & 15)) * 8;  // patch offset of position k
 #pragma unroll
         for (int b = 0; b < NTW; ++b) {
-          const int nt = wave + 4 * b;
-          if (nt < ntiles_n) {
-            const int half = nt & 1, row = nt >> 1;  // row = dt*7 + dh
-            const int dt = row / 7, dh = row - dt * 7;
-            const int ti = to - pT + dt;
-            const int slot = ((ti % p.kT) + p.kT) % p.kT;
-            const char* ptr = patch + slot * ST_FRAMEB + (2 * hol + dh) * ST_ROWB +
-                              (2 * wol + half * 4 + p4) * 8;
-            const bf16x8 bf = st_tr_pair(ptr, ptr + 4 * 16);  // +4 positions = +8 pixels... see note
+          if (wave + 4 * b < ntiles_n) {
+            int sl = slot0 + nt_dt[b];
+            if (sl >= p.kT) sl -= p.kT;
+            const char* ptr = patch + sl * ST_FRAMEB + nt_off[b] + rowk;
+            const bf16x8 bf = st_tr_pair(ptr, ptr + 4 * 16);  // +4 positions = +64 bytes
 #pragma unroll
             for (int a = 0; a < MT; ++a)
               acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf, acc[a][b], 0, 0, 0);

@@ -318,8 +318,10 @@ def bn_apply(y, scale, shift, residual=None, relu=True, out=None):
     return out
 
 
-def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres, dy_out=None, dgamma=None, dbeta=None):
-    """Returns (dy, dres|None, dgamma, dbeta); dgamma / dbeta may be given (param.grad views)."""
+def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres, dy_out=None, dgamma=None, dbeta=None,
+           beta=None):
+    """Returns (dy, dres|None, dgamma, dbeta); dgamma / dbeta may be given (param.grad views).
+    With `beta` given and z None the ReLU mask is recomputed from y (no residual input)."""
     rows, c = act_rows(y), y.shape[1]
     dev = y.device
     nblk = _lib.load().vs_bn_bwd_reduce_rows(rows, c)
@@ -327,9 +329,10 @@ def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres, dy_out=None, dgamma=N
         raise _lib.VsError("bn_bwd: unsupported channel count")
     partial = torch.empty((nblk, 2, c), dtype=torch.float32, device=dev)
     zz = z if relu else None
+    z_ld = act_ld(zz) if zz is not None else 0
     _lib.call("vs_bn_bwd_reduce", _ptr(dz), _ptr(zz), _ptr(y), _ptr(mean), _ptr(invstd),
-              _ptr(partial), rows, c, act_ld(dz), act_ld(z) if relu else 0, act_ld(y), int(relu),
-              _stream())
+              _ptr(gamma), _ptr(beta), _ptr(partial), rows, c, act_ld(dz), z_ld, act_ld(y),
+              int(relu), _stream())
     if dgamma is None:
         dgamma = torch.empty(c, dtype=torch.float32, device=dev)
     if dbeta is None:
@@ -338,8 +341,8 @@ def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres, dy_out=None, dgamma=N
     dy = new_act(*y.shape, device=dev) if dy_out is None else dy_out
     dres = new_act(*y.shape, device=dev) if want_dres else None
     _lib.call("vs_bn_bwd_apply", _ptr(dz), _ptr(zz), _ptr(y), _ptr(mean), _ptr(invstd),
-              _ptr(gamma), _ptr(dgamma), _ptr(dbeta), _ptr(dy), _ptr(dres), rows, c, act_ld(dz),
-              act_ld(z) if relu else 0, act_ld(y), act_ld(dy), act_ld(dres) if want_dres else 0,
+              _ptr(gamma), _ptr(beta), _ptr(dgamma), _ptr(dbeta), _ptr(dy), _ptr(dres), rows, c,
+              act_ld(dz), z_ld, act_ld(y), act_ld(dy), act_ld(dres) if want_dres else 0,
               int(relu), _stream())
     return dy, dres, dgamma, dbeta
 

@@ -136,7 +136,8 @@ class _Unit:
         z = ops.bn_apply(y, scale, shift, residual, relu, out=out)
         if _Unit.trace is not None:
             _Unit.trace.append((conv, y.float().cpu(), z.float().cpu(), mean.cpu(), invstd.cpu()))
-        saved.append(dict(conv=conv, bn=bn, x=x, y=y, z=z, mean=mean, invstd=invstd, relu=relu))
+        saved.append(dict(conv=conv, bn=bn, x=x, y=y, z=z, mean=mean, invstd=invstd, relu=relu,
+                          has_res=residual is not None))
         return z
 
     @staticmethod
@@ -148,9 +149,11 @@ class _Unit:
             bn.weight.grad = torch.zeros_like(bn.weight)
         if bn.bias.grad is None:
             bn.bias.grad = torch.zeros_like(bn.bias)
+        # without a residual input the ReLU mask is recomputed from y (z is not read)
+        zmask = rec["z"] if (relu and rec["has_res"]) else None
         dy, dres, _, _ = ops.bn_bwd(
-            dz, rec["z"], rec["y"], rec["mean"], rec["invstd"], bn.weight, relu, want_dres,
-            dgamma=bn.weight.grad, dbeta=bn.bias.grad)
+            dz, zmask, rec["y"], rec["mean"], rec["invstd"], bn.weight, relu, want_dres,
+            dgamma=bn.weight.grad, dbeta=bn.bias.grad, beta=bn.bias)
         x = rec["x"]
         if conv.is_stem:
             _set_grad(conv.weight, ops.stem_conv_wgrad(dy, x, conv.k[0]))
