@@ -367,12 +367,12 @@ extern "C" int vs_bn_bwd_finalize(const float* partial, int nparts, float* dgamm
   return VS_OK;
 }
 
+template <int MASK>  // 0: no relu, 1: mask from z, 2: mask recomputed from y
 __global__ void bn_bwd_apply_kernel(const uint16_t* dz, const uint16_t* z, const uint16_t* y,
                                     const float* mean, const float* invstd, const float* gamma,
                                     const float* beta, const float* dgamma, const float* dbeta,
-                                    uint16_t* dy,
-                                    uint16_t* dres, long long rows, int C, int dz_ld, int z_ld,
-                                    int y_ld, int dy_ld, int dres_ld, int relu) {
+                                    uint16_t* dy, uint16_t* dres, long long rows, int C, int dz_ld,
+                                    int z_ld, int y_ld, int dy_ld, int dres_ld) {
   const int cpr = C >> 3;
   const long long total = rows * cpr;
   const float invM = 1.0f / (float)rows;
@@ -380,21 +380,34 @@ __global__ void bn_bwd_apply_kernel(const uint16_t* dz, const uint16_t* z, const
        idx += (long long)gridDim.x * blockDim.x) {
     const long long row = idx / cpr;
     const int c = (int)(idx - row * cpr) * 8;
-    float g[8], yv[8], o[8];
+    float g[8], yv[8], o[8], mu[8], is[8], ga[8], be[8], dg[8], db[8];
     unpack8_bf16(*(const uint4*)(dz + row * dz_ld + c), g);
     unpack8_bf16(*(const uint4*)(y + row * y_ld + c), yv);
-    if (relu && z) {
+    *(float4*)(mu) = *(const float4*)(mean + c);
+    *(float4*)(mu + 4) = *(const float4*)(mean + c + 4);
+    *(float4*)(is) = *(const float4*)(invstd + c);
+    *(float4*)(is + 4) = *(const float4*)(invstd + c + 4);
+    *(float4*)(ga) = *(const float4*)(gamma + c);
+    *(float4*)(ga + 4) = *(const float4*)(gamma + c + 4);
+    *(float4*)(dg) = *(const float4*)(dgamma + c);
+    *(float4*)(dg + 4) = *(const float4*)(dgamma + c + 4);
+    *(float4*)(db) = *(const float4*)(dbeta + c);
+    *(float4*)(db + 4) = *(const float4*)(dbeta + c + 4);
+    if (MASK == 1) {
       float zv[8];
       unpack8_bf16(*(const uint4*)(z + row * z_ld + c), zv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) g[e] = zv[e] > 0.f ? g[e] : 0.f;
     }
+    if (MASK == 2) {
+      *(float4*)(be) = *(const float4*)(beta + c);
+      *(float4*)(be + 4) = *(const float4*)(beta + c + 4);
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float is = invstd[c + e];
-      const float xh = (yv[e] - mean[c + e]) * is;
-      if (relu && !z) g[e] = (xh * gamma[c + e] + beta[c + e]) > 0.f ? g[e] : 0.f;
-      o[e] = gamma[c + e] * is * (g[e] - dbeta[c + e] * invM - xh * dgamma[c + e] * invM);
+      const float xh = (yv[e] - mu[e]) * is[e];
+      if (MASK == 2) g[e] = (xh * ga[e] + be[e]) > 0.f ? g[e] : 0.f;
+      o[e] = ga[e] * is[e] * (g[e] - db[e] * invM - xh * dg[e] * invM);
     }
     *(uint4*)(dy + row * dy_ld + c) = pack8_bf16(o);
     if (dres) *(uint4*)(dres + row * dres_ld + c) = pack8_bf16(g);
@@ -409,10 +422,15 @@ extern "C" int vs_bn_bwd_apply(const void* dz, const void* z, const void* y, con
   VS_CHECK_ARG(dz && y && mean && invstd && gamma && dgamma && dbeta && dy, "null tensor");
   VS_CHECK_ARG(!relu || z || beta, "relu needs z, or beta to recompute the mask");
   VS_CHECK_ARG(C % 8 == 0, "C must be a multiple of 8");
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * (C / 8))), dim3(256), 0,
-                     (hipStream_t)stream, (const uint16_t*)dz, (const uint16_t*)z,
-                     (const uint16_t*)y, mean, invstd, gamma, beta, dgamma, dbeta, (uint16_t*)dy,
-                     (uint16_t*)dres, (long long)rows, C, dz_ld, z_ld, y_ld, dy_ld, dres_ld, relu);
+  const dim3 grid(ew_grid(rows * (C / 8))), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define BNB_ARGS (const uint16_t*)dz, (const uint16_t*)z, (const uint16_t*)y, mean, invstd, gamma, beta, \
+                 dgamma, dbeta, (uint16_t*)dy, (uint16_t*)dres, (long long)rows, C, dz_ld, z_ld, y_ld, \
+                 dy_ld, dres_ld
+  if (!relu) hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, grid, block, 0, st, BNB_ARGS);
+  else if (z) hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, grid, block, 0, st, BNB_ARGS);
+  else hipLaunchKernelGGL(bn_bwd_apply_kernel<2>, grid, block, 0, st, BNB_ARGS);
+#undef BNB_ARGS
   VS_CHECK_LAUNCH();
   return VS_OK;
 }
