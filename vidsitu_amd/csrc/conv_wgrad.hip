@@ -27,7 +27,10 @@ struct WgradP {
   int To, Ho, Wo, Ti, Hi, Wi;
   int kT, kH, kW, sT, sH, sW, pT, pH, pW;
   int tilesM, tilesN, S, rows_per_split;
+  unsigned x_bytes, dy_bytes;
 };
+
+#define WG_OOB 0x80000000u
 
 #define WG_ROWTAB 1024  // positions decoded per refill (16 steps of 64)
 
@@ -76,35 +79,42 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   }
 
   u32x4 ra[IM], rb[IN];
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  const __amdgpu_buffer_rsrc_t xsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dysrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.dy_bytes, 0x00020000);
+  // constant per thread: byte offset of its channel chunk and of its tap inside x
+  const unsigned dycol = (unsigned)((m0 + ccm * 8) * 2);
+  const unsigned xtap = (MODE == 1)
+      ? (unsigned)(((((long long)dt * p.Hi + dh) * p.Wi + dw) * p.x_ld + c0) * 2)
+      : (unsigned)(ncol * 2);
 
+  // branch-free loads: every predicate becomes an out-of-range offset (buffer_load -> zeros)
   auto gload = [&](int pstep, int chunk0) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < IM; ++i) {
       const int r = rm + RPM * i;
       const int pp = pstep + r;
-      ra[i] = zero4;
-      if (r < 64 && mcol_ok && pp < pend)
-        ra[i] = *(const u32x4*)(p.dy + (long long)pp * p.dy_ld + m0 + ccm * 8);
+      const unsigned ok = (unsigned)(r < 64) & (unsigned)mcol_ok & (unsigned)(pp < pend);
+      const unsigned off = ok ? (unsigned)pp * (unsigned)(p.dy_ld * 2) + dycol : WG_OOB;
+      ra[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dysrc, off, 0, 0));
     }
 #pragma unroll
     for (int i = 0; i < IN; ++i) {
       const int r = rn + RPN * i;
       const int pp = pstep + r;
-      rb[i] = zero4;
-      if (r < 64 && ncol_ok && pp < pend) {
-        if (MODE == 0) {
-          rb[i] = *(const u32x4*)(p.x + (long long)pp * p.x_ld + ncol);
-        } else {
-          const int4 e = rowtab[pp - chunk0];
-          const int ti = e.y + dt, hi = e.z + dh, wi = e.w + dw;
-          if ((unsigned)ti < (unsigned)p.Ti && (unsigned)hi < (unsigned)p.Hi &&
-              (unsigned)wi < (unsigned)p.Wi) {
-            const long long pos = (long long)e.x + (long long)((ti * p.Hi + hi) * p.Wi + wi);
-            rb[i] = *(const u32x4*)(p.x + pos * p.x_ld + c0);
-          }
-        }
+      unsigned ok = (unsigned)(r < 64) & (unsigned)ncol_ok & (unsigned)(pp < pend);
+      unsigned off;
+      if (MODE == 0) {
+        off = (unsigned)pp * (unsigned)(p.x_ld * 2) + xtap;
+      } else {
+        const int4 e = rowtab[(pp - chunk0) & (WG_ROWTAB - 1)];
+        const int ti = e.y + dt, hi = e.z + dh, wi = e.w + dw;
+        ok &= (unsigned)((unsigned)ti < (unsigned)p.Ti) & (unsigned)((unsigned)hi < (unsigned)p.Hi) &
+              (unsigned)((unsigned)wi < (unsigned)p.Wi);
+        off = (unsigned)e.x + xtap;
       }
+      rb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, ok ? off : WG_OOB, 0, 0));
     }
   };
 
@@ -182,10 +192,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
           const int wo = pp % p.Wo, t1 = pp / p.Wo;
           const int ho = t1 % p.Ho, t2 = t1 / p.Ho;
           const int to = t2 % p.To, n = t2 / p.To;
-          e.x = n * p.Ti * p.Hi * p.Wi;
           e.y = to * p.sT - p.pT;
           e.z = ho * p.sH - p.pH;
           e.w = wo * p.sW - p.pW;
+          const long long pos0 = (((long long)n * p.Ti + e.y) * p.Hi + e.z) * p.Wi + e.w;
+          e.x = (int)(unsigned)(pos0 * p.x_ld * 2);  // exact modulo 2^32 whenever the tap is valid
         }
         rowtab[i] = e;
       }
@@ -196,15 +207,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     __syncthreads();  // all waves finished computing on both buffers (previous chunk)
     sstore(0);
     __syncthreads();
-    for (int st = 0; st < nsteps; ++st) {
+    for (int st = 0; st < nsteps - 1; ++st) {  // straight-line body, last step peeled
       const int cur = st & 1;
-      if (st + 1 < nsteps) gload(chunk0 + (st + 1) * 64, chunk0);
+      gload(chunk0 + (st + 1) * 64, chunk0);
       __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs
       compute(cur);
       __builtin_amdgcn_sched_barrier(0);
-      if (st + 1 < nsteps) sstore(cur ^ 1);
+      sstore(cur ^ 1);
       __syncthreads();
     }
+    compute((nsteps - 1) & 1);
+    __syncthreads();
   }
 
   // D[m][n]: row = g*4 + reg (cout), col = li (k' column)
@@ -351,6 +364,13 @@ extern "C" int vs_conv_wgrad(const void* dy, const void* x, float* dw, const vs_
   p.kT = d->kT; p.kH = d->kH; p.kW = d->kW;
   p.sT = d->sT; p.sH = d->sH; p.sW = d->sW;
   p.pT = d->pT; p.pH = d->pH; p.pW = d->pW;
+  {
+    const long long xb = (long long)d->N * d->Ti * d->Hi * d->Wi * d->x_ld * 2;
+    const long long db = (long long)p.P * d->y_ld * 2;
+    VS_CHECK_ARG(xb < (1ll << 31) && db < (1ll << 31), "tensor larger than 2 GiB");
+    p.x_bytes = (unsigned)xb;
+    p.dy_bytes = (unsigned)db;
+  }
   p.tilesM = c.tilesM;
   p.tilesN = c.tilesN;
   p.S = c.S;

@@ -16,11 +16,15 @@
 // K in float4 units; x chunk [MT][256] staged in LDS and shared by the 4 waves.
 // grid = (ceil(N/4), ceil(M/MT))
 // ----------------------------------------------------------------------------
+// One output column per wave (N/4 blocks keep every CU busy); the wave issues the weight loads
+// of KU = 4 consecutive 256-wide K chunks up front, so 4 KiB per wave / 16 KiB per CU are in
+// flight while x chunks are staged through LDS (one chunk in flight left it latency bound).
 template <int MT>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x,
                                                          const float* __restrict__ w,
                                                          const float* __restrict__ b, float* y,
                                                          int M, int N, int K, int relu) {
+  constexpr int KU = 4;
   __shared__ float4 xs[MT][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + wave;
@@ -29,42 +33,51 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
 #pragma unroll
   for (int m = 0; m < MT; ++m) acc[m] = 0.f;
   const bool vec_ok = (K & 3) == 0;
-  for (int k0 = 0; k0 < K; k0 += 256) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < MT * 64; i += 256) {
-      const int m = i >> 6, l = i & 63;
-      const int k = k0 + l * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (mbase + m < M) {
-        const float* src = x + (long long)(mbase + m) * K + k;
+  for (int kg = 0; kg < K; kg += 256 * KU) {
+    float4 wv[KU];
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const int k = kg + u * 256 + lane * 4;
+      wv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < N && k < K) {
+        const float* src = w + (long long)n * K + k;
         if (vec_ok && k + 3 < K) {
-          v = *(const float4*)src;
+          wv[u] = *(const float4*)src;
         } else {
-          if (k < K) v.x = src[0];
-          if (k + 1 < K) v.y = src[1];
-          if (k + 2 < K) v.z = src[2];
-          if (k + 3 < K) v.w = src[3];
+          wv[u].x = src[0];
+          if (k + 1 < K) wv[u].y = src[1];
+          if (k + 2 < K) wv[u].z = src[2];
+          if (k + 3 < K) wv[u].w = src[3];
         }
       }
-      xs[m][l] = v;
     }
-    __syncthreads();
-    if (n < N) {
-      const int k = k0 + lane * 4;
-      float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float* src = w + (long long)n * K + k;
-      if (vec_ok && k + 3 < K) {
-        wv = *(const float4*)src;
-      } else {
-        if (k < K) wv.x = src[0];
-        if (k + 1 < K) wv.y = src[1];
-        if (k + 2 < K) wv.z = src[2];
-        if (k + 3 < K) wv.w = src[3];
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const int k0 = kg + u * 256;
+      if (k0 >= K) break;
+      __syncthreads();
+      for (int i = threadIdx.x; i < MT * 64; i += 256) {
+        const int m = i >> 6, l = i & 63;
+        const int kk = k0 + l * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mbase + m < M && kk < K) {
+          const float* src = x + (long long)(mbase + m) * K + kk;
+          if (vec_ok && kk + 3 < K) {
+            v = *(const float4*)src;
+          } else {
+            v.x = src[0];
+            if (kk + 1 < K) v.y = src[1];
+            if (kk + 2 < K) v.z = src[2];
+            if (kk + 3 < K) v.w = src[3];
+          }
+        }
+        xs[m][l] = v;
       }
+      __syncthreads();
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const float4 xv = xs[m][lane];
-        acc[m] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+        acc[m] += xv.x * wv[u].x + xv.y * wv[u].y + xv.z * wv[u].z + xv.w * wv[u].w;
       }
     }
   }

@@ -431,7 +431,8 @@ def linear_fwd(x, w, b=None, relu=False):
     return y
 
 
-def linear_bwd(dy, x, w, need_dx=True, has_bias=True):
+def linear_bwd(dy, x, w, need_dx=True, has_bias=True, dw_out=None, db_out=None):
+    """dw_out / db_out: write the parameter gradients in place (gradient-arena views)."""
     dy, x, w = _f32c(dy), _f32c(x), _f32c(w)
     m, n = dy.shape
     k = x.shape[1]
@@ -441,15 +442,24 @@ def linear_bwd(dy, x, w, need_dx=True, has_bias=True):
         _lib.call("vs_transpose_f32", _ptr(w), _ptr(wt), n, k, _stream())
         dx = torch.empty((m, k), dtype=torch.float32, device=x.device)
         _lib.call("vs_linear_bwd_data", _ptr(dy), _ptr(wt), _ptr(dx), m, n, k, _stream())
-    dw = torch.empty((n, k), dtype=torch.float32, device=x.device)
-    db = torch.empty(n, dtype=torch.float32, device=x.device) if has_bias else None
+    dw = dw_out if dw_out is not None else torch.empty((n, k), dtype=torch.float32, device=x.device)
+    db = None
+    if has_bias:
+        db = db_out if db_out is not None else torch.empty(n, dtype=torch.float32, device=x.device)
     _lib.call("vs_linear_bwd_weight", _ptr(dy), _ptr(x), _ptr(dw), _ptr(db), m, n, k, _stream())
     return dx, dw, db
 
 
+_ones_cache = {}
+
+
 def dropout_mask(shape, p, device):
-    """0 or 1/(1-p) per element, from torch's (hipGraph-safe) generator."""
-    return (torch.rand(shape, device=device) >= p).to(torch.float32).mul_(1.0 / (1.0 - p))
+    """0 or 1/(1-p) per element, from torch's (hipGraph-safe) generator -- one launch."""
+    key = (tuple(shape), str(device))
+    ones = _ones_cache.get(key)
+    if ones is None:
+        ones = _ones_cache[key] = torch.ones(shape, dtype=torch.float32, device=device)
+    return torch.nn.functional.dropout(ones, p, True)
 
 
 def attn_small_fwd(q, k, v, n_heads, scale, drop_mask=None):

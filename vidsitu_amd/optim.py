@@ -48,6 +48,7 @@ class ParamArena:
                 v.copy_(p.detach())
                 p.data = v
                 p.grad = _dense_view(self.grad, off, p)
+                p._vs_direct_grad = True  # HIP backward kernels may write p.grad in place
         self.numel = total
         self._tr_table, self._loose_convs, self.data_bf16 = None, [], None
         if adopt_conv:

@@ -26,6 +26,10 @@ class LinearFn(torch.autograd.Function):
         y = ops.linear_fwd(x2, w, b, relu)
         ctx.save_for_backward(x2, w, y if relu else None)
         ctx.has_bias, ctx.relu, ctx.shp = b is not None, relu, shp
+        # parameters that live in a ParamArena take their gradient in place (overwrite
+        # semantics, like the conv / BN parameters) instead of through autograd's accumulate
+        ctx.w_param = w if getattr(w, "_vs_direct_grad", False) else None
+        ctx.b_param = b if (b is not None and getattr(b, "_vs_direct_grad", False)) else None
         return y.reshape(*shp[:-1], w.shape[0])
 
     @staticmethod
@@ -34,9 +38,16 @@ class LinearFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, w.shape[0])
         if ctx.relu:
             dy2 = dy2 * (y > 0).to(dy2.dtype)
-        dx, dw, db = ops.linear_bwd(dy2.contiguous(), x2, w, need_dx=ctx.needs_input_grad[0],
-                                    has_bias=ctx.has_bias)
-        return (dx.reshape(ctx.shp) if dx is not None else None), dw, db, None
+        direct = ctx.w_param is not None and ctx.w_param.grad is not None and \
+            (not ctx.has_bias or (ctx.b_param is not None and ctx.b_param.grad is not None))
+        dx, dw, db = ops.linear_bwd(
+            dy2.contiguous(), x2, w, need_dx=ctx.needs_input_grad[0], has_bias=ctx.has_bias,
+            dw_out=ctx.w_param.grad if direct else None,
+            db_out=ctx.b_param.grad if (direct and ctx.has_bias) else None)
+        dx = dx.reshape(ctx.shp) if dx is not None else None
+        if direct:
+            return dx, None, None, None
+        return dx, dw, db, None
 
 
 class AttnSmallFn(torch.autograd.Function):
