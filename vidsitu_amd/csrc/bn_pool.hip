@@ -226,7 +226,7 @@ extern "C" int vs_bn_apply(const void* y, const float* scale, const float* shift
 //   apply  : dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M) ; dres = g
 // block = 256 threads = cpr chunk-columns x (256/cpr) row lanes, cpr = C/8 | 256
 // ----------------------------------------------------------------------------
-#define BNB_ROWS_PER_LANE 8  // 2 batches of 4 rows, the 4 rows' loads issued together
+#define BNB_ROWS_PER_LANE 16
 
 // relu with z == nullptr: the mask is recomputed as gamma*xhat + beta > 0 (units without a
 // residual input), which drops one of the three reads of each pass.
@@ -253,26 +253,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
       sg[e] = 0.f;
       sx[e] = 0.f;
     }
-    for (int it0 = 0; it0 < BNB_ROWS_PER_LANE; it0 += 4) {
-      uint4 vdz[4], vy[4], vz[4];
-      bool ok[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {  // issue every load of the batch before using any
-        const long long row = r0 + (long long)(it0 + u) * rl + lane_r;
-        ok[u] = row < rows;
-        const long long rr = ok[u] ? row : 0;
-        vdz[u] = *(const uint4*)(dz + rr * dz_ld + c);
-        vy[u] = *(const uint4*)(y + rr * y_ld + c);
-        if (relu && z) vz[u] = *(const uint4*)(z + rr * z_ld + c);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
+    for (int it = 0; it < BNB_ROWS_PER_LANE; ++it) {
+      const long long row = r0 + (long long)it * rl + lane_r;
+      if (row < rows) {
         float g[8], yv[8];
-        unpack8_bf16(vdz[u], g);
-        unpack8_bf16(vy[u], yv);
+        unpack8_bf16(*(const uint4*)(dz + row * dz_ld + c), g);
+        unpack8_bf16(*(const uint4*)(y + row * y_ld + c), yv);
         if (relu && z) {
           float zv[8];
-          unpack8_bf16(vz[u], zv);
+          unpack8_bf16(*(const uint4*)(z + row * z_ld + c), zv);
 #pragma unroll
           for (int e = 0; e < 8; ++e) g[e] = zv[e] > 0.f ? g[e] : 0.f;
         } else if (relu) {
@@ -280,12 +269,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
           for (int e = 0; e < 8; ++e)
             g[e] = ((yv[e] - mu[e]) * is[e] * ga[e] + be[e]) > 0.f ? g[e] : 0.f;
         }
-        if (ok[u]) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            sg[e] += g[e];
-            sx[e] += g[e] * (yv[e] - mu[e]) * is[e];
-          }
+        for (int e = 0; e < 8; ++e) {
+          sg[e] += g[e];
+          sx[e] += g[e] * (yv[e] - mu[e]) * is[e];
         }
       }
     }
