@@ -177,10 +177,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   const __amdgpu_buffer_rsrc_t wsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
 
-  u32x4 ra[AI], rb[BJ];
+  u32x4 ra0[AI], rb0[BJ], ra1[AI], rb1[BJ];  // two tiles of loads in flight (prefetch distance 2)
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
-  auto gload = [&](int kt) __attribute__((always_inline)) {
+  auto gload = [&](int kt, u32x4* ra, u32x4* rb) __attribute__((always_inline)) {
     const int k8 = kt * 8 + kc;
     const bool kval = k8 < K8;
     if (FAST) {
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     }
   };
 
-  auto sstore = [&](int buf) __attribute__((always_inline)) {
+  auto sstore = [&](int buf, const u32x4* ra, const u32x4* rb) __attribute__((always_inline)) {
     char* A = smem + buf * STAGE;
     char* B = A + BM * 128;
 #pragma unroll
@@ -296,21 +296,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 
   const int nk = (p.K + 63) >> 6;
   __syncthreads();  // ktab visible
-  gload(0);
-  sstore(0);
+  // Software pipeline, prefetch distance 2: while tile kt is multiplied, tile kt+1 sits in one
+  // register set (loaded during step kt-1, written to LDS at the end of step kt) and the loads
+  // of tile kt+2 are issued into the other set.  With one block per CU a single tile in flight
+  // left every k-step waiting out a full memory latency.  Loads past the last tile fall on
+  // the K tail (OOB -> zeros) and are never stored.  Loop body is branch-free (unrolled by 2).
+  gload(0, ra0, rb0);
+  sstore(0, ra0, rb0);
+  gload(1, ra1, rb1);  // tile 1 (or K-tail zeros) -> set 1
   __syncthreads();
-  // loop body without control flow (the last k-step is peeled): keeps the accumulators in
-  // place instead of being copied between register files around every branch
-  for (int kt = 0; kt < nk - 1; ++kt) {
-    const int cur = kt & 1;
-    gload(kt + 1);                        // issue the next tile's loads first ...
-    __builtin_amdgcn_sched_barrier(0);    // (the scheduler otherwise sinks them below the MFMAs)
-    compute(cur);                         // ... so their latency hides under this tile's MFMAs
+  int kt = 0;
+  for (; kt + 2 < nk; kt += 2) {
+    gload(kt + 2, ra0, rb0);
     __builtin_amdgcn_sched_barrier(0);
-    sstore(cur ^ 1);
+    compute(0);
+    __builtin_amdgcn_sched_barrier(0);
+    sstore(1, ra1, rb1);  // tile kt+1
+    __syncthreads();
+    gload(kt + 3, ra1, rb1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(1);
+    __builtin_amdgcn_sched_barrier(0);
+    sstore(0, ra0, rb0);  // tile kt+2
     __syncthreads();
   }
-  compute((nk - 1) & 1);
+  // remaining: nk - kt is 1 or 2; buffer 0 holds tile kt, set 1 holds tile kt+1 (if any)
+  compute(0);
+  if (kt + 1 < nk) {
+    sstore(1, ra1, rb1);
+    __syncthreads();
+    compute(1);
+  }
   __syncthreads();
 
   // ---------------- epilogue ----------------
