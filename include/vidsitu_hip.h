@@ -94,8 +94,12 @@ int vs_stem_conv_wgrad(const void* dy, const void* x4, float* dwp, int N, int T,
  *   in_scale/in_shift: [Cin] fp32 when VS_CONV_APRO. */
 int vs_conv_fwd(const void* x, const void* w, void* y, const vs_conv_desc* d, const float* scale,
                 const float* shift, const void* residual, float* stats_partial,
-                const float* in_scale, const float* in_shift, void* stream);
+                const float* in_scale, const float* in_shift, void* workspace, size_t ws_bytes,
+                void* stream);
 int vs_conv_stats_rows(const vs_conv_desc* d);
+/* fp32 split-K slabs (few-tile, deep-K layers); 0 when the plan for this shape has no split.
+ * dgrad = 1 sizes the workspace of vs_conv_dgrad for the same descriptor. */
+size_t vs_conv_workspace_bytes(const vs_conv_desc* d, int dgrad);
 
 /* Data gradient: dx[N,Ti,Hi,Wi,Cin] = conv_transpose(dy, w) (+ residual when
  * desc.flags has VS_CONV_RESIDUAL: the gradient arriving over the other branch
@@ -103,7 +107,7 @@ int vs_conv_stats_rows(const vs_conv_desc* d);
  * [Cin][kT][kH][kW][Cout] bf16 image made by vs_weight_transpose.
  * Replaces autograd's cudnn_convolution_backward_input for the same layers. */
 int vs_conv_dgrad(const void* dy, const void* wt, void* dx, const vs_conv_desc* d,
-                  const void* residual, void* stream);
+                  const void* residual, void* workspace, size_t ws_bytes, void* stream);
 int vs_weight_transpose(const void* w, void* wt, int Cout, int taps, int Cin, void* stream);
 /* Every dgrad weight image of a model in one launch: src/dst are bf16 arenas with equal
  * element offsets; table[i] = {offset, Cout, taps, Cin, first flat index} (int64 x 5). */

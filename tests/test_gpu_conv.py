@@ -99,8 +99,8 @@ def test_conv_fused_epilogue_and_concat_write(dev):
     assert float(buf[:, :32].float().abs().max()) == 0.0  # neighbours untouched
 
 
-@pytest.mark.parametrize("case", [CASES[1], CASES[7], CASES[11], CASES[13], CASES[17], CASES[18], CASES[20],
-                                  CASES[21]], ids=lambda c: c[0])
+@pytest.mark.parametrize("case", [CASES[1], CASES[7], CASES[10], CASES[11], CASES[13], CASES[14], CASES[17],
+                                  CASES[18], CASES[20], CASES[21]], ids=lambda c: c[0])
 def test_conv_bn_stat_partials(case, dev):
     from vidsitu_amd import ops
 
@@ -174,6 +174,30 @@ def test_direct_kernel_epilogue_and_residual(dev):
     y_tiled, _ = ops.conv_fwd(xa, wa, k, s, p, scale=scale.to(dev), shift=shift.to(dev),
                               residual=to_act(res, dev), relu=True, tile=5)
     assert_close(y, y_tiled.float(), 8e-3, "direct vs tiled kernel")
+
+
+def test_splitk_path_epilogue(dev):
+    """Few-tile deep-K shapes take the split-K plan (fp32 slabs + fused reduce/epilogue kernel):
+    affine + residual + ReLU + BN partials must match, and two runs must be bit-identical."""
+    from vidsitu_amd import ops
+
+    for case in (CASES[10], CASES[14]):  # t3_640_256 (S=3), s3_128_128 (S=2)
+        x, w, k, s, p = _mk(case, seed=31)
+        g = torch.Generator().manual_seed(32)
+        cout = w.shape[0]
+        scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+        ref0 = F.conv3d(x, w, stride=s, padding=p)
+        res = rb(torch.randn(ref0.shape, generator=g))
+        ref = F.relu(ref0 * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1) + res)
+        xa, wa = to_act(x, dev), to_w(w, dev)
+        y, _ = ops.conv_fwd(xa, wa, k, s, p, scale=scale.to(dev), shift=shift.to(dev),
+                            residual=to_act(res, dev), relu=True)
+        assert_close(y, ref, TOL, case[0] + " split-K fused epilogue")
+        y1, p1 = ops.conv_fwd(xa, wa, k, s, p, stats=True)
+        y2, p2 = ops.conv_fwd(xa, wa, k, s, p, stats=True)
+        assert torch.equal(y1, y2) and torch.equal(p1, p2)
+        y3, _ = ops.conv_fwd(xa, wa, k, s, p, tile=1)  # single-pass 64x128 kernel
+        assert_close(y1, y3.float(), 8e-3, case[0] + " split-K vs single pass")
 
 
 def test_wgrad_is_bitwise_reproducible(dev):

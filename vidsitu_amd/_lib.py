@@ -43,9 +43,10 @@ SIGNATURES = {
     "vs_stem_stats_rows": (_i, [_i, _i, _i, _i]),
     "vs_stem_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "vs_stem_conv_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
-    "vs_conv_fwd": (_i, [_p, _p, _p, _dp, _p, _p, _p, _p, _p, _p, _p]),
+    "vs_conv_fwd": (_i, [_p, _p, _p, _dp, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "vs_conv_stats_rows": (_i, [_dp]),
-    "vs_conv_dgrad": (_i, [_p, _p, _p, _dp, _p, _p]),
+    "vs_conv_workspace_bytes": (_sz, [_dp, _i]),
+    "vs_conv_dgrad": (_i, [_p, _p, _p, _dp, _p, _p, _sz, _p]),
     "vs_weight_transpose": (_i, [_p, _p, _i, _i, _i, _p]),
     "vs_weight_transpose_batched": (_i, [_p, _p, _p, _i, _i64, _p]),
     "vs_conv_wgrad_workspace_bytes": (_sz, [_dp]),

@@ -36,6 +36,8 @@ struct ConvP {
   int y_ld, res_ld, flags;
   int tilesM, tilesN;
   unsigned x_bytes, w_bytes;  // extents for the buffer resources (FAST path)
+  int splitK;                 // > 1: blocks (tile, s) write fp32 partial tiles to `slab`
+  float* slab;                // [splitK][M][Ncols]
 };
 
 template <int BM, int BN>
@@ -52,7 +54,9 @@ struct ConvSmem {
 // `valid ? base + delta[k] : OOB` through a buffer resource whose bounds check supplies the
 // zero padding -- no branches, no 64-bit address math in the loop.
 // !FAST: generic per-load coordinate tests (any tap count).
-template <int BM, int BN, int WM, int WN, int MODE, bool FAST>
+// DBG (diagnostic builds only, wrong results): 1 = no global loads in the loop, 2 = no MFMAs,
+// 3 = no LDS stores in the loop, 4 = no LDS fragment reads (operands stay whatever they were).
+template <int BM, int BN, int WM, int WN, int MODE, bool FAST, int DBG = 0>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int AI = BM / 32;
@@ -73,7 +77,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int tn = swz % p.tilesN, tm = swz / p.tilesN;
+  const int ksplit = swz % p.splitK;  // the splits of one tile are neighbours (same XCD run)
+  const int tile_id = swz / p.splitK;
+  const int tn = tile_id % p.tilesN, tm = tile_id / p.tilesN;
   const int m0 = tm * BM, n0 = tn * BN;
   const int kc = tid & 7, lrow = tid >> 3;
   const int K8 = p.K >> 3;
@@ -183,6 +189,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   auto gload = [&](int kt, u32x4* ra, u32x4* rb) __attribute__((always_inline)) {
     const int k8 = kt * 8 + kc;
     const bool kval = k8 < K8;
+    if (DBG == 1 && kt > 1) return;
     if (FAST) {
       // branch-free: every predicate is folded into the byte offset (OOB -> zeros)
       int2 e = make_int2(0, k8 * 16);
@@ -243,6 +250,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   };
 
   auto sstore = [&](int buf, const u32x4* ra, const u32x4* rb) __attribute__((always_inline)) {
+    if (DBG == 3) {
+      asm volatile("" ::"v"(ra[0]), "v"(rb[0]));  // keep the loads alive
+      return;
+    }
     char* A = smem + buf * STAGE;
     char* B = A + BM * 128;
 #pragma unroll
@@ -279,41 +290,53 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
       for (int a = 0; a < MR; ++a) {
         const int row = wm * TM + a * 16 + lr;
-        af[a] = *(const bf16x8*)(A + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+        if (DBG == 4) af[a] = __builtin_bit_cast(bf16x8, (u32x4){(unsigned)row, (unsigned)ch, 1u, 2u});
+        else af[a] = *(const bf16x8*)(A + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int b = 0; b < NR; ++b) {
         const int row = wn * TN + b * 16 + lr;
-        bfr[b] = *(const bf16x8*)(B + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+        if (DBG == 4) bfr[b] = __builtin_bit_cast(bf16x8, (u32x4){(unsigned)row, (unsigned)ch, 3u, 4u});
+        else bfr[b] = *(const bf16x8*)(B + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
       }
+      if (DBG == 2) {
 #pragma unroll
-      for (int a = 0; a < MR; ++a)
+        for (int a = 0; a < MR; ++a) asm volatile("" ::"v"(af[a]));
 #pragma unroll
-        for (int b = 0; b < NR; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < NR; ++b) asm volatile("" ::"v"(bfr[b]));
+      } else {
+#pragma unroll
+        for (int a = 0; a < MR; ++a)
+#pragma unroll
+          for (int b = 0; b < NR; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+      }
     }
   };
 
-  const int nk = (p.K + 63) >> 6;
+  const int nk_all = (p.K + 63) >> 6;
+  const int kbeg = (int)((long long)nk_all * ksplit / p.splitK);
+  const int nk = (int)((long long)nk_all * (ksplit + 1) / p.splitK) - kbeg;  // this block's k-steps
   __syncthreads();  // ktab visible
   // Software pipeline, prefetch distance 2: while tile kt is multiplied, tile kt+1 sits in one
   // register set (loaded during step kt-1, written to LDS at the end of step kt) and the loads
   // of tile kt+2 are issued into the other set.  With one block per CU a single tile in flight
-  // left every k-step waiting out a full memory latency.  Loads past the last tile fall on
-  // the K tail (OOB -> zeros) and are never stored.  Loop body is branch-free (unrolled by 2).
-  gload(0, ra0, rb0);
+  // left every k-step waiting out a full memory latency.  Loads past the last tile of the
+  // block's range are real data of the next split (or K-tail zeros) and are never stored.
+  // Loop body is branch-free (unrolled by 2).
+  gload(kbeg, ra0, rb0);
   sstore(0, ra0, rb0);
-  gload(1, ra1, rb1);  // tile 1 (or K-tail zeros) -> set 1
+  gload(kbeg + 1, ra1, rb1);
   __syncthreads();
   int kt = 0;
   for (; kt + 2 < nk; kt += 2) {
-    gload(kt + 2, ra0, rb0);
+    gload(kbeg + kt + 2, ra0, rb0);
     __builtin_amdgcn_sched_barrier(0);
     compute(0);
     __builtin_amdgcn_sched_barrier(0);
     sstore(1, ra1, rb1);  // tile kt+1
     __syncthreads();
-    gload(kt + 3, ra1, rb1);
+    gload(kbeg + kt + 3, ra1, rb1);
     __builtin_amdgcn_sched_barrier(0);
     compute(1);
     __builtin_amdgcn_sched_barrier(0);
@@ -328,6 +351,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     compute(1);
   }
   __syncthreads();
+
+  if (p.splitK > 1) {
+    // split-K: raw fp32 partial tile -> slab[ksplit]; BN statistics, affine, residual, ReLU and
+    // the bf16 store happen in conv_splitk_epilogue_kernel after the fixed-order slab sum
+    float* E = (float*)smem;
+#pragma unroll
+    for (int b = 0; b < NR; ++b) {
+      const int col = wn * TN + b * 16 + lr;
+#pragma unroll
+      for (int a = 0; a < MR; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) E[(wm * TM + a * 16 + lq * 4 + r) * BN + col] = acc[a][b][r];
+    }
+    __syncthreads();
+    float* dst = p.slab + (long long)ksplit * p.M * p.Ncols;
+    constexpr int QPR = BN / 4;
+    for (int idx = tid; idx < BM * QPR; idx += 256) {
+      const int row = idx / QPR, c4 = idx - row * QPR;
+      const int m = m0 + row, n = n0 + c4 * 4;
+      if (m < p.M && n < p.Ncols)
+        *(float4*)(dst + (long long)m * p.Ncols + n) = *(const float4*)(E + row * BN + c4 * 4);
+    }
+    return;
+  }
 
   // ---------------- epilogue ----------------
   // (1) BN batch-statistic partials from the fp32 accumulators (tail rows are
@@ -439,6 +486,83 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     float* dst = p.stats + (long long)tm * 2 * p.Ncols;
     dst[n0 + tid] = s;
     dst[p.Ncols + n0 + tid] = q;
+  }
+}
+
+// Sum of the split-K slabs (fixed order) + the whole fused epilogue.  Block = 64 rows x all
+// columns; thread = one 8-channel chunk column x (256 / chunks) row lanes.
+__global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(
+    const float* slab, int S, uint16_t* y, const float* scale, const float* shift,
+    const uint16_t* res, float* stats, int M, int N, int y_ld, int res_ld, int flags) {
+  __shared__ float red[2][256][8];
+  const int cpr = N >> 3;
+  const int ncol = cpr < 256 ? cpr : 256;
+  const int rl = 256 / ncol;
+  const int col = threadIdx.x % ncol, lane_r = threadIdx.x / ncol;
+  const int r0 = blockIdx.x * 64;
+  for (int cb = col; cb < cpr; cb += ncol) {
+    const int c = cb * 8;
+    float sg[8], sq[8], sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sg[e] = sq[e] = 0.f;
+      sc[e] = (flags & VS_CONV_AFFINE) ? scale[c + e] : 1.f;
+      sh[e] = (flags & VS_CONV_AFFINE) ? shift[c + e] : 0.f;
+    }
+    for (int r = lane_r; r < 64 && lane_r < rl; r += rl) {  // (256 % ncol leftover threads idle)
+      const int m = r0 + r;
+      if (m >= M) break;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      for (int s = 0; s < S; ++s) {
+        const float* src = slab + ((long long)s * M + m) * N + c;
+        const float4 a = *(const float4*)src, b = *(const float4*)(src + 4);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+        v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sg[e] += v[e];
+        sq[e] += v[e] * v[e];
+        v[e] = v[e] * sc[e] + sh[e];
+      }
+      if (flags & VS_CONV_RESIDUAL) {
+        float rf[8];
+        unpack8_bf16(*(const uint4*)(res + (long long)m * res_ld + c), rf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rf[e];
+      }
+      if (flags & VS_CONV_RELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      *(uint4*)(y + (long long)m * y_ld + c) = pack8_bf16(v);
+    }
+    if (flags & VS_CONV_STATS) {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[0][threadIdx.x][e] = sg[e];
+        red[1][threadIdx.x][e] = sq[e];
+      }
+      __syncthreads();
+      if (lane_r == 0) {
+        for (int r = 1; r < rl; ++r) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            sg[e] += red[0][r * ncol + col][e];
+            sq[e] += red[1][r * ncol + col][e];
+          }
+        }
+        float* dst = stats + (long long)blockIdx.x * 2 * N;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          dst[c + e] = sg[e];
+          dst[N + c + e] = sq[e];
+        }
+      }
+    }
   }
 }
 
@@ -641,9 +765,6 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p, int tiles_per
 
 #define VS_DIRECT_TPW 8  // 16-row tiles per wave -> 512 rows per block
 
-static bool direct_eligible(const ConvP& p) {
-  return p.Ncols <= 32 && p.K <= 160 && p.kT * p.kH * p.kW <= 31 && p.M >= 64;
-}
 static int direct_blocks(long long M) {
   return (int)((M + 16 * 4 * VS_DIRECT_TPW - 1) / (16 * 4 * VS_DIRECT_TPW));
 }
@@ -740,7 +861,7 @@ template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const ConvP& p, int mode, hipStream_t st) {
   const size_t smem =
       (size_t)ConvSmem<BM, BN>::MAIN + 2 * WM * BN * 4 + (mode ? (size_t)((p.K + 63) >> 6) * 64 : 0);
-  const int grid = p.tilesM * p.tilesN;
+  const int grid = p.tilesM * p.tilesN * p.splitK;
   const bool fast = p.kT * p.kH * p.kW <= 31;
   // dynamic LDS above 64 KiB needs an explicit opt-in, once per kernel
   static bool attr_done = false;
@@ -755,6 +876,15 @@ static int launch_cfg(const ConvP& p, int mode, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, 1, false>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_smem);
     attr_done = true;
+  }
+  const int dbg = (p.flags >> 12) & 7;
+  if (dbg && BM == 128 && BN == 128 && mode == 1 && fast) {
+    if (dbg == 1) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, 1, true, 1>), dim3(grid), dim3(256), smem, st, p);
+    else if (dbg == 2) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, 1, true, 2>), dim3(grid), dim3(256), smem, st, p);
+    else if (dbg == 3) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, 1, true, 3>), dim3(grid), dim3(256), smem, st, p);
+    else hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, 1, true, 4>), dim3(grid), dim3(256), smem, st, p);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
   }
   if (!fast) {  // > 32 taps: only the Cin-padded stems of configurations without a stem kernel
     if (mode != 1) {
@@ -778,13 +908,51 @@ static const TileCfg kTileTable[] = {{128, 128}, {64, 128}, {128, 64}, {64, 64},
                                      {256, 32},  {256, 16}, {256, 128}, {128, 256}};
 static const int kNumTileCfgs = 8;
 
-static TileCfg resolve_tile(long long M, int Ncols, int flags) {
+struct ConvPlan {
+  TileCfg tile;
+  int S;        // split-K factor (1 = none)
+  bool direct;  // register-resident small-channel kernel
+};
+
+// Few-tile, deep-K layers (slow s4 / s5 at batch 8: 100-400 tiles for 256 CUs) leave each CU
+// with at most one block, which is bound by bytes-in-flight / latency; splitting K puts 2-4
+// blocks on every CU (fp32 slabs, fixed-order sum in conv_splitk_epilogue_kernel).
+static ConvPlan plan_conv(long long M, int Ncols, int K, int taps, int flags) {
+  ConvPlan pl;
+  pl.S = 1;
+  pl.direct = false;
   const int forced = (flags >> 8) & 0xf;
-  if (forced >= 1 && forced <= kNumTileCfgs) return kTileTable[forced - 1];
-  return pick_tile(M, Ncols);
+  if (forced >= 1 && forced <= kNumTileCfgs) {
+    pl.tile = kTileTable[forced - 1];
+    return pl;
+  }
+  if (Ncols <= 32 && K <= 160 && taps <= 31 && M >= 64) {
+    pl.direct = true;
+    pl.tile = kTileTable[5];
+    return pl;
+  }
+  pl.tile = pick_tile(M, Ncols);
+  const int nk = (K + 63) / 64;
+  const long long t128 = ((M + 127) / 128) * ((Ncols + 127) / 128);
+  if (Ncols >= 128 && Ncols % 8 == 0 && taps <= 31 && t128 < 384 && nk >= 16) {
+    pl.tile = kTileTable[0];
+    long long S = (512 + t128 - 1) / t128;
+    if (S > nk / 8) S = nk / 8;
+    if (S > 4) S = 4;
+    if (S < 1) S = 1;
+    pl.S = (int)S;
+  }
+  return pl;
 }
 
-static int launch_conv(ConvP& p, int mode, int naive, int flags, hipStream_t st) {
+static size_t plan_ws_bytes(const ConvPlan& pl, long long M, int Ncols) {
+  return pl.S > 1 ? (size_t)pl.S * M * Ncols * sizeof(float) : 0;
+}
+
+static int launch_conv(ConvP& p, int mode, int naive, int flags, void* ws, size_t ws_bytes,
+                       hipStream_t st) {
+  p.splitK = 1;
+  p.slab = nullptr;
   if (naive) {
     const long long total = (long long)p.M * p.Ncols;
     hipLaunchKernelGGL(conv_naive_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
@@ -792,11 +960,30 @@ static int launch_conv(ConvP& p, int mode, int naive, int flags, hipStream_t st)
     VS_CHECK_LAUNCH();
     return VS_OK;
   }
-  if (direct_eligible(p) && ((flags >> 8) & 0xf) == 0)
+  const ConvPlan pl = plan_conv(p.M, p.Ncols, p.K, p.kT * p.kH * p.kW, flags);
+  if (pl.direct)
     return p.Ncols <= 16 ? launch_direct<1>(p, mode, st) : launch_direct<2>(p, mode, st);
-  const TileCfg c = resolve_tile(p.M, p.Ncols, flags);
+  const TileCfg c = pl.tile;
   p.tilesM = (p.M + c.bm - 1) / c.bm;
   p.tilesN = (p.Ncols + c.bn - 1) / c.bn;
+  if (pl.S > 1) {
+    if (ws == nullptr || ws_bytes < plan_ws_bytes(pl, p.M, p.Ncols)) {
+      vs_set_error("conv: split-K workspace too small (%zu < %zu)", ws_bytes,
+                   plan_ws_bytes(pl, p.M, p.Ncols));
+      return VS_ERR_WORKSPACE;
+    }
+    p.splitK = pl.S;
+    p.slab = (float*)ws;
+    const int user_flags = p.flags;
+    p.flags &= ~(VS_CONV_STATS | VS_CONV_AFFINE | VS_CONV_RESIDUAL | VS_CONV_RELU);
+    const int rc = launch_cfg<128, 128, 2, 2>(p, mode, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((p.M + 63) / 64), dim3(256), 0, st,
+                       (const float*)ws, pl.S, p.y, p.scale, p.shift, p.res, p.stats, p.M, p.Ncols,
+                       p.y_ld, p.res_ld, user_flags);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+  }
   if (c.bm == 128 && c.bn == 128) return launch_cfg<128, 128, 2, 2>(p, mode, st);
   if (c.bm == 64 && c.bn == 128) return launch_cfg<64, 128, 1, 4>(p, mode, st);
   if (c.bm == 128 && c.bn == 64) return launch_cfg<128, 64, 2, 2>(p, mode, st);
@@ -830,20 +1017,27 @@ static int check_desc(const vs_conv_desc* d) {
 
 extern "C" int vs_conv_stats_rows(const vs_conv_desc* d) {
   const long long M = (long long)d->N * d->To * d->Ho * d->Wo;
-  ConvP q;
-  q.M = (int)M;
-  q.Ncols = d->Cout;
-  q.K = d->kT * d->kH * d->kW * d->Cin;
-  q.kT = d->kT; q.kH = d->kH; q.kW = d->kW;
-  if (direct_eligible(q) && ((d->flags >> 8) & 0xf) == 0) return direct_blocks(M);
-  const TileCfg c = resolve_tile(M, d->Cout, d->flags);
-  return (int)((M + c.bm - 1) / c.bm);
+  const ConvPlan pl = plan_conv(M, d->Cout, d->kT * d->kH * d->kW * d->Cin, d->kT * d->kH * d->kW,
+                                d->flags);
+  if (pl.direct) return direct_blocks(M);
+  if (pl.S > 1) return (int)((M + 63) / 64);
+  return (int)((M + pl.tile.bm - 1) / pl.tile.bm);
+}
+
+extern "C" size_t vs_conv_workspace_bytes(const vs_conv_desc* d, int dgrad) {
+  const int taps = d->kT * d->kH * d->kW;
+  if (dgrad) {
+    const long long M = (long long)d->N * d->Ti * d->Hi * d->Wi;
+    return plan_ws_bytes(plan_conv(M, d->Cin, taps * d->Cout, taps, d->flags), M, d->Cin);
+  }
+  const long long M = (long long)d->N * d->To * d->Ho * d->Wo;
+  return plan_ws_bytes(plan_conv(M, d->Cout, taps * d->Cin, taps, d->flags), M, d->Cout);
 }
 
 extern "C" int vs_conv_fwd(const void* x, const void* w, void* y, const vs_conv_desc* d,
                            const float* scale, const float* shift, const void* residual,
                            float* stats_partial, const float* in_scale, const float* in_shift,
-                           void* stream) {
+                           void* workspace, size_t ws_bytes, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   VS_CHECK_ARG(x && w && y, "null tensor");
@@ -885,15 +1079,15 @@ extern "C" int vs_conv_fwd(const void* x, const void* w, void* y, const vs_conv_
   }
   p.y_ld = d->y_ld;
   p.res_ld = d->res_ld;
-  p.flags = d->flags & 0xff;
+  p.flags = d->flags & 0x70ff;
   p.tilesM = p.tilesN = 0;
   const bool pointwise = (d->kT * d->kH * d->kW == 1) && d->pT == 0 && d->pH == 0 && d->pW == 0;
-  return launch_conv(p, pointwise ? 0 : 1, (d->flags & VS_CONV_NAIVE) != 0, d->flags,
-                     (hipStream_t)stream);
+  return launch_conv(p, pointwise ? 0 : 1, (d->flags & VS_CONV_NAIVE) != 0, d->flags, workspace,
+                     ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int vs_conv_dgrad(const void* dy, const void* wt, void* dx, const vs_conv_desc* d,
-                             const void* residual, void* stream) {
+                             const void* residual, void* workspace, size_t ws_bytes, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   VS_CHECK_ARG(dy && wt && dx, "null tensor");
@@ -934,7 +1128,8 @@ extern "C" int vs_conv_dgrad(const void* dy, const void* wt, void* dx, const vs_
   const bool pointwise =
       unit_stride && (d->kT * d->kH * d->kW == 1) && d->pT == 0 && d->pH == 0 && d->pW == 0;
   const int mode = pointwise ? 0 : (unit_stride ? 1 : 2);
-  return launch_conv(p, mode, (d->flags & VS_CONV_NAIVE) != 0, d->flags, (hipStream_t)stream);
+  return launch_conv(p, mode, (d->flags & VS_CONV_NAIVE) != 0, d->flags, workspace, ws_bytes,
+                     (hipStream_t)stream);
 }
 
 // w [Cout][taps][Cin] -> wt [Cin][taps][Cout]

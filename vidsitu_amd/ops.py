@@ -147,7 +147,7 @@ def tile_flag(kind, M, ncols, K, k, s, force=None):
 
 
 def conv_fwd(x, w, k, s, p, out=None, scale=None, shift=None, residual=None, relu=False,
-             stats=False, naive=False, tile=None):
+             stats=False, naive=False, tile=None, dbg=0):
     """y = conv3d(x, w) [*scale+shift] [+residual] [relu]; optional BN-stat partials.
     Returns (y, partials|None)."""
     cout = w.shape[0]
@@ -172,14 +172,18 @@ def conv_fwd(x, w, k, s, p, out=None, scale=None, shift=None, residual=None, rel
         flags |= VS_CONV_NAIVE
     flags |= tile_flag("f", ys[0] * ys[2] * ys[3] * ys[4], cout, x.shape[1] * k[0] * k[1] * k[2], k, s,
                        tile)
+    flags |= (dbg & 7) << 12  # diagnostic ablation builds (wrong results), tools/ only
     d = make_desc(x.shape, act_ld(x), ys, act_ld(out), k, s, p, flags,
                   act_ld(residual) if residual is not None else 0)
     partials = None
     if stats:
         rows = _lib.load().vs_conv_stats_rows(C.byref(d))
         partials = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
+    need = _lib.load().vs_conv_workspace_bytes(C.byref(d), 0)
+    ws = _workspace(need, x.device) if need else None
     _lib.call("vs_conv_fwd", _ptr(x), _ptr(w), _ptr(out), C.byref(d), _ptr(scale), _ptr(shift),
-              _ptr(residual), _ptr(partials), None, None, _stream())
+              _ptr(residual), _ptr(partials), None, None, _ptr(ws),
+              C.c_size_t(ws.numel() if ws is not None else 0), _stream())
     return out, partials
 
 
@@ -257,7 +261,10 @@ def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=N
                        tile)
     d = make_desc(xs, act_ld(out), dy.shape, act_ld(dy), k, s, p, flags,
                   act_ld(residual) if residual is not None else 0)
-    _lib.call("vs_conv_dgrad", _ptr(dy), _ptr(wt), _ptr(out), C.byref(d), _ptr(residual), _stream())
+    need = _lib.load().vs_conv_workspace_bytes(C.byref(d), 1)
+    ws = _workspace(need, dy.device) if need else None
+    _lib.call("vs_conv_dgrad", _ptr(dy), _ptr(wt), _ptr(out), C.byref(d), _ptr(residual), _ptr(ws),
+              C.c_size_t(ws.numel() if ws is not None else 0), _stream())
     return out
 
 
