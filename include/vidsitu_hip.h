@@ -50,6 +50,8 @@ typedef enum vs_status {
 /* bits 8..11: forced tile config id + 1 (0 = built-in heuristic); ids index
  * {128x128, 64x128, 128x64, 64x64, 256x32, 256x16, 256x128, 128x256} (BM x BN). */
 #define VS_CONV_TILE(id) (((id) + 1) << 8)
+#define VS_CONV_RING(ns) (((ns) & 7) << 16) /* staging: 0 heuristic, 1 register pipeline, 2..4 LDS-DMA ring stages */
+#define VS_CONV_SPLITK (1 << 15) /* allow the split-K plan (fp32 slabs + fused reduce/epilogue) */
 
 /* Geometry of one Conv3d (bias-free, groups 1, dilation 1).
  * Replaces nn.Conv3d reached from vidsitu_code/mdl_sf_base.py:22-33 (s1..s5,
@@ -100,6 +102,10 @@ int vs_conv_stats_rows(const vs_conv_desc* d);
 /* fp32 split-K slabs (few-tile, deep-K layers); 0 when the plan for this shape has no split.
  * dgrad = 1 sizes the workspace of vs_conv_dgrad for the same descriptor. */
 size_t vs_conv_workspace_bytes(const vs_conv_desc* d, int dgrad);
+/* The launch plan the library picks for this descriptor (dgrad = 1: for vs_conv_dgrad):
+ * out[5] = {tile rows, tile cols, LDS-DMA ring stages (0 = register-staged), split-K factor,
+ * 1 if the register-resident small-channel kernel runs}.  Profiling / attribution only. */
+int vs_conv_plan(const vs_conv_desc* d, int dgrad, int* out);
 
 /* Data gradient: dx[N,Ti,Hi,Wi,Cin] = conv_transpose(dy, w) (+ residual when
  * desc.flags has VS_CONV_RESIDUAL: the gradient arriving over the other branch

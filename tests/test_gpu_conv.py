@@ -191,13 +191,42 @@ def test_splitk_path_epilogue(dev):
         ref = F.relu(ref0 * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1) + res)
         xa, wa = to_act(x, dev), to_w(w, dev)
         y, _ = ops.conv_fwd(xa, wa, k, s, p, scale=scale.to(dev), shift=shift.to(dev),
-                            residual=to_act(res, dev), relu=True)
+                            residual=to_act(res, dev), relu=True, splitk=True)
         assert_close(y, ref, TOL, case[0] + " split-K fused epilogue")
-        y1, p1 = ops.conv_fwd(xa, wa, k, s, p, stats=True)
-        y2, p2 = ops.conv_fwd(xa, wa, k, s, p, stats=True)
+        y1, p1 = ops.conv_fwd(xa, wa, k, s, p, stats=True, splitk=True)
+        y2, p2 = ops.conv_fwd(xa, wa, k, s, p, stats=True, splitk=True)
         assert torch.equal(y1, y2) and torch.equal(p1, p2)
+        tot = p1.double().sum(0).cpu()
+        assert torch.allclose(tot[0], ref0.double().sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=1e-2)
         y3, _ = ops.conv_fwd(xa, wa, k, s, p, tile=1)  # single-pass 64x128 kernel
         assert_close(y1, y3.float(), 8e-3, case[0] + " split-K vs single pass")
+
+
+RING_CASES = [CASES[i] for i in (0, 1, 4, 5, 6, 9, 10, 11, 14, 15, 17)]
+
+
+@pytest.mark.parametrize("ring", [2, 3, 4])
+@pytest.mark.parametrize("case", RING_CASES, ids=[c[0] for c in RING_CASES])
+def test_lds_dma_ring_is_bitwise_the_register_pipeline(case, ring, dev):
+    """The LDS-DMA staging (buffer_load ... lds ring, VS_CONV_RING) feeds the same LDS image
+    to the same MFMA order as the register-staged pipeline: identical bits, for the forward
+    gather, the BN partials and both dgrad gathers, on every tile config that supports it."""
+    from vidsitu_amd import ops
+
+    x, w, k, s, p = _mk(case, seed=3)
+    xa, wa = to_act(x, dev), to_w(w, dev)
+    ref = F.conv3d(x, w, stride=s, padding=p)
+    dy = rb(torch.randn(ref.shape, generator=torch.Generator().manual_seed(5)))
+    dya, wt = to_act(dy, dev), ops.weight_transpose(wa)
+    res = to_act(rb(torch.randn(x.shape, generator=torch.Generator().manual_seed(6))), dev)
+    for tile in (0, 1, 2, 3, 4, 6, 7):
+        y0, p0 = ops.conv_fwd(xa, wa, k, s, p, stats=True, tile=tile, ring=1)
+        y1, p1 = ops.conv_fwd(xa, wa, k, s, p, stats=True, tile=tile, ring=ring)
+        assert torch.equal(y0, y1) and torch.equal(p0, p1), f"{case[0]} fwd tile {tile} ring {ring}"
+        d0 = ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, residual=res, tile=tile, ring=1)
+        d1 = ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, residual=res, tile=tile, ring=ring)
+        assert torch.equal(d0, d1), f"{case[0]} dgrad tile {tile} ring {ring}"
+    assert_close(y1, ref, TOL, case[0] + " ring vs torch")
 
 
 def test_wgrad_is_bitwise_reproducible(dev):

@@ -22,6 +22,8 @@ mdl = sel["mdl"](cfg=cfg, comm=comm).to(dev).train()
 batch = synth_data.synth_batch(cfg, comm, bs=2, n_ev=4, device=dev, dtype=torch.bfloat16)
 
 shapes = {}
+counts = {}
+RINGS = [int(a) for a in os.environ.get("RINGS", "1,2,3,4").split(",")]
 orig_f, orig_d = ops.conv_fwd, ops.conv_dgrad
 
 
@@ -29,12 +31,14 @@ def rec_f(x, w, k, s, p, **kw):
     ys = ops.conv_out_shape(x.shape, w.shape[0], k, s, p)
     key = f"f:{ys[0]*ys[2]*ys[3]*ys[4]}:{ys[1]}:{x.shape[1]*k[0]*k[1]*k[2]}:{k[0]}{k[1]}{k[2]}:{s[0]}{s[1]}{s[2]}"
     shapes.setdefault(key, ("f", tuple(x.shape), ops.act_ld(x), tuple(w.shape), k, s, p))
+    counts[key] = counts.get(key, 0) + 1
     return orig_f(x, w, k, s, p, **kw)
 
 
 def rec_d(dy, wt, xs, k, s, p, **kw):
     key = f"d:{xs[0]*xs[2]*xs[3]*xs[4]}:{xs[1]}:{dy.shape[1]*k[0]*k[1]*k[2]}:{k[0]}{k[1]}{k[2]}:{s[0]}{s[1]}{s[2]}"
     shapes.setdefault(key, ("d", tuple(dy.shape), ops.act_ld(dy), tuple(xs), k, s, p))
+    counts[key] = counts.get(key, 0) + 1
     return orig_d(dy, wt, xs, k, s, p, **kw)
 
 
@@ -70,33 +74,37 @@ for key, spec in sorted(shapes.items()):
         x = ops.new_act(*xs, device=dev, ctot=xld)
         x.normal_()
         w = torch.randn((ws[0], *k, ws[1]), device=dev).to(ops.BF16).permute(0, 4, 1, 2, 3)
-        fn_of = lambda t: (lambda: ops.conv_fwd(x, w, k, s, p, stats=True, tile=t))
+        fn_of = lambda t, r=0: (lambda: ops.conv_fwd(x, w, k, s, p, stats=True, tile=t, ring=r))
     else:
         _, dys, dyld, xs, k, s, p = spec
         dy = ops.new_act(*dys, device=dev, ctot=dyld)
         dy.normal_()
         wt = torch.randn((xs[1], *k, dys[1]), device=dev).to(ops.BF16).permute(0, 4, 1, 2, 3)
-        fn_of = lambda t: (lambda: ops.conv_dgrad(dy, wt, xs, k, s, p, tile=t))
+        fn_of = lambda t, r=0: (lambda: ops.conv_dgrad(dy, wt, xs, k, s, p, tile=t, ring=r))
     times = {}
     for t in cands:
-        try:
-            times[t] = timeit(fn_of(t))
-        except Exception as e:  # a config that cannot launch for this shape
-            times[t] = float("inf")
+        for r in RINGS:
+            if r >= 2 and ops.TILE_CFGS[t][1] < 32:
+                continue
+            try:
+                times[(t, r)] = timeit(fn_of(t, r))
+            except Exception as e:  # a config that cannot launch for this shape
+                times[(t, r)] = float("inf")
     heur = timeit(fn_of(None))
     best = min(times, key=times.get)
-    table[key] = best
-    report.append((key, heur, times[best], ops.TILE_CFGS[best], {ops.TILE_CFGS[t]: round(v, 4) for t, v in times.items()}))
+    table[key] = list(best)
+    report.append((key, heur, times[best], (ops.TILE_CFGS[best[0]], best[1]),
+                   {f"{ops.TILE_CFGS[t][0]}x{ops.TILE_CFGS[t][1]}r{r}": round(v * 1e3, 1) for (t, r), v in times.items()}))
 
-tot_h = sum(r[1] for r in report)
-tot_b = sum(r[2] for r in report)
-for r in sorted(report, key=lambda r: -(r[1] - r[2])):
-    print(f"{r[0]:40s} heuristic {r[1]*1e3:8.1f} us  best {r[2]*1e3:8.1f} us {r[3]}  {r[4]}")
-print(f"sum over distinct shapes: heuristic {tot_h:.3f} ms -> tuned {tot_b:.3f} ms")
-out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vidsitu_amd", "conv_tune.json")
-with open(out, "w") as f:
-    json.dump(table, f, indent=0, sort_keys=True)
+tot_h = sum(r[1] * counts[r[0]] for r in report)
+tot_b = sum(r[2] * counts[r[0]] for r in report)
+lines = []
+for r in sorted(report, key=lambda r: -(r[1] - r[2]) * counts[r[0]]):
+    lines.append(f"{r[0]:40s} x{counts[r[0]]:2d} heuristic {r[1]*1e3:8.1f} us  best {r[2]*1e3:8.1f} us {r[3]}  {r[4]}")
+lines.append(f"sum over the step's conv launches: heuristic {tot_h:.3f} ms -> tuned {tot_b:.3f} ms")
+print("\n".join(lines))
 os.makedirs("gpurun_out", exist_ok=True)
+with open("gpurun_out/autotune_report.txt", "w") as f:
+    f.write("\n".join(lines) + "\n")
 with open("gpurun_out/conv_tune.json", "w") as f:
     json.dump(table, f, indent=0, sort_keys=True)
-print("wrote", out)

@@ -7,6 +7,8 @@ from vidsitu_amd import ops
 dev = torch.device("cuda:0")
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 tiles = [int(a) for a in sys.argv[2:]] or [None]
+rings = [int(a) for a in os.environ.get("RINGS", "0").split(",")]
+dgrad = os.environ.get("DGRAD") == "1"
 # name, N, Cin, T, H, W, Cout, k, s, p
 SHAPES = [
     ("s4.a  1024->256 [3,1,1]", 8, 1024, 8, 14, 14, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
@@ -28,8 +30,8 @@ for name, n, cin, t, h, w, cout, k, s, p in SHAPES:
     flops = 2.0 * ys[0] * ys[2] * ys[3] * ys[4] * cout * cin * k[0] * k[1] * k[2]
     byts = 2.0 * (x.numel() + ys[0] * ys[1] * ys[2] * ys[3] * ys[4] + wt.numel())
     row = f"{name:26s}"
-    for tile in tiles:
-        fn = lambda: ops.conv_fwd(x, wt, k, s, p, stats=True, tile=tile)
+    for tile, ring in [(t, r) for t in tiles for r in rings]:
+        fn = lambda: ops.conv_fwd(x, wt, k, s, p, stats=True, tile=tile, ring=ring)
         try:
             for _ in range(3): fn()
             torch.cuda.synchronize()
@@ -38,7 +40,7 @@ for name, n, cin, t, h, w, cout, k, s, p in SHAPES:
             for _ in range(reps): fn()
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / reps
-            row += f" | t{tile}: {ms*1e3:7.1f} us {flops/ms/1e9:7.1f} TF {byts/ms/1e6:6.0f} GB/s"
+            row += f" | t{tile}r{ring}: {ms*1e3:6.1f} us {flops/ms/1e9:7.1f} TF {byts/ms/1e6:6.0f} GB/s"
         except Exception as e:
             row += f" | t{tile}: ERR"
     print(row)

@@ -40,11 +40,11 @@ struct ConvP {
   float* slab;                // [splitK][M][Ncols]
 };
 
-template <int BM, int BN>
+template <int BM, int BN, int NSTAGE = 2>
 struct ConvSmem {
   static constexpr int STAGE = (BM + BN) * 128;
   static constexpr int EPI = BM * BN * 4;
-  static constexpr int MAIN = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
+  static constexpr int MAIN = (NSTAGE * STAGE > EPI) ? NSTAGE * STAGE : EPI;
 };
 
 #define VS_OOB 0x80000000u  // byte offset beyond any tensor: buffer_load returns zeros
@@ -56,7 +56,9 @@ struct ConvSmem {
 // !FAST: generic per-load coordinate tests (any tap count).
 // DBG (diagnostic builds only, wrong results): 1 = no global loads in the loop, 2 = no MFMAs,
 // 3 = no LDS stores in the loop, 4 = no LDS fragment reads (operands stay whatever they were).
-template <int BM, int BN, int WM, int WN, int MODE, bool FAST, int DBG = 0>
+// NS (FAST only): 0 = register-staged pipeline; >= 2 = LDS-DMA ring of NS stages
+// (`buffer_load_dwordx4 ... lds`, NS-1 tiles in flight, one raw barrier per k-step).
+template <int BM, int BN, int WM, int WN, int MODE, bool FAST, int DBG = 0, int NS = 0>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int AI = BM / 32;
@@ -64,7 +66,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MR = TM / 16, NR = TN / 16;
   constexpr int STAGE = ConvSmem<BM, BN>::STAGE;
-  constexpr int MAIN = ConvSmem<BM, BN>::MAIN;
+  constexpr int MAIN = ConvSmem<BM, BN, (NS > 2 ? NS : 2)>::MAIN;
+  static_assert(NS == 0 || (FAST && NS >= 2 && BN >= 32), "LDS-DMA ring needs the FAST gather");
   static_assert(WM * WN == 4, "4 waves");
   static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile");
 
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 
   if (MODE != 0) {
     const int C8 = p.Cg >> 3;
-    const int K8pad = ((p.K + 63) >> 6) << 3;
+    const int K8pad = (((p.K + 63) >> 6) + (NS > 0 ? NS - 1 : 0)) << 3;  // + the ring's run-ahead
     for (int k8 = tid; k8 < K8pad; k8 += 256) {
       if (k8 >= K8) {  // K tail: tap 31 is never valid (FAST requires <= 31 taps)
         ktab[k8] = FAST ? make_int2(31, 0) : make_int2(0, 0);
@@ -318,6 +321,73 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   const int kbeg = (int)((long long)nk_all * ksplit / p.splitK);
   const int nk = (int)((long long)nk_all * (ksplit + 1) / p.splitK) - kbeg;  // this block's k-steps
   __syncthreads();  // ktab visible
+  if constexpr (NS > 0) {
+    // LDS-DMA ring.  One wave-instruction copies 64 x 16 B = eight 128-byte tile rows straight
+    // into LDS (destination = wave-uniform base + lane * 16, no VGPRs, no ds_write); the XOR
+    // swizzle of the image goes on the SOURCE: the thread that fills physical unit kc of row r
+    // fetches logical unit kc ^ ((r >> 1) & 7).  Every thread issues exactly L loads per tile
+    // (masked ones point out of range: the buffer range check writes zeros), so a counted
+    // vmcnt retires tile kt while tiles kt+1 .. kt+D-1 stay in flight across the raw barrier.
+    constexpr int D = NS - 1;
+    constexpr int L = AI + BJ;
+    static_assert((D - 1) * L <= 63, "vmcnt range");
+    const int kce = kc ^ ((lrow >> 1) & 7);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // The copies are issued from inline asm: a builtin LDS-DMA makes hipcc treat every later
+    // ds_read as dependent on it and wait vmcnt(0), which serialises the ring.  hipcc has no
+    // VMEM of its own between the first copy and the explicit vmcnt(0) that ends the loop, and
+    // it does not use M0 in this kernel (written and read inside one statement).
+    typedef __attribute__((address_space(3))) char* lds_ptr_t;
+    const unsigned lds0 = (unsigned)(unsigned long)(lds_ptr_t)smem + (unsigned)wv * 1024u;
+    auto rsrc_words = [](const void* base, unsigned bytes) __attribute__((always_inline)) {
+      const unsigned long a = (unsigned long)base;
+      return (i32x4){(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+    };
+    const i32x4 xdesc = rsrc_words(p.x, p.x_bytes), wdesc = rsrc_words(p.w, p.w_bytes);
+    auto dma16 = [](const i32x4& desc, unsigned lds_addr, unsigned voff) __attribute__((always_inline)) {
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                   :
+                   : "s"(lds_addr), "v"(voff), "s"(desc)
+                   : "memory");
+    };
+    auto dma = [&](int kt, int stage) __attribute__((always_inline)) {
+      const int k8 = kt * 8 + kce;
+      const bool kval = k8 < K8;
+      int2 e = make_int2(0, k8 * 16);
+      if (MODE != 0) e = ktab[k8];
+      const unsigned kbit = (MODE == 0) ? (unsigned)kval : 1u;
+      const unsigned A = lds0 + (unsigned)(stage * STAGE);
+      const unsigned B = A + BM * 128;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const unsigned ok = kbit & (vmask[i] >> e.x) & 1u;
+        const unsigned off = ok ? roff[i] + (unsigned)e.y : VS_OOB;
+        dma16(xdesc, A + i * 4096, off);
+      }
+#pragma unroll
+      for (int j = 0; j < BJ; ++j) {
+        const unsigned ok = (unsigned)kval & (unsigned)(boff[j] != VS_OOB);
+        const unsigned off = ok ? boff[j] + (unsigned)(k8 * 16) : VS_OOB;
+        dma16(wdesc, B + j * 4096, off);
+      }
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) dma(kbeg + d, d);
+    int st_c = 0, st_l = D;  // stage computed / stage refilled this step
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"i"((D - 1) * L) : "memory");  // my part of tile kt landed
+      __builtin_amdgcn_s_barrier();  // everyone's did; stage st_l (tile kt-1) is no longer read
+      __builtin_amdgcn_sched_barrier(0);
+      dma(kbeg + kt + D, st_l);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(st_c);
+      __builtin_amdgcn_sched_barrier(0);
+      st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
+      st_l = (st_l + 1 == NS) ? 0 : st_l + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // run-ahead tiles (never read) before LDS reuse
+    __syncthreads();
+  } else {
   // Software pipeline, prefetch distance 2: while tile kt is multiplied, tile kt+1 sits in one
   // register set (loaded during step kt-1, written to LDS at the end of step kt) and the loads
   // of tile kt+2 are issued into the other set.  With one block per CU a single tile in flight
@@ -351,6 +421,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     compute(1);
   }
   __syncthreads();
+  }
 
   if (p.splitK > 1) {
     // split-K: raw fp32 partial tile -> slab[ksplit]; BN statistics, affine, residual, ReLU and
@@ -837,19 +908,33 @@ struct TileCfg {
   int bm, bn;
 };
 
-static TileCfg pick_tile(long long M, int Ncols) {
+// Tile + staging plan, from the (tile x ring) sweep of every conv GEMM of the batch-8 train step
+// (tools/autotune_conv.py, profiles/r01_autotune_ring.txt):
+//  * shallow K (<= 2 k-steps): nothing to pipeline -> register staging, 64-row tiles;
+//  * deep K, >= 256 128x128 tiles: 128x128 with a 2-stage ring (64 KB -> 2 blocks per CU);
+//  * deep K, fewer tiles (slow s4 / s5 at batch 8): 64x128 with a 3-stage ring (72 KB, 2 blocks
+//    per CU, 2 tiles in flight per block) -- these layers are latency / bytes-in-flight bound;
+//  * <= 64 output channels: 64x64 (HBM-bound), ring once K is deep enough to matter.
+static TileCfg pick_tile(long long M, int Ncols, int K, int* ring) {
   TileCfg c;
-  if (Ncols >= 128) {
+  const int nk = (K + 63) / 64;
+  *ring = 0;
+  if (Ncols > 64) {
     c.bn = 128;
-    const long long t = ((M + 127) / 128) * ((Ncols + 127) / 128);
-    c.bm = (t >= 512) ? 128 : 64;
-  } else if (Ncols >= 64) {
-    c.bn = 64;
-    const long long t = (M + 127) / 128;
-    c.bm = (t >= 512) ? 128 : 64;
+    const long long t128 = ((M + 127) / 128) * ((Ncols + 127) / 128);
+    if (nk <= 2) {
+      c.bm = 64;
+    } else if (t128 >= 256) {
+      c.bm = 128;
+      *ring = 2;
+    } else {
+      c.bm = 64;
+      *ring = 3;
+    }
   } else if (Ncols >= 32) {
-    c.bn = 32;
-    c.bm = 256;
+    c.bn = 64;
+    c.bm = 64;
+    if (nk >= 8) *ring = 2;
   } else {
     c.bn = 16;
     c.bm = 256;
@@ -857,50 +942,85 @@ static TileCfg pick_tile(long long M, int Ncols) {
   return c;
 }
 
-template <int BM, int BN, int WM, int WN>
-static int launch_cfg(const ConvP& p, int mode, hipStream_t st) {
-  const size_t smem =
-      (size_t)ConvSmem<BM, BN>::MAIN + 2 * WM * BN * 4 + (mode ? (size_t)((p.K + 63) >> 6) * 64 : 0);
-  const int grid = p.tilesM * p.tilesN * p.splitK;
-  const bool fast = p.kT * p.kH * p.kW <= 31;
-  // dynamic LDS above 64 KiB needs an explicit opt-in, once per kernel
-  static bool attr_done = false;
+template <int BM, int BN, int WM, int WN, int MODE, int NS>
+static int launch_one(const ConvP& p, int grid, size_t smem, hipStream_t st) {
+  static bool attr_done = false;  // dynamic LDS above 64 KiB needs an explicit opt-in, once per kernel
   if (!attr_done) {
-    const int max_smem = 160 * 1024;
-    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, 0, true>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, max_smem);
-    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, 1, true>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, max_smem);
-    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, 2, true>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, max_smem);
-    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, 1, false>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, max_smem);
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, MODE, true, 0, NS>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MODE, true, 0, NS>), dim3(grid), dim3(256),
+                     smem, st, p);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int NS>
+static int launch_mode(const ConvP& p, int mode, int grid, size_t smem, hipStream_t st) {
+  if (mode == 0) return launch_one<BM, BN, WM, WN, 0, NS>(p, grid, smem, st);
+  if (mode == 1) return launch_one<BM, BN, WM, WN, 1, NS>(p, grid, smem, st);
+  return launch_one<BM, BN, WM, WN, 2, NS>(p, grid, smem, st);
+}
+
+static size_t conv_smem_bytes(int bm, int bn, int wm, int ns, int mode, int K) {
+  const size_t stage = (size_t)(bm + bn) * 128, epi = (size_t)bm * bn * 4;
+  const size_t ring = (size_t)(ns > 2 ? ns : 2) * stage;
+  const size_t tab = mode ? (size_t)(((K + 63) >> 6) + (ns > 0 ? ns - 1 : 0)) * 64 : 0;
+  return (ring > epi ? ring : epi) + (size_t)2 * wm * bn * 4 + tab;
+}
+
+// ring: 0 = register-staged pipeline, 2..4 = LDS-DMA ring with that many stages
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(const ConvP& p, int mode, int ring, hipStream_t st) {
+  const int grid = p.tilesM * p.tilesN * p.splitK;
+  const bool fast = p.kT * p.kH * p.kW <= 31;
+  if (!fast || BN < 32) ring = 0;
+  while (ring >= 2 && conv_smem_bytes(BM, BN, WM, ring, mode, p.K) > 160 * 1024) --ring;
+  if (ring < 2) ring = 0;
+  const size_t smem = conv_smem_bytes(BM, BN, WM, ring, mode, p.K);
   const int dbg = (p.flags >> 12) & 7;
   if (dbg && BM == 128 && BN == 128 && mode == 1 && fast) {
-    if (dbg == 1) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, 1, true, 1>), dim3(grid), dim3(256), smem, st, p);
-    else if (dbg == 2) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, 1, true, 2>), dim3(grid), dim3(256), smem, st, p);
-    else if (dbg == 3) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, 1, true, 3>), dim3(grid), dim3(256), smem, st, p);
-    else hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, 1, true, 4>), dim3(grid), dim3(256), smem, st, p);
+    static bool dbg_attr = false;
+    if (!dbg_attr) {
+      (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<128, 128, 2, 2, 1, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<128, 128, 2, 2, 1, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<128, 128, 2, 2, 1, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<128, 128, 2, 2, 1, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      dbg_attr = true;
+    }
+    const size_t sm = conv_smem_bytes(128, 128, 2, 0, 1, p.K);
+    if (dbg == 1) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, 1, true, 1>), dim3(grid), dim3(256), sm, st, p);
+    else if (dbg == 2) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, 1, true, 2>), dim3(grid), dim3(256), sm, st, p);
+    else if (dbg == 3) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, 1, true, 3>), dim3(grid), dim3(256), sm, st, p);
+    else hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, 1, true, 4>), dim3(grid), dim3(256), sm, st, p);
     VS_CHECK_LAUNCH();
     return VS_OK;
   }
-  if (!fast) {  // > 32 taps: only the Cin-padded stems of configurations without a stem kernel
+  if (!fast) {  // > 31 taps: only the Cin-padded stems of configurations without a stem kernel
     if (mode != 1) {
       vs_set_error("conv: more than 31 taps is only supported for the forward gather");
       return VS_ERR_UNSUPPORTED;
     }
+    static bool slow_attr = false;
+    if (!slow_attr) {
+      (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, 1, false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      slow_attr = true;
+    }
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, false>), dim3(grid), dim3(256), smem,
                        st, p);
-  } else if (mode == 0)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 0, true>), dim3(grid), dim3(256), smem, st, p);
-  else if (mode == 1)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, true>), dim3(grid), dim3(256), smem, st, p);
-  else
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 2, true>), dim3(grid), dim3(256), smem, st, p);
-  VS_CHECK_LAUNCH();
-  return VS_OK;
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+  }
+  if constexpr (BN >= 32) {
+    if (ring == 2) return launch_mode<BM, BN, WM, WN, 2>(p, mode, grid, smem, st);
+    if (ring == 3) return launch_mode<BM, BN, WM, WN, 3>(p, mode, grid, smem, st);
+    if constexpr ((BM + BN) * 128 * 4 <= 144 * 1024) {
+      if (ring == 4) return launch_mode<BM, BN, WM, WN, 4>(p, mode, grid, smem, st);
+    }
+  }
+  return launch_mode<BM, BN, WM, WN, 0>(p, mode, grid, smem, st);
 }
 
 // tile configs addressable through vs_conv_desc.flags bits 8..11 (value = id + 1; 0 = heuristic)
@@ -912,6 +1032,7 @@ struct ConvPlan {
   TileCfg tile;
   int S;        // split-K factor (1 = none)
   bool direct;  // register-resident small-channel kernel
+  int ring;     // 0 = register-staged pipeline, 2..4 = LDS-DMA ring stages
 };
 
 // Few-tile, deep-K layers (slow s4 / s5 at batch 8: 100-400 tiles for 256 CUs) leave each CU
@@ -921,6 +1042,8 @@ static ConvPlan plan_conv(long long M, int Ncols, int K, int taps, int flags) {
   ConvPlan pl;
   pl.S = 1;
   pl.direct = false;
+  const int fring = (flags >> 16) & 7;  // VS_CONV_RING: 1 = register-staged, 2..4 = ring stages
+  pl.ring = fring >= 2 ? (fring > 4 ? 4 : fring) : 0;
   const int forced = (flags >> 8) & 0xf;
   if (forced >= 1 && forced <= kNumTileCfgs) {
     pl.tile = kTileTable[forced - 1];
@@ -931,11 +1054,16 @@ static ConvPlan plan_conv(long long M, int Ncols, int K, int taps, int flags) {
     pl.tile = kTileTable[5];
     return pl;
   }
-  pl.tile = pick_tile(M, Ncols);
+  int hring = 0;
+  pl.tile = pick_tile(M, Ncols, K, &hring);
+  if (fring == 0 && taps <= 31) pl.ring = hring;
   const int nk = (K + 63) / 64;
   const long long t128 = ((M + 127) / 128) * ((Ncols + 127) / 128);
-  if (Ncols >= 128 && Ncols % 8 == 0 && taps <= 31 && t128 < 384 && nk >= 16) {
+  // measured on MI355X at batch 8: the slab write + re-read costs more than the extra occupancy
+  // buys (s4.a 46 -> 58 us), so the split plan is opt-in (VS_CONV_SPLITK) until batches grow
+  if ((flags & VS_CONV_SPLITK) && Ncols >= 128 && Ncols % 8 == 0 && taps <= 31 && t128 < 384 && nk >= 16) {
     pl.tile = kTileTable[0];
+    pl.ring = fring >= 2 ? pl.ring : 0;
     long long S = (512 + t128 - 1) / t128;
     if (S > nk / 8) S = nk / 8;
     if (S > 4) S = 4;
@@ -976,7 +1104,7 @@ static int launch_conv(ConvP& p, int mode, int naive, int flags, void* ws, size_
     p.slab = (float*)ws;
     const int user_flags = p.flags;
     p.flags &= ~(VS_CONV_STATS | VS_CONV_AFFINE | VS_CONV_RESIDUAL | VS_CONV_RELU);
-    const int rc = launch_cfg<128, 128, 2, 2>(p, mode, st);
+    const int rc = launch_cfg<128, 128, 2, 2>(p, mode, pl.ring, st);
     if (rc) return rc;
     hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((p.M + 63) / 64), dim3(256), 0, st,
                        (const float*)ws, pl.S, p.y, p.scale, p.shift, p.res, p.stats, p.M, p.Ncols,
@@ -984,14 +1112,14 @@ static int launch_conv(ConvP& p, int mode, int naive, int flags, void* ws, size_
     VS_CHECK_LAUNCH();
     return VS_OK;
   }
-  if (c.bm == 128 && c.bn == 128) return launch_cfg<128, 128, 2, 2>(p, mode, st);
-  if (c.bm == 64 && c.bn == 128) return launch_cfg<64, 128, 1, 4>(p, mode, st);
-  if (c.bm == 128 && c.bn == 64) return launch_cfg<128, 64, 2, 2>(p, mode, st);
-  if (c.bm == 64 && c.bn == 64) return launch_cfg<64, 64, 2, 2>(p, mode, st);
-  if (c.bm == 256 && c.bn == 32) return launch_cfg<256, 32, 4, 1>(p, mode, st);
-  if (c.bm == 256 && c.bn == 128) return launch_cfg<256, 128, 4, 1>(p, mode, st);
-  if (c.bm == 128 && c.bn == 256) return launch_cfg<128, 256, 1, 4>(p, mode, st);
-  return launch_cfg<256, 16, 4, 1>(p, mode, st);
+  if (c.bm == 128 && c.bn == 128) return launch_cfg<128, 128, 2, 2>(p, mode, pl.ring, st);
+  if (c.bm == 64 && c.bn == 128) return launch_cfg<64, 128, 1, 4>(p, mode, pl.ring, st);
+  if (c.bm == 128 && c.bn == 64) return launch_cfg<128, 64, 2, 2>(p, mode, pl.ring, st);
+  if (c.bm == 64 && c.bn == 64) return launch_cfg<64, 64, 2, 2>(p, mode, pl.ring, st);
+  if (c.bm == 256 && c.bn == 32) return launch_cfg<256, 32, 4, 1>(p, mode, pl.ring, st);
+  if (c.bm == 256 && c.bn == 128) return launch_cfg<256, 128, 4, 1>(p, mode, pl.ring, st);
+  if (c.bm == 128 && c.bn == 256) return launch_cfg<128, 256, 1, 4>(p, mode, pl.ring, st);
+  return launch_cfg<256, 16, 4, 1>(p, mode, pl.ring, st);
 }
 
 static int ilog2_exact(int v) {
@@ -1022,6 +1150,25 @@ extern "C" int vs_conv_stats_rows(const vs_conv_desc* d) {
   if (pl.direct) return direct_blocks(M);
   if (pl.S > 1) return (int)((M + 63) / 64);
   return (int)((M + pl.tile.bm - 1) / pl.tile.bm);
+}
+
+extern "C" int vs_conv_plan(const vs_conv_desc* d, int dgrad, int* out) {
+  VS_CHECK_ARG(d != nullptr && out != nullptr, "null argument");
+  const int taps = d->kT * d->kH * d->kW;
+  ConvPlan pl;
+  if (dgrad) {
+    const long long M = (long long)d->N * d->Ti * d->Hi * d->Wi;
+    pl = plan_conv(M, d->Cin, taps * d->Cout, taps, d->flags);
+  } else {
+    const long long M = (long long)d->N * d->To * d->Ho * d->Wo;
+    pl = plan_conv(M, d->Cout, taps * d->Cin, taps, d->flags);
+  }
+  out[0] = pl.tile.bm;
+  out[1] = pl.tile.bn;
+  out[2] = (taps <= 31 && pl.tile.bn >= 32 && !pl.direct) ? pl.ring : 0;
+  out[3] = pl.S;
+  out[4] = pl.direct ? 1 : 0;
+  return VS_OK;
 }
 
 extern "C" size_t vs_conv_workspace_bytes(const vs_conv_desc* d, int dgrad) {
@@ -1079,7 +1226,7 @@ extern "C" int vs_conv_fwd(const void* x, const void* w, void* y, const vs_conv_
   }
   p.y_ld = d->y_ld;
   p.res_ld = d->res_ld;
-  p.flags = d->flags & 0x70ff;
+  p.flags = d->flags & 0x70ff;  // epilogue bits + debug ablation
   p.tilesM = p.tilesN = 0;
   const bool pointwise = (d->kT * d->kH * d->kW == 1) && d->pT == 0 && d->pH == 0 && d->pW == 0;
   return launch_conv(p, pointwise ? 0 : 1, (d->flags & VS_CONV_NAIVE) != 0, d->flags, workspace,

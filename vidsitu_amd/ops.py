@@ -147,7 +147,7 @@ def tile_flag(kind, M, ncols, K, k, s, force=None):
 
 
 def conv_fwd(x, w, k, s, p, out=None, scale=None, shift=None, residual=None, relu=False,
-             stats=False, naive=False, tile=None, dbg=0):
+             stats=False, naive=False, tile=None, dbg=0, splitk=False, ring=0):
     """y = conv3d(x, w) [*scale+shift] [+residual] [relu]; optional BN-stat partials.
     Returns (y, partials|None)."""
     cout = w.shape[0]
@@ -173,6 +173,9 @@ def conv_fwd(x, w, k, s, p, out=None, scale=None, shift=None, residual=None, rel
     flags |= tile_flag("f", ys[0] * ys[2] * ys[3] * ys[4], cout, x.shape[1] * k[0] * k[1] * k[2], k, s,
                        tile)
     flags |= (dbg & 7) << 12  # diagnostic ablation builds (wrong results), tools/ only
+    if splitk:
+        flags |= 1 << 15  # VS_CONV_SPLITK
+    flags |= (ring & 7) << 16  # VS_CONV_RING
     d = make_desc(x.shape, act_ld(x), ys, act_ld(out), k, s, p, flags,
                   act_ld(residual) if residual is not None else 0)
     partials = None
@@ -252,13 +255,14 @@ def weight_transpose_batched(src_arena, dst_arena, table, total):
               table.shape[0], int(total), _stream())
 
 
-def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=None):
+def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=None, ring=0):
     """dx[xs] = conv_transpose(dy, w) (+ residual).  wt from weight_transpose."""
     if out is None:
         out = new_act(*xs, device=dy.device)
     flags = (VS_CONV_NAIVE if naive else 0) | (VS_CONV_RESIDUAL if residual is not None else 0)
     flags |= tile_flag("d", xs[0] * xs[2] * xs[3] * xs[4], xs[1], dy.shape[1] * k[0] * k[1] * k[2], k, s,
                        tile)
+    flags |= (ring & 7) << 16  # VS_CONV_RING
     d = make_desc(xs, act_ld(out), dy.shape, act_ld(dy), k, s, p, flags,
                   act_ld(residual) if residual is not None else 0)
     need = _lib.load().vs_conv_workspace_bytes(C.byref(d), 1)
