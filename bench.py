@@ -12,8 +12,8 @@ Workloads (BASELINE.json `configs`):
   sf_txenc_train  configs[2]: SlowFast-R50 + 6-layer TxEncoder verb prediction, fwd+bwd+Adam
 
 `roofline` is computed for the dominant kernel family of the step from per-launch HIP-event
-timings taken in a separate instrumented pass on the launch stream (algorithmic FLOPs of each
-conv launch / its measured duration); `cpu_baseline` times the fp32 torch oracle restatement
+timings of every C-ABI entry point, taken in a separate instrumented pass on the launch stream
+(algorithmic FLOPs or bytes of each launch / its measured duration); `cpu_baseline` times the fp32 torch oracle restatement
 (kind "port": the reference's own CPU path cannot run) on a bounded sample.
 """
 import argparse
@@ -47,84 +47,141 @@ def parse():
     return ap.parse_args()
 
 
-def pick_tile(M, ncols):
-    """Python twin of pick_tile() in csrc/conv_igemm.hip (for kernel attribution only)."""
-    if ncols >= 128:
-        t = ((M + 127) // 128) * ((ncols + 127) // 128)
-        return (128 if t >= 512 else 64, 128)
-    if ncols >= 64:
-        return (128 if (M + 127) // 128 >= 512 else 64, 64)
-    return (256, 32) if ncols >= 32 else (256, 16)
+def _v(a):
+    """ctypes scalar / plain python number -> python number."""
+    return a.value if hasattr(a, "value") else a
 
 
-class ConvProbe:
-    """Wraps ops.conv_* with HIP events on the launch stream; aggregates per kernel family."""
+def _nn(a):
+    """1 if a pointer argument is non-null."""
+    return 0 if a is None or _v(a) in (None, 0) else 1
+
+
+_WAVES = {(128, 128): (2, 2), (64, 128): (1, 4), (128, 64): (2, 2), (64, 64): (2, 2),
+          (256, 32): (4, 1), (256, 16): (4, 1), (256, 128): (4, 1), (128, 256): (1, 4)}
+
+
+class EntryProbe:
+    """Brackets EVERY C-ABI entry point (vidsitu_amd._lib.call) with HIP events recorded on the
+    launch stream and aggregates per kernel family.  The label of a conv launch is the kernel
+    template instance the library's own plan (vs_conv_plan) selects, spelled as rocprofv3 prints
+    it, so the families line up with profiles/*kernel_stats*.csv.  While the step is enqueued
+    the GPU is parked behind a spin kernel, so the launches run back to back and an event pair
+    measures kernel time, not the Python launch latency in front of it."""
 
     def __init__(self):
         self.records = []
 
     def install(self):
-        from vidsitu_amd import ops
+        from vidsitu_amd import _lib
 
-        self.ops = ops
-        self.saved = (ops.conv_fwd, ops.conv_dgrad, ops.conv_wgrad)
+        self._lib = _lib
+        lib = _lib.load()
         probe = self
+        import ctypes as C
 
-        def timed(fn, key_fn):
-            def inner(*a, **kw):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                out = fn(*a, **kw)
-                e1.record()
-                probe.records.append((key_fn(*a, **kw), e0, e1))
-                return out
-            return inner
+        def conv_label(d, dgrad):
+            out = (C.c_int * 5)()
+            lib.vs_conv_plan(C.byref(d), dgrad, out)
+            bm, bn, ring, S, direct = list(out)
+            taps = d.kT * d.kH * d.kW
+            unit = d.sT == 1 and d.sH == 1 and d.sW == 1
+            pw = taps == 1 and d.pT == 0 and d.pH == 0 and d.pW == 0
+            mode = (0 if (pw and unit) else (1 if unit else 2)) if dgrad else (0 if pw else 1)
+            if direct:
+                ncols = d.Cin if dgrad else d.Cout
+                K = taps * (d.Cout if dgrad else d.Cin)
+                return f"conv_direct_kernel<{1 if ncols <= 16 else 2}, {min((K + 31) // 32, 5)}, {mode}>"
+            wm, wn = _WAVES[(bm, bn)]
+            fast = "true" if taps <= 31 else "false"
+            tail = f", 0, {ring}" if taps <= 31 else ""
+            name = f"conv_igemm_kernel<{bm}, {bn}, {wm}, {wn}, {mode}, {fast}{tail}>"
+            return name + (f" +splitk{S}" if S > 1 else "")
 
-        def k_fwd(x, w, k, s, p, **kw):
-            ys = ops.conv_out_shape(x.shape, w.shape[0], k, s, p)
-            M = ys[0] * ys[2] * ys[3] * ys[4]
-            K = x.shape[1] * k[0] * k[1] * k[2]
-            bm, bn = pick_tile(M, ys[1])
-            pw = k == (1, 1, 1) and p == (0, 0, 0)
-            # real (unpadded) input channels for the algorithmic count
-            cin = 3 if x.shape[1] == 8 and k[1] == 7 else x.shape[1]
-            flops = 2.0 * M * ys[1] * cin * k[0] * k[1] * k[2]
-            byts = 2.0 * (x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] * x.shape[4] + M * ys[1])
-            return (f"conv_igemm_kernel<{bm},{bn}> mode{0 if pw else 1} (fwd)", flops, byts)
+        def describe(name, a):
+            """-> (family label, bound, algorithmic flops, algorithmic bytes)"""
+            if name in ("vs_conv_fwd", "vs_conv_dgrad", "vs_conv_wgrad"):
+                d = a[3]._obj
+                taps = d.kT * d.kH * d.kW
+                mo = d.N * d.To * d.Ho * d.Wo
+                mi = d.N * d.Ti * d.Hi * d.Wi
+                flops = 2.0 * mo * d.Cout * d.Cin * taps
+                byts = 2.0 * (mi * d.Cin + mo * d.Cout + d.Cout * d.Cin * taps)
+                if name == "vs_conv_wgrad":
+                    return "conv_wgrad_kernel (+wgrad_reduce_kernel)", "mfma", flops, byts
+                if name == "vs_conv_fwd" and (d.flags & 2):
+                    byts += 2.0 * mo * d.Cout
+                return conv_label(d, 1 if name == "vs_conv_dgrad" else 0), "mfma", flops, byts
+            if name in ("vs_stem_conv_fwd", "vs_stem_conv_wgrad"):
+                n, t, h, w, cout, kt = [_v(x) for x in a[3:9]]
+                ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+                flops = 2.0 * n * t * ho * wo * cout * 3 * kt * 49  # the 3 real input channels
+                byts = 2.0 * (n * t * h * w * 4 + n * t * ho * wo * cout)
+                return ("stem_conv_kernel" if name == "vs_stem_conv_fwd" else
+                        "stem_wgrad_kernel (+stem_slab_reduce_kernel)"), "mfma", flops, byts
+            if name == "vs_bn_apply":
+                rows, c = _v(a[5]), _v(a[6])
+                return "bn_apply_kernel", "hbm", 0.0, 2.0 * rows * c * (2 + _nn(a[3]))
+            if name == "vs_bn_bwd_reduce":
+                rows, c = _v(a[8]), _v(a[9])
+                return "bn_bwd_reduce_kernel", "hbm", 0.0, 2.0 * rows * c * (2 + _nn(a[1]))
+            if name == "vs_bn_bwd_apply":
+                rows, c = _v(a[11]), _v(a[12])
+                n_t = 2 + _nn(a[1]) + 1 + _nn(a[10])  # dz, y (+z) in; dy (+dres) out
+                return "bn_bwd_apply_kernel", "hbm", 0.0, 2.0 * rows * c * n_t
+            if name == "vs_adam_step_dev" or name == "vs_adam_step":
+                return "adam_kernel", "hbm", 0.0, 4.0 * _v(a[4]) * 7  # p,g,m,v in; p,m,v out
+            return name.replace("vs_", "") + " (entry point)", None, 0.0, 0.0
 
-        def k_dgrad(dy, wt, xs, k, s, p, **kw):
-            M = xs[0] * xs[2] * xs[3] * xs[4]
-            bm, bn = pick_tile(M, xs[1])
-            flops = 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * dy.shape[4] * dy.shape[1] * \
-                xs[1] * k[0] * k[1] * k[2]
-            byts = 2.0 * (dy.numel() + M * xs[1])
-            return (f"conv_igemm_kernel<{bm},{bn}> (dgrad)", flops, byts)
+        def hook(name, args, fn):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            probe.records.append((describe(name, args), e0, e1))
+            return rc
 
-        def k_wgrad(dy, x, k, s, p, **kw):
-            cin = 3 if x.shape[1] == 8 and k[1] == 7 else x.shape[1]
-            flops = 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * dy.shape[4] * dy.shape[1] * \
-                cin * k[0] * k[1] * k[2]
-            byts = 2.0 * (dy.numel() + x.numel())
-            return ("conv_wgrad_kernel (wgrad)", flops, byts)
-
-        ops.conv_fwd = timed(self.saved[0], k_fwd)
-        ops.conv_dgrad = timed(self.saved[1], k_dgrad)
-        ops.conv_wgrad = timed(self.saved[2], k_wgrad)
+        _lib._probe = hook
 
     def remove(self):
-        self.ops.conv_fwd, self.ops.conv_dgrad, self.ops.conv_wgrad = self.saved
+        self._lib._probe = None
 
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for (name, flops, byts), e0, e1 in self.records:
-            ms = e0.elapsed_time(e1)
-            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+        for (name, bound, flops, byts), e0, e1 in self.records:
+            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0, bound])
             a[0] += 1
-            a[1] += ms
+            a[1] += e0.elapsed_time(e1)
             a[2] += flops
             a[3] += byts
         return agg
+
+
+def park_gpu(ms):
+    """Keep the GPU busy for ~ms with a spin kernel so that the launches enqueued behind it run
+    back to back (profiling pass only)."""
+    if not hasattr(park_gpu, "per_mcycle"):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(1000000)
+        torch.cuda.synchronize()
+        e0.record()
+        torch.cuda._sleep(1000000)
+        e1.record()
+        torch.cuda.synchronize()
+        park_gpu.per_mcycle = max(e0.elapsed_time(e1), 1e-3)
+    torch.cuda._sleep(int(ms / park_gpu.per_mcycle * 1e6))
+
+
+def load_pmc_traffic():
+    """HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/pmc_traffic.sh ->
+    profiles/pmc_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except OSError:
+        return {}
 
 
 def cpu_baseline(workload, n_vocab):
@@ -264,29 +321,61 @@ def main():
 
     roof = None
     if rank == 0 and not args.no_roofline:
-        probe = ConvProbe()
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - t0) * 1e3  # CPU time to enqueue one eager step
+        probe = EntryProbe()
         probe.install()
+        reps = 3
         try:
-            for _ in range(3):
+            for _ in range(reps):
+                try:
+                    park_gpu(1.3 * eager_ms + 10.0)
+                except Exception:  # no spin kernel: event pairs then include launch gaps
+                    pass
                 step()
+                torch.cuda.synchronize()
         finally:
             probe.remove()
         agg = probe.summary()
-        tot_ms = sum(a[1] for a in agg.values())
-        tot_fl = sum(a[2] for a in agg.values())
-        name, a = max(agg.items(), key=lambda kv: kv[1][1])
-        ach = a[2] / (a[1] * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": name, "launches_per_step": a[0] // 3,
-                "avg_launch_us": round(a[1] / a[0] * 1e3, 2), "achieved": round(ach, 2),
-                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                "traffic": None,
-                "all_conv": {"ms_per_step": round(tot_ms / 3, 3),
-                             "achieved_tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
-                             "algorithmic_gbs": round(sum(x[3] for x in agg.values()) /
-                                                      (tot_ms * 1e-3) / 1e9, 1)},
-                "families": {k: {"launches": v[0] // 3, "ms_per_step": round(v[1] / 3, 3),
-                                 "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)}
-                             for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
+        pmc = load_pmc_traffic()
+
+        def fam(name, v):
+            n, ms, fl, by, bound = v
+            out = {"kernel": name, "launches_per_step": n // reps,
+                   "ms_per_step": round(ms / reps, 3), "avg_launch_us": round(ms / n * 1e3, 2),
+                   "bound": bound}
+            if bound == "mfma":
+                ach = fl / (ms * 1e-3) / 1e12
+                out.update({"achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(ach / PEAK_BF16_TFLOPS, 4)})
+            elif bound == "hbm":
+                ach = by / (ms * 1e-3) / 1e9
+                out.update({"achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": round(ach / PEAK_HBM_GBS, 4)})
+            out["algorithmic_bytes_per_launch"] = round(by / n)
+            # PMC table rows whose kernel name starts with this family's name (a family such as
+            # bn_bwd_apply_kernel covers several template instances): launch-weighted mean
+            key = name.split(" (")[0].split(" +")[0]
+            rows = [t for k, t in pmc.items() if k.startswith(key) and not k.startswith("_")]
+            nl = sum(t["launches"] for t in rows)
+            out["traffic"] = round(sum((t["fetch_bytes"] + t["write_bytes"]) * t["launches"]
+                                       for t in rows) / nl) if nl else None
+            return out
+
+        fams = sorted(agg.items(), key=lambda kv: -kv[1][1])
+        tot_ms = sum(v[1] for _, v in fams) / reps
+        top = next((fam(k, v) for k, v in fams if v[4] is not None), None)
+        roof = dict(top)
+        roof["probed_ms_per_step"] = round(tot_ms, 3)
+        roof["note"] = ("dominant entry point of the step by summed HIP-event time; separate "
+                        "instrumented eager pass (the timed region replays a hipGraph)")
+        conv = [v for k, v in fams if v[4] == "mfma"]
+        cms, cfl = sum(v[1] for v in conv), sum(v[2] for v in conv)
+        roof["all_conv"] = {"ms_per_step": round(cms / reps, 3),
+                            "achieved_tflops": round(cfl / (cms * 1e-3) / 1e12, 2)}
+        roof["families"] = [fam(k, v) for k, v in fams[:16]]
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:

@@ -130,7 +130,15 @@ def check(rc, what=""):
         raise VsError(f"{what} failed with vs_status {rc}: {msg.decode() if msg else ''}")
 
 
+# bench.py installs a callable here to bracket every entry point with HIP events on the launch
+# stream (profiling only; None = straight call)
+_probe = None
+
+
 def call(name, *args):
     lib = load()
-    rc = getattr(lib, name)(*args)
+    if _probe is not None:
+        rc = _probe(name, args, getattr(lib, name))
+    else:
+        rc = getattr(lib, name)(*args)
     check(rc, name)

@@ -69,7 +69,21 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
   const int c = blockIdx.x * 32 + cl;
   double s = 0.0, q = 0.0;
   if (c < C) {
-    for (int p = sl; p < nparts; p += 32) {
+    int p = sl;
+    for (; p + 96 < nparts; p += 128) {  // 8 loads in flight, same summation order
+      float a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = partials[(long long)(p + 32 * u) * 2 * C + c];
+        b[u] = partials[(long long)(p + 32 * u) * 2 * C + C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s += (double)a[u];
+        q += (double)b[u];
+      }
+    }
+    for (; p < nparts; p += 32) {
       s += (double)partials[(long long)p * 2 * C + c];
       q += (double)partials[(long long)p * 2 * C + C + c];
     }
@@ -226,20 +240,34 @@ extern "C" int vs_bn_apply(const void* y, const float* scale, const float* shift
 //   apply  : dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M) ; dres = g
 // block = 256 threads = cpr chunk-columns x (256/cpr) row lanes, cpr = C/8 | 256
 // ----------------------------------------------------------------------------
-#define BNB_ROWS_PER_LANE 16
+// Rows per thread come in batches of 4 whose loads are all issued before the first use (a
+// one-row-at-a-time loop is a chain of HBM latencies: 16 us floor however small the tensor).
+// The batch count adapts to the tensor so that small layers still fill the chip.
+#define BNB_BATCH 4
 
-// relu with z == nullptr: the mask is recomputed as gamma*xhat + beta > 0 (units without a
-// residual input), which drops one of the three reads of each pass.
+static int bnb_batches(long long rows, int C) {
+  const int cpr = C / 8;
+  const int ncol = cpr < 256 ? cpr : 256;
+  const long long rl = 256 / ncol;
+  long long nb = (rows + rl * BNB_BATCH * 1024 - 1) / (rl * BNB_BATCH * 1024);  // aim at ~1024 blocks
+  if (nb < 1) nb = 1;
+  if (nb > 4) nb = 4;
+  return (int)nb;
+}
+
+// MASK 0: no relu; 1: relu mask from z; 2: mask recomputed as gamma*xhat + beta > 0 (units
+// without a residual input), which drops one of the three reads of each pass.
+template <int MASK>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const uint16_t* dz, const uint16_t* z, const uint16_t* y, const float* mean,
     const float* invstd, const float* gamma, const float* beta, float* partial, long long rows,
-    int C, int dz_ld, int z_ld, int y_ld, int relu) {
+    int C, int dz_ld, int z_ld, int y_ld, int nbatch) {
   __shared__ float red[256 * 16];
   const int cpr = C >> 3;
   const int ncol = cpr < 256 ? cpr : 256;  // chunk columns handled per pass
   const int rl = 256 / ncol;               // row lanes
   const int col = threadIdx.x % ncol, lane_r = threadIdx.x / ncol;
-  const long long rows_per_blk = (long long)rl * BNB_ROWS_PER_LANE;
+  const long long rows_per_blk = (long long)rl * BNB_BATCH * nbatch;
   const long long r0 = (long long)blockIdx.x * rows_per_blk;
   for (int cb = col; cb < cpr; cb += ncol) {
     const int c = cb * 8;
@@ -248,23 +276,34 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     for (int e = 0; e < 8; ++e) {
       mu[e] = mean[c + e];
       is[e] = invstd[c + e];
-      ga[e] = (relu && !z) ? gamma[c + e] : 0.f;
-      be[e] = (relu && !z) ? beta[c + e] : 0.f;
+      ga[e] = (MASK == 2) ? gamma[c + e] : 0.f;
+      be[e] = (MASK == 2) ? beta[c + e] : 0.f;
       sg[e] = 0.f;
       sx[e] = 0.f;
     }
-    for (int it = 0; it < BNB_ROWS_PER_LANE; ++it) {
-      const long long row = r0 + (long long)it * rl + lane_r;
-      if (row < rows) {
+    for (int b = 0; b < nbatch; ++b) {
+      uint4 vg[BNB_BATCH], vy[BNB_BATCH], vz[BNB_BATCH];
+#pragma unroll
+      for (int u = 0; u < BNB_BATCH; ++u) {  // branch-free: a row past the end re-reads row 0, g := 0
+        const long long row = r0 + (long long)(b * BNB_BATCH + u) * rl + lane_r;
+        const bool ok = row < rows;
+        const long long rr = ok ? row : 0;
+        vg[u] = *(const uint4*)(dz + rr * dz_ld + c);
+        vy[u] = *(const uint4*)(y + rr * y_ld + c);
+        if (MASK == 1) vz[u] = *(const uint4*)(z + rr * z_ld + c);
+        if (!ok) vg[u] = make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < BNB_BATCH; ++u) {
         float g[8], yv[8];
-        unpack8_bf16(*(const uint4*)(dz + row * dz_ld + c), g);
-        unpack8_bf16(*(const uint4*)(y + row * y_ld + c), yv);
-        if (relu && z) {
+        unpack8_bf16(vg[u], g);
+        unpack8_bf16(vy[u], yv);
+        if (MASK == 1) {
           float zv[8];
-          unpack8_bf16(*(const uint4*)(z + row * z_ld + c), zv);
+          unpack8_bf16(vz[u], zv);
 #pragma unroll
           for (int e = 0; e < 8; ++e) g[e] = zv[e] > 0.f ? g[e] : 0.f;
-        } else if (relu) {
+        } else if (MASK == 2) {
 #pragma unroll
           for (int e = 0; e < 8; ++e)
             g[e] = ((yv[e] - mu[e]) * is[e] * ga[e] + be[e]) > 0.f ? g[e] : 0.f;
@@ -276,7 +315,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
         }
       }
     }
-    // reduce over the rl row lanes through LDS
+    // fixed-order tree over the rl row lanes through LDS
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -284,19 +323,20 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
       red[threadIdx.x * 16 + 8 + e] = sx[e];
     }
     __syncthreads();
-    if (lane_r == 0) {
-      for (int r = 1; r < rl; ++r) {
+    for (int st = rl >> 1; st >= 1; st >>= 1) {
+      if (lane_r < st) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          sg[e] += red[(r * ncol + col) * 16 + e];
-          sx[e] += red[(r * ncol + col) * 16 + 8 + e];
-        }
+        for (int e = 0; e < 16; ++e)
+          red[threadIdx.x * 16 + e] += red[(threadIdx.x + st * ncol) * 16 + e];
       }
+      __syncthreads();
+    }
+    if (lane_r == 0) {
       float* dst = partial + (long long)blockIdx.x * 2 * C;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        dst[c + e] = sg[e];
-        dst[C + c + e] = sx[e];
+        dst[c + e] = red[threadIdx.x * 16 + e];
+        dst[C + c + e] = red[threadIdx.x * 16 + 8 + e];
       }
     }
   }
@@ -312,7 +352,7 @@ extern "C" int vs_bn_bwd_reduce_rows(int64_t rows, int C) {
   if (!bnb_check(C)) return -1;
   const int cpr = C / 8;
   const int ncol = cpr < 256 ? cpr : 256;
-  const long long rpb = (long long)(256 / ncol) * BNB_ROWS_PER_LANE;
+  const long long rpb = (long long)(256 / ncol) * BNB_BATCH * bnb_batches(rows, C);
   return (int)((rows + rpb - 1) / rpb);
 }
 
@@ -324,9 +364,15 @@ extern "C" int vs_bn_bwd_reduce(const void* dz, const void* z, const void* y, co
   VS_CHECK_ARG(!relu || z || (gamma && beta), "relu needs z, or gamma/beta to recompute the mask");
   VS_CHECK_ARG(bnb_check(C), "C/8 must be a power of two");
   const int nblk = vs_bn_bwd_reduce_rows(rows, C);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream,
-                     (const uint16_t*)dz, (const uint16_t*)z, (const uint16_t*)y, mean, invstd, gamma,
-                     beta, partial, (long long)rows, C, dz_ld, z_ld, y_ld, relu);
+  const int nb = bnb_batches(rows, C);
+#define VS_BNB_LAUNCH(MASK)                                                                        \
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel<MASK>, dim3(nblk), dim3(256), 0, (hipStream_t)stream,    \
+                     (const uint16_t*)dz, (const uint16_t*)z, (const uint16_t*)y, mean, invstd,    \
+                     gamma, beta, partial, (long long)rows, C, dz_ld, z_ld, y_ld, nb)
+  if (!relu) VS_BNB_LAUNCH(0);
+  else if (z) VS_BNB_LAUNCH(1);
+  else VS_BNB_LAUNCH(2);
+#undef VS_BNB_LAUNCH
   VS_CHECK_LAUNCH();
   return VS_OK;
 }
@@ -339,7 +385,21 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* part
   const int c = blockIdx.x * 32 + cl;
   double s = 0.0, q = 0.0;
   if (c < C) {
-    for (int p = sl; p < nparts; p += 32) {
+    int p = sl;
+    for (; p + 96 < nparts; p += 128) {  // 8 loads in flight, same summation order
+      float a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = partial[(long long)(p + 32 * u) * 2 * C + c];
+        b[u] = partial[(long long)(p + 32 * u) * 2 * C + C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s += (double)a[u];
+        q += (double)b[u];
+      }
+    }
+    for (; p < nparts; p += 32) {
       s += (double)partial[(long long)p * 2 * C + c];
       q += (double)partial[(long long)p * 2 * C + C + c];
     }

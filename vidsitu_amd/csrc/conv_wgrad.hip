@@ -247,7 +247,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, f
   if (i < n4) {
     const int per = (S + 15) / 16;
     const int s0 = sl * per, s1 = min(S, s0 + per);
-    for (int s = s0; s < s1; ++s) {
+    // 8 slab rows in flight per thread (a one-load-at-a-time loop is a chain of memory
+    // latencies: 20 us for S = 1024); the sum order stays s0, s0+1, ...
+    int s = s0;
+    for (; s + 8 <= s1; s += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(slabs + (long long)(s + u) * n + i * 4);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc.x += v[u].x;
+        acc.y += v[u].y;
+        acc.z += v[u].z;
+        acc.w += v[u].w;
+      }
+    }
+    for (; s < s1; ++s) {
       const float4 v = *(const float4*)(slabs + (long long)s * n + i * 4);
       acc.x += v.x;
       acc.y += v.y;
