@@ -207,3 +207,46 @@ def test_sfbase_logits_and_top5_indices(dev):
     loss.backward()
     assert torch.isfinite(loss) and mdl.proj_head[0].weight.grad is not None
     assert mdl.sf_mdl.s1.pathway0_stem.conv.weight.grad is not None
+
+
+def test_feature_dump_roundtrip_into_txenc(dev, tmp_path):
+    """A8 (`feat_extractor.py:90-112`): trunk -> head -> `<vseg>_feats.npy` f32 [5, D] per video,
+    equal to the oracle's features, readable by the A9-A11 consumer (`dat_loader.py:503-511` ->
+    `SFPreFeats_TxEncDec.forward_encoder`, `mdl_sf_base.py:806-832`)."""
+    import numpy as np
+    from oracle.slowfast_ref import SFBaseRef, randomize_bn
+    from vidsitu_amd import feat_extractor as fx, synth_data
+    from vidsitu_amd.extended_config import get_cfg
+    from vidsitu_amd.mdl_selector import get_mdl_loss_eval
+
+    cfg = get_cfg({"mdl.sf_mdl_name": "i3d_tiny", "synth.num_verbs": 31,
+                   "ds.vsitu.vsitu_frm_feats": str(tmp_path)})
+    comm = synth_data.make_comm(cfg)
+    torch.manual_seed(0)
+    mdl = get_mdl_loss_eval(cfg)["mdl"](cfg=cfg, comm=comm)
+    ref = SFBaseRef(cfg.sf_mdl, 31)
+    randomize_bn(ref, 3)
+    mdl.load_state_dict(ref.state_dict(), strict=True)
+    mdl = mdl.to(dev).eval()
+    ref.eval()
+    ds = fx.SynthFrameDataset(cfg, comm, n_videos=3, n_ev=5, seed=11, crop=32)
+    ext = fx.FeatExtract(cfg)
+    ext.set_mdl_dl(mdl, fx.SimpleLoader(ds, batch_size=2), mdl_name="i3d_tiny_synth", split_name="valid")
+    files = ext.forward_all(device=dev)
+    assert [f.name for f in files] == [f"{n}_feats.npy" for n in ds.vseg_lst]
+    for ix, f in enumerate(files):
+        arr = np.load(f)
+        assert arr.dtype == np.float32 and arr.shape[0] == 5 and arr.ndim == 2
+        with torch.no_grad():
+            want = ref.forward_feats([ds[ix]["frms_ev_fast_tensor"]])
+        want = want.reshape(5, -1)
+        assert arr.shape == tuple(want.shape)
+        err = float(np.abs(arr - want.numpy()).max()) / float(want.abs().max())
+        assert err < 3e-2, f"video {ix}: feature error {err:.3e}"
+    # consumer side: [B, 5, D] features -> vid_feat_encoder -> TxEncoder -> EncoderOut [1, 5B, 1024]
+    from vidsitu_amd.mdl_sf_base import SFPreFeats_TxEncDec
+    enc = SFPreFeats_TxEncDec(cfg, comm, head_dim=np.load(files[0]).shape[1]).to(dev).eval()
+    feats = torch.stack([fx.read_frm_feats(ext.out_tdir, n)["frm_feats"] for n in ds.vseg_lst]).to(dev)
+    with torch.no_grad():
+        out = enc.forward_encoder({"frm_feats": feats, "vseg_idx": torch.arange(3, device=dev)})
+    assert tuple(out.encoder_out.shape) == (1, 15, 1024) and torch.isfinite(out.encoder_out).all()

@@ -249,12 +249,13 @@ class SFPreFeats_TxEncDec(nn.Module):
     vid_feat_encoder -> TxEncoderNew -> EncoderOut [1, 5B, 1024].  The fairseq / GPT-2
     decoder half is SURVEY.md section 8(f) rows f2/f3 (not built yet)."""
 
-    def __init__(self, cfg, comm):
+    def __init__(self, cfg, comm, head_dim=None):
         super().__init__()
         self.full_cfg = cfg
         self.cfg = cfg.mdl
         self.comm = comm
-        head_dim = get_head_dim(self.full_cfg)
+        if head_dim is None:  # the reference derives it from the feature directory's name
+            head_dim = get_head_dim(self.full_cfg)
         self.vid_feat_encoder = HipMLP(nn.Linear(head_dim, 1024), nn.ReLU(), nn.Linear(1024, 1024))
         self.use_encoder = True
         self.vid_feat_txenc = TxEncoder(self.full_cfg, self.comm)
