@@ -237,6 +237,41 @@ int vs_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, fl
 /* fp32 -> bf16 cast of the parameter arena (weights used by the conv kernels). */
 int vs_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 
+/* ---- GPT-2 decoder + beam-search scoring (fp32) --------------------------------------------
+ * Replaces huggingface GPT2LMHeadModel as called by HuggingFaceGPT2Decoder
+ * (vidsitu_code/hf_gpt2_fseq.py:150,165-203) and the per-step scoring of SeqGenCustom._generate
+ * (vidsitu_code/seq_gen.py:310-385).  Weights are kept K-contiguous ([out][in], nn.Linear
+ * layout; the host mirror transposes HF Conv1D tensors on load). */
+/* y[M,N] = act(x[M,K] . w[N,K]^T + b[N]) + res[M,N];  b, res may be NULL; act 0 none, 1 relu,
+ * 2 gelu_new.  M <= 64: one wave streams one weight row (HBM-bound); else fp32 MFMA tiles. */
+int vs_gemm_nt_f32(const float* x, const float* w, const float* b, const float* res, float* y, int M,
+                   int N, int K, int act, void* stream);
+/* out[r,l,:] = wte[tokens[r,l]] + wpe[pos0 + l]  (GPT2Model embeddings, default position ids). */
+int vs_gpt2_embed(const int64_t* tokens, const float* wte, const float* wpe, float* out, int R, int L,
+                  int D, int pos0, int V, void* stream);
+/* Causal self-attention on the fused c_attn output qkv[R,L,3D]; key_mask[R,L] (1 = attend, NULL =
+ * all); masked scores are -1e4 exactly as modeling_gpt2 does; out[R,L,D] with heads merged. */
+int vs_attn_causal_fwd(const float* qkv, const uint8_t* key_mask, float* out, int R, int L, int H,
+                       int dh, void* stream);
+/* One incremental step: append k,v of qkv[rows,3D] at position t of the caches
+ * [rows][H][Lmax][dh], attend the new query over 0..t; key_mask[rows,Lmax] or NULL. */
+int vs_attn_decode(const float* qkv, float* kcache, float* vcache, const uint8_t* key_mask, float* out,
+                   int rows, int H, int dh, int Lmax, int t, void* stream);
+/* dst[r] = src[index[r]] for the first len positions of every head (beam reorder of a cache). */
+int vs_kv_gather(const float* src, float* dst, const int64_t* index, int rows_out, int H, int dh,
+                 int Lmax, int len, void* stream);
+/* Beam-search step scoring: lp = log_softmax(logits/T), NaN -> -inf, lp[pad] = -inf,
+ * lp[unk] -= unk_penalty, flags&1: only eos, flags&2: eos banned, forced[r] >= 0 (and != pad):
+ * only that token; + cum[r]; the k (<= 32) best (value, token) per row, descending, ties ->
+ * lowest token id.  cum, forced may be NULL. */
+int vs_beam_topk(const float* logits, const float* cum, const int64_t* forced, float* out_val,
+                 int64_t* out_idx, int rows, int V, int k, int pad, int eos, int unk,
+                 float unk_penalty, float temperature, int flags, void* stream);
+/* Mean token cross entropy with ignore_index (Simple_TxDec.forward, mdl_sf_base.py:660-664):
+ * nll_rows[rows] scratch, loss_out[2] = {mean nll over counted rows, count}; ld = row pitch. */
+int vs_xent_ignore(const float* logits, const int64_t* labels, float* nll_rows, float* loss_out,
+                   int rows, int V, int64_t ld, int ignore_index, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,240 @@
+"""Parity of the GPT-2 decoder path through the C-ABI:
+fp32 GEMM / attention / embedding kernels against the oracle and the huggingface golden logits,
+cached decoding against the whole-sequence pass, and the beam search (`vidsitu_amd.seq_gen`)
+against the numpy restatement driven by the oracle language model -- token ids bit-exact.
+Tolerances: fp32 kernels with a different summation order: 2e-4 of the tensor's max; logits
+vs the golden (BASELINE: "logits within 1e-3 of reference"): 1e-3 absolute."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import beam_ref, gpt2_ref
+
+pytestmark = pytest.mark.gpu
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "gpt2_*.npz")))
+
+
+def _model_from_golden(path, dev):
+    from vidsitu_amd.hf_gpt2_fseq import GPT2LMHeadModelHip
+
+    z = np.load(path)
+    vocab, n_pos, d, n_layer, n_head, seed = [int(v) for v in z["dims"]]
+    w = gpt2_ref.make_weights(vocab, n_pos, d, n_layer, seed)
+    m = GPT2LMHeadModelHip(n_layer, d, n_head, n_pos, vocab)
+    sd = {k: torch.from_numpy(v) for k, v in w.items()}
+    sd["lm_head.weight"] = sd["transformer.wte.weight"]
+    m.load_state_dict(sd, strict=True)
+    return z, w, n_head, m.to(dev).eval()
+
+
+@pytest.mark.parametrize("m,n,k,act,use_res", [(5, 7, 12, 0, False), (40, 1024, 1024, 2, True),
+                                               (64, 96, 50, 1, False), (65, 130, 36, 2, True),
+                                               (300, 3072, 1024, 0, False), (600, 1024, 4096, 0, True),
+                                               (257, 97, 64, 2, False)])
+def test_gemm_nt_f32(m, n, k, act, use_res, dev):
+    from vidsitu_amd import ops
+
+    g = torch.Generator().manual_seed(m * 7 + n)
+    x = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) / k ** 0.5
+    b = torch.randn(n, generator=g)
+    res = torch.randn(m, n, generator=g) if use_res else None
+    ref = x.double() @ w.double().t() + b.double()
+    if act == 1:
+        ref = ref.clamp_min(0)
+    elif act == 2:
+        ref = torch.from_numpy(gpt2_ref.gelu_new(ref.numpy()))
+    if use_res:
+        ref = ref + res.double()
+    y = ops.gemm_nt(x.to(dev), w.to(dev), b.to(dev), res.to(dev) if use_res else None, act)
+    err = float((y.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 2e-5, f"gemm_nt {m}x{n}x{k} act {act}: rel err {err:.2e}"
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
+def test_gpt2_logits_match_transformers_golden(path, dev):
+    z, w, n_head, m = _model_from_golden(path, dev)
+    toks, mask = torch.from_numpy(z["tokens"]).to(dev), torch.from_numpy(z["mask"]).to(dev)
+    logits = m.forward_logits(toks, mask).cpu().numpy()
+    valid = z["mask"].astype(bool)
+    if "logits" in z:
+        err = np.abs(logits - z["logits"])[valid].max()
+    else:
+        err = np.abs(logits[:, :, :64] - z["logits_first64"])[valid].max()
+        assert (logits.argmax(-1) == z["logits_argmax"])[valid].all()
+        assert np.abs(logits.max(-1) - z["logits_max"])[valid].max() < 1e-3
+    print(f"{os.path.basename(path)}: max |logit - golden| = {err:.3e}")
+    assert err < 1e-3
+
+
+def test_cached_decode_equals_whole_sequence_pass(dev):
+    from vidsitu_amd.hf_gpt2_fseq import KVCacheState
+
+    z, w, n_head, m = _model_from_golden(GOLD[0], dev)
+    toks = torch.from_numpy(z["tokens"]).to(dev)  # no padding in generation
+    toks = toks.clamp(min=1)
+    full = m.forward_logits(toks, None)
+    st = KVCacheState()
+    for t in range(toks.shape[1]):
+        step = m.forward_step(toks[:, t].contiguous(), st, max_len=toks.shape[1])
+        assert float((step - full[:, t]).abs().max()) < 2e-4 * float(full.abs().max())
+
+
+def test_lm_loss_with_ignore_index(dev):
+    from vidsitu_amd.hf_gpt2_fseq import lm_loss
+
+    z, w, n_head, m = _model_from_golden(GOLD[1], dev)
+    pad = int(z["pad"])
+    toks, mask = torch.from_numpy(z["tokens"]).to(dev), torch.from_numpy(z["mask"]).to(dev)
+    logits = m.forward_logits(toks, mask)
+    got = float(lm_loss(logits, toks, pad))
+    want = gpt2_ref.lm_loss(gpt2_ref.forward(w, z["tokens"], z["mask"], n_head), z["tokens"], pad)
+    assert abs(got - want) < 1e-4 * max(1.0, abs(want)), (got, want)
+
+
+def test_beam_topk_kernel_rules(dev):
+    from vidsitu_amd import ops
+
+    rs = np.random.RandomState(0)
+    rows, V, k = 6, 1000, 10
+    pad, eos, unk = 999, 998, 5
+    x = rs.randn(rows, V).astype(np.float32) * 3
+    x[0, 17] = x[0, 400]            # an exact tie: lowest token first
+    x[1, 3] = np.nan                # NaN -> -inf
+    cum = rs.randn(rows).astype(np.float32)
+    cum[5] = -np.inf                # a dead beam: all -inf, indices 0,1,2,...
+    forced = np.array([-1, -1, 42, pad, -1, -1], dtype=np.int64)
+    for flags in (0, 1, 2):
+        lp = beam_ref.log_softmax(x / np.float32(0.7))
+        lp[lp != lp] = -np.inf
+        lp[:, pad] = -np.inf
+        lp[:, unk] -= 0.25
+        if flags & 1:
+            lp[:, :eos] = -np.inf
+            lp[:, eos + 1:] = -np.inf
+        for r in range(rows):
+            if forced[r] >= 0 and forced[r] != pad:
+                keep = lp[r, forced[r]]
+                lp[r] = -np.inf
+                lp[r, forced[r]] = keep
+            elif flags & 2:
+                lp[r, eos] = -np.inf
+        want_v, want_i = beam_ref.topk_lowest_index(lp + cum[:, None], k)
+        v, i = ops.beam_topk(torch.from_numpy(x).to(dev), torch.from_numpy(cum).to(dev),
+                             torch.from_numpy(forced).to(dev), k, pad, eos, unk, unk_penalty=0.25,
+                             temperature=0.7, eos_only=bool(flags & 1), ban_eos=bool(flags & 2))
+        assert np.array_equal(i.cpu().numpy(), want_i), f"flags {flags}"
+        fin = np.isfinite(want_v)
+        assert np.allclose(v.cpu().numpy()[fin], want_v[fin], atol=2e-5)
+        assert np.array_equal(np.isneginf(v.cpu().numpy()), np.isneginf(want_v))
+
+
+class _Tok:
+    def __init__(self, vocab, pad, eos, unk):
+        self.v, self._pad, self._eos, self._unk = vocab, pad, eos, unk
+        self.pad_token_id, self.eos_token_id = pad, eos
+
+    def __len__(self):
+        return self.v
+
+    def pad(self):
+        return self._pad
+
+    def eos(self):
+        return self._eos
+
+    def unk(self):
+        return self._unk
+
+
+class _LM(torch.nn.Module):
+    """Minimal model object of the `SeqGenCustom` contract around a GPT2LMHeadModelHip."""
+
+    def __init__(self, m, pad):
+        super().__init__()
+        from vidsitu_amd.hf_gpt2_fseq import HuggingFaceGPT2Decoder
+
+        self.use_encoder = False
+        dec = HuggingFaceGPT2Decoder.__new__(HuggingFaceGPT2Decoder)
+        torch.nn.Module.__init__(dec)
+        dec.model, dec.pad_idx = m, pad
+        self.decoder = dec
+
+    def max_decoder_positions(self):
+        return self.decoder.model.config.n_positions - 1
+
+    def forward_encoder(self, inp):
+        return None
+
+
+@pytest.mark.parametrize("beam,min_len,max_len_b,use_prefix,kv", [(1, 0, 6, True, True), (3, 1, 7, True, True),
+                                                                  (3, 1, 7, True, False), (4, 0, 5, False, True),
+                                                                  (5, 2, 9, True, True)])
+def test_beam_search_tokens_bit_exact_vs_oracle(beam, min_len, max_len_b, use_prefix, kv, dev):
+    from vidsitu_amd.seq_gen import SeqGenCustom
+
+    z, w, n_head, m = _model_from_golden(GOLD[0], dev)
+    vocab = int(z["dims"][0])
+    pad, eos, unk = vocab - 1, vocab - 2, vocab - 2
+    # make eos reasonably likely so that hypotheses finish at different steps
+    w = dict(w)
+    w["transformer.wte.weight"] = w["transformer.wte.weight"].copy()
+    w["transformer.wte.weight"][eos] *= 3.0
+    with torch.no_grad():
+        m.P("transformer.wte.weight")[eos] *= 3.0
+    bsz = 4
+    prefix = np.array([[5], [9], [5], [70]], dtype=np.int64) if use_prefix else None
+
+    def step_logits(tokens, sent_ids):
+        mask = (tokens != pad).astype(np.int64)
+        return gpt2_ref.forward(w, tokens, mask, n_head)[:, -1, :]
+
+    want = beam_ref.generate(step_logits, bsz=bsz, vocab=vocab, pad=pad, eos=eos, unk=unk,
+                             beam_size=beam, max_len_b=max_len_b, min_len=min_len,
+                             prefix_tokens=prefix, max_decoder_positions=int(z["dims"][1]) - 1)
+    gen = SeqGenCustom([_LM(m, pad)], _Tok(vocab, pad, eos, unk), beam_size=beam, max_len_b=max_len_b,
+                       min_len=min_len, use_kv_cache=kv)
+    sample = {"src_tokens": torch.zeros(bsz, 1, dtype=torch.long, device=dev),
+              "src_lengths": torch.ones(bsz, dtype=torch.long, device=dev)}
+    got = gen._generate(sample, prefix_tokens=None if prefix is None else torch.from_numpy(prefix).to(dev))
+    assert len(got) == bsz
+    for sent in range(bsz):
+        assert len(got[sent]) == len(want[sent]) == min(beam, vocab - 1)
+        for hg, hw in zip(got[sent], want[sent]):
+            assert hg["tokens"].tolist() == hw["tokens"].tolist(), f"sentence {sent}"
+            assert abs(float(hg["score"]) - hw["score"]) < 1e-4
+            assert np.allclose(hg["positional_scores"].cpu().numpy(), hw["positional_scores"], atol=1e-4)
+
+
+def test_simple_txdec_plugin_surface(dev):
+    """`get_mdl_loss_eval` rows `tx_only` / `sfpret_txe_txd_vbarg` with tx_dec_type gpt2: LM loss
+    forward, `forward_gen` through `EvalB_Gen` (cfg.gen), output tensor contract [B, E, 1, L]."""
+    from vidsitu_amd import synth_data
+    from vidsitu_amd.extended_config import get_cfg
+    from vidsitu_amd.mdl_selector import get_mdl_loss_eval
+
+    for name in ("tx_only", "sfpret_txe_txd_vbarg"):
+        cfg = get_cfg({"task_type": "vb_arg", "mdl.mdl_name": name, "mdl.tx_dec_type": "gpt2",
+                       "mdl.gpt2_mdl_name": "gpt2-synth-tiny", "synth.gpt2_vocab": 97,
+                       "gen.beam_size": 2, "gen.max_len_b": 8})
+        comm = synth_data.make_comm(cfg)
+        sel = get_mdl_loss_eval(cfg)
+        torch.manual_seed(0)
+        mdl = sel["mdl"](cfg=cfg, comm=comm).to(dev).eval()
+        batch = synth_data.synth_srl_batch(comm, bs=2, n_ev=5, seq_len=12, feat_dim=2304, device=dev)
+        out = mdl(batch)
+        assert tuple(out["logits"].shape) == (10, 12, 97) and torch.isfinite(out["loss"])
+        want = gpt2_ref.lm_loss(out["logits"].cpu().numpy(), batch["seq_out_by_ev"].view(10, 12).cpu().numpy(),
+                                comm.gpt2_hf_tok.pad_token_id)
+        assert abs(float(out["loss"]) - want) < 1e-4 * max(1.0, abs(want))
+        assert abs(float(sel["loss"](cfg, comm)(out, batch)["loss"]) - float(out["loss"])) == 0.0
+        res = sel["evl"](cfg, comm, dev).forward_one_batch(mdl, batch)
+        assert len(res) == 2 and set(res[0]["vb_output"]) == {f"Ev{i}" for i in range(1, 6)}
+        for r, b in zip(res, range(2)):
+            for e in range(5):
+                toks = r["vb_output"][f"Ev{e + 1}"]["tokens"]
+                assert toks[0] == int(batch["seq_out_by_ev"][b, e, 0, 0])  # forced first token
+                assert len(toks) <= 9

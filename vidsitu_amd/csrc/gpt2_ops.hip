@@ -1,0 +1,501 @@
+// GPT-2 decoder kernels (fp32, gfx950): the language model the reference decodes SRL
+// arguments with -- vidsitu_code/hf_gpt2_fseq.py:124-215 (huggingface GPT2LMHeadModel:
+// Conv1D projections, causal + key-padding attention, gelu_new MLP, tied lm_head) -- and the
+// per-step scoring of its beam search (vidsitu_code/seq_gen.py:310-385 + fairseq BeamSearch.step).
+// All arithmetic is fp32 like the reference (no AMP anywhere): dense projections
+// run on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, 157 TFLOP/s dense on MI355X) when there
+// are more than 64 rows and as weight-streaming dot products (txenc_ops.hip) below that.
+#include <math.h>
+
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ float gelu_new_f(float x) {
+  // transformers activations.gelu_new
+  return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+}
+
+// ----------------------------------------------------------------------------
+// y[M,N] = act(x[M,K] . w[N,K]^T + b) + res      ("NT": both operands K-contiguous)
+// 128x128x32 tile, 4 waves as 2x2, each wave a 64x64 block of four 32x32 MFMA accumulators.
+// LDS rows are K-major with an odd pitch (33 floats): the fragment read of a 32x32x2 MFMA
+// (lane l: row l&31, k = l>>5) is then conflict free.  Register-staged double buffer.
+// ----------------------------------------------------------------------------
+#define GM_BM 128
+#define GM_BN 128
+#define GM_BK 32
+#define GM_LD 33
+
+__global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ w,
+                                                          const float* __restrict__ bias,
+                                                          const float* res, float* y, int M, int N,
+                                                          int K, int act) {
+  __shared__ float As[2][GM_BM * GM_LD];
+  __shared__ float Bs[2][GM_BN * GM_LD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * GM_BM, n0 = blockIdx.x * GM_BN;
+  // loader mapping: 8 float4 per 32-float row, 32 rows per pass, 4 passes per operand
+  const int lc = tid & 7, lr = tid >> 3;
+  const bool kvec = (K & 3) == 0;
+  float4 ra[4], rb[4];
+
+  auto gload = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = lr + 32 * i, k = k0 + lc * 4;
+      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+      if (m0 + r < M && k < K) {
+        const float* s = x + (long long)(m0 + r) * K + k;
+        if (kvec) va = *(const float4*)s;
+        else { va.x = s[0]; if (k + 1 < K) va.y = s[1]; if (k + 2 < K) va.z = s[2]; if (k + 3 < K) va.w = s[3]; }
+      }
+      if (n0 + r < N && k < K) {
+        const float* s = w + (long long)(n0 + r) * K + k;
+        if (kvec) vb = *(const float4*)s;
+        else { vb.x = s[0]; if (k + 1 < K) vb.y = s[1]; if (k + 2 < K) vb.z = s[2]; if (k + 3 < K) vb.w = s[3]; }
+      }
+      ra[i] = va;
+      rb[i] = vb;
+    }
+  };
+  auto sstore = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float* a = &As[buf][(lr + 32 * i) * GM_LD + lc * 4];
+      float* b = &Bs[buf][(lr + 32 * i) * GM_LD + lc * 4];
+      a[0] = ra[i].x; a[1] = ra[i].y; a[2] = ra[i].z; a[3] = ra[i].w;
+      b[0] = rb[i].x; b[1] = rb[i].y; b[2] = rb[i].z; b[3] = rb[i].w;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  const int fr = lane & 31, fk = lane >> 5;
+  const int nk = (K + GM_BK - 1) / GM_BK;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload((kt + 1) * GM_BK);
+    const float* A = &As[cur][(wm * 64 + fr) * GM_LD + fk];
+    const float* B = &Bs[cur][(wn * 64 + fr) * GM_LD + fk];
+#pragma unroll
+    for (int ks = 0; ks < GM_BK; ks += 2) {
+      const float a0 = A[ks], a1 = A[32 * GM_LD + ks];
+      const float b0 = B[ks], b1 = B[32 * GM_LD + ks];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (kt + 1 < nk) sstore(cur ^ 1);
+    __syncthreads();
+  }
+  // D layout of 32x32x2: col = lane & 31, row = 8*(e/4) + 4*(lane>>5) + (e&3)
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int n = n0 + wn * 64 + b * 32 + (lane & 31);
+      if (n >= N) continue;
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + a * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+        if (m < M) {
+          float v = acc[a][b][e] + bv;
+          if (act == 1) v = fmaxf(v, 0.f);
+          else if (act == 2) v = gelu_new_f(v);
+          if (res) v += res[(long long)m * N + n];
+          y[(long long)m * N + n] = v;
+        }
+      }
+    }
+}
+
+int vs_gemm_nt_f32_mfma(const float* x, const float* w, const float* b, const float* res, float* y,
+                        int M, int N, int K, int act, hipStream_t st) {
+  hipLaunchKernelGGL(gemm_nt_f32_kernel, dim3((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM),
+                     dim3(256), 0, st, x, w, b, res, y, M, N, K, act);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// ----------------------------------------------------------------------------
+// h[r, l, :] = wte[tok[r, l]] + wpe[pos0 + l]      (GPT2Model: default position ids)
+// ----------------------------------------------------------------------------
+__global__ void gpt2_embed_kernel(const int64_t* tok, const float* wte, const float* wpe, float* out,
+                                  int rows, int L, int D, int pos0, int V) {
+  const int row = blockIdx.x;  // r * L + l
+  const int l = row % L;
+  long long t = tok[row];
+  if (t < 0 || t >= V) t = 0;  // never dereference outside the table
+  const float4* a = (const float4*)(wte + t * D);
+  const float4* p = (const float4*)(wpe + (long long)(pos0 + l) * D);
+  float4* o = (float4*)(out + (long long)row * D);
+  for (int i = threadIdx.x; i < D / 4; i += blockDim.x) {
+    const float4 u = a[i], v = p[i];
+    o[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+  }
+}
+
+extern "C" int vs_gpt2_embed(const int64_t* tokens, const float* wte, const float* wpe, float* out,
+                             int R, int L, int D, int pos0, int V, void* stream) {
+  VS_CHECK_ARG(tokens && wte && wpe && out && R > 0 && L > 0 && D % 4 == 0, "bad args");
+  hipLaunchKernelGGL(gpt2_embed_kernel, dim3(R * L), dim3(256), 0, (hipStream_t)stream, tokens, wte,
+                     wpe, out, R * L, L, D, pos0, V);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// ----------------------------------------------------------------------------
+// Causal self-attention over a fused qkv buffer [R, L, 3D] (c_attn output), modeling_gpt2
+// Attention._attn:  w = q k^T / sqrt(dh);  w = where(j <= i, w, -1e4);  w += (1-mask_j) * -1e4;
+// softmax over ALL j (the -1e4 entries underflow to exactly 0 unless a whole row is masked,
+// in which case the reference's behaviour is reproduced too);  out = p v, heads merged.
+// One block per (r, head): K and V of the head live in LDS (pitch dh+1), one wave per query.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_causal_kernel(const float* qkv, const uint8_t* kmask,
+                                                          float* out, int L, int H, int dh) {
+  extern __shared__ float sm[];
+  const int D = H * dh, ld = dh + 1;
+  const int r = blockIdx.x / H, h = blockIdx.x % H;
+  float* Ks = sm;
+  float* Vs = Ks + L * ld;
+  float* Ps = Vs + L * ld;   // [4][L]
+  float* Qs = Ps + 4 * L;    // [4][dh]
+  const float* base = qkv + (long long)r * L * 3 * D;
+  for (int i = threadIdx.x; i < L * dh; i += 256) {
+    const int j = i / dh, d = i - j * dh;
+    Ks[j * ld + d] = base[(long long)j * 3 * D + D + h * dh + d];
+    Vs[j * ld + d] = base[(long long)j * 3 * D + 2 * D + h * dh + d];
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float scale = 1.0f / sqrtf((float)dh);
+  float* P = Ps + wave * L;
+  float* Q = Qs + wave * dh;
+  for (int i = wave; i < L; i += 4) {
+    for (int d = lane; d < dh; d += 64) Q[d] = base[(long long)i * 3 * D + h * dh + d];
+    __builtin_amdgcn_wave_barrier();
+    float mx = -INFINITY;
+    for (int j = lane; j < L; j += 64) {
+      float s = 0.f;
+      for (int d = 0; d < dh; ++d) s += Q[d] * Ks[j * ld + d];
+      s *= scale;
+      if (j > i) s = -1e4f;
+      if (kmask && !kmask[(long long)r * L + j]) s += -1e4f;
+      P[j] = s;
+      mx = fmaxf(mx, s);
+    }
+    mx = wave_reduce_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < L; j += 64) {
+      const float e = expf(P[j] - mx);
+      P[j] = e;
+      sum += e;
+    }
+    sum = wave_reduce_sum(sum);
+    __builtin_amdgcn_wave_barrier();
+    const float inv = 1.0f / sum;
+    for (int d = lane; d < dh; d += 64) {
+      float o = 0.f;
+      for (int j = 0; j < L; ++j) o += P[j] * Vs[j * ld + d];
+      out[((long long)r * L + i) * D + h * dh + d] = o * inv;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+extern "C" int vs_attn_causal_fwd(const float* qkv, const uint8_t* key_mask, float* out, int R, int L,
+                                  int H, int dh, void* stream) {
+  VS_CHECK_ARG(qkv && out && R > 0 && L > 0 && H > 0 && dh > 0, "bad args");
+  const size_t smem = ((size_t)2 * L * (dh + 1) + 4 * L + 4 * dh) * sizeof(float);
+  VS_CHECK_ARG(smem <= 160 * 1024, "sequence too long for the LDS-resident attention (L*dh)");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)attn_causal_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(attn_causal_kernel, dim3(R * H), dim3(256), smem, (hipStream_t)stream, qkv,
+                     key_mask, out, L, H, dh);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// ----------------------------------------------------------------------------
+// Incremental decoding step with a KV cache [rows][H][Lmax][dh]: append this step's k, v at
+// position t, attend the single new query over positions 0..t (every cached key is causal-
+// visible; key_mask as above).  One wave per (row, head).
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void attn_decode_kernel(const float* qkv, float* kc, float* vc,
+                                                         const uint8_t* kmask, float* out, int H,
+                                                         int dh, int Lmax, int t) {
+  extern __shared__ float sm[];  // P[t+1] + Q[dh]
+  const int r = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
+  const int D = H * dh;
+  float* P = sm;
+  float* Q = sm + (t + 1);
+  float* kch = kc + ((long long)r * H + h) * Lmax * dh;
+  float* vch = vc + ((long long)r * H + h) * Lmax * dh;
+  const float* src = qkv + (long long)r * 3 * D;
+  for (int d = lane; d < dh; d += 64) {
+    Q[d] = src[h * dh + d];
+    kch[(long long)t * dh + d] = src[D + h * dh + d];
+    vch[(long long)t * dh + d] = src[2 * D + h * dh + d];
+  }
+  __syncthreads();  // one wave: orders the global writes above before the reads below
+  const float scale = 1.0f / sqrtf((float)dh);
+  float mx = -INFINITY;
+  for (int j = lane; j <= t; j += 64) {
+    float s = 0.f;
+    for (int d = 0; d < dh; ++d) s += Q[d] * kch[(long long)j * dh + d];
+    s *= scale;
+    if (kmask && !kmask[(long long)r * Lmax + j]) s += -1e4f;
+    P[j] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_reduce_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j <= t; j += 64) {
+    const float e = expf(P[j] - mx);
+    P[j] = e;
+    sum += e;
+  }
+  sum = wave_reduce_sum(sum);
+  __syncthreads();
+  const float inv = 1.0f / sum;
+  for (int d = lane; d < dh; d += 64) {
+    float o = 0.f;
+    for (int j = 0; j <= t; ++j) o += P[j] * vch[(long long)j * dh + d];
+    out[(long long)r * D + h * dh + d] = o * inv;
+  }
+}
+
+extern "C" int vs_attn_decode(const float* qkv, float* kcache, float* vcache, const uint8_t* key_mask,
+                              float* out, int rows, int H, int dh, int Lmax, int t, void* stream) {
+  VS_CHECK_ARG(qkv && kcache && vcache && out && rows > 0 && t >= 0 && t < Lmax, "bad args");
+  const size_t smem = (size_t)(t + 1 + dh) * sizeof(float);
+  VS_CHECK_ARG(smem <= 64 * 1024, "cache too long");
+  hipLaunchKernelGGL(attn_decode_kernel, dim3(rows * H), dim3(64), smem, (hipStream_t)stream, qkv,
+                     kcache, vcache, key_mask, out, H, dh, Lmax, t);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// Beam reorder of a KV cache: dst[r] = src[index[r]] for the first `len` positions of every head
+// (fairseq reorder_incremental_state; seq_gen.py:305-313).
+__global__ void kv_gather_kernel(const float* src, float* dst, const int64_t* index, int H, int dh,
+                                 int Lmax, int len) {
+  const int r = blockIdx.x / H, h = blockIdx.x % H;
+  const float4* s = (const float4*)(src + (((long long)index[r]) * H + h) * Lmax * dh);
+  float4* d = (float4*)(dst + ((long long)r * H + h) * Lmax * dh);
+  const int n4 = len * dh / 4;
+  for (int i = threadIdx.x; i < n4; i += blockDim.x) d[i] = s[i];
+}
+
+extern "C" int vs_kv_gather(const float* src, float* dst, const int64_t* index, int rows_out, int H,
+                            int dh, int Lmax, int len, void* stream) {
+  VS_CHECK_ARG(src && dst && index && rows_out > 0 && len >= 0 && len <= Lmax && dh % 4 == 0, "bad args");
+  if (len == 0) return VS_OK;
+  hipLaunchKernelGGL(kv_gather_kernel, dim3(rows_out * H), dim3(128), 0, (hipStream_t)stream, src,
+                     dst, index, H, dh, Lmax, len);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// ----------------------------------------------------------------------------
+// Beam-search scoring of one step (seq_gen.py:318-353 + EnsembleModel.forward_decoder :845-853
+// + fairseq BeamSearch.step):  lp = log_softmax(logits / T);  NaN -> -inf;  lp[pad] = -inf;
+// lp[unk] -= unk_penalty;  flags & 1: only eos allowed (step >= max_len);  flags & 2: eos banned
+// (step < min_len);  forced[r] >= 0: only that token keeps its score (prefix forcing);
+// then + cum[r] and the k best (value, token) of the row, descending, ties -> lowest token.
+// One block per row; every thread keeps its own top-k over a strided slice, merged through LDS.
+// ----------------------------------------------------------------------------
+#define BT_MAXK 32
+
+__device__ __forceinline__ bool bt_better(float v, int i, float w, int j) {
+  return v > w || (v == w && i < j);
+}
+
+__global__ __launch_bounds__(256) void beam_topk_kernel(const float* logits, const float* cum,
+                                                        const int64_t* forced, float* out_val,
+                                                        int64_t* out_idx, int V, int k, int pad,
+                                                        int eos, int unk, float unk_penalty,
+                                                        float inv_temp, int flags) {
+  __shared__ float red[256];
+  __shared__ float cv[256 * 4];
+  __shared__ int ci[256 * 4];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const float* x = logits + (long long)r * V;
+  float mx = -INFINITY;
+  for (int j = tid; j < V; j += 256) mx = fmaxf(mx, x[j] * inv_temp);
+  red[tid] = mx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+    __syncthreads();
+  }
+  mx = red[0];
+  __syncthreads();
+  float sum = 0.f;
+  for (int j = tid; j < V; j += 256) sum += expf(x[j] * inv_temp - mx);
+  red[tid] = sum;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  const float lse = mx + logf(red[0]);
+  const float add = cum ? cum[r] : 0.f;
+  const long long f = forced ? forced[r] : -1;
+  const bool force = f >= 0 && f != pad;
+
+  auto score = [&](int j) {
+    float lp = x[j] * inv_temp - lse;
+    if (lp != lp) lp = -INFINITY;
+    if (j == pad) lp = -INFINITY;
+    if (j == unk) lp -= unk_penalty;
+    if ((flags & 1) && j != eos) lp = -INFINITY;
+    if (force) {
+      if (j != (int)f) lp = -INFINITY;
+    } else if ((flags & 2) && j == eos) {
+      lp = -INFINITY;
+    }
+    return lp + add;
+  };
+  // k rounds of a block-wide argmax; each round every thread rescans its slice for its best
+  // candidate that is worse than the previous winner (value, index order) -- k <= 2*beam is small
+  float pv = INFINITY;
+  int pi = -1;
+  for (int round = 0; round < k; ++round) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = tid; j < V; j += 256) {
+      const float v = score(j);
+      // strictly after the previous winner in (value desc, index asc) order
+      const bool after = (v < pv) || (v == pv && j > pi);
+      if (after && bt_better(v, j, bv, bi)) {
+        bv = v;
+        bi = j;
+      }
+    }
+    cv[tid] = bv;
+    ci[tid] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s && bt_better(cv[tid + s], ci[tid + s], cv[tid], ci[tid])) {
+        cv[tid] = cv[tid + s];
+        ci[tid] = ci[tid + s];
+      }
+      __syncthreads();
+    }
+    pv = cv[0];
+    pi = ci[0];
+    if (tid == 0) {
+      out_val[(long long)r * k + round] = pv;
+      out_idx[(long long)r * k + round] = pi;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int vs_beam_topk(const float* logits, const float* cum, const int64_t* forced,
+                            float* out_val, int64_t* out_idx, int rows, int V, int k, int pad,
+                            int eos, int unk, float unk_penalty, float temperature, int flags,
+                            void* stream) {
+  VS_CHECK_ARG(logits && out_val && out_idx && rows > 0 && V > 1, "bad args");
+  VS_CHECK_ARG(k >= 1 && k <= BT_MAXK && k < V, "k must be in [1, 32] and < V");
+  VS_CHECK_ARG(temperature > 0.f, "temperature must be > 0");
+  hipLaunchKernelGGL(beam_topk_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, cum,
+                     forced, out_val, out_idx, V, k, pad, eos, unk, unk_penalty, 1.0f / temperature,
+                     flags);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// Token-level cross entropy with ignore_index (Simple_TxDec.forward, mdl_sf_base.py:660-664):
+// per row nll = logsumexp(x) - x[label]; rows with label == ignore contribute nothing.
+// out[0] = sum of nll, out[1] = number of counted rows (fixed-order single-block finish).
+__global__ __launch_bounds__(256) void xent_ignore_rows_kernel(const float* logits,
+                                                               const int64_t* labels, float* nll,
+                                                               int V, long long ld, int ignore) {
+  __shared__ float red[256];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const long long lb = labels[r];
+  if (lb == ignore) {
+    if (tid == 0) nll[r] = 0.f;
+    return;
+  }
+  const float* x = logits + (long long)r * ld;
+  float mx = -INFINITY;
+  for (int j = tid; j < V; j += 256) mx = fmaxf(mx, x[j]);
+  red[tid] = mx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+    __syncthreads();
+  }
+  mx = red[0];
+  __syncthreads();
+  float sum = 0.f;
+  for (int j = tid; j < V; j += 256) sum += expf(x[j] - mx);
+  red[tid] = sum;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0) nll[r] = mx + logf(red[0]) - x[lb];
+}
+
+__global__ __launch_bounds__(256) void xent_ignore_finish_kernel(const float* nll,
+                                                                 const int64_t* labels, float* out,
+                                                                 int rows, int ignore) {
+  __shared__ double rs[256];
+  __shared__ int rc[256];
+  double s = 0.0;
+  int c = 0;
+  for (int r = threadIdx.x; r < rows; r += 256)
+    if (labels[r] != ignore) {
+      s += (double)nll[r];
+      ++c;
+    }
+  rs[threadIdx.x] = s;
+  rc[threadIdx.x] = c;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st) {
+      rs[threadIdx.x] += rs[threadIdx.x + st];
+      rc[threadIdx.x] += rc[threadIdx.x + st];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = rc[0] > 0 ? (float)(rs[0] / rc[0]) : 0.f;
+    out[1] = (float)rc[0];
+  }
+}
+
+extern "C" int vs_xent_ignore(const float* logits, const int64_t* labels, float* nll_rows,
+                              float* loss_out, int rows, int V, int64_t ld, int ignore_index,
+                              void* stream) {
+  VS_CHECK_ARG(logits && labels && nll_rows && loss_out && rows > 0 && V > 0 && ld >= V, "bad args");
+  hipLaunchKernelGGL(xent_ignore_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits,
+                     labels, nll_rows, V, (long long)ld, ignore_index);
+  hipLaunchKernelGGL(xent_ignore_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, nll_rows,
+                     labels, loss_out, rows, ignore_index);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}

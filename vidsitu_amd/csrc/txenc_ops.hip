@@ -22,8 +22,9 @@
 template <int MT>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x,
                                                          const float* __restrict__ w,
-                                                         const float* __restrict__ b, float* y,
-                                                         int M, int N, int K, int relu) {
+                                                         const float* __restrict__ b,
+                                                         const float* res, float* y, int M, int N,
+                                                         int K, int act) {
   constexpr int KU = 4;
   __shared__ float4 xs[MT][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -88,31 +89,51 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
       float s = wave_reduce_sum(acc[m]);
       if (lane == 0 && mbase + m < M) {
         s += bias;
-        if (relu) s = fmaxf(s, 0.f);
+        if (act == 1) s = fmaxf(s, 0.f);
+        else if (act == 2)  // transformers gelu_new
+          s = 0.5f * s * (1.0f + tanhf(0.7978845608028654f * (s + 0.044715f * s * s * s)));
+        if (res) s += res[(long long)(mbase + m) * N + n];
         y[(long long)(mbase + m) * N + n] = s;
       }
     }
   }
 }
 
+static int linear_small_m(const float* x, const float* w, const float* b, const float* res, float* y,
+                          int M, int N, int K, int act, hipStream_t st) {
+  const int gx = (N + 3) / 4;
+  if (M <= 8)
+    hipLaunchKernelGGL(linear_fwd_kernel<8>, dim3(gx, 1), dim3(256), 0, st, x, w, b, res, y, M, N, K, act);
+  else if (M <= 16)
+    hipLaunchKernelGGL(linear_fwd_kernel<16>, dim3(gx, 1), dim3(256), 0, st, x, w, b, res, y, M, N, K, act);
+  else if (M <= 32)
+    hipLaunchKernelGGL(linear_fwd_kernel<32>, dim3(gx, 1), dim3(256), 0, st, x, w, b, res, y, M, N, K, act);
+  else if (M <= 48)
+    hipLaunchKernelGGL(linear_fwd_kernel<48>, dim3(gx, 1), dim3(256), 0, st, x, w, b, res, y, M, N, K, act);
+  else
+    hipLaunchKernelGGL(linear_fwd_kernel<64>, dim3(gx, (M + 63) / 64), dim3(256), 0, st, x, w, b, res,
+                       y, M, N, K, act);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
 extern "C" int vs_linear_fwd(const float* x, const float* w, const float* b, float* y, int M,
                              int N, int K, int relu, void* stream) {
   VS_CHECK_ARG(x && w && y && M > 0 && N > 0 && K > 0, "bad args");
-  hipStream_t st = (hipStream_t)stream;
-  const int gx = (N + 3) / 4;
-  if (M <= 8)
-    hipLaunchKernelGGL(linear_fwd_kernel<8>, dim3(gx, 1), dim3(256), 0, st, x, w, b, y, M, N, K, relu);
-  else if (M <= 16)
-    hipLaunchKernelGGL(linear_fwd_kernel<16>, dim3(gx, 1), dim3(256), 0, st, x, w, b, y, M, N, K, relu);
-  else if (M <= 32)
-    hipLaunchKernelGGL(linear_fwd_kernel<32>, dim3(gx, 1), dim3(256), 0, st, x, w, b, y, M, N, K, relu);
-  else if (M <= 48)
-    hipLaunchKernelGGL(linear_fwd_kernel<48>, dim3(gx, 1), dim3(256), 0, st, x, w, b, y, M, N, K, relu);
-  else
-    hipLaunchKernelGGL(linear_fwd_kernel<64>, dim3(gx, (M + 63) / 64), dim3(256), 0, st, x, w, b, y,
-                       M, N, K, relu);
-  VS_CHECK_LAUNCH();
-  return VS_OK;
+  return linear_small_m(x, w, b, nullptr, y, M, N, K, relu ? 1 : 0, (hipStream_t)stream);
+}
+
+// y = act(x . w^T + b) + res, act 0 none / 1 relu / 2 gelu_new.  Up to 64 rows every weight row is
+// streamed exactly once by one wave (HBM-bound decode steps); above that the fp32 matrix cores.
+int vs_gemm_nt_f32_mfma(const float* x, const float* w, const float* b, const float* res, float* y,
+                        int M, int N, int K, int act, hipStream_t st);
+
+extern "C" int vs_gemm_nt_f32(const float* x, const float* w, const float* b, const float* res,
+                              float* y, int M, int N, int K, int act, void* stream) {
+  VS_CHECK_ARG(x && w && y && M > 0 && N > 0 && K > 0, "bad args");
+  VS_CHECK_ARG(act >= 0 && act <= 2, "act must be 0 (none), 1 (relu) or 2 (gelu_new)");
+  if (M <= 64) return linear_small_m(x, w, b, res, y, M, N, K, act, (hipStream_t)stream);
+  return vs_gemm_nt_f32_mfma(x, w, b, res, y, M, N, K, act, (hipStream_t)stream);
 }
 
 // dx[M,K] = dy[M,N] @ W[N,K] is the forward kernel on the transposed weight

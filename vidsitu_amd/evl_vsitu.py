@@ -57,3 +57,33 @@ class EvalB(nn.Module):
             c5 += int(hit.any(dim=1).sum())
         return ({"loss": loss_sum / max(nb, 1)},
                 {"Per_Ev_Top_1": c1 / max(n, 1), "Per_Ev_Top_5": c5 / max(n, 1)})
+
+
+class EvalB_Gen(EvalB):
+    """`EvalB_Gen.forward_one_batch` (`vidsitu_code/evl_vsitu.py:159-214`): build a `SeqGenCustom`
+    from `cfg.gen`, generate one SRL token sequence per event and decode it with the tokenizer.
+    The SRL string parsing / caption metrics (cider, rouge, lea: external java + python packages)
+    are out of scope; the integer token sequences -- the bit-exact part -- are returned."""
+
+    def __init__(self, cfg, comm, device=None):
+        super().__init__(cfg, comm, device)
+        self.met_keys = ["cider", "rouge", "lea", "MacroVb_cider", "MacroArg_cider"]
+        self.compute_loss = False
+
+    @torch.no_grad()
+    def forward_one_batch(self, mdl, inp):
+        from .seq_gen import SeqGenCustom
+
+        gen_kw = {k: self.cfg.gen[k] for k in self.cfg.gen}
+        seq_gen = SeqGenCustom([mdl], tgt_dict=self.comm.gpt2_hf_tok, **gen_kw)
+        out_sents = mdl.forward_gen(inp, seq_gen)  # [B, num_ev, 1, L] token ids, pad-filled
+        wvoc = self.comm.gpt2_hf_tok
+        out = []
+        for pred_sent, ann_idx in zip(out_sents.tolist(), inp["vseg_idx"].tolist()):
+            vb_output = {}
+            for ev_ix, ev_sent in enumerate(pred_sent):
+                assert len(ev_sent) == 1
+                vb_output[f"Ev{ev_ix + 1}"] = {"tokens": ev_sent[0],
+                                              "text": wvoc.decode(ev_sent[0], skip_special_tokens=True)}
+            out.append({"ann_idx": ann_idx, "vb_output": vb_output})
+        return out

@@ -4,8 +4,8 @@ Mirrors `vidsitu_code/mdl_selector.py:26-73` for the rows of the hot path; names
 outside it raise NotImplementedError exactly like an unknown name does upstream
 (:46,71,73).
 """
-from .mdl_sf_base import SFBase, SFBase_TxEnc, LossB, LossLambda, SFPreFeats_TxEncDec
-from .evl_vsitu import EvalB
+from .mdl_sf_base import SFBase, SFBase_TxEnc, LossB, LossLambda, SFPreFeats_TxEncDec, Simple_TxDec
+from .evl_vsitu import EvalB, EvalB_Gen
 
 
 def get_mdl_loss_eval(cfg):
@@ -17,8 +17,10 @@ def get_mdl_loss_eval(cfg):
             return {"mdl": SFBase_TxEnc, "loss": LossB, "evl": EvalB}
         raise NotImplementedError
     elif cfg.task_type == "vb_arg":
+        if cfg.mdl.mdl_name == "tx_only":
+            return {"mdl": Simple_TxDec, "loss": LossLambda, "evl": EvalB_Gen}
         if cfg.mdl.mdl_name == "sfpret_txe_txd_vbarg":
-            return {"mdl": SFPreFeats_TxEncDec, "loss": LossLambda, "evl": EvalB}
+            return {"mdl": SFPreFeats_TxEncDec, "loss": LossLambda, "evl": EvalB_Gen}
         raise NotImplementedError
     else:
         raise NotImplementedError

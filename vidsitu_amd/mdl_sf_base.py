@@ -1,8 +1,9 @@
 """Host-side mirror of `vidsitu_code/mdl_sf_base.py` for the hot path, on the HIP
 kernels: `SlowFast_FeatModel` / `ResNet_FeatModel` (:20-62), `ResNetBasicHead_Trimmed`
 (:65-113), `SFBase` (:116-216), `LossB` (:219-231), `LossLambda` (:234-243),
-`TxEncoderNew` / `TxEncoder()` (:341-432), `get_head_dim` (:751-760) and the
-encoder half of `SFPreFeats_TxEncDec` (:793-832).
+`TxEncoderNew` / `TxEncoder()` (:341-432), `GPT2_hf_fseqDec` / `TxDecoder()` (:449-464),
+`Simple_TxDec` (:595-675), `Reorderer` (:694-748), `get_head_dim` (:751-760) and
+`SFPreFeats_TxEncDec` (:793-832).
 
 Same constructor contracts (`mdl(cfg=cfg, comm=comm)`, `loss(cfg, comm)`), same
 attribute names (`sf_mdl`, `head`, `proj_head`, `vid_feat_encoder`,
@@ -21,6 +22,7 @@ from torch import nn
 from . import ops
 from .trunk import VideoTrunk
 from .transformer_code import Transformer as TxCodeEnc, LinearFn
+from .hf_gpt2_fseq import HuggingFaceGPT2Decoder, lm_loss as gpt2_lm_loss
 
 EncoderOut = namedtuple(
     "EncoderOut",
@@ -244,16 +246,118 @@ def get_head_dim(full_cfg) -> int:
     raise NotImplementedError
 
 
-class SFPreFeats_TxEncDec(nn.Module):
-    """Encoder half (mdl_sf_base.py:793-832): pre-extracted [B,5,2304] features ->
-    vid_feat_encoder -> TxEncoderNew -> EncoderOut [1, 5B, 1024].  The fairseq / GPT-2
-    decoder half is SURVEY.md section 8(f) rows f2/f3 (not built yet)."""
+class GPT2_hf_fseqDec(HuggingFaceGPT2Decoder):
+    """mdl_sf_base.py:449-455."""
 
-    def __init__(self, cfg, comm, head_dim=None):
+    def __init__(self, cfg, comm):
+        self.full_cfg = cfg
+        self.comm = comm
+        super().__init__(cfg, comm.gpt2_hf_tok)
+
+
+def TxDecoder(full_cfg, comm):
+    """mdl_sf_base.py:458-464."""
+    if full_cfg.mdl.tx_dec_type == "gpt2":
+        return GPT2_hf_fseqDec(full_cfg, comm)
+    # "txdec" = fairseq TransformerDecoder with cross-attention (SURVEY.md section 8f row f3)
+    raise NotImplementedError(f"tx_dec_type={full_cfg.mdl.tx_dec_type} is outside the hot path")
+
+
+class Simple_TxDec(nn.Module):
+    """mdl_sf_base.py:595-675: teacher-forced LM loss over the SRL token sequence of every event
+    (first annotation only) and beam-search generation from its first token.  Inference and the
+    loss forward run on the HIP kernels; the decoder's backward is not built (round >= 2)."""
+
+    def __init__(self, cfg, comm):
         super().__init__()
         self.full_cfg = cfg
         self.cfg = cfg.mdl
+        self.sf_cfg = cfg.sf_mdl
         self.comm = comm
+        self.use_encoder = False
+        self.build_model()
+
+    def build_model(self):
+        self.decoder = TxDecoder(self.full_cfg, self.comm)
+        self.pad_index = self.comm.gpt2_hf_tok.pad_token_id
+        self.bos_index = self.comm.gpt2_hf_tok.eos_token_id
+        self.max_decoder_positions = lambda: 1024
+
+    def forward_encoder(self, inp):
+        return None
+
+    def prepare_prev_toks_inp(self, inp):
+        dst_toks1 = inp["seq_out_by_ev"][:, :, [0], :]
+        dst_attn1 = inp["seq_out_lens_by_ev"][:, :, [0], :]
+        vb_toks1 = inp["vb_out_by_ev"][:, :, [0], :]
+        B, num_ev, num_seq_eg, seq_len = dst_toks1.shape
+        assert num_seq_eg == 1
+        dst_toks = dst_toks1.reshape(B * num_ev, num_seq_eg * seq_len)
+        dst_attn_mask = dst_attn1.reshape(B * num_ev, num_seq_eg * seq_len)
+        dst_lens = dst_attn_mask.sum(dim=-1)
+        vb_toks = vb_toks1.reshape(B * num_ev, num_seq_eg * vb_toks1.size(-1))
+        return {"dst_toks": dst_toks, "dst_lens": dst_lens, "vb_only_tokens": vb_toks}
+
+    def forward_decoder(self, prev_tokens, encoder_out, incremental_state=None, temperature=None):
+        if isinstance(encoder_out, list) and len(encoder_out) == 0:
+            encoder_out = None
+        return self.decoder(prev_tokens, encoder_out=encoder_out, incremental_state=incremental_state)
+
+    def forward(self, inp):
+        inp_prep = self.prepare_prev_toks_inp(inp)
+        encoder_out = self.forward_encoder(inp)
+        prev_tokens = inp_prep["dst_toks"]
+        logits = self.forward_decoder(prev_tokens=prev_tokens, encoder_out=encoder_out)[0]
+        loss = gpt2_lm_loss(logits, prev_tokens, self.pad_index)
+        return {"loss": loss, "logits": logits}
+
+    def forward_gen(self, inp, seq_gen):
+        inp_prep = self.prepare_prev_toks_inp(inp)
+        inp["src_tokens"] = inp_prep["dst_toks"][..., :1]
+        inp["src_lengths"] = inp_prep["dst_lens"]
+        inp_ids = inp_prep["dst_toks"][..., :1]
+        out_sents = seq_gen._generate(inp, prefix_tokens=inp_ids)
+        B, num_ev, num_seq_eg, seq_len = inp["seq_out_by_ev"][:, :, [0], :].shape
+        max_len = max(len(o[0]["tokens"]) for o in out_sents)
+        B1 = inp_ids.size(0)
+        out_sents_tensor = inp_ids.new_full((B1, max_len), self.pad_index)
+        for ix in range(B1):
+            xtoks = out_sents[ix][0]["tokens"]
+            out_sents_tensor[ix, : len(xtoks)] = xtoks
+        return out_sents_tensor.view(B, num_ev, num_seq_eg, -1)
+
+
+class Reorderer:
+    """mdl_sf_base.py:694-748: beam reorder of an EncoderOut (T x B x C tensors along dim 1)."""
+
+    def reorder_encoder_out(self, encoder_out, new_order):
+        sel = lambda t, d: t if t is None else t.index_select(d, new_order)
+        states = encoder_out.encoder_states
+        if states is not None:
+            states = [st.index_select(1, new_order) for st in states]
+        return EncoderOut(encoder_out=sel(encoder_out.encoder_out, 1),
+                          encoder_padding_mask=sel(encoder_out.encoder_padding_mask, 0),
+                          encoder_embedding=sel(encoder_out.encoder_embedding, 0),
+                          encoder_states=states, src_tokens=sel(encoder_out.src_tokens, 0),
+                          src_lengths=sel(encoder_out.src_lengths, 0))
+
+
+class SFPreFeats_TxEncDec(Simple_TxDec, Reorderer):
+    """mdl_sf_base.py:793-832: pre-extracted [B,5,2304] features -> vid_feat_encoder ->
+    TxEncoderNew -> EncoderOut [1, 5B, 1024] (each event is its own one-token memory) -> decoder
+    (`Simple_TxDec.forward` / `forward_gen`)."""
+
+    def __init__(self, cfg, comm, head_dim=None):
+        self._head_dim = head_dim
+        super().__init__(cfg, comm)
+
+    def build_model(self):
+        if self.full_cfg.mdl.tx_dec_type == "gpt2":
+            super().build_model()
+        else:  # encoder half only (the fairseq decoder is row f3)
+            self.decoder = None
+            self.pad_index = self.bos_index = None
+        head_dim = self._head_dim
         if head_dim is None:  # the reference derives it from the feature directory's name
             head_dim = get_head_dim(self.full_cfg)
         self.vid_feat_encoder = HipMLP(nn.Linear(head_dim, 1024), nn.ReLU(), nn.Linear(1024, 1024))
@@ -274,7 +378,9 @@ class SFPreFeats_TxEncDec(nn.Module):
                           encoder_states=None, src_tokens=None, src_lengths=None)
 
     def forward(self, inp):
-        raise NotImplementedError("decoder half: SURVEY.md section 8(f) f2/f3")
+        if self.decoder is None:
+            raise NotImplementedError("fairseq TransformerDecoder: SURVEY.md section 8(f) f3")
+        return super().forward(inp)
 
 
 class SFBase_TxEnc(SFBase):

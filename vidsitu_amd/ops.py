@@ -551,3 +551,83 @@ def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, step_counter, grad_scale=1.
 
 def cast_bf16(src_f32, dst_bf16):
     _lib.call("vs_cast_f32_to_bf16", _ptr(src_f32), _ptr(dst_bf16), src_f32.numel(), _stream())
+
+
+# ----------------------------------------------------------------------------
+# GPT-2 decoder + beam-search scoring (csrc/gpt2_ops.hip)
+# ----------------------------------------------------------------------------
+ACT_NONE, ACT_RELU, ACT_GELU_NEW = 0, 1, 2
+
+
+def gemm_nt(x, w, b=None, res=None, act=ACT_NONE, out=None):
+    """act(x[M,K] @ w[N,K]^T + b) + res, fp32."""
+    x, w = _f32c(x), _f32c(w)
+    m, k = x.shape
+    n = w.shape[0]
+    if w.shape[1] != k:
+        raise _lib.VsError(f"gemm_nt: K mismatch {tuple(x.shape)} x {tuple(w.shape)}")
+    y = torch.empty((m, n), dtype=torch.float32, device=x.device) if out is None else out
+    _lib.call("vs_gemm_nt_f32", _ptr(x), _ptr(w), _ptr(b), _ptr(res), _ptr(y), m, n, k, int(act),
+              _stream())
+    return y
+
+
+def gpt2_embed(tokens, wte, wpe, pos0=0):
+    """tokens i64 [R, L] -> f32 [R*L, D] = wte[tok] + wpe[pos0 + l]."""
+    tokens = tokens.contiguous()
+    r, l = tokens.shape
+    if pos0 + l > wpe.shape[0]:
+        raise _lib.VsError(f"gpt2_embed: position {pos0 + l} beyond n_positions {wpe.shape[0]}")
+    out = torch.empty((r * l, wte.shape[1]), dtype=torch.float32, device=wte.device)
+    _lib.call("vs_gpt2_embed", _ptr(tokens), _ptr(wte), _ptr(wpe), _ptr(out), r, l, wte.shape[1],
+              int(pos0), wte.shape[0], _stream())
+    return out
+
+
+def attn_causal(qkv, key_mask, r, l, n_head):
+    """qkv f32 [R*L, 3D]; key_mask uint8 [R, L] or None -> f32 [R*L, D]."""
+    d = qkv.shape[1] // 3
+    out = torch.empty((r * l, d), dtype=torch.float32, device=qkv.device)
+    _lib.call("vs_attn_causal_fwd", _ptr(qkv), _ptr(key_mask), _ptr(out), r, l, n_head, d // n_head,
+              _stream())
+    return out
+
+
+def attn_decode(qkv, kcache, vcache, key_mask, t):
+    """qkv f32 [rows, 3D]; caches f32 [rows, H, Lmax, dh] (updated in place at position t)."""
+    rows, h, lmax, dh = kcache.shape
+    out = torch.empty((rows, h * dh), dtype=torch.float32, device=qkv.device)
+    _lib.call("vs_attn_decode", _ptr(qkv), _ptr(kcache), _ptr(vcache), _ptr(key_mask), _ptr(out), rows,
+              h, dh, lmax, int(t), _stream())
+    return out
+
+
+def kv_gather(src, dst, index, length):
+    rows_out = index.numel()
+    _, h, lmax, dh = src.shape
+    _lib.call("vs_kv_gather", _ptr(src), _ptr(dst), _ptr(index.contiguous()), rows_out, h, dh, lmax,
+              int(length), _stream())
+
+
+def beam_topk(logits, cum, forced, k, pad, eos, unk, unk_penalty=0.0, temperature=1.0,
+              eos_only=False, ban_eos=False):
+    logits = _f32c(logits)
+    rows, v = logits.shape
+    val = torch.empty((rows, k), dtype=torch.float32, device=logits.device)
+    idx = torch.empty((rows, k), dtype=torch.int64, device=logits.device)
+    flags = (1 if eos_only else 0) | (2 if ban_eos else 0)
+    _lib.call("vs_beam_topk", _ptr(logits), _ptr(cum), _ptr(forced), _ptr(val), _ptr(idx), rows, v,
+              int(k), int(pad), int(eos), int(unk), float(unk_penalty), float(temperature), flags,
+              _stream())
+    return val, idx
+
+
+def xent_ignore(logits, labels, ignore_index):
+    """Mean CE over rows whose label != ignore_index -> (loss 0-dim, count)."""
+    logits = _f32c(logits)
+    rows, v = logits.shape
+    nll = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    out = torch.empty(2, dtype=torch.float32, device=logits.device)
+    _lib.call("vs_xent_ignore", _ptr(logits), _ptr(labels.contiguous()), _ptr(nll), _ptr(out), rows, v,
+              v, int(ignore_index), _stream())
+    return out[0], out[1]

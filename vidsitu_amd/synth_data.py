@@ -30,13 +30,68 @@ def slow_index(t, alpha):
     return torch.linspace(0, t - 1, t // alpha).long()
 
 
+class SynthGPT2Tok:
+    """Stand-in for `comm.gpt2_hf_tok` (`dat_loader.py:87`: a GPT2TokenizerFast with added pad /
+    SRL tokens): the members the decoder path uses -- `len()`, `pad()/eos()/unk()` (fairseq
+    dictionary style, `hf_gpt2_fseq.py:155`, `seq_gen.py:81-83`), `pad_token_id`, `eos_token_id`,
+    `decode`.  Token ids: eos = vocab-2 (GPT-2's <|endoftext|> is the last base token), pad =
+    vocab-1 (the added token)."""
+
+    def __init__(self, vocab_size):
+        self.vocab_size = vocab_size
+        self.eos_token_id = vocab_size - 2
+        self.pad_token_id = vocab_size - 1
+        self.unk_token_id = self.eos_token_id  # GPT-2: unk_token == eos_token
+
+    def __len__(self):
+        return self.vocab_size
+
+    def pad(self):
+        return self.pad_token_id
+
+    def eos(self):
+        return self.eos_token_id
+
+    def unk(self):
+        return self.unk_token_id
+
+    def decode(self, ids, skip_special_tokens=True):
+        special = {self.pad_token_id, self.eos_token_id} if skip_special_tokens else set()
+        return " ".join(f"t{int(i)}" for i in ids if int(i) not in special)
+
+
 def make_comm(cfg):
     sf = cfg.sf_mdl
     arch = sf.MODEL.ARCH
     path_type = "multi" if arch in sf.MODEL.MULTI_PATHWAY_ARCH else "single"
     nv = cfg.synth.num_verbs if "synth" in cfg else 1564
+    ntok = cfg.synth.gpt2_vocab if ("synth" in cfg and "gpt2_vocab" in cfg.synth) else 50259
     return SimpleNamespace(path_type=path_type, vb_id_vocab=[f"verb_{i}" for i in range(nv)],
-                           num_frms=sf.DATA.NUM_FRAMES, sampling_rate=sf.DATA.SAMPLING_RATE)
+                           num_frms=sf.DATA.NUM_FRAMES, sampling_rate=sf.DATA.SAMPLING_RATE,
+                           gpt2_hf_tok=SynthGPT2Tok(ntok))
+
+
+def synth_srl_batch(comm, bs, n_ev=5, n_ann=1, seq_len=60, feat_dim=2304, seed=1234, device="cpu"):
+    """Batch of the vb_arg contract (`dat_loader.py:220-452,503-511`): `seq_out_by_ev`
+    i64 [B,E,n_ann,60] right-padded SRL token ids, `seq_out_lens_by_ev` {0,1} mask of the same
+    shape, `vb_out_by_ev` i64 [B,E,n_ann,5], `frm_feats` f32 [B,E,feat_dim], `vseg_idx`."""
+    tok = comm.gpt2_hf_tok
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    seq = torch.full((bs, n_ev, n_ann, seq_len), tok.pad_token_id, dtype=torch.long)
+    mask = torch.zeros((bs, n_ev, n_ann, seq_len), dtype=torch.long)
+    for b in range(bs):
+        for e in range(n_ev):
+            for a in range(n_ann):
+                n = int(torch.randint(4, max(5, seq_len * 2 // 3), (1,), generator=g))
+                seq[b, e, a, :n] = torch.randint(0, len(tok) - 2, (n,), generator=g)
+                seq[b, e, a, n] = tok.eos_token_id
+                mask[b, e, a, : n + 1] = 1
+    return {
+        "seq_out_by_ev": seq.to(device), "seq_out_lens_by_ev": mask.to(device),
+        "vb_out_by_ev": seq[..., :5].contiguous().to(device),
+        "frm_feats": torch.randn(bs, n_ev, feat_dim, generator=g).to(device),
+        "vseg_idx": torch.arange(bs, dtype=torch.long, device=device),
+    }
 
 
 def synth_batch(cfg, comm, bs, n_ev=5, seed=1234, device="cpu", dtype=torch.float32,
