@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--workload", default=os.environ.get("VS_BENCH_WORKLOAD", "sf_txenc_train"),
                     choices=["feat_fwd", "sf_txenc_train"])
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a hipGraph")
+    ap.add_argument("--overlap", type=int, default=-1,
+                    help="train: split the step into segment graphs and all-reduce finished gradient "
+                         "buckets behind the remaining backward (default: on when WORLD_SIZE > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -220,10 +223,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    # VS_BENCH_FORCE_DIST=1: initialise RCCL even for one rank (exercises the distributed step on
+    # a single-GPU box)
+    if world > 1 or os.environ.get("VS_BENCH_FORCE_DIST") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
@@ -248,20 +255,56 @@ def main():
     batch = synth_data.synth_batch(cfg, comm, bs=CLIPS_PER_GPU // 4, n_ev=4, seed=1234 + rank,
                                    device=dev, dtype=torch.bfloat16)
 
+    dist_on = world > 1 or (dist.is_available() and dist.is_initialized())
+    comm = {"on": dist_on}  # the rank-0-only instrumented pass must not enter a collective
+    overlap = train and (args.overlap == 1 or (args.overlap < 0 and world > 1))
+    segments = None
     if train:
         mdl.train()
         arena = ParamArena(mdl)
         arena.broadcast_params(0)
         opt = ArenaAdam(arena, lr=cfg.train.lr, betas=(0.9, 0.99))
 
-        def step():
+        def fwd_bwd():
             opt.zero_grad()
             out = mdl(batch)
             loss = loss_fn(out, batch)["loss"]
             loss.backward()
-            w = arena.all_reduce()
-            opt.step(world=w)
             return loss
+
+        if overlap:
+            # Segment s: [python callable, gradient bucket that is complete after it].  The trunk's
+            # manual backward is deferred out of autograd and run stage group by stage group; the
+            # bucket of a finished group is all-reduced (RCCL, async on its own stream) while the
+            # next group computes.  Arena order = registration order: s1..s3 | s4 | s5 | heads+TxEnc.
+            trunk = mdl.sf_mdl
+            trunk.defer_backward = True
+            segs = list(trunk.BWD_SEGMENTS)
+            ranges = arena.bucket_ranges([trunk.backward_segment_modules(sg) for sg in segs])
+            segments = [(fwd_bwd, ranges[-1])]  # everything outside the trunk is done after autograd
+            for sg, rg in zip(segs, ranges[:-1]):
+                segments.append((lambda sg=sg: trunk.run_backward_segment(sg), rg))
+
+            def step():
+                works = []
+                out = None
+                for fn, (lo, hi) in segments:
+                    r = fn()
+                    out = r if out is None else out
+                    if comm["on"]:
+                        works.append(arena.all_reduce_range(lo, hi, async_op=True))
+                for w in works:
+                    if w is not None:
+                        w.wait()
+                opt.step(world=world)
+                return out
+        else:
+            def step():
+                loss = fwd_bwd()
+                if comm["on"]:
+                    arena.all_reduce()
+                opt.step(world=world)
+                return loss
     else:
         mdl.eval()
 
@@ -279,7 +322,26 @@ def main():
             out = step()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    if args.graph and not (train and world > 1):
+    seg_graphs = None
+    if args.graph and segments is not None:
+        # one hipGraph per segment + one for Adam; the RCCL calls stay outside the graphs
+        try:
+            seg_graphs, pool = [], None
+            for fn, _ in segments + [(lambda: opt.step(world=world), None)]:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    fn()
+                pool = g.pool()
+                seg_graphs.append(g)
+            torch.cuda.synchronize()
+            used_graph = True
+        except Exception as e:
+            if rank == 0:
+                print(f"[bench] segmented hipGraph capture failed, running eagerly: {e!r}", file=sys.stderr)
+            seg_graphs = None
+            mdl.sf_mdl._deferred = None
+            torch.cuda.synchronize()
+    elif args.graph and not (train and dist_on):
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
@@ -293,8 +355,21 @@ def main():
             graph = None
             torch.cuda.synchronize()
 
+    def run_segmented():
+        works = []
+        for g, (_, (lo, hi)) in zip(seg_graphs[:-1], segments):
+            g.replay()
+            if dist_on:
+                works.append(arena.all_reduce_range(lo, hi, async_op=True))
+        for w in works:
+            if w is not None:
+                w.wait()
+        seg_graphs[-1].replay()
+
     def run_once():
-        if graph is not None:
+        if seg_graphs is not None:
+            run_segmented()
+        elif graph is not None:
             graph.replay()
         else:
             step()
@@ -321,10 +396,12 @@ def main():
 
     roof = None
     if rank == 0 and not args.no_roofline:
+        comm["on"] = False
         t0 = time.perf_counter()
         step()
         torch.cuda.synchronize()
         eager_ms = (time.perf_counter() - t0) * 1e3  # CPU time to enqueue one eager step
+        comm["on"] = False
         probe = EntryProbe()
         probe.install()
         reps = 3
@@ -394,13 +471,17 @@ def main():
                                     "BASELINE configs[1]: SlowFast-R50 feature extractor only, eval, "
                                     "8 clips x 3x32x224x224 per GPU"),
                        "clips_per_gpu": CLIPS_PER_GPU, "hipgraph": used_graph,
+                       "grad_allreduce": ("bucketed, overlapped with backward (4 segment graphs)"
+                                          if segments is not None else
+                                          ("single" if train else None)),
                        "model_tflops": round(value * flop_per_clip / 1e3, 2),
                        "frac_of_bf16_mfma_peak": round(value * flop_per_clip / 1e3 / world /
                                                        PEAK_BF16_TFLOPS, 4)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()  # rank 0 is still in its instrumented pass / CPU baseline: leave together
         dist.destroy_process_group()
 
 

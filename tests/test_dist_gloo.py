@@ -71,6 +71,17 @@ def _worker(rank, world, port, ret):
     gathered = [torch.empty_like(out) for _ in range(world)]
     dist.all_gather(gathered, out)
     assert all(torch.equal(gathered[0], g) for g in gathered), "ranks diverged"
+    # bucketed, asynchronous all-reduce (bench.py's overlapped step) == the single all-reduce
+    ranges = arena.bucket_ranges([[model.fc]])  # -> [fc bucket, everything else]
+    assert sorted(ranges) == [(0, arena.offsets[1]), (arena.offsets[1], arena.numel)]
+    g = torch.Generator().manual_seed(7 + rank)
+    arena.grad.copy_(torch.randn(arena.numel, generator=g))
+    want = arena.grad.clone()
+    dist.all_reduce(want)
+    works = [arena.all_reduce_range(lo, hi, async_op=True) for lo, hi in ranges]
+    for wk in works:
+        wk.wait()
+    assert torch.equal(arena.grad, want)
     dist.destroy_process_group()
 
 

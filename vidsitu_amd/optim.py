@@ -96,6 +96,39 @@ class ParamArena:
             return dist.get_world_size()
         return 1
 
+    def bucket_ranges(self, module_groups):
+        """[start, end) element ranges of the arena covered by each group of modules (gradient
+        buckets for an all-reduce that overlaps the rest of the backward); parameters that belong
+        to no group form a final bucket.  Ranges must be contiguous in the arena (parameter
+        registration order) or ValueError is raised."""
+        owner = {}
+        for gi, mods in enumerate(module_groups):
+            for m in mods:
+                for p in m.parameters():
+                    owner[id(p)] = gi
+        spans = {}
+        for p, off, end in zip(self.params, self.offsets, self.offsets[1:]):
+            gi = owner.get(id(p), len(module_groups))
+            lo, hi, n = spans.get(gi, (off, off, 0))
+            spans[gi] = (min(lo, off), max(hi, end), n + (end - off))
+        out = []
+        for gi in range(len(module_groups) + 1):
+            if gi not in spans:
+                out.append((0, 0))
+                continue
+            lo, hi, n = spans[gi]
+            if hi - lo != n:
+                raise ValueError(f"gradient bucket {gi} is not contiguous in the arena")
+            out.append((lo, hi))
+        return out
+
+    def all_reduce_range(self, lo, hi, async_op=False):
+        """All-reduce grad[lo:hi] (SUM).  Returns the work handle when async_op (None if nothing
+        to do: single process or empty range)."""
+        if hi <= lo or not (dist.is_available() and dist.is_initialized()):
+            return None
+        return dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=async_op)
+
     def broadcast_params(self, src=0):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.broadcast(self.data, src=src)

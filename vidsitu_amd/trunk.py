@@ -497,29 +497,63 @@ class VideoTrunk(nn.Module):
                   train=train, saved=saved)
 
     # ---- backward (mirror of _run, popping `saved`) ----------------------------------
+    # Backward segments, in execution order.  With `defer_backward` the autograd node only parks
+    # the incoming gradients and the caller runs the segments itself (bench.py captures each one
+    # in its own hipGraph and all-reduces a finished bucket of gradients behind the next segment).
+    BWD_SEGMENTS = ("s5", "s4", "rest")
+    defer_backward = False
+    _deferred = None
+
     def _backward(self, saved, dfeats):
-        P = self.num_pathways
-        d = list(dfeats)
-        for k in range(5, 1, -1):
-            stage = getattr(self, f"s{k}")
-            fuse = getattr(self, f"s{k}_fuse", None) if self.multi else None
-            if k == 2:
-                for p in reversed(range(P)):
-                    if self.pool1[p][0] > 1:
-                        rec = saved.pop()
-                        d[p] = ops.maxpool_t_bwd(d[p], rec["tpool_idx"], rec["tpool_in"], rec["kt"])
-            if fuse is not None:
+        st = {"saved": saved, "d": list(dfeats)}
+        if self.defer_backward:
+            self._deferred = st
+            return
+        for seg in self.BWD_SEGMENTS:
+            self._backward_segment(st, seg)
+
+    def run_backward_segment(self, seg):
+        if self._deferred is None:
+            raise ops._lib.VsError("run_backward_segment without a deferred backward")
+        self._backward_segment(self._deferred, seg)
+        if seg == self.BWD_SEGMENTS[-1]:
+            self._deferred = None
+
+    def backward_segment_modules(self, seg):
+        """Modules whose parameter gradients are complete once `seg` has run."""
+        names = {"s5": ["s5"], "s4": ["s4", "s4_fuse"],
+                 "rest": ["s1", "s1_fuse", "s2", "s2_fuse", "s3", "s3_fuse"]}[seg]
+        return [getattr(self, n) for n in names if hasattr(self, n)]
+
+    def _backward_segment(self, st, seg):
+        for k in {"s5": (5,), "s4": (4,), "rest": (3, 2)}[seg]:
+            self._backward_stage(st, k)
+        if seg == "rest":
+            saved, d = st["saved"], st["d"]
+            if self.multi:
                 d = self._fuse_bwd(saved, d)
+            for p in reversed(range(self.num_pathways)):
+                getattr(self.s1, f"pathway{p}_stem").bwd(saved, d[p])
+            assert not saved, "trunk backward did not consume every saved record"
+
+    def _backward_stage(self, st, k):
+        saved, d = st["saved"], st["d"]
+        P = self.num_pathways
+        stage = getattr(self, f"s{k}")
+        fuse = getattr(self, f"s{k}_fuse", None) if self.multi else None
+        if k == 2:
             for p in reversed(range(P)):
-                g = d[p]
-                for blk in reversed(stage.blocks(p)):
-                    g = blk.bwd(saved, g)
-                d[p] = g
-        if self.multi:
+                if self.pool1[p][0] > 1:
+                    rec = saved.pop()
+                    d[p] = ops.maxpool_t_bwd(d[p], rec["tpool_idx"], rec["tpool_in"], rec["kt"])
+        if fuse is not None:
             d = self._fuse_bwd(saved, d)
         for p in reversed(range(P)):
-            getattr(self.s1, f"pathway{p}_stem").bwd(saved, d[p])
-        assert not saved, "trunk backward did not consume every saved record"
+            g = d[p]
+            for blk in reversed(stage.blocks(p)):
+                g = blk.bwd(saved, g)
+            d[p] = g
+        st["d"] = d
 
     def _fuse_bwd(self, saved, d):
         d_cat, d_fast = d
