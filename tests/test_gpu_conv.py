@@ -229,6 +229,42 @@ def test_lds_dma_ring_is_bitwise_the_register_pipeline(case, ring, dev):
     assert_close(y1, ref, TOL, case[0] + " ring vs torch")
 
 
+@pytest.mark.parametrize("ring", [2, 3])
+@pytest.mark.parametrize("case", WG_CASES, ids=[c[0] for c in WG_CASES])
+def test_wgrad_lds_dma_ring_is_bitwise_the_register_pipeline(case, ring, dev):
+    """conv_wgrad_ring_kernel (LDS-DMA staging, tap-mask position table rebuilt a chunk ahead,
+    pipeline never drained) accumulates the same tiles in the same order as conv_wgrad_kernel."""
+    from vidsitu_amd import ops
+
+    if case[7][0] * case[7][1] * case[7][2] > 31:
+        pytest.skip("more than 31 taps: register-staged kernel only")
+    x, w, k, s, p = _mk(case, seed=21)
+    y = F.conv3d(x, w, stride=s, padding=p)
+    dy = rb(torch.randn(y.shape, generator=torch.Generator().manual_seed(22)))
+    xa, dya = to_act(x, dev), to_act(dy, dev)
+    d0 = ops.conv_wgrad(dya, xa, k, s, p, ring=1)
+    d1 = ops.conv_wgrad(dya, xa, k, s, p, ring=ring)
+    assert torch.equal(d0, d1), f"{case[0]} ring {ring}: max diff {float((d0 - d1).abs().max()):.3e}"
+
+
+def test_wgrad_ring_long_position_range(dev):
+    """> 2 table chunks per block (the double-buffered position table wraps) and a ragged tail."""
+    from vidsitu_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    x = rb(torch.randn(1, 128, 4, 40, 44, generator=g))      # 7040 positions, Cout x K' = one tile
+    dy = rb(torch.randn(1, 128, 4, 40, 44, generator=g))
+    k, s, p = (1, 3, 3), (1, 1, 1), (0, 1, 1)
+    xa, dya = to_act(x, dev), to_act(dy, dev)
+    d0 = ops.conv_wgrad(dya, xa, k, s, p, ring=1)
+    for ring in (2, 3):
+        assert torch.equal(d0, ops.conv_wgrad(dya, xa, k, s, p, ring=ring))
+    xr = x.clone().requires_grad_()
+    wr = torch.zeros(128, 128, 1, 3, 3, requires_grad=True)
+    (gw,) = torch.autograd.grad(F.conv3d(xr, wr, padding=p), wr, dy)
+    assert_close(d0, gw, TOL, "long-range wgrad vs autograd")
+
+
 def test_wgrad_is_bitwise_reproducible(dev):
     from vidsitu_amd import ops
 

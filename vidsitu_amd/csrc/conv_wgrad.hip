@@ -235,6 +235,212 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA ring variant (taps <= 31).  Same images, same MFMA order and therefore the same bits as
+// conv_wgrad_kernel, but: (1) both operand tiles go global -> LDS by `buffer_load_dwordx4 ... lds`
+// (one wave-instruction = 64 x 16 B = four 256-byte tile rows, swizzle applied to the SOURCE
+// channel chunk), NS stages, NS-1 tiles in flight behind a counted vmcnt and ONE raw barrier per
+// 64-position step; (2) the position table holds (byte offset, bitmask of valid taps) per row, is
+// double buffered and rebuilt one chunk ahead, so the pipeline never drains inside a block
+// (the register-staged kernel restarts it every 1024 positions).
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int MODE, int NS>
+__global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MR = TM / 16, NR = TN / 16;
+  constexpr int CM = BM / 8, CN = BN / 8;  // 16-byte chunks that carry data (of 16 per row)
+  constexpr int IMG = 64 * 256;
+  constexpr int STAGE = 2 * IMG;
+  constexpr int D = NS - 1;
+  constexpr int L = 8;  // DMA instructions per thread per step: 4 row groups x 2 images
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert((D - 1) * L <= 63, "vmcnt range");
+
+  const int tid = threadIdx.x;
+  int bid = blockIdx.x;
+  const int s = bid % p.S;
+  bid /= p.S;
+  const int tn = bid % p.tilesN, tm = bid / p.tilesN;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int pbeg = s * p.rows_per_split;
+  const int pend = min(p.P, pbeg + p.rows_per_split);
+  const int nsteps = (pend - pbeg + 63) >> 6;
+  int2* rowtab = (int2*)(smem + NS * STAGE);  // [2][WG_ROWTAB] (byte offset, tap mask)
+
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int rg = lane >> 4, cc = lane & 15;
+  // logical 16-byte chunk this thread fetches into physical chunk cc of rows 16 i + 4 wv + rg
+  const int lc = cc ^ ((rg << 1) | ((wv >> 1) << 3));
+  const bool mcol_ok = lc < CM && (m0 + lc * 8) < p.Cout;
+  const int ncol = n0 + lc * 8;
+  const bool ncol_ok = lc < CN && ncol < p.Kp;
+  int tap = 0, c0 = 0, dt = 0, dh = 0, dw = 0;
+  if (MODE == 1 && ncol_ok) {
+    tap = ncol / p.Cin;
+    c0 = ncol - tap * p.Cin;
+    dw = tap % p.kW;
+    const int t2 = tap / p.kW;
+    dh = t2 % p.kH;
+    dt = t2 / p.kH;
+  }
+  const unsigned dycol = (unsigned)((m0 + lc * 8) * 2);
+  const unsigned xtap = (MODE == 1)
+      ? (unsigned)(((((long long)dt * p.Hi + dh) * p.Wi + dw) * p.x_ld + c0) * 2)
+      : (unsigned)(ncol * 2);
+  const unsigned dy_pitch = (unsigned)(p.dy_ld * 2), x_pitch = (unsigned)(p.x_ld * 2);
+
+  typedef __attribute__((address_space(3))) char* lds_ptr_t;
+  const unsigned lds0 = (unsigned)(unsigned long)(lds_ptr_t)smem + (unsigned)wv * 1024u;
+  auto rsrc_words = [](const void* base, unsigned bytes) __attribute__((always_inline)) {
+    const unsigned long a = (unsigned long)base;
+    return (i32x4){(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+  };
+  const i32x4 xdesc = rsrc_words(p.x, p.x_bytes), dydesc = rsrc_words(p.dy, p.dy_bytes);
+  // issued from inline asm: see conv_igemm.hip (a builtin LDS-DMA serialises every later ds_read)
+  auto dma16 = [](const i32x4& desc, unsigned lds_addr, unsigned voff) __attribute__((always_inline)) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(desc)
+                 : "memory");
+  };
+
+  auto build_tab = [&](int chunk) __attribute__((always_inline)) {
+    int2* tab = rowtab + (chunk & 1) * WG_ROWTAB;
+    const int base = pbeg + chunk * WG_ROWTAB;
+    for (int i = tid; i < WG_ROWTAB; i += 256) {
+      const int pp = base + i;
+      int2 e = make_int2(0, 0);
+      if (pp < pend) {
+        const int wo = pp % p.Wo, t1 = pp / p.Wo;
+        const int ho = t1 % p.Ho, t2 = t1 / p.Ho;
+        const int to = t2 % p.To, n = t2 / p.To;
+        const int ti0 = to * p.sT - p.pT, hi0 = ho * p.sH - p.pH, wi0 = wo * p.sW - p.pW;
+        const long long pos0 = (((long long)n * p.Ti + ti0) * p.Hi + hi0) * p.Wi + wi0;
+        e.x = (int)(unsigned)(pos0 * p.x_ld * 2);  // exact modulo 2^32 whenever the tap is valid
+        unsigned mt = 0u, mh = 0u, mw = 0u;
+        for (int a = 0; a < p.kT; ++a) mt |= ((unsigned)(ti0 + a) < (unsigned)p.Ti ? 1u : 0u) << a;
+        for (int a = 0; a < p.kH; ++a) mh |= ((unsigned)(hi0 + a) < (unsigned)p.Hi ? 1u : 0u) << a;
+        for (int a = 0; a < p.kW; ++a) mw |= ((unsigned)(wi0 + a) < (unsigned)p.Wi ? 1u : 0u) << a;
+        unsigned mk = 0u;
+        int tp = 0;
+        for (int a = 0; a < p.kT; ++a)
+          for (int b = 0; b < p.kH; ++b) {
+            const unsigned th = (mt >> a) & (mh >> b) & 1u;
+            mk |= (th ? mw : 0u) << tp;
+            tp += p.kW;
+          }
+        e.y = (int)mk;
+      }
+      tab[i] = e;
+    }
+  };
+
+  auto dma = [&](int st, int stage) __attribute__((always_inline)) {
+    const unsigned A = lds0 + (unsigned)(stage * STAGE);
+    const unsigned B = A + IMG;
+    const int rel0 = st * 64 + 4 * wv + rg;  // position of row group 0, relative to pbeg
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rel = rel0 + 16 * i;
+      const int pp = pbeg + rel;
+      const unsigned ok = (unsigned)mcol_ok & (unsigned)(pp < pend);
+      dma16(dydesc, A + i * 4096, ok ? (unsigned)pp * dy_pitch + dycol : WG_OOB);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rel = rel0 + 16 * i;
+      const int pp = pbeg + rel;
+      unsigned ok = (unsigned)ncol_ok & (unsigned)(pp < pend);
+      unsigned off;
+      if (MODE == 0) {
+        off = (unsigned)pp * x_pitch + xtap;
+      } else {
+        const int2 e = rowtab[((rel >> 10) & 1) * WG_ROWTAB + (rel & (WG_ROWTAB - 1))];
+        ok &= ((unsigned)e.y >> tap) & 1u;
+        off = (unsigned)e.x + xtap;
+      }
+      dma16(xdesc, B + i * 4096, ok ? off : WG_OOB);
+    }
+  };
+
+  const int wm = wv / WN, wn = wv % WN;
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, pp4 = li & 3;
+  f32x4 acc[MR][NR];
+#pragma unroll
+  for (int a = 0; a < MR; ++a)
+#pragma unroll
+    for (int b = 0; b < NR; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int stage) __attribute__((always_inline)) {
+    const char* A = smem + stage * STAGE;
+    const char* B = A + IMG;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int row = ks * 32 + 8 * g + q;  // this lane supplies row `row` (and row+4)
+      const int swz = ((row & 3) << 2) | (((row >> 3) & 1) << 4);
+      bf16x8 af[MR], bfr[NR];
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+#pragma unroll
+      for (int a = 0; a < MR; ++a) {
+        const int unit = ((wm * TM + a * 16) >> 2) + pp4;
+        const lds_s16x4* ptr = (const lds_s16x4*)(A + row * 256 + ((unit ^ swz) << 3));
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)ptr);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ptr + 128));
+        af[a] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+#pragma unroll
+      for (int b = 0; b < NR; ++b) {
+        const int unit = ((wn * TN + b * 16) >> 2) + pp4;
+        const lds_s16x4* ptr = (const lds_s16x4*)(B + row * 256 + ((unit ^ swz) << 3));
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)ptr);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ptr + 128));
+        bfr[b] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+#pragma unroll
+      for (int a = 0; a < MR; ++a)
+#pragma unroll
+        for (int b = 0; b < NR; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+    }
+  };
+
+  if (MODE == 1) {
+    build_tab(0);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) dma(d, d);
+  int st_c = 0, st_l = D;
+  for (int st = 0; st < nsteps; ++st) {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"((D - 1) * L) : "memory");
+    __builtin_amdgcn_s_barrier();  // tile st landed everywhere; stage st_l and the old table are free
+    __builtin_amdgcn_sched_barrier(0);
+    if (MODE == 1 && (st & 15) == 0 && pbeg + ((st >> 4) + 1) * WG_ROWTAB < pend)
+      build_tab((st >> 4) + 1);  // next chunk's table, first read >= 13 steps from now
+    dma(st + D, st_l);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(st_c);
+    __builtin_amdgcn_sched_barrier(0);
+    st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
+    st_l = (st_l + 1 == NS) ? 0 : st_l + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  float* dst = p.out + (long long)s * p.Cout * p.Kp;
+#pragma unroll
+  for (int a = 0; a < MR; ++a)
+#pragma unroll
+    for (int b = 0; b < NR; ++b) {
+      const int col = n0 + wn * TN + b * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * TM + a * 16 + g * 4 + r;
+        if (row < p.Cout && col < p.Kp) dst[(long long)row * p.Kp + col] = acc[a][b][r];
+      }
+    }
+}
+
 // dw[i] = sum_s slab[s][i], bitwise reproducible: block = 16 float4 columns x 16 slab slices,
 // each slice summed in order, the 16 slice sums combined in order through LDS.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, float* dw,
@@ -304,7 +510,9 @@ static WgCfg wg_pick(const vs_conv_desc* d) {
   // Skinny outputs (fast pathway, stems: a handful of tiles, 10^5..10^6 positions) are
   // latency bound per 64-position step, so they get up to 2048 blocks.
   const long long target = (d->Cout <= 32) ? 2048 : 512;
-  long long S = (target + tiles - 1) / tiles;
+  // two blocks are resident per CU (80 KB of LDS each): 512 slots.  Round the split DOWN so that
+  // the grid fits one residency round -- 528 blocks on 512 slots run as two rounds (s4.a: +45 %)
+  long long S = (d->Cout <= 32) ? (target + tiles - 1) / tiles : target / tiles;
   const long long maxS = (P + 511) / 512;
   if (S > maxS) S = maxS;
   const long long slab_cap = (64ll << 20) / ((long long)d->Cout * Kp * 4);  // <= 64 MB of slabs
@@ -326,17 +534,39 @@ extern "C" size_t vs_conv_wgrad_workspace_bytes(const vs_conv_desc* d) {
 }
 
 template <int BM, int BN, int WM, int WN>
-static int wg_launch(const WgradP& p, int mode, hipStream_t st) {
-  const size_t smem = 2 * 2 * 64 * 256 + (mode ? WG_ROWTAB * sizeof(int4) : 0);
+static int wg_launch(const WgradP& p, int mode, int ring, hipStream_t st) {
+  const int grid = p.tilesM * p.tilesN * p.S;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<BM, BN, WM, WN, 0>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<BM, BN, WM, WN, 1>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<BM, BN, WM, WN, 0, 2>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<BM, BN, WM, WN, 1, 2>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<BM, BN, WM, WN, 0, 3>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<BM, BN, WM, WN, 1, 3>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  const int grid = p.tilesM * p.tilesN * p.S;
+  if (ring >= 2) {
+    const size_t tab = mode ? 2 * WG_ROWTAB * sizeof(int2) : 0;
+    const size_t smem = (size_t)ring * 2 * 64 * 256 + tab;
+    if (ring == 2 && mode == 0)
+      hipLaunchKernelGGL((conv_wgrad_ring_kernel<BM, BN, WM, WN, 0, 2>), dim3(grid), dim3(256), smem, st, p);
+    else if (ring == 2)
+      hipLaunchKernelGGL((conv_wgrad_ring_kernel<BM, BN, WM, WN, 1, 2>), dim3(grid), dim3(256), smem, st, p);
+    else if (mode == 0)
+      hipLaunchKernelGGL((conv_wgrad_ring_kernel<BM, BN, WM, WN, 0, 3>), dim3(grid), dim3(256), smem, st, p);
+    else
+      hipLaunchKernelGGL((conv_wgrad_ring_kernel<BM, BN, WM, WN, 1, 3>), dim3(grid), dim3(256), smem, st, p);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+  }
+  const size_t smem = 2 * 2 * 64 * 256 + (mode ? WG_ROWTAB * sizeof(int4) : 0);
   if (mode == 0)
     hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, 0>), dim3(grid), dim3(256), smem, st, p);
   else
@@ -394,15 +624,21 @@ extern "C" int vs_conv_wgrad(const void* dy, const void* x, float* dw, const vs_
                      d->pT == 0 && d->pH == 0 && d->pW == 0;
   const int mode = dense ? 0 : 1;
   hipStream_t st = (hipStream_t)stream;
+  // staging: VS_CONV_RING(1) register pipeline, (2|3) LDS-DMA ring stages, 0 = heuristic
+  const int fring = (d->flags >> 16) & 7;
+  // heuristic: the 2-stage ring wins 3-8 % on the 128-row tiles (profiles/r01_wgrad_ring.txt) and
+  // loses a little on the skinny ones
+  int ring = fring == 1 ? 0 : (fring >= 2 ? (fring > 3 ? 3 : fring) : (c.bm == 128 ? 2 : 0));
+  if (d->kT * d->kH * d->kW > 31) ring = 0;  // the tap bitmask of the ring's position table
   int rc;
-  if (c.bm == 128 && c.bn == 128) rc = wg_launch<128, 128, 2, 2>(p, mode, st);
-  else if (c.bm == 128) rc = wg_launch<128, 64, 2, 2>(p, mode, st);
-  else if (c.bm == 64 && c.bn == 128) rc = wg_launch<64, 128, 2, 2>(p, mode, st);
-  else if (c.bm == 64) rc = wg_launch<64, 64, 2, 2>(p, mode, st);
-  else if (c.bm == 32 && c.bn == 128) rc = wg_launch<32, 128, 1, 4>(p, mode, st);
-  else if (c.bm == 32) rc = wg_launch<32, 64, 1, 4>(p, mode, st);
-  else if (c.bn == 128) rc = wg_launch<16, 128, 1, 4>(p, mode, st);
-  else rc = wg_launch<16, 64, 1, 4>(p, mode, st);
+  if (c.bm == 128 && c.bn == 128) rc = wg_launch<128, 128, 2, 2>(p, mode, ring, st);
+  else if (c.bm == 128) rc = wg_launch<128, 64, 2, 2>(p, mode, ring, st);
+  else if (c.bm == 64 && c.bn == 128) rc = wg_launch<64, 128, 2, 2>(p, mode, ring, st);
+  else if (c.bm == 64) rc = wg_launch<64, 64, 2, 2>(p, mode, ring, st);
+  else if (c.bm == 32 && c.bn == 128) rc = wg_launch<32, 128, 1, 4>(p, mode, ring, st);
+  else if (c.bm == 32) rc = wg_launch<32, 64, 1, 4>(p, mode, ring, st);
+  else if (c.bn == 128) rc = wg_launch<16, 128, 1, 4>(p, mode, ring, st);
+  else rc = wg_launch<16, 64, 1, 4>(p, mode, ring, st);
   if (rc) return rc;
   if (c.S > 1) {
     const long long n = (long long)d->Cout * p.Kp;

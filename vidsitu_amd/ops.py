@@ -284,14 +284,15 @@ def _workspace(nbytes, device):
     return ws
 
 
-def conv_wgrad(dy, x, k, s, p, out=None):
-    """dw fp32, logical [Cout,Cin,kT,kH,kW], memory [Cout][taps][Cin]."""
+def conv_wgrad(dy, x, k, s, p, out=None, ring=0):
+    """dw fp32, logical [Cout,Cin,kT,kH,kW], memory [Cout][taps][Cin].
+    ring: 0 heuristic, 1 register-staged pipeline, 2 / 3 LDS-DMA ring stages (VS_CONV_RING)."""
     cout, cin = dy.shape[1], x.shape[1]
     if out is None:
         out = torch.empty((cout, *k, cin), dtype=torch.float32, device=x.device).permute(0, 4, 1, 2, 3)
     elif not out.permute(0, 2, 3, 4, 1).is_contiguous() or out.dtype != torch.float32:
         raise _lib.VsError("conv_wgrad out must be fp32 with [Cout][taps][Cin] memory")
-    d = make_desc(x.shape, act_ld(x), dy.shape, act_ld(dy), k, s, p)
+    d = make_desc(x.shape, act_ld(x), dy.shape, act_ld(dy), k, s, p, (ring & 7) << 16)
     need = _lib.load().vs_conv_wgrad_workspace_bytes(C.byref(d))
     ws = _workspace(need, x.device) if need else None
     _lib.call("vs_conv_wgrad", _ptr(dy), _ptr(x), _ptr(out), C.byref(d), None, None, _ptr(ws),
