@@ -307,8 +307,57 @@ def ops_ensure_act(t):
     return t
 
 
+class _Fork:
+    """Fork / join of the two pathways onto two HIP streams.  Between two lateral connections the
+    slow and the fast pathway are independent chains; the fast one (1/8 of the channels) is made of
+    small, latency-bound launches that hide behind the slow pathway's when both are in flight.
+    Pathway 0 stays on the caller's stream, pathway 1 runs on a side stream; `join` makes the
+    caller's stream wait for the side stream (and the side stream for the caller's at the next
+    `fork`), so a captured hipGraph gets two parallel branches per stage.  Tensors that cross
+    streams are kept alive (`keep`) until the join: nothing is freed and re-used while the other
+    stream may still read it."""
+
+    def __init__(self, side):
+        self.side = side
+        self.main = None
+        self.active = False
+
+    def fork(self):
+        if self.side is None:
+            return
+        self.main = torch.cuda.current_stream()
+        self.side.wait_stream(self.main)
+        self.active = True
+
+    def on(self, p):
+        import contextlib
+
+        if self.side is None or not self.active or p == 0:
+            return contextlib.nullcontext()
+        return torch.cuda.stream(self.side)
+
+    def join(self, keep=None):
+        if self.side is None or not self.active:
+            return
+        self.main.wait_stream(self.side)
+        self.active = False
+        del keep
+
+
 class VideoTrunk(nn.Module):
     """`SlowFast_FeatModel` / `ResNet_FeatModel` (mdl_sf_base.py:20-62)."""
+
+    dual_stream = True  # run the two pathways of a multi-pathway trunk on two streams
+    _side_streams = {}
+
+    def _fork_ctx(self, dev):
+        if not (self.dual_stream and self.multi and dev.type == "cuda"):
+            return _Fork(None)
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        side = VideoTrunk._side_streams.get(key)
+        if side is None:
+            side = VideoTrunk._side_streams[key] = torch.cuda.Stream(device=dev)
+        return _Fork(side)
 
     def __init__(self, cfg):
         super().__init__()
@@ -434,20 +483,24 @@ class VideoTrunk(nn.Module):
             self._ensure_folds()
         # ---- s1 (+ fuse): stems write straight into the concat buffer of the slow path
         cur = []
+        par = self._fork_ctx(dev)
+        par.fork()
         for p in range(P):
             stem = getattr(self.s1, f"pathway{p}_stem")
             n, _, t, h, w = shapes[p]
             ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
             hp, wp = (ho + 2 - 3) // 2 + 1, (wo + 2 - 3) // 2 + 1
             c = stem.conv.cout
-            if self.multi and p == 0:
-                cf = self.s1_fuse.conv_f2s.cout
-                buf = ops.new_act(n, c + cf, t, hp, wp, dev)
-                out = ops.channel_slice(buf, 0, c)
-            else:
-                buf = out = ops.new_act(n, c, t, hp, wp, dev)
-            stem.fwd(xin[p], out, train, saved)
+            with par.on(p):  # allocate on the stream that writes the buffer first
+                if self.multi and p == 0:
+                    cf = self.s1_fuse.conv_f2s.cout
+                    buf = ops.new_act(n, c + cf, t, hp, wp, dev)
+                    out = ops.channel_slice(buf, 0, c)
+                else:
+                    buf = out = ops.new_act(n, c, t, hp, wp, dev)
+                stem.fwd(xin[p], out, train, saved)
             cur.append(buf)
+        par.join()
         if self.multi:
             self._fuse_fwd(self.s1_fuse, cur, train, saved)
         if self.debug_taps is not None:
@@ -456,7 +509,9 @@ class VideoTrunk(nn.Module):
             stage = getattr(self, f"s{k}")
             fuse = getattr(self, f"s{k}_fuse", None) if self.multi else None
             nxt = []
+            par.fork()
             for p in range(P):
+              with par.on(p):
                 x = cur[p]
                 blocks = stage.blocks(p)
                 for i, blk in enumerate(blocks):
@@ -474,6 +529,7 @@ class VideoTrunk(nn.Module):
                     else:
                         x = blk.fwd(x, None, train, saved)
                 nxt.append(x)
+            par.join(keep=cur)
             cur = nxt
             if fuse is not None:
                 self._fuse_fwd(fuse, cur, train, saved)
@@ -532,8 +588,12 @@ class VideoTrunk(nn.Module):
             saved, d = st["saved"], st["d"]
             if self.multi:
                 d = self._fuse_bwd(saved, d)
+            par = self._fork_ctx(d[0].device)
+            par.fork()
             for p in reversed(range(self.num_pathways)):
-                getattr(self.s1, f"pathway{p}_stem").bwd(saved, d[p])
+                with par.on(p):
+                    getattr(self.s1, f"pathway{p}_stem").bwd(saved, d[p])
+            par.join(keep=d)
             assert not saved, "trunk backward did not consume every saved record"
 
     def _backward_stage(self, st, k):
@@ -548,11 +608,16 @@ class VideoTrunk(nn.Module):
                     d[p] = ops.maxpool_t_bwd(d[p], rec["tpool_idx"], rec["tpool_in"], rec["kt"])
         if fuse is not None:
             d = self._fuse_bwd(saved, d)
+        par = self._fork_ctx(d[0].device)
+        d_in = list(d)  # keep the incoming gradients alive until both streams are done with them
+        par.fork()
         for p in reversed(range(P)):
-            g = d[p]
-            for blk in reversed(stage.blocks(p)):
-                g = blk.bwd(saved, g)
-            d[p] = g
+            with par.on(p):
+                g = d[p]
+                for blk in reversed(stage.blocks(p)):
+                    g = blk.bwd(saved, g)
+                d[p] = g
+        par.join(keep=d_in)
         st["d"] = d
 
     def _fuse_bwd(self, saved, d):
