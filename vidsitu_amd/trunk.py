@@ -16,6 +16,8 @@ tensors handed back keep the reference's logical NCDHW shape.
          conv dgrad / wgrad) and writes parameter gradients straight into
          `param.grad` (one fp32 arena), so DDP-style averaging is one all-reduce.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -109,6 +111,62 @@ def _set_grad(param, g):
         param.grad.copy_(g)
 
 
+class _WgradLanes:
+    """Weight gradients have no consumer before the optimizer, so every conv_wgrad launch goes to
+    a side stream of the stream it was issued from and runs beside the dgrad / BN kernels that
+    continue the backward chain (both are far from filling the chip at batch 8).  Operands are
+    kept alive until `join_all` (end of a stage), where each issuing stream waits for its lane."""
+
+    # VS_WGRAD_LANES (measured, batch 8 train step, hipGraph):
+    #   0  off                                                              17.24 ms
+    #   4  DEFAULT: launches issued from the caller's (slow-pathway) stream only, lane joined
+    #      right after the same unit's dgrad (wgrad || dgrad)               16.71 ms
+    #   3  as 4 but joined at the end of the stage                          19.13 ms
+    #   5  fast-pathway launches too, joined by the origin stream at the stage join  18.83 ms
+    #   1 / 2  lanes forked from AND joined back into the trunk's side stream: hipGraph capture
+    #      of such a nested fork segfaults in hipStreamEndCapture on ROCm 7.2 -- do not use
+    mode = int(os.environ.get("VS_WGRAD_LANES", "4"))
+    enabled = mode > 0
+    # (device index, issued from the trunk's side stream?) -> [issuing stream, lane stream,
+    # keepalive list, pending].  Lane streams are created once (never inside a hipGraph capture,
+    # where creating a stream is an unsafe call) and reused whatever stream is current.
+    lanes = {}
+    origin = None  # the stream the current fork started from (set by _Fork.fork)
+
+    @classmethod
+    def run(cls, fn, *keep):
+        if not cls.enabled or not keep[0].is_cuda:
+            return fn()
+        main = torch.cuda.current_stream()
+        dev = main.device.index
+        side = VideoTrunk._side_streams.get(dev)
+        key = (dev, side is not None and side.cuda_stream == main.cuda_stream)
+        if key[1] and cls.mode in (3, 4):  # no fork from the trunk's side stream
+            return fn()
+        lane = cls.lanes.get(key)
+        if lane is None:
+            lane = cls.lanes[key] = [main, torch.cuda.Stream(device=main.device), [], False]
+        # mode 5: work issued from the side stream is joined by the ORIGIN stream at the stage's
+        # join (a lane forked from and joined back into a forked stream crashes hipGraph capture)
+        joiner = cls.origin if (key[1] and cls.mode == 5 and cls.origin is not None) else main
+        if lane[3] and lane[0].cuda_stream != joiner.cuda_stream:  # never leave a lane un-joined
+            lane[0].wait_stream(lane[1])
+        lane[0] = joiner
+        lane[1].wait_stream(main)
+        with torch.cuda.stream(lane[1]):
+            fn()
+        lane[2].extend(keep)
+        lane[3] = True
+
+    @classmethod
+    def join_all(cls, only_main=False):
+        for key, lane in cls.lanes.items():
+            if lane[3] and not (only_main and key[1]):
+                lane[0].wait_stream(lane[1])
+                lane[2].clear()
+                lane[3] = False
+
+
 class _Unit:
     """conv -> BN (-> +residual) (-> ReLU) executed on the HIP kernels."""
 
@@ -156,18 +214,25 @@ class _Unit:
             dgamma=bn.weight.grad, dbeta=bn.bias.grad, beta=bn.bias)
         x = rec["x"]
         if conv.is_stem:
-            _set_grad(conv.weight, ops.stem_conv_wgrad(dy, x, conv.k[0]))
+            _WgradLanes.run(lambda: _set_grad(conv.weight, ops.stem_conv_wgrad(dy, x, conv.k[0])), dy, x)
         elif conv.cin_pad == conv.cin:
             if conv.weight.grad is None:
                 conv.weight.grad = torch.empty_like(conv.weight)
-            ops.conv_wgrad(dy, x, conv.k, conv.s, conv.p, out=conv.weight.grad)
+            _WgradLanes.run(lambda: ops.conv_wgrad(dy, x, conv.k, conv.s, conv.p, out=conv.weight.grad),
+                            dy, x)
         else:
-            dwp = ops.conv_wgrad(dy, x, conv.k, conv.s, conv.p)
-            _set_grad(conv.weight, dwp[:, : conv.cin])
+            def legacy():
+                dwp = ops.conv_wgrad(dy, x, conv.k, conv.s, conv.p)
+                _set_grad(conv.weight, dwp[:, : conv.cin])
+            _WgradLanes.run(legacy, dy, x)
         dx = None
         if need_dx:
             dx = ops.conv_dgrad(dy, conv.wt(), tuple(x.shape), conv.k, conv.s, conv.p,
                                 residual=dx_residual)
+        if _WgradLanes.mode in (2, 4):
+            _WgradLanes.join_all()
+        elif _WgradLanes.mode == 5:
+            _WgradLanes.join_all(only_main=True)
         return dx, dres
 
 
@@ -326,6 +391,7 @@ class _Fork:
         if self.side is None:
             return
         self.main = torch.cuda.current_stream()
+        _WgradLanes.origin = self.main
         self.side.wait_stream(self.main)
         self.active = True
 
@@ -337,6 +403,7 @@ class _Fork:
         return torch.cuda.stream(self.side)
 
     def join(self, keep=None):
+        _WgradLanes.join_all()
         if self.side is None or not self.active:
             return
         self.main.wait_stream(self.side)
