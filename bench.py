@@ -111,7 +111,7 @@ class EntryProbe:
                 flops = 2.0 * mo * d.Cout * d.Cin * taps
                 byts = 2.0 * (mi * d.Cin + mo * d.Cout + d.Cout * d.Cin * taps)
                 if name == "vs_conv_wgrad":
-                    return "conv_wgrad_kernel (+wgrad_reduce_kernel)", "mfma", flops, byts
+                    return "conv_wgrad (conv_wgrad_ring_kernel | conv_wgrad_kernel, + wgrad_reduce_kernel)", "mfma", flops, byts
                 if name == "vs_conv_fwd" and (d.flags & 2):
                     byts += 2.0 * mo * d.Cout
                 return conv_label(d, 1 if name == "vs_conv_dgrad" else 0), "mfma", flops, byts
@@ -256,7 +256,7 @@ def main():
                                    device=dev, dtype=torch.bfloat16)
 
     dist_on = world > 1 or (dist.is_available() and dist.is_initialized())
-    comm = {"on": dist_on}  # the rank-0-only instrumented pass must not enter a collective
+    gate = {"on": dist_on}  # the rank-0-only instrumented pass must not enter a collective
     overlap = train and (args.overlap == 1 or (args.overlap < 0 and world > 1))
     segments = None
     if train:
@@ -291,7 +291,7 @@ def main():
                 for fn, (lo, hi) in segments:
                     r = fn()
                     out = r if out is None else out
-                    if comm["on"]:
+                    if gate["on"]:
                         works.append(arena.all_reduce_range(lo, hi, async_op=True))
                 for w in works:
                     if w is not None:
@@ -301,7 +301,7 @@ def main():
         else:
             def step():
                 loss = fwd_bwd()
-                if comm["on"]:
+                if gate["on"]:
                     arena.all_reduce()
                 opt.step(world=world)
                 return loss
@@ -396,12 +396,18 @@ def main():
 
     roof = None
     if rank == 0 and not args.no_roofline:
-        comm["on"] = False
+        gate["on"] = False
+        # per-kernel durations are taken with every launch on ONE stream (the timed region runs the
+        # two pathways and the weight gradients on parallel streams, where launches overlap and a
+        # launch's wall duration no longer measures the kernel)
+        from vidsitu_amd import trunk as _trunk
+        saved_modes = (_trunk.VideoTrunk.dual_stream, _trunk._WgradLanes.enabled)
+        _trunk.VideoTrunk.dual_stream, _trunk._WgradLanes.enabled = False, False
         t0 = time.perf_counter()
         step()
         torch.cuda.synchronize()
         eager_ms = (time.perf_counter() - t0) * 1e3  # CPU time to enqueue one eager step
-        comm["on"] = False
+        gate["on"] = False
         probe = EntryProbe()
         probe.install()
         reps = 3
@@ -415,6 +421,7 @@ def main():
                 torch.cuda.synchronize()
         finally:
             probe.remove()
+            _trunk.VideoTrunk.dual_stream, _trunk._WgradLanes.enabled = saved_modes
         agg = probe.summary()
         pmc = load_pmc_traffic()
 
@@ -447,7 +454,8 @@ def main():
         roof = dict(top)
         roof["probed_ms_per_step"] = round(tot_ms, 3)
         roof["note"] = ("dominant entry point of the step by summed HIP-event time; separate "
-                        "instrumented eager pass (the timed region replays a hipGraph)")
+                        "instrumented eager pass on one stream (the timed region replays a hipGraph "
+                        "whose pathway / wgrad branches run concurrently)")
         conv = [v for k, v in fams if v[4] == "mfma"]
         cms, cfl = sum(v[1] for v in conv), sum(v[2] for v in conv)
         roof["all_conv"] = {"ms_per_step": round(cms / reps, 3),

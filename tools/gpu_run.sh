@@ -19,6 +19,8 @@ if [ "${RUN_TRAIN:-0}" = "1" ]; then
 fi
 if [ "${RUN_PROF:-1}" = "1" ]; then
   echo "== rocprof"
+  # one stream: per-kernel durations of launches that do not overlap (what bench.py's roofline uses)
+  export VS_DUAL_STREAM=0 VS_WGRAD_LANES=0
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 5 --warmup 2 --workload ${PROF_WORKLOAD:-feat_fwd} --no-cpu-baseline --no-roofline --graph 0 > $OUT/rocprof.log 2>&1
   echo "rocprof exit $?" | tee -a $OUT/rocprof.log
   find $OUT/prof -name "*kernel_stats*.csv" | head -3

@@ -414,7 +414,8 @@ class _Fork:
 class VideoTrunk(nn.Module):
     """`SlowFast_FeatModel` / `ResNet_FeatModel` (mdl_sf_base.py:20-62)."""
 
-    dual_stream = True  # run the two pathways of a multi-pathway trunk on two streams
+    # run the two pathways of a multi-pathway trunk on two streams (VS_DUAL_STREAM=0: one stream)
+    dual_stream = os.environ.get("VS_DUAL_STREAM", "1") != "0"
     _side_streams = {}
 
     def _fork_ctx(self, dev):
