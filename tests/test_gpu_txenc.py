@@ -55,7 +55,10 @@ def test_txenc_backward_matches_reference_golden(path, dev):
 
 
 @pytest.mark.parametrize("m,n,k,relu", [(1, 7, 5, False), (8, 1564, 1152, False), (40, 1024, 1024, True),
-                                        (40, 1024, 2304, True), (50, 33, 130, False), (130, 64, 96, True)])
+                                        (40, 1024, 2304, True), (50, 33, 130, False), (130, 64, 96, True),
+                                        # whole-x-in-LDS kernel (M <= 16, K <= 2048, K % 4 == 0)
+                                        (8, 1024, 1024, True), (16, 515, 2048, False), (3, 40, 12, True),
+                                        (10, 1024, 2304, False), (8, 1024, 2304, True), (5, 77, 4096, False)])
 def test_linear_fwd_bwd(m, n, k, relu, dev):
     from vidsitu_amd import ops
 

@@ -85,8 +85,12 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
   if (n < N) {
     const float bias = b ? b[n] : 0.f;
 #pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] += __shfl_xor(acc[m], o, 64);
+#pragma unroll
     for (int m = 0; m < MT; ++m) {
-      float s = wave_reduce_sum(acc[m]);
+      float s = acc[m];
       if (lane == 0 && mbase + m < M) {
         s += bias;
         if (act == 1) s = fmaxf(s, 0.f);
@@ -99,9 +103,212 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
   }
 }
 
+// Few rows (M <= 16) and K <= 4096 / MT floats: the whole x lives in LDS (one staging pass, one
+// barrier) and every weight chunk of the wave's row is requested before anything is waited for.
+// The chunked kernel above pays a global-load latency plus two barriers per 256-wide K chunk,
+// which at M = 8 (TxEncoder tokens of one rank) left each launch at ~10 us for 4 MB of weights.
+template <int MT, int KC>  // KC = number of 256-wide K chunks held in registers (K <= 256 * KC)
+__global__ __launch_bounds__(256) void linear_fullx_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ w,
+                                                           const float* __restrict__ b,
+                                                           const float* res, float* y, int M, int N,
+                                                           int K, int act) {
+  extern __shared__ float4 xs4[];  // [MT][K/4]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + wave;
+  const int K4 = K >> 2;
+  float4 wv[KC];
+#pragma unroll
+  for (int u = 0; u < KC; ++u) {
+    const int k4 = u * 64 + lane;
+    const bool ok = n < N && k4 < K4;  // branch-free (see linear_rows16_kernel)
+    const float4 v = *(const float4*)(w + (ok ? (long long)n * K + k4 * 4 : 0));
+    wv[u] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // staging: thread t owns float4 columns t, t+256, ...; all MT loads of a column in flight at once
+#pragma unroll
+  for (int h = 0; h < (KC + 3) / 4; ++h) {
+    const int k4 = h * 256 + threadIdx.x;
+    float4 t[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const bool ok = m < M && k4 < K4;
+      const float4 v = *(const float4*)(x + (ok ? (long long)m * K + k4 * 4 : 0));
+      t[m] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (k4 < K4) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) xs4[m * K4 + k4] = t[m];
+    }
+  }
+  __syncthreads();
+  float acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+#pragma unroll
+  for (int u = 0; u < KC; ++u) {
+    const int k4 = u * 64 + lane;
+    if (k4 < K4) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const float4 xv = xs4[m * K4 + k4];
+        acc[m] += xv.x * wv[u].x + xv.y * wv[u].y + xv.z * wv[u].z + xv.w * wv[u].w;
+      }
+    }
+  }
+  // cross-lane sums through LDS (see linear_rows16_kernel): lane m < MT finishes output (m, n)
+  __syncthreads();
+  float* red = (float*)xs4;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) red[(wave * MT + m) * 65 + lane] = acc[m];
+  __syncthreads();
+  if (lane < MT && lane < M && n < N) {
+    const float* row = red + (wave * MT + lane) * 65;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) s += row[j];
+    s += b ? b[n] : 0.f;
+    if (act == 1) s = fmaxf(s, 0.f);
+    else if (act == 2) s = 0.5f * s * (1.0f + tanhf(0.7978845608028654f * (s + 0.044715f * s * s * s)));
+    if (res) s += res[(long long)lane * N + n];
+    y[(long long)lane * N + n] = s;
+  }
+}
+
+template <int MT, int KC>
+static void launch_fullx(const float* x, const float* w, const float* b, const float* res, float* y,
+                         int M, int N, int K, int act, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)linear_fullx_kernel<MT, KC>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  size_t smem = (size_t)MT * K * 4;
+  if (smem < (size_t)4 * MT * 65 * 4) smem = (size_t)4 * MT * 65 * 4;
+  hipLaunchKernelGGL((linear_fullx_kernel<MT, KC>), dim3((N + 3) / 4), dim3(256), smem, st, x, w, b,
+                     res, y, M, N, K, act);
+}
+
+// 17..64 rows (GPT-2 decode steps: batch x beam rows): 16-row x 16-column blocks, four columns per
+// wave so that one LDS read of x feeds 16 FMAs (the one-column kernel is LDS-read bound above
+// ~16 rows: 123 GB/s of weights at M = 50), x staged 1024 floats of K at a time (64 KB, two blocks per CU).
+#define LR_ROWS 16
+#define LR_CPW 4
+#define LR_KCH 1024
+
+__global__ __launch_bounds__(256) void linear_rows16_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ w,
+                                                            const float* __restrict__ b,
+                                                            const float* res, float* y, int M, int N,
+                                                            int K, int act) {
+  extern __shared__ float4 xs4[];  // [LR_ROWS][LR_KCH / 4]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n0 = (blockIdx.x * 4 + wave) * LR_CPW;
+  const int m0 = blockIdx.y * LR_ROWS;
+  float acc[LR_ROWS][LR_CPW];
+#pragma unroll
+  for (int m = 0; m < LR_ROWS; ++m)
+#pragma unroll
+    for (int c = 0; c < LR_CPW; ++c) acc[m][c] = 0.f;
+  for (int kc = 0; kc < K; kc += LR_KCH) {
+    float4 wv[LR_CPW][4];
+#pragma unroll
+    for (int c = 0; c < LR_CPW; ++c)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        // branch-free: a predicated load would sit in its own basic block behind its own wait
+        // (16 serialised L2 round trips per chunk); load a safe address and select instead
+        const int k = kc + (u * 64 + lane) * 4;
+        const bool ok = n0 + c < N && k < K;
+        const float4 v = *(const float4*)(w + (ok ? (long long)(n0 + c) * K + k : 0));
+        wv[c][u] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    __syncthreads();  // previous chunk's readers are done
+    {  // all LR_ROWS loads of this thread in flight before the first LDS store
+      float4 t[LR_ROWS];
+      const int k = kc + threadIdx.x * 4;
+#pragma unroll
+      for (int m = 0; m < LR_ROWS; ++m) {
+        const bool ok = m0 + m < M && k < K;
+        const float4 v = *(const float4*)(x + (ok ? (long long)(m0 + m) * K + k : 0));
+        t[m] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int m = 0; m < LR_ROWS; ++m) xs4[m * (LR_KCH / 4) + threadIdx.x] = t[m];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int m = 0; m < LR_ROWS; ++m) {
+        const float4 xv = xs4[m * (LR_KCH / 4) + u * 64 + lane];
+#pragma unroll
+        for (int c = 0; c < LR_CPW; ++c)
+          acc[m][c] += xv.x * wv[c][u].x + xv.y * wv[c][u].y + xv.z * wv[c][u].z + xv.w * wv[c][u].w;
+      }
+    }
+  }
+  // cross-lane sums through LDS (the x buffer is free now): wave w stores accumulator a of lane l
+  // at red[(w*64 + a) * 65 + l]; thread (w, a) then adds its row of 64 -- every thread finishes ONE
+  // output.  (64 butterfly reductions on ds_bpermute were 384 dependent LDS-crossbar round trips
+  // per wave: ~16 us per block.)
+  __syncthreads();
+  float* red = (float*)xs4;
+#pragma unroll
+  for (int m = 0; m < LR_ROWS; ++m)
+#pragma unroll
+    for (int c = 0; c < LR_CPW; ++c) red[(wave * 64 + m * LR_CPW + c) * 65 + lane] = acc[m][c];
+  __syncthreads();
+  {
+    const float* row = red + (wave * 64 + lane) * 65;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) s += row[j];
+    const int m = lane / LR_CPW, c = lane % LR_CPW;
+    const int n = n0 + c;
+    if (n < N && m0 + m < M) {
+      s += b ? b[n] : 0.f;
+      if (act == 1) s = fmaxf(s, 0.f);
+      else if (act == 2) s = 0.5f * s * (1.0f + tanhf(0.7978845608028654f * (s + 0.044715f * s * s * s)));
+      if (res) s += res[(long long)(m0 + m) * N + n];
+      y[(long long)(m0 + m) * N + n] = s;
+    }
+  }
+}
+
 static int linear_small_m(const float* x, const float* w, const float* b, const float* res, float* y,
                           int M, int N, int K, int act, hipStream_t st) {
   const int gx = (N + 3) / 4;
+  if (M <= 8 && (K & 3) == 0 && K > 2048 && K <= 4096) {
+    launch_fullx<8, 16>(x, w, b, res, y, M, N, K, act, st);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+  }
+  if (M <= 16 && (K & 3) == 0 && K <= 2048) {
+    const bool k1 = K <= 1024;
+    if (M <= 8) {
+      if (k1) launch_fullx<8, 4>(x, w, b, res, y, M, N, K, act, st);
+      else launch_fullx<8, 8>(x, w, b, res, y, M, N, K, act, st);
+    } else {
+      if (k1) launch_fullx<16, 4>(x, w, b, res, y, M, N, K, act, st);
+      else launch_fullx<16, 8>(x, w, b, res, y, M, N, K, act, st);
+    }
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+  }
+  if (M > 16 && (K & 3) == 0) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)linear_rows16_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr = true;
+    }
+    hipLaunchKernelGGL(linear_rows16_kernel, dim3((N + 15) / 16, (M + LR_ROWS - 1) / LR_ROWS), dim3(256),
+                       (size_t)4 * 64 * 65 * 4, st, x, w, b, res, y, M, N, K, act);  // >= LR_ROWS * LR_KCH * 4
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+  }
   if (M <= 8)
     hipLaunchKernelGGL(linear_fwd_kernel<8>, dim3(gx, 1), dim3(256), 0, st, x, w, b, res, y, M, N, K, act);
   else if (M <= 16)
