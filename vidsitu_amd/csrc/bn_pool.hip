@@ -220,16 +220,99 @@ static inline int ew_grid(long long total) {
   return (int)g;
 }
 
+// Column-owner form (C/8 a power of two): a thread keeps the scale / shift of ITS 8 channels in
+// registers and walks rows in batches of 4 with every load of a batch in flight before the first
+// use; no per-element 64-bit division, no per-element parameter reloads.
+#define BNA_BATCH 4
+
+static int bn_rows_batches(long long rows, int C, int target_blocks) {
+  const int cpr = C / 8;
+  const int ncol = cpr < 256 ? cpr : 256;
+  const long long rl = 256 / ncol;
+  long long nb = (rows + rl * BNA_BATCH * target_blocks - 1) / (rl * BNA_BATCH * target_blocks);
+  if (nb < 1) nb = 1;
+  if (nb > 4) nb = 4;
+  return (int)nb;
+}
+
+static bool cpr_pow2(int C) {
+  const int cpr = C / 8;
+  return C % 8 == 0 && cpr > 0 && (cpr & (cpr - 1)) == 0;
+}
+
+template <bool RES, bool RELU>
+__global__ __launch_bounds__(256) void bn_apply_cols_kernel(const uint16_t* y, const float* scale,
+                                                            const float* shift, const uint16_t* res,
+                                                            uint16_t* out, long long rows, int C,
+                                                            int y_ld, int res_ld, int out_ld,
+                                                            int nbatch) {
+  const int cpr = C >> 3;
+  const int ncol = cpr < 256 ? cpr : 256;
+  const int rl = 256 / ncol;
+  const int col = threadIdx.x % ncol, lane_r = threadIdx.x / ncol;
+  const long long r0 = (long long)blockIdx.x * rl * BNA_BATCH * nbatch;
+  for (int cb = col; cb < cpr; cb += ncol) {
+    const int c = cb * 8;
+    float sc[8], sh[8];
+    *(float4*)(sc) = *(const float4*)(scale + c);
+    *(float4*)(sc + 4) = *(const float4*)(scale + c + 4);
+    *(float4*)(sh) = *(const float4*)(shift + c);
+    *(float4*)(sh + 4) = *(const float4*)(shift + c + 4);
+    for (int b = 0; b < nbatch; ++b) {
+      uint4 vy[BNA_BATCH], vr[BNA_BATCH];
+      long long row[BNA_BATCH];
+#pragma unroll
+      for (int u = 0; u < BNA_BATCH; ++u) {
+        row[u] = r0 + (long long)(b * BNA_BATCH + u) * rl + lane_r;
+        const long long rr = row[u] < rows ? row[u] : 0;
+        vy[u] = *(const uint4*)(y + rr * y_ld + c);
+        if (RES) vr[u] = *(const uint4*)(res + rr * res_ld + c);
+      }
+#pragma unroll
+      for (int u = 0; u < BNA_BATCH; ++u) {
+        float v[8], r[8];
+        unpack8_bf16(vy[u], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+        if (RES) {
+          unpack8_bf16(vr[u], r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+        if (RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (row[u] < rows) *(uint4*)(out + row[u] * out_ld + c) = pack8_bf16(v);
+      }
+    }
+  }
+}
+
 extern "C" int vs_bn_apply(const void* y, const float* scale, const float* shift,
                            const void* residual, void* out, int64_t rows, int C, int y_ld,
                            int res_ld, int out_ld, int relu, void* stream) {
   VS_CHECK_ARG(y && scale && shift && out, "null tensor");
   VS_CHECK_ARG(C % 8 == 0 && y_ld % 8 == 0 && out_ld % 8 == 0 && (!residual || res_ld % 8 == 0),
                "channels / pitches must be multiples of 8");
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(rows * (C / 8))), dim3(256), 0,
-                     (hipStream_t)stream, (const uint16_t*)y, scale, shift,
-                     (const uint16_t*)residual, (uint16_t*)out, (long long)rows, C, y_ld, res_ld,
-                     out_ld, relu);
+  hipStream_t st = (hipStream_t)stream;
+  if (cpr_pow2(C)) {
+    const int nb = bn_rows_batches(rows, C, 2048);
+    const int cpr = C / 8, ncol = cpr < 256 ? cpr : 256;
+    const long long rpb = (long long)(256 / ncol) * BNA_BATCH * nb;
+    const dim3 grid((unsigned)((rows + rpb - 1) / rpb)), block(256);
+#define BNA_ARGS (const uint16_t*)y, scale, shift, (const uint16_t*)residual, (uint16_t*)out,                  (long long)rows, C, y_ld, res_ld, out_ld, nb
+    if (residual && relu) hipLaunchKernelGGL((bn_apply_cols_kernel<true, true>), grid, block, 0, st, BNA_ARGS);
+    else if (residual) hipLaunchKernelGGL((bn_apply_cols_kernel<true, false>), grid, block, 0, st, BNA_ARGS);
+    else if (relu) hipLaunchKernelGGL((bn_apply_cols_kernel<false, true>), grid, block, 0, st, BNA_ARGS);
+    else hipLaunchKernelGGL((bn_apply_cols_kernel<false, false>), grid, block, 0, st, BNA_ARGS);
+#undef BNA_ARGS
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+  }
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(rows * (C / 8))), dim3(256), 0, st,
+                     (const uint16_t*)y, scale, shift, (const uint16_t*)residual, (uint16_t*)out,
+                     (long long)rows, C, y_ld, res_ld, out_ld, relu);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }
@@ -474,6 +557,70 @@ __global__ void bn_bwd_apply_kernel(const uint16_t* dz, const uint16_t* z, const
   }
 }
 
+// Column-owner form of the backward apply (see bn_apply_cols_kernel): per-channel constants
+// a = gamma*invstd, b1 = dbeta/M, b2 = dgamma/M live in registers.
+template <int MASK, bool DRES>
+__global__ __launch_bounds__(256) void bn_bwd_apply_cols_kernel(
+    const uint16_t* dz, const uint16_t* z, const uint16_t* y, const float* mean, const float* invstd,
+    const float* gamma, const float* beta, const float* dgamma, const float* dbeta, uint16_t* dy,
+    uint16_t* dres, long long rows, int C, int dz_ld, int z_ld, int y_ld, int dy_ld, int dres_ld,
+    int nbatch) {
+  const int cpr = C >> 3;
+  const int ncol = cpr < 256 ? cpr : 256;
+  const int rl = 256 / ncol;
+  const int col = threadIdx.x % ncol, lane_r = threadIdx.x / ncol;
+  const long long r0 = (long long)blockIdx.x * rl * BNA_BATCH * nbatch;
+  const float invM = 1.0f / (float)rows;
+  for (int cb = col; cb < cpr; cb += ncol) {
+    const int c = cb * 8;
+    float mu[8], is[8], ga[8], be[8], b1[8], b2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      mu[e] = mean[c + e];
+      is[e] = invstd[c + e];
+      ga[e] = gamma[c + e];
+      be[e] = (MASK == 2) ? beta[c + e] : 0.f;
+      b1[e] = dbeta[c + e] * invM;
+      b2[e] = dgamma[c + e] * invM;
+    }
+    for (int b = 0; b < nbatch; ++b) {
+      uint4 vg[BNA_BATCH], vy[BNA_BATCH], vz[BNA_BATCH];
+      long long row[BNA_BATCH];
+#pragma unroll
+      for (int u = 0; u < BNA_BATCH; ++u) {
+        row[u] = r0 + (long long)(b * BNA_BATCH + u) * rl + lane_r;
+        const long long rr = row[u] < rows ? row[u] : 0;
+        vg[u] = *(const uint4*)(dz + rr * dz_ld + c);
+        vy[u] = *(const uint4*)(y + rr * y_ld + c);
+        if (MASK == 1) vz[u] = *(const uint4*)(z + rr * z_ld + c);
+      }
+#pragma unroll
+      for (int u = 0; u < BNA_BATCH; ++u) {
+        float g[8], yv[8], o[8];
+        unpack8_bf16(vg[u], g);
+        unpack8_bf16(vy[u], yv);
+        if (MASK == 1) {
+          float zv[8];
+          unpack8_bf16(vz[u], zv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) g[e] = zv[e] > 0.f ? g[e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (yv[e] - mu[e]) * is[e];
+          if (MASK == 2) g[e] = (xh * ga[e] + be[e]) > 0.f ? g[e] : 0.f;
+          // (dbeta/M and dgamma/M are folded per channel: last-bit differences vs the generic kernel)
+          o[e] = ga[e] * is[e] * (g[e] - b1[e] - xh * b2[e]);
+        }
+        if (row[u] < rows) {
+          *(uint4*)(dy + row[u] * dy_ld + c) = pack8_bf16(o);
+          if (DRES) *(uint4*)(dres + row[u] * dres_ld + c) = pack8_bf16(g);
+        }
+      }
+    }
+  }
+}
+
 extern "C" int vs_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* mean,
                                const float* invstd, const float* gamma, const float* beta,
                                const float* dgamma, const float* dbeta, void* dy, void* dres,
@@ -482,11 +629,27 @@ extern "C" int vs_bn_bwd_apply(const void* dz, const void* z, const void* y, con
   VS_CHECK_ARG(dz && y && mean && invstd && gamma && dgamma && dbeta && dy, "null tensor");
   VS_CHECK_ARG(!relu || z || beta, "relu needs z, or beta to recompute the mask");
   VS_CHECK_ARG(C % 8 == 0, "C must be a multiple of 8");
-  const dim3 grid(ew_grid(rows * (C / 8))), block(256);
   hipStream_t st = (hipStream_t)stream;
 #define BNB_ARGS (const uint16_t*)dz, (const uint16_t*)z, (const uint16_t*)y, mean, invstd, gamma, beta, \
                  dgamma, dbeta, (uint16_t*)dy, (uint16_t*)dres, (long long)rows, C, dz_ld, z_ld, y_ld, \
                  dy_ld, dres_ld
+  if (cpr_pow2(C)) {
+    const int nb = bn_rows_batches(rows, C, 2048);
+    const int cpr = C / 8, ncol = cpr < 256 ? cpr : 256;
+    const long long rpb = (long long)(256 / ncol) * BNA_BATCH * nb;
+    const dim3 grid((unsigned)((rows + rpb - 1) / rpb)), block(256);
+    const int mask = !relu ? 0 : (z ? 1 : 2);
+#define BNB_L(M, D) hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<M, D>), grid, block, 0, st, BNB_ARGS, nb)
+    if (dres) {
+      if (mask == 0) BNB_L(0, true); else if (mask == 1) BNB_L(1, true); else BNB_L(2, true);
+    } else {
+      if (mask == 0) BNB_L(0, false); else if (mask == 1) BNB_L(1, false); else BNB_L(2, false);
+    }
+#undef BNB_L
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+  }
+  const dim3 grid(ew_grid(rows * (C / 8))), block(256);
   if (!relu) hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, grid, block, 0, st, BNB_ARGS);
   else if (z) hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, grid, block, 0, st, BNB_ARGS);
   else hipLaunchKernelGGL(bn_bwd_apply_kernel<2>, grid, block, 0, st, BNB_ARGS);
