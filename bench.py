@@ -266,10 +266,12 @@ def main():
         opt = ArenaAdam(arena, lr=cfg.train.lr, betas=(0.9, 0.99))
 
         def fwd_bwd():
+            arena.transposes_async()  # dgrad weight images of the last update, beside the forward
             opt.zero_grad()
             out = mdl(batch)
             loss = loss_fn(out, batch)["loss"]
             loss.backward()
+            arena._join_transposes()  # no-op unless no dgrad ran (keeps a captured graph closed)
             return loss
 
         if overlap:
@@ -296,14 +298,14 @@ def main():
                 for w in works:
                     if w is not None:
                         w.wait()
-                opt.step(world=world)
+                opt.step(world=world, defer_transposes=True)
                 return out
         else:
             def step():
                 loss = fwd_bwd()
                 if gate["on"]:
                     arena.all_reduce()
-                opt.step(world=world)
+                opt.step(world=world, defer_transposes=True)
                 return loss
     else:
         mdl.eval()
@@ -327,7 +329,7 @@ def main():
         # one hipGraph per segment + one for Adam; the RCCL calls stay outside the graphs
         try:
             seg_graphs, pool = [], None
-            for fn, _ in segments + [(lambda: opt.step(world=world), None)]:
+            for fn, _ in segments + [(lambda: opt.step(world=world, defer_transposes=True), None)]:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool):
                     fn()

@@ -234,6 +234,10 @@ int vs_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
 int vs_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr,
                      float beta1, float beta2, float eps, int* step_counter, float grad_scale,
                      void* stream);
+/* Same step, also writing the bf16 kernel-layout copy of the updated parameters (p_bf16[n]). */
+int vs_adam_step_dev_cast(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n,
+                          float lr, float beta1, float beta2, float eps, int* step_counter,
+                          float grad_scale, void* stream);
 /* fp32 -> bf16 cast of the parameter arena (weights used by the conv kernels). */
 int vs_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 

@@ -238,3 +238,26 @@ def test_adam_matches_torch(dev):
         ops.adam_step_dev(p2, torch.randn(10007, generator=g2).to(dev), m2, v2, 1e-3, 0.9, 0.99, 1e-8, cnt)
     assert int(cnt) == 3
     assert_close(p2, pr.detach(), 1e-6, "adam (device step counter)")
+
+
+def test_adam_with_fused_bf16_cast_and_arena_refresh(dev):
+    """vs_adam_step_dev_cast == vs_adam_step_dev + vs_cast_f32_to_bf16 (bitwise), device step
+    counter shared."""
+    from vidsitu_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    n = 4096 + 8
+    p0 = torch.randn(n, generator=g).to(dev)
+    gr = torch.randn(n, generator=g).to(dev)
+    pa, pb = p0.clone(), p0.clone()
+    ma, va, mb, vb = (torch.zeros(n, device=dev) for _ in range(4))
+    ta = torch.zeros(1, dtype=torch.int32, device=dev)
+    tb = torch.zeros(1, dtype=torch.int32, device=dev)
+    bf = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+    ref_bf = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+    for _ in range(3):
+        ops.adam_step_dev(pa, gr, ma, va, 1e-2, 0.9, 0.99, 1e-8, ta, grad_scale=0.5)
+        ops.adam_step_dev_cast(pb, gr, mb, vb, bf, 1e-2, 0.9, 0.99, 1e-8, tb, grad_scale=0.5)
+    ops.cast_bf16(pa, ref_bf)
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    assert torch.equal(bf.view(torch.int16), ref_bf.view(torch.int16)) and int(tb) == 3

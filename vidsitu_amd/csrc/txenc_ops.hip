@@ -834,12 +834,36 @@ extern "C" int vs_adam_step(float* p, const float* g, float* m, float* v, int64_
 // otherwise replay the bias correction of the step it was captured at).
 __global__ void adam_tick_kernel(int* step) { step[0] += 1; }
 
-__global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, long long n, float lr,
-                                float b1, float b2, float eps, const int* step, float grad_scale) {
+// float4-wide; optionally also emits the bf16 kernel copy of the updated parameters (saves the
+// separate cast pass over the arena)
+__global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, uint16_t* pb,
+                                long long n4, long long n, float lr, float b1, float b2, float eps,
+                                const int* step, float grad_scale) {
   const float t = (float)step[0];
   const float bc1 = 1.f - powf(b1, t);
   const float bc2_sqrt = sqrtf(1.f - powf(b2, t));
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+  const float a = lr / bc1;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float4 g4 = ((const float4*)g)[i];
+    float4 m4 = ((float4*)m)[i], v4 = ((float4*)v)[i], p4 = ((float4*)p)[i];
+    const float gg[4] = {g4.x * grad_scale, g4.y * grad_scale, g4.z * grad_scale, g4.w * grad_scale};
+    float mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+    float pp[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      mm[e] = b1 * mm[e] + (1.f - b1) * gg[e];
+      vv[e] = b2 * vv[e] + (1.f - b2) * gg[e] * gg[e];
+      const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+      pp[e] -= a * (mm[e] / denom);
+    }
+    ((float4*)m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    ((float4*)v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    ((float4*)p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    if (pb) ((uint2*)pb)[i] = make_uint2(pack2_bf16(pp[0], pp[1]), pack2_bf16(pp[2], pp[3]));
+  }
+  // scalar tail (n not a multiple of 4, or unaligned buffers: then n4 == 0 and this is everything)
+  for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
     const float gi = g[i] * grad_scale;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -847,21 +871,41 @@ __global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, lo
     m[i] = mi;
     v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] -= (lr / bc1) * (mi / denom);
+    const float pi = p[i] - a * (mi / denom);
+    p[i] = pi;
+    if (pb) pb[i] = f32_to_bf16(pi);
   }
+}
+
+static int adam_dev_launch(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n,
+                           float lr, float beta1, float beta2, float eps, int* step_counter,
+                           float grad_scale, void* stream) {
+  const bool aligned = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 &&
+                       (((uintptr_t)p_bf16) & 7) == 0;
+  const long long n4 = aligned ? n / 4 : 0;
+  long long grid = ((aligned ? n4 : (long long)n) + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_counter);
+  hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m,
+                     v, (uint16_t*)p_bf16, n4, (long long)n, lr, beta1, beta2, eps,
+                     (const int*)step_counter, grad_scale);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
 }
 
 extern "C" int vs_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr,
                                 float beta1, float beta2, float eps, int* step_counter,
                                 float grad_scale, void* stream) {
   VS_CHECK_ARG(p && g && m && v && n > 0 && step_counter, "bad args");
-  long long grid = (n + 255) / 256;
-  if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_counter);
-  hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m,
-                     v, (long long)n, lr, beta1, beta2, eps, (const int*)step_counter, grad_scale);
-  VS_CHECK_LAUNCH();
-  return VS_OK;
+  return adam_dev_launch(p, g, m, v, nullptr, n, lr, beta1, beta2, eps, step_counter, grad_scale, stream);
+}
+
+extern "C" int vs_adam_step_dev_cast(float* p, const float* g, float* m, float* v, void* p_bf16,
+                                     int64_t n, float lr, float beta1, float beta2, float eps,
+                                     int* step_counter, float grad_scale, void* stream) {
+  VS_CHECK_ARG(p && g && m && v && p_bf16 && n > 0 && step_counter, "bad args");
+  return adam_dev_launch(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, step_counter, grad_scale, stream);
 }
 
 __global__ void cast_f32_bf16_kernel(const float* x, uint16_t* y, long long n) {

@@ -51,6 +51,7 @@ class ParamArena:
                 p._vs_direct_grad = True  # HIP backward kernels may write p.grad in place
         self.numel = total
         self._tr_table, self._loose_convs, self.data_bf16 = None, [], None
+        self._tr_stream, self._tr_pending = None, False
         if adopt_conv:
             self._adopt_conv_weights(dev)
 
@@ -134,20 +135,49 @@ class ParamArena:
             dist.broadcast(self.data, src=src)
             self.refresh()
 
-    def refresh(self):
+    def refresh(self, cast=True, transposes=True):
         """After the fp32 arena changed (optimizer step, broadcast, load): one cast, one
-        batched transpose, the two padded stems, and the trunks are marked up to date."""
+        batched transpose, the two padded stems, and the trunks are marked up to date.
+        cast=False: the bf16 arena was already written (fused into the Adam kernel);
+        transposes=False: the dgrad images are refreshed later by `transposes_async`."""
         if self.data_bf16 is None:
             return
-        ops.cast_bf16(self.data, self.data_bf16)
-        if self._tr_table is not None:
-            ops.weight_transpose_batched(self.data_bf16, self.wt_bf16, self._tr_table, self._tr_total)
+        if cast:
+            ops.cast_bf16(self.data, self.data_bf16)
+        if transposes:
+            self._join_transposes()
+            self._run_transposes()
         for m in self._loose_convs:
             m.refresh()
         for m in self.model.modules():
             if hasattr(m, "_version_key") and hasattr(m, "_weights_version"):
                 m._weights_version = m._version_key()
 
+    def _run_transposes(self):
+        if self._tr_table is not None:
+            ops.weight_transpose_batched(self.data_bf16, self.wt_bf16, self._tr_table, self._tr_total)
+
+    # The transposed (dgrad) weight images are only read by the backward pass: refresh them on a
+    # side stream at the START of a step, beside the forward pass; the first dgrad joins.
+    def transposes_async(self):
+        if self._tr_table is None:
+            return
+        from .trunk import Conv3dP
+
+        self._join_transposes()
+        main = torch.cuda.current_stream()
+        if self._tr_stream is None:
+            self._tr_stream = torch.cuda.Stream(device=main.device)
+        self._tr_stream.wait_stream(main)
+        with torch.cuda.stream(self._tr_stream):
+            self._run_transposes()
+        self._tr_pending = True
+        Conv3dP._wt_guard = self._join_transposes
+
+    def _join_transposes(self):
+        if self._tr_pending:
+            torch.cuda.current_stream().wait_stream(self._tr_stream)
+            self._tr_pending = False
 
 class ArenaAdam:
     """torch.optim.Adam semantics (lr, betas, eps; no weight decay) on the arena."""
@@ -161,7 +191,15 @@ class ArenaAdam:
     def zero_grad(self):
         self.arena.zero_grad()
 
-    def step(self, world=1):
-        ops.adam_step_dev(self.arena.data, self.arena.grad, self.m, self.v, self.lr, self.betas[0],
-                          self.betas[1], self.eps, self.t, grad_scale=1.0 / world)
-        self.arena.refresh()
+    def step(self, world=1, defer_transposes=False):
+        """defer_transposes: leave the dgrad weight images stale; the caller refreshes them with
+        `arena.transposes_async()` at the start of the next step (bench.py)."""
+        a = self.arena
+        if a.data_bf16 is not None:
+            ops.adam_step_dev_cast(a.data, a.grad, self.m, self.v, a.data_bf16, self.lr, self.betas[0],
+                                   self.betas[1], self.eps, self.t, grad_scale=1.0 / world)
+            a.refresh(cast=False, transposes=not defer_transposes)
+        else:
+            ops.adam_step_dev(a.data, a.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1],
+                              self.eps, self.t, grad_scale=1.0 / world)
+            a.refresh()

@@ -85,7 +85,11 @@ class Conv3dP(nn.Module):
         else:
             self.wt_bf16 = None
 
+    _wt_guard = None  # set by ParamArena while an asynchronous refresh of the images is pending
+
     def wt(self):
+        if Conv3dP._wt_guard is not None:
+            Conv3dP._wt_guard()
         if self.wt_bf16 is None:
             self.wt_bf16 = ops.weight_transpose(self.w_bf16)
         return self.wt_bf16
