@@ -465,6 +465,39 @@ def linear_bwd(dy, x, w, need_dx=True, has_bias=True, dw_out=None, db_out=None):
 _ones_cache = {}
 
 
+class DropoutPool:
+    """All dropout masks of one forward pass from ONE generator launch: the first pass records the
+    (shape, p) sequence it is asked for; later passes with the same sequence draw a single flat
+    mask of the total size (`F.dropout` on cached ones, hipGraph-safe) and hand out views.  A
+    pass that asks for anything else falls back to one launch per mask."""
+
+    def __init__(self):
+        self.plan, self.seen, self.flat, self.pos, self.idx = None, [], None, 0, 0
+
+    def begin(self, device):
+        if self.seen and self.plan is None:
+            ps = {p for _, p in self.seen}
+            if len(ps) == 1:
+                self.plan = list(self.seen)
+        self.seen, self.idx, self.pos, self.flat = [], 0, 0, None
+        if self.plan is not None:
+            total = sum(int(torch.Size(sh).numel()) for sh, _ in self.plan)
+            self.flat = dropout_mask((total,), self.plan[0][1], device)
+
+    def get(self, shape, p, device):
+        shape = tuple(shape)
+        self.seen.append((shape, p))
+        if self.flat is not None and self.idx < len(self.plan) and self.plan[self.idx] == (shape, p):
+            n = int(torch.Size(shape).numel())
+            out = self.flat[self.pos: self.pos + n].view(shape)
+            self.pos += n
+            self.idx += 1
+            return out
+        self.flat = None  # sequence changed: per-mask launches for the rest of this pass
+        self.plan = None
+        return dropout_mask(shape, p, device)
+
+
 def dropout_mask(shape, p, device):
     """0 or 1/(1-p) per element, from torch's (hipGraph-safe) generator -- one launch."""
     key = (tuple(shape), str(device))
@@ -506,14 +539,15 @@ def add_layernorm_fwd(x, r, gamma, beta, eps=1e-5, rmask=None):
     return y, mean, rstd
 
 
-def add_layernorm_bwd(dy, x, r, gamma, mean, rstd, rmask=None):
-    """Returns (dx, dr, dgamma, dbeta); dr = dx * rmask."""
+def add_layernorm_bwd(dy, x, r, gamma, mean, rstd, rmask=None, dg_out=None, db_out=None):
+    """Returns (dx, dr, dgamma, dbeta); dr = dx * rmask.  dg_out / db_out: write the parameter
+    gradients in place (gradient-arena views, overwrite semantics)."""
     dy = _f32c(dy)
     rows, d = x.shape
     dx = torch.empty_like(x)
     dr = torch.empty_like(x) if rmask is not None else None
-    dg = torch.empty(d, dtype=torch.float32, device=x.device)
-    db = torch.empty(d, dtype=torch.float32, device=x.device)
+    dg = torch.empty(d, dtype=torch.float32, device=x.device) if dg_out is None else dg_out
+    db = torch.empty(d, dtype=torch.float32, device=x.device) if db_out is None else db_out
     _lib.call("vs_add_layernorm_bwd", _ptr(dy), _ptr(x), _ptr(r), _ptr(rmask), _ptr(gamma),
               _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dr), _ptr(dg), _ptr(db), rows, d, _stream())
     return dx, (dr if dr is not None else dx), dg, db

@@ -78,13 +78,24 @@ class AddLayerNormFn(torch.autograd.Function):
         y, mean, rstd = ops.add_layernorm_fwd(x2, r2, gamma, beta, eps, rmask)
         ctx.save_for_backward(x2, r2, gamma, mean, rstd, rmask)
         ctx.shp = shp
+        # arena parameters take their gradient in place (overwrite), like LinearFn
+        direct = getattr(gamma, "_vs_direct_grad", False) and getattr(beta, "_vs_direct_grad", False)
+        ctx.params = (gamma, beta) if direct else None
         return y.reshape(shp)
 
     @staticmethod
     def backward(ctx, dy):
         x2, r2, gamma, mean, rstd, rmask = ctx.saved_tensors
-        dx, dr, dg, db = ops.add_layernorm_bwd(dy.reshape(x2.shape), x2, r2, gamma, mean, rstd, rmask)
+        direct = ctx.params is not None and ctx.params[0].grad is not None and ctx.params[1].grad is not None
+        dx, dr, dg, db = ops.add_layernorm_bwd(
+            dy.reshape(x2.shape), x2, r2, gamma, mean, rstd, rmask,
+            dg_out=ctx.params[0].grad if direct else None, db_out=ctx.params[1].grad if direct else None)
+        if direct:
+            return dx.reshape(ctx.shp), dr.reshape(ctx.shp), None, None, None, None
         return dx.reshape(ctx.shp), dr.reshape(ctx.shp), dg, db, None, None
+
+
+_masks = ops.DropoutPool()  # one generator launch per encoder pass
 
 
 def hip_linear(mod, x, relu=False):
@@ -117,7 +128,7 @@ class MultiHead(nn.Module):
         p = self.attention.dropout.p
         if self.training and p > 0:  # transformer_code.py:48 dropout(softmax(...))
             b, l, _ = q.shape
-            mask = ops.dropout_mask((b, self.n_heads, l, l), p, q.device)
+            mask = _masks.get((b, self.n_heads, l, l), p, q.device)
         o = AttnSmallFn.apply(q, k, v, self.n_heads, self.attention.scale, mask)
         return hip_linear(self.wo, o)
 
@@ -143,8 +154,8 @@ class ResidualBlock(nn.Module):
         branch = self.layer(*x)
         rmask = None
         if self.training and self.dropout.p > 0:  # transformer_code.py:30 x + dropout(layer(x))
-            rmask = ops.dropout_mask((branch.numel() // branch.shape[-1], branch.shape[-1]),
-                                     self.dropout.p, branch.device)
+            rmask = _masks.get((branch.numel() // branch.shape[-1], branch.shape[-1]),
+                                self.dropout.p, branch.device)
         return AddLayerNormFn.apply(x[0], branch, self.layernorm.weight, self.layernorm.bias,
                                     self.layernorm.eps, rmask)
 
@@ -174,6 +185,8 @@ class Encoder(nn.Module):
         if not x.is_cuda:
             raise ops._lib.VsError("the TxEncoder runs on the HIP kernels only (GPU tensor required)")
         x = x.float().contiguous()
+        if self.training:
+            _masks.begin(x.device)
         if mask is not None:
             x = x * mask
         encoding = [x]
