@@ -24,6 +24,7 @@ sf_mdl_to_cfg_fpath_dct = {
     "slow_fast_nl_r50_8x8": "./configs/vsitu_mdl_cfgs/Kinetics_c2_SLOWFAST_8x8_R50.yaml",
     "i3d_r50_8x8": "./configs/vsitu_mdl_cfgs/Kinetics_c2_I3D_8x8_R50.yaml",
     "i3d_tiny": "./configs/vsitu_mdl_cfgs/I3D_tiny.yaml",
+    "slow_fast_mini": "./configs/vsitu_mdl_cfgs/SLOWFAST_mini.yaml",
 }
 tx_to_cfg_fpath_dct = {"transformer": "./configs/vsitu_tx_cfgs/transformer.yaml"}
 
