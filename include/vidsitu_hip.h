@@ -51,6 +51,7 @@ typedef enum vs_status {
  * {128x128, 64x128, 128x64, 64x64, 256x32, 256x16, 256x128, 128x256} (BM x BN). */
 #define VS_CONV_TILE(id) (((id) + 1) << 8)
 #define VS_CONV_RING(ns) (((ns) & 7) << 16) /* staging: 0 heuristic, 1 register pipeline, 2..4 LDS-DMA ring stages */
+#define VS_CONV_NOCLASS (1 << 19) /* dgrad of a strided conv: disable the stride-class tiling (debug / A-B) */
 #define VS_CONV_SPLITK (1 << 15) /* allow the split-K plan (fp32 slabs + fused reduce/epilogue) */
 
 /* Geometry of one Conv3d (bias-free, groups 1, dilation 1).

@@ -202,6 +202,43 @@ def test_splitk_path_epilogue(dev):
         assert_close(y1, y3.float(), 8e-3, case[0] + " split-K vs single pass")
 
 
+STRIDED = [
+    # name, N, Cin, T, H, W, Cout, k, s, p
+    ("s2_3x3_128", 2, 128, 2, 14, 14, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ("s2_3x3_odd", 1, 64, 3, 13, 11, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ("s2_1x1_256_512", 1, 256, 2, 14, 14, 512, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
+    ("s2_1x1_odd", 1, 64, 2, 9, 7, 128, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
+    ("s4_t7_fuse", 1, 32, 16, 5, 5, 64, (7, 1, 1), (4, 1, 1), (3, 0, 0)),
+    ("s222_3x3x3", 1, 64, 6, 10, 10, 64, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+]
+
+
+@pytest.mark.parametrize("case", STRIDED, ids=[c[0] for c in STRIDED])
+def test_strided_dgrad_stride_classes(case, dev):
+    """dgrad of a strided conv tiles the input positions by stride class (each class walks only
+    the taps that can reach it).  Checked against autograd, against the un-classed gather
+    (VS_CONV_NOCLASS) and with the fused residual, on every tile config / staging variant."""
+    from vidsitu_amd import ops
+
+    x, w, k, s, p = _mk(case, seed=31)
+    x.requires_grad_()
+    y = F.conv3d(x, w, stride=s, padding=p)
+    dy = rb(torch.randn(y.shape, generator=torch.Generator().manual_seed(32)))
+    (dx_ref,) = torch.autograd.grad(y, x, dy)
+    wt = ops.weight_transpose(to_w(w, dev))
+    dya = to_act(dy, dev)
+    r = rb(torch.randn(x.shape, generator=torch.Generator().manual_seed(33)))
+    ra = to_act(r, dev)
+    for tile in (None, 0, 1, 2, 3):
+        for ring in (1, 2, 3):
+            dx = ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, tile=tile, ring=ring)
+            assert_close(dx, dx_ref, TOL, f"{case[0]} tile {tile} ring {ring}")
+            dxr = ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, tile=tile, ring=ring, residual=ra)
+            assert_close(dxr, dx_ref + r, TOL, f"{case[0]} tile {tile} ring {ring} +residual")
+    old = ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, noclass=True)
+    assert_close(old, dx_ref, TOL, case[0] + " un-classed gather")
+
+
 RING_CASES = [CASES[i] for i in (0, 1, 4, 5, 6, 9, 10, 11, 14, 15, 17)]
 
 

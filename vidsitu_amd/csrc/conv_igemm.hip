@@ -38,6 +38,12 @@ struct ConvP {
   unsigned x_bytes, w_bytes;  // extents for the buffer resources (FAST path)
   int splitK;                 // > 1: blocks (tile, s) write fp32 partial tiles to `slab`
   float* slab;                // [splitK][M][Ncols]
+  // MODE 2 (dgrad of a strided conv), stride classes: rows whose coordinate (r + pad) has the same
+  // residues mod (sT, sH, sW) use the same subset of taps (dd == residue mod s); tiles never mix
+  // classes, so a tile walks only ITS taps -- 9/4 instead of 9 for a 3x3 stride-(1,2,2) conv,
+  // 1/4 of the rows (no tap at all) for a 1x1 stride-2 one.  ncls = 0: classes off.
+  int ncls;
+  int cls_tile0[17];          // first M-tile of each class, [ncls] = number of M-tiles
 };
 
 template <int BM, int BN, int NSTAGE = 2>
@@ -83,29 +89,64 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   const int ksplit = swz % p.splitK;  // the splits of one tile are neighbours (same XCD run)
   const int tile_id = swz / p.splitK;
   const int tn = tile_id % p.tilesN, tm = tile_id / p.tilesN;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int n0 = tn * BN;
   const int kc = tid & 7, lrow = tid >> 3;
-  const int K8 = p.K >> 3;
+
+  // ---- stride class of this tile (MODE 2 only) ----
+  const bool cls = (MODE == 2) && p.ncls > 0;
+  int m0 = tm * BM;
+  int Mloc = p.M;                                // rows of the row space this tile indexes
+  int cT = p.Rt, cH = p.Rh, cW = p.Rw;           // extents of that row space
+  int r0T = 0, r0H = 0, r0W = 0, stT = 1, stH = 1, stW = 1;  // r = r0 + st * i
+  int qT = 0, qH = 0, qW = 0, ntT = p.kT, ntH = p.kH, ntW = p.kW;  // taps: dd = q + st * i
+  if (cls) {
+    stT = 1 << p.shT; stH = 1 << p.shH; stW = 1 << p.shW;
+    int cq = 0;
+    while (cq + 1 < p.ncls && tm >= p.cls_tile0[cq + 1]) ++cq;
+    m0 = (tm - p.cls_tile0[cq]) * BM;
+    qW = cq % stW; qH = (cq / stW) % stH; qT = cq / (stW * stH);
+    auto first = [](int q, int off, int st) { return ((q - off) % st + st) % st; };
+    auto count = [](int R, int r0, int st) { return r0 < R ? (R - r0 + st - 1) / st : 0; };
+    r0T = first(qT, p.offT, stT); r0H = first(qH, p.offH, stH); r0W = first(qW, p.offW, stW);
+    cT = count(p.Rt, r0T, stT); cH = count(p.Rh, r0H, stH); cW = count(p.Rw, r0W, stW);
+    Mloc = (p.M / (p.Rt * p.Rh * p.Rw)) * cT * cH * cW;
+    ntT = qT < p.kT ? (p.kT - qT + stT - 1) / stT : 0;
+    ntH = qH < p.kH ? (p.kH - qH + stH - 1) / stH : 0;
+    ntW = qW < p.kW ? (p.kW - qW + stW - 1) / stW : 0;
+  }
+  const int Keff = cls ? ntT * ntH * ntW * p.Cg : p.K;  // this tile's reduction length
+  const int K8 = Keff >> 3;
 
   float* statbuf = (float*)(smem + MAIN);               // [2][WM][BN]
-  int2* ktab = (int2*)(smem + MAIN + 2 * WM * BN * 4);  // [K8]
+  int* rowpos = (int*)(smem + MAIN + 2 * WM * BN * 4);  // [BM] output position of each tile row
+  int2* ktab = (int2*)(smem + MAIN + 2 * WM * BN * 4 + (MODE == 2 ? BM * 4 : 0));  // [K8]
 
   if (MODE != 0) {
     const int C8 = p.Cg >> 3;
-    const int K8pad = (((p.K + 63) >> 6) + (NS > 0 ? NS - 1 : 0)) << 3;  // + the ring's run-ahead
+    const int K8pad = (((Keff + 63) >> 6) + (NS > 0 ? NS - 1 : 0)) << 3;  // + the ring's run-ahead
     for (int k8 = tid; k8 < K8pad; k8 += 256) {
       if (k8 >= K8) {  // K tail: tap 31 is never valid (FAST requires <= 31 taps)
         ktab[k8] = FAST ? make_int2(31, 0) : make_int2(0, 0);
         continue;
       }
-      const int tap = k8 / C8, c8 = k8 - tap * C8;
-      const int dw = tap % p.kW, t2 = tap / p.kW;
-      const int dh = t2 % p.kH, dt = t2 / p.kH;
+      int tap = k8 / C8;
+      const int c8 = k8 - tap * C8;
+      int dw, dh, dt;
+      if (cls) {  // enumerate only the taps of this class
+        const int iw = tap % ntW, t2 = tap / ntW;
+        dw = qW + stW * iw; dh = qH + stH * (t2 % ntH); dt = qT + stT * (t2 / ntH);
+        tap = (dt * p.kH + dh) * p.kW + dw;
+      } else {
+        dw = tap % p.kW;
+        const int t2 = tap / p.kW;
+        dh = t2 % p.kH; dt = t2 / p.kH;
+      }
       if (FAST) {
         long long dpos;
         if (MODE == 1) dpos = (((long long)dt * p.Gh + dh) * p.Gw + dw) * p.tmul;
         else dpos = -(((long long)(dt >> p.shT) * p.Gh + (dh >> p.shH)) * p.Gw + (dw >> p.shW));
-        ktab[k8] = make_int2(tap, (int)((dpos * p.g_ld + c8 * 8) * 2));
+        // .x = tap (5 bits, the row's validity bit) | 16-byte unit of this k inside a weight row
+        ktab[k8] = make_int2(tap | ((tap * C8 + c8) << 5), (int)((dpos * p.g_ld + c8 * 8) * 2));
       } else {
         ktab[k8] = make_int2(dt | (dh << 8) | (dw << 16), c8 * 8);
       }
@@ -123,10 +164,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     rbase[i] = -1;
     roff[i] = VS_OOB;
     vmask[i] = 0u;
-    if (m < p.M) {
-      int rw = m % p.Rw, t1 = m / p.Rw;
-      int rh = t1 % p.Rh, t2 = t1 / p.Rh;
-      int rt = t2 % p.Rt, n = t2 / p.Rt;
+    if (MODE == 2 && kc == 0) rowpos[lrow + 32 * i] = -1;
+    if (m < Mloc) {
+      int rw = m % cW, t1 = m / cW;
+      int rh = t1 % cH, t2 = t1 / cH;
+      int rt = t2 % cT, n = t2 / cT;
+      rw = r0W + stW * rw;  // (identity unless the tile belongs to a stride class)
+      rh = r0H + stH * rh;
+      rt = r0T + stT * rt;
+      if (MODE == 2 && kc == 0)
+        rowpos[lrow + 32 * i] = ((n * p.Rt + rt) * p.Rh + rh) * p.Rw + rw;
       if (MODE == 0) {
         const long long pos =
             ((long long)(n * p.Gt + rt * p.mulT) * p.Gh + rh * p.mulH) * p.Gw + rw * p.mulW;
@@ -198,16 +245,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
       int2 e = make_int2(0, k8 * 16);
       if (MODE != 0) e = ktab[k8];  // table is padded to whole k-steps (tap 31 = never valid)
       const unsigned kbit = (MODE == 0) ? (unsigned)kval : 1u;
+      const unsigned wk = (MODE == 0) ? (unsigned)k8 : ((unsigned)e.x >> 5);
 #pragma unroll
       for (int i = 0; i < AI; ++i) {
-        const unsigned ok = kbit & (vmask[i] >> e.x) & 1u;
+        const unsigned ok = kbit & (vmask[i] >> (e.x & 31)) & 1u;
         const unsigned off = ok ? roff[i] + (unsigned)e.y : VS_OOB;
         ra[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0));
       }
 #pragma unroll
       for (int j = 0; j < BJ; ++j) {
         const unsigned ok = (unsigned)kval & (unsigned)(boff[j] != VS_OOB);
-        const unsigned off = ok ? boff[j] + (unsigned)(k8 * 16) : VS_OOB;
+        const unsigned off = ok ? boff[j] + wk * 16u : VS_OOB;
         rb[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wsrc, off, 0, 0));
       }
       return;
@@ -317,7 +365,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     }
   };
 
-  const int nk_all = (p.K + 63) >> 6;
+  if (MODE == 2 && cls && Keff == 0) {
+    // no tap reaches this stride class (e.g. odd positions of a 1x1 stride-2 conv): the gradient
+    // is zero, the tile is a copy of the residual (or zeros) -- no staging, no MFMA, no LDS tile
+    __syncthreads();  // rowpos
+    constexpr int CPRz = BN / 8;
+    for (int idx = tid; idx < BM * CPRz; idx += 256) {
+      const int row = idx / CPRz, c8 = idx - row * CPRz;
+      const int m = rowpos[row], n = n0 + c8 * 8;
+      if (m >= 0 && n < p.Ncols) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (p.flags & VS_CONV_RESIDUAL) v = *(const uint4*)(p.res + (long long)m * p.res_ld + n);
+        *(uint4*)(p.y + (long long)m * p.y_ld + n) = v;
+      }
+    }
+    return;
+  }
+  const int nk_all = (Keff + 63) >> 6;
   const int kbeg = (int)((long long)nk_all * ksplit / p.splitK);
   const int nk = (int)((long long)nk_all * (ksplit + 1) / p.splitK) - kbeg;  // this block's k-steps
   __syncthreads();  // ktab visible
@@ -356,18 +420,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
       int2 e = make_int2(0, k8 * 16);
       if (MODE != 0) e = ktab[k8];
       const unsigned kbit = (MODE == 0) ? (unsigned)kval : 1u;
+      const unsigned wk = (MODE == 0) ? (unsigned)k8 : ((unsigned)e.x >> 5);
       const unsigned A = lds0 + (unsigned)(stage * STAGE);
       const unsigned B = A + BM * 128;
 #pragma unroll
       for (int i = 0; i < AI; ++i) {
-        const unsigned ok = kbit & (vmask[i] >> e.x) & 1u;
+        const unsigned ok = kbit & (vmask[i] >> (e.x & 31)) & 1u;
         const unsigned off = ok ? roff[i] + (unsigned)e.y : VS_OOB;
         dma16(xdesc, A + i * 4096, off);
       }
 #pragma unroll
       for (int j = 0; j < BJ; ++j) {
         const unsigned ok = (unsigned)kval & (unsigned)(boff[j] != VS_OOB);
-        const unsigned off = ok ? boff[j] + (unsigned)(k8 * 16) : VS_OOB;
+        const unsigned off = ok ? boff[j] + wk * 16u : VS_OOB;
         dma16(wdesc, B + j * 4096, off);
       }
     };
@@ -440,8 +505,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     constexpr int QPR = BN / 4;
     for (int idx = tid; idx < BM * QPR; idx += 256) {
       const int row = idx / QPR, c4 = idx - row * QPR;
-      const int m = m0 + row, n = n0 + c4 * 4;
-      if (m < p.M && n < p.Ncols)
+      const int m = (MODE == 2) ? rowpos[row] : (m0 + row < p.M ? m0 + row : -1), n = n0 + c4 * 4;
+      if (m >= 0 && n < p.Ncols)
         *(float4*)(dst + (long long)m * p.Ncols + n) = *(const float4*)(E + row * BN + c4 * 4);
     }
     return;
@@ -501,8 +566,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     __syncthreads();
     for (int idx = tid; idx < BM * CPR; idx += 256) {
       const int row = idx / CPR, c8 = idx - row * CPR;
-      const int m = m0 + row, n = n0 + c8 * 8;
-      if (m < p.M && n < p.Ncols)
+      const int m = (MODE == 2) ? rowpos[row] : (m0 + row < p.M ? m0 + row : -1), n = n0 + c8 * 8;
+      if (m >= 0 && n < p.Ncols)
         *(uint4*)(p.y + (long long)m * p.y_ld + n) = *(const uint4*)(Eh + row * BN + c8 * 8);
     }
   } else {
@@ -527,8 +592,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     __syncthreads();
     for (int idx = tid; idx < BM * CPR; idx += 256) {
       const int row = idx / CPR, c8 = idx - row * CPR;
-      const int m = m0 + row, n = n0 + c8 * 8;
-      if (m < p.M && n < p.Ncols) {
+      const int m = (MODE == 2) ? rowpos[row] : (m0 + row < p.M ? m0 + row : -1), n = n0 + c8 * 8;
+      if (m >= 0 && n < p.Ncols) {
         float v[8];
         const float4 v0 = *(const float4*)(E + row * BN + c8 * 8);
         const float4 v1 = *(const float4*)(E + row * BN + c8 * 8 + 4);
@@ -967,7 +1032,8 @@ static size_t conv_smem_bytes(int bm, int bn, int wm, int ns, int mode, int K) {
   const size_t stage = (size_t)(bm + bn) * 128, epi = (size_t)bm * bn * 4;
   const size_t ring = (size_t)(ns > 2 ? ns : 2) * stage;
   const size_t tab = mode ? (size_t)(((K + 63) >> 6) + (ns > 0 ? ns - 1 : 0)) * 64 : 0;
-  return (ring > epi ? ring : epi) + (size_t)2 * wm * bn * 4 + tab;
+  const size_t rowpos = mode == 2 ? (size_t)bm * 4 : 0;
+  return (ring > epi ? ring : epi) + (size_t)2 * wm * bn * 4 + rowpos + tab;
 }
 
 // ring: 0 = register-staged pipeline, 2..4 = LDS-DMA ring with that many stages
@@ -1094,6 +1160,30 @@ static int launch_conv(ConvP& p, int mode, int naive, int flags, void* ws, size_
   const TileCfg c = pl.tile;
   p.tilesM = (p.M + c.bm - 1) / c.bm;
   p.tilesN = (p.Ncols + c.bn - 1) / c.bn;
+  p.ncls = 0;
+  if (mode == 2 && p.kT * p.kH * p.kW <= 31 && !(flags & VS_CONV_NOCLASS)) {
+    // stride classes of the transposed gather: tiles are laid out class by class
+    const int sT = 1 << p.shT, sH = 1 << p.shH, sW = 1 << p.shW;
+    const int ncls = sT * sH * sW;
+    if (ncls > 1 && ncls <= 16) {
+      const int nb = p.M / (p.Rt * p.Rh * p.Rw);
+      auto cnt = [](int R, int q, int off, int st) {
+        const int r0 = ((q - off) % st + st) % st;
+        return r0 < R ? (R - r0 + st - 1) / st : 0;
+      };
+      int t0 = 0;
+      for (int q = 0; q < ncls; ++q) {
+        const int qw = q % sW, qh = (q / sW) % sH, qt = q / (sW * sH);
+        const long long rows = (long long)nb * cnt(p.Rt, qt, p.offT, sT) * cnt(p.Rh, qh, p.offH, sH) *
+                               cnt(p.Rw, qw, p.offW, sW);
+        p.cls_tile0[q] = t0;
+        t0 += (int)((rows + c.bm - 1) / c.bm);
+      }
+      p.cls_tile0[ncls] = t0;
+      p.ncls = ncls;
+      p.tilesM = t0;
+    }
+  }
   if (pl.S > 1) {
     if (ws == nullptr || ws_bytes < plan_ws_bytes(pl, p.M, p.Ncols)) {
       vs_set_error("conv: split-K workspace too small (%zu < %zu)", ws_bytes,

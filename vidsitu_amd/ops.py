@@ -255,7 +255,8 @@ def weight_transpose_batched(src_arena, dst_arena, table, total):
               table.shape[0], int(total), _stream())
 
 
-def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=None, ring=0):
+def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=None, ring=0,
+               noclass=False):
     """dx[xs] = conv_transpose(dy, w) (+ residual).  wt from weight_transpose."""
     if out is None:
         out = new_act(*xs, device=dy.device)
@@ -263,6 +264,8 @@ def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=N
     flags |= tile_flag("d", xs[0] * xs[2] * xs[3] * xs[4], xs[1], dy.shape[1] * k[0] * k[1] * k[2], k, s,
                        tile)
     flags |= (ring & 7) << 16  # VS_CONV_RING
+    if noclass:
+        flags |= 1 << 19  # VS_CONV_NOCLASS
     d = make_desc(xs, act_ld(out), dy.shape, act_ld(dy), k, s, p, flags,
                   act_ld(residual) if residual is not None else 0)
     need = _lib.load().vs_conv_workspace_bytes(C.byref(d), 1)
