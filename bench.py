@@ -124,14 +124,14 @@ class EntryProbe:
                         "stem_wgrad_kernel (+stem_slab_reduce_kernel)"), "mfma", flops, byts
             if name == "vs_bn_apply":
                 rows, c = _v(a[5]), _v(a[6])
-                return "bn_apply_kernel", "hbm", 0.0, 2.0 * rows * c * (2 + _nn(a[3]))
+                return "bn_apply_cols_kernel", "hbm", 0.0, 2.0 * rows * c * (2 + _nn(a[3]))
             if name == "vs_bn_bwd_reduce":
                 rows, c = _v(a[8]), _v(a[9])
                 return "bn_bwd_reduce_kernel", "hbm", 0.0, 2.0 * rows * c * (2 + _nn(a[1]))
             if name == "vs_bn_bwd_apply":
                 rows, c = _v(a[11]), _v(a[12])
                 n_t = 2 + _nn(a[1]) + 1 + _nn(a[10])  # dz, y (+z) in; dy (+dres) out
-                return "bn_bwd_apply_kernel", "hbm", 0.0, 2.0 * rows * c * n_t
+                return "bn_bwd_apply_cols_kernel", "hbm", 0.0, 2.0 * rows * c * n_t
             if name == "vs_adam_step_dev" or name == "vs_adam_step":
                 return "adam_kernel", "hbm", 0.0, 4.0 * _v(a[4]) * 7  # p,g,m,v in; p,m,v out
             return name.replace("vs_", "") + " (entry point)", None, 0.0, 0.0
