@@ -77,6 +77,14 @@ int vs_version(void);
  * (vidsitu_code/dat_loader.py:454-501 -> mdl_sf_base.py:169-180). */
 int vs_pack_input(const void* x, int x_is_bf16, void* y, int N, int C, int T, int H, int W,
                   int Cpad, void* stream);
+/* uint8 RGB frames [N][Tin][H][W][3] -> normalised bf16 activations [N][Tout][H][W][Cpad]:
+ * ((x / 255 - mean[c]) / std[c], the reference's fp32 operation order,
+ * utils/video_utils.py:147-164 after vidsitu_code/dat_loader.py:183-191); t_index[Tout] (device,
+ * int32) picks frames (the slow pathway's linspace gather, video_utils.py:59-65), NULL = all.
+ * mean3 / std3 are HOST pointers to 3 floats; reverse_channels = cfg.DATA.REVERSE_INPUT_CHANNEL. */
+int vs_frames_u8_pack(const uint8_t* frames, const int* t_index, void* y, int N, int Tin, int Tout,
+                      int H, int W, int Cpad, const float* mean3, const float* std3,
+                      int reverse_channels, void* stream);
 
 /* Stem convolution Conv3d(3 -> Cout, [kT,7,7], stride [1,2,2], pad [kT/2,3,3]) (the two
  * `pathway{p}_stem.conv` of s1).  x4: NDHWC bf16 with C padded to 4 (vs_pack_input, Cpad = 4);

@@ -250,3 +250,33 @@ def test_feature_dump_roundtrip_into_txenc(dev, tmp_path):
     with torch.no_grad():
         out = enc.forward_encoder({"frm_feats": feats, "vseg_idx": torch.arange(3, device=dev)})
     assert tuple(out.encoder_out.shape) == (1, 15, 1024) and torch.isfinite(out.encoder_out).all()
+
+
+def test_uint8_frames_path_is_bitwise_the_fp32_contract(dev):
+    """f1 (second half): uint8 RGB frames normalised / packed / slow-gathered on the GPU give the
+    same bf16 stem inputs, hence the same logits, bit for bit, as the reference's fp32 tensors."""
+    from vidsitu_amd import ops, synth_data
+    from vidsitu_amd.extended_config import get_cfg
+    from vidsitu_amd.mdl_selector import get_mdl_loss_eval
+
+    cfg = get_cfg({"mdl.sf_mdl_name": "slow_fast_mini", "synth.num_verbs": 23})
+    comm = synth_data.make_comm(cfg)
+    torch.manual_seed(0)
+    mdl = get_mdl_loss_eval(cfg)["mdl"](cfg=cfg, comm=comm).to(dev).eval()
+    b8 = synth_data.synth_u8_batch(cfg, comm, bs=1, n_ev=2, crop=32)
+    ref = synth_data.reference_tensors(b8, cfg, comm)
+    fr = b8["frms_ev_fast_u8"].flatten(0, 1).to(dev)
+    # kernel level: both pathways, both packed layouts
+    idx = synth_data.slow_index(fr.shape[1], cfg.sf_mdl.SLOWFAST.ALPHA).to(torch.int32).to(dev)
+    for cpad in (4, 8):
+        got_f = ops.frames_u8_pack(fr, cpad)
+        got_s = ops.frames_u8_pack(fr, cpad, idx)
+        want_f = ops.pack_input(ref["frms_ev_fast_tensor"].flatten(0, 1).to(dev), cpad)
+        want_s = ops.pack_input(ref["frms_ev_slow_tensor"].flatten(0, 1).to(dev), cpad)
+        assert torch.equal(got_f.view(torch.int16), want_f.view(torch.int16))
+        assert torch.equal(got_s.view(torch.int16), want_s.view(torch.int16))
+    # model level
+    with torch.no_grad():
+        a = mdl({k: v.to(dev) for k, v in b8.items()})["mdl_out"]
+        b = mdl({k: v.to(dev) for k, v in ref.items()})["mdl_out"]
+    assert torch.equal(a, b)

@@ -39,6 +39,7 @@ SIGNATURES = {
     "vs_last_error_string": (C.c_char_p, []),
     "vs_version": (_i, []),
     "vs_pack_input": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "vs_frames_u8_pack": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p]),
     "vs_stem_conv_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "vs_stem_stats_rows": (_i, [_i, _i, _i, _i]),
     "vs_stem_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),

@@ -56,6 +56,56 @@ extern "C" int vs_pack_input(const void* x, int x_is_bf16, void* y, int N, int C
 }
 
 // ----------------------------------------------------------------------------
+// uint8 frames -> normalised bf16 channels-last activations (second half).
+// The reference builds its input on the CPU (vidsitu_code/dat_loader.py:183-191,454-501):
+// PIL RGB 224x224 uint8 [T,H,W,3] -> float()/255 -> (x - mean)/std (utils/video_utils.py:147-164)
+// -> permute to C,T,H,W -> slow pathway = index_select(T, linspace(0,T-1,T/alpha).long())
+// (:59-65) -> .float() -> H2D of fp32 (96 MB per video).  Here the uint8 frames are uploaded
+// (4x fewer PCIe bytes) and ONE kernel per pathway produces the stem's packed layout: same fp32
+// operation order ((x/255 - mean) / std, IEEE division), then the bf16 rounding every activation
+// gets anyway -- bit-identical to vs_pack_input of the reference's fp32 tensor.
+// ----------------------------------------------------------------------------
+__global__ void frames_u8_pack_kernel(const uint8_t* fr, const int* tidx, uint16_t* y, int N, int Tin,
+                                      int Tout, long long HW, int Cpad, float m0, float m1, float m2,
+                                      float s0, float s1, float s2, int reverse) {
+  const long long pos = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (n, to, s)
+  const long long per_n = (long long)Tout * HW;
+  if (pos >= (long long)N * per_n) return;
+  const long long n = pos / per_n, r = pos - n * per_n;
+  const int to = (int)(r / HW);
+  const long long sp = r - (long long)to * HW;
+  const int ti = tidx ? tidx[to] : to;
+  const uint8_t* px = fr + (((long long)n * Tin + ti) * HW + sp) * 3;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float f = (float)px[reverse ? 2 - c : c] / 255.0f;  // tensor.float() / 255.0
+    v[c] = (f - mean[c]) / sd[c];                              // (tensor - mean) / std
+  }
+  if (Cpad == 4) {
+    *(uint2*)(y + pos * 4) = make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
+  } else {
+    *(uint4*)(y + pos * Cpad) = pack8_bf16(v);
+    for (int c0 = 8; c0 < Cpad; c0 += 8) *(uint4*)(y + pos * Cpad + c0) = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
+extern "C" int vs_frames_u8_pack(const uint8_t* frames, const int* t_index, void* y, int N, int Tin,
+                                 int Tout, int H, int W, int Cpad, const float* mean3,
+                                 const float* std3, int reverse_channels, void* stream) {
+  VS_CHECK_ARG(frames && y && mean3 && std3, "null argument (mean3 / std3 are host pointers)");
+  VS_CHECK_ARG((Cpad % 8 == 0 || Cpad == 4) && Cpad >= 3, "Cpad must be 4 or a multiple of 8");
+  VS_CHECK_ARG(N > 0 && Tin > 0 && Tout > 0 && (t_index || Tout == Tin), "Tout != Tin needs t_index");
+  const long long HW = (long long)H * W, total = (long long)N * Tout * HW;
+  hipLaunchKernelGGL(frames_u8_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, frames, t_index, (uint16_t*)y, N, Tin, Tout, HW, Cpad,
+                     mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], reverse_channels);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// ----------------------------------------------------------------------------
 // BN finalize: partial[nparts][2][C] -> mean / biased var -> scale, shift
 // block = 32 channels x 32 slices; fp64 cross-partial accumulation.
 // ----------------------------------------------------------------------------

@@ -156,6 +156,10 @@ class SFBase(nn.Module):
         self.proj_head = HipMLP(nn.Linear(din, din // 2), nn.ReLU(), nn.Linear(din // 2, out_dim))
 
     def get_feats(self, inp):
+        if "frms_ev_fast_u8" in inp:
+            # optional fast path beside the reference contract: the loader's uint8 RGB frames
+            # [B, E, T, H, W, 3]; normalisation and the slow-pathway gather happen on the GPU
+            return [combine_first_ax(inp["frms_ev_fast_u8"])]
         if self.comm.path_type == "multi":
             return [combine_first_ax(inp["frms_ev_slow_tensor"]),
                     combine_first_ax(inp["frms_ev_fast_tensor"])]
@@ -166,7 +170,7 @@ class SFBase(nn.Module):
     def forward_encoder(self, inp):
         feats_used = self.get_feats(inp)
         feat_out = self.sf_mdl.forward_features(feats_used)
-        assert len(feat_out) == len(feats_used)
+        assert len(feat_out) == self.sf_mdl.num_pathways
         return feat_out
 
     def forward_decoder(self, enc_out, inp):
@@ -174,7 +178,7 @@ class SFBase(nn.Module):
         head_out = head_out.permute((0, 2, 3, 4, 1))  # (B, C, T, H, W) -> (B, T, H, W, C)
         proj_out = self.proj_head(head_out)
         B = len(inp["vseg_idx"])
-        n_ev = inp["frms_ev_fast_tensor"].shape[1]
+        n_ev = (inp["frms_ev_fast_u8"] if "frms_ev_fast_u8" in inp else inp["frms_ev_fast_tensor"]).shape[1]
         out = proj_out.view(B, n_ev, -1)
         assert out.size(-1) == len(self.comm.vb_id_vocab)
         return out
@@ -400,7 +404,7 @@ class SFBase_TxEnc(SFBase):
     def forward_decoder(self, enc_out, inp):
         head_out = self.head(enc_out)  # [N, C, 1, 1, 1]
         B = len(inp["vseg_idx"])
-        n_ev = inp["frms_ev_fast_tensor"].shape[1]
+        n_ev = (inp["frms_ev_fast_u8"] if "frms_ev_fast_u8" in inp else inp["frms_ev_fast_tensor"]).shape[1]
         feats = head_out.view(B, n_ev, -1)
         tok = self.vid_feat_encoder(feats)
         tx = self.vid_feat_txenc(src_tokens=tok[..., 0], src_lengths=None,

@@ -85,6 +85,23 @@ def pack_input(x, cpad=8):
     return y
 
 
+def frames_u8_pack(frames, cpad, t_index=None, mean=(0.45, 0.45, 0.45), std=(0.225, 0.225, 0.225),
+                   reverse=False):
+    """uint8 [N, T, H, W, 3] frames -> normalised bf16 activation [N, cpad, Tout, H, W]
+    (channels-last memory); t_index: int32 device tensor of frame indices (slow pathway) or None."""
+    if frames.dtype != torch.uint8 or frames.dim() != 5 or frames.shape[-1] != 3:
+        raise _lib.VsError("frames_u8_pack expects uint8 [N, T, H, W, 3]")
+    frames = frames.contiguous()
+    n, t, h, w, _ = frames.shape
+    tout = t if t_index is None else int(t_index.numel())
+    y = new_act(n, cpad, tout, h, w, frames.device)
+    m3 = (C.c_float * 3)(*[float(a) for a in mean])
+    s3 = (C.c_float * 3)(*[float(a) for a in std])
+    _lib.call("vs_frames_u8_pack", _ptr(frames), _ptr(t_index), _ptr(y), n, t, tout, h, w, cpad,
+              C.cast(m3, C.c_void_p), C.cast(s3, C.c_void_p), int(reverse), _stream())
+    return y
+
+
 # ----------------------------------------------------------------------------
 # convolution
 # ----------------------------------------------------------------------------

@@ -71,6 +71,38 @@ def make_comm(cfg):
                            gpt2_hf_tok=SynthGPT2Tok(ntok))
 
 
+def synth_u8_batch(cfg, comm, bs, n_ev=5, seed=1234, device="cpu", crop=None):
+    """The A0 batch as the loader's PIL step leaves it (`dat_loader.py:183-191`): uint8 RGB frames
+    `frms_ev_fast_u8` [B, E, T, H, W, 3] -- the optional input of the GPU normalise / pack kernel.
+    `reference_tensors(batch, cfg)` gives the fp32 tensors the reference would have built."""
+    sf = cfg.sf_mdl
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    t = sf.DATA.NUM_FRAMES
+    hw = crop or sf.DATA.TRAIN_CROP_SIZE
+    fr = torch.randint(0, 256, (bs, n_ev, t, hw, hw, 3), generator=g, dtype=torch.int32).to(torch.uint8)
+    return {
+        "frms_ev_fast_u8": fr.to(device),
+        "vseg_idx": torch.arange(bs, dtype=torch.long, device=device),
+        "label_tensor": torch.randint(0, len(comm.vb_id_vocab), (bs, n_ev), generator=g).to(device),
+    }
+
+
+def reference_tensors(batch_u8, cfg, comm):
+    """uint8 frames -> the reference's fp32 batch tensors, same operation order as
+    `tensor_normalize` (`utils/video_utils.py:147-164`) and `pack_pathway_output` (:41-74)."""
+    sf = cfg.sf_mdl
+    fr = batch_u8["frms_ev_fast_u8"].cpu()
+    x = fr.float() / 255.0
+    x = x - torch.tensor(list(sf.DATA.MEAN))
+    x = x / torch.tensor(list(sf.DATA.STD))
+    fast = x.permute(0, 1, 5, 2, 3, 4).contiguous()  # [B, E, C, T, H, W]
+    out = {"frms_ev_fast_tensor": fast, "vseg_idx": batch_u8["vseg_idx"].cpu(),
+           "label_tensor": batch_u8["label_tensor"].cpu()}
+    if comm.path_type == "multi":
+        out["frms_ev_slow_tensor"] = fast.index_select(3, slow_index(fast.shape[3], sf.SLOWFAST.ALPHA))
+    return out
+
+
 def synth_srl_batch(comm, bs, n_ev=5, n_ann=1, seq_len=60, feat_dim=2304, seed=1234, device="cpu"):
     """Batch of the vb_arg contract (`dat_loader.py:220-452,503-511`): `seq_out_by_ev`
     i64 [B,E,n_ann,60] right-padded SRL token ids, `seq_out_lens_by_ev` {0,1} mask of the same

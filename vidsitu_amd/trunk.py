@@ -453,6 +453,12 @@ class VideoTrunk(nn.Module):
         arch = cfg.MODEL.ARCH
         self.arch = arch
         self.multi = arch in cfg.MODEL.MULTI_PATHWAY_ARCH
+        data = getattr(cfg, "DATA", None)  # CfgNode or a plain namespace (oracle's default_sf_cfg)
+        self.data_mean = tuple(getattr(data, "MEAN", (0.45, 0.45, 0.45)))
+        self.data_std = tuple(getattr(data, "STD", (0.225, 0.225, 0.225)))
+        self.data_reverse = bool(getattr(data, "REVERSE_INPUT_CHANNEL", False))
+        self.alpha = cfg.SLOWFAST.ALPHA if self.multi else 1
+        self._slow_idx_cache = {}
         self.num_pathways = 2 if self.multi else 1
         self.enable_detection = False
         eps, mom = cfg.BN.EPSILON, cfg.BN.MOMENTUM
@@ -553,17 +559,40 @@ class VideoTrunk(nn.Module):
     def forward(self, x, bboxes=None):
         return self.forward_features(x)
 
+    def _slow_index(self, t, dev):
+        """`pack_pathway_output` (utils/video_utils.py:59-65): linspace(0, T-1, T // alpha).long()."""
+        key = (t, str(dev))
+        if key not in self._slow_idx_cache:
+            idx = torch.linspace(0, t - 1, t // self.alpha).long().to(torch.int32)
+            self._slow_idx_cache[key] = idx.to(dev)
+        return self._slow_idx_cache[key]
+
     def _run(self, inputs, train):
         saved = [] if train else None
         P = self.num_pathways
         xin, shapes = [], []
-        for p, t in enumerate(inputs):
-            if getattr(self.s1, f"pathway{p}_stem").conv.is_stem:
-                xin.append((ops.pack_input(t, 4), None))
-            else:
-                xin.append(ops.pack_input(t))
-            shapes.append(tuple(t.shape))
         dev = inputs[0].device
+        if inputs[0].dtype == torch.uint8:
+            # uint8 frames [N, T, H, W, 3] (what the loader's PIL step produces): normalise, pack and
+            # gather the slow pathway's frames on the GPU (vs_frames_u8_pack), one launch per pathway
+            fr = inputs[0]
+            n, t, h, w, _ = fr.shape
+            for p in range(P):
+                tidx = None
+                if self.multi and p == 0:
+                    tidx = self._slow_index(t, dev)
+                stem = getattr(self.s1, f"pathway{p}_stem").conv.is_stem
+                y = ops.frames_u8_pack(fr, 4 if stem else 8, tidx, self.data_mean, self.data_std,
+                                       self.data_reverse)
+                xin.append((y, None) if stem else y)
+                shapes.append((n, 3, t if tidx is None else int(tidx.numel()), h, w))
+        else:
+            for p, t in enumerate(inputs):
+                if getattr(self.s1, f"pathway{p}_stem").conv.is_stem:
+                    xin.append((ops.pack_input(t, 4), None))
+                else:
+                    xin.append(ops.pack_input(t))
+                shapes.append(tuple(t.shape))
         if train:
             bns = [m.num_batches_tracked for m in self.modules() if isinstance(m, BN3dP)]
             torch._foreach_add_(bns, 1)
