@@ -285,6 +285,25 @@ int vs_beam_topk(const float* logits, const float* cum, const int64_t* forced, f
 int vs_xent_ignore(const float* logits, const int64_t* labels, float* nll_rows, float* loss_out,
                    int rows, int V, int64_t ld, int ignore_index, void* stream);
 
+/* ---- GPT-2 decoder backward (fine-tuning the LM; Simple_TxDec.forward, mdl_sf_base.py:653-667) */
+int vs_gelu_new_fwd(const float* x, float* y, int64_t n, void* stream);
+int vs_gelu_new_bwd(const float* dy, const float* x_pre, float* dx, int64_t n, void* stream);
+int vs_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* out[N] = column sums of x[M,N] (bias gradients), fixed row order. */
+int vs_colsum_f32(const float* x, float* out, int M, int N, void* stream);
+/* Backward of vs_attn_causal_fwd: dqkv[R,L,3D] from dout[R,L,D]; scratch of
+ * vs_attn_causal_bwd_scratch_bytes(R,L,H) bytes (p and dS rows); no atomics. */
+size_t vs_attn_causal_bwd_scratch_bytes(int R, int L, int H);
+int vs_attn_causal_bwd(const float* qkv, const uint8_t* key_mask, const float* dout, float* dqkv,
+                       void* scratch, size_t scratch_bytes, int R, int L, int H, int dh, void* stream);
+/* dwte[tokens] += dh, dwpe[pos0 + l] += dh (fp32 atomics). */
+int vs_gpt2_embed_bwd(const int64_t* tokens, const float* dh, float* dwte, float* dwpe, int R, int L,
+                      int D, int pos0, int V, void* stream);
+/* dlogits of vs_xent_ignore: (softmax - onehot) * grad_scale / count; loss_out from vs_xent_ignore. */
+int vs_xent_ignore_grad(const float* logits, const int64_t* labels, const float* loss_out,
+                        float* dlogits, int rows, int V, int64_t ld, int ignore_index, float grad_scale,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,22 +32,35 @@ for name, vocab, n_pos, d, n_layer, n_head, R, L, seed in CASES:
     sd["lm_head.weight"] = sd["transformer.wte.weight"]
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert not unexpected and all("attn.bias" in k or "masked_bias" in k for k in missing), (missing, unexpected)
+    pad = 0
     rs = np.random.RandomState(seed + 100)
     toks = rs.randint(1, vocab, size=(R, L)).astype(np.int64)
     mask = np.ones((R, L), dtype=np.int64)
-    pad = 0
     for r in range(1, R):  # right padding of different lengths (row 0 stays full)
         n = L - (r * 3) % (L - 2)
         mask[r, n:] = 0
         toks[r, n:] = pad
+    tt, mm = torch.from_numpy(toks), torch.from_numpy(mask)
+    if vocab < 1000:  # training golden: Simple_TxDec.forward's loss (mdl_sf_base.py:653-667) + grads
+        m.zero_grad()
+        out = m(input_ids=tt, attention_mask=mm)
+        lg = out.logits
+        loss = torch.nn.functional.cross_entropy(lg[:, :-1].reshape(-1, vocab), tt[:, 1:].reshape(-1),
+                                                 ignore_index=pad)
+        loss.backward()
+        grads = {"grad." + k: v.grad.numpy().copy() for k, v in m.named_parameters()}
+        grads["loss"] = np.float32(loss.item())
+    else:
+        grads = {}
     with torch.no_grad():
-        out = m(input_ids=torch.from_numpy(toks), attention_mask=torch.from_numpy(mask))
+        out = m(input_ids=tt, attention_mask=mm)
     logits = out.logits.numpy().astype(np.float32)
     ours = gpt2_ref.forward(w, toks, mask, n_head)
     err = float(np.abs(ours - logits)[mask.astype(bool)].max())
     print(f"{name}: logits {logits.shape}, |oracle - HF| max over valid rows {err:.3e}, "
           f"max |logit| {np.abs(logits).max():.3f}")
     save = dict(tokens=toks, mask=mask, dims=np.array([vocab, n_pos, d, n_layer, n_head, seed]), pad=np.int64(pad))
+    save.update(grads)
     if logits.size < 200000:
         save["logits"] = logits
     else:

@@ -238,3 +238,63 @@ def test_simple_txdec_plugin_surface(dev):
                 toks = r["vb_output"][f"Ev{e + 1}"]["tokens"]
                 assert toks[0] == int(batch["seq_out_by_ev"][b, e, 0, 0])  # forced first token
                 assert len(toks) <= 9
+
+
+@pytest.mark.parametrize("path", [p for p in GOLD if "medium" not in p], ids=lambda p: os.path.basename(p))
+def test_gpt2_training_gradients_match_transformers_golden(path, dev):
+    """Simple_TxDec's training math (`mdl_sf_base.py:653-667`): teacher-forced logits, shift-by-one
+    CE with ignore_index = pad, loss.backward() -- every parameter gradient of the HIP backward
+    against the gradients huggingface transformers computed for the same weights and tokens."""
+    from vidsitu_amd.hf_gpt2_fseq import HuggingFaceGPT2Decoder, lm_loss
+
+    z, w, n_head, m = _model_from_golden(path, dev)
+    pad = int(z["pad"])
+    dec = HuggingFaceGPT2Decoder.__new__(HuggingFaceGPT2Decoder)
+    torch.nn.Module.__init__(dec)
+    dec.model, dec.pad_idx = m, pad
+    dec.train()
+    toks = torch.from_numpy(z["tokens"]).to(dev)
+    logits = dec(toks)[0]
+    assert logits.requires_grad
+    loss = lm_loss(logits, toks, pad)
+    loss.backward()
+    assert abs(float(loss) - float(z["loss"])) < 1e-4 * max(1.0, abs(float(z["loss"])))
+    worst = 0.0
+    for k in z.files:
+        if not k.startswith("grad."):
+            continue
+        want = z[k]
+        got = m.P(k[5:]).grad.cpu().numpy()
+        assert got.shape == want.shape, k
+        err = float(np.abs(got - want).max()) / max(float(np.abs(want).max()), 1e-12)
+        worst = max(worst, err)
+        assert err < 5e-4, f"{k}: relative error {err:.3e}"
+    print(f"{os.path.basename(path)}: worst relative gradient error {worst:.3e}")
+
+
+def test_gpt2_training_step_through_plugin_surface(dev):
+    """`tx_only` model in train mode: loss -> backward -> fused Adam on the parameter arena; the
+    loss of the same batch goes down."""
+    from vidsitu_amd import synth_data
+    from vidsitu_amd.extended_config import get_cfg
+    from vidsitu_amd.mdl_selector import get_mdl_loss_eval
+    from vidsitu_amd.optim import ArenaAdam, ParamArena
+
+    cfg = get_cfg({"task_type": "vb_arg", "mdl.mdl_name": "tx_only", "mdl.tx_dec_type": "gpt2",
+                   "mdl.gpt2_mdl_name": "gpt2-synth-tiny", "synth.gpt2_vocab": 97})
+    comm = synth_data.make_comm(cfg)
+    sel = get_mdl_loss_eval(cfg)
+    torch.manual_seed(0)
+    mdl = sel["mdl"](cfg=cfg, comm=comm).to(dev).train()
+    loss_fn = sel["loss"](cfg, comm)
+    batch = synth_data.synth_srl_batch(comm, bs=2, n_ev=5, seq_len=12, device=dev)
+    arena = ParamArena(mdl, adopt_conv=False)
+    opt = ArenaAdam(arena, lr=3e-3)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        loss = loss_fn(mdl(batch), batch)["loss"]
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0] - 0.05, losses

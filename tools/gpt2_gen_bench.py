@@ -30,3 +30,16 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 o = mdl(batch)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(f"teacher-forced loss forward: {5*B}x60 tokens in {dt*1e3:.1f} ms, loss {float(o['loss']):.4f}")
+# one fine-tuning step of the language model (teacher-forced loss, manual backward, fused Adam)
+from vidsitu_amd.optim import ArenaAdam, ParamArena
+mdl.train()
+arena = ParamArena(mdl, adopt_conv=False)
+opt = ArenaAdam(arena, lr=1e-5)
+for it in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    opt.zero_grad()
+    loss = sel["loss"](cfg, comm)(mdl(batch), batch)["loss"]
+    loss.backward()
+    opt.step()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"train step {it}: {5*B}x60 tokens fwd+bwd+Adam in {dt*1e3:.1f} ms, loss {float(loss.detach()):.4f}")

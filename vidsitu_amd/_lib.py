@@ -90,6 +90,14 @@ SIGNATURES = {
     "vs_kv_gather": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vs_beam_topk": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _i, _p]),
     "vs_xent_ignore": (_i, [_p, _p, _p, _p, _i, _i, _i64, _i, _p]),
+    "vs_gelu_new_fwd": (_i, [_p, _p, _i64, _p]),
+    "vs_gelu_new_bwd": (_i, [_p, _p, _p, _i64, _p]),
+    "vs_add_f32": (_i, [_p, _p, _p, _i64, _p]),
+    "vs_colsum_f32": (_i, [_p, _p, _i, _i, _p]),
+    "vs_attn_causal_bwd_scratch_bytes": (_sz, [_i, _i, _i]),
+    "vs_attn_causal_bwd": (_i, [_p, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _p]),
+    "vs_gpt2_embed_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vs_xent_ignore_grad": (_i, [_p, _p, _p, _p, _i, _i, _i64, _i, _f, _p]),
 }
 
 

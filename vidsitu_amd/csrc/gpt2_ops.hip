@@ -499,3 +499,269 @@ extern "C" int vs_xent_ignore(const float* logits, const int64_t* labels, float*
   VS_CHECK_LAUNCH();
   return VS_OK;
 }
+
+// =============================================================================================
+// Backward of the GPT-2 decoder (fine-tuning the language model: Simple_TxDec.forward ->
+// loss.backward(), vidsitu_code/mdl_sf_base.py:653-667).  Dense gradients reuse vs_gemm_nt_f32
+// (dx = dy . W with the Conv1D parameter itself as the K-contiguous operand; dW = x^T dy on
+// transposed activations); the kernels below are the rest of the chain.
+// =============================================================================================
+__device__ __forceinline__ float gelu_new_grad_f(float x) {
+  const float k = 0.7978845608028654f, c = 0.044715f;
+  const float u = k * (x + c * x * x * x);
+  const float t = tanhf(u);
+  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * k * (1.0f + 3.0f * c * x * x);
+}
+
+__global__ void gelu_new_fwd_kernel(const float* x, float* y, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    y[i] = gelu_new_f(x[i]);
+}
+__global__ void gelu_new_bwd_kernel(const float* dy, const float* x, float* dx, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    dx[i] = dy[i] * gelu_new_grad_f(x[i]);
+}
+__global__ void add_f32_kernel(const float* a, const float* b, float* out, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    out[i] = a[i] + b[i];
+}
+static inline unsigned ew_blocks(long long n) {
+  long long g = (n + 255) / 256;
+  if (g > 4096) g = 4096;
+  return (unsigned)(g < 1 ? 1 : g);
+}
+extern "C" int vs_gelu_new_fwd(const float* x, float* y, int64_t n, void* stream) {
+  VS_CHECK_ARG(x && y && n > 0, "bad args");
+  hipLaunchKernelGGL(gelu_new_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, y,
+                     (long long)n);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+extern "C" int vs_gelu_new_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream) {
+  VS_CHECK_ARG(dy && x && dx && n > 0, "bad args");
+  hipLaunchKernelGGL(gelu_new_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dy, x,
+                     dx, (long long)n);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+extern "C" int vs_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream) {
+  VS_CHECK_ARG(a && b && out && n > 0, "bad args");
+  hipLaunchKernelGGL(add_f32_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, out,
+                     (long long)n);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// out[n] = sum_m x[m][n]  (bias gradients): one thread per column, fixed row order.
+__global__ void colsum_f32_kernel(const float* x, float* out, int M, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  int m = 0;
+  for (; m + 4 <= M; m += 4) {
+    const float a = x[(long long)m * N + n], b = x[(long long)(m + 1) * N + n],
+                c = x[(long long)(m + 2) * N + n], d = x[(long long)(m + 3) * N + n];
+    s += a; s += b; s += c; s += d;
+  }
+  for (; m < M; ++m) s += x[(long long)m * N + n];
+  out[n] = s;
+}
+extern "C" int vs_colsum_f32(const float* x, float* out, int M, int N, void* stream) {
+  VS_CHECK_ARG(x && out && M > 0 && N > 0, "bad args");
+  hipLaunchKernelGGL(colsum_f32_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, x,
+                     out, M, N);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// ----------------------------------------------------------------------------
+// Causal attention backward.  One block per (r, head): Q, K, V, dO of the head in LDS
+// (pitch dh+1).  Pass A (one wave per query i): p_i = softmax(s_i) with the forward's masking,
+// dP_ij = dO_i . V_j, D_i = sum_j p_ij dP_ij, dS_ij = p_ij (dP_ij - D_i); dQ_i = scale * dS_i K;
+// P and dS rows go to a scratch [L][L] pair.  Pass B (one wave per key j, lanes over d):
+// dK_j = scale * sum_i dS_ij Q_i, dV_j = sum_i p_ij dO_i -- every output has one owner, fixed
+// summation order, no atomics.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_causal_bwd_kernel(const float* qkv, const uint8_t* kmask,
+                                                              const float* dout, float* dqkv,
+                                                              float* scratch, int L, int H, int dh) {
+  extern __shared__ float sm[];
+  const int D = H * dh, ld = dh + 1;
+  const int r = blockIdx.x / H, h = blockIdx.x % H;
+  float* Qs = sm;
+  float* Ks = Qs + L * ld;
+  float* Vs = Ks + L * ld;
+  float* Os = Vs + L * ld;   // dO
+  float* Pw = Os + L * ld;   // [4][L] per-wave p row
+  float* Sw = Pw + 4 * L;    // [4][L] per-wave dS row
+  const float* base = qkv + (long long)r * L * 3 * D;
+  const float* dob = dout + (long long)r * L * D;
+  float* P = scratch + (long long)blockIdx.x * 2 * L * L;
+  float* dS = P + (long long)L * L;
+  for (int i = threadIdx.x; i < L * dh; i += 256) {
+    const int j = i / dh, d = i - j * dh;
+    Qs[j * ld + d] = base[(long long)j * 3 * D + h * dh + d];
+    Ks[j * ld + d] = base[(long long)j * 3 * D + D + h * dh + d];
+    Vs[j * ld + d] = base[(long long)j * 3 * D + 2 * D + h * dh + d];
+    Os[j * ld + d] = dob[(long long)j * D + h * dh + d];
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float scale = 1.0f / sqrtf((float)dh);
+  float* pw = Pw + wave * L;
+  float* sw = Sw + wave * L;
+  for (int i = wave; i < L; i += 4) {
+    float mx = -INFINITY;
+    for (int j = lane; j < L; j += 64) {
+      float s = 0.f;
+      for (int d = 0; d < dh; ++d) s += Qs[i * ld + d] * Ks[j * ld + d];
+      s *= scale;
+      if (j > i) s = -1e4f;
+      if (kmask && !kmask[(long long)r * L + j]) s += -1e4f;
+      pw[j] = s;
+      mx = fmaxf(mx, s);
+    }
+    mx = wave_reduce_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < L; j += 64) {
+      const float e = expf(pw[j] - mx);
+      pw[j] = e;
+      sum += e;
+    }
+    sum = wave_reduce_sum(sum);
+    const float inv = 1.0f / sum;
+    float dsum = 0.f;
+    for (int j = lane; j < L; j += 64) {
+      const float p = pw[j] * inv;
+      float dp = 0.f;
+      for (int d = 0; d < dh; ++d) dp += Os[i * ld + d] * Vs[j * ld + d];
+      pw[j] = p;
+      sw[j] = dp;
+      dsum += p * dp;
+    }
+    dsum = wave_reduce_sum(dsum);
+    for (int j = lane; j < L; j += 64) {
+      const float ds = pw[j] * (sw[j] - dsum);
+      sw[j] = ds;
+      P[(long long)i * L + j] = pw[j];
+      dS[(long long)i * L + j] = ds;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int d = lane; d < dh; d += 64) {
+      float a = 0.f;
+      for (int j = 0; j < L; ++j) a += sw[j] * Ks[j * ld + d];
+      dqkv[((long long)r * L + i) * 3 * D + h * dh + d] = a * scale;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int j = wave; j < L; j += 4) {
+    for (int d = lane; d < dh; d += 64) {
+      float dk = 0.f, dv = 0.f;
+      for (int i = 0; i < L; ++i) {
+        dk += dS[(long long)i * L + j] * Qs[i * ld + d];
+        dv += P[(long long)i * L + j] * Os[i * ld + d];
+      }
+      dqkv[((long long)r * L + j) * 3 * D + D + h * dh + d] = dk * scale;
+      dqkv[((long long)r * L + j) * 3 * D + 2 * D + h * dh + d] = dv;
+    }
+  }
+}
+
+extern "C" size_t vs_attn_causal_bwd_scratch_bytes(int R, int L, int H) {
+  return (size_t)R * H * 2 * L * L * sizeof(float);
+}
+
+extern "C" int vs_attn_causal_bwd(const float* qkv, const uint8_t* key_mask, const float* dout,
+                                  float* dqkv, void* scratch, size_t scratch_bytes, int R, int L, int H,
+                                  int dh, void* stream) {
+  VS_CHECK_ARG(qkv && dout && dqkv && scratch && R > 0 && L > 0 && H > 0 && dh > 0, "bad args");
+  VS_CHECK_ARG(scratch_bytes >= vs_attn_causal_bwd_scratch_bytes(R, L, H), "scratch too small");
+  const size_t smem = ((size_t)4 * L * (dh + 1) + 8 * L) * sizeof(float);
+  VS_CHECK_ARG(smem <= 160 * 1024, "sequence too long for the LDS-resident attention backward");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)attn_causal_bwd_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(attn_causal_bwd_kernel, dim3(R * H), dim3(256), smem, (hipStream_t)stream, qkv,
+                     key_mask, dout, dqkv, (float*)scratch, L, H, dh);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// Embedding backward: dwte[tok] += dh, dwpe[pos0 + l] += dh (fp32 atomics: several rows may hit the
+// same token / position; the sum order, hence the last bits, can differ between runs).
+__global__ void gpt2_embed_bwd_kernel(const int64_t* tok, const float* dh, float* dwte, float* dwpe,
+                                      int L, int D, int pos0, int V) {
+  const int row = blockIdx.x;
+  const int l = row % L;
+  long long t = tok[row];
+  if (t < 0 || t >= V) return;
+  for (int i = threadIdx.x; i < D; i += blockDim.x) {
+    const float g = dh[(long long)row * D + i];
+    atomicAdd(dwte + t * D + i, g);
+    atomicAdd(dwpe + (long long)(pos0 + l) * D + i, g);
+  }
+}
+extern "C" int vs_gpt2_embed_bwd(const int64_t* tokens, const float* dh, float* dwte, float* dwpe, int R,
+                                 int L, int D, int pos0, int V, void* stream) {
+  VS_CHECK_ARG(tokens && dh && dwte && dwpe && R > 0 && L > 0, "bad args");
+  hipLaunchKernelGGL(gpt2_embed_bwd_kernel, dim3(R * L), dim3(256), 0, (hipStream_t)stream, tokens, dh,
+                     dwte, dwpe, L, D, pos0, V);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// dlogits of the ignore-index mean cross entropy: (softmax - onehot) * gscale / count for counted
+// rows, 0 for ignored ones; count = loss_out[1] of vs_xent_ignore (device memory).
+__global__ __launch_bounds__(256) void xent_ignore_grad_kernel(const float* logits,
+                                                               const int64_t* labels,
+                                                               const float* loss_out, float* dlogits,
+                                                               int V, long long ld, int ignore,
+                                                               float gscale) {
+  __shared__ float red[256];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const long long lb = labels[r];
+  float* dst = dlogits + (long long)r * ld;
+  if (lb == ignore) {
+    for (int j = tid; j < V; j += 256) dst[j] = 0.f;
+    return;
+  }
+  const float* x = logits + (long long)r * ld;
+  float mx = -INFINITY;
+  for (int j = tid; j < V; j += 256) mx = fmaxf(mx, x[j]);
+  red[tid] = mx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+    __syncthreads();
+  }
+  mx = red[0];
+  __syncthreads();
+  float sum = 0.f;
+  for (int j = tid; j < V; j += 256) sum += expf(x[j] - mx);
+  red[tid] = sum;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  const float inv = gscale / (red[0] * fmaxf(loss_out[1], 1.0f));
+  const float onehot = gscale / fmaxf(loss_out[1], 1.0f);
+  for (int j = tid; j < V; j += 256) dst[j] = expf(x[j] - mx) * inv - (j == lb ? onehot : 0.f);
+}
+extern "C" int vs_xent_ignore_grad(const float* logits, const int64_t* labels, const float* loss_out,
+                                   float* dlogits, int rows, int V, int64_t ld, int ignore_index,
+                                   float grad_scale, void* stream) {
+  VS_CHECK_ARG(logits && labels && loss_out && dlogits && rows > 0 && V > 0 && ld >= V, "bad args");
+  hipLaunchKernelGGL(xent_ignore_grad_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits,
+                     labels, loss_out, dlogits, V, (long long)ld, ignore_index, grad_scale);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}

@@ -181,6 +181,84 @@ class GPT2LMHeadModelHip(nn.Module):
         state.len = t + 1
         return self._head(h)
 
+    # ---- training (teacher-forced pass with saved activations + manual backward) ------------
+    def forward_train(self, tokens, attention_mask=None):
+        """Like forward_logits, keeping what the backward needs (fp32, no recompute except the
+        attention probabilities)."""
+        r, l = tokens.shape
+        km = None if attention_mask is None else attention_mask.to(torch.uint8).contiguous()
+        h = ops.gpt2_embed(tokens, self.P("transformer.wte.weight"), self.P("transformer.wpe.weight"))
+        layers = []
+        for i in range(self.n_layer):
+            q = f"transformer.h.{i}."
+            a, mean1, rstd1 = ops.add_layernorm_fwd(h, None, self.P(q + "ln_1.weight"),
+                                                    self.P(q + "ln_1.bias"), 1e-5)
+            qkv = ops.gemm_nt(a, self._w(q + "attn.c_attn.weight"), self.P(q + "attn.c_attn.bias"))
+            o = ops.attn_causal(qkv, km, r, l, self.n_head)
+            h_mid = ops.gemm_nt(o, self._w(q + "attn.c_proj.weight"), self.P(q + "attn.c_proj.bias"), res=h)
+            m, mean2, rstd2 = ops.add_layernorm_fwd(h_mid, None, self.P(q + "ln_2.weight"),
+                                                    self.P(q + "ln_2.bias"), 1e-5)
+            f_pre = ops.gemm_nt(m, self._w(q + "mlp.c_fc.weight"), self.P(q + "mlp.c_fc.bias"))
+            f = ops.gelu_new_fwd(f_pre)
+            h_out = ops.gemm_nt(f, self._w(q + "mlp.c_proj.weight"), self.P(q + "mlp.c_proj.bias"), res=h_mid)
+            layers.append((h, a, mean1, rstd1, qkv, o, h_mid, m, mean2, rstd2, f_pre, f))
+            h = h_out
+        hf, meanf, rstdf = ops.add_layernorm_fwd(h, None, self.P("transformer.ln_f.weight"),
+                                                 self.P("transformer.ln_f.bias"), 1e-5)
+        logits = ops.gemm_nt(hf, self.P("transformer.wte.weight"))
+        self._saved = (tokens, km, r, l, layers, h, hf, meanf, rstdf)
+        return logits.view(r, l, -1)
+
+    def _grad(self, name):
+        p = self.P(name)
+        if p.grad is None:
+            p.grad = torch.empty_like(p)
+        return p.grad
+
+    def _dense_bwd(self, name, x, dy, need_dx=True):
+        """y = x @ W + b with the Conv1D parameter W [in, out]: dW = x^T dy, db = colsum(dy),
+        dx = dy @ W^T (the parameter itself is the K-contiguous operand of that product)."""
+        ops.gemm_nt(ops.transpose_f32(x), ops.transpose_f32(dy), out=self._grad(name + ".weight"))
+        ops.colsum_f32(dy, out=self._grad(name + ".bias"))
+        return ops.gemm_nt(dy, self.P(name + ".weight")) if need_dx else None
+
+    @torch.no_grad()
+    def backward(self, dlogits):
+        """dlogits [R*L, V] -> .grad of every parameter (overwrite semantics, like the trunk)."""
+        tokens, km, r, l, layers, h_last, hf, meanf, rstdf = self._saved
+        self._saved = None
+        wte = self.P("transformer.wte.weight")
+        dlogits = dlogits.reshape(r * l, -1)
+        # tied lm_head: logits = hf @ wte^T
+        dwte = self._grad("transformer.wte.weight")
+        ops.gemm_nt(ops.transpose_f32(dlogits), ops.transpose_f32(hf), out=dwte)
+        dhf = ops.gemm_nt(dlogits, ops.transpose_f32(wte))
+        dh, _, _, _ = ops.add_layernorm_bwd(dhf, h_last, None, self.P("transformer.ln_f.weight"), meanf,
+                                            rstdf, dg_out=self._grad("transformer.ln_f.weight"),
+                                            db_out=self._grad("transformer.ln_f.bias"))
+        for i in reversed(range(self.n_layer)):
+            q = f"transformer.h.{i}."
+            h_in, a, mean1, rstd1, qkv, o, h_mid, m, mean2, rstd2, f_pre, f = layers[i]
+            df = self._dense_bwd(q + "mlp.c_proj", f, dh)
+            df_pre = ops.gelu_new_bwd(df, f_pre)
+            dm = self._dense_bwd(q + "mlp.c_fc", m, df_pre)
+            dmid_ln, _, _, _ = ops.add_layernorm_bwd(dm, h_mid, None, self.P(q + "ln_2.weight"), mean2, rstd2,
+                                                     dg_out=self._grad(q + "ln_2.weight"),
+                                                     db_out=self._grad(q + "ln_2.bias"))
+            d_mid = ops.add_f32(dh, dmid_ln)
+            do = self._dense_bwd(q + "attn.c_proj", o, d_mid)
+            dqkv = ops.attn_causal_bwd(qkv, km, do, r, l, self.n_head)
+            da = self._dense_bwd(q + "attn.c_attn", a, dqkv)
+            din_ln, _, _, _ = ops.add_layernorm_bwd(da, h_in, None, self.P(q + "ln_1.weight"), mean1, rstd1,
+                                                    dg_out=self._grad(q + "ln_1.weight"),
+                                                    db_out=self._grad(q + "ln_1.bias"))
+            dh = ops.add_f32(d_mid, din_ln)
+            layers[i] = None
+        dwpe = self._grad("transformer.wpe.weight")
+        dwpe.zero_()
+        ops.gpt2_embed_bwd(tokens, dh, dwte, dwpe)  # adds the embedding rows onto the lm_head gradient
+        self._wt.clear()  # the optimizer is about to change the parameters
+
     def reorder_state(self, state: KVCacheState, new_order):
         """fairseq reorder_incremental_state: row r of the cache becomes old row new_order[r]."""
         if state.k is None:
@@ -192,6 +270,34 @@ class GPT2LMHeadModelHip(nn.Module):
         state.k, state.k2 = state.k2, state.k
         state.v, state.v2 = state.v2, state.v
         state.rows = rows
+
+
+class _GPT2TrainFn(torch.autograd.Function):
+    """One autograd node for the whole language model (manual HIP backward)."""
+
+    @staticmethod
+    def forward(ctx, model, tokens, mask, _tick):
+        ctx.model = model
+        return model.forward_train(tokens, mask)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        ctx.model.backward(dlogits.contiguous())
+        return None, None, None, None
+
+
+class _XentIgnoreFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits2d, labels, ignore_index):
+        loss, pair = ops.xent_ignore(logits2d, labels, ignore_index)
+        ctx.save_for_backward(logits2d, labels, pair)
+        ctx.ignore_index = ignore_index
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, go):
+        logits2d, labels, pair = ctx.saved_tensors
+        return ops.xent_ignore_grad(logits2d, labels, pair, ctx.ignore_index, float(go)), None, None
 
 
 class HuggingFaceGPT2Decoder(nn.Module):
@@ -217,6 +323,9 @@ class HuggingFaceGPT2Decoder(nn.Module):
                                              max_len=getattr(incremental_state, "max_len", None))
             return (logits.unsqueeze(1),)
         features_mask = prev_output_tokens.ne(self.pad_idx)  # don't attend to padding symbols (:185)
+        if self.training and torch.is_grad_enabled():
+            tick = torch.zeros(1, device=prev_output_tokens.device, requires_grad=True)
+            return (_GPT2TrainFn.apply(self.model, prev_output_tokens, features_mask, tick),)
         return (self.model.forward_logits(prev_output_tokens, features_mask),)
 
     def reorder_incremental_state(self, incremental_state, new_order):
@@ -236,5 +345,7 @@ def lm_loss(logits, tokens, pad_index):
     r, l, v = logits.shape
     labels = torch.full((r, l), pad_index, dtype=torch.int64, device=tokens.device)
     labels[:, :-1] = tokens[:, 1:]
+    if logits.requires_grad:
+        return _XentIgnoreFn.apply(logits.reshape(r * l, v), labels.reshape(-1), pad_index)
     loss, _ = ops.xent_ignore(logits.reshape(r * l, v), labels.reshape(-1), pad_index)
     return loss

@@ -692,4 +692,68 @@ def xent_ignore(logits, labels, ignore_index):
     out = torch.empty(2, dtype=torch.float32, device=logits.device)
     _lib.call("vs_xent_ignore", _ptr(logits), _ptr(labels.contiguous()), _ptr(nll), _ptr(out), rows, v,
               v, int(ignore_index), _stream())
-    return out[0], out[1]
+    return out[0], out  # (loss, [loss, count] device pair for xent_ignore_grad)
+
+
+# ---- GPT-2 decoder backward ------------------------------------------------------------------
+def transpose_f32(x):
+    """[R, C] fp32 -> [C, R] (vs_transpose_f32)."""
+    x = _f32c(x)
+    r, c = x.shape
+    out = torch.empty((c, r), dtype=torch.float32, device=x.device)
+    _lib.call("vs_transpose_f32", _ptr(x), _ptr(out), r, c, _stream())
+    return out
+
+
+def gelu_new_fwd(x):
+    x = _f32c(x)
+    y = torch.empty_like(x)
+    _lib.call("vs_gelu_new_fwd", _ptr(x), _ptr(y), x.numel(), _stream())
+    return y
+
+
+def gelu_new_bwd(dy, x_pre):
+    dy, x_pre = _f32c(dy), _f32c(x_pre)
+    dx = torch.empty_like(dy)
+    _lib.call("vs_gelu_new_bwd", _ptr(dy), _ptr(x_pre), _ptr(dx), dy.numel(), _stream())
+    return dx
+
+
+def add_f32(a, b, out=None):
+    a, b = _f32c(a), _f32c(b)
+    out = torch.empty_like(a) if out is None else out
+    _lib.call("vs_add_f32", _ptr(a), _ptr(b), _ptr(out), a.numel(), _stream())
+    return out
+
+
+def colsum_f32(x, out=None):
+    x = _f32c(x)
+    m, n = x.shape
+    out = torch.empty(n, dtype=torch.float32, device=x.device) if out is None else out
+    _lib.call("vs_colsum_f32", _ptr(x), _ptr(out), m, n, _stream())
+    return out
+
+
+def attn_causal_bwd(qkv, key_mask, dout, r, l, n_head):
+    d = qkv.shape[1] // 3
+    dqkv = torch.empty_like(qkv)
+    need = _lib.load().vs_attn_causal_bwd_scratch_bytes(r, l, n_head)
+    ws = _workspace(need, qkv.device)
+    _lib.call("vs_attn_causal_bwd", _ptr(qkv), _ptr(key_mask), _ptr(_f32c(dout)), _ptr(dqkv), _ptr(ws),
+              C.c_size_t(ws.numel()), r, l, n_head, d // n_head, _stream())
+    return dqkv
+
+
+def gpt2_embed_bwd(tokens, dh, dwte, dwpe, pos0=0):
+    r, l = tokens.shape
+    _lib.call("vs_gpt2_embed_bwd", _ptr(tokens.contiguous()), _ptr(_f32c(dh)), _ptr(dwte), _ptr(dwpe), r, l,
+              dwte.shape[1], int(pos0), dwte.shape[0], _stream())
+
+
+def xent_ignore_grad(logits, labels, loss_out, ignore_index, grad_scale=1.0):
+    logits = _f32c(logits)
+    rows, v = logits.shape
+    dl = torch.empty_like(logits)
+    _lib.call("vs_xent_ignore_grad", _ptr(logits), _ptr(labels.contiguous()), _ptr(loss_out), _ptr(dl), rows,
+              v, v, int(ignore_index), float(grad_scale), _stream())
+    return dl
