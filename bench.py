@@ -267,7 +267,7 @@ def main():
 
         def fwd_bwd():
             arena.transposes_async()  # dgrad weight images of the last update, beside the forward
-            opt.zero_grad()
+            opt.zero_grad()  # (every gradient is overwritten anyway; the memset overlaps the stems)
             out = mdl(batch)
             loss = loss_fn(out, batch)["loss"]
             loss.backward()

@@ -280,3 +280,31 @@ def test_uint8_frames_path_is_bitwise_the_fp32_contract(dev):
         a = mdl({k: v.to(dev) for k, v in b8.items()})["mdl_out"]
         b = mdl({k: v.to(dev) for k, v in ref.items()})["mdl_out"]
     assert torch.equal(a, b)
+
+
+def test_every_gradient_is_overwritten(dev):
+    """bench.py skips the per-step gradient memset: poison every parameter's gradient with NaN and
+    check that one backward pass of the config-3 model (SlowFast mini + TxEncoder) leaves none."""
+    from vidsitu_amd import synth_data
+    from vidsitu_amd.extended_config import get_cfg
+    from vidsitu_amd.mdl_selector import get_mdl_loss_eval
+    from vidsitu_amd.optim import ParamArena
+
+    cfg = get_cfg({"mdl.mdl_name": "sf_base_txenc", "mdl.sf_mdl_name": "slow_fast_mini",
+                   "synth.num_verbs": 31, "tx_dec.encoder_layers": 2})
+    comm = synth_data.make_comm(cfg)
+    torch.manual_seed(0)
+    sel = get_mdl_loss_eval(cfg)
+    mdl = sel["mdl"](cfg=cfg, comm=comm).to(dev).train()
+    arena = ParamArena(mdl)
+    batch = synth_data.synth_batch(cfg, comm, bs=2, n_ev=2, crop=32, device=dev, dtype=torch.bfloat16)
+    loss_fn = sel["loss"](cfg, comm)
+    for it in range(2):
+        arena.zero_grad(fill=(it == 0))
+        for p in arena.params:
+            p.grad.fill_(float("nan"))
+        loss_fn(mdl(batch), batch)["loss"].backward()
+        torch.cuda.synchronize()
+        bad = [n for n, p in mdl.named_parameters() if not torch.isfinite(p.grad).all()]
+        assert not bad, f"gradients not overwritten: {bad[:5]}"
+        assert torch.isfinite(arena.grad).all()

@@ -84,8 +84,14 @@ class ParamArena:
         self._tr_table = torch.tensor(rows, dtype=torch.int64, device=dev) if rows else None
         self.refresh()
 
-    def zero_grad(self):
-        self.grad.zero_()
+    def zero_grad(self, fill=True):
+        """fill=False: skip the 300 MB memset.  Valid when every parameter's gradient is WRITTEN
+        (overwrite semantics) by the backward -- true for the HIP modules of this package (conv /
+        BN / linear / LayerNorm kernels write `param.grad` in place; checked by
+        tests/test_gpu_trunk.py::test_every_gradient_is_overwritten) -- and the arena was zeroed
+        once, so the alignment gaps between parameters stay zero."""
+        if fill:
+            self.grad.zero_()
         for p, off in zip(self.params, self.offsets):  # re-attach if something replaced .grad
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
                 p.grad = _dense_view(self.grad, off, p)
@@ -188,8 +194,8 @@ class ArenaAdam:
         self.v = torch.zeros_like(arena.data)
         self.t = torch.zeros(1, dtype=torch.int32, device=arena.data.device)  # device-side: graph safe
 
-    def zero_grad(self):
-        self.arena.zero_grad()
+    def zero_grad(self, fill=True):
+        self.arena.zero_grad(fill)
 
     def step(self, world=1, defer_transposes=False):
         """defer_transposes: leave the dgrad weight images stale; the caller refreshes them with
