@@ -43,10 +43,6 @@ typedef enum vs_status {
 #define VS_CONV_RELU 4     /* y = max(y, 0)                                        */
 #define VS_CONV_STATS 8    /* per-block per-channel sum / sum-of-squares partials  */
 #define VS_CONV_NAIVE 16   /* debug: one-thread-per-output direct kernel           */
-#define VS_CONV_APRO 32    /* a = relu?(a*in_scale[c]+in_shift[c]) applied to the  \
-                              gathered input (train-mode BN of the producer fused  \
-                              into this consumer); padding stays zero              */
-#define VS_CONV_APRO_RELU 64
 /* bits 8..11: forced tile config id + 1 (0 = built-in heuristic); ids index
  * {128x128, 64x128, 128x64, 64x64, 256x32, 256x16, 256x128, 128x256} (BM x BN). */
 #define VS_CONV_TILE(id) (((id) + 1) << 8)
@@ -101,12 +97,10 @@ int vs_stem_conv_wgrad(const void* dy, const void* x4, float* dwp, int N, int T,
                        int Cout, int kT, int dy_ld, void* workspace, size_t ws_bytes, void* stream);
 
 /* Forward conv as implicit GEMM on bf16 MFMA, fp32 accumulate.
- *   stats_partial: [vs_conv_stats_rows(desc)][2][Cout] fp32 when VS_CONV_STATS.
- *   in_scale/in_shift: [Cin] fp32 when VS_CONV_APRO. */
+ *   stats_partial: [vs_conv_stats_rows(desc)][2][Cout] fp32 when VS_CONV_STATS. */
 int vs_conv_fwd(const void* x, const void* w, void* y, const vs_conv_desc* d, const float* scale,
                 const float* shift, const void* residual, float* stats_partial,
-                const float* in_scale, const float* in_shift, void* workspace, size_t ws_bytes,
-                void* stream);
+                void* workspace, size_t ws_bytes, void* stream);
 int vs_conv_stats_rows(const vs_conv_desc* d);
 /* fp32 split-K slabs (few-tile, deep-K layers); 0 when the plan for this shape has no split.
  * dgrad = 1 sizes the workspace of vs_conv_dgrad for the same descriptor. */
@@ -130,13 +124,10 @@ int vs_weight_transpose_batched(const void* src, void* dst, const int64_t* table
                                 int64_t total, void* stream);
 
 /* Weight gradient: dw[Cout][taps][Cin] fp32 = sum_p dy[p][co] * x[p@tap][ci].
- * workspace: vs_conv_wgrad_workspace_bytes(desc) bytes of fp32 split-K slabs.
- * in_scale/in_shift (+relu flag via desc.flags APRO) re-apply the producer's BN
- * to x on load. */
+ * workspace: vs_conv_wgrad_workspace_bytes(desc) bytes of fp32 split-K slabs. */
 size_t vs_conv_wgrad_workspace_bytes(const vs_conv_desc* d);
 int vs_conv_wgrad(const void* dy, const void* x, float* dw, const vs_conv_desc* d,
-                  const float* in_scale, const float* in_shift, void* workspace, size_t ws_bytes,
-                  void* stream);
+                  void* workspace, size_t ws_bytes, void* stream);
 
 /* BatchNorm3d (mdl_sf_base.py:22-33 via slowfast BN modules; eps 1e-5, mom 0.1).
  * finalize: reduce conv-epilogue partials -> batch mean / biased var ->

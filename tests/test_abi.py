@@ -46,6 +46,6 @@ def test_argument_validation_without_gpu():
     lib = _lib.load()
     d = _lib.ConvDesc()
     d.N, d.Cin, d.Cout = 1, 3, 8  # Cin not a multiple of 8
-    rc = lib.vs_conv_fwd(None, None, None, ctypes.byref(d), None, None, None, None, None, None, None, 0, None)
+    rc = lib.vs_conv_fwd(None, None, None, ctypes.byref(d), None, None, None, None, None, 0, None)
     assert rc == -1
     assert b"multiples of 8" in lib.vs_last_error_string()

@@ -1,6 +1,6 @@
 """Measure every tile config on every distinct conv GEMM shape of the bench step (fwd + dgrad)
-on the GPU box and write vidsitu_amd/conv_tune.json (shape key -> tile id).  Run through gpurun:
-    python tools/autotune_conv.py && cp vidsitu_amd/conv_tune.json gpurun_out/
+on the GPU box; writes gpurun_out/autotune_report.txt (+ conv_tune.json, informational).  Run through gpurun:
+    python tools/autotune_conv.py
 """
 import json
 import os

@@ -16,8 +16,6 @@ VS_CONV_RESIDUAL = 2
 VS_CONV_RELU = 4
 VS_CONV_STATS = 8
 VS_CONV_NAIVE = 16
-VS_CONV_APRO = 32
-VS_CONV_APRO_RELU = 64
 
 
 class ConvDesc(C.Structure):
@@ -44,7 +42,7 @@ SIGNATURES = {
     "vs_stem_stats_rows": (_i, [_i, _i, _i, _i]),
     "vs_stem_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "vs_stem_conv_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
-    "vs_conv_fwd": (_i, [_p, _p, _p, _dp, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "vs_conv_fwd": (_i, [_p, _p, _p, _dp, _p, _p, _p, _p, _p, _sz, _p]),
     "vs_conv_stats_rows": (_i, [_dp]),
     "vs_conv_workspace_bytes": (_sz, [_dp, _i]),
     "vs_conv_plan": (_i, [_dp, _i, _p]),
@@ -52,7 +50,7 @@ SIGNATURES = {
     "vs_weight_transpose": (_i, [_p, _p, _i, _i, _i, _p]),
     "vs_weight_transpose_batched": (_i, [_p, _p, _p, _i, _i64, _p]),
     "vs_conv_wgrad_workspace_bytes": (_sz, [_dp]),
-    "vs_conv_wgrad": (_i, [_p, _p, _p, _dp, _p, _p, _p, _sz, _p]),
+    "vs_conv_wgrad": (_i, [_p, _p, _p, _dp, _p, _sz, _p]),
     "vs_bn_finalize": (_i, [_p, _i, _d, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i, _p]),
     "vs_bn_partials_reduce": (_i, [_p, _i, _p, _i, _i, _p]),
     "vs_bn_apply": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p]),

@@ -1273,20 +1273,13 @@ extern "C" size_t vs_conv_workspace_bytes(const vs_conv_desc* d, int dgrad) {
 
 extern "C" int vs_conv_fwd(const void* x, const void* w, void* y, const vs_conv_desc* d,
                            const float* scale, const float* shift, const void* residual,
-                           float* stats_partial, const float* in_scale, const float* in_shift,
-                           void* workspace, size_t ws_bytes, void* stream) {
+                           float* stats_partial, void* workspace, size_t ws_bytes, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   VS_CHECK_ARG(x && w && y, "null tensor");
   VS_CHECK_ARG(!(d->flags & VS_CONV_AFFINE) || (scale && shift), "AFFINE needs scale/shift");
   VS_CHECK_ARG(!(d->flags & VS_CONV_RESIDUAL) || residual, "RESIDUAL needs residual");
   VS_CHECK_ARG(!(d->flags & VS_CONV_STATS) || stats_partial, "STATS needs stats_partial");
-  if (d->flags & VS_CONV_APRO) {
-    (void)in_scale;
-    (void)in_shift;
-    vs_set_error("vs_conv_fwd: VS_CONV_APRO not implemented yet");
-    return VS_ERR_UNSUPPORTED;
-  }
   ConvP p;
   p.x = (const uint16_t*)x;
   p.w = (const uint16_t*)w;

@@ -576,18 +576,12 @@ static int wg_launch(const WgradP& p, int mode, int ring, hipStream_t st) {
 }
 
 extern "C" int vs_conv_wgrad(const void* dy, const void* x, float* dw, const vs_conv_desc* d,
-                             const float* in_scale, const float* in_shift, void* workspace,
+                             void* workspace,
                              size_t ws_bytes, void* stream) {
   VS_CHECK_ARG(d && dy && x && dw, "null argument");
   VS_CHECK_ARG(d->Cin % 8 == 0 && d->Cout % 8 == 0, "Cin and Cout must be multiples of 8");
   VS_CHECK_ARG(d->x_ld % 8 == 0 && d->y_ld % 8 == 0, "row pitches must be multiples of 8");
   VS_CHECK_ARG((long long)d->N * d->Ti * d->Hi * d->Wi < (1ll << 31), "too many positions");
-  if (d->flags & VS_CONV_APRO) {
-    (void)in_scale;
-    (void)in_shift;
-    vs_set_error("vs_conv_wgrad: VS_CONV_APRO not implemented yet");
-    return VS_ERR_UNSUPPORTED;
-  }
   const WgCfg c = wg_pick(d);
   const size_t need = vs_conv_wgrad_workspace_bytes(d);
   if (need > 0 && (workspace == nullptr || ws_bytes < need)) {

@@ -139,28 +139,9 @@ TILE_CFGS = [(128, 128), (64, 128), (128, 64), (64, 64), (256, 32), (256, 16), (
 _tune = None
 
 
-def _tune_table():
-    """Per-shape tile choices measured on MI355X by tools/autotune_conv.py (optional)."""
-    global _tune
-    if _tune is None:
-        import json
-        import os
-
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_tune.json")
-        _tune = {}
-        if os.path.exists(path):
-            with open(path) as f:
-                _tune = json.load(f)
-    return _tune
-
-
 def tile_flag(kind, M, ncols, K, k, s, force=None):
-    """flags bits 8..11 for this GEMM shape: forced id, tuned id, or 0 (C-side heuristic)."""
-    if force is not None:
-        return (force + 1) << 8
-    key = f"{kind}:{M}:{ncols}:{K}:{k[0]}{k[1]}{k[2]}:{s[0]}{s[1]}{s[2]}"
-    tid = _tune_table().get(key)
-    return ((tid + 1) << 8) if tid is not None else 0
+    """flags bits 8..11: a forced tile id, or 0 = the library's own plan (pick_tile)."""
+    return (force + 1) << 8 if force is not None else 0
 
 
 def conv_fwd(x, w, k, s, p, out=None, scale=None, shift=None, residual=None, relu=False,
@@ -202,7 +183,7 @@ def conv_fwd(x, w, k, s, p, out=None, scale=None, shift=None, residual=None, rel
     need = _lib.load().vs_conv_workspace_bytes(C.byref(d), 0)
     ws = _workspace(need, x.device) if need else None
     _lib.call("vs_conv_fwd", _ptr(x), _ptr(w), _ptr(out), C.byref(d), _ptr(scale), _ptr(shift),
-              _ptr(residual), _ptr(partials), None, None, _ptr(ws),
+              _ptr(residual), _ptr(partials), _ptr(ws),
               C.c_size_t(ws.numel() if ws is not None else 0), _stream())
     return out, partials
 
@@ -315,7 +296,7 @@ def conv_wgrad(dy, x, k, s, p, out=None, ring=0):
     d = make_desc(x.shape, act_ld(x), dy.shape, act_ld(dy), k, s, p, (ring & 7) << 16)
     need = _lib.load().vs_conv_wgrad_workspace_bytes(C.byref(d))
     ws = _workspace(need, x.device) if need else None
-    _lib.call("vs_conv_wgrad", _ptr(dy), _ptr(x), _ptr(out), C.byref(d), None, None, _ptr(ws),
+    _lib.call("vs_conv_wgrad", _ptr(dy), _ptr(x), _ptr(out), C.byref(d), _ptr(ws),
               C.c_size_t(ws.numel() if ws is not None else 0), _stream())
     return out
 
