@@ -146,6 +146,12 @@ int vs_bn_partials_reduce(const float* partials, int nparts, float* out, int C, 
 int vs_bn_apply(const void* y, const float* scale, const float* shift, const void* residual,
                 void* out, int64_t rows, int C, int y_ld, int res_ld, int out_ld, int relu,
                 void* stream);
+/* vs_bn_apply with ReLU that also writes the ReLU mask as bits: relu_bits[rows][C/8] bytes, bit e of
+ * byte (row, c/8) = out[row][c + e] > 0.  vs_bn_bwd_reduce / vs_bn_bwd_apply take it in place of z
+ * with relu = 2 (16x fewer mask bytes than re-reading the output).  C/8 must be a power of two. */
+int vs_bn_apply_mask(const void* y, const float* scale, const float* shift, const void* residual,
+                     void* out, uint8_t* relu_bits, int64_t rows, int C, int y_ld, int res_ld,
+                     int out_ld, void* stream);
 /* Backward of z = relu?(bn(y) (+res)):  g = dz * [z>0];
  *   pass 1 (reduce): partial[blk][2][C] = (sum g, sum g*xhat), xhat=(y-mean)*invstd
  *   pass 2 (apply):  dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M); dres = g. */

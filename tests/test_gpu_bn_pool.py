@@ -87,7 +87,20 @@ def test_bn_backward_matches_autograd(c, hw, relu, res, dev):
     assert_close(dbeta, grads[2], 2e-2, "dbeta")
     if res:
         assert_close(dres, grads[3], 2e-2, "dres")
-    elif relu:  # same backward with the ReLU mask recomputed from y instead of read from z
+    if relu:
+        # ReLU mask as bits written by the forward apply: bit-identical to the mask read from z
+        z2, bits = ops.bn_apply(yd, scale.to(dev), shift.to(dev), to_act(r.detach(), dev) if res else None,
+                                True, want_bits=True)
+        assert torch.equal(z2, z) and bits.shape == (n * t * hw * hw, c // 8)
+        want_bits = (z.permute(0, 2, 3, 4, 1).reshape(-1, c // 8, 8) > 0).to(torch.uint8)
+        want_bits = (want_bits << torch.arange(8, device=dev, dtype=torch.uint8)).sum(-1).to(torch.uint8)
+        assert torch.equal(bits, want_bits)
+        dy3, dres3, dg3, db3 = ops.bn_bwd(to_act(dz, dev), None, yd, mean.to(dev), invstd.to(dev),
+                                          gamma.detach().to(dev), True, want_dres=res, zbits=bits)
+        assert torch.equal(dy3, dy) and torch.equal(dg3, dgamma) and torch.equal(db3, dbeta)
+        if res:
+            assert torch.equal(dres3, dres)
+    if relu and not res:  # same backward with the ReLU mask recomputed from y instead of read from z
         dy2, _, dg2, db2 = ops.bn_bwd(to_act(dz, dev), None, yd, mean.to(dev), invstd.to(dev),
                                       gamma.detach().to(dev), True, want_dres=False,
                                       beta=beta.detach().to(dev))

@@ -293,9 +293,9 @@ static bool cpr_pow2(int C) {
 template <bool RES, bool RELU>
 __global__ __launch_bounds__(256) void bn_apply_cols_kernel(const uint16_t* y, const float* scale,
                                                             const float* shift, const uint16_t* res,
-                                                            uint16_t* out, long long rows, int C,
-                                                            int y_ld, int res_ld, int out_ld,
-                                                            int nbatch) {
+                                                            uint16_t* out, uint8_t* bits,
+                                                            long long rows, int C, int y_ld,
+                                                            int res_ld, int out_ld, int nbatch) {
   const int cpr = C >> 3;
   const int ncol = cpr < 256 ? cpr : 256;
   const int rl = 256 / ncol;
@@ -329,19 +329,28 @@ __global__ __launch_bounds__(256) void bn_apply_cols_kernel(const uint16_t* y, c
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += r[e];
         }
+        unsigned mbits = 0u;
         if (RELU) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          for (int e = 0; e < 8; ++e) {
+            mbits |= (v[e] > 0.f ? 1u : 0u) << e;
+            v[e] = fmaxf(v[e], 0.f);
+          }
         }
-        if (row[u] < rows) *(uint4*)(out + row[u] * out_ld + c) = pack8_bf16(v);
+        if (row[u] < rows) {
+          *(uint4*)(out + row[u] * out_ld + c) = pack8_bf16(v);
+          // ReLU mask as one bit per element: the backward passes read it instead of the 16x
+          // larger output tensor
+          if (RELU && bits) bits[row[u] * cpr + cb] = (uint8_t)mbits;
+        }
       }
     }
   }
 }
 
-extern "C" int vs_bn_apply(const void* y, const float* scale, const float* shift,
-                           const void* residual, void* out, int64_t rows, int C, int y_ld,
-                           int res_ld, int out_ld, int relu, void* stream) {
+static int bn_apply_impl(const void* y, const float* scale, const float* shift, const void* residual,
+                         void* out, uint8_t* relu_bits, int64_t rows, int C, int y_ld, int res_ld,
+                         int out_ld, int relu, void* stream) {
   VS_CHECK_ARG(y && scale && shift && out, "null tensor");
   VS_CHECK_ARG(C % 8 == 0 && y_ld % 8 == 0 && out_ld % 8 == 0 && (!residual || res_ld % 8 == 0),
                "channels / pitches must be multiples of 8");
@@ -351,7 +360,7 @@ extern "C" int vs_bn_apply(const void* y, const float* scale, const float* shift
     const int cpr = C / 8, ncol = cpr < 256 ? cpr : 256;
     const long long rpb = (long long)(256 / ncol) * BNA_BATCH * nb;
     const dim3 grid((unsigned)((rows + rpb - 1) / rpb)), block(256);
-#define BNA_ARGS (const uint16_t*)y, scale, shift, (const uint16_t*)residual, (uint16_t*)out,                  (long long)rows, C, y_ld, res_ld, out_ld, nb
+#define BNA_ARGS (const uint16_t*)y, scale, shift, (const uint16_t*)residual, (uint16_t*)out, relu_bits, (long long)rows, C, y_ld, res_ld, out_ld, nb
     if (residual && relu) hipLaunchKernelGGL((bn_apply_cols_kernel<true, true>), grid, block, 0, st, BNA_ARGS);
     else if (residual) hipLaunchKernelGGL((bn_apply_cols_kernel<true, false>), grid, block, 0, st, BNA_ARGS);
     else if (relu) hipLaunchKernelGGL((bn_apply_cols_kernel<false, true>), grid, block, 0, st, BNA_ARGS);
@@ -360,11 +369,27 @@ extern "C" int vs_bn_apply(const void* y, const float* scale, const float* shift
     VS_CHECK_LAUNCH();
     return VS_OK;
   }
+  VS_CHECK_ARG(!relu_bits, "the ReLU bit mask needs C/8 to be a power of two");
   hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(rows * (C / 8))), dim3(256), 0, st,
                      (const uint16_t*)y, scale, shift, (const uint16_t*)residual, (uint16_t*)out,
                      (long long)rows, C, y_ld, res_ld, out_ld, relu);
   VS_CHECK_LAUNCH();
   return VS_OK;
+}
+
+extern "C" int vs_bn_apply(const void* y, const float* scale, const float* shift,
+                           const void* residual, void* out, int64_t rows, int C, int y_ld,
+                           int res_ld, int out_ld, int relu, void* stream) {
+  return bn_apply_impl(y, scale, shift, residual, out, nullptr, rows, C, y_ld, res_ld, out_ld, relu,
+                       stream);
+}
+
+extern "C" int vs_bn_apply_mask(const void* y, const float* scale, const float* shift,
+                                const void* residual, void* out, uint8_t* relu_bits, int64_t rows,
+                                int C, int y_ld, int res_ld, int out_ld, void* stream) {
+  VS_CHECK_ARG(relu_bits, "null mask");
+  return bn_apply_impl(y, scale, shift, residual, out, relu_bits, rows, C, y_ld, res_ld, out_ld, 1,
+                       stream);
 }
 
 // ----------------------------------------------------------------------------
@@ -389,7 +414,8 @@ static int bnb_batches(long long rows, int C) {
 }
 
 // MASK 0: no relu; 1: relu mask from z; 2: mask recomputed as gamma*xhat + beta > 0 (units
-// without a residual input), which drops one of the three reads of each pass.
+// without a residual input), which drops one of the three reads of each pass; 3: `z` is the
+// bit mask written by vs_bn_apply_mask ([rows][C/8] bytes): one byte instead of 16 per load.
 template <int MASK>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const uint16_t* dz, const uint16_t* z, const uint16_t* y, const float* mean,
@@ -424,6 +450,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
         vg[u] = *(const uint4*)(dz + rr * dz_ld + c);
         vy[u] = *(const uint4*)(y + rr * y_ld + c);
         if (MASK == 1) vz[u] = *(const uint4*)(z + rr * z_ld + c);
+        if (MASK == 3) vz[u].x = ((const uint8_t*)z)[rr * cpr + cb];
         if (!ok) vg[u] = make_uint4(0u, 0u, 0u, 0u);
       }
 #pragma unroll
@@ -440,6 +467,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 #pragma unroll
           for (int e = 0; e < 8; ++e)
             g[e] = ((yv[e] - mu[e]) * is[e] * ga[e] + be[e]) > 0.f ? g[e] : 0.f;
+        } else if (MASK == 3) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) g[e] = ((vz[u].x >> e) & 1u) ? g[e] : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -495,6 +525,7 @@ extern "C" int vs_bn_bwd_reduce(const void* dz, const void* z, const void* y, co
                                 int relu, void* stream) {
   VS_CHECK_ARG(dz && y && mean && invstd && partial, "null tensor");
   VS_CHECK_ARG(!relu || z || (gamma && beta), "relu needs z, or gamma/beta to recompute the mask");
+  VS_CHECK_ARG(relu != 2 || z, "relu = 2 needs the bit mask in z");
   VS_CHECK_ARG(bnb_check(C), "C/8 must be a power of two");
   const int nblk = vs_bn_bwd_reduce_rows(rows, C);
   const int nb = bnb_batches(rows, C);
@@ -503,6 +534,7 @@ extern "C" int vs_bn_bwd_reduce(const void* dz, const void* z, const void* y, co
                      (const uint16_t*)dz, (const uint16_t*)z, (const uint16_t*)y, mean, invstd,    \
                      gamma, beta, partial, (long long)rows, C, dz_ld, z_ld, y_ld, nb)
   if (!relu) VS_BNB_LAUNCH(0);
+  else if (relu == 2) VS_BNB_LAUNCH(3);
   else if (z) VS_BNB_LAUNCH(1);
   else VS_BNB_LAUNCH(2);
 #undef VS_BNB_LAUNCH
@@ -643,6 +675,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cols_kernel(
         vg[u] = *(const uint4*)(dz + rr * dz_ld + c);
         vy[u] = *(const uint4*)(y + rr * y_ld + c);
         if (MASK == 1) vz[u] = *(const uint4*)(z + rr * z_ld + c);
+        if (MASK == 3) vz[u].x = ((const uint8_t*)z)[rr * cpr + cb];
       }
 #pragma unroll
       for (int u = 0; u < BNA_BATCH; ++u) {
@@ -654,6 +687,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cols_kernel(
           unpack8_bf16(vz[u], zv);
 #pragma unroll
           for (int e = 0; e < 8; ++e) g[e] = zv[e] > 0.f ? g[e] : 0.f;
+        }
+        if (MASK == 3) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) g[e] = ((vz[u].x >> e) & 1u) ? g[e] : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -688,17 +725,20 @@ extern "C" int vs_bn_bwd_apply(const void* dz, const void* z, const void* y, con
     const int cpr = C / 8, ncol = cpr < 256 ? cpr : 256;
     const long long rpb = (long long)(256 / ncol) * BNA_BATCH * nb;
     const dim3 grid((unsigned)((rows + rpb - 1) / rpb)), block(256);
-    const int mask = !relu ? 0 : (z ? 1 : 2);
+    const int mask = !relu ? 0 : (relu == 2 ? 3 : (z ? 1 : 2));
 #define BNB_L(M, D) hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<M, D>), grid, block, 0, st, BNB_ARGS, nb)
     if (dres) {
-      if (mask == 0) BNB_L(0, true); else if (mask == 1) BNB_L(1, true); else BNB_L(2, true);
+      if (mask == 0) BNB_L(0, true); else if (mask == 1) BNB_L(1, true);
+      else if (mask == 2) BNB_L(2, true); else BNB_L(3, true);
     } else {
-      if (mask == 0) BNB_L(0, false); else if (mask == 1) BNB_L(1, false); else BNB_L(2, false);
+      if (mask == 0) BNB_L(0, false); else if (mask == 1) BNB_L(1, false);
+      else if (mask == 2) BNB_L(2, false); else BNB_L(3, false);
     }
 #undef BNB_L
     VS_CHECK_LAUNCH();
     return VS_OK;
   }
+  VS_CHECK_ARG(relu != 2, "the ReLU bit mask needs C/8 to be a power of two");
   const dim3 grid(ew_grid(rows * (C / 8))), block(256);
   if (!relu) hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, grid, block, 0, st, BNB_ARGS);
   else if (z) hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, grid, block, 0, st, BNB_ARGS);

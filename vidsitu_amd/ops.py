@@ -322,30 +322,43 @@ def bn_finalize(partials, count, gamma, beta, running_mean, running_var, momentu
     return scale, shift, mean, invstd
 
 
-def bn_apply(y, scale, shift, residual=None, relu=True, out=None):
+def bn_apply(y, scale, shift, residual=None, relu=True, out=None, want_bits=False):
+    """out = relu?(y * scale + shift (+ residual)).  want_bits (with relu): also returns the ReLU
+    mask as bits, uint8 [rows, C/8], for the backward passes (vs_bn_apply_mask)."""
     if out is None:
         out = new_act(*y.shape, device=y.device)
+    if want_bits and relu:
+        bits = torch.empty((act_rows(y), y.shape[1] // 8), dtype=torch.uint8, device=y.device)
+        _lib.call("vs_bn_apply_mask", _ptr(y), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out),
+                  _ptr(bits), act_rows(y), y.shape[1], act_ld(y),
+                  act_ld(residual) if residual is not None else 0, act_ld(out), _stream())
+        return out, bits
     _lib.call("vs_bn_apply", _ptr(y), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out),
               act_rows(y), y.shape[1], act_ld(y), act_ld(residual) if residual is not None else 0,
               act_ld(out), int(relu), _stream())
-    return out
+    return (out, None) if want_bits else out
 
 
 def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres, dy_out=None, dgamma=None, dbeta=None,
-           beta=None):
+           beta=None, zbits=None):
     """Returns (dy, dres|None, dgamma, dbeta); dgamma / dbeta may be given (param.grad views).
-    With `beta` given and z None the ReLU mask is recomputed from y (no residual input)."""
+    ReLU mask source, in order of preference: `zbits` (uint8 [rows, C/8] from bn_apply), `z`
+    (the unit's output), or -- with `beta` given and both None -- recomputed from y (units
+    without a residual input)."""
     rows, c = act_rows(y), y.shape[1]
     dev = y.device
     nblk = _lib.load().vs_bn_bwd_reduce_rows(rows, c)
     if nblk <= 0:
         raise _lib.VsError("bn_bwd: unsupported channel count")
     partial = torch.empty((nblk, 2, c), dtype=torch.float32, device=dev)
+    mode = int(relu)
     zz = z if relu else None
     z_ld = act_ld(zz) if zz is not None else 0
+    if relu and zbits is not None:
+        mode, zz, z_ld = 2, zbits, c // 8
     _lib.call("vs_bn_bwd_reduce", _ptr(dz), _ptr(zz), _ptr(y), _ptr(mean), _ptr(invstd),
               _ptr(gamma), _ptr(beta), _ptr(partial), rows, c, act_ld(dz), z_ld, act_ld(y),
-              int(relu), _stream())
+              mode, _stream())
     if dgamma is None:
         dgamma = torch.empty(c, dtype=torch.float32, device=dev)
     if dbeta is None:
@@ -356,7 +369,7 @@ def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres, dy_out=None, dgamma=N
     _lib.call("vs_bn_bwd_apply", _ptr(dz), _ptr(zz), _ptr(y), _ptr(mean), _ptr(invstd),
               _ptr(gamma), _ptr(beta), _ptr(dgamma), _ptr(dbeta), _ptr(dy), _ptr(dres), rows, c,
               act_ld(dz), z_ld, act_ld(y), act_ld(dy), act_ld(dres) if want_dres else 0,
-              int(relu), _stream())
+              mode, _stream())
     return dy, dres, dgamma, dbeta
 
 

@@ -195,11 +195,15 @@ class _Unit:
         scale, shift, mean, invstd = ops.bn_finalize(
             partials, ops.act_rows(y), bn.weight, bn.bias, bn.running_mean, bn.running_var,
             bn.momentum, bn.eps, train=True)
-        z = ops.bn_apply(y, scale, shift, residual, relu, out=out)
+        # a unit with a residual input cannot recompute its ReLU mask from y alone: keep it as bits
+        want_bits = relu and residual is not None and y.shape[1] % 8 == 0 and \
+            ((y.shape[1] // 8) & (y.shape[1] // 8 - 1)) == 0
+        z, zbits = ops.bn_apply(y, scale, shift, residual, relu, out=out, want_bits=True) if want_bits \
+            else (ops.bn_apply(y, scale, shift, residual, relu, out=out), None)
         if _Unit.trace is not None:
             _Unit.trace.append((conv, y.float().cpu(), z.float().cpu(), mean.cpu(), invstd.cpu()))
-        saved.append(dict(conv=conv, bn=bn, x=x, y=y, z=z, mean=mean, invstd=invstd, relu=relu,
-                          has_res=residual is not None))
+        saved.append(dict(conv=conv, bn=bn, x=x, y=y, z=z, zbits=zbits, mean=mean, invstd=invstd,
+                          relu=relu, has_res=residual is not None))
         return z
 
     @staticmethod
@@ -212,10 +216,11 @@ class _Unit:
         if bn.bias.grad is None:
             bn.bias.grad = torch.zeros_like(bn.bias)
         # without a residual input the ReLU mask is recomputed from y (z is not read)
-        zmask = rec["z"] if (relu and rec["has_res"]) else None
+        zbits = rec.get("zbits") if relu else None
+        zmask = rec["z"] if (relu and rec["has_res"] and zbits is None) else None
         dy, dres, _, _ = ops.bn_bwd(
             dz, zmask, rec["y"], rec["mean"], rec["invstd"], bn.weight, relu, want_dres,
-            dgamma=bn.weight.grad, dbeta=bn.bias.grad, beta=bn.bias)
+            dgamma=bn.weight.grad, dbeta=bn.bias.grad, beta=bn.bias, zbits=zbits)
         x = rec["x"]
         if conv.is_stem:
             _WgradLanes.run(lambda: _set_grad(conv.weight, ops.stem_conv_wgrad(dy, x, conv.k[0])), dy, x)
