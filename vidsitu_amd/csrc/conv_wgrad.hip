@@ -13,6 +13,8 @@
 //   unit' = unit ^ ((row & 3) << 2) ^ (((row >> 3) & 1) << 4).
 // Split-K partials go to fp32 slabs [S][Cout][K'] and are summed in a fixed
 // order by a second kernel (bitwise reproducible; no atomics).
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -509,7 +511,14 @@ static WgCfg wg_pick(const vs_conv_desc* d) {
   // traffic (S x |dW| fp32, written and re-read) stays small next to the operand reads
   // Skinny outputs (fast pathway, stems: a handful of tiles, 10^5..10^6 positions) are
   // latency bound per 64-position step, so they get up to 2048 blocks.
-  const long long target = (d->Cout <= 32) ? 2048 : 512;
+  static const long long slots = [] {
+    const char* e = getenv("VS_WGRAD_SLOTS");  // experiment knob: resident block slots to fill
+    return e ? atoll(e) : 512ll;
+  }();
+  // pointwise convs (one tap, small K'): fewer, longer blocks beat a full residency round
+  // (s4.c 23.3 -> 21.5 us, s3.c 25.4 -> 21.1 us at 384 slots; 3x3 / temporal convs want all 512)
+  const bool dense = d->kT * d->kH * d->kW == 1;
+  const long long target = (d->Cout <= 32) ? 2048 : (dense && !getenv("VS_WGRAD_SLOTS") ? 384 : slots);
   // two blocks are resident per CU (80 KB of LDS each): 512 slots.  Round the split DOWN so that
   // the grid fits one residency round -- 528 blocks on 512 slots run as two rounds (s4.a: +45 %)
   long long S = (d->Cout <= 32) ? (target + tiles - 1) / tiles : target / tiles;
