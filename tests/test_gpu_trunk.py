@@ -308,3 +308,93 @@ def test_every_gradient_is_overwritten(dev):
         bad = [n for n, p in mdl.named_parameters() if not torch.isfinite(p.grad).all()]
         assert not bad, f"gradients not overwritten: {bad[:5]}"
         assert torch.isfinite(arena.grad).all()
+
+
+@pytest.mark.parametrize("sf_name,crop,bs,n_ev,layers", [("slow_fast_mini", 64, 2, 2, 2),
+                                                         ("slow_fast_nl_r50_8x8", 224, 2, 4, 6)],
+                         ids=["mini", "r50_bench_config"])
+def test_hipgraph_two_stream_step_is_bitwise_the_one_stream_eager_step(sf_name, crop, bs, n_ev, layers, dev):
+    """The timed region of bench.py replays a hipGraph whose pathway / wgrad branches run on
+    parallel streams.  Every kernel is deterministic, so gradients and loss of that replay must
+    equal, bit for bit, an eager step with everything on one stream -- a missing dependency between
+    the streams would show up here as a mismatch."""
+    from vidsitu_amd import synth_data, trunk as T
+    from vidsitu_amd.extended_config import get_cfg
+    from vidsitu_amd.mdl_selector import get_mdl_loss_eval
+    from vidsitu_amd.optim import ParamArena
+
+    cfg = get_cfg({"mdl.mdl_name": "sf_base_txenc", "mdl.sf_mdl_name": sf_name,
+                   "synth.num_verbs": 31, "tx_dec.encoder_layers": layers, "tx_dec.dropout": 0.0})
+    comm = synth_data.make_comm(cfg)
+    torch.manual_seed(0)
+    sel = get_mdl_loss_eval(cfg)
+    mdl = sel["mdl"](cfg=cfg, comm=comm).to(dev).train()
+    loss_fn = sel["loss"](cfg, comm)
+    arena = ParamArena(mdl)
+    batch = synth_data.synth_batch(cfg, comm, bs=bs, n_ev=n_ev, crop=crop, device=dev, dtype=torch.bfloat16)
+    out = {}
+
+    def step():
+        arena.zero_grad()
+        loss = loss_fn(mdl(batch), batch)["loss"]
+        loss.backward()
+        out["loss"] = loss.detach()
+
+    saved = (T.VideoTrunk.dual_stream, T._WgradLanes.enabled)
+    try:
+        T.VideoTrunk.dual_stream, T._WgradLanes.enabled = False, False
+        step()
+        torch.cuda.synchronize()
+        g_ref, l_ref = arena.grad.clone(), out["loss"].clone()
+        assert torch.isfinite(g_ref).all() and float(g_ref.abs().max()) > 0
+        T.VideoTrunk.dual_stream, T._WgradLanes.enabled = True, True
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert torch.equal(arena.grad, g_ref), "eager two-stream step differs from one-stream"
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        for it in range(3):
+            arena.grad.fill_(float("nan"))
+            graph.replay()
+            torch.cuda.synchronize()
+            if not torch.equal(arena.grad, g_ref):
+                bad = []
+                for (n, p_), off, end in zip(mdl.named_parameters(), arena.offsets, arena.offsets[1:]):
+                    a, b = arena.grad[off:off + p_.numel()], g_ref[off:off + p_.numel()]
+                    if not torch.equal(a, b):
+                        bad.append((n, float((a - b).abs().max()), float(b.abs().max()),
+                                    int(torch.isnan(a).sum())))
+                raise AssertionError(f"hipGraph replay {it} differs from the eager step in "
+                                     f"{len(bad)} parameters: {bad[:12]}")
+            assert torch.equal(out["loss"], l_ref)
+        # the distributed step of bench.py: trunk backward deferred out of autograd and captured as
+        # one graph per segment (gradient buckets are all-reduced between the replays)
+        trunk = mdl.sf_mdl
+        trunk.defer_backward = True
+        segs = [step] + [(lambda sg=sg: trunk.run_backward_segment(sg)) for sg in trunk.BWD_SEGMENTS]
+        for fn in segs:  # eager warm-up of the deferred path
+            fn()
+        torch.cuda.synchronize()
+        assert torch.equal(arena.grad, g_ref), "eager segmented step differs"
+        graphs, pool = [], None
+        for fn in segs:
+            gseg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gseg, pool=pool):
+                fn()
+            pool = gseg.pool()
+            graphs.append(gseg)
+        for it in range(2):
+            arena.grad.fill_(float("nan"))
+            for gseg in graphs:
+                gseg.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(arena.grad, g_ref), f"segmented hipGraph replay {it} differs"
+    finally:
+        T.VideoTrunk.dual_stream, T._WgradLanes.enabled = saved
+        mdl.sf_mdl.defer_backward = False

@@ -577,6 +577,18 @@ class VideoTrunk(nn.Module):
         P = self.num_pathways
         xin, shapes = [], []
         dev = inputs[0].device
+        if train:
+            bns = [m.num_batches_tracked for m in self.modules() if isinstance(m, BN3dP)]
+            torch._foreach_add_(bns, 1)
+            self._stats_epoch += 1
+        else:
+            self._ensure_folds()
+        # Fork BEFORE packing: each pathway's packed input must belong to the stream that reads it
+        # (a buffer from the main stream's pool, freed when the fast stem's backward record is
+        # dropped, was re-used by the slow pathway while the fast stem's wgrad was still reading
+        # it: caught by test_hipgraph_two_stream_step_is_bitwise_the_one_stream_eager_step)
+        par = self._fork_ctx(dev)
+        par.fork()
         if inputs[0].dtype == torch.uint8:
             # uint8 frames [N, T, H, W, 3] (what the loader's PIL step produces): normalise, pack and
             # gather the slow pathway's frames on the GPU (vs_frames_u8_pack), one launch per pathway
@@ -587,27 +599,21 @@ class VideoTrunk(nn.Module):
                 if self.multi and p == 0:
                     tidx = self._slow_index(t, dev)
                 stem = getattr(self.s1, f"pathway{p}_stem").conv.is_stem
-                y = ops.frames_u8_pack(fr, 4 if stem else 8, tidx, self.data_mean, self.data_std,
-                                       self.data_reverse)
+                with par.on(p):
+                    y = ops.frames_u8_pack(fr, 4 if stem else 8, tidx, self.data_mean, self.data_std,
+                                           self.data_reverse)
                 xin.append((y, None) if stem else y)
                 shapes.append((n, 3, t if tidx is None else int(tidx.numel()), h, w))
         else:
             for p, t in enumerate(inputs):
-                if getattr(self.s1, f"pathway{p}_stem").conv.is_stem:
-                    xin.append((ops.pack_input(t, 4), None))
-                else:
-                    xin.append(ops.pack_input(t))
+                with par.on(p):
+                    if getattr(self.s1, f"pathway{p}_stem").conv.is_stem:
+                        xin.append((ops.pack_input(t, 4), None))
+                    else:
+                        xin.append(ops.pack_input(t))
                 shapes.append(tuple(t.shape))
-        if train:
-            bns = [m.num_batches_tracked for m in self.modules() if isinstance(m, BN3dP)]
-            torch._foreach_add_(bns, 1)
-            self._stats_epoch += 1
-        else:
-            self._ensure_folds()
         # ---- s1 (+ fuse): stems write straight into the concat buffer of the slow path
         cur = []
-        par = self._fork_ctx(dev)
-        par.fork()
         for p in range(P):
             stem = getattr(self.s1, f"pathway{p}_stem")
             n, _, t, h, w = shapes[p]
