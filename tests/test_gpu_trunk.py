@@ -398,3 +398,49 @@ def test_hipgraph_two_stream_step_is_bitwise_the_one_stream_eager_step(sf_name, 
     finally:
         T.VideoTrunk.dual_stream, T._WgradLanes.enabled = saved
         mdl.sf_mdl.defer_backward = False
+
+
+def test_hipgraph_two_stream_eval_forward_is_bitwise_the_one_stream_one(dev):
+    """configs[1] (feature extractor, eval): activations are freed as the pass goes, so a buffer
+    re-used across the two pathway streams would corrupt the features -- compare the two-stream
+    hipGraph replay with a one-stream eager pass, bit for bit, at the bench configuration."""
+    from vidsitu_amd import synth_data, trunk as T
+    from vidsitu_amd.extended_config import get_cfg
+    from vidsitu_amd.mdl_selector import get_mdl_loss_eval
+
+    cfg = get_cfg({"mdl.mdl_name": "sf_base"})
+    comm = synth_data.make_comm(cfg)
+    torch.manual_seed(0)
+    mdl = get_mdl_loss_eval(cfg)["mdl"](cfg=cfg, comm=comm).to(dev).eval()
+    batch = synth_data.synth_batch(cfg, comm, bs=2, n_ev=4, device=dev, dtype=torch.bfloat16)
+    out = {}
+
+    def fwd():
+        with torch.no_grad():
+            out["f"] = mdl.head(mdl.forward_encoder(batch))
+
+    saved = T.VideoTrunk.dual_stream
+    try:
+        T.VideoTrunk.dual_stream = False
+        fwd()
+        torch.cuda.synchronize()
+        ref = out["f"].clone()
+        T.VideoTrunk.dual_stream = True
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                fwd()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert torch.equal(out["f"], ref)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fwd()
+        for _ in range(3):
+            out["f"].fill_(float("nan"))
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out["f"], ref)
+    finally:
+        T.VideoTrunk.dual_stream = saved
