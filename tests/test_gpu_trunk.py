@@ -444,3 +444,75 @@ def test_hipgraph_two_stream_eval_forward_is_bitwise_the_one_stream_one(dev):
             assert torch.equal(out["f"], ref)
     finally:
         T.VideoTrunk.dual_stream = saved
+
+
+def test_bench_style_training_trajectory_in_hipgraph_matches_eager(dev):
+    """Three optimizer steps replayed from the bench's graph (two pathway streams, wgrad lane,
+    dgrad weight images refreshed on a third stream at step start, bf16 cast fused into Adam)
+    leave exactly the parameters of three plain eager steps with a full weight refresh."""
+    from vidsitu_amd import synth_data, trunk as T
+    from vidsitu_amd.extended_config import get_cfg
+    from vidsitu_amd.mdl_selector import get_mdl_loss_eval
+    from vidsitu_amd.optim import ArenaAdam, ParamArena
+
+    cfg = get_cfg({"mdl.mdl_name": "sf_base_txenc", "mdl.sf_mdl_name": "slow_fast_mini",
+                   "synth.num_verbs": 31, "tx_dec.encoder_layers": 2, "tx_dec.dropout": 0.0})
+    comm = synth_data.make_comm(cfg)
+    torch.manual_seed(0)
+    sel = get_mdl_loss_eval(cfg)
+    mdl = sel["mdl"](cfg=cfg, comm=comm).to(dev).train()
+    loss_fn = sel["loss"](cfg, comm)
+    arena = ParamArena(mdl)
+    opt = ArenaAdam(arena, lr=1e-2)
+    batch = synth_data.synth_batch(cfg, comm, bs=2, n_ev=2, crop=64, device=dev, dtype=torch.bfloat16)
+    init = arena.data.clone()
+    bufs = {k: v.clone() for k, v in mdl.named_buffers()}
+
+    def reset():
+        arena.data.copy_(init)
+        opt.m.zero_(); opt.v.zero_(); opt.t.zero_()
+        for k, v in mdl.named_buffers():
+            v.copy_(bufs[k])
+        arena.refresh()
+
+    def fwd_bwd():
+        opt.zero_grad()
+        loss_fn(mdl(batch), batch)["loss"].backward()
+
+    saved = (T.VideoTrunk.dual_stream, T._WgradLanes.enabled)
+    try:
+        T.VideoTrunk.dual_stream, T._WgradLanes.enabled = False, False
+        reset()
+        for _ in range(3):
+            fwd_bwd()
+            opt.step()
+        torch.cuda.synchronize()
+        want = arena.data.clone()
+        assert not torch.equal(want, init)
+        T.VideoTrunk.dual_stream, T._WgradLanes.enabled = True, True
+
+        def step():
+            arena.transposes_async()
+            fwd_bwd()
+            arena._join_transposes()
+            opt.step(defer_transposes=True)
+
+        reset()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()  # warm-up (allocations, lane streams)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step()
+        torch.cuda.synchronize()
+        reset()
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(arena.data, want), \
+            f"max |diff| {float((arena.data - want).abs().max()):.3e}"
+    finally:
+        T.VideoTrunk.dual_stream, T._WgradLanes.enabled = saved
