@@ -18,64 +18,64 @@ __device__ __forceinline__ float gelu_new_f(float x) {
 
 // ----------------------------------------------------------------------------
 // y[M,N] = act(x[M,K] . w[N,K]^T + b) + res      ("NT": both operands K-contiguous)
-// 128x128x32 tile, 4 waves as 2x2, each wave a 64x64 block of four 32x32 MFMA accumulators.
+// 128x128x32 (or 64x64x32) tile, 4 waves as 2x2, each wave a block of 32x32 MFMA accumulators.
 // LDS rows are K-major with an odd pitch (33 floats): the fragment read of a 32x32x2 MFMA
 // (lane l: row l&31, k = l>>5) is then conflict free.  Register-staged double buffer.
 // ----------------------------------------------------------------------------
-#define GM_BM 128
-#define GM_BN 128
 #define GM_BK 32
 #define GM_LD 33
 
+template <int BM, int BN>  // 128x128 (2x2 MFMA tiles per wave) or 64x64 (one per wave)
 __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restrict__ x,
                                                           const float* __restrict__ w,
                                                           const float* __restrict__ bias,
                                                           const float* res, float* y, int M, int N,
                                                           int K, int act) {
-  __shared__ float As[2][GM_BM * GM_LD];
-  __shared__ float Bs[2][GM_BN * GM_LD];
+  constexpr int MR = BM / 64, NR = BN / 64;  // 32x32 accumulators per wave
+  constexpr int PA = BM / 32, PB = BN / 32;  // loader passes (32 rows each)
+  __shared__ float As[2][BM * GM_LD];
+  __shared__ float Bs[2][BN * GM_LD];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * GM_BM, n0 = blockIdx.x * GM_BN;
-  // loader mapping: 8 float4 per 32-float row, 32 rows per pass, 4 passes per operand
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // loader mapping: 8 float4 per 32-float row, 32 rows per pass
   const int lc = tid & 7, lr = tid >> 3;
   const bool kvec = (K & 3) == 0;
-  float4 ra[4], rb[4];
+  float4 ra[PA], rb[PB];
 
+  auto ld4 = [&](const float* base, int row, int rows, int k) __attribute__((always_inline)) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < rows && k < K) {
+      const float* s = base + (long long)row * K + k;
+      if (kvec) v = *(const float4*)s;
+      else { v.x = s[0]; if (k + 1 < K) v.y = s[1]; if (k + 2 < K) v.z = s[2]; if (k + 3 < K) v.w = s[3]; }
+    }
+    return v;
+  };
   auto gload = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = lr + 32 * i, k = k0 + lc * 4;
-      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-      if (m0 + r < M && k < K) {
-        const float* s = x + (long long)(m0 + r) * K + k;
-        if (kvec) va = *(const float4*)s;
-        else { va.x = s[0]; if (k + 1 < K) va.y = s[1]; if (k + 2 < K) va.z = s[2]; if (k + 3 < K) va.w = s[3]; }
-      }
-      if (n0 + r < N && k < K) {
-        const float* s = w + (long long)(n0 + r) * K + k;
-        if (kvec) vb = *(const float4*)s;
-        else { vb.x = s[0]; if (k + 1 < K) vb.y = s[1]; if (k + 2 < K) vb.z = s[2]; if (k + 3 < K) vb.w = s[3]; }
-      }
-      ra[i] = va;
-      rb[i] = vb;
-    }
+    for (int i = 0; i < PA; ++i) ra[i] = ld4(x, m0 + lr + 32 * i, M, k0 + lc * 4);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) rb[i] = ld4(w, n0 + lr + 32 * i, N, k0 + lc * 4);
   };
   auto sstore = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < PA; ++i) {
       float* a = &As[buf][(lr + 32 * i) * GM_LD + lc * 4];
-      float* b = &Bs[buf][(lr + 32 * i) * GM_LD + lc * 4];
       a[0] = ra[i].x; a[1] = ra[i].y; a[2] = ra[i].z; a[3] = ra[i].w;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      float* b = &Bs[buf][(lr + 32 * i) * GM_LD + lc * 4];
       b[0] = rb[i].x; b[1] = rb[i].y; b[2] = rb[i].z; b[3] = rb[i].w;
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[MR][NR];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < MR; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NR; ++b)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
@@ -87,33 +87,37 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) gload((kt + 1) * GM_BK);
-    const float* A = &As[cur][(wm * 64 + fr) * GM_LD + fk];
-    const float* B = &Bs[cur][(wn * 64 + fr) * GM_LD + fk];
+    const float* A = &As[cur][(wm * (BM / 2) + fr) * GM_LD + fk];
+    const float* B = &Bs[cur][(wn * (BN / 2) + fr) * GM_LD + fk];
 #pragma unroll
     for (int ks = 0; ks < GM_BK; ks += 2) {
-      const float a0 = A[ks], a1 = A[32 * GM_LD + ks];
-      const float b0 = B[ks], b1 = B[32 * GM_LD + ks];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      float av[MR], bv[NR];
+#pragma unroll
+      for (int a = 0; a < MR; ++a) av[a] = A[a * 32 * GM_LD + ks];
+#pragma unroll
+      for (int b = 0; b < NR; ++b) bv[b] = B[b * 32 * GM_LD + ks];
+#pragma unroll
+      for (int a = 0; a < MR; ++a)
+#pragma unroll
+        for (int b = 0; b < NR; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
     }
     if (kt + 1 < nk) sstore(cur ^ 1);
     __syncthreads();
   }
   // D layout of 32x32x2: col = lane & 31, row = 8*(e/4) + 4*(lane>>5) + (e&3)
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < MR; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int n = n0 + wn * 64 + b * 32 + (lane & 31);
+    for (int b = 0; b < NR; ++b) {
+      const int n = n0 + wn * (BN / 2) + b * 32 + (lane & 31);
       if (n >= N) continue;
-      const float bv = bias ? bias[n] : 0.f;
+      const float bvv = bias ? bias[n] : 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 64 + a * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+        const int m = m0 + wm * (BM / 2) + a * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
         if (m < M) {
-          float v = acc[a][b][e] + bv;
+          float v = acc[a][b][e] + bvv;
           if (act == 1) v = fmaxf(v, 0.f);
           else if (act == 2) v = gelu_new_f(v);
           if (res) v += res[(long long)m * N + n];
@@ -125,8 +129,14 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
 
 int vs_gemm_nt_f32_mfma(const float* x, const float* w, const float* b, const float* res, float* y,
                         int M, int N, int K, int act, hipStream_t st) {
-  hipLaunchKernelGGL(gemm_nt_f32_kernel, dim3((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM),
-                     dim3(256), 0, st, x, w, b, res, y, M, N, K, act);
+  // fewer than one 128x128 tile per CU: 64x64 tiles (4x the blocks) keep the chip busy
+  const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
+  if (t128 >= 256)
+    hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 128>), dim3((N + 127) / 128, (M + 127) / 128), dim3(256),
+                       0, st, x, w, b, res, y, M, N, K, act);
+  else
+    hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 64>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0,
+                       st, x, w, b, res, y, M, N, K, act);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }

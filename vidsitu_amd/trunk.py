@@ -127,6 +127,8 @@ class _WgradLanes:
     #      right after the same unit's dgrad (wgrad || dgrad)               16.71 ms
     #   3  as 4 but joined at the end of the stage                          19.13 ms
     #   5  fast-pathway launches too, joined by the origin stream at the stage join  18.83 ms
+    #   6  as 4, but a unit's lane is joined just before the NEXT unit's wgrad is issued (one
+    #      wgrad in flight behind the next unit's BN backward kernels)
     #   1 / 2  lanes forked from AND joined back into the trunk's side stream: hipGraph capture
     #      of such a nested fork segfaults in hipStreamEndCapture on ROCm 7.2 -- do not use
     mode = int(os.environ.get("VS_WGRAD_LANES", "4"))
@@ -145,7 +147,7 @@ class _WgradLanes:
         dev = main.device.index
         side = VideoTrunk._side_streams.get(dev)
         key = (dev, side is not None and side.cuda_stream == main.cuda_stream)
-        if key[1] and cls.mode in (3, 4):  # no fork from the trunk's side stream
+        if key[1] and cls.mode in (3, 4, 6):  # no fork from the trunk's side stream
             return fn()
         lane = cls.lanes.get(key)
         if lane is None:
@@ -153,8 +155,11 @@ class _WgradLanes:
         # mode 5: work issued from the side stream is joined by the ORIGIN stream at the stage's
         # join (a lane forked from and joined back into a forked stream crashes hipGraph capture)
         joiner = cls.origin if (key[1] and cls.mode == 5 and cls.origin is not None) else main
-        if lane[3] and lane[0].cuda_stream != joiner.cuda_stream:  # never leave a lane un-joined
+        if lane[3] and (lane[0].cuda_stream != joiner.cuda_stream or cls.mode == 6):
+            # never leave a lane un-joined; mode 6: the previous unit's wgrad is joined HERE, i.e.
+            # it had this unit's BN backward kernels to hide behind as well as its own dgrad
             lane[0].wait_stream(lane[1])
+            lane[2].clear()
         lane[0] = joiner
         lane[1].wait_stream(main)
         with torch.cuda.stream(lane[1]):
