@@ -116,28 +116,19 @@ def _set_grad(param, g):
 
 
 class _WgradLanes:
-    """Weight gradients have no consumer before the optimizer, so every conv_wgrad launch goes to
-    a side stream of the stream it was issued from and runs beside the dgrad / BN kernels that
-    continue the backward chain (both are far from filling the chip at batch 8).  Operands are
-    kept alive until `join_all` (end of a stage), where each issuing stream waits for its lane."""
+    """Weight gradients have no consumer before the optimizer, so a conv_wgrad launch issued from the
+    caller's (slow-pathway) stream goes to a side lane and runs beside the same unit's dgrad; the
+    lane is joined right after that dgrad (`join_all`), operands kept alive until then.
+    Measured alternatives (batch-8 train step, hipGraph; 17.24 ms without lanes, 16.71 ms with):
+    joining only at the end of a stage 19.1 ms, joining one unit later 17.7 ms (wgrad then competes
+    with the BN passes for bandwidth), lanes for the fast pathway as well 18.8 ms; a lane forked from
+    AND joined back into the trunk's (already forked) side stream makes hipStreamEndCapture
+    segfault on ROCm 7.2, so launches issued from that stream stay inline.  VS_WGRAD_LANES=0: off."""
 
-    # VS_WGRAD_LANES (measured, batch 8 train step, hipGraph):
-    #   0  off                                                              17.24 ms
-    #   4  DEFAULT: launches issued from the caller's (slow-pathway) stream only, lane joined
-    #      right after the same unit's dgrad (wgrad || dgrad)               16.71 ms
-    #   3  as 4 but joined at the end of the stage                          19.13 ms
-    #   5  fast-pathway launches too, joined by the origin stream at the stage join  18.83 ms
-    #   6  as 4, but a unit's lane is joined just before the NEXT unit's wgrad is issued (one
-    #      wgrad in flight behind the next unit's BN backward kernels)
-    #   1 / 2  lanes forked from AND joined back into the trunk's side stream: hipGraph capture
-    #      of such a nested fork segfaults in hipStreamEndCapture on ROCm 7.2 -- do not use
-    mode = int(os.environ.get("VS_WGRAD_LANES", "4"))
-    enabled = mode > 0
-    # (device index, issued from the trunk's side stream?) -> [issuing stream, lane stream,
-    # keepalive list, pending].  Lane streams are created once (never inside a hipGraph capture,
-    # where creating a stream is an unsafe call) and reused whatever stream is current.
+    enabled = os.environ.get("VS_WGRAD_LANES", "1") != "0"
+    # device index -> [issuing stream, lane stream, keepalive list, pending].  Lane streams are
+    # created once (never inside a hipGraph capture, where creating a stream is an unsafe call).
     lanes = {}
-    origin = None  # the stream the current fork started from (set by _Fork.fork)
 
     @classmethod
     def run(cls, fn, *keep):
@@ -146,21 +137,15 @@ class _WgradLanes:
         main = torch.cuda.current_stream()
         dev = main.device.index
         side = VideoTrunk._side_streams.get(dev)
-        key = (dev, side is not None and side.cuda_stream == main.cuda_stream)
-        if key[1] and cls.mode in (3, 4, 6):  # no fork from the trunk's side stream
-            return fn()
-        lane = cls.lanes.get(key)
+        if side is not None and side.cuda_stream == main.cuda_stream:
+            return fn()  # issued from the fast pathway's stream: no nested fork
+        lane = cls.lanes.get(dev)
         if lane is None:
-            lane = cls.lanes[key] = [main, torch.cuda.Stream(device=main.device), [], False]
-        # mode 5: work issued from the side stream is joined by the ORIGIN stream at the stage's
-        # join (a lane forked from and joined back into a forked stream crashes hipGraph capture)
-        joiner = cls.origin if (key[1] and cls.mode == 5 and cls.origin is not None) else main
-        if lane[3] and (lane[0].cuda_stream != joiner.cuda_stream or cls.mode == 6):
-            # never leave a lane un-joined; mode 6: the previous unit's wgrad is joined HERE, i.e.
-            # it had this unit's BN backward kernels to hide behind as well as its own dgrad
+            lane = cls.lanes[dev] = [main, torch.cuda.Stream(device=main.device), [], False]
+        if lane[3] and lane[0].cuda_stream != main.cuda_stream:  # never leave a lane un-joined
             lane[0].wait_stream(lane[1])
             lane[2].clear()
-        lane[0] = joiner
+        lane[0] = main
         lane[1].wait_stream(main)
         with torch.cuda.stream(lane[1]):
             fn()
@@ -168,9 +153,9 @@ class _WgradLanes:
         lane[3] = True
 
     @classmethod
-    def join_all(cls, only_main=False):
-        for key, lane in cls.lanes.items():
-            if lane[3] and not (only_main and key[1]):
+    def join_all(cls):
+        for lane in cls.lanes.values():
+            if lane[3]:
                 lane[0].wait_stream(lane[1])
                 lane[2].clear()
                 lane[3] = False
@@ -243,10 +228,7 @@ class _Unit:
         if need_dx:
             dx = ops.conv_dgrad(dy, conv.wt(), tuple(x.shape), conv.k, conv.s, conv.p,
                                 residual=dx_residual)
-        if _WgradLanes.mode in (2, 4):
-            _WgradLanes.join_all()
-        elif _WgradLanes.mode == 5:
-            _WgradLanes.join_all(only_main=True)
+        _WgradLanes.join_all()  # wgrad || dgrad of this unit, no further
         return dx, dres
 
 
@@ -405,7 +387,6 @@ class _Fork:
         if self.side is None:
             return
         self.main = torch.cuda.current_stream()
-        _WgradLanes.origin = self.main
         self.side.wait_stream(self.main)
         self.active = True
 
@@ -425,28 +406,15 @@ class _Fork:
         if isinstance(keep, list):
             keep.clear()
 
-    # one-directional waits between fork and join (VS_FORK_SYNC=event): the slow pathway waits for
-    # the fast one only where a lateral connection needs its output (forward), the fast pathway
-    # waits for the slow one only where it needs the lateral connection's gradient (backward)
-    def main_wait_side(self):
-        if self.side is not None and self.active:
-            self.main.wait_stream(self.side)
-
-    def side_wait_main(self):
-        if self.side is not None and self.active:
-            self.side.wait_stream(self.main)
-
 
 class VideoTrunk(nn.Module):
     """`SlowFast_FeatModel` / `ResNet_FeatModel` (mdl_sf_base.py:20-62)."""
 
     # run the two pathways of a multi-pathway trunk on two streams (VS_DUAL_STREAM=0: one stream)
     dual_stream = os.environ.get("VS_DUAL_STREAM", "1") != "0"
-    # "stage" (default): fork + full join around every stage.  "event": fork once per forward /
-    # backward segment with one-directional waits at the lateral connections, so the fast pathway
-    # may run ahead -- measured SLOWER (train 16.85 vs 16.47 ms, forward 3.17 vs 2.96 ms at batch 8:
-    # a pathway that runs far ahead only adds contention for the kernels on the critical path)
-    fork_sync = os.environ.get("VS_FORK_SYNC", "stage")
+    # Fork + full join around every stage.  A one-directional variant (fork once per pass, the slow
+    # pathway waits for the fast one only at the lateral connections, so the fast pathway may run
+    # ahead) was measured SLOWER: train 16.85 vs 16.47 ms, forward 3.17 vs 2.96 ms at batch 8.
     _side_streams = {}
 
     def _fork_ctx(self, dev):
@@ -634,13 +602,7 @@ class VideoTrunk(nn.Module):
                     buf = out = ops.new_act(n, c, t, hp, wp, dev)
                 stem.fwd(xin[p], out, train, saved)
             cur.append(buf)
-        relaxed = self.fork_sync == "event"
-        keep_fwd = []  # eval mode frees activations as it goes: hold what the other stream reads
-        if relaxed:
-            par.main_wait_side()
-            keep_fwd.extend(cur)
-        else:
-            par.join()
+        par.join()
         if self.multi:
             self._fuse_fwd(self.s1_fuse, cur, train, saved)
         if self.debug_taps is not None:
@@ -649,8 +611,7 @@ class VideoTrunk(nn.Module):
             stage = getattr(self, f"s{k}")
             fuse = getattr(self, f"s{k}_fuse", None) if self.multi else None
             nxt = []
-            if not relaxed:
-                par.fork()
+            par.fork()
             for p in range(P):
               with par.on(p):
                 x = cur[p]
@@ -670,13 +631,7 @@ class VideoTrunk(nn.Module):
                     else:
                         x = blk.fwd(x, None, train, saved)
                 nxt.append(x)
-            if relaxed:
-                keep_fwd.extend(cur)
-                keep_fwd.extend(nxt)
-                if fuse is not None:
-                    par.main_wait_side()  # the lateral conv reads the fast pathway's stage output
-            else:
-                par.join(keep=cur)
+            par.join(keep=cur)
             cur = nxt
             if fuse is not None:
                 self._fuse_fwd(fuse, cur, train, saved)
@@ -691,8 +646,6 @@ class VideoTrunk(nn.Module):
                         cur[p] = y
             if self.debug_taps is not None:
                 self.debug_taps[f"s{k}"] = [c.float().cpu() for c in cur]
-        if relaxed:
-            par.join(keep=keep_fwd)
         return cur, saved
 
     def _fuse_fwd(self, fuse, cur, train, saved):
@@ -732,48 +685,23 @@ class VideoTrunk(nn.Module):
         return [getattr(self, n) for n in names if hasattr(self, n)]
 
     def _backward_segment(self, st, seg):
-        relaxed = self.fork_sync == "event"
-        if relaxed:  # one fork / join per segment; the fast pathway waits at the lateral connections
-            st["par"] = par = self._fork_ctx(st["d"][0].device)
-            st["keep"] = list(st["d"])
-            par.fork()
         for k in {"s5": (5,), "s4": (4,), "rest": (3, 2)}[seg]:
             self._backward_stage(st, k)
         if seg == "rest":
             saved, d = st["saved"], st["d"]
-            if not relaxed:
-                if self.multi:
-                    d = self._fuse_bwd(saved, d)
-                par = self._fork_ctx(d[0].device)
-                par.fork()
-            elif self.multi:
-                d = self._fuse_bwd_on_side(st, d)
+            if self.multi:
+                d = self._fuse_bwd(saved, d)
+            par = self._fork_ctx(d[0].device)
+            par.fork()
             for p in reversed(range(self.num_pathways)):
                 with par.on(p):
                     getattr(self.s1, f"pathway{p}_stem").bwd(saved, d[p])
-            if not relaxed:
-                par.join(keep=d)
+            par.join(keep=d)
             assert not saved, "trunk backward did not consume every saved record"
-        if relaxed:
-            st["keep"].extend(st["d"])
-            par.join(keep=st["keep"])
-
-    def _fuse_bwd_on_side(self, st, d):
-        """Lateral connection backward on the fast pathway's stream: it needs the slow pathway's
-        gradient of the concat buffer (wait for it), the slow pathway needs nothing from it."""
-        par, keep = st["par"], st["keep"]
-        keep.extend(d)
-        keep.append(st["saved"][-1])  # the unit's saved tensors live on the other stream's pool
-        par.side_wait_main()
-        with par.on(1):
-            d = self._fuse_bwd(st["saved"], d)
-        keep.extend(d)
-        return d
 
     def _backward_stage(self, st, k):
         saved, d = st["saved"], st["d"]
         P = self.num_pathways
-        relaxed = self.fork_sync == "event"
         stage = getattr(self, f"s{k}")
         fuse = getattr(self, f"s{k}_fuse", None) if self.multi else None
         if k == 2:
@@ -782,21 +710,17 @@ class VideoTrunk(nn.Module):
                     rec = saved.pop()
                     d[p] = ops.maxpool_t_bwd(d[p], rec["tpool_idx"], rec["tpool_in"], rec["kt"])
         if fuse is not None:
-            d = self._fuse_bwd_on_side(st, d) if relaxed else self._fuse_bwd(saved, d)
-        if relaxed:
-            par = st["par"]
-        else:
-            par = self._fork_ctx(d[0].device)
-            d_in = list(d)  # keep the incoming gradients alive until both streams are done with them
-            par.fork()
+            d = self._fuse_bwd(saved, d)
+        par = self._fork_ctx(d[0].device)
+        d_in = list(d)  # keep the incoming gradients alive until both streams are done with them
+        par.fork()
         for p in reversed(range(P)):
             with par.on(p):
                 g = d[p]
                 for blk in reversed(stage.blocks(p)):
                     g = blk.bwd(saved, g)
                 d[p] = g
-        if not relaxed:
-            par.join(keep=d_in)
+        par.join(keep=d_in)
         st["d"] = d
 
     def _fuse_bwd(self, saved, d):
