@@ -122,6 +122,10 @@ int vs_weight_transpose(const void* w, void* wt, int Cout, int taps, int Cin, vo
  * element offsets; table[i] = {offset, Cout, taps, Cin, first flat index} (int64 x 5). */
 int vs_weight_transpose_batched(const void* src, void* dst, const int64_t* table, int n,
                                 int64_t total, void* stream);
+/* fp32 nn.Linear weights [N][K] -> [K][N] for all linears of a model in one launch (table rows
+ * {element offset (same in src and dst), N, 1, K, first flat index}). */
+int vs_transpose_f32_batched(const float* src, float* dst, const int64_t* table, int n, int64_t total,
+                             void* stream);
 
 /* Weight gradient: dw[Cout][taps][Cin] fp32 = sum_p dy[p][co] * x[p@tap][ci].
  * workspace: vs_conv_wgrad_workspace_bytes(desc) bytes of fp32 split-K slabs. */

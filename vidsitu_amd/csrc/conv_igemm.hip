@@ -1387,8 +1387,9 @@ extern "C" int vs_weight_transpose(const void* w, void* wt, int Cout, int taps, 
 
 // All dgrad weight images of a model in ONE launch.  table[i] = {element offset (same in
 // src and dst arenas), Cout, taps, Cin, first flat index}; entries sorted by first index.
-__global__ void weight_transpose_batched_kernel(const uint16_t* src, uint16_t* dst,
-                                                const long long* table, int n, long long total) {
+template <typename T>
+__global__ void weight_transpose_batched_kernel(const T* src, T* dst, const long long* table, int n,
+                                                long long total) {
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
     int lo = 0, hi = n - 1;
@@ -1412,9 +1413,22 @@ extern "C" int vs_weight_transpose_batched(const void* src, void* dst, const int
   VS_CHECK_ARG(src && dst && table && n > 0 && total > 0, "bad args");
   long long grid = (total + 255) / 256;
   if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(weight_transpose_batched_kernel, dim3((unsigned)grid), dim3(256), 0,
+  hipLaunchKernelGGL(weight_transpose_batched_kernel<uint16_t>, dim3((unsigned)grid), dim3(256), 0,
                      (hipStream_t)stream, (const uint16_t*)src, (uint16_t*)dst,
                      (const long long*)table, n, (long long)total);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// The same for fp32 nn.Linear weights (taps = 1: [N][K] -> [K][N]), the operand of the
+// weight-streaming dx = dy @ W kernel: all linears of a model in one launch.
+extern "C" int vs_transpose_f32_batched(const float* src, float* dst, const int64_t* table, int n,
+                                        int64_t total, void* stream) {
+  VS_CHECK_ARG(src && dst && table && n > 0 && total > 0, "bad args");
+  long long grid = (total + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(weight_transpose_batched_kernel<float>, dim3((unsigned)grid), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, (const long long*)table, n, (long long)total);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }

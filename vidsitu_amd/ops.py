@@ -253,6 +253,11 @@ def weight_transpose_batched(src_arena, dst_arena, table, total):
               table.shape[0], int(total), _stream())
 
 
+def transpose_f32_batched(src, dst, table, total):
+    _lib.call("vs_transpose_f32_batched", _ptr(src), _ptr(dst), _ptr(table), table.shape[0], int(total),
+              _stream())
+
+
 def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=None, ring=0,
                noclass=False):
     """dx[xs] = conv_transpose(dy, w) (+ residual).  wt from weight_transpose."""
@@ -457,15 +462,17 @@ def linear_fwd(x, w, b=None, relu=False):
     return y
 
 
-def linear_bwd(dy, x, w, need_dx=True, has_bias=True, dw_out=None, db_out=None):
-    """dw_out / db_out: write the parameter gradients in place (gradient-arena views)."""
+def linear_bwd(dy, x, w, need_dx=True, has_bias=True, dw_out=None, db_out=None, wt=None):
+    """dw_out / db_out: write the parameter gradients in place (gradient-arena views).
+    wt: an up-to-date [K][N] image of w (the parameter arena keeps one); else transposed here."""
     dy, x, w = _f32c(dy), _f32c(x), _f32c(w)
     m, n = dy.shape
     k = x.shape[1]
     dx = None
     if need_dx:
-        wt = torch.empty((k, n), dtype=torch.float32, device=x.device)
-        _lib.call("vs_transpose_f32", _ptr(w), _ptr(wt), n, k, _stream())
+        if wt is None:
+            wt = torch.empty((k, n), dtype=torch.float32, device=x.device)
+            _lib.call("vs_transpose_f32", _ptr(w), _ptr(wt), n, k, _stream())
         dx = torch.empty((m, k), dtype=torch.float32, device=x.device)
         _lib.call("vs_linear_bwd_data", _ptr(dy), _ptr(wt), _ptr(dx), m, n, k, _stream())
     dw = dw_out if dw_out is not None else torch.empty((n, k), dtype=torch.float32, device=x.device)

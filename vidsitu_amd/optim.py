@@ -52,8 +52,10 @@ class ParamArena:
         self.numel = total
         self._tr_table, self._loose_convs, self.data_bf16 = None, [], None
         self._tr_stream, self._tr_pending = None, False
+        self._lin_table, self.wt_f32 = None, None
         if adopt_conv:
             self._adopt_conv_weights(dev)
+            self._adopt_linear_weights(dev)
 
     def _adopt_conv_weights(self, dev):
         """bf16 kernel-layout weights and their transposed dgrad images become views into two
@@ -83,6 +85,34 @@ class ParamArena:
         self._tr_total = first
         self._tr_table = torch.tensor(rows, dtype=torch.int64, device=dev) if rows else None
         self.refresh()
+
+    def _adopt_linear_weights(self, dev):
+        """fp32 nn.Linear weights (heads, TxEncoder) get a transposed image [K][N] in a second fp32
+        arena with the same offsets: the operand of dx = dy @ W in LinearFn.backward, refreshed for
+        ALL linears by one launch instead of one small transpose per linear per step."""
+        from torch import nn
+
+        off_of = {id(p): off for p, off in zip(self.params, self.offsets)}
+        rows, first = [], 0
+        mods = []
+        for m in self.model.modules():
+            if isinstance(m, nn.Linear) and id(m.weight) in off_of and m.weight.dtype == torch.float32:
+                n, k = m.weight.shape
+                rows.append([off_of[id(m.weight)], n, 1, k, first])
+                first += n * k
+                mods.append(m)
+        if not rows:
+            return
+        self.wt_f32 = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self._lin_total = first
+        self._lin_table = torch.tensor(rows, dtype=torch.int64, device=dev)
+        self._lin_weights = [m.weight for m in mods]
+        for m, r in zip(mods, rows):
+            n, k = m.weight.shape
+            m.weight._vs_wt = self.wt_f32[r[0]: r[0] + n * k].view(k, n)
+        ops.transpose_f32_batched(self.data, self.wt_f32, self._lin_table, self._lin_total)
+        for w in self._lin_weights:
+            w._vs_wt_version = w._version
 
     def zero_grad(self, fill=True):
         """fill=False: skip the 300 MB memset.  Valid when every parameter's gradient is WRITTEN
@@ -162,11 +192,15 @@ class ParamArena:
     def _run_transposes(self):
         if self._tr_table is not None:
             ops.weight_transpose_batched(self.data_bf16, self.wt_bf16, self._tr_table, self._tr_total)
+        if self._lin_table is not None:
+            ops.transpose_f32_batched(self.data, self.wt_f32, self._lin_table, self._lin_total)
+            for w in self._lin_weights:
+                w._vs_wt_version = w._version
 
     # The transposed (dgrad) weight images are only read by the backward pass: refresh them on a
     # side stream at the START of a step, beside the forward pass; the first dgrad joins.
     def transposes_async(self):
-        if self._tr_table is None:
+        if self._tr_table is None and self._lin_table is None:
             return
         from .trunk import Conv3dP
 
@@ -193,6 +227,34 @@ class ArenaAdam:
         self.m = torch.zeros_like(arena.data)
         self.v = torch.zeros_like(arena.data)
         self.t = torch.zeros(1, dtype=torch.int32, device=arena.data.device)  # device-side: graph safe
+
+    def _adopt_linear_weights(self, dev):
+        """fp32 nn.Linear weights (heads, TxEncoder) get a transposed image [K][N] in a second fp32
+        arena with the same offsets: the operand of dx = dy @ W in LinearFn.backward, refreshed for
+        ALL linears by one launch instead of one small transpose per linear per step."""
+        from torch import nn
+
+        off_of = {id(p): off for p, off in zip(self.params, self.offsets)}
+        rows, first = [], 0
+        mods = []
+        for m in self.model.modules():
+            if isinstance(m, nn.Linear) and id(m.weight) in off_of and m.weight.dtype == torch.float32:
+                n, k = m.weight.shape
+                rows.append([off_of[id(m.weight)], n, 1, k, first])
+                first += n * k
+                mods.append(m)
+        if not rows:
+            return
+        self.wt_f32 = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self._lin_total = first
+        self._lin_table = torch.tensor(rows, dtype=torch.int64, device=dev)
+        self._lin_weights = [m.weight for m in mods]
+        for m, r in zip(mods, rows):
+            n, k = m.weight.shape
+            m.weight._vs_wt = self.wt_f32[r[0]: r[0] + n * k].view(k, n)
+        ops.transpose_f32_batched(self.data, self.wt_f32, self._lin_table, self._lin_total)
+        for w in self._lin_weights:
+            w._vs_wt_version = w._version
 
     def zero_grad(self, fill=True):
         self.arena.zero_grad(fill)

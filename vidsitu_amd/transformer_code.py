@@ -29,6 +29,8 @@ class LinearFn(torch.autograd.Function):
         # parameters that live in a ParamArena take their gradient in place (overwrite
         # semantics, like the conv / BN parameters) instead of through autograd's accumulate
         ctx.w_param = w if getattr(w, "_vs_direct_grad", False) else None
+        # the arena's [K][N] image of w, unless w was modified behind the arena's back since
+        ctx.w_wt = w._vs_wt if getattr(w, "_vs_wt_version", None) == w._version else None
         ctx.b_param = b if (b is not None and getattr(b, "_vs_direct_grad", False)) else None
         return y.reshape(*shp[:-1], w.shape[0])
 
@@ -40,10 +42,16 @@ class LinearFn(torch.autograd.Function):
             dy2 = dy2 * (y > 0).to(dy2.dtype)
         direct = ctx.w_param is not None and ctx.w_param.grad is not None and \
             (not ctx.has_bias or (ctx.b_param is not None and ctx.b_param.grad is not None))
+        wt = ctx.w_wt  # the arena's transposed image (refreshed once per step)
+        if wt is not None:
+            from .trunk import Conv3dP
+
+            if Conv3dP._wt_guard is not None:  # an asynchronous refresh may still be in flight
+                Conv3dP._wt_guard()
         dx, dw, db = ops.linear_bwd(
             dy2.contiguous(), x2, w, need_dx=ctx.needs_input_grad[0], has_bias=ctx.has_bias,
             dw_out=ctx.w_param.grad if direct else None,
-            db_out=ctx.b_param.grad if (direct and ctx.has_bias) else None)
+            db_out=ctx.b_param.grad if (direct and ctx.has_bias) else None, wt=wt)
         dx = dx.reshape(ctx.shp) if dx is not None else None
         if direct:
             return dx, None, None, None
