@@ -516,3 +516,35 @@ def test_bench_style_training_trajectory_in_hipgraph_matches_eager(dev):
             f"max |diff| {float((arena.data - want).abs().max()):.3e}"
     finally:
         T.VideoTrunk.dual_stream, T._WgradLanes.enabled = saved
+
+
+def test_overfit_one_batch_end_to_end(dev):
+    """The reference's `overfit_batch` mode (`trn_utils.py:915-939`): the whole plugin surface --
+    SlowFast trunk (both pathways) + TxEncoder + loss + manual backward + fused Adam -- drives the
+    loss of one fixed batch towards zero and its top-1 accuracy to 1."""
+    from vidsitu_amd import synth_data
+    from vidsitu_amd.extended_config import get_cfg
+    from vidsitu_amd.mdl_selector import get_mdl_loss_eval
+    from vidsitu_amd.optim import ArenaAdam, ParamArena
+
+    cfg = get_cfg({"mdl.mdl_name": "sf_base_txenc", "synth.num_verbs": 31, "tx_dec.encoder_layers": 2})
+    comm = synth_data.make_comm(cfg)
+    torch.manual_seed(0)
+    sel = get_mdl_loss_eval(cfg)
+    mdl = sel["mdl"](cfg=cfg, comm=comm).to(dev).train()  # SlowFast-R50
+    loss_fn = sel["loss"](cfg, comm)
+    arena = ParamArena(mdl)
+    opt = ArenaAdam(arena, lr=3e-4)
+    batch = synth_data.synth_batch(cfg, comm, bs=2, n_ev=4, crop=112, device=dev, dtype=torch.bfloat16)
+    losses = []
+    for _ in range(40):
+        opt.zero_grad()
+        loss = loss_fn(mdl(batch), batch)["loss"]
+        loss.backward()
+        opt.step()
+        losses.append(loss.detach())
+    losses = [float(x) for x in losses]
+    assert losses[-1] < 0.05 * losses[0], (losses[0], losses[-1])
+    mdl.eval()
+    _, mets = sel["evl"](cfg, comm, dev)(mdl, loss_fn, [batch])
+    assert mets["Per_Ev_Top_1"] >= 0.9, mets
