@@ -257,7 +257,8 @@ int vs_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
  * (vidsitu_code/seq_gen.py:310-385).  Weights are kept K-contiguous ([out][in], nn.Linear
  * layout; the host mirror transposes HF Conv1D tensors on load). */
 /* y[M,N] = act(x[M,K] . w[N,K]^T + b[N]) + res[M,N];  b, res may be NULL; act 0 none, 1 relu,
- * 2 gelu_new.  M <= 64: one wave streams one weight row (HBM-bound); else fp32 MFMA tiles. */
+ * 2 gelu_new.  M <= 16: one wave streams one weight row; 17..64 rows (K % 128 == 0): skinny fp32-MFMA
+ * tiles straight from global memory; else 128x128 fp32 MFMA tiles through LDS. */
 int vs_gemm_nt_f32(const float* x, const float* w, const float* b, const float* res, float* y, int M,
                    int N, int K, int act, void* stream);
 /* out[r,l,:] = wte[tokens[r,l]] + wpe[pos0 + l]  (GPT2Model embeddings, default position ids). */
@@ -268,19 +269,25 @@ int vs_gpt2_embed(const int64_t* tokens, const float* wte, const float* wpe, flo
 int vs_attn_causal_fwd(const float* qkv, const uint8_t* key_mask, float* out, int R, int L, int H,
                        int dh, void* stream);
 /* One incremental step: append k,v of qkv[rows,3D] at position t of the caches
- * [rows][H][Lmax][dh], attend the new query over 0..t; key_mask[rows,Lmax] or NULL. */
-int vs_attn_decode(const float* qkv, float* kcache, float* vcache, const uint8_t* key_mask, float* out,
-                   int rows, int H, int dh, int Lmax, int t, void* stream);
+ * [rows][H][Lmax][dh], attend the new query over 0..t; key_mask[rows,Lmax] or NULL.
+ * ancestry[rows][Lmax] (or NULL): position j < t of row r is read from cache row ancestry[r][j] --
+ * a beam reorder then permutes this table (vs_beam_step) instead of gathering the cache. */
+int vs_attn_decode(const float* qkv, float* kcache, float* vcache, const uint8_t* key_mask,
+                   const int32_t* ancestry, float* out, int rows, int H, int dh, int Lmax, int t,
+                   void* stream);
 /* dst[r] = src[index[r]] for the first len positions of every head (beam reorder of a cache). */
 int vs_kv_gather(const float* src, float* dst, const int64_t* index, int rows_out, int H, int dh,
                  int Lmax, int len, void* stream);
 /* Beam-search step scoring: lp = log_softmax(logits/T), NaN -> -inf, lp[pad] = -inf,
  * lp[unk] -= unk_penalty, flags&1: only eos, flags&2: eos banned, forced[r] >= 0 (and != pad):
  * only that token; + cum[r]; the k (<= 32) best (value, token) per row, descending, ties ->
- * lowest token id.  cum, forced may be NULL. */
+ * lowest token id.  cum, forced may be NULL.  With a workspace (vs_beam_topk_workspace_bytes) rows
+ * of more than 2048 tokens are cut into slices (slices x rows blocks); NULL = one block per row. */
+size_t vs_beam_topk_workspace_bytes(int rows, int V, int k);
 int vs_beam_topk(const float* logits, const float* cum, const int64_t* forced, float* out_val,
                  int64_t* out_idx, int rows, int V, int k, int pad, int eos, int unk,
-                 float unk_penalty, float temperature, int flags, void* stream);
+                 float unk_penalty, float temperature, int flags, void* workspace, size_t ws_bytes,
+                 void* stream);
 /* Mean token cross entropy with ignore_index (Simple_TxDec.forward, mdl_sf_base.py:660-664):
  * nll_rows[rows] scratch, loss_out[2] = {mean nll over counted rows, count}; ld = row pitch. */
 int vs_xent_ignore(const float* logits, const int64_t* labels, float* nll_rows, float* loss_out,
@@ -304,6 +311,22 @@ int vs_gpt2_embed_bwd(const int64_t* tokens, const float* dh, float* dwte, float
 int vs_xent_ignore_grad(const float* logits, const int64_t* labels, const float* loss_out,
                         float* dlogits, int rows, int V, int64_t ld, int ignore_index, float grad_scale,
                         void* stream);
+
+/* Device-side beam-search bookkeeping of one step (SeqGenCustom._generate between two decoder
+ * calls, seq_gen.py:368-520, and finalize_hypos :579-697), one block per sentence, no host sync:
+ * merges the per-row lists of vs_beam_topk into the 2*beam candidates (ties -> lowest beam*V+token),
+ * finalizes eos hypotheses into fin_* ([bsz][beam][max_len+1] tokens / positional scores, score,
+ * length), marks finished sentences (remaining[0] counts the others), picks the next beam's live
+ * candidates, writes the gathered token / score rows (ping-pong buffers, row pitch max_len+2 /
+ * max_len+1) and the parent-row index `reorder` for vs_kv_gather.  Finished sentences stay in the
+ * batch as idle rows.  anc_in / anc_out ([bsz*beam][anc_ld] ping-pong, or both NULL): the ancestry
+ * table of vs_attn_decode, gathered like the token rows, entry step+1 of a new row = the row itself. */
+int vs_beam_step(const float* row_val, const int64_t* row_idx, const int64_t* tok_in, int64_t* tok_out,
+                 const float* sc_in, float* sc_out, uint8_t* ignore, uint8_t* finished, int* nfin,
+                 int* remaining, int64_t* fin_tok, float* fin_score, float* fin_pos, int* fin_len,
+                 int64_t* reorder, const int32_t* anc_in, int32_t* anc_out, int anc_ld, int bsz, int beam,
+                 int k, int V, int step, int max_len, int eos, int normalize, float len_penalty,
+                 void* stream);
 
 #ifdef __cplusplus
 }

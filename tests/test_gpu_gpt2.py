@@ -33,7 +33,13 @@ def _model_from_golden(path, dev):
 @pytest.mark.parametrize("m,n,k,act,use_res", [(5, 7, 12, 0, False), (40, 1024, 1024, 2, True),
                                                (64, 96, 50, 1, False), (65, 130, 36, 2, True),
                                                (300, 3072, 1024, 0, False), (600, 1024, 4096, 0, True),
-                                               (257, 97, 64, 2, False)])
+                                               (257, 97, 64, 2, False),
+                                               # 17..64 rows, K % 128 == 0: the skinny MFMA kernels (three tile shapes)
+                                               (17, 1024, 1024, 0, False), (33, 100, 256, 1, True),
+                                               (50, 3072, 1024, 2, True), (50, 1024, 4096, 0, True),
+                                               (64, 50259, 1024, 0, False), (48, 1030, 128, 2, False),
+                                               (20, 24, 384, 0, True), (40, 1000, 512, 1, False),
+                                               (30, 4096, 1024, 0, False), (50, 1024, 1024, 0, True)])
 def test_gemm_nt_f32(m, n, k, act, use_res, dev):
     from vidsitu_amd import ops
 
@@ -49,9 +55,11 @@ def test_gemm_nt_f32(m, n, k, act, use_res, dev):
         ref = torch.from_numpy(gpt2_ref.gelu_new(ref.numpy()))
     if use_res:
         ref = ref + res.double()
-    y = ops.gemm_nt(x.to(dev), w.to(dev), b.to(dev), res.to(dev) if use_res else None, act)
+    args = (x.to(dev), w.to(dev), b.to(dev), res.to(dev) if use_res else None, act)
+    y = ops.gemm_nt(*args)
     err = float((y.cpu().double() - ref).abs().max()) / float(ref.abs().max())
     assert err < 2e-5, f"gemm_nt {m}x{n}x{k} act {act}: rel err {err:.2e}"
+    assert torch.equal(ops.gemm_nt(*args), y)
 
 
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
@@ -70,17 +78,42 @@ def test_gpt2_logits_match_transformers_golden(path, dev):
     assert err < 1e-3
 
 
-def test_cached_decode_equals_whole_sequence_pass(dev):
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
+def test_cached_decode_equals_whole_sequence_pass(path, dev):
     from vidsitu_amd.hf_gpt2_fseq import KVCacheState
 
-    z, w, n_head, m = _model_from_golden(GOLD[0], dev)
+    z, w, n_head, m = _model_from_golden(path, dev)
     toks = torch.from_numpy(z["tokens"]).to(dev)  # no padding in generation
-    toks = toks.clamp(min=1)
+    toks = toks.clamp(min=1)[:, :12].contiguous()
     full = m.forward_logits(toks, None)
     st = KVCacheState()
     for t in range(toks.shape[1]):
         step = m.forward_step(toks[:, t].contiguous(), st, max_len=toks.shape[1])
         assert float((step - full[:, t]).abs().max()) < 2e-4 * float(full.abs().max())
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
+def test_ancestry_table_equals_cache_gather(path, dev):
+    """A beam reorder through the ancestry table (vs_attn_decode reads position j of row r from cache
+    row anc[r][j]) gives the bits of the physical gather (vs_kv_gather)."""
+    from vidsitu_amd.hf_gpt2_fseq import KVCacheState
+
+    z, w, n_head, m = _model_from_golden(path, dev)
+    rows, steps = 6, 7
+    g = torch.Generator().manual_seed(3)
+    toks = torch.randint(1, 60, (steps, rows), generator=g).to(dev)
+    perms = [torch.randint(0, rows, (rows,), generator=g).to(dev) for _ in range(steps)]
+    a, b = KVCacheState(), KVCacheState()
+    b.anc = torch.arange(rows, dtype=torch.int32, device=dev).view(-1, 1).repeat(1, steps).contiguous()
+    for t in range(steps):
+        if t > 0:  # new row r continues old row perm[r]
+            m.reorder_state(a, perms[t])
+            anc = b.anc[perms[t]].contiguous()
+            anc[:, t:] = torch.arange(rows, dtype=torch.int32, device=dev).view(-1, 1)
+            b.anc = anc
+        la = m.forward_step(toks[t].contiguous(), a, max_len=steps)
+        lb = m.forward_step(toks[t].contiguous(), b, max_len=steps)
+        assert torch.equal(la, lb), f"step {t}"
 
 
 def test_lm_loss_with_ignore_index(dev):
@@ -95,14 +128,16 @@ def test_lm_loss_with_ignore_index(dev):
     assert abs(got - want) < 1e-4 * max(1.0, abs(want)), (got, want)
 
 
-def test_beam_topk_kernel_rules(dev):
+@pytest.mark.parametrize("V", [1000, 5000, 50259])  # one block per row / 3 and 25 slices per row
+def test_beam_topk_kernel_rules(V, dev):
     from vidsitu_amd import ops
 
     rs = np.random.RandomState(0)
-    rows, V, k = 6, 1000, 10
-    pad, eos, unk = 999, 998, 5
+    rows, k = 6, 10
+    pad, eos, unk = V - 1, V - 2, 5
     x = rs.randn(rows, V).astype(np.float32) * 3
     x[0, 17] = x[0, 400]            # an exact tie: lowest token first
+    x[4, V - 3] = x[4, 2] = 30.0    # a tie across slices
     x[1, 3] = np.nan                # NaN -> -inf
     cum = rs.randn(rows).astype(np.float32)
     cum[5] = -np.inf                # a dead beam: all -inf, indices 0,1,2,...
@@ -170,10 +205,11 @@ class _LM(torch.nn.Module):
         return None
 
 
+@pytest.mark.parametrize("device_search", [True, False], ids=["device", "host"])
 @pytest.mark.parametrize("beam,min_len,max_len_b,use_prefix,kv", [(1, 0, 6, True, True), (3, 1, 7, True, True),
                                                                   (3, 1, 7, True, False), (4, 0, 5, False, True),
-                                                                  (5, 2, 9, True, True)])
-def test_beam_search_tokens_bit_exact_vs_oracle(beam, min_len, max_len_b, use_prefix, kv, dev):
+                                                                  (5, 2, 9, True, True), (2, 0, 20, True, True)])
+def test_beam_search_tokens_bit_exact_vs_oracle(beam, min_len, max_len_b, use_prefix, kv, device_search, dev):
     from vidsitu_amd.seq_gen import SeqGenCustom
 
     z, w, n_head, m = _model_from_golden(GOLD[0], dev)
@@ -196,7 +232,7 @@ def test_beam_search_tokens_bit_exact_vs_oracle(beam, min_len, max_len_b, use_pr
                              beam_size=beam, max_len_b=max_len_b, min_len=min_len,
                              prefix_tokens=prefix, max_decoder_positions=int(z["dims"][1]) - 1)
     gen = SeqGenCustom([_LM(m, pad)], _Tok(vocab, pad, eos, unk), beam_size=beam, max_len_b=max_len_b,
-                       min_len=min_len, use_kv_cache=kv)
+                       min_len=min_len, use_kv_cache=kv, device_search=device_search)
     sample = {"src_tokens": torch.zeros(bsz, 1, dtype=torch.long, device=dev),
               "src_lengths": torch.ones(bsz, dtype=torch.long, device=dev)}
     got = gen._generate(sample, prefix_tokens=None if prefix is None else torch.from_numpy(prefix).to(dev))
@@ -207,6 +243,71 @@ def test_beam_search_tokens_bit_exact_vs_oracle(beam, min_len, max_len_b, use_pr
             assert hg["tokens"].tolist() == hw["tokens"].tolist(), f"sentence {sent}"
             assert abs(float(hg["score"]) - hw["score"]) < 1e-4
             assert np.allclose(hg["positional_scores"].cpu().numpy(), hw["positional_scores"], atol=1e-4)
+
+
+def test_device_search_graph_replays_equal_the_oracle(dev):
+    """Uses 1 / 2 / 3+ of one generation shape run eagerly / capture one hipGraph per step / replay
+    them; every use gets different prefix tokens and must reproduce the oracle's tokens."""
+    from vidsitu_amd.seq_gen import SeqGenCustom
+
+    z, w, n_head, m = _model_from_golden(GOLD[0], dev)
+    vocab = int(z["dims"][0])
+    pad, eos, unk = vocab - 1, vocab - 2, vocab - 2
+    w = dict(w)
+    w["transformer.wte.weight"] = w["transformer.wte.weight"].copy()
+    w["transformer.wte.weight"][eos] *= 3.0
+    with torch.no_grad():
+        m.P("transformer.wte.weight")[eos] *= 3.0
+    bsz, beam = 4, 3
+    lm = _LM(m, pad)
+
+    def step_logits(tokens, sent_ids):
+        return gpt2_ref.forward(w, tokens, (tokens != pad).astype(np.int64), n_head)[:, -1, :]
+
+    sample = {"src_tokens": torch.zeros(bsz, 1, dtype=torch.long, device=dev),
+              "src_lengths": torch.ones(bsz, dtype=torch.long, device=dev)}
+    for use in range(4):
+        prefix = np.array([[5 + use], [9], [50 - use], [70]], dtype=np.int64)
+        want = beam_ref.generate(step_logits, bsz=bsz, vocab=vocab, pad=pad, eos=eos, unk=unk,
+                                 beam_size=beam, max_len_b=9, min_len=1, prefix_tokens=prefix,
+                                 max_decoder_positions=int(z["dims"][1]) - 1)
+        gen = SeqGenCustom([lm], _Tok(vocab, pad, eos, unk), beam_size=beam, max_len_b=9, min_len=1)
+        got = gen._generate(sample, prefix_tokens=torch.from_numpy(prefix).to(dev))
+        ses = list(lm.decoder._vs_search_sessions.values())[-1]
+        assert ses.uses == use + 1 and (len(ses.graphs) > 0) == (use >= 1)
+        for sent in range(bsz):
+            assert [h["tokens"].tolist() for h in got[sent]] == [h["tokens"].tolist() for h in want[sent]]
+            for hg, hw in zip(got[sent], want[sent]):
+                assert abs(float(hg["score"]) - hw["score"]) < 1e-4
+
+
+def test_device_search_equals_host_search_on_a_gpt2_medium_slice(dev):
+    """d_model 1024 / 50 300 tokens / 40 rows: the skinny MFMA GEMMs with K-split, the sliced top-k, the
+    dh = 64 ancestry attention and the per-step graphs against the host loop with the cache gather."""
+    from vidsitu_amd.seq_gen import SeqGenCustom
+
+    path = [p for p in GOLD if "medium" in p][0]
+    z, w, n_head, m = _model_from_golden(path, dev)
+    vocab = int(z["dims"][0])
+    pad, eos, unk = vocab - 1, vocab - 2, vocab - 2
+    bsz, beam = 8, 5
+    lm = _LM(m, pad)
+    sample = {"src_tokens": torch.zeros(bsz, 1, dtype=torch.long, device=dev),
+              "src_lengths": torch.ones(bsz, dtype=torch.long, device=dev)}
+    for use in range(3):
+        prefix = torch.randint(0, 1000, (bsz, 2), generator=torch.Generator().manual_seed(use)).to(dev)
+        outs = []
+        for device_search in (False, True):
+            gen = SeqGenCustom([lm], _Tok(vocab, pad, eos, unk), beam_size=beam, max_len_b=12, min_len=3,
+                               device_search=device_search)
+            outs.append(gen._generate(sample, prefix_tokens=prefix))
+        for sent in range(bsz):
+            assert [h["tokens"].tolist() for h in outs[0][sent]] == [h["tokens"].tolist() for h in outs[1][sent]]
+            for hh, hd in zip(outs[0][sent], outs[1][sent]):
+                # the host loop drops finished sentences, so its later steps run other GEMM kernels
+                # (fewer rows): same tokens, scores equal to fp32 summation-order noise
+                assert abs(float(hh["score"]) - float(hd["score"])) < 1e-5 * max(1.0, abs(float(hh["score"])))
+                assert torch.allclose(hh["positional_scores"], hd["positional_scores"], atol=2e-5)
 
 
 def test_simple_txdec_plugin_surface(dev):

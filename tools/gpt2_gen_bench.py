@@ -19,13 +19,18 @@ torch.manual_seed(0)
 mdl = sel["mdl"](cfg=cfg, comm=comm).to(dev).eval()
 batch = synth_data.synth_srl_batch(comm, bs=B, n_ev=5, seq_len=60, device=dev)
 evl = sel["evl"](cfg, comm, dev)
-for it in range(2):
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    out = evl.forward_one_batch(mdl, batch)
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    ntok = sum(len(v["tokens"]) for r in out for v in r["vb_output"].values())
-    print(f"gen: {B} videos x 5 events, beam {beam}: {dt*1e3:.1f} ms, {ntok} output tokens, "
-          f"{5*B*beam*max_len/dt:.0f} beam-token steps/s")
+outs = {}
+for dsearch in (False, True):
+    evl.cfg.gen.device_search = dsearch
+    for it in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = evl.forward_one_batch(mdl, batch)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        ntok = sum(len(v["tokens"]) for r in out for v in r["vb_output"].values())
+        print(f"gen ({'device' if dsearch else 'host'} search): {B} videos x 5 events, beam {beam}: "
+              f"{dt*1e3:.1f} ms, {ntok} output tokens, {5*B*beam*max_len/dt:.0f} beam-token steps/s")
+    outs[dsearch] = [v["tokens"] for r in out for v in r["vb_output"].values()]
+print("device search tokens == host search tokens:", outs[True] == outs[False])
 torch.cuda.synchronize(); t0 = time.perf_counter()
 o = mdl(batch)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0

@@ -86,10 +86,12 @@ SIGNATURES = {
     "vs_gemm_nt_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vs_gpt2_embed": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vs_attn_causal_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
-    "vs_attn_decode": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vs_attn_decode": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vs_beam_topk_workspace_bytes": (_sz, [_i, _i, _i]),
     "vs_kv_gather": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "vs_beam_topk": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _i, _p]),
+    "vs_beam_topk": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _i, _p, _sz, _p]),
     "vs_xent_ignore": (_i, [_p, _p, _p, _p, _i, _i, _i64, _i, _p]),
+    "vs_beam_step": (_i, [_p] * 17 + [_i] * 9 + [_f, _p]),
     "vs_gelu_new_fwd": (_i, [_p, _p, _i64, _p]),
     "vs_gelu_new_bwd": (_i, [_p, _p, _p, _i64, _p]),
     "vs_add_f32": (_i, [_p, _p, _p, _i64, _p]),

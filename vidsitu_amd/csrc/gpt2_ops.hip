@@ -293,13 +293,106 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const float* qkv, float
   }
 }
 
+// dh in {16, 32, 64}: dh/16 lanes share a key (16-byte loads, 64 contiguous bytes per lane), the new
+// position's k / v come straight from qkv, and the cached rows of position j are read from cache row
+// anc[r][j] when an ancestry table is given: a beam reorder then only permutes that small table
+// (vs_beam_step) instead of copying the whole cache every step (vs_kv_gather: 590 MB per step for
+// GPT-2 medium at 50 rows x 30 positions).
+template <int DH>
+__global__ __launch_bounds__(64) void attn_decode_anc_kernel(const float* qkv, float* kc, float* vc,
+                                                             const uint8_t* kmask, const int* anc,
+                                                             float* out, int H, int Lmax, int t) {
+  extern __shared__ float sm[];  // P[t+1], then row index [t+1]
+  constexpr int PARTS = DH / 16, KPP = 64 / PARTS;
+  const int r = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
+  const int D = H * DH;
+  float* P = sm;
+  int* rowj = (int*)(sm + (t + 1));
+  const float* src = qkv + (long long)r * 3 * D + h * DH;
+  if (lane < DH) {
+    const long long own = (((long long)r * H + h) * Lmax + t) * DH + lane;
+    kc[own] = src[D + lane];
+    vc[own] = src[2 * D + lane];
+  }
+  const int part = lane % PARTS, jj = lane / PARTS;
+  float4 q4[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) q4[u] = *(const float4*)(src + part * 16 + u * 4);
+  const float scale = 1.0f / sqrtf((float)DH);
+  float mx = -INFINITY;
+  for (int j0 = 0; j0 <= t; j0 += KPP) {
+    const int j = j0 + jj;
+    const bool ok = j <= t;
+    const int jc = ok ? j : t;
+    const int rj = (anc && jc < t) ? anc[(long long)r * Lmax + jc] : r;
+    const float* kp = jc == t ? src + D + part * 16
+                              : kc + (((long long)rj * H + h) * Lmax + jc) * DH + part * 16;
+    float4 k4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) k4[u] = *(const float4*)(kp + u * 4);
+    float sdot = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      sdot += (q4[u].x * k4[u].x + q4[u].y * k4[u].y) + (q4[u].z * k4[u].z + q4[u].w * k4[u].w);
+#pragma unroll
+    for (int o = 1; o < PARTS; o <<= 1) sdot += __shfl_xor(sdot, o, 64);
+    sdot *= scale;
+    if (kmask && !kmask[(long long)r * Lmax + jc]) sdot += -1e4f;
+    if (ok) {
+      if (part == 0) {
+        P[j] = sdot;
+        rowj[j] = rj;
+      }
+      mx = fmaxf(mx, sdot);
+    }
+  }
+  mx = wave_reduce_max(mx);
+  __syncthreads();
+  float sum = 0.f;
+  for (int j = lane; j <= t; j += 64) {
+    const float e = expf(P[j] - mx);
+    P[j] = e;
+    sum += e;
+  }
+  sum = wave_reduce_sum(sum);
+  __syncthreads();
+  if (lane < DH) {
+    float o = P[t] * src[2 * D + lane];
+    const float* vb = vc + (long long)h * Lmax * DH + lane;
+    int j = 0;
+    for (; j + 4 <= t; j += 4) {
+      float vv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) vv[u] = vb[((long long)rowj[j + u] * H * Lmax + (j + u)) * DH];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) o += P[j + u] * vv[u];
+    }
+    for (; j < t; ++j) o += P[j] * vb[((long long)rowj[j] * H * Lmax + j) * DH];
+    out[(long long)r * D + h * DH + lane] = o / sum;
+  }
+}
+
 extern "C" int vs_attn_decode(const float* qkv, float* kcache, float* vcache, const uint8_t* key_mask,
-                              float* out, int rows, int H, int dh, int Lmax, int t, void* stream) {
+                              const int32_t* ancestry, float* out, int rows, int H, int dh, int Lmax,
+                              int t, void* stream) {
   VS_CHECK_ARG(qkv && kcache && vcache && out && rows > 0 && t >= 0 && t < Lmax, "bad args");
-  const size_t smem = (size_t)(t + 1 + dh) * sizeof(float);
+  const size_t smem = (size_t)(2 * (t + 1) + dh) * sizeof(float);
   VS_CHECK_ARG(smem <= 64 * 1024, "cache too long");
-  hipLaunchKernelGGL(attn_decode_kernel, dim3(rows * H), dim3(64), smem, (hipStream_t)stream, qkv,
-                     kcache, vcache, key_mask, out, H, dh, Lmax, t);
+  const bool al = (((uintptr_t)qkv | (uintptr_t)kcache) & 15) == 0;
+  if (dh == 64 && al)
+    hipLaunchKernelGGL(attn_decode_anc_kernel<64>, dim3(rows * H), dim3(64), smem, (hipStream_t)stream,
+                       qkv, kcache, vcache, key_mask, ancestry, out, H, Lmax, t);
+  else if (dh == 32 && al)
+    hipLaunchKernelGGL(attn_decode_anc_kernel<32>, dim3(rows * H), dim3(64), smem, (hipStream_t)stream,
+                       qkv, kcache, vcache, key_mask, ancestry, out, H, Lmax, t);
+  else if (dh == 16 && al)
+    hipLaunchKernelGGL(attn_decode_anc_kernel<16>, dim3(rows * H), dim3(64), smem, (hipStream_t)stream,
+                       qkv, kcache, vcache, key_mask, ancestry, out, H, Lmax, t);
+  else {
+    VS_CHECK_ARG(!ancestry, "ancestry tables need dh in {16, 32, 64}");
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(rows * H), dim3(64), smem, (hipStream_t)stream, qkv,
+                       kcache, vcache, key_mask, out, H, dh, Lmax, t);
+  }
   VS_CHECK_LAUNCH();
   return VS_OK;
 }
@@ -421,13 +514,200 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const float* logits, con
   }
 }
 
+// ---- large vocabularies: the row is cut into slices of BT_SLICE tokens (grid = slices x rows
+// instead of one block per row: 50 blocks x 12 passes over 50 k tokens took 550 us per step).
+//   1. per slice: max and sum exp      2. per slice: the row's lse from the partials (fixed order,
+//   the same bits in every block), exact scores of the slice in registers, k rounds of block argmax
+//   3. per row: merge slices x k candidates.  Same (value desc, token asc) order as the one-block kernel.
+#define BT_SLICE 2048
+#define BT_E (BT_SLICE / 256)
+
+__global__ __launch_bounds__(256) void beam_lse_part_kernel(const float* logits, float2* part, int V,
+                                                            float inv_temp) {
+  __shared__ float red[4];
+  const int sl = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, S = gridDim.x;
+  const float* x = logits + (long long)r * V;
+  float v[BT_E];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < BT_E; ++e) {
+    const int j = sl * BT_SLICE + e * 256 + tid;
+    const bool ok = j < V;
+    const float t = x[ok ? j : 0] * inv_temp;
+    v[e] = ok ? t : -INFINITY;
+    mx = fmaxf(mx, v[e]);
+  }
+  mx = wave_reduce_max(mx);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < BT_E; ++e) {
+    const int j = sl * BT_SLICE + e * 256 + tid;
+    if (j < V) sum += expf(v[e] - mx);
+  }
+  sum = wave_reduce_sum(sum);
+  if ((tid & 63) == 0) red[tid >> 6] = sum;
+  __syncthreads();
+  if (tid == 0) part[(long long)r * S + sl] = make_float2(mx, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+__device__ __forceinline__ void bt_block_argbest(float& bv, int& bi, float* cv, int* ci, int tid) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (bt_better(ov, oi, bv, bi)) {
+      bv = ov;
+      bi = oi;
+    }
+  }
+  __syncthreads();  // previous round's readers are done
+  if ((tid & 63) == 0) {
+    cv[tid >> 6] = bv;
+    ci[tid >> 6] = bi;
+  }
+  __syncthreads();
+  bv = cv[0];
+  bi = ci[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w)
+    if (bt_better(cv[w], ci[w], bv, bi)) {
+      bv = cv[w];
+      bi = ci[w];
+    }
+}
+
+__global__ __launch_bounds__(256) void beam_topk_part_kernel(
+    const float* logits, const float2* part, const float* cum, const int64_t* forced, float* cand_val,
+    int* cand_idx, int V, int k, int pad, int eos, int unk, float unk_penalty, float inv_temp, int flags) {
+  __shared__ float cv[4];
+  __shared__ int ci[4];
+  const int sl = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, S = gridDim.x;
+  const float* x = logits + (long long)r * V;
+  float M = -INFINITY;
+  for (int q = 0; q < S; ++q) M = fmaxf(M, part[(long long)r * S + q].x);
+  float sum = 0.f;
+  for (int q = 0; q < S; ++q) {
+    const float2 pq = part[(long long)r * S + q];
+    sum += pq.y * expf(pq.x - M);
+  }
+  const float lse = M + logf(sum);
+  const float add = cum ? cum[r] : 0.f;
+  const long long f = forced ? forced[r] : -1;
+  const bool force = f >= 0 && f != pad;
+  float v[BT_E];
+  int idx[BT_E];
+#pragma unroll
+  for (int e = 0; e < BT_E; ++e) {
+    const int j = sl * BT_SLICE + e * 256 + tid;
+    const bool ok = j < V;
+    float lp = x[ok ? j : 0] * inv_temp - lse;
+    if (lp != lp) lp = -INFINITY;
+    if (j == pad) lp = -INFINITY;
+    if (j == unk) lp -= unk_penalty;
+    if ((flags & 1) && j != eos) lp = -INFINITY;
+    if (force) {
+      if (j != (int)f) lp = -INFINITY;
+    } else if ((flags & 2) && j == eos) {
+      lp = -INFINITY;
+    }
+    v[e] = ok ? lp + add : -INFINITY;
+    idx[e] = ok ? j : 0x7fffffff;
+  }
+  for (int round = 0; round < k; ++round) {
+    float bv = v[0];
+    int bi = idx[0];
+#pragma unroll
+    for (int e = 1; e < BT_E; ++e)
+      if (bt_better(v[e], idx[e], bv, bi)) {
+        bv = v[e];
+        bi = idx[e];
+      }
+    bt_block_argbest(bv, bi, cv, ci, tid);
+#pragma unroll
+    for (int e = 0; e < BT_E; ++e)
+      if (idx[e] == bi) {  // consumed (a padding sentinel never matches a live entry again)
+        v[e] = -INFINITY;
+        idx[e] = 0x7fffffff;
+      }
+    if (tid == 0) {
+      cand_val[((long long)r * S + sl) * k + round] = bv;
+      cand_idx[((long long)r * S + sl) * k + round] = bi;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void beam_topk_merge_kernel(const float* cand_val, const int* cand_idx,
+                                                              float* out_val, int64_t* out_idx, int n,
+                                                              int k) {
+  __shared__ float cv[4];
+  __shared__ int ci[4];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  float v[4];
+  int idx[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = e * 256 + tid;
+    const bool ok = c < n;
+    v[e] = ok ? cand_val[(long long)r * n + (ok ? c : 0)] : -INFINITY;
+    idx[e] = ok ? cand_idx[(long long)r * n + (ok ? c : 0)] : 0x7fffffff;
+  }
+  for (int round = 0; round < k; ++round) {
+    float bv = v[0];
+    int bi = idx[0];
+#pragma unroll
+    for (int e = 1; e < 4; ++e)
+      if (bt_better(v[e], idx[e], bv, bi)) {
+        bv = v[e];
+        bi = idx[e];
+      }
+    bt_block_argbest(bv, bi, cv, ci, tid);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (idx[e] == bi) {
+        v[e] = -INFINITY;
+        idx[e] = 0x7fffffff;
+      }
+    if (tid == 0) {
+      out_val[(long long)r * k + round] = bv;
+      out_idx[(long long)r * k + round] = bi;
+    }
+  }
+}
+
+static inline int bt_slices(int V) { return (V + BT_SLICE - 1) / BT_SLICE; }
+
+extern "C" size_t vs_beam_topk_workspace_bytes(int rows, int V, int k) {
+  const size_t S = (size_t)bt_slices(V);
+  return (size_t)rows * S * 8 + (size_t)rows * S * (size_t)k * 8 + 256;
+}
+
 extern "C" int vs_beam_topk(const float* logits, const float* cum, const int64_t* forced,
                             float* out_val, int64_t* out_idx, int rows, int V, int k, int pad,
                             int eos, int unk, float unk_penalty, float temperature, int flags,
-                            void* stream) {
+                            void* workspace, size_t ws_bytes, void* stream) {
   VS_CHECK_ARG(logits && out_val && out_idx && rows > 0 && V > 1, "bad args");
   VS_CHECK_ARG(k >= 1 && k <= BT_MAXK && k < V, "k must be in [1, 32] and < V");
   VS_CHECK_ARG(temperature > 0.f, "temperature must be > 0");
+  const int S = bt_slices(V);
+  if (workspace && S >= 2 && S * k <= 1024) {
+    VS_CHECK_ARG(ws_bytes >= vs_beam_topk_workspace_bytes(rows, V, k), "workspace too small");
+    float2* part = (float2*)workspace;
+    float* cval = (float*)((char*)workspace + (((size_t)rows * S * 8 + 127) & ~(size_t)127));
+    int* cidx = (int*)(cval + (size_t)rows * S * k);
+    hipLaunchKernelGGL(beam_lse_part_kernel, dim3(S, rows), dim3(256), 0, (hipStream_t)stream, logits,
+                       part, V, 1.0f / temperature);
+    hipLaunchKernelGGL(beam_topk_part_kernel, dim3(S, rows), dim3(256), 0, (hipStream_t)stream, logits,
+                       part, cum, forced, cval, cidx, V, k, pad, eos, unk, unk_penalty,
+                       1.0f / temperature, flags);
+    hipLaunchKernelGGL(beam_topk_merge_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, cval, cidx,
+                       out_val, out_idx, S * k, k);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+  }
   hipLaunchKernelGGL(beam_topk_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, cum,
                      forced, out_val, out_idx, V, k, pad, eos, unk, unk_penalty, 1.0f / temperature,
                      flags);
@@ -772,6 +1052,203 @@ extern "C" int vs_xent_ignore_grad(const float* logits, const int64_t* labels, c
   VS_CHECK_ARG(logits && labels && loss_out && dlogits && rows > 0 && V > 0 && ld >= V, "bad args");
   hipLaunchKernelGGL(xent_ignore_grad_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits,
                      labels, loss_out, dlogits, V, (long long)ld, ignore_index, grad_scale);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// =============================================================================================
+// Device-side beam-search bookkeeping: everything SeqGenCustom._generate does
+// on the host between two decoder calls (seq_gen.py:368-520 + finalize_hypos :579-697) for ONE
+// step, one block per sentence, no host synchronisation.  Finished sentences are not removed from
+// the batch (the reference shrinks it); their rows idle, results are unchanged.
+// =============================================================================================
+struct BeamStepP {
+  const float* row_val;     // [bsz*beam][k]   per-row top-k of vs_beam_topk (cumulative scores added)
+  const int64_t* row_idx;   // [bsz*beam][k]
+  const int64_t* tok_in;    // [bsz*beam][Lt]  Lt = max_len + 2
+  int64_t* tok_out;
+  const float* sc_in;       // [bsz*beam][Ls]  Ls = max_len + 1
+  float* sc_out;
+  uint8_t* ignore;          // [bsz][beam]     cands_to_ignore
+  uint8_t* finished;        // [bsz]
+  int* nfin;                // [bsz]           hypotheses finalized so far
+  int* remaining;           // [1]             sentences not finished yet
+  int64_t* fin_tok;         // [bsz][beam][Ls] finalized token sequences (eos included)
+  float* fin_score;         // [bsz][beam]
+  float* fin_pos;           // [bsz][beam][Ls] positional scores
+  int* fin_len;             // [bsz][beam]
+  int64_t* reorder;         // [bsz*beam]      parent row of every new row (KV-cache gather index)
+  const int* anc_in;        // [bsz*beam][anc_ld] or NULL: cache row holding position j of the hypothesis
+  int* anc_out;             //                  (vs_attn_decode's ancestry table; replaces the gather)
+  int anc_ld;
+  int beam, k, V, step, max_len, Lt, Ls, eos, normalize;
+  float len_penalty;
+};
+
+#define BS_MAXC 64  // 2 * beam candidates kept per sentence (beam <= 32)
+
+__device__ __forceinline__ void bs_anc_row(const BeamStepP& p, long long nrow, long long prow, int lane) {
+  if (!p.anc_out) return;
+  for (int j = lane; j <= p.step + 1 && j < p.anc_ld; j += 64)
+    p.anc_out[nrow * p.anc_ld + j] = j <= p.step ? p.anc_in[prow * p.anc_ld + j] : (int)nrow;
+}
+
+__global__ __launch_bounds__(64) void beam_step_kernel(BeamStepP p) {
+  __shared__ float cv[BS_MAXC];      // merged candidates: value
+  __shared__ int ct[BS_MAXC];        //                    token
+  __shared__ int cb[BS_MAXC];        //                    beam (parent, relative)
+  __shared__ int act[BS_MAXC];       // active hypotheses (candidate index) of the next step
+  __shared__ float bestv[64];
+  __shared__ long long bestf[64];
+  __shared__ int besti[64];
+  __shared__ int sh_new_fin;
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int beam = p.beam, k = p.k, csz = 2 * beam;
+  const long long row0 = (long long)s * beam;
+  if (p.finished[s]) {  // idle rows: carry the state over unchanged
+    for (int b = 0; b < beam; ++b) {
+      for (int j = lane; j < p.Lt; j += 64) p.tok_out[(row0 + b) * p.Lt + j] = p.tok_in[(row0 + b) * p.Lt + j];
+      for (int j = lane; j < p.Ls; j += 64) p.sc_out[(row0 + b) * p.Ls + j] = p.sc_in[(row0 + b) * p.Ls + j];
+      if (lane == 0) p.reorder[row0 + b] = row0 + b;
+      bs_anc_row(p, row0 + b, row0 + b, lane);
+    }
+    return;
+  }
+  // ---- fairseq BeamSearch.step on the per-row lists: the csz best of beam*k entries, by value
+  //      descending, ties towards the lowest flattened index beam*V + token (step 0: first beam only)
+  const int nb = p.step == 0 ? 1 : beam;
+  const int total = nb * k;
+  float pv = INFINITY;
+  long long pf = -1;
+  for (int c = 0; c < csz; ++c) {
+    float bv = -INFINITY;
+    long long bf = 0x7fffffffffffffffll;
+    int bi = -1;
+    if (c < k) {
+      for (int e = lane; e < total; e += 64) {
+        const float v = p.row_val[row0 * k + e];
+        const long long f = (long long)(e / k) * p.V + p.row_idx[row0 * k + e];
+        const bool after = (v < pv) || (v == pv && f > pf);
+        if (after && (v > bv || (v == bv && f < bf))) { bv = v; bf = f; bi = e; }
+      }
+    }
+    bestv[lane] = bv; bestf[lane] = bf; besti[lane] = bi;
+    __syncthreads();
+    for (int st = 32; st > 0; st >>= 1) {
+      if (lane < st) {
+        const float v2 = bestv[lane + st]; const long long f2 = bestf[lane + st];
+        if (besti[lane + st] >= 0 && (besti[lane] < 0 || v2 > bestv[lane] || (v2 == bestv[lane] && f2 < bestf[lane]))) {
+          bestv[lane] = v2; bestf[lane] = f2; besti[lane] = besti[lane + st];
+        }
+      }
+      __syncthreads();
+    }
+    if (lane == 0) {
+      if (besti[0] >= 0) {
+        cv[c] = bestv[0]; ct[c] = (int)p.row_idx[row0 * k + besti[0]]; cb[c] = besti[0] / k;
+      } else {  // fewer than 2*beam candidates exist (tiny vocabularies): -inf padding
+        cv[c] = -INFINITY; ct[c] = 0; cb[c] = 0;
+      }
+    }
+    pv = bestv[0]; pf = bestf[0];
+    __syncthreads();
+  }
+  // ---- finalize hypotheses that end in eos among the first `beam` candidates (lane 0: in order)
+  if (lane == 0) {
+    int seen = 0;
+    for (int c = 0; c < beam; ++c) {
+      const bool is_eos = ct[c] == p.eos && cv[c] != -INFINITY && !p.ignore[s * beam + c];
+      if (!is_eos) continue;
+      seen = 1;
+      if (p.nfin[s] < beam) {
+        const int h = p.nfin[s]++;
+        const long long prow = row0 + cb[c];
+        int64_t* ft = p.fin_tok + ((long long)s * beam + h) * p.Ls;
+        float* fp = p.fin_pos + ((long long)s * beam + h) * p.Ls;
+        for (int j = 0; j < p.step; ++j) ft[j] = p.tok_in[prow * p.Lt + 1 + j];
+        ft[p.step] = p.eos;
+        float prev = 0.f;
+        for (int j = 0; j < p.step; ++j) {
+          const float cur = p.sc_in[prow * p.Ls + j];
+          fp[j] = j == 0 ? cur : cur - prev;
+          prev = cur;
+        }
+        fp[p.step] = p.step == 0 ? cv[c] : cv[c] - prev;
+        float sc = cv[c];
+        if (p.normalize) sc = sc / powf((float)(p.step + 1), p.len_penalty);
+        p.fin_score[s * beam + h] = sc;
+        p.fin_len[s * beam + h] = p.step + 1;
+      }
+    }
+    int fin_now = 0;
+    if (seen && (p.nfin[s] == beam || p.step == p.max_len)) {
+      p.finished[s] = 1;
+      atomicSub(p.remaining, 1);
+      fin_now = 1;
+    }
+    sh_new_fin = fin_now;
+  }
+  __syncthreads();
+  if (sh_new_fin) {
+    for (int b = 0; b < beam; ++b) {
+      for (int j = lane; j < p.Lt; j += 64) p.tok_out[(row0 + b) * p.Lt + j] = p.tok_in[(row0 + b) * p.Lt + j];
+      for (int j = lane; j < p.Ls; j += 64) p.sc_out[(row0 + b) * p.Ls + j] = p.sc_in[(row0 + b) * p.Ls + j];
+      if (lane == 0) p.reorder[row0 + b] = row0 + b;
+      bs_anc_row(p, row0 + b, row0 + b, lane);
+    }
+    return;
+  }
+  // ---- the `beam` live candidates with the smallest rank (eos / ignored ones sort behind)
+  if (lane == 0) {
+    int n = 0;
+    for (int pass = 0; pass < 2 && n < beam; ++pass)
+      for (int c = 0; c < csz && n < beam; ++c) {
+        bool dead = ct[c] == p.eos && cv[c] != -INFINITY;
+        if (c < beam) dead = dead || p.ignore[s * beam + c];
+        if ((pass == 0) == !dead) act[n++] = c | (dead ? 0x10000 : 0);
+      }
+    for (int b = 0; b < beam; ++b) p.ignore[s * beam + b] = (act[b] & 0x10000) ? 1 : 0;
+  }
+  __syncthreads();
+  for (int b = 0; b < beam; ++b) {
+    const int c = act[b] & 0xffff;
+    const long long prow = row0 + cb[c], nrow = row0 + b;
+    for (int j = lane; j < p.Lt; j += 64) {
+      int64_t t = p.tok_in[prow * p.Lt + j];
+      if (j == p.step + 1) t = ct[c];
+      p.tok_out[nrow * p.Lt + j] = t;
+    }
+    for (int j = lane; j < p.Ls; j += 64) {
+      float v = p.sc_in[prow * p.Ls + j];
+      if (j == p.step) v = cv[c];
+      p.sc_out[nrow * p.Ls + j] = v;
+    }
+    if (lane == 0) p.reorder[nrow] = prow;
+    bs_anc_row(p, nrow, prow, lane);
+  }
+}
+
+extern "C" int vs_beam_step(const float* row_val, const int64_t* row_idx, const int64_t* tok_in,
+                            int64_t* tok_out, const float* sc_in, float* sc_out, uint8_t* ignore,
+                            uint8_t* finished, int* nfin, int* remaining, int64_t* fin_tok,
+                            float* fin_score, float* fin_pos, int* fin_len, int64_t* reorder,
+                            const int32_t* anc_in, int32_t* anc_out, int anc_ld, int bsz, int beam, int k,
+                            int V, int step, int max_len, int eos, int normalize, float len_penalty,
+                            void* stream) {
+  VS_CHECK_ARG(row_val && row_idx && tok_in && tok_out && sc_in && sc_out && ignore && finished && nfin &&
+                   remaining && fin_tok && fin_score && fin_pos && fin_len && reorder, "null argument");
+  VS_CHECK_ARG(bsz > 0 && beam >= 1 && 2 * beam <= BS_MAXC && k >= 1 && k <= 2 * beam, "beam <= 32, k <= 2*beam");
+  VS_CHECK_ARG((anc_in == nullptr) == (anc_out == nullptr) && (!anc_out || anc_ld > step), "ancestry tables");
+  BeamStepP p;
+  p.anc_in = anc_in; p.anc_out = anc_out; p.anc_ld = anc_ld;
+  p.row_val = row_val; p.row_idx = row_idx; p.tok_in = tok_in; p.tok_out = tok_out;
+  p.sc_in = sc_in; p.sc_out = sc_out; p.ignore = ignore; p.finished = finished; p.nfin = nfin;
+  p.remaining = remaining; p.fin_tok = fin_tok; p.fin_score = fin_score; p.fin_pos = fin_pos;
+  p.fin_len = fin_len; p.reorder = reorder;
+  p.beam = beam; p.k = k; p.V = V; p.step = step; p.max_len = max_len;
+  p.Lt = max_len + 2; p.Ls = max_len + 1; p.eos = eos; p.normalize = normalize;
+  p.len_penalty = len_penalty;
+  hipLaunchKernelGGL(beam_step_kernel, dim3(bsz), dim3(64), 0, (hipStream_t)stream, p);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }

@@ -277,6 +277,171 @@ __global__ __launch_bounds__(256) void linear_rows16_kernel(const float* __restr
   }
 }
 
+// 17..64 rows on the fp32 matrix cores (GPT-2 decode steps: sentences x beam rows).
+// One block = NW waves that split K (wave w takes the 16-float chunk w of every 16*NW) and each
+// accumulate the block's whole (RB*16 rows) x (CB*16 columns) tile with v_mfma_f32_16x16x4_f32;
+// fragments come straight from global memory in the MFMA operand layout (lane = (row or column,
+// k-quad): one float4 feeds four MFMAs), two register stages of CH chunks, loads unconditional and
+// fenced from the MFMAs by scheduling barriers (hipcc otherwise sinks a stage's loads next to their
+// first use, or waits vmcnt(0) at the join of a conditional load: no overlap); the NW partial tiles
+// are added through LDS in wave order (bitwise reproducible).  These layers are a few MB: a launch is
+// one memory latency + 2-4 us of MFMA work, so what counts is (a) enough blocks for 256 CUs without a
+// K split across blocks -- measured, a slab + ticket combine costs three memory round trips (~6 us) --
+// and (b) every load of a wave in flight from the start: wide K splits inside the block (8-16 waves,
+// both register stages cover all of K = 1024) rather than a deep loop in 4 waves.  Tile shapes
+// (launch_skinny):
+//   <4,4,2, 4>  64 rows x 64 columns, 8 loads per 64 MFMAs   (lm_head: N / 64 = 786 blocks)
+//   <4,1,4, 8>  64 rows x 16 columns, 5 loads per 16 MFMAs   (c_attn, mlp.c_fc: N / 16 = 192 / 256 blocks)
+//   <1,1,4,16>  16 rows x 16 columns, 2 loads per  4 MFMAs   (attn.c_proj, mlp.c_proj with N = 1024:
+//               256 blocks; the row groups of a column tile are neighbours on one XCD, so the weight
+//               tile leaves HBM once)
+typedef float lsk_v4f __attribute__((ext_vector_type(4)));
+
+template <int RB, int CB, int CH>
+struct LskStage {
+  float4 a[RB][CH];
+  float4 bw[CB][CH];
+};
+
+__device__ __forceinline__ float lsk_f4e(const float4& v, int e) {
+  return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w;
+}
+
+template <int RB, int CB, int CH, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_skinny_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+    const float* res, float* y, int M, int N, int K, int act, int tiles, int rgroups) {
+  extern __shared__ lsk_v4f lsk_red[];  // [NW waves][RB*CB tiles][64 lanes]
+  // block id -> (column tile, row group): ids are dealt round-robin to the 8 XCDs, so the row groups
+  // of one column tile get consecutive slots of the same XCD
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tile = (slot / rgroups) * 8 + xcd, rg = slot % rgroups;
+  if (tile >= tiles) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n0 = tile * (16 * CB), m0 = rg * (16 * RB), col = lane & 15, kq = lane >> 4;
+  const int kbase = wave * 16 + kq * 4;
+  constexpr int GK = 16 * NW * CH;  // floats of K per group (all waves, one stage)
+  const float* wp[CB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb) {
+    const int n = n0 + cb * 16 + col < N ? n0 + cb * 16 + col : N - 1;
+    wp[cb] = w + (long long)n * K + kbase;
+  }
+  const float* xp[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int m = m0 + rb * 16 + col < M ? m0 + rb * 16 + col : M - 1;
+    xp[rb] = x + (long long)m * K + kbase;
+  }
+  lsk_v4f acc[RB][CB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) acc[rb][cb] = lsk_v4f{0.f, 0.f, 0.f, 0.f};
+
+  const int groups = K / GK;
+  auto load = [&](LskStage<RB, CB, CH>& st, int g) {
+    const int off = g * GK;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) st.bw[cb][c] = *(const float4*)(wp[cb] + off + c * (16 * NW));
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) st.a[rb][c] = *(const float4*)(xp[rb] + off + c * (16 * NW));
+    }
+  };
+  auto compute = [&](const LskStage<RB, CB, CH>& st) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb)
+            acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(lsk_f4e(st.a[rb][c], e), lsk_f4e(st.bw[cb][c], e),
+                                                               acc[rb][cb], 0, 0, 0);
+  };
+  LskStage<RB, CB, CH> s0, s1;
+  load(s0, 0);
+  const int glast = groups - 1;
+  int g = 0;
+  for (; g + 2 <= groups; g += 2) {
+    load(s1, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(s0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (g + 2 < groups) load(s0, g + 2 < glast ? g + 2 : glast);  // (uniform; skipped on the last trip)
+    __builtin_amdgcn_sched_barrier(0);
+    compute(s1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (g < groups) compute(s0);  // odd tail: the loop's last load (or the prologue's) fetched it
+  constexpr int NT = RB * CB;
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) lsk_red[(wave * NT + rb * CB + cb) * 64 + lane] = acc[rb][cb];
+  __syncthreads();
+  // wave w' finishes tiles w', w'+NW, ...: rows m0 + rb*16 + 4*(lane/16) + 0..3, column cb*16 + lane%16
+  for (int t = wave; t < NT; t += NW) {
+    const int rb = t / CB, cb = t % CB;
+    lsk_v4f v = lsk_red[t * 64 + lane];
+#pragma unroll
+    for (int q = 1; q < NW; ++q) v += lsk_red[(q * NT + t) * 64 + lane];
+    const int n = n0 + cb * 16 + col;
+    if (n >= N) continue;
+    const float bias = b ? b[n] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int m = m0 + rb * 16 + 4 * kq + e;
+      if (m < M) {
+        float sv = v[e] + bias;
+        if (act == 1) sv = fmaxf(sv, 0.f);
+        else if (act == 2) sv = 0.5f * sv * (1.0f + tanhf(0.7978845608028654f * (sv + 0.044715f * sv * sv * sv)));
+        if (res) sv += res[(long long)m * N + n];
+        y[(long long)m * N + n] = sv;
+      }
+    }
+  }
+}
+
+template <int RB, int CB, int CH, int NW>
+static void launch_skinny_cfg(const float* x, const float* w, const float* b, const float* res, float* y,
+                              int M, int N, int K, int act, hipStream_t st) {
+  constexpr int smem = NW * RB * CB * 64 * 16;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)linear_skinny_kernel<RB, CB, CH, NW>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr = true;
+  }
+  const int tiles = (N + 16 * CB - 1) / (16 * CB), tiles8 = (tiles + 7) & ~7;
+  const int rgroups = (M + 16 * RB - 1) / (16 * RB);
+  hipLaunchKernelGGL((linear_skinny_kernel<RB, CB, CH, NW>), dim3(tiles8 * rgroups), dim3(64 * NW), smem, st, x,
+                     w, b, res, y, M, N, K, act, tiles, rgroups);
+}
+
+static bool linear_skinny(const float* x, const float* w, const float* b, const float* res, float* y,
+                          int M, int N, int K, int act, hipStream_t st) {
+  if (M <= 16 || M > 64 || (K & 127) != 0) return false;
+  if (((uintptr_t)x | (uintptr_t)w) & 15) return false;
+  const int rbn = (M + 15) / 16;
+  // the largest tile that still yields ~190 blocks; its K group (16 * NW * CH floats) must divide K
+  if (N >= 190 * 64 || ((K & 511) != 0)) {
+    if (rbn == 2) launch_skinny_cfg<2, 4, 2, 4>(x, w, b, res, y, M, N, K, act, st);
+    else if (rbn == 3) launch_skinny_cfg<3, 4, 2, 4>(x, w, b, res, y, M, N, K, act, st);
+    else launch_skinny_cfg<4, 4, 2, 4>(x, w, b, res, y, M, N, K, act, st);
+  } else if (N >= 190 * 16 || ((K & 1023) != 0)) {
+    if (rbn == 2) launch_skinny_cfg<2, 1, 4, 8>(x, w, b, res, y, M, N, K, act, st);
+    else if (rbn == 3) launch_skinny_cfg<3, 1, 4, 8>(x, w, b, res, y, M, N, K, act, st);
+    else launch_skinny_cfg<4, 1, 4, 8>(x, w, b, res, y, M, N, K, act, st);
+  } else {
+    launch_skinny_cfg<1, 1, 4, 16>(x, w, b, res, y, M, N, K, act, st);
+  }
+  return true;
+}
+
 static int linear_small_m(const float* x, const float* w, const float* b, const float* res, float* y,
                           int M, int N, int K, int act, hipStream_t st) {
   const int gx = (N + 3) / 4;
@@ -339,6 +504,10 @@ extern "C" int vs_gemm_nt_f32(const float* x, const float* w, const float* b, co
                               float* y, int M, int N, int K, int act, void* stream) {
   VS_CHECK_ARG(x && w && y && M > 0 && N > 0 && K > 0, "bad args");
   VS_CHECK_ARG(act >= 0 && act <= 2, "act must be 0 (none), 1 (relu) or 2 (gelu_new)");
+  if (linear_skinny(x, w, b, res, y, M, N, K, act, (hipStream_t)stream)) {
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+  }
   if (M <= 64) return linear_small_m(x, w, b, res, y, M, N, K, act, (hipStream_t)stream);
   return vs_gemm_nt_f32_mfma(x, w, b, res, y, M, N, K, act, (hipStream_t)stream);
 }
@@ -623,13 +792,89 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* x, 
   }
 }
 
+// D % 4 == 0: 16-byte accesses, every load of the row issued before the first use and no load inside
+// a divergent branch (the scalar kernel's `if (d < D)` loads were 16 serialised round trips: 12.5 us
+// for 50 x 1024)
+__global__ __launch_bounds__(256) void add_layernorm_fwd_vec_kernel(
+    const float* x, const float* r, const float* rmask, const float* gamma, const float* beta, float* y,
+    float* mean, float* rstd, int rows, int D, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  constexpr int NE = LN_MAXE / 4;
+  const int D4 = D >> 2;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* x4 = (const float4*)(x + (long long)row * D);
+  float4 v[NE], g4[NE], b4[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int d = lane + 64 * e;
+    const bool ok = d < D4;
+    const float4 t = x4[ok ? d : 0];
+    v[e] = ok ? t : z4;
+    g4[e] = ((const float4*)gamma)[ok ? d : 0];
+    b4[e] = ((const float4*)beta)[ok ? d : 0];
+  }
+  if (r) {
+    const float4* r4 = (const float4*)(r + (long long)row * D);
+    const float4* m4 = rmask ? (const float4*)(rmask + (long long)row * D) : nullptr;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int d = lane + 64 * e;
+      const bool ok = d < D4;
+      float4 t = r4[ok ? d : 0];
+      if (m4) {
+        const float4 m = m4[ok ? d : 0];
+        t.x *= m.x; t.y *= m.y; t.z *= m.z; t.w *= m.w;
+      }
+      if (ok) { v[e].x += t.x; v[e].y += t.y; v[e].z += t.z; v[e].w += t.w; }
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) s += (v[e].x + v[e].y) + (v[e].z + v[e].w);
+  const float mu = wave_reduce_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    if (lane + 64 * e < D4) {
+      const float a = v[e].x - mu, b = v[e].y - mu, c = v[e].z - mu, d2 = v[e].w - mu;
+      q += (a * a + b * b) + (c * c + d2 * d2);
+    }
+  }
+  const float rs = rsqrtf(wave_reduce_sum(q) / (float)D + eps);
+  float4* y4 = (float4*)(y + (long long)row * D);
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int d = lane + 64 * e;
+    if (d < D4) {
+      float4 o;
+      o.x = (v[e].x - mu) * rs * g4[e].x + b4[e].x;
+      o.y = (v[e].y - mu) * rs * g4[e].y + b4[e].y;
+      o.z = (v[e].z - mu) * rs * g4[e].z + b4[e].z;
+      o.w = (v[e].w - mu) * rs * g4[e].w + b4[e].w;
+      y4[d] = o;
+    }
+  }
+  if (lane == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = rs;
+  }
+}
+
 extern "C" int vs_add_layernorm_fwd(const float* x, const float* r, const float* rmask,
                                     const float* gamma, const float* beta, float* y, float* mean,
                                     float* rstd, int rows, int D, float eps, void* stream) {
   VS_CHECK_ARG(x && gamma && beta && y && rows > 0, "bad args");
   VS_CHECK_ARG(D >= 1 && D <= 64 * LN_MAXE, "D <= 2048");
-  hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0,
-                     (hipStream_t)stream, x, r, rmask, gamma, beta, y, mean, rstd, rows, D, eps);
+  const uintptr_t al = (uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)r |
+                       (uintptr_t)rmask;
+  if ((D & 3) == 0 && (al & 15) == 0)
+    hipLaunchKernelGGL(add_layernorm_fwd_vec_kernel, dim3((rows + 3) / 4), dim3(256), 0,
+                       (hipStream_t)stream, x, r, rmask, gamma, beta, y, mean, rstd, rows, D, eps);
+  else
+    hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0,
+                       (hipStream_t)stream, x, r, rmask, gamma, beta, y, mean, rstd, rows, D, eps);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }

@@ -37,6 +37,9 @@ class KVCacheState:
     def __init__(self):
         self.k = self.v = self.k2 = self.v2 = None
         self.len = 0
+        # i32 [rows, Lmax] or None: cache row holding position j of row r (device-side beam search:
+        # vs_beam_step permutes this table instead of gathering the cache)
+        self.anc = None
 
     def __bool__(self):
         return True
@@ -77,6 +80,7 @@ class GPT2LMHeadModelHip(nn.Module):
         for k, v in p.items():
             self.register_parameter(k.replace(".", "__"), v)
         self._wt = {}  # K-contiguous ([out][in]) copies of the Conv1D weights for the kernels
+        self._wt_epoch = 0  # bumped whenever the copies are dropped (captured decode graphs go stale)
 
     # ---- huggingface-compatible state dict -------------------------------------------------
     def P(self, name):
@@ -108,7 +112,7 @@ class GPT2LMHeadModelHip(nn.Module):
             if k not in self._names and k != "lm_head.weight" and not k.endswith(".attn.bias") \
                     and not k.endswith(".attn.masked_bias"):
                 unexpected_keys.append(prefix + k)
-        self._wt.clear()
+        self._drop_wt()
 
     def resize_token_embeddings(self, new_size):
         """transformers PreTrainedModel.resize_token_embeddings: keep the first rows, initialise
@@ -122,11 +126,18 @@ class GPT2LMHeadModelHip(nn.Module):
         setattr(self, "transformer__wte__weight", nn.Parameter(new))
         self.config.vocab_size = new_size
 
+    def _drop_wt(self):
+        self._wt.clear()
+        self._wt_epoch += 1
+
     def _w(self, name):
         """[out][in] view of a Conv1D weight (transposed once, after load / device move)."""
         w = self.P(name)
         t = self._wt.get(name)
         if t is None or t.device != w.device:
+            if torch.cuda.is_current_stream_capturing():
+                raise ops._lib.VsError("GPT-2 weight copies must exist before a graph capture "
+                                       "(run one eager step first)")
             t = w.detach().t().contiguous()
             self._wt[name] = t
         return t
@@ -171,13 +182,12 @@ class GPT2LMHeadModelHip(nn.Module):
             dev = last_tokens.device
             state.k = torch.zeros(shape, dtype=torch.float32, device=dev)
             state.v = torch.zeros(shape, dtype=torch.float32, device=dev)
-            state.k2, state.v2 = torch.empty_like(state.k), torch.empty_like(state.v)
         t = state.len
         h = ops.gpt2_embed(last_tokens.view(rows, 1), self.P("transformer.wte.weight"),
                            self.P("transformer.wpe.weight"), pos0=t)
         for i in range(self.n_layer):
-            h = self._block(i, h, lambda li, qkv: ops.attn_decode(qkv, state.k[li][:rows],
-                                                                  state.v[li][:rows], key_mask, t))
+            h = self._block(i, h, lambda li, qkv: ops.attn_decode(qkv, state.k[li][:rows], state.v[li][:rows],
+                                                                  key_mask, t, ancestry=state.anc))
         state.len = t + 1
         return self._head(h)
 
@@ -257,13 +267,17 @@ class GPT2LMHeadModelHip(nn.Module):
         dwpe = self._grad("transformer.wpe.weight")
         dwpe.zero_()
         ops.gpt2_embed_bwd(tokens, dh, dwte, dwpe)  # adds the embedding rows onto the lm_head gradient
-        self._wt.clear()  # the optimizer is about to change the parameters
+        self._drop_wt()  # the optimizer is about to change the parameters
 
     def reorder_state(self, state: KVCacheState, new_order):
         """fairseq reorder_incremental_state: row r of the cache becomes old row new_order[r]."""
         if state.k is None:
             return
+        if state.anc is not None:
+            raise ops._lib.VsError("this cache is reordered through its ancestry table (vs_beam_step)")
         rows = new_order.numel()
+        if state.k2 is None:
+            state.k2, state.v2 = torch.empty_like(state.k), torch.empty_like(state.v)
         for li in range(self.n_layer):
             ops.kv_gather(state.k[li], state.k2[li], new_order, state.len)
             ops.kv_gather(state.v[li], state.v2[li], new_order, state.len)
@@ -303,6 +317,10 @@ class _XentIgnoreFn(torch.autograd.Function):
 class HuggingFaceGPT2Decoder(nn.Module):
     """hf_gpt2_fseq.py:124-215.  `args` is the full config (`args.mdl.gpt2_mdl_name`), `dictionary`
     the tokenizer object (`pad()`, `eos()`, `__len__`)."""
+
+    # `forward` never reads encoder_out (hf_gpt2_fseq.py:165-203 does not either): decode steps may be
+    # captured in hipGraphs without pinning the encoder output's address
+    uses_encoder_out = False
 
     def __init__(self, args, dictionary, state_dict=None):
         super().__init__()

@@ -656,12 +656,16 @@ def attn_causal(qkv, key_mask, r, l, n_head):
     return out
 
 
-def attn_decode(qkv, kcache, vcache, key_mask, t):
-    """qkv f32 [rows, 3D]; caches f32 [rows, H, Lmax, dh] (updated in place at position t)."""
+def attn_decode(qkv, kcache, vcache, key_mask, t, ancestry=None):
+    """qkv f32 [rows, 3D]; caches f32 [rows, H, Lmax, dh] (updated in place at position t);
+    ancestry i32 [rows, Lmax] (optional): cache row that holds position j of row r."""
     rows, h, lmax, dh = kcache.shape
+    if ancestry is not None and (ancestry.dtype != torch.int32 or tuple(ancestry.shape) != (rows, lmax)
+                                 or not ancestry.is_contiguous()):
+        raise _lib.VsError("attn_decode: ancestry must be a contiguous int32 [rows, Lmax] tensor")
     out = torch.empty((rows, h * dh), dtype=torch.float32, device=qkv.device)
-    _lib.call("vs_attn_decode", _ptr(qkv), _ptr(kcache), _ptr(vcache), _ptr(key_mask), _ptr(out), rows,
-              h, dh, lmax, int(t), _stream())
+    _lib.call("vs_attn_decode", _ptr(qkv), _ptr(kcache), _ptr(vcache), _ptr(key_mask), _ptr(ancestry),
+              _ptr(out), rows, h, dh, lmax, int(t), _stream())
     return out
 
 
@@ -679,9 +683,11 @@ def beam_topk(logits, cum, forced, k, pad, eos, unk, unk_penalty=0.0, temperatur
     val = torch.empty((rows, k), dtype=torch.float32, device=logits.device)
     idx = torch.empty((rows, k), dtype=torch.int64, device=logits.device)
     flags = (1 if eos_only else 0) | (2 if ban_eos else 0)
+    ws = torch.empty(int(_lib.load().vs_beam_topk_workspace_bytes(rows, v, int(k))), dtype=torch.uint8,
+                     device=logits.device)
     _lib.call("vs_beam_topk", _ptr(logits), _ptr(cum), _ptr(forced), _ptr(val), _ptr(idx), rows, v,
               int(k), int(pad), int(eos), int(unk), float(unk_penalty), float(temperature), flags,
-              _stream())
+              _ptr(ws), ws.numel(), _stream())
     return val, idx
 
 
@@ -758,3 +764,16 @@ def xent_ignore_grad(logits, labels, loss_out, ignore_index, grad_scale=1.0):
     _lib.call("vs_xent_ignore_grad", _ptr(logits), _ptr(labels.contiguous()), _ptr(loss_out), _ptr(dl), rows,
               v, v, int(ignore_index), float(grad_scale), _stream())
     return dl
+
+
+def beam_step(row_val, row_idx, tok_in, tok_out, sc_in, sc_out, ignore, finished, nfin, remaining,
+              fin_tok, fin_score, fin_pos, fin_len, reorder, bsz, beam, k, vocab, step, max_len, eos,
+              normalize, len_penalty, anc_in=None, anc_out=None):
+    """One step of the device-side beam-search bookkeeping (vs_beam_step); all tensors on the GPU."""
+    anc_ld = 0 if anc_in is None else anc_in.shape[1]
+    _lib.call("vs_beam_step", _ptr(row_val), _ptr(row_idx), _ptr(tok_in), _ptr(tok_out), _ptr(sc_in),
+              _ptr(sc_out), _ptr(ignore), _ptr(finished), _ptr(nfin), _ptr(remaining), _ptr(fin_tok),
+              _ptr(fin_score), _ptr(fin_pos), _ptr(fin_len), _ptr(reorder), _ptr(anc_in), _ptr(anc_out),
+              int(anc_ld), int(bsz), int(beam), int(k),
+              int(vocab), int(step), int(max_len), int(eos), int(bool(normalize)), float(len_penalty),
+              _stream())

@@ -15,6 +15,7 @@ best first).  Differences, all deliberate:
   `match_source_len`, no constraints / lm_model (unused by the reference's configs: they raise).
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -61,11 +62,137 @@ class EnsembleModel(nn.Module):
         return out[0][:, -1, :]
 
 
+class _DeviceSearchSession:
+    """Static buffers of one generation shape (batch, beam, lengths, vocabulary rules) and, when the
+    decoder keeps a KV cache, one hipGraph per step: every kernel argument of a step (position,
+    ping-pong parity, flags) is then a constant, and a replayed step costs one launch instead of
+    ~230.  Use 1 of a shape runs eagerly (library / allocator / weight-copy warm-up), use 2 captures
+    each step before replaying it, later uses only replay.  Graphs are dropped when the decoder's
+    weight copies change (`_wt_epoch`)."""
+
+    def __init__(self, key, dev):
+        (self.bsz, self.beam, self.max_len, self.min_len, self.plen, self.V, self.pad, self.eos, self.unk,
+         self.unk_penalty, self.temperature, self.normalize, self.len_penalty, self.kv, _) = key
+        bsz, beam, max_len = self.bsz, self.beam, self.max_len
+        rows, Lt, Ls = bsz * beam, max_len + 2, max_len + 1
+        self.rows, self.Lt, self.Ls = rows, Lt, Ls
+        i64, f32, i32, u8 = torch.long, torch.float32, torch.int32, torch.uint8
+        self.tok = [torch.empty((rows, Lt), dtype=i64, device=dev) for _ in range(2)]
+        self.sc = [torch.empty((rows, Ls), dtype=f32, device=dev) for _ in range(2)]
+        self.anc = [torch.empty((rows, Lt), dtype=i32, device=dev) for _ in range(2)] if self.kv else None
+        self.anc0 = torch.arange(rows, dtype=i32, device=dev).view(-1, 1).repeat(1, Lt) if self.kv else None
+        self.ignore = torch.empty((bsz, beam), dtype=u8, device=dev)
+        self.finished = torch.empty(bsz, dtype=u8, device=dev)
+        self.nfin = torch.empty(bsz, dtype=i32, device=dev)
+        self.remaining = torch.empty(1, dtype=i32, device=dev)
+        self.fin_tok = torch.empty((bsz, beam, Ls), dtype=i64, device=dev)
+        self.fin_score = torch.empty((bsz, beam), dtype=f32, device=dev)
+        self.fin_pos = torch.empty((bsz, beam, Ls), dtype=f32, device=dev)
+        self.fin_len = torch.empty((bsz, beam), dtype=i32, device=dev)
+        self.reorder = torch.empty(rows, dtype=i64, device=dev)
+        self.prefix = torch.empty((bsz, self.plen), dtype=i64, device=dev) if self.plen else None
+        self.k = min(2 * beam, beam * self.V - 1, self.V - 1)
+        self.state = None
+        if self.kv:
+            self.state = KVCacheState()
+            self.state.max_len = Lt
+        self.uses = 0
+        self.graphs = {}
+        self.pool = None
+        self.epoch = None
+        self.enc = None
+        self.use_graphs = self.kv and os.environ.get("VS_GEN_GRAPHS", "1") != "0"
+
+    def _reset(self, prefix_tokens, bos_token):
+        self.tok[0].fill_(self.pad)
+        self.tok[0][:, 0] = self.eos if bos_token is None else bos_token
+        self.sc[0].zero_()
+        for t in (self.ignore, self.finished, self.nfin, self.fin_score, self.fin_pos, self.fin_len):
+            t.zero_()
+        self.fin_tok.fill_(self.pad)
+        self.remaining.fill_(self.bsz)
+        if self.anc is not None:
+            self.anc[0].copy_(self.anc0)
+        if self.prefix is not None:
+            self.prefix.copy_(prefix_tokens)
+
+    def _step(self, gen, step):
+        cur = step & 1
+        st = self.state
+        prev = self.tok[cur][:, : step + 1]
+        if st is not None:
+            st.len = step
+            st.anc = self.anc[cur]
+        else:
+            prev = prev.contiguous()
+        logits = gen.model.decoder_logits(prev, self.enc, st)
+        forced, ban_eos = None, False
+        if self.prefix is not None and step < self.plen and step < self.max_len:
+            forced = self.prefix[:, step].unsqueeze(-1).repeat(1, self.beam).view(-1).contiguous()
+        elif step < self.min_len:
+            ban_eos = True
+        cum = None if step == 0 else self.sc[cur][:, step - 1].contiguous()
+        row_val, row_idx = ops.beam_topk(logits, cum, forced, self.k, self.pad, self.eos, self.unk,
+                                         self.unk_penalty, self.temperature,
+                                         eos_only=step >= self.max_len, ban_eos=ban_eos)
+        anc_in, anc_out = (self.anc[cur], self.anc[1 - cur]) if self.anc is not None else (None, None)
+        ops.beam_step(row_val, row_idx, self.tok[cur], self.tok[1 - cur], self.sc[cur], self.sc[1 - cur],
+                      self.ignore, self.finished, self.nfin, self.remaining, self.fin_tok, self.fin_score,
+                      self.fin_pos, self.fin_len, self.reorder, self.bsz, self.beam, self.k, self.V, step,
+                      self.max_len, self.eos, self.normalize, self.len_penalty, anc_in=anc_in,
+                      anc_out=anc_out)
+
+    def run(self, gen, encoder_outs, prefix_tokens, bos_token):
+        dec_model = getattr(gen.model.single_model.decoder, "model", None)
+        epoch = getattr(dec_model, "_wt_epoch", 0)
+        if epoch != self.epoch:  # weights changed (or first use): graphs are stale, warm up again
+            self.graphs, self.pool, self.uses, self.epoch = {}, None, 0, epoch
+        # a decoder that reads encoder outputs would need them at a fixed address inside the graphs
+        dec = gen.model.single_model.decoder
+        graphs = self.use_graphs and self.uses >= 1 and (not encoder_outs or
+                                                         getattr(dec, "uses_encoder_out", True) is False)
+        self.enc = encoder_outs
+        self._reset(prefix_tokens, bos_token)
+        for step in range(self.max_len + 1):
+            if graphs:
+                g = self.graphs.get(step)
+                if g is None:
+                    g = torch.cuda.CUDAGraph()
+                    if self.pool is None:
+                        self.pool = torch.cuda.graph_pool_handle()
+                    with torch.cuda.graph(g, pool=self.pool):
+                        self._step(gen, step)
+                    self.graphs[step] = g
+                g.replay()
+            else:
+                self._step(gen, step)
+            if (step % 8 == 7 or step == self.max_len) and int(self.remaining) == 0:
+                break
+        self.uses += 1
+        self.enc = None
+        dev = self.nfin.device
+        n_h, f_tok, f_sc, f_pos, f_len = (t.cpu() for t in (self.nfin, self.fin_tok, self.fin_score,
+                                                            self.fin_pos, self.fin_len))
+        finalized = []
+        for sent in range(self.bsz):
+            hyps = []
+            for h in range(int(n_h[sent])):
+                n = int(f_len[sent, h])
+                hyps.append({"tokens": f_tok[sent, h, :n].to(dev), "score": f_sc[sent, h].to(dev),
+                             "attention": torch.empty(0), "alignment": torch.empty(0),
+                             "positional_scores": f_pos[sent, h, :n].to(dev)})
+            order = torch.sort(torch.tensor([float(h["score"]) for h in hyps]), descending=True,
+                               stable=True)[1]
+            finalized.append([hyps[int(i)] for i in order])
+        return finalized
+
+
 class SeqGenCustom(nn.Module):
     def __init__(self, models, tgt_dict, beam_size=1, max_len_a=0, max_len_b=200, min_len=1,
                  normalize_scores=True, len_penalty=1.0, unk_penalty=0.0, temperature=1.0,
                  match_source_len=False, no_repeat_ngram_size=0, search_strategy=None, eos=None,
-                 symbols_to_strip_from_output=None, lm_model=None, lm_weight=1.0, use_kv_cache=True):
+                 symbols_to_strip_from_output=None, lm_model=None, lm_weight=1.0, use_kv_cache=True,
+                 device_search=True):
         super().__init__()
         self.model = models if isinstance(models, EnsembleModel) else EnsembleModel(models)
         self.tgt_dict = tgt_dict
@@ -80,6 +207,10 @@ class SeqGenCustom(nn.Module):
         if match_source_len or no_repeat_ngram_size > 0 or search_strategy is not None or lm_model is not None:
             raise NotImplementedError("option unused by the reference's configs (configs/vsitu_cfg.yml:76-85)")
         self.use_kv_cache = use_kv_cache
+        # device_search: the bookkeeping between two decoder calls runs in one kernel per step
+        # (vs_beam_step) with a host sync every 8 steps only; False = the torch-op mirror of the
+        # reference's host loop below (one or more syncs per step)
+        self.device_search = device_search and self.beam_size <= 32
         self.model.eval()
 
     @torch.no_grad()
@@ -93,6 +224,44 @@ class SeqGenCustom(nn.Module):
     def _generate(self, sample, prefix_tokens=None, constraints=None, bos_token=None):
         if constraints is not None:
             raise NotImplementedError
+        if self.device_search:
+            return self._generate_device(sample, prefix_tokens, bos_token)
+        return self._generate_host(sample, prefix_tokens, bos_token)
+
+    def _generate_device(self, sample, prefix_tokens=None, bos_token=None):
+        """Same search, state on the GPU: per step one decoder call, one
+        vs_beam_topk, one vs_beam_step; the KV cache is never copied (ancestry table); finished
+        sentences stay in the batch as idle rows instead of being removed; the host looks at the
+        `remaining` counter every 8 steps.  With a KV cache the step sequence of one generation shape
+        is captured in per-step hipGraphs on its second use (`_DeviceSearchSession`)."""
+        src_tokens = sample["src_tokens"]
+        dev = src_tokens.device
+        bsz, src_len = src_tokens.size()[:2]
+        max_len = min(int(self.max_len_a * src_len + self.max_len_b),
+                      self.model.max_decoder_positions() - 1)
+        assert self.min_len <= max_len, "min_len cannot be larger than max_len, please adjust these!"
+        if prefix_tokens is not None and bool((prefix_tokens == self.eos).any()):
+            raise NotImplementedError("eos inside prefix_tokens (unused by the reference's callers)")
+        enc_inp = {k: v for k, v in sample.items() if "prev_tok" not in k}
+        encoder_outs = self.model.forward_encoder(enc_inp)
+        new_order = torch.arange(bsz, device=dev).view(-1, 1).repeat(1, self.beam_size).view(-1)
+        encoder_outs = self.model.reorder_encoder_out(encoder_outs, new_order)  # beams of a sentence
+        # share their encoder output, so later beam reorders leave it unchanged
+        plen = 0 if prefix_tokens is None else prefix_tokens.size(1)
+        dec = self.model.single_model.decoder
+        key = (bsz, self.beam_size, max_len, self.min_len, plen, self.vocab_size, self.pad, self.eos,
+               self.unk, float(self.unk_penalty), float(self.temperature), bool(self.normalize_scores),
+               float(self.len_penalty), bool(self.use_kv_cache), str(dev))
+        cache = dec.__dict__.setdefault("_vs_search_sessions", {})
+        ses = cache.pop(key, None)
+        if ses is None:
+            ses = _DeviceSearchSession(key, dev)
+            while len(cache) >= 2:  # a session owns a KV cache and a graph pool
+                cache.pop(next(iter(cache)))
+        cache[key] = ses  # most recently used last
+        return ses.run(self, encoder_outs, prefix_tokens, bos_token)
+
+    def _generate_host(self, sample, prefix_tokens=None, bos_token=None):
         src_tokens = sample["src_tokens"]
         dev = src_tokens.device
         bsz, src_len = src_tokens.size()[:2]
