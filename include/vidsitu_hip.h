@@ -261,6 +261,20 @@ int vs_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
  * tiles straight from global memory; else 128x128 fp32 MFMA tiles through LDS. */
 int vs_gemm_nt_f32(const float* x, const float* w, const float* b, const float* res, float* y, int M,
                    int N, int K, int act, void* stream);
+/* Decode-step (1..64 rows) GEMM on fragment-major operands.  vs_pack_rows_f32 copies a row-major
+ * matrix src[R][K] (K % 16 == 0) into 1-KB blocks of 16 rows x 16 floats in v_mfma_f32_16x16x4_f32
+ * operand order (block (r/16, k/16) at index (r/16)*(K/16) + k/16; lane (k%16/4)*16 + r%16 holds floats
+ * k%4 = 0..3; rows up to the next multiple of 16 are zero): dst holds ceil16(R) * K floats.  Weights are
+ * packed once; the activations are written in this layout by their producers (vs_layernorm_fwd_packed,
+ * vs_attn_decode(out_packed), vs_gemm_nt_f32_packed(y_packed)), so every fragment load of the GEMM is
+ * one contiguous KB.  y = act(x . w^T + b) + res as vs_gemm_nt_f32; res, y row-major unless y_packed;
+ * K % 128 == 0; a packed y needs N % 16 == 0. */
+int vs_pack_rows_f32(const float* src, float* dst, int R, int K, void* stream);
+int vs_gemm_nt_f32_packed(const float* x_packed, const float* w_packed, const float* b, const float* res,
+                          float* y, int M, int N, int K, int act, int y_packed, void* stream);
+/* LayerNorm(x) * gamma + beta written fragment-major (D % 16 == 0, D <= 2048). */
+int vs_layernorm_fwd_packed(const float* x, const float* gamma, const float* beta, float* y_packed,
+                            int rows, int D, float eps, void* stream);
 /* out[r,l,:] = wte[tokens[r,l]] + wpe[pos0 + l]  (GPT2Model embeddings, default position ids). */
 int vs_gpt2_embed(const int64_t* tokens, const float* wte, const float* wpe, float* out, int R, int L,
                   int D, int pos0, int V, void* stream);
@@ -271,10 +285,11 @@ int vs_attn_causal_fwd(const float* qkv, const uint8_t* key_mask, float* out, in
 /* One incremental step: append k,v of qkv[rows,3D] at position t of the caches
  * [rows][H][Lmax][dh], attend the new query over 0..t; key_mask[rows,Lmax] or NULL.
  * ancestry[rows][Lmax] (or NULL): position j < t of row r is read from cache row ancestry[r][j] --
- * a beam reorder then permutes this table (vs_beam_step) instead of gathering the cache. */
+ * a beam reorder then permutes this table (vs_beam_step) instead of gathering the cache.
+ * out_packed: out is written fragment-major (vs_pack_rows_f32) for vs_gemm_nt_f32_packed. */
 int vs_attn_decode(const float* qkv, float* kcache, float* vcache, const uint8_t* key_mask,
                    const int32_t* ancestry, float* out, int rows, int H, int dh, int Lmax, int t,
-                   void* stream);
+                   int out_packed, void* stream);
 /* dst[r] = src[index[r]] for the first len positions of every head (beam reorder of a cache). */
 int vs_kv_gather(const float* src, float* dst, const int64_t* index, int rows_out, int H, int dh,
                  int Lmax, int len, void* stream);

@@ -62,6 +62,58 @@ def test_gemm_nt_f32(m, n, k, act, use_res, dev):
     assert torch.equal(ops.gemm_nt(*args), y)
 
 
+@pytest.mark.parametrize("m,n,k,act,use_res,ypk", [(50, 3072, 1024, 0, False, False), (50, 1024, 1024, 0, True, False),
+                                                   (50, 4096, 1024, 2, False, True), (50, 1024, 4096, 0, True, False),
+                                                   (40, 50259, 1024, 0, False, False), (17, 48, 128, 1, True, True),
+                                                   (9, 1000, 256, 0, False, False), (64, 208, 512, 2, True, True),
+                                                   (33, 4096, 2048, 0, False, False)])
+def test_gemm_nt_packed_equals_row_major(m, n, k, act, use_res, ypk, dev):
+    """Fragment-major operands (vs_pack_rows_f32) give the bits of the row-major skinny kernel -- same
+    MFMA sequence, only the addresses differ -- and the round trip pack -> unpack is the identity."""
+    from vidsitu_amd import ops
+
+    g = torch.Generator().manual_seed(m + n + k)
+    x = torch.randn(m, k, generator=g).to(dev)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(dev)
+    b = torch.randn(n, generator=g).to(dev)
+    res = torch.randn(m, n, generator=g).to(dev) if use_res else None
+    xp, wp = ops.pack_rows_f32(x), ops.pack_rows_f32(w)
+    assert torch.equal(ops.unpack_rows_f32(xp, m, k), x) and torch.equal(ops.unpack_rows_f32(wp, n, k), w)
+    y = ops.gemm_nt_packed(xp, wp, m, n, k, b=b, res=res, act=act, y_packed=ypk)
+    if ypk:
+        y = ops.unpack_rows_f32(y, m, n)
+    ref = x.double() @ w.double().t() + b.double()
+    if act == 1:
+        ref = ref.clamp_min(0)
+    elif act == 2:
+        ref = torch.from_numpy(gpt2_ref.gelu_new(ref.cpu().numpy())).to(dev)
+    if use_res:
+        ref = ref + res.double()
+    err = float((y.double() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 2e-5, f"packed gemm {m}x{n}x{k}: rel err {err:.2e}"
+    if m > 16:
+        assert torch.equal(y, ops.gemm_nt(x, w, b, res, act))
+
+
+def test_packed_layernorm_and_attention_outputs(dev):
+    from vidsitu_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    rows, d, heads, lmax, t = 37, 1024, 16, 9, 6
+    x = torch.randn(rows, d, generator=g).to(dev)
+    gamma, beta = torch.randn(d, generator=g).to(dev), torch.randn(d, generator=g).to(dev)
+    want = ops.add_layernorm_fwd(x, None, gamma, beta, 1e-5)[0]
+    got = ops.unpack_rows_f32(ops.layernorm_fwd_packed(x, gamma, beta, 1e-5), rows, d)
+    assert torch.equal(got, want)
+    qkv = torch.randn(rows, 3 * d, generator=g).to(dev)
+    kc = torch.randn(rows, heads, lmax, d // heads, generator=g).to(dev)
+    vc = torch.randn(rows, heads, lmax, d // heads, generator=g).to(dev)
+    anc = torch.randint(0, rows, (rows, lmax), generator=g).to(torch.int32).to(dev)
+    o_row = ops.attn_decode(qkv, kc.clone(), vc.clone(), None, t, ancestry=anc)
+    o_pk = ops.attn_decode(qkv, kc.clone(), vc.clone(), None, t, ancestry=anc, out_packed=True)
+    assert torch.equal(ops.unpack_rows_f32(o_pk, rows, d), o_row)
+
+
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
 def test_gpt2_logits_match_transformers_golden(path, dev):
     z, w, n_head, m = _model_from_golden(path, dev)
@@ -85,6 +137,8 @@ def test_cached_decode_equals_whole_sequence_pass(path, dev):
     z, w, n_head, m = _model_from_golden(path, dev)
     toks = torch.from_numpy(z["tokens"]).to(dev)  # no padding in generation
     toks = toks.clamp(min=1)[:, :12].contiguous()
+    if "medium" in path:  # 20 rows: the fragment-major (packed) decode step
+        toks = torch.cat([toks, toks.flip(1), (toks * 7 + 1) % 50000] * 3)[:20].contiguous()
     full = m.forward_logits(toks, None)
     st = KVCacheState()
     for t in range(toks.shape[1]):

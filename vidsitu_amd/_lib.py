@@ -86,7 +86,10 @@ SIGNATURES = {
     "vs_gemm_nt_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vs_gpt2_embed": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vs_attn_causal_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
-    "vs_attn_decode": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vs_attn_decode": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "vs_pack_rows_f32": (_i, [_p, _p, _i, _i, _p]),
+    "vs_gemm_nt_f32_packed": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vs_layernorm_fwd_packed": (_i, [_p, _p, _p, _p, _i, _i, _f, _p]),
     "vs_beam_topk_workspace_bytes": (_sz, [_i, _i, _i]),
     "vs_kv_gather": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vs_beam_topk": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _i, _p, _sz, _p]),

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const float* qkv, float
 template <int DH>
 __global__ __launch_bounds__(64) void attn_decode_anc_kernel(const float* qkv, float* kc, float* vc,
                                                              const uint8_t* kmask, const int* anc,
-                                                             float* out, int H, int Lmax, int t) {
+                                                             float* out, int H, int Lmax, int t, int opk) {
   extern __shared__ float sm[];  // P[t+1], then row index [t+1]
   constexpr int PARTS = DH / 16, KPP = 64 / PARTS;
   const int r = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
@@ -368,28 +368,32 @@ __global__ __launch_bounds__(64) void attn_decode_anc_kernel(const float* qkv, f
       for (int u = 0; u < 4; ++u) o += P[j + u] * vv[u];
     }
     for (; j < t; ++j) o += P[j] * vb[((long long)rowj[j] * H * Lmax + j) * DH];
-    out[(long long)r * D + h * DH + lane] = o / sum;
+    const int kk = h * DH + lane;
+    // opk: fragment-major output (vs_pack_rows_f32's layout), the x operand of vs_gemm_nt_f32_packed
+    if (opk) out[(((long long)(r >> 4) * (D >> 4) + (kk >> 4)) * 64 + ((kk & 15) >> 2) * 16 + (r & 15)) * 4 + (kk & 3)] = o / sum;
+    else out[(long long)r * D + kk] = o / sum;
   }
 }
 
 extern "C" int vs_attn_decode(const float* qkv, float* kcache, float* vcache, const uint8_t* key_mask,
                               const int32_t* ancestry, float* out, int rows, int H, int dh, int Lmax,
-                              int t, void* stream) {
+                              int t, int out_packed, void* stream) {
   VS_CHECK_ARG(qkv && kcache && vcache && out && rows > 0 && t >= 0 && t < Lmax, "bad args");
+  VS_CHECK_ARG(!out_packed || (dh == 16 || dh == 32 || dh == 64), "a packed output needs dh in {16, 32, 64}");
   const size_t smem = (size_t)(2 * (t + 1) + dh) * sizeof(float);
   VS_CHECK_ARG(smem <= 64 * 1024, "cache too long");
   const bool al = (((uintptr_t)qkv | (uintptr_t)kcache) & 15) == 0;
   if (dh == 64 && al)
     hipLaunchKernelGGL(attn_decode_anc_kernel<64>, dim3(rows * H), dim3(64), smem, (hipStream_t)stream,
-                       qkv, kcache, vcache, key_mask, ancestry, out, H, Lmax, t);
+                       qkv, kcache, vcache, key_mask, ancestry, out, H, Lmax, t, out_packed);
   else if (dh == 32 && al)
     hipLaunchKernelGGL(attn_decode_anc_kernel<32>, dim3(rows * H), dim3(64), smem, (hipStream_t)stream,
-                       qkv, kcache, vcache, key_mask, ancestry, out, H, Lmax, t);
+                       qkv, kcache, vcache, key_mask, ancestry, out, H, Lmax, t, out_packed);
   else if (dh == 16 && al)
     hipLaunchKernelGGL(attn_decode_anc_kernel<16>, dim3(rows * H), dim3(64), smem, (hipStream_t)stream,
-                       qkv, kcache, vcache, key_mask, ancestry, out, H, Lmax, t);
+                       qkv, kcache, vcache, key_mask, ancestry, out, H, Lmax, t, out_packed);
   else {
-    VS_CHECK_ARG(!ancestry, "ancestry tables need dh in {16, 32, 64}");
+    VS_CHECK_ARG(!ancestry && !out_packed, "ancestry tables / packed outputs need dh in {16, 32, 64}");
     hipLaunchKernelGGL(attn_decode_kernel, dim3(rows * H), dim3(64), smem, (hipStream_t)stream, qkv,
                        kcache, vcache, key_mask, out, H, dh, Lmax, t);
   }

@@ -307,10 +307,10 @@ __device__ __forceinline__ float lsk_f4e(const float4& v, int e) {
   return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w;
 }
 
-template <int RB, int CB, int CH, int NW>
+template <int RB, int CB, int CH, int NW, bool PK>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_skinny_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
-    const float* res, float* y, int M, int N, int K, int act, int tiles, int rgroups) {
+    const float* res, float* y, int M, int N, int K, int act, int tiles, int rgroups, int ypk) {
   extern __shared__ lsk_v4f lsk_red[];  // [NW waves][RB*CB tiles][64 lanes]
   // block id -> (column tile, row group): ids are dealt round-robin to the 8 XCDs, so the row groups
   // of one column tile get consecutive slots of the same XCD
@@ -321,17 +321,31 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_skinny_kernel
   const int n0 = tile * (16 * CB), m0 = rg * (16 * RB), col = lane & 15, kq = lane >> 4;
   const int kbase = wave * 16 + kq * 4;
   constexpr int GK = 16 * NW * CH;  // floats of K per group (all waves, one stage)
+  // PK: both operands in the fragment-major layout of vs_pack_rows_f32 (a 16-row x 16-float block =
+  // 1 KB in lane order): every fragment load is 64 lanes x 16 contiguous bytes instead of 16 rows x 64 B
+  // (which keeps the texture-address path busy 4x longer: 6.6 TB/s chip-wide was all it delivered)
+  constexpr int CSTR = PK ? 256 : 16;  // floats between consecutive 16-float chunks of one row block
   const float* wp[CB];
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) {
-    const int n = n0 + cb * 16 + col < N ? n0 + cb * 16 + col : N - 1;
-    wp[cb] = w + (long long)n * K + kbase;
+    if (PK) {
+      const int nt16 = (N + 15) >> 4;
+      const int t16 = n0 / 16 + cb < nt16 ? n0 / 16 + cb : nt16 - 1;
+      wp[cb] = w + ((long long)t16 * (K >> 4) + wave) * 256 + lane * 4;
+    } else {
+      const int n = n0 + cb * 16 + col < N ? n0 + cb * 16 + col : N - 1;
+      wp[cb] = w + (long long)n * K + kbase;
+    }
   }
   const float* xp[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
-    const int m = m0 + rb * 16 + col < M ? m0 + rb * 16 + col : M - 1;
-    xp[rb] = x + (long long)m * K + kbase;
+    if (PK) {
+      xp[rb] = x + ((long long)(m0 / 16 + rb) * (K >> 4) + wave) * 256 + lane * 4;
+    } else {
+      const int m = m0 + rb * 16 + col < M ? m0 + rb * 16 + col : M - 1;
+      xp[rb] = x + (long long)m * K + kbase;
+    }
   }
   lsk_v4f acc[RB][CB];
 #pragma unroll
@@ -341,13 +355,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_skinny_kernel
 
   const int groups = K / GK;
   auto load = [&](LskStage<RB, CB, CH>& st, int g) {
-    const int off = g * GK;
+    const int off = g * (NW * CH * CSTR);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) st.bw[cb][c] = *(const float4*)(wp[cb] + off + c * (16 * NW));
+      for (int cb = 0; cb < CB; ++cb) st.bw[cb][c] = *(const float4*)(wp[cb] + off + c * (NW * CSTR));
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) st.a[rb][c] = *(const float4*)(xp[rb] + off + c * (16 * NW));
+      for (int rb = 0; rb < RB; ++rb) st.a[rb][c] = *(const float4*)(xp[rb] + off + c * (NW * CSTR));
     }
   };
   auto compute = [&](const LskStage<RB, CB, CH>& st) {
@@ -400,46 +414,91 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void linear_skinny_kernel
         if (act == 1) sv = fmaxf(sv, 0.f);
         else if (act == 2) sv = 0.5f * sv * (1.0f + tanhf(0.7978845608028654f * (sv + 0.044715f * sv * sv * sv)));
         if (res) sv += res[(long long)m * N + n];
-        y[(long long)m * N + n] = sv;
+        if (ypk) y[(((long long)(m >> 4) * (N >> 4) + (n >> 4)) * 64 + ((n & 15) >> 2) * 16 + (m & 15)) * 4 + (n & 3)] = sv;
+        else y[(long long)m * N + n] = sv;
       }
     }
   }
 }
 
-template <int RB, int CB, int CH, int NW>
+template <int RB, int CB, int CH, int NW, bool PK>
 static void launch_skinny_cfg(const float* x, const float* w, const float* b, const float* res, float* y,
-                              int M, int N, int K, int act, hipStream_t st) {
+                              int M, int N, int K, int act, int ypk, hipStream_t st) {
   constexpr int smem = NW * RB * CB * 64 * 16;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)linear_skinny_kernel<RB, CB, CH, NW>,
+    (void)hipFuncSetAttribute((const void*)linear_skinny_kernel<RB, CB, CH, NW, PK>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr = true;
   }
   const int tiles = (N + 16 * CB - 1) / (16 * CB), tiles8 = (tiles + 7) & ~7;
   const int rgroups = (M + 16 * RB - 1) / (16 * RB);
-  hipLaunchKernelGGL((linear_skinny_kernel<RB, CB, CH, NW>), dim3(tiles8 * rgroups), dim3(64 * NW), smem, st, x,
-                     w, b, res, y, M, N, K, act, tiles, rgroups);
+  hipLaunchKernelGGL((linear_skinny_kernel<RB, CB, CH, NW, PK>), dim3(tiles8 * rgroups), dim3(64 * NW), smem, st,
+                     x, w, b, res, y, M, N, K, act, tiles, rgroups, ypk);
 }
 
+template <bool PK>
 static bool linear_skinny(const float* x, const float* w, const float* b, const float* res, float* y,
-                          int M, int N, int K, int act, hipStream_t st) {
-  if (M <= 16 || M > 64 || (K & 127) != 0) return false;
+                          int M, int N, int K, int act, int ypk, hipStream_t st) {
+  if ((!PK && M <= 16) || M > 64 || (K & 127) != 0) return false;
   if (((uintptr_t)x | (uintptr_t)w) & 15) return false;
   const int rbn = (M + 15) / 16;
   // the largest tile that still yields ~190 blocks; its K group (16 * NW * CH floats) must divide K
   if (N >= 190 * 64 || ((K & 511) != 0)) {
-    if (rbn == 2) launch_skinny_cfg<2, 4, 2, 4>(x, w, b, res, y, M, N, K, act, st);
-    else if (rbn == 3) launch_skinny_cfg<3, 4, 2, 4>(x, w, b, res, y, M, N, K, act, st);
-    else launch_skinny_cfg<4, 4, 2, 4>(x, w, b, res, y, M, N, K, act, st);
+    if (rbn == 1) launch_skinny_cfg<1, 4, 2, 4, PK>(x, w, b, res, y, M, N, K, act, ypk, st);
+    else if (rbn == 2) launch_skinny_cfg<2, 4, 2, 4, PK>(x, w, b, res, y, M, N, K, act, ypk, st);
+    else if (rbn == 3) launch_skinny_cfg<3, 4, 2, 4, PK>(x, w, b, res, y, M, N, K, act, ypk, st);
+    else launch_skinny_cfg<4, 4, 2, 4, PK>(x, w, b, res, y, M, N, K, act, ypk, st);
   } else if (N >= 190 * 16 || ((K & 1023) != 0)) {
-    if (rbn == 2) launch_skinny_cfg<2, 1, 4, 8>(x, w, b, res, y, M, N, K, act, st);
-    else if (rbn == 3) launch_skinny_cfg<3, 1, 4, 8>(x, w, b, res, y, M, N, K, act, st);
-    else launch_skinny_cfg<4, 1, 4, 8>(x, w, b, res, y, M, N, K, act, st);
+    if (rbn == 1) launch_skinny_cfg<1, 1, 4, 8, PK>(x, w, b, res, y, M, N, K, act, ypk, st);
+    else if (rbn == 2) launch_skinny_cfg<2, 1, 4, 8, PK>(x, w, b, res, y, M, N, K, act, ypk, st);
+    else if (rbn == 3) launch_skinny_cfg<3, 1, 4, 8, PK>(x, w, b, res, y, M, N, K, act, ypk, st);
+    else launch_skinny_cfg<4, 1, 4, 8, PK>(x, w, b, res, y, M, N, K, act, ypk, st);
   } else {
-    launch_skinny_cfg<1, 1, 4, 16>(x, w, b, res, y, M, N, K, act, st);
+    launch_skinny_cfg<1, 1, 4, 16, PK>(x, w, b, res, y, M, N, K, act, ypk, st);
   }
   return true;
+}
+
+// Fragment-major copy of a row-major matrix src[R][K] (K % 16 == 0): block (r / 16, k / 16) of 16 x 16
+// floats is 1 KB at index (r / 16) * (K / 16) + k / 16; inside, lane (k % 16 / 4) * 16 + r % 16 holds
+// the four floats k % 4 = 0..3 -- the v_mfma_f32_16x16x4_f32 operand order, so a fragment load is one
+// contiguous KB.  Rows up to the next multiple of 16 are zero-filled.
+__global__ void pack_rows_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int K) {
+  const long long blk = blockIdx.x;  // one 1-KB block per wave; 4 per workgroup
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int kc16 = K >> 4;
+  const long long id = blk * 4 + wave;
+  const long long nblk = (long long)((R + 15) >> 4) * kc16;
+  if (id >= nblk) return;
+  const int rblk = (int)(id / kc16), kc = (int)(id % kc16);
+  const int r = rblk * 16 + (lane & 15), k = kc * 16 + (lane >> 4) * 4;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r < R) v = *(const float4*)(src + (long long)r * K + k);
+  *(float4*)(dst + id * 256 + lane * 4) = v;
+}
+
+extern "C" int vs_pack_rows_f32(const float* src, float* dst, int R, int K, void* stream) {
+  VS_CHECK_ARG(src && dst && R > 0 && K > 0 && (K & 15) == 0, "K must be a multiple of 16");
+  VS_CHECK_ARG((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "16-byte aligned pointers");
+  const long long nblk = (long long)((R + 15) >> 4) * (K >> 4);
+  hipLaunchKernelGGL(pack_rows_f32_kernel, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     src, dst, R, K);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+extern "C" int vs_gemm_nt_f32_packed(const float* x_packed, const float* w_packed, const float* b,
+                                     const float* res, float* y, int M, int N, int K, int act,
+                                     int y_packed, void* stream) {
+  VS_CHECK_ARG(x_packed && w_packed && y && M > 0 && M <= 64 && N > 0 && K > 0, "1..64 rows");
+  VS_CHECK_ARG(act >= 0 && act <= 2, "act must be 0 (none), 1 (relu) or 2 (gelu_new)");
+  VS_CHECK_ARG((K & 127) == 0, "K must be a multiple of 128");
+  VS_CHECK_ARG(!y_packed || (N & 15) == 0, "a packed output needs N % 16 == 0");
+  VS_CHECK_ARG(linear_skinny<true>(x_packed, w_packed, b, res, y, M, N, K, act, y_packed, (hipStream_t)stream),
+               "unaligned operands");
+  VS_CHECK_LAUNCH();
+  return VS_OK;
 }
 
 static int linear_small_m(const float* x, const float* w, const float* b, const float* res, float* y,
@@ -504,7 +563,7 @@ extern "C" int vs_gemm_nt_f32(const float* x, const float* w, const float* b, co
                               float* y, int M, int N, int K, int act, void* stream) {
   VS_CHECK_ARG(x && w && y && M > 0 && N > 0 && K > 0, "bad args");
   VS_CHECK_ARG(act >= 0 && act <= 2, "act must be 0 (none), 1 (relu) or 2 (gelu_new)");
-  if (linear_skinny(x, w, b, res, y, M, N, K, act, (hipStream_t)stream)) {
+  if (linear_skinny<false>(x, w, b, res, y, M, N, K, act, 0, (hipStream_t)stream)) {
     VS_CHECK_LAUNCH();
     return VS_OK;
   }
@@ -797,7 +856,7 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* x, 
 // for 50 x 1024)
 __global__ __launch_bounds__(256) void add_layernorm_fwd_vec_kernel(
     const float* x, const float* r, const float* rmask, const float* gamma, const float* beta, float* y,
-    float* mean, float* rstd, int rows, int D, float eps) {
+    float* mean, float* rstd, int rows, int D, float eps, int ypk) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -843,7 +902,9 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_vec_kernel(
     }
   }
   const float rs = rsqrtf(wave_reduce_sum(q) / (float)D + eps);
-  float4* y4 = (float4*)(y + (long long)row * D);
+  // ypk: fragment-major output (vs_pack_rows_f32's layout) for vs_gemm_nt_f32_packed; D % 16 == 0
+  float4* y4 = ypk ? (float4*)y + ((long long)(row >> 4) * (D >> 4)) * 64 + (row & 15)
+                   : (float4*)(y + (long long)row * D);
 #pragma unroll
   for (int e = 0; e < NE; ++e) {
     const int d = lane + 64 * e;
@@ -853,7 +914,7 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_vec_kernel(
       o.y = (v[e].y - mu) * rs * g4[e].y + b4[e].y;
       o.z = (v[e].z - mu) * rs * g4[e].z + b4[e].z;
       o.w = (v[e].w - mu) * rs * g4[e].w + b4[e].w;
-      y4[d] = o;
+      y4[ypk ? (d >> 2) * 64 + (d & 3) * 16 : d] = o;
     }
   }
   if (lane == 0) {
@@ -871,10 +932,25 @@ extern "C" int vs_add_layernorm_fwd(const float* x, const float* r, const float*
                        (uintptr_t)rmask;
   if ((D & 3) == 0 && (al & 15) == 0)
     hipLaunchKernelGGL(add_layernorm_fwd_vec_kernel, dim3((rows + 3) / 4), dim3(256), 0,
-                       (hipStream_t)stream, x, r, rmask, gamma, beta, y, mean, rstd, rows, D, eps);
+                       (hipStream_t)stream, x, r, rmask, gamma, beta, y, mean, rstd, rows, D, eps, 0);
   else
     hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0,
                        (hipStream_t)stream, x, r, rmask, gamma, beta, y, mean, rstd, rows, D, eps);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+/* LayerNorm forward whose output is written fragment-major (vs_pack_rows_f32's layout, rows padded
+ * to 16 by the caller's allocation) -- the x operand of vs_gemm_nt_f32_packed. */
+extern "C" int vs_layernorm_fwd_packed(const float* x, const float* gamma, const float* beta,
+                                       float* y_packed, int rows, int D, float eps, void* stream) {
+  VS_CHECK_ARG(x && gamma && beta && y_packed && rows > 0, "bad args");
+  VS_CHECK_ARG(D >= 16 && D <= 64 * LN_MAXE && (D & 15) == 0, "D % 16 == 0, D <= 2048");
+  VS_CHECK_ARG((((uintptr_t)x | (uintptr_t)y_packed | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0,
+               "16-byte aligned pointers");
+  hipLaunchKernelGGL(add_layernorm_fwd_vec_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x,
+                     (const float*)nullptr, (const float*)nullptr, gamma, beta, y_packed, (float*)nullptr,
+                     (float*)nullptr, rows, D, eps, 1);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }

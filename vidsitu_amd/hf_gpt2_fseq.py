@@ -81,6 +81,7 @@ class GPT2LMHeadModelHip(nn.Module):
             self.register_parameter(k.replace(".", "__"), v)
         self._wt = {}  # K-contiguous ([out][in]) copies of the Conv1D weights for the kernels
         self._wt_epoch = 0  # bumped whenever the copies are dropped (captured decode graphs go stale)
+        self._wpk = {}  # fragment-major copies for the decode-step GEMMs (ops.gemm_nt_packed)
 
     # ---- huggingface-compatible state dict -------------------------------------------------
     def P(self, name):
@@ -128,7 +129,20 @@ class GPT2LMHeadModelHip(nn.Module):
 
     def _drop_wt(self):
         self._wt.clear()
+        self._wpk.clear()
         self._wt_epoch += 1
+
+    def _wp(self, name, transposed=True):
+        """Fragment-major copy of a weight ([out][in] orientation) for the 17..64-row decode GEMMs."""
+        t = self._wpk.get(name)
+        w = self.P(name)
+        if t is None or t.device != w.device:
+            if torch.cuda.is_current_stream_capturing():
+                raise ops._lib.VsError("GPT-2 weight copies must exist before a graph capture "
+                                       "(run one eager step first)")
+            t = ops.pack_rows_f32(self._w(name) if transposed else w.detach())
+            self._wpk[name] = t
+        return t
 
     def _w(self, name):
         """[out][in] view of a Conv1D weight (transposed once, after load / device move)."""
@@ -185,11 +199,36 @@ class GPT2LMHeadModelHip(nn.Module):
         t = state.len
         h = ops.gpt2_embed(last_tokens.view(rows, 1), self.P("transformer.wte.weight"),
                            self.P("transformer.wpe.weight"), pos0=t)
+        if 16 < rows <= 64 and self.d_model % 128 == 0 and (self.d_model // self.n_head) in (16, 32, 64):
+            return self._forward_step_packed(h, rows, state, key_mask, t)
         for i in range(self.n_layer):
             h = self._block(i, h, lambda li, qkv: ops.attn_decode(qkv, state.k[li][:rows], state.v[li][:rows],
                                                                   key_mask, t, ancestry=state.anc))
         state.len = t + 1
         return self._head(h)
+
+    def _forward_step_packed(self, h, rows, state, key_mask, t):
+        """The cached step for 17..64 rows (sentences x beams): every GEMM operand fragment-major --
+        weights packed once, activations written in that layout by their producers (layernorm,
+        attention, the gelu epilogue) -- so each MFMA fragment load is one contiguous KB."""
+        d, v = self.d_model, self.P("transformer.wte.weight").shape[0]
+        for i in range(self.n_layer):
+            q = f"transformer.h.{i}."
+            a = ops.layernorm_fwd_packed(h, self.P(q + "ln_1.weight"), self.P(q + "ln_1.bias"), 1e-5)
+            qkv = ops.gemm_nt_packed(a, self._wp(q + "attn.c_attn.weight"), rows, 3 * d, d,
+                                     b=self.P(q + "attn.c_attn.bias"))
+            o = ops.attn_decode(qkv, state.k[i][:rows], state.v[i][:rows], key_mask, t, ancestry=state.anc,
+                                out_packed=True)
+            h = ops.gemm_nt_packed(o, self._wp(q + "attn.c_proj.weight"), rows, d, d,
+                                   b=self.P(q + "attn.c_proj.bias"), res=h)
+            m = ops.layernorm_fwd_packed(h, self.P(q + "ln_2.weight"), self.P(q + "ln_2.bias"), 1e-5)
+            f = ops.gemm_nt_packed(m, self._wp(q + "mlp.c_fc.weight"), rows, 4 * d, d,
+                                   b=self.P(q + "mlp.c_fc.bias"), act=ops.ACT_GELU_NEW, y_packed=True)
+            h = ops.gemm_nt_packed(f, self._wp(q + "mlp.c_proj.weight"), rows, d, 4 * d,
+                                   b=self.P(q + "mlp.c_proj.bias"), res=h)
+        state.len = t + 1
+        hf = ops.layernorm_fwd_packed(h, self.P("transformer.ln_f.weight"), self.P("transformer.ln_f.bias"), 1e-5)
+        return ops.gemm_nt_packed(hf, self._wp("transformer.wte.weight", transposed=False), rows, v, d)
 
     # ---- training (teacher-forced pass with saved activations + manual backward) ------------
     def forward_train(self, tokens, attention_mask=None):

@@ -635,6 +635,49 @@ def gemm_nt(x, w, b=None, res=None, act=ACT_NONE, out=None):
     return y
 
 
+def _pad16(n):
+    return (n + 15) // 16 * 16
+
+
+def pack_rows_f32(src):
+    """Row-major f32 [R, K] (K % 16 == 0) -> fragment-major copy (flat, ceil16(R) * K floats) for
+    `gemm_nt_packed` (vs_pack_rows_f32: 16 x 16 blocks in v_mfma_f32_16x16x4_f32 operand order)."""
+    src = _f32c(src)
+    r, k = src.shape
+    dst = torch.empty(_pad16(r) * k, dtype=torch.float32, device=src.device)
+    _lib.call("vs_pack_rows_f32", _ptr(src), _ptr(dst), r, k, _stream())
+    return dst
+
+
+def unpack_rows_f32(packed, r, k):
+    """Inverse of pack_rows_f32 as torch ops (tests / debugging)."""
+    return packed.view(_pad16(r) // 16, k // 16, 4, 16, 4).permute(0, 3, 1, 2, 4).reshape(_pad16(r), k)[:r]
+
+
+def gemm_nt_packed(x_packed, w_packed, m, n, k, b=None, res=None, act=ACT_NONE, y_packed=False):
+    """act(x @ w^T + b) + res for 1..64 rows on fragment-major operands; the output is row-major
+    [m, n], or fragment-major (flat, ceil16(m) * n floats) when y_packed."""
+    if x_packed.numel() < _pad16(m) * k or w_packed.numel() < _pad16(n) * k:
+        raise _lib.VsError("gemm_nt_packed: packed operand too small for the given shape")
+    if y_packed:
+        y = torch.empty(_pad16(m) * n, dtype=torch.float32, device=x_packed.device)
+    else:
+        y = torch.empty((m, n), dtype=torch.float32, device=x_packed.device)
+    _lib.call("vs_gemm_nt_f32_packed", _ptr(x_packed), _ptr(w_packed), _ptr(b), _ptr(res), _ptr(y), int(m),
+              int(n), int(k), int(act), int(bool(y_packed)), _stream())
+    return y
+
+
+def layernorm_fwd_packed(x, gamma, beta, eps=1e-5):
+    """LayerNorm of f32 [rows, D] written fragment-major (flat, ceil16(rows) * D floats)."""
+    x = _f32c(x)
+    rows, d = x.shape
+    y = torch.empty(_pad16(rows) * d, dtype=torch.float32, device=x.device)
+    _lib.call("vs_layernorm_fwd_packed", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), rows, d, float(eps),
+              _stream())
+    return y
+
+
 def gpt2_embed(tokens, wte, wpe, pos0=0):
     """tokens i64 [R, L] -> f32 [R*L, D] = wte[tok] + wpe[pos0 + l]."""
     tokens = tokens.contiguous()
@@ -656,16 +699,20 @@ def attn_causal(qkv, key_mask, r, l, n_head):
     return out
 
 
-def attn_decode(qkv, kcache, vcache, key_mask, t, ancestry=None):
+def attn_decode(qkv, kcache, vcache, key_mask, t, ancestry=None, out_packed=False):
     """qkv f32 [rows, 3D]; caches f32 [rows, H, Lmax, dh] (updated in place at position t);
-    ancestry i32 [rows, Lmax] (optional): cache row that holds position j of row r."""
+    ancestry i32 [rows, Lmax] (optional): cache row that holds position j of row r;
+    out_packed: fragment-major output (flat, ceil16(rows) * D floats) for gemm_nt_packed."""
     rows, h, lmax, dh = kcache.shape
     if ancestry is not None and (ancestry.dtype != torch.int32 or tuple(ancestry.shape) != (rows, lmax)
                                  or not ancestry.is_contiguous()):
         raise _lib.VsError("attn_decode: ancestry must be a contiguous int32 [rows, Lmax] tensor")
-    out = torch.empty((rows, h * dh), dtype=torch.float32, device=qkv.device)
+    if out_packed:
+        out = torch.empty(_pad16(rows) * h * dh, dtype=torch.float32, device=qkv.device)
+    else:
+        out = torch.empty((rows, h * dh), dtype=torch.float32, device=qkv.device)
     _lib.call("vs_attn_decode", _ptr(qkv), _ptr(kcache), _ptr(vcache), _ptr(key_mask), _ptr(ancestry),
-              _ptr(out), rows, h, dh, lmax, int(t), _stream())
+              _ptr(out), rows, h, dh, lmax, int(t), int(bool(out_packed)), _stream())
     return out
 
 
