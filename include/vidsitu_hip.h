@@ -261,6 +261,23 @@ int vs_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
  * tiles straight from global memory; else 128x128 fp32 MFMA tiles through LDS. */
 int vs_gemm_nt_f32(const float* x, const float* w, const float* b, const float* res, float* y, int M,
                    int N, int K, int act, void* stream);
+/* Frame resize of the loader, `img.resize((224, 224))` in VsituDS.read_img
+ * (vidsitu_code/dat_loader.py:183-191) = Pillow's two-pass bicubic resampling of 8-bit RGB (Resample.c,
+ * pillow=7.2.0), bit for bit.  vs_resize_ksize / vs_resize_coeffs fill HOST tables for one axis
+ * (bounds[out][2] = first source index and count, kk[out][ksize] = 22-bit fixed-point weights, computed
+ * in double precision as Pillow does); the caller uploads them.  vs_resize_bicubic_u8: src u8
+ * [frames][H0][W0][3] -> dst u8 [frames][Ho][Wo][3]; y0, y1 = first / one-past-last source row the
+ * vertical pass reads (bounds_v[0][0] and bounds_v[Ho-1][0] + bounds_v[Ho-1][1]); tmp holds
+ * frames * (y1 - y0) * Wo * 3 bytes (vs_resize_tmp_bytes gives the H0-row upper bound); a pass whose
+ * size does not change is skipped, as in Pillow. */
+int vs_resize_ksize(int in_size, int out_size);
+int vs_resize_coeffs(int in_size, int out_size, int32_t* bounds_host, int32_t* kk_host);
+size_t vs_resize_tmp_bytes(int64_t frames, int H0, int Wo);
+int vs_resize_bicubic_u8(const uint8_t* src, uint8_t* dst, uint8_t* tmp, int64_t frames, int H0, int W0,
+                         int Ho, int Wo, const int32_t* bounds_h, const int32_t* kk_h, int ksize_h,
+                         const int32_t* bounds_v, const int32_t* kk_v, int ksize_v, int y0, int y1,
+                         void* stream);
+
 /* Decode-step (1..64 rows) GEMM on fragment-major operands.  vs_pack_rows_f32 copies a row-major
  * matrix src[R][K] (K % 16 == 0) into 1-KB blocks of 16 rows x 16 floats in v_mfma_f32_16x16x4_f32
  * operand order (block (r/16, k/16) at index (r/16)*(K/16) + k/16; lane (k%16/4)*16 + r%16 holds floats

@@ -88,6 +88,10 @@ SIGNATURES = {
     "vs_attn_causal_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "vs_attn_decode": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "vs_pack_rows_f32": (_i, [_p, _p, _i, _i, _p]),
+    "vs_resize_ksize": (_i, [_i, _i]),
+    "vs_resize_coeffs": (_i, [_i, _i, _p, _p]),
+    "vs_resize_tmp_bytes": (_sz, [_i64, _i, _i]),
+    "vs_resize_bicubic_u8": (_i, [_p, _p, _p, _i64, _i, _i, _i, _i, _p, _p, _i, _p, _p, _i, _i, _i, _p]),
     "vs_gemm_nt_f32_packed": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vs_layernorm_fwd_packed": (_i, [_p, _p, _p, _p, _i, _i, _f, _p]),
     "vs_beam_topk_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -116,6 +116,13 @@ def hip_cross_entropy(logits, labels):
     return _XentFn.apply(logits.float().contiguous(), labels)
 
 
+def _num_events(inp):
+    for key in ("frms_ev_raw_u8", "frms_ev_fast_u8", "frms_ev_fast_tensor"):
+        if key in inp:
+            return inp[key].shape[1]
+    raise KeyError("no frame tensor in the batch")
+
+
 class SFBase(nn.Module):
     def __init__(self, cfg, comm):
         super().__init__()
@@ -156,6 +163,11 @@ class SFBase(nn.Module):
         self.proj_head = HipMLP(nn.Linear(din, din // 2), nn.ReLU(), nn.Linear(din // 2, out_dim))
 
     def get_feats(self, inp):
+        if "frms_ev_raw_u8" in inp:
+            # decoded frames at their source size [B, E, T, H0, W0, 3]: the loader's
+            # `img.resize((224, 224))` (dat_loader.py:188, PIL bicubic) runs on the GPU, bit-exact
+            crop = int(self.sf_cfg.DATA.TRAIN_CROP_SIZE)
+            return [combine_first_ax(ops.resize_bicubic_u8(inp["frms_ev_raw_u8"], crop, crop))]
         if "frms_ev_fast_u8" in inp:
             # optional fast path beside the reference contract: the loader's uint8 RGB frames
             # [B, E, T, H, W, 3]; normalisation and the slow-pathway gather happen on the GPU
@@ -178,7 +190,7 @@ class SFBase(nn.Module):
         head_out = head_out.permute((0, 2, 3, 4, 1))  # (B, C, T, H, W) -> (B, T, H, W, C)
         proj_out = self.proj_head(head_out)
         B = len(inp["vseg_idx"])
-        n_ev = (inp["frms_ev_fast_u8"] if "frms_ev_fast_u8" in inp else inp["frms_ev_fast_tensor"]).shape[1]
+        n_ev = _num_events(inp)
         out = proj_out.view(B, n_ev, -1)
         assert out.size(-1) == len(self.comm.vb_id_vocab)
         return out
@@ -404,7 +416,7 @@ class SFBase_TxEnc(SFBase):
     def forward_decoder(self, enc_out, inp):
         head_out = self.head(enc_out)  # [N, C, 1, 1, 1]
         B = len(inp["vseg_idx"])
-        n_ev = (inp["frms_ev_fast_u8"] if "frms_ev_fast_u8" in inp else inp["frms_ev_fast_tensor"]).shape[1]
+        n_ev = _num_events(inp)
         feats = head_out.view(B, n_ev, -1)
         tok = self.vid_feat_encoder(feats)
         tx = self.vid_feat_txenc(src_tokens=tok[..., 0], src_lengths=None,

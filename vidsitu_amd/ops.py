@@ -635,6 +635,48 @@ def gemm_nt(x, w, b=None, res=None, act=ACT_NONE, out=None):
     return y
 
 
+_RESIZE_TABLES = {}
+
+
+def resize_tables(in_size, out_size, device):
+    """(bounds i32 [out, 2], kk i32 [out, ksize]) of one axis on `device`, plus the host bounds
+    (vs_resize_coeffs: Pillow's precompute_coeffs / normalize_coeffs_8bpc); cached per shape."""
+    key = (int(in_size), int(out_size), str(device))
+    t = _RESIZE_TABLES.get(key)
+    if t is None:
+        lib = _lib.load()
+        ksize = lib.vs_resize_ksize(int(in_size), int(out_size))
+        bounds = torch.zeros((out_size, 2), dtype=torch.int32)
+        kk = torch.zeros((out_size, ksize), dtype=torch.int32)
+        _lib.check(lib.vs_resize_coeffs(int(in_size), int(out_size), C.c_void_p(bounds.data_ptr()),
+                                        C.c_void_p(kk.data_ptr())), "vs_resize_coeffs")
+        t = (bounds.to(device), kk.to(device), bounds)
+        _RESIZE_TABLES[key] = t
+    return t
+
+
+def resize_bicubic_u8(frames, out_h=224, out_w=224):
+    """u8 [..., H0, W0, 3] -> u8 [..., out_h, out_w, 3]: PIL's `img.resize((out_w, out_h))` (bicubic) of
+    `VsituDS.read_img`, bit-exact, on the GPU."""
+    if frames.dtype != torch.uint8 or frames.shape[-1] != 3 or frames.dim() < 3:
+        raise _lib.VsError("resize_bicubic_u8 expects uint8 [..., H, W, 3]")
+    frames = frames.contiguous()
+    h0, w0 = frames.shape[-3], frames.shape[-2]
+    n = frames.numel() // (h0 * w0 * 3)
+    dev = frames.device
+    bh, kh, _ = resize_tables(w0, out_w, dev)
+    bv, kv, bv_host = resize_tables(h0, out_h, dev)
+    y0 = int(bv_host[0, 0])
+    y1 = int(bv_host[-1, 0] + bv_host[-1, 1])
+    dst = torch.empty(frames.shape[:-3] + (out_h, out_w, 3), dtype=torch.uint8, device=dev)
+    tmp = torch.empty(n * (y1 - y0) * out_w * 3, dtype=torch.uint8, device=dev) \
+        if (w0 != out_w and h0 != out_h) else None
+    _ptr(frames)
+    _lib.call("vs_resize_bicubic_u8", _ptr(frames), _ptr(dst), _ptr(tmp), n, h0, w0, out_h, out_w, _ptr(bh),
+              _ptr(kh), kh.shape[1], _ptr(bv), _ptr(kv), kv.shape[1], y0, y1, _stream())
+    return dst
+
+
 def _pad16(n):
     return (n + 15) // 16 * 16
 
