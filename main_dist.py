@@ -7,7 +7,10 @@ Kept: uid + dotted overrides, `num_gpus` from the visible devices, one process p
 `mp.spawn` with a localhost TCP rendezvous and backend `cfg.DIST_BACKEND` ("nccl" == RCCL on
 ROCm; `utils/trn_dist_utils.py:5-42`), `get_mdl_loss_eval` plugin lookup, Adam(betas=(0.9, 0.99))
 at `train.lr`, per-rank batch = `train.bs // num_gpus` (`utils/dat_utils.py:42-43`).
-Not kept: MLflow / progress bars / checkpoint rotation (`utils/trn_utils.py`, out of scope).
+`train.resume` / `train.resume_path` / `train.load_opt` / `train.strict_load` restore a checkpoint in the
+reference's file format before training and `misc.tmp_path/models/<uid>.pth` is written after it
+(`vidsitu_amd/checkpoint.py`; `utils/trn_utils.py:631-716`).
+Not kept: MLflow / progress bars / per-epoch checkpoint rotation (`utils/trn_utils.py`, out of scope).
 The loop never syncs with the host inside a step (the reference does twice: `trn_utils.py:600,610`).
 """
 import sys
@@ -17,7 +20,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from vidsitu_amd import synth_data
+from vidsitu_amd import checkpoint, synth_data
 from vidsitu_amd.extended_config import get_cfg
 from vidsitu_amd.mdl_selector import get_mdl_loss_eval
 from vidsitu_amd.optim import ArenaAdam, ParamArena
@@ -39,6 +42,14 @@ def main_fn(rank, cfg, steps):
     arena = ParamArena(mdl)
     arena.broadcast_params(0)
     opt = ArenaAdam(arena, lr=cfg.train.lr, betas=(0.9, 0.99))
+    num_it = 0
+    if cfg.train.resume:
+        got = checkpoint.load_model_dict(cfg.train.resume_path, mdl, opt, load_opt=cfg.train.load_opt,
+                                         strict=cfg.train.strict_load, arena=arena)
+        if got is not None:
+            num_it = got["num_it"] or 0
+            if rank == 0:
+                print(f"[{cfg.uid}] resumed {cfg.train.resume_path} at iteration {num_it}")
     bs = max(cfg.train.bs // world, 1)
     n_ev = cfg.ds.vsitu.num_ev
     batches = [synth_data.synth_batch(cfg, comm, bs, n_ev, seed=cfg.synth.seed + 17 * i + rank, device=dev)
@@ -58,6 +69,9 @@ def main_fn(rank, cfg, steps):
             ls = [round(float(x), 4) for x in losses]
             print(f"[{cfg.uid}] {steps} steps, {bs * n_ev * world * steps / (time.time() - t0):.1f} clips/s, "
                   f"loss {ls[0]} -> {ls[-1]}")
+            mfile = f"{cfg.misc.tmp_path}/models/{cfg.uid}.pth"
+            checkpoint.save_model_dict(mfile, mdl, opt, num_it=num_it + steps, cfg=None)
+            print(f"[{cfg.uid}] saved {mfile}")
     loss_d, acc_d = eval_fn(mdl, loss_fn, batches, "valid", rank)
     if rank == 0:
         print(f"[{cfg.uid}] valid {loss_d} {acc_d}")

@@ -259,6 +259,46 @@ class ArenaAdam:
     def zero_grad(self, fill=True):
         self.arena.zero_grad(fill)
 
+    # ---- torch.optim.Adam's checkpoint format (`utils/trn_utils.py:699-716` saves
+    #      `optimizer.state_dict()`; `:689-697` loads it): parameter i of `mdl.parameters()` order
+    #      -> {"step", "exp_avg", "exp_avg_sq"} in the parameter's logical shape -----------------
+    def state_dict(self):
+        a = self.arena
+        step = float(int(self.t.item()))
+        state = {}
+        for i, (p, off) in enumerate(zip(a.params, a.offsets)):
+            state[i] = {"step": torch.tensor(step),
+                        "exp_avg": _dense_view(self.m, off, p).detach().clone().contiguous(),
+                        "exp_avg_sq": _dense_view(self.v, off, p).detach().clone().contiguous()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0,
+                 "amsgrad": False, "params": list(range(len(a.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        a = self.arena
+        groups = sd["param_groups"]
+        order = [i for g in groups for i in g["params"]]
+        if len(order) != len(a.params):
+            raise ValueError(f"optimizer state has {len(order)} parameters, the model {len(a.params)}")
+        g0 = groups[0]
+        self.lr, self.betas, self.eps = g0["lr"], tuple(g0["betas"]), g0["eps"]
+        if any(g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) for g in groups):
+            raise ValueError("weight_decay / amsgrad are not implemented by the fused Adam kernel")
+        self.m.zero_()
+        self.v.zero_()
+        steps = set()
+        with torch.no_grad():
+            for key, p, off in zip(order, a.params, a.offsets):
+                st = sd["state"].get(key)
+                if st is None:  # a parameter that never received a gradient
+                    continue
+                _dense_view(self.m, off, p).copy_(st["exp_avg"].to(self.m.device))
+                _dense_view(self.v, off, p).copy_(st["exp_avg_sq"].to(self.v.device))
+                steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): one shared counter here")
+        self.t.fill_(steps.pop() if steps else 0)
+
     def step(self, world=1, defer_transposes=False):
         """defer_transposes: leave the dgrad weight images stale; the caller refreshes them with
         `arena.transposes_async()` at the start of the next step (bench.py)."""
