@@ -360,6 +360,17 @@ int vs_beam_step(const float* row_val, const int64_t* row_idx, const int64_t* to
                  int k, int V, int step, int max_len, int eos, int normalize, float len_penalty,
                  void* stream);
 
+/* fairseq TransformerDecoder (TxDecoderReal, vidsitu_code/mdl_sf_base.py:435-446) pieces beside the
+ * shared GEMM / attention / layernorm kernels: out[t] = scale * emb[tokens[t]] + pos_table[pos_idx[t]]
+ * (embed_scale * embed_tokens + sinusoidal positions; the caller's table has a zero row for padding);
+ * demb += scale * dx per non-padding token (nn.Embedding(padding_idx) backward; demb zero-filled by the
+ * caller); dx = y > 0 ? dy : 0 (relu FFN). */
+int vs_embed_pos_fwd(const int64_t* tokens, const float* emb, const float* pos_table, const int64_t* pos_idx,
+                     float* out, int64_t n_tok, int D, float scale, void* stream);
+int vs_embed_scatter_bwd(const int64_t* tokens, const float* dx, float* demb, int64_t n_tok, int D, float scale,
+                         int64_t pad, void* stream);
+int vs_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

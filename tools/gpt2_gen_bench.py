@@ -1,5 +1,7 @@
-"""Timing of GPT-2-medium beam-search generation through the plugin surface (BASELINE configs[4]
-shape on one GPU: B videos x 5 events, beam 5, up to 60 tokens).  Informational, not bench.py."""
+"""Timing of beam-search generation through the plugin surface (BASELINE configs[4] shape on one GPU:
+B videos x 5 events, beam 5, up to 60 tokens) with the GPT-2-medium decoder, or -- `DEC=txdec` in the
+environment -- the fairseq-style 3-layer TransformerDecoder (the reference's default `tx_dec_type`).
+Informational, not bench.py."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,7 +13,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 beam = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 max_len = int(sys.argv[3]) if len(sys.argv) > 3 else 60
 dev = torch.device("cuda:0")
-cfg = get_cfg({"task_type": "vb_arg", "mdl.mdl_name": "sfpret_txe_txd_vbarg", "mdl.tx_dec_type": "gpt2",
+cfg = get_cfg({"task_type": "vb_arg", "mdl.mdl_name": "sfpret_txe_txd_vbarg",
+               "mdl.tx_dec_type": os.environ.get("DEC", "gpt2"),
                "gen.beam_size": beam, "gen.max_len_b": max_len, "gen.min_len": max_len - 1})
 comm = synth_data.make_comm(cfg)
 sel = get_mdl_loss_eval(cfg)

@@ -88,6 +88,9 @@ SIGNATURES = {
     "vs_attn_causal_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "vs_attn_decode": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "vs_pack_rows_f32": (_i, [_p, _p, _i, _i, _p]),
+    "vs_embed_pos_fwd": (_i, [_p, _p, _p, _p, _p, _i64, _i, _f, _p]),
+    "vs_embed_scatter_bwd": (_i, [_p, _p, _p, _i64, _i, _f, _i64, _p]),
+    "vs_relu_bwd": (_i, [_p, _p, _p, _i64, _p]),
     "vs_resize_ksize": (_i, [_i, _i]),
     "vs_resize_coeffs": (_i, [_i, _i, _p, _p]),
     "vs_resize_tmp_bytes": (_sz, [_i64, _i, _i]),

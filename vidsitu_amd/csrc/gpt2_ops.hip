@@ -309,10 +309,10 @@ __global__ __launch_bounds__(64) void attn_decode_anc_kernel(const float* qkv, f
   float* P = sm;
   int* rowj = (int*)(sm + (t + 1));
   const float* src = qkv + (long long)r * 3 * D + h * DH;
-  if (lane < DH) {
-    const long long own = (((long long)r * H + h) * Lmax + t) * DH + lane;
-    kc[own] = src[D + lane];
-    vc[own] = src[2 * D + lane];
+  for (int dd = lane; dd < DH; dd += 64) {
+    const long long own = (((long long)r * H + h) * Lmax + t) * DH + dd;
+    kc[own] = src[D + dd];
+    vc[own] = src[2 * D + dd];
   }
   const int part = lane % PARTS, jj = lane / PARTS;
   float4 q4[4];
@@ -356,9 +356,9 @@ __global__ __launch_bounds__(64) void attn_decode_anc_kernel(const float* qkv, f
   }
   sum = wave_reduce_sum(sum);
   __syncthreads();
-  if (lane < DH) {
-    float o = P[t] * src[2 * D + lane];
-    const float* vb = vc + (long long)h * Lmax * DH + lane;
+  for (int dd = lane; dd < DH; dd += 64) {
+    float o = P[t] * src[2 * D + dd];
+    const float* vb = vc + (long long)h * Lmax * DH + dd;
     int j = 0;
     for (; j + 4 <= t; j += 4) {
       float vv[4];
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(64) void attn_decode_anc_kernel(const float* qkv, f
       for (int u = 0; u < 4; ++u) o += P[j + u] * vv[u];
     }
     for (; j < t; ++j) o += P[j] * vb[((long long)rowj[j] * H * Lmax + j) * DH];
-    const int kk = h * DH + lane;
+    const int kk = h * DH + dd;
     // opk: fragment-major output (vs_pack_rows_f32's layout), the x operand of vs_gemm_nt_f32_packed
     if (opk) out[(((long long)(r >> 4) * (D >> 4) + (kk >> 4)) * 64 + ((kk & 15) >> 2) * 16 + (r & 15)) * 4 + (kk & 3)] = o / sum;
     else out[(long long)r * D + kk] = o / sum;
@@ -379,7 +379,8 @@ extern "C" int vs_attn_decode(const float* qkv, float* kcache, float* vcache, co
                               const int32_t* ancestry, float* out, int rows, int H, int dh, int Lmax,
                               int t, int out_packed, void* stream) {
   VS_CHECK_ARG(qkv && kcache && vcache && out && rows > 0 && t >= 0 && t < Lmax, "bad args");
-  VS_CHECK_ARG(!out_packed || (dh == 16 || dh == 32 || dh == 64), "a packed output needs dh in {16, 32, 64}");
+  VS_CHECK_ARG(!out_packed || (dh == 16 || dh == 32 || dh == 64 || dh == 128),
+               "a packed output needs dh in {16, 32, 64, 128}");
   const size_t smem = (size_t)(2 * (t + 1) + dh) * sizeof(float);
   VS_CHECK_ARG(smem <= 64 * 1024, "cache too long");
   const bool al = (((uintptr_t)qkv | (uintptr_t)kcache) & 15) == 0;
@@ -392,8 +393,11 @@ extern "C" int vs_attn_decode(const float* qkv, float* kcache, float* vcache, co
   else if (dh == 16 && al)
     hipLaunchKernelGGL(attn_decode_anc_kernel<16>, dim3(rows * H), dim3(64), smem, (hipStream_t)stream,
                        qkv, kcache, vcache, key_mask, ancestry, out, H, Lmax, t, out_packed);
+  else if (dh == 128 && al)
+    hipLaunchKernelGGL(attn_decode_anc_kernel<128>, dim3(rows * H), dim3(64), smem, (hipStream_t)stream,
+                       qkv, kcache, vcache, key_mask, ancestry, out, H, Lmax, t, out_packed);
   else {
-    VS_CHECK_ARG(!ancestry && !out_packed, "ancestry tables / packed outputs need dh in {16, 32, 64}");
+    VS_CHECK_ARG(!ancestry && !out_packed, "ancestry tables / packed outputs need dh in {16, 32, 64, 128}");
     hipLaunchKernelGGL(attn_decode_kernel, dim3(rows * H), dim3(64), smem, (hipStream_t)stream, qkv,
                        kcache, vcache, key_mask, out, H, dh, Lmax, t);
   }
@@ -1253,6 +1257,67 @@ extern "C" int vs_beam_step(const float* row_val, const int64_t* row_idx, const 
   p.Lt = max_len + 2; p.Ls = max_len + 1; p.eos = eos; p.normalize = normalize;
   p.len_penalty = len_penalty;
   hipLaunchKernelGGL(beam_step_kernel, dim3(bsz), dim3(64), 0, (hipStream_t)stream, p);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+
+// =============================================================================================
+// fairseq TransformerDecoder pieces (TxDecoderReal, vidsitu_code/mdl_sf_base.py:435-446):
+// x = embed_scale * embed_tokens(tok) + positions (fairseq/models/transformer.py extract_features)
+// with the sinusoidal rows gathered from a small table through a per-token index (row 0 = zeros for
+// padding), the scatter of its gradient (padding row left at zero, nn.Embedding(padding_idx)), and
+// the relu gradient of the FFN.
+// =============================================================================================
+__global__ void embed_pos_fwd_kernel(const int64_t* tokens, const float* emb, const float* pos_table,
+                                     const int64_t* pos_idx, float* out, long long n_tok, int D, float scale) {
+  const long long t = blockIdx.x;
+  const float4* e = (const float4*)(emb + tokens[t] * D);
+  const float4* p = (const float4*)(pos_table + pos_idx[t] * D);
+  float4* o = (float4*)(out + t * D);
+  for (int i = threadIdx.x; i < D / 4; i += blockDim.x) {
+    const float4 a = e[i], b = p[i];
+    o[i] = make_float4(scale * a.x + b.x, scale * a.y + b.y, scale * a.z + b.z, scale * a.w + b.w);
+  }
+}
+
+extern "C" int vs_embed_pos_fwd(const int64_t* tokens, const float* emb, const float* pos_table,
+                                const int64_t* pos_idx, float* out, int64_t n_tok, int D, float scale,
+                                void* stream) {
+  VS_CHECK_ARG(tokens && emb && pos_table && pos_idx && out && n_tok > 0 && D > 0 && (D & 3) == 0, "bad args");
+  hipLaunchKernelGGL(embed_pos_fwd_kernel, dim3((unsigned)n_tok), dim3(256), 0, (hipStream_t)stream, tokens, emb,
+                     pos_table, pos_idx, out, (long long)n_tok, D, scale);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+__global__ void embed_scatter_bwd_kernel(const int64_t* tokens, const float* dx, float* demb, int D, float scale,
+                                         long long pad) {
+  const long long t = blockIdx.x;
+  const long long tok = tokens[t];
+  if (tok == pad) return;
+  for (int i = threadIdx.x; i < D; i += blockDim.x) atomicAdd(demb + tok * D + i, scale * dx[t * D + i]);
+}
+
+/* demb (zero-filled by the caller) += scale * dx for every non-padding token. */
+extern "C" int vs_embed_scatter_bwd(const int64_t* tokens, const float* dx, float* demb, int64_t n_tok, int D,
+                                    float scale, int64_t pad, void* stream) {
+  VS_CHECK_ARG(tokens && dx && demb && n_tok > 0 && D > 0, "bad args");
+  hipLaunchKernelGGL(embed_scatter_bwd_kernel, dim3((unsigned)n_tok), dim3(256), 0, (hipStream_t)stream, tokens,
+                     dx, demb, D, scale, (long long)pad);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+__global__ void relu_bwd_kernel(const float* dy, const float* y, float* dx, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+extern "C" int vs_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream) {
+  VS_CHECK_ARG(dy && y && dx && n > 0, "bad args");
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx,
+                     (long long)n);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }

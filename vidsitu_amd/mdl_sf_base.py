@@ -23,6 +23,7 @@ from . import ops
 from .trunk import VideoTrunk
 from .transformer_code import Transformer as TxCodeEnc, LinearFn
 from .hf_gpt2_fseq import HuggingFaceGPT2Decoder, lm_loss as gpt2_lm_loss
+from .fseq_txdec import TxDecoderReal
 
 EncoderOut = namedtuple(
     "EncoderOut",
@@ -275,14 +276,16 @@ def TxDecoder(full_cfg, comm):
     """mdl_sf_base.py:458-464."""
     if full_cfg.mdl.tx_dec_type == "gpt2":
         return GPT2_hf_fseqDec(full_cfg, comm)
-    # "txdec" = fairseq TransformerDecoder with cross-attention (SURVEY.md section 8f row f3)
-    raise NotImplementedError(f"tx_dec_type={full_cfg.mdl.tx_dec_type} is outside the hot path")
+    if full_cfg.mdl.tx_dec_type == "txdec":  # fairseq TransformerDecoder (SURVEY.md section 8f row f3)
+        return TxDecoderReal(full_cfg, comm)
+    raise NotImplementedError(f"tx_dec_type={full_cfg.mdl.tx_dec_type}")
 
 
 class Simple_TxDec(nn.Module):
     """mdl_sf_base.py:595-675: teacher-forced LM loss over the SRL token sequence of every event
-    (first annotation only) and beam-search generation from its first token.  Inference and the
-    loss forward run on the HIP kernels; the decoder's backward is not built (round >= 2)."""
+    (first annotation only) and beam-search generation from its first token; decoder = GPT-2
+    (`tx_dec_type: gpt2`) or the fairseq-style TransformerDecoder (`txdec`), forward and backward on
+    the HIP kernels."""
 
     def __init__(self, cfg, comm):
         super().__init__()
@@ -368,11 +371,7 @@ class SFPreFeats_TxEncDec(Simple_TxDec, Reorderer):
         super().__init__(cfg, comm)
 
     def build_model(self):
-        if self.full_cfg.mdl.tx_dec_type == "gpt2":
-            super().build_model()
-        else:  # encoder half only (the fairseq decoder is row f3)
-            self.decoder = None
-            self.pad_index = self.bos_index = None
+        super().build_model()
         head_dim = self._head_dim
         if head_dim is None:  # the reference derives it from the feature directory's name
             head_dim = get_head_dim(self.full_cfg)
@@ -392,12 +391,6 @@ class SFPreFeats_TxEncDec(Simple_TxDec, Reorderer):
         enc_out3 = enc_out_batch1.view(B * n_ev, 1, -1).transpose(0, 1).contiguous()
         return EncoderOut(encoder_out=enc_out3, encoder_padding_mask=None, encoder_embedding=None,
                           encoder_states=None, src_tokens=None, src_lengths=None)
-
-    def forward(self, inp):
-        if self.decoder is None:
-            raise NotImplementedError("fairseq TransformerDecoder: SURVEY.md section 8(f) f3")
-        return super().forward(inp)
-
 
 class SFBase_TxEnc(SFBase):
     """BASELINE config 3 ("SlowFast-R50 + 6-layer TxEnc verb-pred"), a composition the

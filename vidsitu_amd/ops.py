@@ -866,3 +866,27 @@ def beam_step(row_val, row_idx, tok_in, tok_out, sc_in, sc_out, ignore, finished
               int(anc_ld), int(bsz), int(beam), int(k),
               int(vocab), int(step), int(max_len), int(eos), int(bool(normalize)), float(len_penalty),
               _stream())
+
+
+# ---- fairseq TransformerDecoder pieces ---------------------------------------------------------
+def embed_pos_fwd(tokens, emb, pos_table, pos_idx, scale):
+    """scale * emb[tokens] + pos_table[pos_idx] -> f32 [tokens.numel(), D]."""
+    tokens, pos_idx = tokens.contiguous(), pos_idx.contiguous()
+    out = torch.empty((tokens.numel(), emb.shape[1]), dtype=torch.float32, device=emb.device)
+    _lib.call("vs_embed_pos_fwd", _ptr(tokens), _ptr(emb), _ptr(pos_table), _ptr(pos_idx), _ptr(out),
+              tokens.numel(), emb.shape[1], float(scale), _stream())
+    return out
+
+
+def embed_scatter_bwd(tokens, dx, demb, scale, pad):
+    """demb (zero-filled) += scale * dx per non-padding token."""
+    tokens = tokens.contiguous()
+    _lib.call("vs_embed_scatter_bwd", _ptr(tokens), _ptr(_f32c(dx)), _ptr(demb), tokens.numel(), demb.shape[1],
+              float(scale), int(pad), _stream())
+
+
+def relu_bwd(dy, y):
+    dy, y = _f32c(dy), _f32c(y)
+    dx = torch.empty_like(dy)
+    _lib.call("vs_relu_bwd", _ptr(dy), _ptr(y), _ptr(dx), dy.numel(), _stream())
+    return dx

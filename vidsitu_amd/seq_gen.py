@@ -153,6 +153,9 @@ class _DeviceSearchSession:
                                                          getattr(dec, "uses_encoder_out", True) is False)
         self.enc = encoder_outs
         self._reset(prefix_tokens, bos_token)
+        if self.state is not None and hasattr(dec, "begin_incremental"):
+            # per-generation constants (encoder attention) into the state's static buffers, eagerly
+            dec.begin_incremental(self.state, encoder_outs[0] if encoder_outs else None, self.rows, self.Lt)
         for step in range(self.max_len + 1):
             if graphs:
                 g = self.graphs.get(step)
