@@ -322,6 +322,15 @@ def test_pack_input_layout(dev):
     assert float(y[:, 3:].float().abs().max()) == 0.0
     y2 = ops.pack_input(x.to(dev).to(torch.bfloat16))
     assert torch.equal(y2.float(), y.float())
+    # stem layout (4 channels per pixel): the 8-pixels-per-thread kernel (T*H*W % 8 == 0) and the
+    # one-pixel fallback, fp32 and bf16 inputs
+    for shape in [(2, 3, 4, 6, 12), (1, 3, 3, 5, 7), (3, 2, 2, 8, 8)]:
+        xs = torch.randn(*shape)
+        for inp in (xs.to(dev), xs.to(dev).to(torch.bfloat16)):
+            y4 = ops.pack_input(inp, 4)
+            assert tuple(y4.shape) == (shape[0], 4) + shape[2:]
+            assert torch.equal(y4[:, :shape[1]].float().cpu(), rb(xs)), shape
+            assert float(y4[:, shape[1]:].float().abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("cout,kt,t,h,w", [(64, 1, 2, 32, 32), (8, 5, 6, 32, 32), (64, 1, 1, 36, 44),

@@ -39,11 +39,55 @@ __global__ void pack_input_kernel(const void* xin, uint16_t* y, int N, int C, lo
   }
 }
 
+// Stem layout (Cpad = 4), 8 consecutive pixels per thread: one 16-byte (bf16) or two 16-byte (f32) loads
+// per channel plane and four 16-byte stores -- the one-pixel form moved 2 bytes per lane and load
+// (0.84 TB/s on the 32 x 224 x 224 fast-pathway input).
+template <bool IN_BF16>
+__global__ void pack_input_c4x8_kernel(const void* xin, uint16_t* y, int N, int C, long long THW8) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // n * THW8 + s8
+  if (i >= (long long)N * THW8) return;
+  const long long n = i / THW8, s8 = i - n * THW8;
+  float v[3][8];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    if (c < C) {
+      const long long off = ((n * C + c) * THW8 + s8) * 8;
+      if (IN_BF16) {
+        unpack8_bf16(*(const uint4*)((const uint16_t*)xin + off), v[c]);
+      } else {
+        const float4 a = *(const float4*)((const float*)xin + off), b = *(const float4*)((const float*)xin + off + 4);
+        v[c][0] = a.x; v[c][1] = a.y; v[c][2] = a.z; v[c][3] = a.w;
+        v[c][4] = b.x; v[c][5] = b.y; v[c][6] = b.z; v[c][7] = b.w;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+    }
+  }
+  uint4* o = (uint4*)(y + i * 32);
+#pragma unroll
+  for (int e = 0; e < 8; e += 2)
+    o[e >> 1] = make_uint4(pack2_bf16(v[0][e], v[1][e]), pack2_bf16(v[2][e], 0.f),
+                           pack2_bf16(v[0][e + 1], v[1][e + 1]), pack2_bf16(v[2][e + 1], 0.f));
+}
+
 extern "C" int vs_pack_input(const void* x, int x_is_bf16, void* y, int N, int C, int T, int H,
                              int W, int Cpad, void* stream) {
   VS_CHECK_ARG(x && y, "null tensor");
   VS_CHECK_ARG((Cpad % 8 == 0 || Cpad == 4) && Cpad >= C, "Cpad must be 4 or a multiple of 8, >= C");
   const long long THW = (long long)T * H * W, total = THW * N;
+  if (Cpad == 4 && C <= 3 && (THW & 7) == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+    const long long t8 = total / 8;
+    const dim3 g8((unsigned)((t8 + 255) / 256));
+    if (x_is_bf16)
+      hipLaunchKernelGGL(pack_input_c4x8_kernel<true>, g8, dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)y, N,
+                         C, THW / 8);
+    else
+      hipLaunchKernelGGL(pack_input_c4x8_kernel<false>, g8, dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)y,
+                         N, C, THW / 8);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+  }
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   if (x_is_bf16)
     hipLaunchKernelGGL(pack_input_kernel<true>, grid, block, 0, (hipStream_t)stream, x,
