@@ -126,6 +126,11 @@ int vs_weight_transpose_batched(const void* src, void* dst, const int64_t* table
  * {element offset (same in src and dst), N, 1, K, first flat index}). */
 int vs_transpose_f32_batched(const float* src, float* dst, const int64_t* table, int n, int64_t total,
                              void* stream);
+/* The same two transposes, tiled through LDS (reads contiguous along Cin, writes along Cout): table as
+ * above; tile_first[i] = first tile of entry i, tiles(i) = taps * ceil(Cout/TS) * ceil(Cin/TS) with
+ * TS = 64 for 2-byte (bf16 conv weights) and 32 for 4-byte (fp32 linear weights) elements. */
+int vs_weight_transpose_tiled(const void* src, void* dst, const int64_t* table, const int64_t* tile_first,
+                              int n, int64_t total_tiles, int elem_bytes, void* stream);
 
 /* Weight gradient: dw[Cout][taps][Cin] fp32 = sum_p dy[p][co] * x[p@tap][ci].
  * workspace: vs_conv_wgrad_workspace_bytes(desc) bytes of fp32 split-K slabs. */

@@ -375,3 +375,31 @@ def test_stem_wgrad_matches_autograd(cout, kt, t, h, w, dev):
     assert_close(dw, dw_ref, 5e-3, "stem wgrad")
     dw2 = ops.stem_conv_wgrad(to_act(dy, dev), ops.pack_input(x.to(dev), 4), kt)
     assert torch.equal(dw.contiguous(), dw2.contiguous())  # fixed-order slab reduce
+
+
+def test_tiled_batched_transposes_equal_the_per_element_kernels(dev):
+    """`vs_weight_transpose_tiled` (LDS tiles, one launch for all weights) against the per-element batched
+    kernels: conv weights [Cout][taps][Cin] bf16 and linear weights [N][K] fp32, ragged shapes."""
+    from vidsitu_amd import ops
+
+    g = torch.Generator().manual_seed(0)
+    for dtype, shapes in ((torch.bfloat16, [(64, 27, 8), (8, 35, 3), (256, 1, 64), (80, 9, 72), (512, 3, 128), (33, 5, 17)]),
+                          (torch.float32, [(1024, 1, 2304), (1564, 1, 1152), (100, 1, 33), (64, 1, 64), (7, 1, 300)])):
+        rows, off, first = [], 0, 0
+        for cout, taps, cin in shapes:
+            n = cout * taps * cin
+            rows.append([off, cout, taps, cin, first])
+            off += (n + 3) // 4 * 4
+            first += n
+        table = torch.tensor(rows, dtype=torch.int64, device=dev)
+        src = torch.randn(off, generator=g).to(dtype).to(dev)
+        a, b = torch.zeros_like(src), torch.zeros_like(src)
+        fn = ops.weight_transpose_batched if dtype == torch.bfloat16 else ops.transpose_f32_batched
+        fn(src, a, table, first, tiled=False)
+        fn(src, b, table, first, tiled=True)
+        assert torch.equal(a.view(torch.int16 if dtype == torch.bfloat16 else torch.int32),
+                           b.view(torch.int16 if dtype == torch.bfloat16 else torch.int32))
+        for (o, cout, taps, cin, _) in rows:  # and against torch
+            n = cout * taps * cin
+            want = src[o:o + n].view(cout, taps, cin).permute(2, 1, 0).contiguous().view(-1)
+            assert torch.equal(b[o:o + n], want)

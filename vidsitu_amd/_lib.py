@@ -50,6 +50,7 @@ SIGNATURES = {
     "vs_weight_transpose": (_i, [_p, _p, _i, _i, _i, _p]),
     "vs_weight_transpose_batched": (_i, [_p, _p, _p, _i, _i64, _p]),
     "vs_transpose_f32_batched": (_i, [_p, _p, _p, _i, _i64, _p]),
+    "vs_weight_transpose_tiled": (_i, [_p, _p, _p, _p, _i, _i64, _i, _p]),
     "vs_conv_wgrad_workspace_bytes": (_sz, [_dp]),
     "vs_conv_wgrad": (_i, [_p, _p, _p, _dp, _p, _sz, _p]),
     "vs_bn_finalize": (_i, [_p, _i, _d, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i, _p]),

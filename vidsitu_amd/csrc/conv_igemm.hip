@@ -1432,3 +1432,62 @@ extern "C" int vs_transpose_f32_batched(const float* src, float* dst, const int6
   VS_CHECK_LAUNCH();
   return VS_OK;
 }
+
+
+// Tiled form of the two batched transposes (the per-element kernel above reads with a stride of
+// taps*Cin elements per lane: 0.5 TB/s on the bf16 conv weights, 1.4 TB/s on the fp32 linears): a block
+// moves one TS x TS tile of one (entry, tap) through LDS -- reads contiguous along Cin, writes contiguous
+// along Cout -- and finds its entry by ONE binary search over tile_first[] (first tile of every entry).
+template <typename T, int TS>
+__global__ __launch_bounds__(256) void weight_transpose_tiled_kernel(const T* __restrict__ src, T* __restrict__ dst,
+                                                                     const long long* __restrict__ table,
+                                                                     const long long* __restrict__ tile_first,
+                                                                     int n) {
+  __shared__ T tile[TS][TS + (sizeof(T) == 2 ? 2 : 1)];
+  const long long b = blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tile_first[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  const long long off = table[lo * 5 + 0];
+  const int Cout = (int)table[lo * 5 + 1], taps = (int)table[lo * 5 + 2], Cin = (int)table[lo * 5 + 3];
+  const int tco = (Cout + TS - 1) / TS, tci = (Cin + TS - 1) / TS;
+  long long t = b - tile_first[lo];
+  const int ic = (int)(t % tci);
+  t /= tci;
+  const int oc = (int)(t % tco);
+  const int tap = (int)(t / tco);
+  constexpr int RY = 256 / TS;  // thread rows per pass
+  const int tx = threadIdx.x % TS, ty = threadIdx.x / TS;
+#pragma unroll
+  for (int r = 0; r < TS; r += RY) {
+    const int co = oc * TS + ty + r, ci = ic * TS + tx;
+    if (co < Cout && ci < Cin) tile[ty + r][tx] = src[off + ((long long)co * taps + tap) * Cin + ci];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < TS; r += RY) {
+    const int ci = ic * TS + ty + r, co = oc * TS + tx;
+    if (ci < Cin && co < Cout) dst[off + ((long long)ci * taps + tap) * Cout + co] = tile[tx][ty + r];
+  }
+}
+
+/* Tiled batched transpose: table as vs_weight_transpose_batched; tile_first[i] = first tile of entry i
+ * with tiles(i) = taps * ceil(Cout / TS) * ceil(Cin / TS), TS = 64 for 2-byte and 32 for 4-byte elements. */
+extern "C" int vs_weight_transpose_tiled(const void* src, void* dst, const int64_t* table,
+                                         const int64_t* tile_first, int n, int64_t total_tiles, int elem_bytes,
+                                         void* stream) {
+  VS_CHECK_ARG(src && dst && table && tile_first && n > 0 && total_tiles > 0, "bad args");
+  VS_CHECK_ARG(elem_bytes == 2 || elem_bytes == 4, "2- or 4-byte elements");
+  if (elem_bytes == 2)
+    hipLaunchKernelGGL((weight_transpose_tiled_kernel<uint16_t, 64>), dim3((unsigned)total_tiles), dim3(256), 0,
+                       (hipStream_t)stream, (const uint16_t*)src, (uint16_t*)dst, (const long long*)table,
+                       (const long long*)tile_first, n);
+  else
+    hipLaunchKernelGGL((weight_transpose_tiled_kernel<float, 32>), dim3((unsigned)total_tiles), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)src, (float*)dst, (const long long*)table,
+                       (const long long*)tile_first, n);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}

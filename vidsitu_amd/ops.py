@@ -248,14 +248,44 @@ def weight_transpose(w, out=None):
     return wt
 
 
-def weight_transpose_batched(src_arena, dst_arena, table, total):
-    _lib.call("vs_weight_transpose_batched", _ptr(src_arena), _ptr(dst_arena), _ptr(table),
-              table.shape[0], int(total), _stream())
+_TILE_TABLES = {}
 
 
-def transpose_f32_batched(src, dst, table, total):
-    _lib.call("vs_transpose_f32_batched", _ptr(src), _ptr(dst), _ptr(table), table.shape[0], int(total),
-              _stream())
+def _tile_table(table, ts):
+    """(tile_first i64 [n] on the table's device, total tiles) of a batched-transpose table; cached."""
+    key = (table.data_ptr(), ts)
+    t = _TILE_TABLES.get(key)
+    if t is None:
+        rows = table.cpu().tolist()
+        first, acc = [], 0
+        for _, cout, taps, cin, _ in rows:
+            first.append(acc)
+            acc += taps * ((cout + ts - 1) // ts) * ((cin + ts - 1) // ts)
+        t = (torch.tensor(first, dtype=torch.int64, device=table.device), acc, table)  # (keeps table alive)
+        _TILE_TABLES[key] = t
+    return t[0], t[1]
+
+
+def weight_transpose_batched(src_arena, dst_arena, table, total, tiled=True):
+    """All dgrad weight images [Cout][taps][Cin] -> [Cin][taps][Cout] (bf16) in one launch."""
+    if not tiled:
+        _lib.call("vs_weight_transpose_batched", _ptr(src_arena), _ptr(dst_arena), _ptr(table),
+                  table.shape[0], int(total), _stream())
+        return
+    first, ntiles = _tile_table(table, 64)
+    _lib.call("vs_weight_transpose_tiled", _ptr(src_arena), _ptr(dst_arena), _ptr(table), _ptr(first),
+              table.shape[0], int(ntiles), 2, _stream())
+
+
+def transpose_f32_batched(src, dst, table, total, tiled=True):
+    """All fp32 linear weights [N][K] -> [K][N] in one launch."""
+    if not tiled:
+        _lib.call("vs_transpose_f32_batched", _ptr(src), _ptr(dst), _ptr(table), table.shape[0], int(total),
+                  _stream())
+        return
+    first, ntiles = _tile_table(table, 32)
+    _lib.call("vs_weight_transpose_tiled", _ptr(src), _ptr(dst), _ptr(table), _ptr(first), table.shape[0],
+              int(ntiles), 4, _stream())
 
 
 def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=None, ring=0,
