@@ -1011,9 +1011,23 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const uint16_t* x, flo
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
   if (cb < cpr) {
-    for (long long r = rl; r < rows; r += 8) {
+    const uint16_t* base = x + n * rows * x_ld + cb * 8;
+    long long r = rl;
+    for (; r + 24 < rows; r += 32) {  // four rows of loads in flight (same summation order)
+      uint4 q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) q[u] = *(const uint4*)(base + (r + 8 * u) * x_ld);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float v[8];
+        unpack8_bf16(q[u], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+      }
+    }
+    for (; r < rows; r += 8) {
       float v[8];
-      unpack8_bf16(*(const uint4*)(x + (n * rows + r) * x_ld + cb * 8), v);
+      unpack8_bf16(*(const uint4*)(base + r * x_ld), v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += v[e];
     }
