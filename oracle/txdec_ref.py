@@ -130,3 +130,54 @@ def lm_loss(logits, tokens, pad):
     """Simple_TxDec.forward (mdl_sf_base.py:653-667): CE(logits[:, :-1], tokens[:, 1:]), ignore pad."""
     v = logits.shape[-1]
     return F.cross_entropy(logits[:, :-1].reshape(-1, v), tokens[:, 1:].reshape(-1), ignore_index=pad)
+
+
+# ---- fairseq TransformerEncoder as TxEncoderOld calls it (mdl_sf_base.py:246-338): the video features are
+#      the token embeddings, `src_tokens` (their first feature channel, a float tensor) only feeds the
+#      position / padding rules; post-norm layers without a final norm ----------------------------------
+def encoder_param_names(n_layer):
+    names = []
+    for i in range(n_layer):
+        q = f"layers.{i}."
+        for pr in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            names += [q + f"self_attn.{pr}.weight", q + f"self_attn.{pr}.bias"]
+        names += [q + "self_attn_layer_norm.weight", q + "self_attn_layer_norm.bias", q + "fc1.weight",
+                  q + "fc1.bias", q + "fc2.weight", q + "fc2.bias", q + "final_layer_norm.weight",
+                  q + "final_layer_norm.bias"]
+    return names
+
+
+def make_encoder_weights(d, ffn, n_layer, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    w = {}
+    for n in encoder_param_names(n_layer):
+        if n.endswith("layer_norm.weight"):
+            t = 1.0 + 0.1 * torch.randn(d, generator=g)
+        elif n.endswith(".bias"):
+            t = 0.05 * torch.randn(ffn if n.endswith("fc1.bias") else d, generator=g)
+        elif n.endswith("fc1.weight"):
+            t = torch.randn(ffn, d, generator=g) * d ** -0.5
+        elif n.endswith("fc2.weight"):
+            t = torch.randn(d, ffn, generator=g) * ffn ** -0.5
+        else:
+            t = torch.randn(d, d, generator=g) * d ** -0.5
+        w[n] = t
+    return w
+
+
+def encoder_forward(w, token_embeddings, src_tokens, pad, n_head, n_layer):
+    """token_embeddings f32 [B, L, D], src_tokens [B, L] -> encoder_out [L, B, D] (eval mode)."""
+    d = token_embeddings.shape[-1]
+    pos = make_positions(src_tokens, pad)
+    pe = sinusoidal_rows(pos, d) * pos.ne(pad).unsqueeze(-1)
+    x = math.sqrt(d) * token_embeddings + pe
+    pad_mask = src_tokens.eq(pad)
+    kpm = pad_mask if bool(pad_mask.any()) else None
+    for i in range(n_layer):
+        q = f"layers.{i}."
+        x = F.layer_norm(x + _mha(x, x, w, q + "self_attn.", n_head, None, kpm), (d,),
+                         w[q + "self_attn_layer_norm.weight"], w[q + "self_attn_layer_norm.bias"])
+        f = F.linear(F.relu(F.linear(x, w[q + "fc1.weight"], w[q + "fc1.bias"])), w[q + "fc2.weight"],
+                     w[q + "fc2.bias"])
+        x = F.layer_norm(x + f, (d,), w[q + "final_layer_norm.weight"], w[q + "final_layer_norm.bias"])
+    return x.transpose(0, 1)

@@ -211,3 +211,76 @@ def test_txdec_plugin_surface_trains(dev):
     mdl.eval()
     out = sel["evl"](cfg, comm, dev).forward_one_batch(mdl, batch)
     assert len(out) == 2 and all(len(r["vb_output"]) == 3 for r in out)
+
+
+def test_fseq_encoder_matches_oracle_forward_and_backward(dev):
+    """`TxEncoderOld` (fairseq TransformerEncoder over the per-event video features, `tx_enc_type: old`)."""
+    from types import SimpleNamespace
+    from vidsitu_amd.fseq_txdec import TxEncoderOld
+
+    d, ffn, heads, nl, pad = 128, 256, 8, 2, 96
+    tok = SimpleNamespace(pad_token_id=pad, __len__=lambda: 97)
+
+    class _T:
+        pad_token_id = pad
+
+        def __len__(self):
+            return 97
+
+    cfg = SimpleNamespace(tx_dec=SimpleNamespace(encoder_embed_dim=d, encoder_ffn_embed_dim=ffn,
+                                                 encoder_attention_heads=heads, encoder_layers=nl, dropout=0.0))
+    enc = TxEncoderOld(cfg, SimpleNamespace(gpt2_hf_tok=_T()))
+    w = txdec_ref.make_encoder_weights(d, ffn, nl, seed=11)
+    missing, unexpected = enc.load_state_dict(w, strict=False)
+    assert not unexpected and missing == ["embed_tokens.weight"]
+    enc = enc.to(dev).train()
+    emb = torch.randn(3, 5, d, generator=torch.Generator().manual_seed(2))
+    # oracle with autograd
+    wg = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    emb_ref = emb.clone().requires_grad_(True)
+    out_ref = txdec_ref.encoder_forward(wg, emb_ref, emb_ref[..., 0].detach(), pad, heads, nl)
+    g_out = torch.randn(out_ref.shape, generator=torch.Generator().manual_seed(3))
+    (out_ref * g_out).sum().backward()
+    # HIP
+    emb_d = emb.to(dev).requires_grad_(True)
+    out = enc(src_tokens=emb_d[..., 0].detach(), token_embeddings=emb_d, return_all_hiddens=True)
+    assert tuple(out.encoder_out.shape) == (5, 3, d) and len(out.encoder_states) == nl
+    err = float((out.encoder_out.detach().cpu() - out_ref.detach()).abs().max()) / float(out_ref.abs().max())
+    assert err < 2e-4, err
+    (out.encoder_out * g_out.to(dev)).sum().backward()
+    sd = dict(enc.named_parameters())
+    floor = 1e-3 * max(float(v.grad.abs().max()) for v in wg.values())
+    for name, ref in wg.items():
+        g = sd[name].grad.cpu()
+        e = float((g - ref.grad).abs().max()) / max(float(ref.grad.abs().max()), floor)
+        assert e < 5e-4, (name, e)
+    e = float((emb_d.grad.cpu() - emb_ref.grad).abs().max()) / float(emb_ref.grad.abs().max())
+    assert e < 5e-4, e
+
+
+def test_old_encoder_plus_txdec_plugin_surface_trains(dev):
+    """The paper's SF+TxE+TxD row with both fairseq-style halves: `tx_enc_type: old`, `tx_dec_type: txdec`."""
+    from vidsitu_amd import synth_data
+    from vidsitu_amd.extended_config import get_cfg
+    from vidsitu_amd.mdl_selector import get_mdl_loss_eval
+    from vidsitu_amd.optim import ArenaAdam, ParamArena
+
+    cfg = get_cfg({"task_type": "vb_arg", "mdl.mdl_name": "sfpret_txe_txd_vbarg", "mdl.tx_dec_type": "txdec",
+                   "mdl.tx_enc_type": "old", "tx_dec.decoder_layers": 1, "tx_dec.encoder_layers": 2,
+                   "synth.gpt2_vocab": 211})
+    comm = synth_data.make_comm(cfg)
+    sel = get_mdl_loss_eval(cfg)
+    torch.manual_seed(0)
+    mdl = sel["mdl"](cfg=cfg, comm=comm).to(dev).train()
+    batch = synth_data.synth_srl_batch(comm, bs=2, n_ev=5, seq_len=10, device=dev)
+    arena = ParamArena(mdl, adopt_conv=False)
+    opt = ArenaAdam(arena, lr=3e-4)
+    loss_fn = sel["loss"](cfg, comm)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        loss = loss_fn(mdl(batch), batch)["loss"]
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0] - 0.2, losses

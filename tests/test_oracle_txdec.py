@@ -53,3 +53,30 @@ def test_layers_equal_torch_nn_transformer_decoder_layer():
     want = (x @ w["project_out_dim.weight"].t()) @ w["output_projection.weight"].t()
     valid = toks.ne(pad)
     assert float((logits - want)[valid].abs().max()) < 2e-4 * float(want.abs().max())
+
+
+def test_encoder_layers_equal_torch_nn_transformer_encoder_layer():
+    torch.manual_seed(1)
+    d, ffn, n_layer, heads, pad = 32, 48, 2, 4, 9
+    w = txdec_ref.make_encoder_weights(d, ffn, n_layer, seed=4)
+    emb = torch.randn(3, 5, d)
+    src = emb[..., 0]
+    out = txdec_ref.encoder_forward(w, emb, src, pad, heads, n_layer)
+    pos = txdec_ref.make_positions(src, pad)
+    assert pos.tolist() == [[pad + 1 + t for t in range(5)]] * 3  # float features never equal the pad id
+    x = math.sqrt(d) * emb + txdec_ref.sinusoidal_rows(pos, d)
+    for i in range(n_layer):
+        q = f"layers.{i}."
+        layer = torch.nn.TransformerEncoderLayer(d, heads, ffn, dropout=0.0, activation="relu", batch_first=True,
+                                                 norm_first=False).eval()
+        with torch.no_grad():
+            layer.self_attn.in_proj_weight.copy_(torch.cat([w[q + f"self_attn.{p}_proj.weight"] for p in "qkv"]))
+            layer.self_attn.in_proj_bias.copy_(torch.cat([w[q + f"self_attn.{p}_proj.bias"] for p in "qkv"]))
+            layer.self_attn.out_proj.weight.copy_(w[q + "self_attn.out_proj.weight"])
+            layer.self_attn.out_proj.bias.copy_(w[q + "self_attn.out_proj.bias"])
+            layer.norm1.weight.copy_(w[q + "self_attn_layer_norm.weight"]); layer.norm1.bias.copy_(w[q + "self_attn_layer_norm.bias"])
+            layer.norm2.weight.copy_(w[q + "final_layer_norm.weight"]); layer.norm2.bias.copy_(w[q + "final_layer_norm.bias"])
+            layer.linear1.weight.copy_(w[q + "fc1.weight"]); layer.linear1.bias.copy_(w[q + "fc1.bias"])
+            layer.linear2.weight.copy_(w[q + "fc2.weight"]); layer.linear2.bias.copy_(w[q + "fc2.bias"])
+            x = layer(x)
+    assert float((out.transpose(0, 1) - x).abs().max()) < 2e-5 * float(x.abs().max())

@@ -25,11 +25,12 @@ from torch import nn
 
 from . import ops
 from .hf_gpt2_fseq import KVCacheState
+from .transformer_code import AddLayerNormFn, AttnSmallFn, hip_linear
 
 
-def _xavier(out_f, in_f):
+def _xavier(out_f, in_f, gain=1.0):
     t = torch.empty(out_f, in_f)
-    nn.init.xavier_uniform_(t)
+    nn.init.xavier_uniform_(t, gain=gain)
     return t
 
 
@@ -45,8 +46,9 @@ class TransformerDecoderHip(nn.Module):
         for i in range(n_layer):
             q = f"layers.{i}."
             for att in ("self_attn", "encoder_attn"):
-                for pr in ("k_proj", "v_proj", "q_proj", "out_proj"):
-                    p[q + f"{att}.{pr}.weight"] = _xavier(d_model, d_model)
+                for pr in ("k_proj", "v_proj", "q_proj", "out_proj"):  # MultiheadAttention.reset_parameters
+                    p[q + f"{att}.{pr}.weight"] = _xavier(d_model, d_model,
+                                                          1.0 if pr == "out_proj" else 1 / math.sqrt(2))
                     p[q + f"{att}.{pr}.bias"] = torch.zeros(d_model)
                 p[q + f"{att}_layer_norm.weight"] = torch.ones(d_model)
                 p[q + f"{att}_layer_norm.bias"] = torch.zeros(d_model)
@@ -408,3 +410,106 @@ class TxDecoderReal(nn.Module):
 
     def max_decoder_positions(self):
         return self.model.max_positions
+
+
+# ================================================================================================
+# fairseq TransformerEncoder as `TxEncoderOld` uses it (`vidsitu_code/mdl_sf_base.py:246-338`,
+# `tx_enc_type: old`): the per-event video features ARE the token embeddings; `src_tokens` (their first
+# channel, a float tensor) only drives the position / padding rules.  Post-norm layers, no final norm.
+# Built from the autograd functions of the TxEncoderNew path (fused linear, L <= 16 attention, fused
+# residual + dropout + layernorm), so the backward is theirs.
+# ================================================================================================
+def sinusoid_table(pad, n_rows, d, device):
+    """Row 0 = zeros; row 1 + t = fairseq's sinusoidal embedding of position pad + 1 + t (CPU fp32 math)."""
+    half = d // 2
+    freq = torch.exp(torch.arange(half, dtype=torch.float) * -(math.log(10000) / (half - 1)))
+    ang = torch.arange(pad + 1, pad + 1 + n_rows, dtype=torch.float).unsqueeze(1) * freq.unsqueeze(0)
+    tab = torch.cat([torch.sin(ang), torch.cos(ang)], dim=1)
+    if d % 2 == 1:
+        tab = torch.cat([tab, torch.zeros(n_rows, 1)], dim=1)
+    return torch.cat([torch.zeros(1, d), tab]).contiguous().to(device)
+
+
+class _FseqSelfAttn(nn.Module):
+    def __init__(self, d, heads):
+        super().__init__()
+        self.k_proj, self.v_proj = nn.Linear(d, d), nn.Linear(d, d)
+        self.q_proj, self.out_proj = nn.Linear(d, d), nn.Linear(d, d)
+        for m in (self.k_proj, self.v_proj, self.q_proj):
+            nn.init.xavier_uniform_(m.weight, gain=1 / math.sqrt(2))
+        nn.init.xavier_uniform_(self.out_proj.weight)
+        nn.init.zeros_(self.out_proj.bias)
+        self.heads, self.scale = heads, math.sqrt(d // heads)
+
+    def forward(self, x):
+        o = AttnSmallFn.apply(hip_linear(self.q_proj, x), hip_linear(self.k_proj, x), hip_linear(self.v_proj, x),
+                              self.heads, self.scale, None)
+        return hip_linear(self.out_proj, o)
+
+
+class _FseqEncoderLayer(nn.Module):
+    def __init__(self, d, ffn, heads, dropout):
+        super().__init__()
+        self.self_attn = _FseqSelfAttn(d, heads)
+        self.self_attn_layer_norm = nn.LayerNorm(d)
+        self.fc1, self.fc2 = nn.Linear(d, ffn), nn.Linear(ffn, d)
+        self.final_layer_norm = nn.LayerNorm(d)
+        self.p = float(dropout)
+
+    def _mask(self, x):
+        if self.training and self.p > 0:
+            return ops.dropout_mask((x.numel() // x.shape[-1], x.shape[-1]), self.p, x.device)
+        return None
+
+    def forward(self, x):
+        a = self.self_attn(x)
+        ln = self.self_attn_layer_norm
+        x = AddLayerNormFn.apply(x, a, ln.weight, ln.bias, ln.eps, self._mask(a))
+        f = hip_linear(self.fc2, hip_linear(self.fc1, x, relu=True))
+        ln = self.final_layer_norm
+        return AddLayerNormFn.apply(x, f, ln.weight, ln.bias, ln.eps, self._mask(f))
+
+
+class TxEncoderOld(nn.Module):
+    def __init__(self, cfg, comm):
+        super().__init__()
+        from .mdl_sf_base import EncoderOut
+
+        self._EncoderOut = EncoderOut
+        self.full_cfg, self.comm = cfg, comm
+        tok = comm.gpt2_hf_tok  # comm[comm.dct_id]; the vb_arg task's dictionary (dat_loader.py:61)
+        a = cfg.tx_dec
+        d = a.encoder_embed_dim
+        self.padding_idx = tok.pad_token_id
+        # constructed by the reference and part of its checkpoints, never used (token_embeddings are given)
+        self.embed_tokens = nn.Embedding(len(tok), d, self.padding_idx)
+        self.embed_tokens.weight.requires_grad_(False)
+        self.embed_scale = math.sqrt(d)
+        self.p = float(a.dropout)
+        self.layers = nn.ModuleList([_FseqEncoderLayer(d, a.encoder_ffn_embed_dim, a.encoder_attention_heads,
+                                                       a.dropout) for _ in range(a.encoder_layers)])
+        self._tab = {}
+
+    def forward(self, src_tokens=None, src_lengths=None, return_all_hiddens=False, token_embeddings=None):
+        assert token_embeddings is not None, "TxEncoderOld is called with the video features as embeddings"
+        x = token_embeddings.float()
+        if not x.is_cuda:
+            raise ops._lib.VsError("the encoder runs on the HIP kernels only (GPU tensor required)")
+        b, l, d = x.shape
+        tab = self._tab.get(str(x.device))
+        if tab is None or tab.shape[0] < l + 1:
+            tab = self._tab[str(x.device)] = sinusoid_table(self.padding_idx, max(l, 16), d, x.device)
+        mask = src_tokens.ne(self.padding_idx)
+        idx = torch.cumsum(mask, dim=1) * mask  # utils.make_positions, as a row of the table
+        embed = self.embed_scale * x
+        x = embed + tab[idx]
+        if self.training and self.p > 0:
+            x = x * ops.dropout_mask((b, l, d), self.p, x.device)
+        states = [] if return_all_hiddens else None
+        for layer in self.layers:
+            x = layer(x)
+            if states is not None:
+                states.append(x.transpose(0, 1))
+        return self._EncoderOut(encoder_out=x.transpose(0, 1).contiguous(),
+                                encoder_padding_mask=src_tokens.eq(self.padding_idx), encoder_embedding=embed,
+                                encoder_states=states, src_tokens=None, src_lengths=None)

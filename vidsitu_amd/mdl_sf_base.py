@@ -250,8 +250,10 @@ class TxEncoderNew(TxCodeEnc):
 def TxEncoder(cfg, comm):
     if cfg.mdl.tx_enc_type == "new":
         return TxEncoderNew(cfg, comm)
-    # "old" / "new_conc" are the fairseq TransformerEncoder
-    raise NotImplementedError(f"tx_enc_type={cfg.mdl.tx_enc_type} is outside the hot path")
+    if cfg.mdl.tx_enc_type == "old":  # fairseq TransformerEncoder
+        from .fseq_txdec import TxEncoderOld
+        return TxEncoderOld(cfg, comm)
+    raise NotImplementedError(f"tx_enc_type={cfg.mdl.tx_enc_type}")
 
 
 def get_head_dim(full_cfg) -> int:
