@@ -365,6 +365,20 @@ int vs_beam_step(const float* row_val, const int64_t* row_idx, const int64_t* to
                  int k, int V, int step, int max_len, int eos, int normalize, float len_penalty,
                  void* stream);
 
+/* Non-local block pieces (slowfast nonlocal_helper.Nonlocal of the i3d_r50_nl_8x8 feature model,
+ * Kinetics_c2_I3D_NLN_8x8_R50.yaml:25-28): MaxPool3d([1,2,2], stride [1,2,2]) of a channels-last bf16
+ * activation [NT][H][W][C] with a byte argmax per element (0..3 = (dh, dw), first maximum wins) and its
+ * backward; row softmax of bf16 scores [rows][P] (P % 4 == 0, P <= 4096; fp32 math; in place allowed) and
+ * ds = scale * p * (dp - sum(dp * p)); out[c] = sum over rows of a bf16 matrix (row pitch ld).  The
+ * theta.phi^T and softmax.g products run on vs_conv_fwd / vs_conv_wgrad per clip. */
+int vs_maxpool_hw2_fwd(const void* x, void* y, uint8_t* idx, int64_t NT, int H, int W, int C, void* stream);
+int vs_maxpool_hw2_bwd(const void* dy, const uint8_t* idx, void* dx, int64_t NT, int H, int W, int C,
+                       void* stream);
+int vs_softmax_rows_bf16(const void* x, void* y, int64_t rows, int P, void* stream);
+int vs_softmax_rows_bwd_bf16(const void* p, const void* dp, void* ds, int64_t rows, int P, float scale,
+                             void* stream);
+int vs_colsum_bf16(const void* x, float* out, int64_t rows, int C, int ld, void* stream);
+
 /* fairseq TransformerDecoder (TxDecoderReal, vidsitu_code/mdl_sf_base.py:435-446) pieces beside the
  * shared GEMM / attention / layernorm kernels: out[t] = scale * emb[tokens[t]] + pos_table[pos_idx[t]]
  * (embed_scale * embed_tokens + sinusoidal positions; the caller's table has a zero row for padding);

@@ -76,6 +76,12 @@ def default_sf_cfg(arch="slowfast", depth=50, width=64, num_frames=32):
             else [[1], [2], [2], [2]],
         ),
         BN=SimpleNamespace(EPSILON=1e-5, MOMENTUM=0.1),
+        NONLOCAL=SimpleNamespace(
+            LOCATION=[[[], []] if multi else [[]] for _ in range(4)],
+            GROUP=[[1, 1] if multi else [1] for _ in range(4)],
+            INSTANTIATION="dot_product",
+            POOL=[[[1, 2, 2], [1, 2, 2]] for _ in range(4)],
+        ),
     )
 
 
@@ -177,12 +183,55 @@ class ResBlock(nn.Module):
         return self.relu(x)
 
 
+class Nonlocal(nn.Module):
+    """slowfast/models/nonlocal_helper.py `Nonlocal` (un-vendored submodule, restated): theta / phi / g
+    1x1x1 convs (with bias), phi and g on the max-pooled input, softmax(theta.phi / sqrt(dim_inner)) or
+    theta.phi / positions ("dot_product"), 1x1x1 output conv, BatchNorm (gamma zero-initialised), residual."""
+
+    def __init__(self, dim, dim_inner, pool_size, instantiation, cfg):
+        super().__init__()
+        self.dim, self.dim_inner, self.instantiation = dim, dim_inner, instantiation
+        self.use_pool = pool_size is not None and any(s > 1 for s in pool_size)
+        self.conv_theta = nn.Conv3d(dim, dim_inner, 1)
+        self.conv_phi = nn.Conv3d(dim, dim_inner, 1)
+        self.conv_g = nn.Conv3d(dim, dim_inner, 1)
+        self.conv_out = nn.Conv3d(dim_inner, dim, 1)
+        self.bn = _bn(dim, cfg)
+        self.bn.transform_final_bn = True
+        if self.use_pool:
+            self.pool = nn.MaxPool3d(kernel_size=pool_size, stride=pool_size, padding=[0, 0, 0])
+
+    def forward(self, x):
+        x_identity = x
+        n, c, t, h, w = x.size()
+        theta = self.conv_theta(x)
+        if self.use_pool:
+            x = self.pool(x)
+        phi, g = self.conv_phi(x), self.conv_g(x)
+        theta = theta.view(n, self.dim_inner, -1)
+        phi = phi.view(n, self.dim_inner, -1)
+        g = g.view(n, self.dim_inner, -1)
+        theta_phi = torch.einsum("nct,ncp->ntp", theta, phi)
+        if self.instantiation == "softmax":
+            theta_phi = torch.softmax(theta_phi * (self.dim_inner ** -0.5), dim=2)
+        elif self.instantiation == "dot_product":
+            theta_phi = theta_phi / theta_phi.shape[2]
+        else:
+            raise NotImplementedError(self.instantiation)
+        out = torch.einsum("ntg,ncg->nct", theta_phi, g).view(n, self.dim_inner, t, h, w)
+        return x_identity + self.bn(self.conv_out(out))
+
+
 class ResStage(nn.Module):
-    def __init__(self, cins, couts, cinners, tks, strides, nblocks, nblk_tk, cfg):
+    def __init__(self, cins, couts, cinners, tks, strides, nblocks, nblk_tk, cfg, nl_inds=None, nl_pool=None):
         super().__init__()
         self.num_pathways = len(cins)
         self.num_blocks = nblocks
+        self.nl_inds = nl_inds if nl_inds is not None else [[] for _ in cins]
         for p in range(self.num_pathways):
+            for i in self.nl_inds[p]:  # slowfast ResStage._construct: a Nonlocal after block i
+                self.add_module(f"pathway{p}_nonlocal{i}",
+                                Nonlocal(couts[p], couts[p] // 2, nl_pool[p], cfg.NONLOCAL.INSTANTIATION, cfg))
             n = nblocks[p]
             tk_list = (tks[p] * n)[: nblk_tk[p]] + [1] * (n - nblk_tk[p])
             for i in range(n):
@@ -204,6 +253,8 @@ class ResStage(nn.Module):
             x = xs[p]
             for i in range(self.num_blocks[p]):
                 x = getattr(self, f"pathway{p}_res{i}")(x)
+                if i in self.nl_inds[p]:
+                    x = getattr(self, f"pathway{p}_nonlocal{i}")(x)
             out.append(x)
         return out
 
@@ -275,7 +326,8 @@ class VideoTrunk(nn.Module):
             for k in range(4):
                 cout = w * 4 * (2 ** k) if depths[k] > 0 else cin
                 stage = ResStage(
-                    [cin], [cout], [inner * (2 ** k)], tk[k + 1], ss[k], [depths[k]], nbt[k], cfg
+                    [cin], [cout], [inner * (2 ** k)], tk[k + 1], ss[k], [depths[k]], nbt[k], cfg,
+                    nl_inds=cfg.NONLOCAL.LOCATION[k], nl_pool=cfg.NONLOCAL.POOL[k],
                 )
                 setattr(self, f"s{k + 2}", stage)
                 cin = cout

@@ -89,6 +89,11 @@ SIGNATURES = {
     "vs_attn_causal_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "vs_attn_decode": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "vs_pack_rows_f32": (_i, [_p, _p, _i, _i, _p]),
+    "vs_maxpool_hw2_fwd": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p]),
+    "vs_maxpool_hw2_bwd": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p]),
+    "vs_softmax_rows_bf16": (_i, [_p, _p, _i64, _i, _p]),
+    "vs_softmax_rows_bwd_bf16": (_i, [_p, _p, _p, _i64, _i, _f, _p]),
+    "vs_colsum_bf16": (_i, [_p, _p, _i64, _i, _i, _p]),
     "vs_embed_pos_fwd": (_i, [_p, _p, _p, _p, _p, _i64, _i, _f, _p]),
     "vs_embed_scatter_bwd": (_i, [_p, _p, _p, _i64, _i, _f, _i64, _p]),
     "vs_relu_bwd": (_i, [_p, _p, _p, _i64, _p]),

@@ -1081,3 +1081,230 @@ extern "C" int vs_avgpool_bwd(const float* dout, void* dx, int N, int64_t rows_p
   VS_CHECK_LAUNCH();
   return VS_OK;
 }
+
+// =============================================================================================
+// Non-local block pieces (slowfast/models/nonlocal_helper.py `Nonlocal`, used by the i3d_r50_nl_8x8
+// feature model: configs/vsitu_mdl_cfgs/Kinetics_c2_I3D_NLN_8x8_R50.yaml:25-28):
+// MaxPool3d([1,2,2], stride [1,2,2]) on channels-last bf16 with a 2-bit argmax, row softmax of the
+// theta.phi scores (bf16 in / out, fp32 math), its backward, and a bf16 column sum (conv bias gradients).
+// The two batched matrix products run on the implicit-GEMM conv kernel (per clip, phi / g as "weights").
+// =============================================================================================
+__global__ void maxpool_hw2_fwd_kernel(const uint16_t* x, uint16_t* y, uint8_t* idx, long long NT, int H,
+                                       int W, int C, long long total) {
+  const int Ho = H >> 1, Wo = W >> 1, cpr = C >> 3;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % cpr);
+    long long r = i / cpr;
+    const int wo = (int)(r % Wo);
+    r /= Wo;
+    const int ho = (int)(r % Ho);
+    const long long nt = r / Ho;
+    float best[8];
+    uint8_t bi[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long long pos = (nt * H + ho * 2 + (q >> 1)) * W + wo * 2 + (q & 1);
+      float v[8];
+      unpack8_bf16(*(const uint4*)(x + pos * C + c8 * 8), v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (q == 0 || v[e] > best[e]) {  // first maximum wins (torch's tie rule)
+          best[e] = v[e];
+          bi[e] = (uint8_t)q;
+        }
+    }
+    const long long o = ((nt * Ho + ho) * Wo + wo) * C + c8 * 8;
+    *(uint4*)(y + o) = pack8_bf16(best);
+    *(uint2*)(idx + o) = make_uint2(bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24),
+                                    bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24));
+  }
+}
+
+extern "C" int vs_maxpool_hw2_fwd(const void* x, void* y, uint8_t* idx, int64_t NT, int H, int W, int C,
+                                  void* stream) {
+  VS_CHECK_ARG(x && y && idx && NT > 0 && H >= 2 && W >= 2 && C % 8 == 0, "bad args");
+  const long long total = (long long)NT * (H / 2) * (W / 2) * (C / 8);
+  hipLaunchKernelGGL(maxpool_hw2_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)x, (uint16_t*)y, idx, (long long)NT, H, W, C, total);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// dx[input position] = dy[its window] where the position was the window's argmax, else 0 (windows do
+// not overlap; rows / columns beyond 2*floor(H/2), 2*floor(W/2) get 0)
+__global__ void maxpool_hw2_bwd_kernel(const uint16_t* dy, const uint8_t* idx, uint16_t* dx, long long NT,
+                                       int H, int W, int C, long long total) {
+  const int Ho = H >> 1, Wo = W >> 1, cpr = C >> 3;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % cpr);
+    long long r = i / cpr;
+    const int w = (int)(r % W);
+    r /= W;
+    const int h = (int)(r % H);
+    const long long nt = r / H;
+    float out[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int ho = h >> 1, wo = w >> 1;
+    if (ho < Ho && wo < Wo) {
+      const long long o = ((nt * Ho + ho) * Wo + wo) * C + c8 * 8;
+      float g[8];
+      unpack8_bf16(*(const uint4*)(dy + o), g);
+      const uint2 b = *(const uint2*)(idx + o);
+      const int q = ((h & 1) << 1) | (w & 1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int bi = ((e < 4 ? b.x : b.y) >> ((e & 3) * 8)) & 0xff;
+        out[e] = bi == q ? g[e] : 0.f;
+      }
+    }
+    *(uint4*)(dx + ((nt * H + h) * W + w) * C + c8 * 8) = pack8_bf16(out);
+  }
+}
+
+extern "C" int vs_maxpool_hw2_bwd(const void* dy, const uint8_t* idx, void* dx, int64_t NT, int H, int W,
+                                  int C, void* stream) {
+  VS_CHECK_ARG(dy && idx && dx && NT > 0 && H >= 2 && W >= 2 && C % 8 == 0, "bad args");
+  const long long total = (long long)NT * H * W * (C / 8);
+  hipLaunchKernelGGL(maxpool_hw2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)dy, idx, (uint16_t*)dx, (long long)NT, H, W, C, total);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// y[r, :] = softmax(x[r, :]) over P <= 4096 bf16 columns (P % 4 == 0), one wave per row, fp32 math;
+// in place allowed.
+#define SMR_MAX 16  // 8-byte pieces per lane
+__global__ __launch_bounds__(256) void softmax_rows_bf16_kernel(const uint16_t* x, uint16_t* y, long long rows,
+                                                                int P) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int P4 = P >> 2;
+  const uint2* xr = (const uint2*)(x + row * P);
+  float v[SMR_MAX][4];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < SMR_MAX; ++e) {
+    const int i = lane + 64 * e;
+    const bool ok = i < P4;
+    const uint2 q = xr[ok ? i : 0];
+    v[e][0] = ok ? bf16_to_f32((uint16_t)(q.x & 0xffff)) : -INFINITY;
+    v[e][1] = ok ? bf16_to_f32((uint16_t)(q.x >> 16)) : -INFINITY;
+    v[e][2] = ok ? bf16_to_f32((uint16_t)(q.y & 0xffff)) : -INFINITY;
+    v[e][3] = ok ? bf16_to_f32((uint16_t)(q.y >> 16)) : -INFINITY;
+    mx = fmaxf(mx, fmaxf(fmaxf(v[e][0], v[e][1]), fmaxf(v[e][2], v[e][3])));
+  }
+  mx = wave_reduce_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < SMR_MAX; ++e)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[e][k] = expf(v[e][k] - mx);  // exp(-inf) = 0 for the padding
+      sum += v[e][k];
+    }
+  const float inv = 1.0f / wave_reduce_sum(sum);
+  uint2* yr = (uint2*)(y + row * P);
+#pragma unroll
+  for (int e = 0; e < SMR_MAX; ++e) {
+    const int i = lane + 64 * e;
+    if (i < P4) yr[i] = make_uint2(pack2_bf16(v[e][0] * inv, v[e][1] * inv), pack2_bf16(v[e][2] * inv, v[e][3] * inv));
+  }
+}
+
+extern "C" int vs_softmax_rows_bf16(const void* x, void* y, int64_t rows, int P, void* stream) {
+  VS_CHECK_ARG(x && y && rows > 0 && P > 0 && (P & 3) == 0 && P <= 64 * 4 * SMR_MAX, "P % 4 == 0, P <= 4096");
+  hipLaunchKernelGGL(softmax_rows_bf16_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, (long long)rows, P);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// ds = scale * p * (dp - sum_j dp_j p_j): backward of softmax(scale * s) w.r.t. s; in place on dp allowed
+__global__ __launch_bounds__(256) void softmax_rows_bwd_bf16_kernel(const uint16_t* p, const uint16_t* dp,
+                                                                    uint16_t* ds, long long rows, int P,
+                                                                    float scale) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int P4 = P >> 2;
+  const uint2* pr = (const uint2*)(p + row * P);
+  const uint2* gr = (const uint2*)(dp + row * P);
+  float pv[SMR_MAX][4], gv[SMR_MAX][4];
+  float dot = 0.f;
+#pragma unroll
+  for (int e = 0; e < SMR_MAX; ++e) {
+    const int i = lane + 64 * e;
+    const bool ok = i < P4;
+    const uint2 a = pr[ok ? i : 0], b = gr[ok ? i : 0];
+    pv[e][0] = ok ? bf16_to_f32((uint16_t)(a.x & 0xffff)) : 0.f;
+    pv[e][1] = ok ? bf16_to_f32((uint16_t)(a.x >> 16)) : 0.f;
+    pv[e][2] = ok ? bf16_to_f32((uint16_t)(a.y & 0xffff)) : 0.f;
+    pv[e][3] = ok ? bf16_to_f32((uint16_t)(a.y >> 16)) : 0.f;
+    gv[e][0] = bf16_to_f32((uint16_t)(b.x & 0xffff));
+    gv[e][1] = bf16_to_f32((uint16_t)(b.x >> 16));
+    gv[e][2] = bf16_to_f32((uint16_t)(b.y & 0xffff));
+    gv[e][3] = bf16_to_f32((uint16_t)(b.y >> 16));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dot += pv[e][k] * gv[e][k];  // padding: p = 0
+  }
+  dot = wave_reduce_sum(dot);
+  uint2* dr = (uint2*)(ds + row * P);
+#pragma unroll
+  for (int e = 0; e < SMR_MAX; ++e) {
+    const int i = lane + 64 * e;
+    if (i < P4) {
+      float o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = scale * pv[e][k] * (gv[e][k] - dot);
+      dr[i] = make_uint2(pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]));
+    }
+  }
+}
+
+extern "C" int vs_softmax_rows_bwd_bf16(const void* p, const void* dp, void* ds, int64_t rows, int P,
+                                        float scale, void* stream) {
+  VS_CHECK_ARG(p && dp && ds && rows > 0 && P > 0 && (P & 3) == 0 && P <= 64 * 4 * SMR_MAX, "P % 4 == 0, P <= 4096");
+  hipLaunchKernelGGL(softmax_rows_bwd_bf16_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, (const uint16_t*)p, (const uint16_t*)dp, (uint16_t*)ds,
+                     (long long)rows, P, scale);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// out[c] = sum_rows x[row][c] (bf16 in, fp32 out): a block owns 64 columns, 16 waves take rows
+// w, w+16, ..., eight rows of loads in flight, partial sums combined through LDS in wave order.
+__global__ __launch_bounds__(1024) void colsum_bf16_kernel(const uint16_t* x, float* out, long long rows, int C,
+                                                           int ld) {
+  __shared__ float part[16][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 64 + lane;
+  const int cc = c < C ? c : 0;
+  float acc = 0.f;
+  long long r = wave;
+  for (; r + 16 * 7 < rows; r += 16 * 8) {
+    uint16_t q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) q[u] = x[(r + 16 * u) * ld + cc];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += bf16_to_f32(q[u]);
+  }
+  for (; r < rows; r += 16) acc += bf16_to_f32(x[r * ld + cc]);
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && c < C) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += part[w][lane];
+    out[c] = s;
+  }
+}
+
+extern "C" int vs_colsum_bf16(const void* x, float* out, int64_t rows, int C, int ld, void* stream) {
+  VS_CHECK_ARG(x && out && rows > 0 && C > 0 && ld >= C, "bad args");
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream,
+                     (const uint16_t*)x, out, (long long)rows, C, ld);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}

@@ -23,6 +23,8 @@ _REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sf_mdl_to_cfg_fpath_dct = {
     "slow_fast_nl_r50_8x8": "./configs/vsitu_mdl_cfgs/Kinetics_c2_SLOWFAST_8x8_R50.yaml",
     "i3d_r50_8x8": "./configs/vsitu_mdl_cfgs/Kinetics_c2_I3D_8x8_R50.yaml",
+    "i3d_r50_nl_8x8": "./configs/vsitu_mdl_cfgs/Kinetics_c2_I3D_NLN_8x8_R50.yaml",
+    "i3d_tiny_nl": "./configs/vsitu_mdl_cfgs/I3D_tiny_nl.yaml",
     "i3d_tiny": "./configs/vsitu_mdl_cfgs/I3D_tiny.yaml",
     "slow_fast_mini": "./configs/vsitu_mdl_cfgs/SLOWFAST_mini.yaml",
 }
@@ -94,7 +96,10 @@ def sf_defaults():
                        "INPLACE_RELU": True, "NUM_BLOCK_TEMP_KERNEL": [[3], [4], [6], [3]],
                        "SPATIAL_STRIDES": [[1], [2], [2], [2]],
                        "SPATIAL_DILATIONS": [[1], [1], [1], [1]]},
-            "NONLOCAL": {"LOCATION": [[[]], [[]], [[]], [[]]]},
+            "NONLOCAL": {"LOCATION": [[[]], [[]], [[]], [[]]], "GROUP": [[1], [1], [1], [1]],
+                         "INSTANTIATION": "dot_product",
+                         "POOL": [[[1, 2, 2], [1, 2, 2]], [[1, 2, 2], [1, 2, 2]], [[1, 2, 2], [1, 2, 2]],
+                                  [[1, 2, 2], [1, 2, 2]]]},
             "BN": {"EPSILON": 1e-5, "MOMENTUM": 0.1, "NORM_TYPE": "batchnorm"},
             "MODEL": {"ARCH": "slowfast", "MODEL_NAME": "SlowFast", "NUM_CLASSES": 400,
                       "SINGLE_PATHWAY_ARCH": ["c2d", "i3d", "slow"],

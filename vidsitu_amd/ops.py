@@ -920,3 +920,44 @@ def relu_bwd(dy, y):
     dx = torch.empty_like(dy)
     _lib.call("vs_relu_bwd", _ptr(dy), _ptr(y), _ptr(dx), dy.numel(), _stream())
     return dx
+
+
+# ---- non-local block pieces ----------------------------------------------------------------------
+def maxpool_hw2(x):
+    """MaxPool3d([1,2,2], stride [1,2,2]) of a dense channels-last activation -> (y, idx u8)."""
+    n, c, t, h, w = x.shape
+    if act_ld(x) != c:
+        raise _lib.VsError("maxpool_hw2 needs a dense activation")
+    y = new_act(n, c, t, h // 2, w // 2, x.device)
+    idx = torch.empty((n * t * (h // 2) * (w // 2), c), dtype=torch.uint8, device=x.device)
+    _lib.call("vs_maxpool_hw2_fwd", _ptr(x), _ptr(y), _ptr(idx), n * t, h, w, c, _stream())
+    return y, idx
+
+
+def maxpool_hw2_bwd(dy, idx, xs):
+    n, c, t, h, w = xs
+    dx = new_act(n, c, t, h, w, dy.device)
+    _lib.call("vs_maxpool_hw2_bwd", _ptr(dy), _ptr(idx), _ptr(dx), n * t, h, w, c, _stream())
+    return dx
+
+
+def softmax_rows_bf16(x, rows, p, out=None):
+    """Row softmax of a dense bf16 [rows][p] matrix held in any tensor of rows * p elements."""
+    out = x if out is None else out
+    _lib.call("vs_softmax_rows_bf16", _ptr(x), _ptr(out), int(rows), int(p), _stream())
+    return out
+
+
+def softmax_rows_bwd_bf16(prob, dprob, rows, p, scale, out=None):
+    out = dprob if out is None else out
+    _lib.call("vs_softmax_rows_bwd_bf16", _ptr(prob), _ptr(dprob), _ptr(out), int(rows), int(p), float(scale),
+              _stream())
+    return out
+
+
+def colsum_bf16(x, out=None):
+    """Per-channel sum of a channels-last bf16 activation -> f32 [C] (conv bias gradient)."""
+    n, c, t, h, w = x.shape
+    out = torch.empty(c, dtype=torch.float32, device=x.device) if out is None else out
+    _lib.call("vs_colsum_bf16", _ptr(x), _ptr(out), n * t * h * w, c, act_ld(x), _stream())
+    return out

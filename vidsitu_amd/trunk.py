@@ -42,12 +42,14 @@ POOL1 = {
 # parameter holders (names = upstream names)
 # ----------------------------------------------------------------------------
 class Conv3dP(nn.Module):
-    """Bias-free Conv3d parameters.  `weight` is the fp32 master in the reference's
+    """Conv3d parameters (bias-free except in the non-local block).  `weight` is the fp32 master in the reference's
     logical shape [Cout,Cin,kT,kH,kW] with channels-last memory."""
 
-    def __init__(self, cin, cout, k, s=(1, 1, 1), p=(0, 0, 0)):
+    def __init__(self, cin, cout, k, s=(1, 1, 1), p=(0, 0, 0), bias=False):
         super().__init__()
         self.cin, self.cout = cin, cout
+        # only the non-local block's 1x1x1 convs carry a bias (slowfast nonlocal_helper: nn.Conv3d default)
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
         self.k, self.s, self.p = tuple(k), tuple(s), tuple(p)
         self.cin_pad = (cin + 7) // 8 * 8
         w = torch.empty(cout, *self.k, cin).permute(0, 4, 1, 2, 3)
@@ -170,6 +172,8 @@ class _Unit:
     def fwd(conv, bn, x, relu, residual=None, out=None, train=False, saved=None):
         if not train:
             scale, shift = bn.fold
+            if conv.bias is not None:  # BN(conv + b) folded: the bias joins the shift
+                shift = shift + conv.bias.detach() * scale
             if conv.is_stem:
                 y, _ = ops.stem_conv_fwd(x[0], conv.w_stem, conv.cout, conv.k[0], out=out,
                                          scale=scale, shift=shift, relu=relu)
@@ -185,6 +189,11 @@ class _Unit:
         scale, shift, mean, invstd = ops.bn_finalize(
             partials, ops.act_rows(y), bn.weight, bn.bias, bn.running_mean, bn.running_var,
             bn.momentum, bn.eps, train=True)
+        if conv.bias is not None:
+            # train-mode BN removes a per-channel constant exactly, so the conv ran without its bias;
+            # only the running mean sees it: mean(conv + b) = mean(conv) + b
+            with torch.no_grad():
+                bn.running_mean.add_(conv.bias.detach() * bn.momentum)
         # a unit with a residual input cannot recompute its ReLU mask from y alone: keep it as bits
         want_bits = relu and residual is not None and y.shape[1] % 8 == 0 and \
             ((y.shape[1] // 8) & (y.shape[1] // 8 - 1)) == 0
@@ -212,6 +221,11 @@ class _Unit:
             dz, zmask, rec["y"], rec["mean"], rec["invstd"], bn.weight, relu, want_dres,
             dgamma=bn.weight.grad, dbeta=bn.bias.grad, beta=bn.bias, zbits=zbits)
         x = rec["x"]
+        if conv.bias is not None:  # analytically zero behind a train-mode BN
+            if conv.bias.grad is None:
+                conv.bias.grad = torch.zeros_like(conv.bias)
+            else:
+                conv.bias.grad.zero_()
         if conv.is_stem:
             _WgradLanes.run(lambda: _set_grad(conv.weight, ops.stem_conv_wgrad(dy, x, conv.k[0])), dy, x)
         elif conv.cin_pad == conv.cin:
@@ -307,13 +321,176 @@ class ResBlock(nn.Module):
         return dx
 
 
+class Nonlocal(nn.Module):
+    """slowfast `nonlocal_helper.Nonlocal` (i3d_r50_nl_8x8: Kinetics_c2_I3D_NLN_8x8_R50.yaml:25-28;
+    SURVEY.md 8f row f4): theta / phi / g 1x1x1 convs with bias, phi and g on the [1,2,2] max-pooled input,
+    softmax(theta.phi / sqrt(dim_inner)) ("softmax") or theta.phi / positions ("dot_product"), output conv,
+    BatchNorm with zero-initialised gamma, residual.  The two batched products run per clip on the
+    implicit-GEMM conv kernels with phi / g^T / g / phi^T as the "weight" operand (forward and dgrad-like
+    products) and on the wgrad kernel (the products that sum over the query positions); scores and
+    probabilities are bf16 like every activation of the trunk."""
+
+    def __init__(self, dim, dim_inner, pool_size, instantiation, eps, mom):
+        super().__init__()
+        if instantiation not in ("softmax", "dot_product"):
+            raise NotImplementedError(f"NONLOCAL.INSTANTIATION={instantiation}")
+        self.dim, self.dim_inner, self.instantiation = dim, dim_inner, instantiation
+        self.use_pool = pool_size is not None and any(v > 1 for v in pool_size)
+        if self.use_pool and list(pool_size) != [1, 2, 2]:
+            raise NotImplementedError(f"NONLOCAL.POOL={pool_size}: only [1, 2, 2] is built")
+        self.conv_theta = Conv3dP(dim, dim_inner, (1, 1, 1), bias=True)
+        self.conv_phi = Conv3dP(dim, dim_inner, (1, 1, 1), bias=True)
+        self.conv_g = Conv3dP(dim, dim_inner, (1, 1, 1), bias=True)
+        self.conv_out = Conv3dP(dim_inner, dim, (1, 1, 1), bias=True)
+        self.bn = BN3dP(dim, eps, mom, zero_init=True)
+        self._const = {}
+
+    K1, S1, P0 = (1, 1, 1), (1, 1, 1), (0, 0, 0)
+
+    def _vec(self, n, value, dev):
+        key = (n, float(value), str(dev))
+        t = self._const.get(key)
+        if t is None:
+            t = self._const[key] = torch.full((n,), float(value), dtype=torch.float32, device=dev)
+        return t
+
+    @staticmethod
+    def _as_weight(a):
+        """One clip's activation [1, C, T, H, W] (memory [positions][C]) as a 1x1x1 conv weight
+        [Cout = positions, Cin = C] -- the same bytes."""
+        _, c, t, h, w = a.shape
+        return a[0].permute(1, 2, 3, 0).reshape(t * h * w, 1, 1, 1, c).permute(0, 4, 1, 2, 3)
+
+    def _biased(self, conv, x):
+        return ops.conv_fwd(x, conv.w_bf16, self.K1, self.S1, self.P0, scale=self._vec(conv.cout, 1.0, x.device),
+                            shift=conv.bias.detach())[0]
+
+    def _keys(self, a, npad):
+        """Per-clip weight views [npad, ci] of a key-side activation (phi / g): the activation's own
+        memory when its position count is a multiple of 8 (the conv kernels' channel granularity),
+        else zero-padded copies."""
+        n, ci = a.shape[0], a.shape[1]
+        npos = a.shape[2] * a.shape[3] * a.shape[4]
+        if npad == npos:
+            return [self._as_weight(a[i:i + 1]) for i in range(n)]
+        buf = torch.zeros((n, npad, ci), dtype=a.dtype, device=a.device)
+        buf[:, :npos].copy_(a.permute(0, 2, 3, 4, 1).reshape(n, npos, ci))
+        return [buf[i].view(npad, 1, 1, 1, ci).permute(0, 4, 1, 2, 3) for i in range(n)]
+
+    def _score_affine(self, npos, npad, dev):
+        """Epilogue of the theta.phi product: the scale of the instantiation and, for padded key columns,
+        a shift that makes their softmax probability exactly 0."""
+        softmax = self.instantiation == "softmax"
+        key = ("aff", npos, npad, str(dev))
+        t = self._const.get(key)
+        if t is None:
+            sc = torch.full((npad,), self.dim_inner ** -0.5 if softmax else 1.0 / npos, dtype=torch.float32,
+                            device=dev)
+            sh = torch.zeros(npad, dtype=torch.float32, device=dev)
+            if softmax:
+                sh[npos:] = -30000.0
+            t = self._const[key] = (sc, sh)
+        return t
+
+    def fwd(self, x, out, train, saved):
+        n, c, t, h, w = x.shape
+        dev = x.device
+        ci = self.dim_inner
+        theta = self._biased(self.conv_theta, x)
+        xp, pidx = ops.maxpool_hw2(x) if self.use_pool else (x, None)
+        phi, g = self._biased(self.conv_phi, xp), self._biased(self.conv_g, xp)
+        npos = xp.shape[2] * xp.shape[3] * xp.shape[4]
+        npad = (npos + 7) // 8 * 8
+        softmax = self.instantiation == "softmax"
+        sc, sh = self._score_affine(npos, npad, dev)
+        phi_w, g_w = self._keys(phi, npad), self._keys(g, npad)
+        prob = ops.new_act(n, npad, t, h, w, dev)  # [clip][query position][key position]
+        for i in range(n):
+            ops.conv_fwd(theta[i:i + 1], phi_w[i], self.K1, self.S1, self.P0, out=prob[i:i + 1], scale=sc, shift=sh)
+        if softmax:
+            ops.softmax_rows_bf16(prob, n * t * h * w, npad)
+        o = ops.new_act(n, ci, t, h, w, dev)
+        for i in range(n):
+            gt = ops.weight_transpose(g_w[i])  # [ci][key positions]
+            ops.conv_fwd(prob[i:i + 1], gt, self.K1, self.S1, self.P0, out=o[i:i + 1])
+        z = _Unit.fwd(self.conv_out, self.bn, o, False, residual=x, out=out, train=train, saved=saved)
+        if train:
+            saved.append(dict(nl=self, x=x, xp=xp, pidx=pidx, theta=theta, phi=phi, g=g, phi_w=phi_w, g_w=g_w,
+                              prob=prob, npos=npos, npad=npad))
+        return z
+
+    def _bias_grad(self, conv, dy):
+        if conv.bias.grad is None:
+            conv.bias.grad = torch.empty_like(conv.bias)
+        ops.colsum_bf16(dy, out=conv.bias.grad)
+
+    def _wgrad(self, conv, dy, x):
+        if conv.weight.grad is None:
+            conv.weight.grad = torch.empty_like(conv.weight)
+        ops.conv_wgrad(dy, x, self.K1, self.S1, self.P0, out=conv.weight.grad)
+
+    @staticmethod
+    def _key_rows(dw, npos, ci):
+        """fp32 [npad][ci] product of the wgrad kernel -> its first npos rows, flat."""
+        return dw.permute(0, 2, 3, 4, 1).reshape(-1)[: npos * ci]
+
+    def bwd(self, saved, gout):
+        rec = saved.pop()
+        x, xp, theta, phi, g, prob = (rec[k] for k in ("x", "xp", "theta", "phi", "g", "prob"))
+        phi_w, g_w, npos, npad = rec["phi_w"], rec["g_w"], rec["npos"], rec["npad"]
+        n, c, t, h, w = x.shape
+        dev = x.device
+        ci = self.dim_inner
+        do, dres = _Unit.bwd(saved.pop(), gout, want_dres=True)  # conv_out + BN; dres: the identity branch
+        softmax = self.instantiation == "softmax"
+        dprob = ops.new_act(n, npad, t, h, w, dev)
+        dg = torch.empty_like(g)
+        for i in range(n):
+            # dprob[m][p] = sum_c do[m][c] g[p][c];  dg[p][c] = sum_m prob[m][p] do[m][c]
+            ops.conv_fwd(do[i:i + 1], g_w[i], self.K1, self.S1, self.P0, out=dprob[i:i + 1])
+            dw = ops.conv_wgrad(prob[i:i + 1], do[i:i + 1], self.K1, self.S1, self.P0)
+            ops.cast_bf16(self._key_rows(dw, npos, ci), dg[i:i + 1])
+        if softmax:
+            ops.softmax_rows_bwd_bf16(prob, dprob, n * t * h * w, npad, ci ** -0.5)  # -> d(theta.phi), in place
+        dtheta, dphi = torch.empty_like(theta), torch.empty_like(phi)
+        sc = None if softmax else self._vec(ci, 1.0 / npos, dev)
+        zero = None if softmax else self._vec(ci, 0.0, dev)
+        for i in range(n):
+            # dtheta[m][c] = sum_p ds[m][p] phi[p][c];  dphi[p][c] = sum_m ds[m][p] theta[m][c]
+            pt = ops.weight_transpose(phi_w[i])
+            ops.conv_fwd(dprob[i:i + 1], pt, self.K1, self.S1, self.P0, out=dtheta[i:i + 1], scale=sc, shift=zero)
+            dw = ops.conv_wgrad(dprob[i:i + 1], theta[i:i + 1], self.K1, self.S1, self.P0)
+            if not softmax:
+                dw = dw * (1.0 / npos)
+            ops.cast_bf16(self._key_rows(dw, npos, ci), dphi[i:i + 1])
+        for conv, dy, xin in ((self.conv_theta, dtheta, x), (self.conv_phi, dphi, xp), (self.conv_g, dg, xp)):
+            self._bias_grad(conv, dy)
+            self._wgrad(conv, dy, xin)
+        if self.use_pool:
+            dxp = ops.conv_dgrad(dphi, self.conv_phi.wt(), tuple(xp.shape), self.K1, self.S1, self.P0)
+            dxp = ops.conv_dgrad(dg, self.conv_g.wt(), tuple(xp.shape), self.K1, self.S1, self.P0, residual=dxp)
+            dpool = ops.maxpool_hw2_bwd(dxp, rec["pidx"], tuple(x.shape))
+            dx = ops.conv_dgrad(dtheta, self.conv_theta.wt(), tuple(x.shape), self.K1, self.S1, self.P0,
+                                residual=dpool)
+            # + the identity branch: one fused add (bn_apply with scale 1, shift 0, residual)
+            return ops.bn_apply(dx, self._vec(c, 1.0, dev), self._vec(c, 0.0, dev), dres, relu=False)
+        dx = ops.conv_dgrad(dtheta, self.conv_theta.wt(), tuple(x.shape), self.K1, self.S1, self.P0, residual=dres)
+        dx = ops.conv_dgrad(dphi, self.conv_phi.wt(), tuple(x.shape), self.K1, self.S1, self.P0, residual=dx)
+        return ops.conv_dgrad(dg, self.conv_g.wt(), tuple(x.shape), self.K1, self.S1, self.P0, residual=dx)
+
+
 class ResStage(nn.Module):
-    def __init__(self, cins, couts, cinners, tks, strides, nblocks, nblk_tk, eps, mom, zero_final):
+    def __init__(self, cins, couts, cinners, tks, strides, nblocks, nblk_tk, eps, mom, zero_final,
+                 nl_inds=None, nl_pool=None, nl_inst="dot_product"):
         super().__init__()
         self.num_pathways = len(cins)
         self.num_blocks = list(nblocks)
         self.couts = list(couts)
+        self.nl_inds = [list(v) for v in nl_inds] if nl_inds is not None else [[] for _ in cins]
         for p in range(self.num_pathways):
+            for i in self.nl_inds[p]:  # slowfast ResStage._construct: a Nonlocal after block i
+                self.add_module(f"pathway{p}_nonlocal{i}",
+                                Nonlocal(couts[p], couts[p] // 2, nl_pool[p], nl_inst, eps, mom))
             n = nblocks[p]
             tk_list = (tks[p] * n)[: nblk_tk[p]] + [1] * (n - nblk_tk[p])
             for i in range(n):
@@ -323,7 +500,12 @@ class ResStage(nn.Module):
                              strides[p] if i == 0 else 1, eps, mom, zero_final))
 
     def blocks(self, p):
-        return [getattr(self, f"pathway{p}_res{i}") for i in range(self.num_blocks[p])]
+        out = []
+        for i in range(self.num_blocks[p]):
+            out.append(getattr(self, f"pathway{p}_res{i}"))
+            if i in self.nl_inds[p]:
+                out.append(getattr(self, f"pathway{p}_nonlocal{i}"))
+        return out
 
 
 class PathwayPool(nn.Module):
@@ -474,9 +656,13 @@ class VideoTrunk(nn.Module):
             cin = w
             for k in range(4):
                 cout = w * 4 * (2 ** k) if depths[k] > 0 else cin
+                nlc = getattr(cfg, "NONLOCAL", None)
+                loc = nlc.LOCATION[k] if nlc is not None else [[]]
                 setattr(self, f"s{k + 2}", ResStage(
                     [cin], [cout], [inner * (2 ** k)], tk[k + 1], ss[k], [depths[k]], nbt[k],
-                    eps, mom, zf))
+                    eps, mom, zf, nl_inds=loc,
+                    nl_pool=(nlc.POOL[k] if (nlc is not None and any(loc)) else None),
+                    nl_inst=getattr(nlc, "INSTANTIATION", "dot_product") if nlc is not None else "dot_product"))
                 cin = cout
             self.dim_out = [cin]
         for p in range(self.num_pathways):
