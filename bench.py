@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("VS_BENCH_WORKLOAD", "sf_txenc_train"),
-                    choices=["feat_fwd", "sf_txenc_train"])
+                    choices=["feat_fwd", "sf_txenc_train", "srl_gen_gpt2", "srl_gen_txdec"])
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a hipGraph")
     ap.add_argument("--overlap", type=int, default=-1,
                     help="train: split the step into segment graphs and all-reduce finished gradient "
@@ -187,6 +187,59 @@ def load_pmc_traffic():
         return {}
 
 
+def bench_srl_gen(args, rank, world, dev):
+    """BASELINE configs[4] (informational, not the headline metric): features -> TxEncoder -> SRL caption per
+    event by beam search (beam 5, 60 tokens, min_len = max_len - 1 so every hypothesis runs the full length),
+    GPT-2 medium (`srl_gen_gpt2`) or the fairseq-style 3-layer decoder (`srl_gen_txdec`, the reference's
+    default).  8 event clips per GPU; ranks are replicas (no collective).  One step = one generation of the
+    batch; value = event captions (one per clip) per second."""
+    from vidsitu_amd import synth_data
+    from vidsitu_amd.extended_config import get_cfg
+    from vidsitu_amd.mdl_selector import get_mdl_loss_eval
+
+    dec = "gpt2" if args.workload == "srl_gen_gpt2" else "txdec"
+    max_len = 60
+    cfg = get_cfg({"task_type": "vb_arg", "mdl.mdl_name": "sfpret_txe_txd_vbarg", "mdl.tx_dec_type": dec,
+                   "gen.beam_size": 5, "gen.max_len_b": max_len, "gen.min_len": max_len - 1})
+    comm = synth_data.make_comm(cfg)
+    sel = get_mdl_loss_eval(cfg)
+    torch.manual_seed(0)
+    mdl = sel["mdl"](cfg=cfg, comm=comm).to(dev).eval()
+    batch = synth_data.synth_srl_batch(comm, bs=CLIPS_PER_GPU // 4, n_ev=4, seq_len=60, seed=1234 + rank, device=dev)
+    evl = sel["evl"](cfg, comm, dev)
+    for _ in range(max(args.warmup, 2)):  # eager warm-up, then the per-step hipGraph capture
+        evl.forward_one_batch(mdl, batch)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = evl.forward_one_batch(mdl, batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ntok = sum(len(v["tokens"]) for r in out for v in r["vb_output"].values())
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"clips/s SRL caption generation, beam 5 x {max_len} tokens, {dec} decoder",
+            "value": round(CLIPS_PER_GPU * world * args.steps / dt, 2), "unit": "clips/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[4] shape: pre-extracted features -> TxEncoder -> {dec} "
+                                   f"decoder, beam 5, {max_len} tokens, 8 event clips/GPU as 2 videos x 4 events",
+                       "clips_per_gpu": CLIPS_PER_GPU, "hipgraph": True, "tokens_per_generation": ntok,
+                       "device_side_search": True},
+            "roofline": None, "cpu_baseline": None}))
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def cpu_baseline(workload, n_vocab):
     """fp32 torch oracle on the host cores, ONE clip of the batch (bounded sample)."""
     from oracle.slowfast_ref import SFBaseRef, default_sf_cfg, slow_index
@@ -240,6 +293,8 @@ def main():
     from vidsitu_amd.mdl_selector import get_mdl_loss_eval
     from vidsitu_amd.optim import ArenaAdam, ParamArena
 
+    if args.workload.startswith("srl_gen"):
+        return bench_srl_gen(args, rank, world, dev)
     train = args.workload == "sf_txenc_train"
     overrides = {"mdl.mdl_name": "sf_base_txenc" if train else "sf_base"}
     if train:
