@@ -44,11 +44,17 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
   float4 ra[PA], rb[PB];
 
   auto ld4 = [&](const float* base, int row, int rows, int k) __attribute__((always_inline)) {
+    const bool ok = row < rows && k < K;
+    if (kvec) {
+      // branch-free: a load inside `if (ok)` sits in its own basic block behind its own wait -- the 8
+      // loads of a k-tile were 8 serialised L2 round trips (the kernel ran at 18 % of the fp32 MFMA peak)
+      const float4 t = *(const float4*)(base + (ok ? (long long)row * K + k : 0));
+      return ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < rows && k < K) {
+    if (ok) {
       const float* s = base + (long long)row * K + k;
-      if (kvec) v = *(const float4*)s;
-      else { v.x = s[0]; if (k + 1 < K) v.y = s[1]; if (k + 2 < K) v.z = s[2]; if (k + 3 < K) v.w = s[3]; }
+      v.x = s[0]; if (k + 1 < K) v.y = s[1]; if (k + 2 < K) v.z = s[2]; if (k + 3 < K) v.w = s[3];
     }
     return v;
   };
@@ -853,24 +859,36 @@ extern "C" int vs_add_f32(const float* a, const float* b, float* out, int64_t n,
   return VS_OK;
 }
 
-// out[n] = sum_m x[m][n]  (bias gradients): one thread per column, fixed row order.
-__global__ void colsum_f32_kernel(const float* x, float* out, int M, int N) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+// out[n] = sum_m x[m][n]  (bias gradients): a block owns 64 columns, its 16 waves take rows w, w+16, ...
+// with eight rows of loads in flight, partial sums meet in LDS in wave order (bitwise reproducible).  The
+// one-thread-per-column loop was a chain of M / 4 memory latencies: 46 us for 600 x 1024.
+__global__ __launch_bounds__(1024) void colsum_f32_kernel(const float* x, float* out, int M, int N) {
+  __shared__ float part[16][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 64 + lane;
+  const int nc = n < N ? n : 0;
   float s = 0.f;
-  int m = 0;
-  for (; m + 4 <= M; m += 4) {
-    const float a = x[(long long)m * N + n], b = x[(long long)(m + 1) * N + n],
-                c = x[(long long)(m + 2) * N + n], d = x[(long long)(m + 3) * N + n];
-    s += a; s += b; s += c; s += d;
+  int m = wave;
+  for (; m + 16 * 7 < M; m += 16 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = x[(long long)(m + 16 * u) * N + nc];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
   }
-  for (; m < M; ++m) s += x[(long long)m * N + n];
-  out[n] = s;
+  for (; m < M; m += 16) s += x[(long long)m * N + nc];
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += part[w][lane];
+    out[n] = t;
+  }
 }
 extern "C" int vs_colsum_f32(const float* x, float* out, int M, int N, void* stream) {
   VS_CHECK_ARG(x && out && M > 0 && N > 0, "bad args");
-  hipLaunchKernelGGL(colsum_f32_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, x,
-                     out, M, N);
+  hipLaunchKernelGGL(colsum_f32_kernel, dim3((N + 63) / 64), dim3(1024), 0, (hipStream_t)stream, x, out, M, N);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }
@@ -885,7 +903,8 @@ extern "C" int vs_colsum_f32(const float* x, float* out, int M, int N, void* str
 // ----------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_causal_bwd_kernel(const float* qkv, const uint8_t* kmask,
                                                               const float* dout, float* dqkv,
-                                                              float* scratch, int L, int H, int dh) {
+                                                              float* scratch, int L, int H, int dh,
+                                                              int pds_in_lds) {
   extern __shared__ float sm[];
   const int D = H * dh, ld = dh + 1;
   const int r = blockIdx.x / H, h = blockIdx.x % H;
@@ -897,7 +916,9 @@ __global__ __launch_bounds__(256) void attn_causal_bwd_kernel(const float* qkv, 
   float* Sw = Pw + 4 * L;    // [4][L] per-wave dS row
   const float* base = qkv + (long long)r * L * 3 * D;
   const float* dob = dout + (long long)r * L * D;
-  float* P = scratch + (long long)blockIdx.x * 2 * L * L;
+  // the two [L][L] matrices between the passes: in LDS when they fit (pass B then reads them without a
+  // chain of global round trips), else in the caller's scratch
+  float* P = pds_in_lds ? Sw + 4 * L : scratch + (long long)blockIdx.x * 2 * L * L;
   float* dS = P + (long long)L * L;
   for (int i = threadIdx.x; i < L * dh; i += 256) {
     const int j = i / dh, d = i - j * dh;
@@ -979,8 +1000,11 @@ extern "C" int vs_attn_causal_bwd(const float* qkv, const uint8_t* key_mask, con
                                   int dh, void* stream) {
   VS_CHECK_ARG(qkv && dout && dqkv && scratch && R > 0 && L > 0 && H > 0 && dh > 0, "bad args");
   VS_CHECK_ARG(scratch_bytes >= vs_attn_causal_bwd_scratch_bytes(R, L, H), "scratch too small");
-  const size_t smem = ((size_t)4 * L * (dh + 1) + 8 * L) * sizeof(float);
+  size_t smem = ((size_t)4 * L * (dh + 1) + 8 * L) * sizeof(float);
   VS_CHECK_ARG(smem <= 160 * 1024, "sequence too long for the LDS-resident attention backward");
+  const size_t with_pds = smem + (size_t)2 * L * L * sizeof(float);
+  const int pds_in_lds = with_pds <= 156 * 1024;
+  if (pds_in_lds) smem = with_pds;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)attn_causal_bwd_kernel,
@@ -988,7 +1012,7 @@ extern "C" int vs_attn_causal_bwd(const float* qkv, const uint8_t* key_mask, con
     attr = true;
   }
   hipLaunchKernelGGL(attn_causal_bwd_kernel, dim3(R * H), dim3(256), smem, (hipStream_t)stream, qkv,
-                     key_mask, dout, dqkv, (float*)scratch, L, H, dh);
+                     key_mask, dout, dqkv, (float*)scratch, L, H, dh, pds_in_lds);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }
