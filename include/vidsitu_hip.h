@@ -283,6 +283,14 @@ int vs_resize_bicubic_u8(const uint8_t* src, uint8_t* dst, uint8_t* tmp, int64_t
                          const int32_t* bounds_v, const int32_t* kk_v, int ksize_v, int y0, int y1,
                          void* stream);
 
+/* vs_gemm_nt_f32 with a split-K workspace: GEMMs of more than 64 rows with few 64x64 output tiles (a
+ * 600-token batch against a 1024-wide layer) are cut into K slices whose partial tiles are added in slice
+ * order by a second launch (bitwise reproducible).  vs_gemm_nt_f32_workspace_bytes: bytes needed (0 = the
+ * plain call does the same). */
+size_t vs_gemm_nt_f32_workspace_bytes(int M, int N, int K);
+int vs_gemm_nt_f32_ws(const float* x, const float* w, const float* b, const float* res, float* y, int M,
+                      int N, int K, int act, void* workspace, size_t ws_bytes, void* stream);
+
 /* Decode-step (1..64 rows) GEMM on fragment-major operands.  vs_pack_rows_f32 copies a row-major
  * matrix src[R][K] (K % 16 == 0) into 1-KB blocks of 16 rows x 16 floats in v_mfma_f32_16x16x4_f32
  * operand order (block (r/16, k/16) at index (r/16)*(K/16) + k/16; lane (k%16/4)*16 + r%16 holds floats

@@ -39,7 +39,11 @@ def _model_from_golden(path, dev):
                                                (50, 3072, 1024, 2, True), (50, 1024, 4096, 0, True),
                                                (64, 50259, 1024, 0, False), (48, 1030, 128, 2, False),
                                                (20, 24, 384, 0, True), (40, 1000, 512, 1, False),
-                                               (30, 4096, 1024, 0, False), (50, 1024, 1024, 0, True)])
+                                               (30, 4096, 1024, 0, False), (50, 1024, 1024, 0, True),
+                                               # > 64 rows with few output tiles: split-K slabs + reduce
+                                               (600, 1024, 1024, 2, True), (600, 3072, 1024, 0, False),
+                                               (599, 1000, 4096, 1, True), (130, 64, 520, 0, False),
+                                               (1024, 600, 600, 0, False)])
 def test_gemm_nt_f32(m, n, k, act, use_res, dev):
     from vidsitu_amd import ops
 

@@ -89,6 +89,8 @@ SIGNATURES = {
     "vs_attn_causal_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "vs_attn_decode": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "vs_pack_rows_f32": (_i, [_p, _p, _i, _i, _p]),
+    "vs_gemm_nt_f32_workspace_bytes": (_sz, [_i, _i, _i]),
+    "vs_gemm_nt_f32_ws": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "vs_maxpool_hw2_fwd": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p]),
     "vs_maxpool_hw2_bwd": (_i, [_p, _p, _p, _i64, _i, _i, _i, _p]),
     "vs_softmax_rows_bf16": (_i, [_p, _p, _i64, _i, _p]),

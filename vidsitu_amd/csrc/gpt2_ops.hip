@@ -25,12 +25,16 @@ __device__ __forceinline__ float gelu_new_f(float x) {
 #define GM_BK 32
 #define GM_LD 33
 
+// Split-K (gridDim.z = S > 1): slice z covers k-tiles [z * kts, (z + 1) * kts) and stores its raw partial
+// tile into slab z of `y` (M * N floats each); gemm_splitk_reduce_kernel adds the slabs in slice order and
+// applies the epilogue.  Layers with few output tiles (600 x 1024: 160 tiles of 64 x 64 for 256 CUs) then
+// run 3-4 blocks per CU and overlap each other's memory latency.
 template <int BM, int BN>  // 128x128 (2x2 MFMA tiles per wave) or 64x64 (one per wave)
 __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restrict__ x,
                                                           const float* __restrict__ w,
                                                           const float* __restrict__ bias,
                                                           const float* res, float* y, int M, int N,
-                                                          int K, int act) {
+                                                          int K, int act, int kts) {
   constexpr int MR = BM / 64, NR = BN / 64;  // 32x32 accumulators per wave
   constexpr int PA = BM / 32, PB = BN / 32;  // loader passes (32 rows each)
   __shared__ float As[2][BM * GM_LD];
@@ -86,11 +90,15 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
   const int fr = lane & 31, fk = lane >> 5;
-  const int nk = (K + GM_BK - 1) / GM_BK;
-  gload(0);
-  sstore(0);
+  const int nk_all = (K + GM_BK - 1) / GM_BK;
+  const bool split = gridDim.z > 1;
+  const int kt0 = split ? blockIdx.z * kts : 0;
+  const int nk = split ? min(nk_all, kt0 + kts) : nk_all;
+  if (split) y += (long long)blockIdx.z * M * N;
+  gload(kt0 * GM_BK);
+  sstore(kt0 & 1);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = kt0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) gload((kt + 1) * GM_BK);
     const float* A = &As[cur][(wm * (BM / 2) + fr) * GM_LD + fk];
@@ -118,6 +126,14 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     for (int b = 0; b < NR; ++b) {
       const int n = n0 + wn * (BN / 2) + b * 32 + (lane & 31);
       if (n >= N) continue;
+      if (split) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wm * (BM / 2) + a * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+          if (m < M) y[(long long)m * N + n] = acc[a][b][e];
+        }
+        continue;
+      }
       const float bvv = bias ? bias[n] : 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -133,18 +149,74 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
     }
 }
 
+__global__ void gemm_splitk_reduce_kernel(const float* slabs, const float* bias, const float* res, float* y,
+                                          long long MN, int N, int S, int act) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < MN; i += (long long)gridDim.x * blockDim.x) {
+    float v = slabs[i];
+    for (int s2 = 1; s2 < S; ++s2) v += slabs[(long long)s2 * MN + i];
+    if (bias) v += bias[i % N];
+    if (act == 1) v = fmaxf(v, 0.f);
+    else if (act == 2) v = gelu_new_f(v);
+    if (res) v += res[i];
+    y[i] = v;
+  }
+}
+
+// K slices for a GEMM with few output tiles: about 700 blocks, at least 4 k-tiles (128 floats) per slice
+static int gemm_split(int M, int N, int K) {
+  const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
+  if (t128 >= 256) return 1;
+  const long long t64 = (long long)((M + 63) / 64) * ((N + 63) / 64);
+  const int nk = (K + GM_BK - 1) / GM_BK;
+  int S = (int)(704 / t64);
+  if (S > nk / 4) S = nk / 4;
+  if (S > 16) S = 16;
+  return S < 2 ? 1 : S;
+}
+
+extern "C" size_t vs_gemm_nt_f32_workspace_bytes(int M, int N, int K) {
+  if (M <= 64) return 0;
+  const int S = gemm_split(M, N, K);
+  return S > 1 ? (size_t)S * M * N * sizeof(float) : 0;
+}
+
 int vs_gemm_nt_f32_mfma(const float* x, const float* w, const float* b, const float* res, float* y,
-                        int M, int N, int K, int act, hipStream_t st) {
+                        int M, int N, int K, int act, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0) {
   // fewer than one 128x128 tile per CU: 64x64 tiles (4x the blocks) keep the chip busy
   const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
-  if (t128 >= 256)
+  if (t128 >= 256) {
     hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 128>), dim3((N + 127) / 128, (M + 127) / 128), dim3(256),
-                       0, st, x, w, b, res, y, M, N, K, act);
-  else
+                       0, st, x, w, b, res, y, M, N, K, act, 0);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+  }
+  const int S = ws ? gemm_split(M, N, K) : 1;
+  if (S > 1 && ws_bytes >= (size_t)S * M * N * sizeof(float)) {
+    const int nk = (K + GM_BK - 1) / GM_BK;
+    const int kts = (nk + S - 1) / S;
+    const int Se = (nk + kts - 1) / kts;  // slices that own at least one k-tile
+    hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 64>), dim3((N + 63) / 64, (M + 63) / 64, Se), dim3(256), 0, st,
+                       x, w, (const float*)nullptr, (const float*)nullptr, (float*)ws, M, N, K, 0, kts);
+    const long long MN = (long long)M * N;
+    long long grid = (MN + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, st, (const float*)ws, b,
+                       res, y, MN, N, Se, act);
+  } else {
     hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 64>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0,
-                       st, x, w, b, res, y, M, N, K, act);
+                       st, x, w, b, res, y, M, N, K, act, 0);
+  }
   VS_CHECK_LAUNCH();
   return VS_OK;
+}
+
+/* vs_gemm_nt_f32 with a split-K workspace (vs_gemm_nt_f32_workspace_bytes(M, N, K); 0 = not needed). */
+extern "C" int vs_gemm_nt_f32_ws(const float* x, const float* w, const float* b, const float* res, float* y,
+                                 int M, int N, int K, int act, void* workspace, size_t ws_bytes, void* stream) {
+  VS_CHECK_ARG(x && w && y && M > 0 && N > 0 && K > 0, "bad args");
+  VS_CHECK_ARG(act >= 0 && act <= 2, "act must be 0 (none), 1 (relu) or 2 (gelu_new)");
+  if (M <= 64 || !workspace) return vs_gemm_nt_f32(x, w, b, res, y, M, N, K, act, stream);
+  return vs_gemm_nt_f32_mfma(x, w, b, res, y, M, N, K, act, (hipStream_t)stream, workspace, ws_bytes);
 }
 
 // ----------------------------------------------------------------------------

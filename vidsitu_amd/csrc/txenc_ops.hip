@@ -557,7 +557,7 @@ extern "C" int vs_linear_fwd(const float* x, const float* w, const float* b, flo
 // y = act(x . w^T + b) + res, act 0 none / 1 relu / 2 gelu_new.  Up to 64 rows every weight row is
 // streamed exactly once by one wave (HBM-bound decode steps); above that the fp32 matrix cores.
 int vs_gemm_nt_f32_mfma(const float* x, const float* w, const float* b, const float* res, float* y,
-                        int M, int N, int K, int act, hipStream_t st);
+                        int M, int N, int K, int act, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0);
 
 extern "C" int vs_gemm_nt_f32(const float* x, const float* w, const float* b, const float* res,
                               float* y, int M, int N, int K, int act, void* stream) {

@@ -660,8 +660,14 @@ def gemm_nt(x, w, b=None, res=None, act=ACT_NONE, out=None):
     if w.shape[1] != k:
         raise _lib.VsError(f"gemm_nt: K mismatch {tuple(x.shape)} x {tuple(w.shape)}")
     y = torch.empty((m, n), dtype=torch.float32, device=x.device) if out is None else out
-    _lib.call("vs_gemm_nt_f32", _ptr(x), _ptr(w), _ptr(b), _ptr(res), _ptr(y), m, n, k, int(act),
-              _stream())
+    need = _lib.load().vs_gemm_nt_f32_workspace_bytes(m, n, k) if m > 64 else 0
+    if need:
+        ws = _workspace(need, x.device)
+        _lib.call("vs_gemm_nt_f32_ws", _ptr(x), _ptr(w), _ptr(b), _ptr(res), _ptr(y), m, n, k, int(act),
+                  _ptr(ws), C.c_size_t(ws.numel()), _stream())
+    else:
+        _lib.call("vs_gemm_nt_f32", _ptr(x), _ptr(w), _ptr(b), _ptr(res), _ptr(y), m, n, k, int(act),
+                  _stream())
     return y
 
 
