@@ -29,7 +29,7 @@ __device__ __forceinline__ float gelu_new_f(float x) {
 // tile into slab z of `y` (M * N floats each); gemm_splitk_reduce_kernel adds the slabs in slice order and
 // applies the epilogue.  Layers with few output tiles (600 x 1024: 160 tiles of 64 x 64 for 256 CUs) then
 // run 3-4 blocks per CU and overlap each other's memory latency.
-template <int BM, int BN>  // 128x128 (2x2 MFMA tiles per wave) or 64x64 (one per wave)
+template <int BM, int BN, bool KVEC>  // 128x128 (2x2 MFMA tiles per wave) or 64x64 (one per wave); K % 4 == 0
 __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restrict__ x,
                                                           const float* __restrict__ w,
                                                           const float* __restrict__ bias,
@@ -44,17 +44,18 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   // loader mapping: 8 float4 per 32-float row, 32 rows per pass
   const int lc = tid & 7, lr = tid >> 3;
-  const bool kvec = (K & 3) == 0;
+  constexpr bool kvec = KVEC;  // compile time: a runtime flag put every load behind a branch (and a wait)
   float4 ra[PA], rb[PB];
 
-  auto ld4 = [&](const float* base, int row, int rows, int k) __attribute__((always_inline)) {
+  // Loads are branch-free (a load inside `if (ok)` sits in its own basic block behind its own wait: the 8
+  // loads of a k-tile were 8 serialised round trips) and RAW: out-of-range lanes read element 0 and are
+  // zeroed only when the tile is written to LDS, so nothing touches the loaded registers -- and no wait is
+  // placed -- before the MFMAs of the current tile have been issued.
+  unsigned okmask = 0;
+  auto ld4 = [&](const float* base, int row, int rows, int k, int bit) __attribute__((always_inline)) {
     const bool ok = row < rows && k < K;
-    if (kvec) {
-      // branch-free: a load inside `if (ok)` sits in its own basic block behind its own wait -- the 8
-      // loads of a k-tile were 8 serialised L2 round trips (the kernel ran at 18 % of the fp32 MFMA peak)
-      const float4 t = *(const float4*)(base + (ok ? (long long)row * K + k : 0));
-      return ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    okmask = ok ? (okmask | (1u << bit)) : (okmask & ~(1u << bit));
+    if constexpr (kvec) return *(const float4*)(base + (ok ? (long long)row * K + k : 0));
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ok) {
       const float* s = base + (long long)row * K + k;
@@ -64,20 +65,22 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
   };
   auto gload = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < PA; ++i) ra[i] = ld4(x, m0 + lr + 32 * i, M, k0 + lc * 4);
+    for (int i = 0; i < PA; ++i) ra[i] = ld4(x, m0 + lr + 32 * i, M, k0 + lc * 4, i);
 #pragma unroll
-    for (int i = 0; i < PB; ++i) rb[i] = ld4(w, n0 + lr + 32 * i, N, k0 + lc * 4);
+    for (int i = 0; i < PB; ++i) rb[i] = ld4(w, n0 + lr + 32 * i, N, k0 + lc * 4, PA + i);
   };
   auto sstore = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
       float* a = &As[buf][(lr + 32 * i) * GM_LD + lc * 4];
-      a[0] = ra[i].x; a[1] = ra[i].y; a[2] = ra[i].z; a[3] = ra[i].w;
+      const bool ok = (okmask >> i) & 1;
+      a[0] = ok ? ra[i].x : 0.f; a[1] = ok ? ra[i].y : 0.f; a[2] = ok ? ra[i].z : 0.f; a[3] = ok ? ra[i].w : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
       float* b = &Bs[buf][(lr + 32 * i) * GM_LD + lc * 4];
-      b[0] = rb[i].x; b[1] = rb[i].y; b[2] = rb[i].z; b[3] = rb[i].w;
+      const bool ok = (okmask >> (PA + i)) & 1;
+      b[0] = ok ? rb[i].x : 0.f; b[1] = ok ? rb[i].y : 0.f; b[2] = ok ? rb[i].z : 0.f; b[3] = ok ? rb[i].w : 0.f;
     }
   };
 
@@ -184,9 +187,14 @@ int vs_gemm_nt_f32_mfma(const float* x, const float* w, const float* b, const fl
                         int M, int N, int K, int act, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0) {
   // fewer than one 128x128 tile per CU: 64x64 tiles (4x the blocks) keep the chip busy
   const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
+  const bool kv = (K & 3) == 0 && ((((uintptr_t)x | (uintptr_t)w)) & 15) == 0;
   if (t128 >= 256) {
-    hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 128>), dim3((N + 127) / 128, (M + 127) / 128), dim3(256),
-                       0, st, x, w, b, res, y, M, N, K, act, 0);
+    if (kv)
+      hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 128, true>), dim3((N + 127) / 128, (M + 127) / 128),
+                         dim3(256), 0, st, x, w, b, res, y, M, N, K, act, 0);
+    else
+      hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 128, false>), dim3((N + 127) / 128, (M + 127) / 128),
+                         dim3(256), 0, st, x, w, b, res, y, M, N, K, act, 0);
     VS_CHECK_LAUNCH();
     return VS_OK;
   }
@@ -195,15 +203,22 @@ int vs_gemm_nt_f32_mfma(const float* x, const float* w, const float* b, const fl
     const int nk = (K + GM_BK - 1) / GM_BK;
     const int kts = (nk + S - 1) / S;
     const int Se = (nk + kts - 1) / kts;  // slices that own at least one k-tile
-    hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 64>), dim3((N + 63) / 64, (M + 63) / 64, Se), dim3(256), 0, st,
-                       x, w, (const float*)nullptr, (const float*)nullptr, (float*)ws, M, N, K, 0, kts);
+    if (kv)
+      hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 64, true>), dim3((N + 63) / 64, (M + 63) / 64, Se), dim3(256),
+                         0, st, x, w, (const float*)nullptr, (const float*)nullptr, (float*)ws, M, N, K, 0, kts);
+    else
+      hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 64, false>), dim3((N + 63) / 64, (M + 63) / 64, Se), dim3(256),
+                         0, st, x, w, (const float*)nullptr, (const float*)nullptr, (float*)ws, M, N, K, 0, kts);
     const long long MN = (long long)M * N;
     long long grid = (MN + 255) / 256;
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, st, (const float*)ws, b,
                        res, y, MN, N, Se, act);
+  } else if (kv) {
+    hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 64, true>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0,
+                       st, x, w, b, res, y, M, N, K, act, 0);
   } else {
-    hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 64>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0,
+    hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 64, false>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0,
                        st, x, w, b, res, y, M, N, K, act, 0);
   }
   VS_CHECK_LAUNCH();
