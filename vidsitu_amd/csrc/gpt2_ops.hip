@@ -268,11 +268,15 @@ extern "C" int vs_gpt2_embed(const int64_t* tokens, const float* wte, const floa
 // in which case the reference's behaviour is reproduced too);  out = p v, heads merged.
 // One block per (r, head): K and V of the head live in LDS (pitch dh+1), one wave per query.
 // ----------------------------------------------------------------------------
+// Grid = (r, head) x chunks of AC_QC queries: 160 blocks of 60 queries each were a latency-bound launch
+// (91 us per layer); a chunk's block loads the K rows up to its last query and all V rows.
+#define AC_QC 16
 __global__ __launch_bounds__(256) void attn_causal_kernel(const float* qkv, const uint8_t* kmask,
                                                           float* out, int L, int H, int dh) {
   extern __shared__ float sm[];
   const int D = H * dh, ld = dh + 1;
   const int r = blockIdx.x / H, h = blockIdx.x % H;
+  const int i0 = blockIdx.y * AC_QC, i1 = min(L, i0 + AC_QC);
   float* Ks = sm;
   float* Vs = Ks + L * ld;
   float* Ps = Vs + L * ld;   // [4][L]
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(256) void attn_causal_kernel(const float* qkv, cons
   const float* base = qkv + (long long)r * L * 3 * D;
   for (int i = threadIdx.x; i < L * dh; i += 256) {
     const int j = i / dh, d = i - j * dh;
-    Ks[j * ld + d] = base[(long long)j * 3 * D + D + h * dh + d];
+    if (j < i1) Ks[j * ld + d] = base[(long long)j * 3 * D + D + h * dh + d];  // keys beyond are masked
     Vs[j * ld + d] = base[(long long)j * 3 * D + 2 * D + h * dh + d];
   }
   __syncthreads();
@@ -288,15 +292,17 @@ __global__ __launch_bounds__(256) void attn_causal_kernel(const float* qkv, cons
   const float scale = 1.0f / sqrtf((float)dh);
   float* P = Ps + wave * L;
   float* Q = Qs + wave * dh;
-  for (int i = wave; i < L; i += 4) {
+  for (int i = i0 + wave; i < i1; i += 4) {
     for (int d = lane; d < dh; d += 64) Q[d] = base[(long long)i * 3 * D + h * dh + d];
     __builtin_amdgcn_wave_barrier();
     float mx = -INFINITY;
     for (int j = lane; j < L; j += 64) {
-      float s = 0.f;
-      for (int d = 0; d < dh; ++d) s += Q[d] * Ks[j * ld + d];
-      s *= scale;
-      if (j > i) s = -1e4f;
+      float s = -1e4f;
+      if (j <= i) {
+        s = 0.f;
+        for (int d = 0; d < dh; ++d) s += Q[d] * Ks[j * ld + d];
+        s *= scale;
+      }
       if (kmask && !kmask[(long long)r * L + j]) s += -1e4f;
       P[j] = s;
       mx = fmaxf(mx, s);
@@ -331,8 +337,8 @@ extern "C" int vs_attn_causal_fwd(const float* qkv, const uint8_t* key_mask, flo
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL(attn_causal_kernel, dim3(R * H), dim3(256), smem, (hipStream_t)stream, qkv,
-                     key_mask, out, L, H, dh);
+  hipLaunchKernelGGL(attn_causal_kernel, dim3(R * H, (L + AC_QC - 1) / AC_QC), dim3(256), smem,
+                     (hipStream_t)stream, qkv, key_mask, out, L, H, dh);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }
@@ -981,54 +987,61 @@ extern "C" int vs_colsum_f32(const float* x, float* out, int M, int N, void* str
 }
 
 // ----------------------------------------------------------------------------
-// Causal attention backward.  One block per (r, head): Q, K, V, dO of the head in LDS
-// (pitch dh+1).  Pass A (one wave per query i): p_i = softmax(s_i) with the forward's masking,
-// dP_ij = dO_i . V_j, D_i = sum_j p_ij dP_ij, dS_ij = p_ij (dP_ij - D_i); dQ_i = scale * dS_i K;
-// P and dS rows go to a scratch [L][L] pair.  Pass B (one wave per key j, lanes over d):
-// dK_j = scale * sum_i dS_ij Q_i, dV_j = sum_i p_ij dO_i -- every output has one owner, fixed
+// Causal attention backward in two launches over (r, head) x chunks of AC_QC queries / keys (one block
+// per (r, head) with every query and key was 160 latency-bound blocks: 177-223 us per layer).
+// Launch A (query chunk, one wave per query i): p_i = softmax(s_i) with the forward's masking,
+// dP_ij = dO_i . V_j, D_i = sum_j p_ij dP_ij, dS_ij = p_ij (dP_ij - D_i); dQ_i = scale * sum_{j<=i} dS_ij K_j
+// (a future key's score is the constant -1e4: no gradient); the P and dS rows go to the scratch [L][L] pair.
+// Launch B (key chunk, one wave per key j, lanes over d): dK_j = scale * sum_{i>=j} dS_ij Q_i,
+// dV_j = sum_i p_ij dO_i, the chunk's P / dS columns staged in LDS -- every output has one owner, fixed
 // summation order, no atomics.
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_causal_bwd_kernel(const float* qkv, const uint8_t* kmask,
-                                                              const float* dout, float* dqkv,
-                                                              float* scratch, int L, int H, int dh,
-                                                              int pds_in_lds) {
+__global__ __launch_bounds__(256) void attn_causal_bwd_q_kernel(const float* qkv, const uint8_t* kmask,
+                                                                const float* dout, float* dqkv,
+                                                                float* scratch, int L, int H, int dh) {
   extern __shared__ float sm[];
   const int D = H * dh, ld = dh + 1;
   const int r = blockIdx.x / H, h = blockIdx.x % H;
-  float* Qs = sm;
-  float* Ks = Qs + L * ld;
+  const int i0 = blockIdx.y * AC_QC, i1 = min(L, i0 + AC_QC);
+  float* Ks = sm;
   float* Vs = Ks + L * ld;
-  float* Os = Vs + L * ld;   // dO
-  float* Pw = Os + L * ld;   // [4][L] per-wave p row
-  float* Sw = Pw + 4 * L;    // [4][L] per-wave dS row
+  float* Qs = Vs + L * ld;       // [AC_QC][ld] the chunk's queries
+  float* Os = Qs + AC_QC * ld;   // [AC_QC][ld] the chunk's dO rows
+  float* Pw = Os + AC_QC * ld;   // [4][L] per-wave p row
+  float* Sw = Pw + 4 * L;        // [4][L] per-wave dS row
   const float* base = qkv + (long long)r * L * 3 * D;
   const float* dob = dout + (long long)r * L * D;
-  // the two [L][L] matrices between the passes: in LDS when they fit (pass B then reads them without a
-  // chain of global round trips), else in the caller's scratch
-  float* P = pds_in_lds ? Sw + 4 * L : scratch + (long long)blockIdx.x * 2 * L * L;
+  float* P = scratch + (long long)blockIdx.x * 2 * L * L;
   float* dS = P + (long long)L * L;
   for (int i = threadIdx.x; i < L * dh; i += 256) {
     const int j = i / dh, d = i - j * dh;
-    Qs[j * ld + d] = base[(long long)j * 3 * D + h * dh + d];
-    Ks[j * ld + d] = base[(long long)j * 3 * D + D + h * dh + d];
+    if (j < i1) Ks[j * ld + d] = base[(long long)j * 3 * D + D + h * dh + d];
     Vs[j * ld + d] = base[(long long)j * 3 * D + 2 * D + h * dh + d];
-    Os[j * ld + d] = dob[(long long)j * D + h * dh + d];
+  }
+  for (int i = threadIdx.x; i < (i1 - i0) * dh; i += 256) {
+    const int q = i / dh, d = i - q * dh;
+    Qs[q * ld + d] = base[(long long)(i0 + q) * 3 * D + h * dh + d];
+    Os[q * ld + d] = dob[(long long)(i0 + q) * D + h * dh + d];
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float scale = 1.0f / sqrtf((float)dh);
   float* pw = Pw + wave * L;
   float* sw = Sw + wave * L;
-  for (int i = wave; i < L; i += 4) {
+  for (int i = i0 + wave; i < i1; i += 4) {
+    const float* qi = Qs + (i - i0) * ld;
+    const float* oi = Os + (i - i0) * ld;
     float mx = -INFINITY;
     for (int j = lane; j < L; j += 64) {
-      float s = 0.f;
-      for (int d = 0; d < dh; ++d) s += Qs[i * ld + d] * Ks[j * ld + d];
-      s *= scale;
-      if (j > i) s = -1e4f;
-      if (kmask && !kmask[(long long)r * L + j]) s += -1e4f;
-      pw[j] = s;
-      mx = fmaxf(mx, s);
+      float sc = -1e4f;
+      if (j <= i) {
+        sc = 0.f;
+        for (int d = 0; d < dh; ++d) sc += qi[d] * Ks[j * ld + d];
+        sc *= scale;
+      }
+      if (kmask && !kmask[(long long)r * L + j]) sc += -1e4f;
+      pw[j] = sc;
+      mx = fmaxf(mx, sc);
     }
     mx = wave_reduce_max(mx);
     float sum = 0.f;
@@ -1041,12 +1054,12 @@ __global__ __launch_bounds__(256) void attn_causal_bwd_kernel(const float* qkv, 
     const float inv = 1.0f / sum;
     float dsum = 0.f;
     for (int j = lane; j < L; j += 64) {
-      const float p = pw[j] * inv;
+      const float pj = pw[j] * inv;
       float dp = 0.f;
-      for (int d = 0; d < dh; ++d) dp += Os[i * ld + d] * Vs[j * ld + d];
-      pw[j] = p;
+      for (int d = 0; d < dh; ++d) dp += oi[d] * Vs[j * ld + d];
+      pw[j] = pj;
       sw[j] = dp;
-      dsum += p * dp;
+      dsum += pj * dp;
     }
     dsum = wave_reduce_sum(dsum);
     for (int j = lane; j < L; j += 64) {
@@ -1057,21 +1070,49 @@ __global__ __launch_bounds__(256) void attn_causal_bwd_kernel(const float* qkv, 
     }
     __builtin_amdgcn_wave_barrier();
     for (int d = lane; d < dh; d += 64) {
-      float a = 0.f;
-      for (int j = 0; j < L; ++j) a += sw[j] * Ks[j * ld + d];
-      dqkv[((long long)r * L + i) * 3 * D + h * dh + d] = a * scale;
+      float acc = 0.f;
+      for (int j = 0; j <= i; ++j) acc += sw[j] * Ks[j * ld + d];
+      dqkv[((long long)r * L + i) * 3 * D + h * dh + d] = acc * scale;
     }
     __builtin_amdgcn_wave_barrier();
   }
-  __threadfence_block();
+}
+
+__global__ __launch_bounds__(256) void attn_causal_bwd_kv_kernel(const float* qkv, const float* dout,
+                                                                 float* dqkv, const float* scratch, int L,
+                                                                 int H, int dh) {
+  extern __shared__ float sm[];
+  const int D = H * dh, ld = dh + 1;
+  const int r = blockIdx.x / H, h = blockIdx.x % H;
+  const int j0 = blockIdx.y * AC_QC, j1 = min(L, j0 + AC_QC);
+  float* Qs = sm;                 // rows j0 .. L-1 (dK sums over i >= j)
+  float* Os = Qs + L * ld;        // all rows (dV sums over every i)
+  float* Pc = Os + L * ld;        // [L][AC_QC] the chunk's columns of P
+  float* Sc = Pc + L * AC_QC;     // [L][AC_QC] ... of dS
+  const float* base = qkv + (long long)r * L * 3 * D;
+  const float* dob = dout + (long long)r * L * D;
+  const float* P = scratch + (long long)blockIdx.x * 2 * L * L;
+  const float* dS = P + (long long)L * L;
+  for (int i = threadIdx.x; i < L * dh; i += 256) {
+    const int q = i / dh, d = i - q * dh;
+    if (q >= j0) Qs[q * ld + d] = base[(long long)q * 3 * D + h * dh + d];
+    Os[q * ld + d] = dob[(long long)q * D + h * dh + d];
+  }
+  for (int i = threadIdx.x; i < L * AC_QC; i += 256) {
+    const int q = i / AC_QC, c = i - q * AC_QC;
+    const bool ok = j0 + c < j1;
+    Pc[i] = ok ? P[(long long)q * L + j0 + c] : 0.f;
+    Sc[i] = ok ? dS[(long long)q * L + j0 + c] : 0.f;
+  }
   __syncthreads();
-  for (int j = wave; j < L; j += 4) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float scale = 1.0f / sqrtf((float)dh);
+  for (int j = j0 + wave; j < j1; j += 4) {
+    const int c = j - j0;
     for (int d = lane; d < dh; d += 64) {
       float dk = 0.f, dv = 0.f;
-      for (int i = 0; i < L; ++i) {
-        dk += dS[(long long)i * L + j] * Qs[i * ld + d];
-        dv += P[(long long)i * L + j] * Os[i * ld + d];
-      }
+      for (int i = 0; i < L; ++i) dv += Pc[i * AC_QC + c] * Os[i * ld + d];
+      for (int i = j; i < L; ++i) dk += Sc[i * AC_QC + c] * Qs[i * ld + d];
       dqkv[((long long)r * L + j) * 3 * D + D + h * dh + d] = dk * scale;
       dqkv[((long long)r * L + j) * 3 * D + 2 * D + h * dh + d] = dv;
     }
@@ -1087,19 +1128,23 @@ extern "C" int vs_attn_causal_bwd(const float* qkv, const uint8_t* key_mask, con
                                   int dh, void* stream) {
   VS_CHECK_ARG(qkv && dout && dqkv && scratch && R > 0 && L > 0 && H > 0 && dh > 0, "bad args");
   VS_CHECK_ARG(scratch_bytes >= vs_attn_causal_bwd_scratch_bytes(R, L, H), "scratch too small");
-  size_t smem = ((size_t)4 * L * (dh + 1) + 8 * L) * sizeof(float);
-  VS_CHECK_ARG(smem <= 160 * 1024, "sequence too long for the LDS-resident attention backward");
-  const size_t with_pds = smem + (size_t)2 * L * L * sizeof(float);
-  const int pds_in_lds = with_pds <= 156 * 1024;
-  if (pds_in_lds) smem = with_pds;
+  const size_t smem_q = ((size_t)(2 * L + 2 * AC_QC) * (dh + 1) + 8 * L) * sizeof(float);
+  const size_t smem_kv = ((size_t)2 * L * (dh + 1) + 2 * L * AC_QC) * sizeof(float);
+  VS_CHECK_ARG(smem_q <= 160 * 1024 && smem_kv <= 160 * 1024,
+               "sequence too long for the LDS-resident attention backward");
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)attn_causal_bwd_kernel,
+    (void)hipFuncSetAttribute((const void*)attn_causal_bwd_q_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)attn_causal_bwd_kv_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL(attn_causal_bwd_kernel, dim3(R * H), dim3(256), smem, (hipStream_t)stream, qkv,
-                     key_mask, dout, dqkv, (float*)scratch, L, H, dh, pds_in_lds);
+  const dim3 grid(R * H, (L + AC_QC - 1) / AC_QC);
+  hipLaunchKernelGGL(attn_causal_bwd_q_kernel, grid, dim3(256), smem_q, (hipStream_t)stream, qkv, key_mask,
+                     dout, dqkv, (float*)scratch, L, H, dh);
+  hipLaunchKernelGGL(attn_causal_bwd_kv_kernel, grid, dim3(256), smem_kv, (hipStream_t)stream, qkv, dout, dqkv,
+                     (const float*)scratch, L, H, dh);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }
