@@ -216,12 +216,14 @@ int vs_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, 
  * scale is sqrt(d_model) there, passed explicitly. */
 /* drop_mask (nullable): [B,H,L,L] fp32 holding 0 or 1/(1-p), the train-mode dropout of the
  * attention probabilities (transformer_code.py:48); probs keeps the pre-dropout softmax. */
+/* ld_qkv: row pitch (floats) of q, k, v -- and of dq, dk, dv -- e.g. 3*H*dh when they are the three column
+ * blocks of one fused projection buffer [B*L, 3*H*dh]; 0 = dense (H*dh).  o / dout are dense. */
 int vs_attn_small_fwd(const float* q, const float* k, const float* v, float* o, float* probs,
-                      const float* drop_mask, int B, int L, int H, int dh, float scale,
+                      const float* drop_mask, int B, int L, int H, int dh, int ld_qkv, float scale,
                       void* stream);
 int vs_attn_small_bwd(const float* q, const float* k, const float* v, const float* probs,
                       const float* dout, float* dq, float* dk, float* dv, const float* drop_mask,
-                      int B, int L, int H, int dh, float scale, void* stream);
+                      int B, int L, int H, int dh, int ld_qkv, float scale, void* stream);
 
 /* y = LayerNorm(x + r*rmask) (utils/transformer_code.py:21-30: x + dropout(layer(x))), fp32.
  * rmask (nullable): [rows,D] holding 0 or 1/(1-p).  bwd: dx = d(x), dr = dx*rmask. */

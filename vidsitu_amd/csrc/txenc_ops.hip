@@ -663,7 +663,7 @@ extern "C" int vs_linear_bwd_weight(const float* dy, const float* x, float* dw, 
 __global__ __launch_bounds__(256) void attn_small_fwd_kernel(const float* q, const float* k,
                                                              const float* v, float* o, float* probs,
                                                              const float* drop_mask, int L, int H,
-                                                             int dh, float inv_scale) {
+                                                             int dh, float inv_scale, int ld) {
   extern __shared__ __attribute__((aligned(16))) char smem_att[];
   float* qs = (float*)smem_att;  // [L][dh]
   float* ks = qs + L * dh;
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(const float* q, con
   const int D = H * dh;
   for (int i = threadIdx.x; i < L * dh; i += 256) {
     const int r = i / dh, d = i - r * dh;
-    const long long off = ((long long)b * L + r) * D + h * dh + d;
+    const long long off = ((long long)b * L + r) * ld + h * dh + d;  // ld: row pitch of q / k / v
     qs[i] = q[off];
     ks[i] = k[off];
     vs[i] = v[off];
@@ -715,12 +715,13 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(const float* q, con
 
 extern "C" int vs_attn_small_fwd(const float* q, const float* k, const float* v, float* o,
                                  float* probs, const float* drop_mask, int B, int L, int H, int dh,
-                                 float scale, void* stream) {
+                                 int ld_qkv, float scale, void* stream) {
   VS_CHECK_ARG(q && k && v && o, "null tensor");
   VS_CHECK_ARG(L >= 1 && L <= ATT_MAXL && dh >= 1 && dh <= 512, "L <= 16, dh <= 512");
+  VS_CHECK_ARG(ld_qkv == 0 || ld_qkv >= H * dh, "row pitch of q / k / v");
   const size_t smem = (size_t)(3 * L * dh + L * L) * sizeof(float);
   hipLaunchKernelGGL(attn_small_fwd_kernel, dim3(B * H), dim3(256), smem, (hipStream_t)stream, q, k,
-                     v, o, probs, drop_mask, L, H, dh, 1.0f / scale);
+                     v, o, probs, drop_mask, L, H, dh, 1.0f / scale, ld_qkv ? ld_qkv : H * dh);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }
@@ -729,7 +730,7 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* q, con
                                                              const float* v, const float* probs,
                                                              const float* dout, float* dq, float* dk,
                                                              float* dv, const float* drop_mask,
-                                                             int L, int H, int dh, float inv_scale) {
+                                                             int L, int H, int dh, float inv_scale, int ld) {
   extern __shared__ __attribute__((aligned(16))) char smem_att[];
   float* qs = (float*)smem_att;  // [L][dh]
   float* ks = qs + L * dh;
@@ -742,11 +743,11 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* q, con
   const int D = H * dh;
   for (int i = threadIdx.x; i < L * dh; i += 256) {
     const int r = i / dh, d = i - r * dh;
-    const long long off = ((long long)b * L + r) * D + h * dh + d;
+    const long long off = ((long long)b * L + r) * ld + h * dh + d;  // ld: pitch of q/k/v and dq/dk/dv
     qs[i] = q[off];
     ks[i] = k[off];
     vs[i] = v[off];
-    dos[i] = dout[off];
+    dos[i] = dout[((long long)b * L + r) * D + h * dh + d];
   }
   for (int e = threadIdx.x; e < L * L; e += 256) {
     ps[e] = probs[((long long)b * H + h) * L * L + e];
@@ -777,7 +778,7 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* q, con
       ak += dss[j * L + r] * qs[j * dh + d];   // dK[r] = sum_i dS[i][r] Q[i]
       av += ps[j * L + r] * ms[j * L + r] * dos[j * dh + d];  // dV[r] = sum_i P'[i][r] dO[i]
     }
-    const long long off = ((long long)b * L + r) * D + h * dh + d;
+    const long long off = ((long long)b * L + r) * ld + h * dh + d;
     dq[off] = aq;
     dk[off] = ak;
     dv[off] = av;
@@ -787,12 +788,14 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* q, con
 extern "C" int vs_attn_small_bwd(const float* q, const float* k, const float* v,
                                  const float* probs, const float* dout, float* dq, float* dk,
                                  float* dv, const float* drop_mask, int B, int L, int H, int dh,
-                                 float scale, void* stream) {
+                                 int ld_qkv, float scale, void* stream) {
   VS_CHECK_ARG(q && k && v && probs && dout && dq && dk && dv, "null tensor");
   VS_CHECK_ARG(L >= 1 && L <= ATT_MAXL && dh >= 1 && dh <= 512, "L <= 16, dh <= 512");
+  VS_CHECK_ARG(ld_qkv == 0 || ld_qkv >= H * dh, "row pitch of q / k / v");
   const size_t smem = (size_t)(4 * L * dh + 3 * L * L) * sizeof(float);
   hipLaunchKernelGGL(attn_small_bwd_kernel, dim3(B * H), dim3(256), smem, (hipStream_t)stream, q, k,
-                     v, probs, dout, dq, dk, dv, drop_mask, L, H, dh, 1.0f / scale);
+                     v, probs, dout, dq, dk, dv, drop_mask, L, H, dh, 1.0f / scale,
+                     ld_qkv ? ld_qkv : H * dh);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }
@@ -1154,6 +1157,40 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* logits,
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float lsum = 0.f;
   const float invR = 1.0f / (float)rows;
+  if (V <= 64 * 32) {
+    // the whole row in registers (32 per lane), every load in flight before the first use: the three
+    // passes below re-read memory in dependent little loops (28 us for 8 x 1564 on the step's critical path)
+    for (int row = wave; row < rows; row += 4) {
+      const float* lg = logits + (long long)row * V;
+      float v[32];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 32; ++e) {
+        const int j = lane + 64 * e;
+        const float t = lg[j < V ? j : 0];
+        v[e] = j < V ? t : -INFINITY;
+        mx = fmaxf(mx, v[e]);
+      }
+      mx = wave_reduce_max(mx);
+      float den = 0.f;
+#pragma unroll
+      for (int e = 0; e < 32; ++e) {
+        v[e] = expf(v[e] - mx);  // exp(-inf) = 0 for the padding
+        den += v[e];
+      }
+      den = wave_reduce_sum(den);
+      const int lab = (int)labels[row];
+      lsum += mx + logf(den) - lg[lab];
+      if (dlogits) {
+        const float inv = 1.0f / den;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+          const int j = lane + 64 * e;
+          if (j < V) dlogits[(long long)row * V + j] = (v[e] * inv - (j == lab ? 1.f : 0.f)) * invR;
+        }
+      }
+    }
+  } else
   for (int row = wave; row < rows; row += 4) {
     const float* lg = logits + (long long)row * V;
     float mx = -INFINITY;

@@ -564,7 +564,7 @@ def attn_small_fwd(q, k, v, n_heads, scale, drop_mask=None):
     o = torch.empty_like(q)
     probs = torch.empty((b, n_heads, l, l), dtype=torch.float32, device=q.device)
     _lib.call("vs_attn_small_fwd", _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(probs),
-              _ptr(drop_mask), b, l, n_heads, d // n_heads, float(scale), _stream())
+              _ptr(drop_mask), b, l, n_heads, d // n_heads, 0, float(scale), _stream())
     return o, probs
 
 
@@ -573,9 +573,31 @@ def attn_small_bwd(q, k, v, probs, do, n_heads, scale, drop_mask=None):
     b, l, d = q.shape
     dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
     _lib.call("vs_attn_small_bwd", _ptr(q), _ptr(k), _ptr(v), _ptr(probs), _ptr(do), _ptr(dq),
-              _ptr(dk), _ptr(dv), _ptr(drop_mask), b, l, n_heads, d // n_heads, float(scale),
+              _ptr(dk), _ptr(dv), _ptr(drop_mask), b, l, n_heads, d // n_heads, 0, float(scale),
               _stream())
     return dq, dk, dv
+
+
+def attn_small_fwd_fused(qkv, b, l, n_heads, scale, drop_mask=None):
+    """Self-attention on a fused projection buffer qkv f32 [b*l, 3d] (columns q | k | v) -> (o [b,l,d],
+    probs): the kernel reads the three column blocks in place (row pitch 3d)."""
+    d = qkv.shape[1] // 3
+    o = torch.empty((b, l, d), dtype=torch.float32, device=qkv.device)
+    probs = torch.empty((b, n_heads, l, l), dtype=torch.float32, device=qkv.device)
+    _lib.call("vs_attn_small_fwd", _ptr(qkv), _ptr(qkv[:, d:]), _ptr(qkv[:, 2 * d:]), _ptr(o), _ptr(probs),
+              _ptr(drop_mask), b, l, n_heads, d // n_heads, 3 * d, float(scale), _stream())
+    return o, probs
+
+
+def attn_small_bwd_fused(qkv, probs, do, b, l, n_heads, scale, drop_mask=None):
+    """-> dqkv f32 [b*l, 3d] (dq | dk | dv written in place, row pitch 3d)."""
+    do = _f32c(do)
+    d = qkv.shape[1] // 3
+    dqkv = torch.empty_like(qkv)
+    _lib.call("vs_attn_small_bwd", _ptr(qkv), _ptr(qkv[:, d:]), _ptr(qkv[:, 2 * d:]), _ptr(probs), _ptr(do),
+              _ptr(dqkv), _ptr(dqkv[:, d:]), _ptr(dqkv[:, 2 * d:]), _ptr(drop_mask), b, l, n_heads,
+              d // n_heads, 3 * d, float(scale), _stream())
+    return dqkv
 
 
 def add_layernorm_fwd(x, r, gamma, beta, eps=1e-5, rmask=None):

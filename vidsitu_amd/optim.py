@@ -92,24 +92,65 @@ class ParamArena:
         ALL linears by one launch instead of one small transpose per linear per step."""
         from torch import nn
 
+        from .transformer_code import MultiHead
+
         off_of = {id(p): off for p, off in zip(self.params, self.offsets)}
         rows, first = [], 0
-        mods = []
+        mods, fused_w = [], {}
+        # self-attention blocks whose three bias-free projections sit back to back in the arena (they do:
+        # registration order wq, wk, wv): ONE [3d, d] matrix for the forward / weight-gradient GEMMs and
+        # ONE transposed image [d][3d] for dx = dqkv @ W (transformer_code.FusedQKVAttnFn)
+        for mh in self.model.modules():
+            if not isinstance(mh, MultiHead):
+                continue
+            ws = [mh.wq.weight, mh.wk.weight, mh.wv.weight]
+            if any(id(w) not in off_of or w.dtype != torch.float32 or w.shape != ws[0].shape for w in ws) \
+                    or any(l.bias is not None for l in (mh.wq, mh.wk, mh.wv)):
+                continue
+            n, k = ws[0].shape
+            o0 = off_of[id(ws[0])]
+            if off_of[id(ws[1])] != o0 + n * k or off_of[id(ws[2])] != o0 + 2 * n * k:
+                continue
+            rows.append([o0, 3 * n, 1, k, first])
+            first += 3 * n * k
+            fused_w[id(ws[0])] = fused_w[id(ws[1])] = fused_w[id(ws[2])] = (mh, o0, n, k, ws)
         for m in self.model.modules():
-            if isinstance(m, nn.Linear) and id(m.weight) in off_of and m.weight.dtype == torch.float32:
+            if isinstance(m, nn.Linear) and id(m.weight) in off_of and m.weight.dtype == torch.float32 \
+                    and id(m.weight) not in fused_w:
                 n, k = m.weight.shape
                 rows.append([off_of[id(m.weight)], n, 1, k, first])
                 first += n * k
                 mods.append(m)
         if not rows:
             return
+        rows.sort(key=lambda r: r[0])  # (the batched kernels search by first index: keep it ascending)
+        first = 0
+        for r in rows:
+            r[4] = first
+            first += r[1] * r[3]
         self.wt_f32 = torch.zeros(self.numel, dtype=torch.float32, device=dev)
         self._lin_total = first
         self._lin_table = torch.tensor(rows, dtype=torch.int64, device=dev)
         self._lin_weights = [m.weight for m in mods]
-        for m, r in zip(mods, rows):
+        self._fused_qkv = []
+        off_row = {r[0]: r for r in rows}
+        for m in mods:
             n, k = m.weight.shape
-            m.weight._vs_wt = self.wt_f32[r[0]: r[0] + n * k].view(k, n)
+            o = off_of[id(m.weight)]
+            m.weight._vs_wt = self.wt_f32[o: o + n * k].view(k, n)
+        done = set()
+        for mh, o0, n, k, ws in fused_w.values():
+            if id(mh) in done:
+                continue
+            done.add(id(mh))
+            for w in ws:  # no per-projection image any more: LinearFn transposes on demand if ever asked
+                w._vs_wt = None
+                w._vs_wt_version = None
+            mh._qkv = {"w": self.data[o0: o0 + 3 * n * k].view(3 * n, k),
+                       "dw": self.grad[o0: o0 + 3 * n * k].view(3 * n, k),
+                       "wt": self.wt_f32[o0: o0 + 3 * n * k].view(k, 3 * n),
+                       "weights": ws, "grads": [w.grad for w in ws], "versions": [w._version for w in ws]}
+            self._fused_qkv.append(mh._qkv)
         ops.transpose_f32_batched(self.data, self.wt_f32, self._lin_table, self._lin_total)
         for w in self._lin_weights:
             w._vs_wt_version = w._version
@@ -196,6 +237,8 @@ class ParamArena:
             ops.transpose_f32_batched(self.data, self.wt_f32, self._lin_table, self._lin_total)
             for w in self._lin_weights:
                 w._vs_wt_version = w._version
+            for f in getattr(self, "_fused_qkv", ()):
+                f["versions"] = [w._version for w in f["weights"]]
 
     # The transposed (dgrad) weight images are only read by the backward pass: refresh them on a
     # side stream at the START of a step, beside the forward pass; the first dgrad joins.
@@ -227,34 +270,6 @@ class ArenaAdam:
         self.m = torch.zeros_like(arena.data)
         self.v = torch.zeros_like(arena.data)
         self.t = torch.zeros(1, dtype=torch.int32, device=arena.data.device)  # device-side: graph safe
-
-    def _adopt_linear_weights(self, dev):
-        """fp32 nn.Linear weights (heads, TxEncoder) get a transposed image [K][N] in a second fp32
-        arena with the same offsets: the operand of dx = dy @ W in LinearFn.backward, refreshed for
-        ALL linears by one launch instead of one small transpose per linear per step."""
-        from torch import nn
-
-        off_of = {id(p): off for p, off in zip(self.params, self.offsets)}
-        rows, first = [], 0
-        mods = []
-        for m in self.model.modules():
-            if isinstance(m, nn.Linear) and id(m.weight) in off_of and m.weight.dtype == torch.float32:
-                n, k = m.weight.shape
-                rows.append([off_of[id(m.weight)], n, 1, k, first])
-                first += n * k
-                mods.append(m)
-        if not rows:
-            return
-        self.wt_f32 = torch.zeros(self.numel, dtype=torch.float32, device=dev)
-        self._lin_total = first
-        self._lin_table = torch.tensor(rows, dtype=torch.int64, device=dev)
-        self._lin_weights = [m.weight for m in mods]
-        for m, r in zip(mods, rows):
-            n, k = m.weight.shape
-            m.weight._vs_wt = self.wt_f32[r[0]: r[0] + n * k].view(k, n)
-        ops.transpose_f32_batched(self.data, self.wt_f32, self._lin_table, self._lin_total)
-        for w in self._lin_weights:
-            w._vs_wt_version = w._version
 
     def zero_grad(self, fill=True):
         self.arena.zero_grad(fill)

@@ -39,7 +39,7 @@ class LinearFn(torch.autograd.Function):
         x2, w, y = ctx.saved_tensors
         dy2 = dy.reshape(-1, w.shape[0])
         if ctx.relu:
-            dy2 = dy2 * (y > 0).to(dy2.dtype)
+            dy2 = ops.relu_bwd(dy2, y)  # one launch (compare + cast + multiply were three)
         direct = ctx.w_param is not None and ctx.w_param.grad is not None and \
             (not ctx.has_bias or (ctx.b_param is not None and ctx.b_param.grad is not None))
         wt = ctx.w_wt  # the arena's transposed image (refreshed once per step)
@@ -74,6 +74,42 @@ class AttnSmallFn(torch.autograd.Function):
         dq, dk, dv = ops.attn_small_bwd(q.contiguous(), k.contiguous(), v.contiguous(), probs, do,
                                         ctx.n_heads, ctx.scale, drop_mask)
         return dq, dk, dv, None, None, None
+
+
+class FusedQKVAttnFn(torch.autograd.Function):
+    """Self-attention of one `MultiHead` as ONE autograd node: the q / k / v projections run as one GEMM on
+    the [3d, d] block the three weights form in the parameter arena (`ParamArena._adopt_linear_weights`
+    sets `MultiHead._qkv`), the attention kernels read / write the fused [rows, 3d] buffers in place.
+    Per layer this replaces 3 forward launches, 3 + 3 backward launches and two gradient adds by 1 + 1 + 1
+    -- the encoder runs on 8 tokens, every launch is pure latency on the critical path of the step."""
+
+    @staticmethod
+    def forward(ctx, x, fused, n_heads, scale, drop_mask):
+        b, l, d = x.shape
+        x2 = x.reshape(b * l, d)
+        qkv = ops.linear_fwd(x2, fused["w"], None, False)
+        o, probs = ops.attn_small_fwd_fused(qkv, b, l, n_heads, scale, drop_mask)
+        ctx.save_for_backward(x2, qkv, probs, drop_mask)
+        ctx.fused, ctx.n_heads, ctx.scale, ctx.bl = fused, n_heads, scale, (b, l)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        x2, qkv, probs, drop_mask = ctx.saved_tensors
+        b, l = ctx.bl
+        f = ctx.fused
+        dqkv = ops.attn_small_bwd_fused(qkv, probs, do, b, l, ctx.n_heads, ctx.scale, drop_mask)
+        wt = f["wt"] if all(w._version == v for w, v in zip(f["weights"], f["versions"])) else None
+        if wt is not None:
+            from .trunk import Conv3dP
+
+            if Conv3dP._wt_guard is not None:  # an asynchronous refresh of the images may be in flight
+                Conv3dP._wt_guard()
+        for w, g in zip(f["weights"], f["grads"]):  # re-attach if something replaced .grad
+            if w.grad is None or w.grad.data_ptr() != g.data_ptr():
+                w.grad = g
+        dx, _, _ = ops.linear_bwd(dqkv, x2, f["w"], need_dx=True, has_bias=False, dw_out=f["dw"], wt=wt)
+        return dx.reshape(b, l, -1), None, None, None, None
 
 
 class AddLayerNormFn(torch.autograd.Function):
@@ -129,11 +165,20 @@ class MultiHead(nn.Module):
         self.wv = nn.Linear(d_value, d_value, bias=False)
         self.wo = nn.Linear(d_value, d_key, bias=False)
         self.n_heads = n_heads
+        self._qkv = None  # set by ParamArena when wq / wk / wv sit back to back in the arena
 
     def forward(self, query, key, value):
+        p = self.attention.dropout.p
+        fused = self._qkv
+        if fused is not None and query is key and key is value and query.dim() == 3 and query.is_cuda \
+                and torch.is_grad_enabled() and query.requires_grad \
+                and fused["w"].data_ptr() == self.wq.weight.data_ptr():
+            b, l, _ = query.shape
+            mask = _masks.get((b, self.n_heads, l, l), p, query.device) if self.training and p > 0 else None
+            o = FusedQKVAttnFn.apply(query, fused, self.n_heads, self.attention.scale, mask)
+            return hip_linear(self.wo, o)
         q, k, v = hip_linear(self.wq, query), hip_linear(self.wk, key), hip_linear(self.wv, value)
         mask = None
-        p = self.attention.dropout.p
         if self.training and p > 0:  # transformer_code.py:48 dropout(softmax(...))
             b, l, _ = q.shape
             mask = _masks.get((b, self.n_heads, l, l), p, q.device)
