@@ -997,12 +997,14 @@ extern "C" int vs_maxpool_t_bwd(const void* dy, const uint8_t* idx, void* dx, in
 
 // ----------------------------------------------------------------------------
 // AdaptiveAvgPool3d(1) + concat: out[n][c_off+c] = mean_rows x[n,row,c]  (fp32 out)
-// block = 32 chunk-columns x 8 row lanes ; grid = (ceil(cpr/32), N)
+// block = 32 chunk-columns x 32 row lanes (1024 threads: the pool sits on the step's critical path between
+// the trunk and the heads; 8 row lanes walked 49 rows each) ; grid = (ceil(cpr/32), N)
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const uint16_t* x, float* out,
-                                                          long long rows, int C, int x_ld,
-                                                          int out_ld, int c_off) {
-  __shared__ float red[8][32][8];
+#define AVP_RL 32
+__global__ __launch_bounds__(1024) void avgpool_fwd_kernel(const uint16_t* x, float* out,
+                                                           long long rows, int C, int x_ld,
+                                                           int out_ld, int c_off) {
+  __shared__ float red[AVP_RL][32][8];
   const int cpr = C >> 3;
   const int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int cb = blockIdx.x * 32 + col;
@@ -1013,10 +1015,10 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const uint16_t* x, flo
   if (cb < cpr) {
     const uint16_t* base = x + n * rows * x_ld + cb * 8;
     long long r = rl;
-    for (; r + 24 < rows; r += 32) {  // four rows of loads in flight (same summation order)
+    for (; r + 3 * AVP_RL < rows; r += 4 * AVP_RL) {  // four rows of loads in flight
       uint4 q[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) q[u] = *(const uint4*)(base + (r + 8 * u) * x_ld);
+      for (int u = 0; u < 4; ++u) q[u] = *(const uint4*)(base + (r + AVP_RL * u) * x_ld);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         float v[8];
@@ -1025,7 +1027,7 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const uint16_t* x, flo
         for (int e = 0; e < 8; ++e) acc[e] += v[e];
       }
     }
-    for (; r < rows; r += 8) {
+    for (; r < rows; r += AVP_RL) {
       float v[8];
       unpack8_bf16(*(const uint4*)(base + r * x_ld), v);
 #pragma unroll
@@ -1035,21 +1037,18 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const uint16_t* x, flo
 #pragma unroll
   for (int e = 0; e < 8; ++e) red[rl][col][e] = acc[e];
   __syncthreads();
-  if (rl == 0 && cb < cpr) {
+  if (rl < 8 && cb < cpr) {  // thread (rl = e, col): one output channel, fixed order over the row lanes
     const float inv = 1.0f / (float)rows;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float s = 0.f;
-      for (int r = 0; r < 8; ++r) s += red[r][col][e];
-      out[n * out_ld + c_off + cb * 8 + e] = s * inv;
-    }
+    float s = 0.f;
+    for (int r = 0; r < AVP_RL; ++r) s += red[r][col][rl];
+    out[n * out_ld + c_off + cb * 8 + rl] = s * inv;
   }
 }
 
 extern "C" int vs_avgpool_fwd(const void* x, float* out, int N, int64_t rows_per_clip, int C,
                               int x_ld, int out_ld, int c_off, void* stream) {
   VS_CHECK_ARG(x && out && C % 8 == 0 && x_ld % 8 == 0, "bad args");
-  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3((C / 8 + 31) / 32, N), dim3(256), 0,
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3((C / 8 + 31) / 32, N), dim3(1024), 0,
                      (hipStream_t)stream, (const uint16_t*)x, out, (long long)rows_per_clip, C,
                      x_ld, out_ld, c_off);
   VS_CHECK_LAUNCH();
