@@ -258,6 +258,40 @@ def test_fseq_encoder_matches_oracle_forward_and_backward(dev):
     assert e < 5e-4, e
 
 
+@pytest.mark.parametrize("dec", ["txdec", "gpt2"])
+def test_sfpret_txed_vbarg_row_trains_and_generates(dec, dev):
+    """Selector row `sfpret_txed_vbarg` (`SFPreFeats_TxDec`: feature MLP -> decoder, no transformer encoder)."""
+    from vidsitu_amd import synth_data
+    from vidsitu_amd.extended_config import get_cfg
+    from vidsitu_amd.mdl_selector import get_mdl_loss_eval
+    from vidsitu_amd.optim import ArenaAdam, ParamArena
+
+    over = {"task_type": "vb_arg", "mdl.mdl_name": "sfpret_txed_vbarg", "mdl.tx_dec_type": dec,
+            "tx_dec.decoder_layers": 1, "synth.gpt2_vocab": 211, "gen.beam_size": 2, "gen.max_len_b": 6}
+    if dec == "gpt2":
+        over["mdl.gpt2_mdl_name"] = "gpt2-synth-tiny"
+    cfg = get_cfg(over)
+    comm = synth_data.make_comm(cfg)
+    sel = get_mdl_loss_eval(cfg)
+    torch.manual_seed(0)
+    mdl = sel["mdl"](cfg=cfg, comm=comm).to(dev).train()
+    batch = synth_data.synth_srl_batch(comm, bs=2, n_ev=5, seq_len=10, device=dev)
+    arena = ParamArena(mdl, adopt_conv=False)
+    opt = ArenaAdam(arena, lr=3e-4)
+    loss_fn = sel["loss"](cfg, comm)
+    losses = []
+    for _ in range(5):
+        opt.zero_grad()
+        loss = loss_fn(mdl(batch), batch)["loss"]
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    mdl.eval()
+    out = sel["evl"](cfg, comm, dev).forward_one_batch(mdl, batch)
+    assert len(out) == 2 and all(len(r["vb_output"]) == 5 for r in out)
+
+
 def test_old_encoder_plus_txdec_plugin_surface_trains(dev):
     """The paper's SF+TxE+TxD row with both fairseq-style halves: `tx_enc_type: old`, `tx_dec_type: txdec`."""
     from vidsitu_amd import synth_data

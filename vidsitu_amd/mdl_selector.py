@@ -4,7 +4,8 @@ Mirrors `vidsitu_code/mdl_selector.py:26-73` for the rows of the hot path; names
 outside it raise NotImplementedError exactly like an unknown name does upstream
 (:46,71,73).
 """
-from .mdl_sf_base import SFBase, SFBase_TxEnc, LossB, LossLambda, SFPreFeats_TxEncDec, Simple_TxDec
+from .mdl_sf_base import (SFBase, SFBase_TxEnc, LossB, LossLambda, SFPreFeats_TxDec, SFPreFeats_TxEncDec,
+                          Simple_TxDec)
 from .evl_vsitu import EvalB, EvalB_Gen
 
 
@@ -19,6 +20,8 @@ def get_mdl_loss_eval(cfg):
     elif cfg.task_type == "vb_arg":
         if cfg.mdl.mdl_name == "tx_only":
             return {"mdl": Simple_TxDec, "loss": LossLambda, "evl": EvalB_Gen}
+        if cfg.mdl.mdl_name == "sfpret_txed_vbarg":
+            return {"mdl": SFPreFeats_TxDec, "loss": LossLambda, "evl": EvalB_Gen}
         if cfg.mdl.mdl_name == "sfpret_txe_txd_vbarg":
             return {"mdl": SFPreFeats_TxEncDec, "loss": LossLambda, "evl": EvalB_Gen}
         raise NotImplementedError

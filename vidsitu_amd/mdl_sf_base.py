@@ -363,6 +363,24 @@ class Reorderer:
                           src_lengths=sel(encoder_out.src_lengths, 0))
 
 
+class SFPreFeats_TxDec(Simple_TxDec, Reorderer):
+    """mdl_sf_base.py:763-790 (`sfpret_txed_vbarg`): pre-extracted [B,5,head_dim] features -> vid_feat_encoder
+    -> EncoderOut [1, 5B, 1024] (no transformer encoder) -> decoder."""
+
+    def build_model(self):
+        super().build_model()
+        self.vid_feat_encoder = HipMLP(nn.Linear(get_head_dim(self.full_cfg), 1024), nn.ReLU(),
+                                       nn.Linear(1024, 1024))
+        self.use_encoder = True
+
+    def forward_encoder(self, inp):
+        frm_feats = inp["frm_feats"]
+        B, n_ev = inp["vseg_idx"].size(0), frm_feats.size(1)
+        out = self.vid_feat_encoder(frm_feats.float()).view(B * n_ev, 1, -1)
+        return EncoderOut(encoder_out=out.transpose(0, 1).contiguous(), encoder_padding_mask=None,
+                          encoder_embedding=None, encoder_states=None, src_tokens=None, src_lengths=None)
+
+
 class SFPreFeats_TxEncDec(Simple_TxDec, Reorderer):
     """mdl_sf_base.py:793-832: pre-extracted [B,5,2304] features -> vid_feat_encoder ->
     TxEncoderNew -> EncoderOut [1, 5B, 1024] (each event is its own one-token memory) -> decoder
