@@ -458,15 +458,20 @@ __global__ __launch_bounds__(64) void attn_decode_anc_kernel(const float* qkv, f
   for (int dd = lane; dd < DH; dd += 64) {
     float o = P[t] * src[2 * D + dd];
     const float* vb = vc + (long long)h * Lmax * DH + dd;
-    int j = 0;
-    for (; j + 4 <= t; j += 4) {
-      float vv[4];
+    // 16 rows of V in flight per step (4 made the loop a chain of ~t/4 memory latencies); positions past
+    // t - 1 are clamped and weighted 0, same summation order as a plain loop
+    for (int j = 0; j < t; j += 16) {
+      float vv[16], pp[16];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) vv[u] = vb[((long long)rowj[j + u] * H * Lmax + (j + u)) * DH];
+      for (int u = 0; u < 16; ++u) {
+        const int jj = j + u < t ? j + u : t - 1;
+        vv[u] = vb[((long long)rowj[jj] * H * Lmax + jj) * DH];
+        pp[u] = j + u < t ? P[jj] : 0.f;
+      }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) o += P[j + u] * vv[u];
+      for (int u = 0; u < 16; ++u)
+        if (j + u < t) o += pp[u] * vv[u];
     }
-    for (; j < t; ++j) o += P[j] * vb[((long long)rowj[j] * H * Lmax + j) * DH];
     const int kk = h * DH + dd;
     // opk: fragment-major output (vs_pack_rows_f32's layout), the x operand of vs_gemm_nt_f32_packed
     if (opk) out[(((long long)(r >> 4) * (D >> 4) + (kk >> 4)) * 64 + ((kk & 15) >> 2) * 16 + (r & 15)) * 4 + (kk & 3)] = o / sum;
