@@ -103,3 +103,23 @@ def lm_loss(logits, tokens, pad):
     nll = lse - lg[np.arange(len(lb)), lb]
     keep = lb != pad
     return float(nll[keep].mean())
+
+
+def greedy_generate(w, input_ids, max_length, pad, eos, n_head):
+    """huggingface `generate(num_beams=1, do_sample=False)` as `Simple_GPT2.forward_gen` /
+    `Simple_GPT2_New.forward_gen` call it (`mdl_sf_base.py:494-503, 577-585`): argmax of the last position,
+    rows that have emitted `eos` receive `pad` from then on, the loop ends when every row has or at
+    `max_length` tokens.  Restates transformers' published greedy loop (third-party, the reference pins
+    3.3.1: generation_utils.py `_generate_no_beam_search`); pinned by tests/golden/greedy_gpt2_tiny.npz.
+    -> i64 [R, <= max_length]."""
+    ids = np.asarray(input_ids, dtype=np.int64)
+    unfinished = np.ones(ids.shape[0], dtype=bool)
+    while ids.shape[1] < max_length:
+        logits = forward(w, ids, np.ones_like(ids), n_head)[:, -1]
+        nxt = logits.argmax(-1)
+        add = np.where(unfinished, nxt, pad)
+        ids = np.concatenate([ids, add[:, None]], axis=1)
+        unfinished &= add != eos
+        if not unfinished.any():
+            break
+    return ids

@@ -457,3 +457,75 @@ def test_gpt2_training_step_through_plugin_surface(dev):
         opt.step()
         losses.append(float(loss))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0] - 0.05, losses
+
+
+def _greedy_cases():
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "greedy_gpt2_tiny.npz"))
+    return z, range(int(z["n_cases"]))
+
+
+@pytest.mark.parametrize("ci", list(_greedy_cases()[1]))
+@pytest.mark.parametrize("sync_every", [1, 8])
+def test_greedy_generation_tokens_equal_transformers_golden(ci, sync_every, dev):
+    """`Simple_GPT2(_New).forward_gen`'s huggingface `generate` call (mdl_sf_base.py:494-503, 577-585):
+    token ids bit-exact against tests/golden/greedy_gpt2_tiny.npz (rows stopping at eos and padded, rows
+    running to max_length, a batch that stops early), whether the host tests every step or every 8th."""
+    from vidsitu_amd.hf_gpt2_fseq import GPT2LMHeadModelHip
+
+    z, _ = _greedy_cases()
+    vocab, n_pos, d, n_layer, n_head, seed, max_length, pad, eos = [int(v) for v in z[f"c{ci}_dims"]]
+    w = gpt2_ref.make_weights(vocab, n_pos, d, n_layer, seed)
+    m = GPT2LMHeadModelHip(n_layer, d, n_head, n_pos, vocab)
+    sd = {k: torch.from_numpy(v) for k, v in w.items()}
+    sd["lm_head.weight"] = sd["transformer.wte.weight"]
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    first = torch.from_numpy(z[f"c{ci}_first"]).to(dev)
+    got = m.generate_greedy(first, max_length, pad, eos, sync_every=sync_every).cpu().numpy()
+    want = z[f"c{ci}_out"]
+    assert got.shape == want.shape and (got == want).all()
+    assert (gpt2_ref.greedy_generate(w, z[f"c{ci}_first"], max_length, pad, eos, n_head) == want).all()
+
+
+def test_new_gpt2_only_row_trains_and_generates(dev):
+    """`get_mdl_loss_eval` row `new_gpt2_only` (Simple_GPT2_New, mdl_sf_base.py:560-587): LM loss against the
+    oracle, a few Adam steps lower it, `forward_gen` through EvalB_Gen returns [B, E, 1, <= 61] token ids
+    equal to the oracle's greedy continuation of the trained weights."""
+    from vidsitu_amd import synth_data
+    from vidsitu_amd.extended_config import get_cfg
+    from vidsitu_amd.mdl_selector import get_mdl_loss_eval
+    from vidsitu_amd.optim import ArenaAdam, ParamArena
+
+    cfg = get_cfg({"task_type": "vb_arg", "mdl.mdl_name": "new_gpt2_only", "mdl.gpt2_mdl_name": "gpt2-synth-tiny",
+                   "synth.gpt2_vocab": 97})
+    comm = synth_data.make_comm(cfg)
+    sel = get_mdl_loss_eval(cfg)
+    torch.manual_seed(0)
+    mdl = sel["mdl"](cfg=cfg, comm=comm).to(dev)
+    assert type(mdl).__name__ == "Simple_GPT2_New"
+    batch = synth_data.synth_srl_batch(comm, bs=2, n_ev=5, seq_len=12, device=dev)
+    pad, eos = comm.gpt2_hf_tok.pad_token_id, comm.gpt2_hf_tok.eos_token_id
+    out = mdl.eval()(batch)
+    want = gpt2_ref.lm_loss(out["logits"].cpu().numpy(), batch["seq_out_by_ev"].view(10, 12).cpu().numpy(), pad)
+    assert abs(float(out["loss"]) - want) < 1e-4 * max(1.0, abs(want))
+    mdl.train()
+    loss_fn = sel["loss"](cfg, comm)
+    arena = ParamArena(mdl, adopt_conv=False)
+    opt = ArenaAdam(arena, lr=3e-3)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        loss = loss_fn(mdl(batch), batch)["loss"]
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0] - 0.05, losses
+    mdl.eval()
+    sents = mdl.forward_gen(batch)
+    assert sents.shape[:3] == (2, 5, 1) and sents.shape[3] <= 61
+    w = {k: v.detach().cpu().numpy() for k, v in mdl.gpt2_mdl.state_dict().items() if k != "lm_head.weight"}
+    first = batch["seq_out_by_ev"][:, :, 0, :1].reshape(10, 1).cpu().numpy()
+    ref = gpt2_ref.greedy_generate(w, first, 61, pad, eos, 4)
+    assert sents.view(10, -1).shape == ref.shape and (sents.view(10, -1).cpu().numpy() == ref).all()
+    res = sel["evl"](cfg, comm, dev).forward_one_batch(mdl, batch)
+    assert len(res) == 2 and set(res[0]["vb_output"]) == {f"Ev{i}" for i in range(1, 6)}

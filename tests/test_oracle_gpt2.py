@@ -124,3 +124,18 @@ def test_beam_scores_are_length_normalised_sums_of_token_log_probs():
                 lp = beam_ref.log_softmax((table[prev2, seq[i - 1]] + 0.1 * sent)[None])[0]
                 s += lp[seq[i]]
             assert np.isclose(s / len(h["tokens"]), h["score"], atol=1e-4)
+
+
+def test_greedy_generation_oracle_matches_transformers_golden():
+    """oracle.gpt2_ref.greedy_generate against huggingface `generate` outputs
+    (tests/golden/gen_gpt2_greedy_golden.py): eos -> pad fill, max_length, early stop."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "greedy_gpt2_tiny.npz"))
+    shorter = 0
+    for ci in range(int(z["n_cases"])):
+        vocab, n_pos, d, n_layer, n_head, seed, max_length, pad, eos = [int(v) for v in z[f"c{ci}_dims"]]
+        w = gpt2_ref.make_weights(vocab, n_pos, d, n_layer, seed)
+        got = gpt2_ref.greedy_generate(w, z[f"c{ci}_first"], max_length, pad, eos, n_head)
+        want = z[f"c{ci}_out"]
+        assert got.shape == want.shape and (got == want).all()
+        shorter += want.shape[1] < max_length
+    assert shorter >= 1  # the fixture holds a batch that stops before max_length

@@ -230,6 +230,43 @@ class GPT2LMHeadModelHip(nn.Module):
         hf = ops.layernorm_fwd_packed(h, self.P("transformer.ln_f.weight"), self.P("transformer.ln_f.bias"), 1e-5)
         return ops.gemm_nt_packed(hf, self._wp("transformer.wte.weight", transposed=False), rows, v, d)
 
+    @torch.no_grad()
+    def generate_greedy(self, input_ids, max_length, pad_token_id, eos_token_id, sync_every=8):
+        """huggingface `generate(num_beams=1, do_sample=False, use_cache=True)` as `Simple_GPT2.forward_gen`
+        calls it (mdl_sf_base.py:494-503, 577-585): argmax of the newest position on the cached decode
+        step, rows that have emitted eos receive pad from then on, and the result ends at the step where
+        the last row finished (or at max_length).  The all-finished test reads the device only every
+        `sync_every` steps; columns generated past the stopping step are cut off afterwards, so the result
+        is the one of a loop testing after every token.  -> i64 [rows, <= max_length]"""
+        rows, plen = input_ids.shape
+        if not input_ids.is_cuda:
+            raise ops._lib.VsError("GPT-2 runs on the HIP kernels only (GPU tensor required)")
+        if not 1 <= plen <= max_length <= self.n_positions:
+            raise ops._lib.VsError(f"prompt {plen} / max_length {max_length} / n_positions {self.n_positions}")
+        state = KVCacheState()
+        out = torch.full((rows, max_length), pad_token_id, dtype=torch.int64, device=input_ids.device)
+        out[:, :plen] = input_ids
+        unfinished = torch.ones(rows, dtype=torch.bool, device=input_ids.device)
+        alive = torch.ones(max_length, dtype=torch.bool, device=input_ids.device)  # any row unfinished after col t
+        logits = None
+        for t in range(plen):  # the prompt, one cached position at a time (prompts here are one token)
+            logits = self.forward_step(input_ids[:, t].contiguous(), state, max_len=max_length)
+        end = max_length
+        for t in range(plen, max_length):
+            _, nxt = ops.softmax_topk(logits, 1)
+            add = torch.where(unfinished, nxt[:, 0], torch.full_like(nxt[:, 0], pad_token_id))
+            out[:, t] = add
+            unfinished = unfinished & add.ne(eos_token_id)
+            alive[t] = unfinished.any()
+            if (t - plen) % sync_every == sync_every - 1 or t == max_length - 1:
+                dead = (~alive[plen:t + 1]).nonzero()
+                if dead.numel():
+                    end = plen + int(dead[0]) + 1
+                    break
+            if t + 1 < max_length:
+                logits = self.forward_step(add, state, max_len=max_length)
+        return out[:, :end].contiguous()
+
     # ---- training (teacher-forced pass with saved activations + manual backward) ------------
     def forward_train(self, tokens, attention_mask=None):
         """Like forward_logits, keeping what the backward needs (fp32, no recompute except the

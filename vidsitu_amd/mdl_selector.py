@@ -5,7 +5,7 @@ outside it raise NotImplementedError exactly like an unknown name does upstream
 (:46,71,73).
 """
 from .mdl_sf_base import (SFBase, SFBase_TxEnc, LossB, LossLambda, SFPreFeats_TxDec, SFPreFeats_TxEncDec,
-                          Simple_TxDec)
+                          Simple_GPT2_New, Simple_TxDec)
 from .evl_vsitu import EvalB, EvalB_Gen
 
 
@@ -18,6 +18,8 @@ def get_mdl_loss_eval(cfg):
             return {"mdl": SFBase_TxEnc, "loss": LossB, "evl": EvalB}
         raise NotImplementedError
     elif cfg.task_type == "vb_arg":
+        if cfg.mdl.mdl_name == "new_gpt2_only":
+            return {"mdl": Simple_GPT2_New, "loss": LossLambda, "evl": EvalB_Gen}
         if cfg.mdl.mdl_name == "tx_only":
             return {"mdl": Simple_TxDec, "loss": LossLambda, "evl": EvalB_Gen}
         if cfg.mdl.mdl_name == "sfpret_txed_vbarg":

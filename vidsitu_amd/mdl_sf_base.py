@@ -22,7 +22,8 @@ from torch import nn
 from . import ops
 from .trunk import VideoTrunk
 from .transformer_code import Transformer as TxCodeEnc, LinearFn
-from .hf_gpt2_fseq import HuggingFaceGPT2Decoder, lm_loss as gpt2_lm_loss
+from .hf_gpt2_fseq import (GPT2_DIMS, GPT2LMHeadModelHip, HuggingFaceGPT2Decoder, _GPT2TrainFn,
+                           lm_loss as gpt2_lm_loss)
 from .fseq_txdec import TxDecoderReal
 
 EncoderOut = namedtuple(
@@ -281,6 +282,59 @@ def TxDecoder(full_cfg, comm):
     if full_cfg.mdl.tx_dec_type == "txdec":  # fairseq TransformerDecoder
         return TxDecoderReal(full_cfg, comm)
     raise NotImplementedError(f"tx_dec_type={full_cfg.mdl.tx_dec_type}")
+
+
+class Simple_GPT2(nn.Module):
+    """mdl_sf_base.py:467-532: the text-only baseline -- GPT-2 fine-tuned as a language model over the SRL
+    token sequence of every event (first annotation), greedy generation from its first token."""
+
+    GEN_MAX_LENGTH = 60  # mdl_sf_base.py:497
+
+    def __init__(self, cfg, comm):
+        super().__init__()
+        self.full_cfg = cfg
+        self.cfg = cfg.mdl
+        self.comm = comm
+        self.build_model()
+
+    def build_model(self):
+        self.gpt2_mdl = GPT2LMHeadModelHip(*GPT2_DIMS[self.cfg.gpt2_mdl_name])
+        self.voc_size = len(self.comm.gpt2_hf_tok)
+        self.gpt2_mdl.resize_token_embeddings(self.voc_size)
+        self.pad_index = self.comm.gpt2_hf_tok.pad_token_id
+        self.bos_index = self.comm.gpt2_hf_tok.eos_token_id
+
+    def _first_tokens(self, inp):
+        src_toks1 = inp["seq_out_by_ev"][:, :, [0], :]
+        B, num_ev, num_seq_eg, seq_len = src_toks1.shape
+        return src_toks1.reshape(B * num_ev, num_seq_eg * seq_len)[..., :1].contiguous(), (B, num_ev, num_seq_eg)
+
+    def forward_gen(self, inp, *args):
+        inp_ids, (B, num_ev, num_seq_eg) = self._first_tokens(inp)
+        # huggingface's generate stops a row at the model config's eos id, the tokenizer's eos (= bos here)
+        out_sents = self.gpt2_mdl.generate_greedy(inp_ids, self.GEN_MAX_LENGTH, self.pad_index, self.bos_index)
+        return out_sents.view(B, num_ev, num_seq_eg, -1)
+
+    def forward(self, inp):
+        src_toks1 = inp["seq_out_by_ev"][:, :, [0], :]
+        src_attn1 = inp["seq_out_lens_by_ev"][:, :, [0], :]
+        B, num_ev, num_seq_eg, seq_len = src_toks1.shape
+        assert num_seq_eg == 1
+        src_toks = src_toks1.reshape(B * num_ev, num_seq_eg * seq_len)
+        src_attn_mask = src_attn1.reshape(B * num_ev, num_seq_eg * seq_len).ne(0)
+        if self.training and torch.is_grad_enabled():
+            tick = torch.zeros(1, device=src_toks.device, requires_grad=True)
+            logits = _GPT2TrainFn.apply(self.gpt2_mdl, src_toks, src_attn_mask, tick)
+        else:
+            logits = self.gpt2_mdl.forward_logits(src_toks, src_attn_mask)
+        return {"loss": gpt2_lm_loss(logits, src_toks, self.pad_index), "logits": logits}
+
+
+class Simple_GPT2_New(Simple_GPT2):
+    """mdl_sf_base.py:560-587 (`new_gpt2_only`): the same model; generation runs to 60 tokens past the prompt.
+    (`GPT2_New.prepare_inputs_for_generation`'s `vid_emb` prefix is never passed by this caller.)"""
+
+    GEN_MAX_LENGTH = 60 + 1  # mdl_sf_base.py:579: 60 + inp_ids.size(-1), prompts are one token
 
 
 class Simple_TxDec(nn.Module):
