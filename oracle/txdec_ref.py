@@ -181,3 +181,12 @@ def encoder_forward(w, token_embeddings, src_tokens, pad, n_head, n_layer):
                      w[q + "fc2.bias"])
         x = F.layer_norm(x + f, (d,), w[q + "final_layer_norm.weight"], w[q + "final_layer_norm.bias"])
     return x.transpose(0, 1)
+
+
+def encoder_conc_forward(w, token_embeddings, src_tokens, pad, n_head, n_layer):
+    """`TxEncoderNew_Conc.forward` (`mdl_sf_base.py:402-420`): cat(features, encoder output) ->
+    Linear-ReLU-Linear (`orig_tx_out_comb.0/.2`) -> [L, B, D]."""
+    enc = encoder_forward(w, token_embeddings, src_tokens, pad, n_head, n_layer).transpose(0, 1)
+    h = F.relu(F.linear(torch.cat([token_embeddings, enc], dim=-1), w["orig_tx_out_comb.0.weight"],
+                        w["orig_tx_out_comb.0.bias"]))
+    return F.linear(h, w["orig_tx_out_comb.2.weight"], w["orig_tx_out_comb.2.bias"]).transpose(0, 1)

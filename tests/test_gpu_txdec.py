@@ -258,6 +258,54 @@ def test_fseq_encoder_matches_oracle_forward_and_backward(dev):
     assert e < 5e-4, e
 
 
+def test_conc_encoder_matches_oracle_forward_and_backward(dev):
+    """`TxEncoderNew_Conc` (`tx_enc_type: new_conc`, mdl_sf_base.py:395-420): encoder output concatenated with
+    the features and mixed by a 2-layer MLP -- output, feature gradient and every parameter gradient."""
+    from types import SimpleNamespace
+    from vidsitu_amd.mdl_sf_base import TxEncoderNew_Conc
+
+    d, ffn, heads, nl, pad = 128, 256, 8, 2, 96
+
+    class _T:
+        pad_token_id = pad
+
+        def __len__(self):
+            return 97
+
+    cfg = SimpleNamespace(tx_dec=SimpleNamespace(encoder_embed_dim=d, encoder_ffn_embed_dim=ffn,
+                                                 encoder_attention_heads=heads, encoder_layers=nl, dropout=0.0))
+    enc = TxEncoderNew_Conc(cfg, SimpleNamespace(gpt2_hf_tok=_T()))
+    w = txdec_ref.make_encoder_weights(d, ffn, nl, seed=13)
+    g = torch.Generator().manual_seed(5)
+    w.update({"orig_tx_out_comb.0.weight": torch.randn(d, 2 * d, generator=g) / (2 * d) ** 0.5,
+              "orig_tx_out_comb.0.bias": torch.randn(d, generator=g) * 0.1,
+              "orig_tx_out_comb.2.weight": torch.randn(d, d, generator=g) / d ** 0.5,
+              "orig_tx_out_comb.2.bias": torch.randn(d, generator=g) * 0.1})
+    missing, unexpected = enc.load_state_dict(w, strict=False)
+    assert not unexpected and missing == ["embed_tokens.weight"]
+    enc = enc.to(dev).train()
+    emb = torch.randn(4, 5, d, generator=torch.Generator().manual_seed(2))
+    wg = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    emb_ref = emb.clone().requires_grad_(True)
+    out_ref = txdec_ref.encoder_conc_forward(wg, emb_ref, emb_ref[..., 0].detach(), pad, heads, nl)
+    g_out = torch.randn(out_ref.shape, generator=torch.Generator().manual_seed(3))
+    (out_ref * g_out).sum().backward()
+    emb_d = emb.to(dev).requires_grad_(True)
+    out = enc(src_tokens=emb_d[..., 0].detach(), token_embeddings=emb_d)
+    assert tuple(out.encoder_out.shape) == (5, 4, d) and out.encoder_padding_mask is None
+    err = float((out.encoder_out.detach().cpu() - out_ref.detach()).abs().max()) / float(out_ref.abs().max())
+    assert err < 2e-4, err
+    (out.encoder_out * g_out.to(dev)).sum().backward()
+    sd = dict(enc.named_parameters())
+    floor = 1e-3 * max(float(v.grad.abs().max()) for v in wg.values())
+    for name, ref in wg.items():
+        gr = sd[name].grad.cpu()
+        e = float((gr - ref.grad).abs().max()) / max(float(ref.grad.abs().max()), floor)
+        assert e < 5e-4, (name, e)
+    e = float((emb_d.grad.cpu() - emb_ref.grad).abs().max()) / float(emb_ref.grad.abs().max())
+    assert e < 5e-4, e
+
+
 @pytest.mark.parametrize("dec", ["txdec", "gpt2"])
 def test_sfpret_txed_vbarg_row_trains_and_generates(dec, dev):
     """Selector row `sfpret_txed_vbarg` (`SFPreFeats_TxDec`: feature MLP -> decoder, no transformer encoder)."""
@@ -292,15 +340,17 @@ def test_sfpret_txed_vbarg_row_trains_and_generates(dec, dev):
     assert len(out) == 2 and all(len(r["vb_output"]) == 5 for r in out)
 
 
-def test_old_encoder_plus_txdec_plugin_surface_trains(dev):
-    """The paper's SF+TxE+TxD row with both fairseq-style halves: `tx_enc_type: old`, `tx_dec_type: txdec`."""
+@pytest.mark.parametrize("enc_type", ["old", "new_conc"])
+def test_old_encoder_plus_txdec_plugin_surface_trains(enc_type, dev):
+    """The paper's SF+TxE+TxD row with both fairseq-style halves: `tx_enc_type: old` / `new_conc`,
+    `tx_dec_type: txdec`."""
     from vidsitu_amd import synth_data
     from vidsitu_amd.extended_config import get_cfg
     from vidsitu_amd.mdl_selector import get_mdl_loss_eval
     from vidsitu_amd.optim import ArenaAdam, ParamArena
 
     cfg = get_cfg({"task_type": "vb_arg", "mdl.mdl_name": "sfpret_txe_txd_vbarg", "mdl.tx_dec_type": "txdec",
-                   "mdl.tx_enc_type": "old", "tx_dec.decoder_layers": 1, "tx_dec.encoder_layers": 2,
+                   "mdl.tx_enc_type": enc_type, "tx_dec.decoder_layers": 1, "tx_dec.encoder_layers": 2,
                    "synth.gpt2_vocab": 211})
     comm = synth_data.make_comm(cfg)
     sel = get_mdl_loss_eval(cfg)

@@ -24,7 +24,7 @@ from .trunk import VideoTrunk
 from .transformer_code import Transformer as TxCodeEnc, LinearFn
 from .hf_gpt2_fseq import (GPT2_DIMS, GPT2LMHeadModelHip, HuggingFaceGPT2Decoder, _GPT2TrainFn,
                            lm_loss as gpt2_lm_loss)
-from .fseq_txdec import TxDecoderReal
+from .fseq_txdec import TxDecoderReal, TxEncoderOld
 
 EncoderOut = namedtuple(
     "EncoderOut",
@@ -248,12 +248,31 @@ class TxEncoderNew(TxCodeEnc):
                           src_tokens=None, src_lengths=None)
 
 
+class TxEncoderNew_Conc(TxEncoderOld):
+    """mdl_sf_base.py:395-420 (`tx_enc_type: new_conc`): the fairseq-style encoder's output concatenated with
+    its input features and mixed by Linear(2d, d)-ReLU-Linear(d, d) (d = 1024 upstream)."""
+
+    def __init__(self, cfg, comm):
+        super().__init__(cfg, comm)
+        d = cfg.tx_dec.encoder_embed_dim
+        self.orig_tx_out_comb = HipMLP(nn.Linear(2 * d, d), nn.ReLU(), nn.Linear(d, d))
+
+    def forward(self, src_tokens=None, src_lengths=None, return_all_hiddens=False, token_embeddings=None):
+        tx_out = super().forward(src_tokens=src_tokens, src_lengths=src_lengths,
+                                 return_all_hiddens=return_all_hiddens, token_embeddings=token_embeddings)
+        enc_out = tx_out.encoder_out.transpose(0, 1)  # B x T x C
+        enc_out3 = self.orig_tx_out_comb(torch.cat([token_embeddings.float(), enc_out], dim=-1))
+        return EncoderOut(encoder_out=enc_out3.transpose(0, 1).contiguous(), encoder_padding_mask=None,
+                          encoder_embedding=None, encoder_states=None, src_tokens=None, src_lengths=None)
+
+
 def TxEncoder(cfg, comm):
     if cfg.mdl.tx_enc_type == "new":
         return TxEncoderNew(cfg, comm)
     if cfg.mdl.tx_enc_type == "old":  # fairseq TransformerEncoder (SURVEY.md section 8f, row f3)
-        from .fseq_txdec import TxEncoderOld
         return TxEncoderOld(cfg, comm)
+    if cfg.mdl.tx_enc_type == "new_conc":
+        return TxEncoderNew_Conc(cfg, comm)
     raise NotImplementedError(f"tx_enc_type={cfg.mdl.tx_enc_type}")
 
 
