@@ -1,4 +1,5 @@
-"""Per-unit train-mode diagnostics: HIP trunk vs oracle (run on the GPU box)."""
+"""Per-unit train-mode diagnostics: HIP trunk vs oracle (checker script, run by hand on the GPU box:
+python tests/diag_train.py; lives under tests/ because it imports the oracle)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
