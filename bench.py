@@ -485,8 +485,18 @@ def main():
         def fam(name, v):
             n, ms, fl, by, bound = v
             out = {"kernel": name, "launches_per_step": n // reps,
-                   "ms_per_step": round(ms / reps, 3), "avg_launch_us": round(ms / n * 1e3, 2),
-                   "bound": bound}
+                   "ms_per_step": round(ms / reps, 3), "avg_launch_us": round(ms / n * 1e3, 2)}
+            if bound == "mfma" and by > 0:
+                # which roof binds a GEMM-shaped family is its arithmetic intensity against the ridge
+                # (2500 TFLOP/s / 8 TB/s = 312 flop/B): the 1x1x1 convolutions of the early stages and
+                # most weight gradients sit below it -- their roof is HBM, not the matrix cores
+                inten = fl / by
+                out["flop_per_byte"] = round(inten, 1)
+                out["mfma_frac"] = round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)
+                out["hbm_frac"] = round(by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+                if inten < PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
+                    bound = "hbm"
+            out["bound"] = bound
             if bound == "mfma":
                 ach = fl / (ms * 1e-3) / 1e12
                 out.update({"achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -514,9 +524,11 @@ def main():
                         "instrumented eager pass on one stream (the timed region replays a hipGraph "
                         "whose pathway / wgrad branches run concurrently)")
         conv = [v for k, v in fams if v[4] == "mfma"]
-        cms, cfl = sum(v[1] for v in conv), sum(v[2] for v in conv)
+        cms, cfl, cby = sum(v[1] for v in conv), sum(v[2] for v in conv), sum(v[3] for v in conv)
         roof["all_conv"] = {"ms_per_step": round(cms / reps, 3),
-                            "achieved_tflops": round(cfl / (cms * 1e-3) / 1e12, 2)}
+                            "achieved_tflops": round(cfl / (cms * 1e-3) / 1e12, 2),
+                            "algorithmic_gbs": round(cby / (cms * 1e-3) / 1e9, 1),
+                            "flop_per_byte": round(cfl / max(cby, 1), 1)}
         roof["families"] = [fam(k, v) for k, v in fams[:16]]
 
     cpu = None
