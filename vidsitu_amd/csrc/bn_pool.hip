@@ -161,6 +161,12 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
   __shared__ double sh_q[32][33];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
+  // per-channel parameters requested up front (branch-free, clamped), so that their latency runs beside
+  // the partial sums' instead of after the reduction
+  const int cc = c < C ? c : C - 1;
+  const float ga_c = gamma[cc], be_c = beta[cc];
+  const float rm_c = (running_mean ? running_mean : gamma)[cc];
+  const float rv_c = (running_var ? running_var : gamma)[cc];
   double s = 0.0, q = 0.0;
   if (c < C) {
     int p = sl;
@@ -197,20 +203,20 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
       double var = tq / count - mean * mean;
       if (var < 0.0) var = 0.0;
       const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-      sc = gamma[c] * invstd;
-      sf = beta[c] - (float)mean * sc;
+      sc = ga_c * invstd;
+      sf = be_c - (float)mean * sc;
       if (mean_out) mean_out[c] = (float)mean;
       if (invstd_out) invstd_out[c] = invstd;
       if (running_mean) {
         const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        running_mean[c] = (1.f - momentum) * rm_c + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * rv_c + momentum * (float)unb;
       }
     } else {  // eval: fold the running statistics
-      const float invstd = 1.0f / sqrtf(running_var[c] + eps);
-      sc = gamma[c] * invstd;
-      sf = beta[c] - running_mean[c] * sc;
-      if (mean_out) mean_out[c] = running_mean[c];
+      const float invstd = 1.0f / sqrtf(rv_c + eps);
+      sc = ga_c * invstd;
+      sf = be_c - rm_c * sc;
+      if (mean_out) mean_out[c] = rm_c;
       if (invstd_out) invstd_out[c] = invstd;
     }
     scale[c] = sc;
