@@ -83,7 +83,7 @@ class EntryProbe:
         probe = self
         import ctypes as C
 
-        def conv_label(d, dgrad):
+        def conv_label(d, dgrad, bnb=False):
             out = (C.c_int * 5)()
             lib.vs_conv_plan(C.byref(d), dgrad, out)
             bm, bn, ring, S, direct = list(out)
@@ -97,13 +97,13 @@ class EntryProbe:
                 return f"conv_direct_kernel<{1 if ncols <= 16 else 2}, {min((K + 31) // 32, 5)}, {mode}>"
             wm, wn = _WAVES[(bm, bn)]
             fast = "true" if taps <= 31 else "false"
-            tail = f", 0, {ring}" if taps <= 31 else ""
+            tail = f", 0, {ring}, {'true' if bnb else 'false'}" if taps <= 31 else ""
             name = f"conv_igemm_kernel<{bm}, {bn}, {wm}, {wn}, {mode}, {fast}{tail}>"
             return name + (f" +splitk{S}" if S > 1 else "")
 
         def describe(name, a):
             """-> (family label, bound, algorithmic flops, algorithmic bytes)"""
-            if name in ("vs_conv_fwd", "vs_conv_dgrad", "vs_conv_wgrad"):
+            if name in ("vs_conv_fwd", "vs_conv_dgrad", "vs_conv_wgrad", "vs_conv_dgrad_bnstats"):
                 d = a[3]._obj
                 taps = d.kT * d.kH * d.kW
                 mo = d.N * d.To * d.Ho * d.Wo
@@ -114,6 +114,8 @@ class EntryProbe:
                     return "conv_wgrad (conv_wgrad_ring_kernel | conv_wgrad_kernel, + wgrad_reduce_kernel)", "mfma", flops, byts
                 if name == "vs_conv_fwd" and (d.flags & 2):
                     byts += 2.0 * mo * d.Cout
+                if name == "vs_conv_dgrad_bnstats":  # + the producer's saved conv output, read by the epilogue
+                    return conv_label(d, 1, True), "mfma", flops, byts + 2.0 * mi * d.Cin
                 return conv_label(d, 1 if name == "vs_conv_dgrad" else 0), "mfma", flops, byts
             if name in ("vs_stem_conv_fwd", "vs_stem_conv_wgrad"):
                 n, t, h, w, cout, kt = [_v(x) for x in a[3:9]]

@@ -403,3 +403,63 @@ def test_tiled_batched_transposes_equal_the_per_element_kernels(dev):
             n = cout * taps * cin
             want = src[o:o + n].view(cout, taps, cin).permute(2, 1, 0).contiguous().view(-1)
             assert torch.equal(b[o:o + n], want)
+
+
+BNS_CASES = [CASES[i] for i in (0, 1, 4, 5, 6, 7, 9, 10, 11, 14, 15)] + STRIDED[:4] + [STRIDED[5]]
+
+
+@pytest.mark.parametrize("case", BNS_CASES, ids=[c[0] for c in BNS_CASES])
+def test_dgrad_emits_the_producer_bn_backward_sums(case, dev):
+    """vs_conv_dgrad_bnstats: dx bitwise the plain dgrad, and the per-tile partial sums add up to what
+    vs_bn_bwd_reduce (recomputed-mask mode) computes from that dx and the producer's saved conv output --
+    pointwise / gathered / strided dgrads (stride classes incl. classes no tap reaches), every tile shape
+    the path is built for, register pipeline and LDS-DMA ring."""
+    from vidsitu_amd import ops
+    import ctypes as C
+
+    x, w, k, s, p = _mk(case, seed=41)
+    cin = x.shape[1]
+    y = F.conv3d(x, w, stride=s, padding=p)
+    dy = rb(torch.randn(y.shape, generator=torch.Generator().manual_seed(42)))
+    wt = ops.weight_transpose(to_w(w, dev))
+    dya = to_act(dy, dev)
+    g = torch.Generator().manual_seed(43)
+    bn_y = to_act(rb(torch.randn(x.shape, generator=g)), dev)  # the producer's saved conv output
+    mean = (torch.randn(cin, generator=g) * 0.2).to(dev)
+    invstd = (torch.rand(cin, generator=g) + 0.5).to(dev)
+    gamma = (torch.randn(cin, generator=g)).to(dev)
+    beta = (torch.randn(cin, generator=g) * 0.3).to(dev)
+    plain = ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p)
+    rows, c = ops.act_rows(plain), cin
+    nblk = ops._lib.load().vs_bn_bwd_reduce_rows(rows, c)
+    if nblk > 0:
+        want = torch.empty((nblk, 2, c), dtype=torch.float32, device=dev)
+        ops._lib.call("vs_bn_bwd_reduce", ops._ptr(plain), None, ops._ptr(bn_y), ops._ptr(mean), ops._ptr(invstd),
+                      ops._ptr(gamma), ops._ptr(beta), ops._ptr(want), rows, c, ops.act_ld(plain), 0,
+                      ops.act_ld(bn_y), 1, ops._stream())
+        want, tol = want.double().sum(0).cpu(), 1e-5
+    else:  # the reduce kernel wants C/8 a power of two: torch restatement (mask ties may round differently)
+        v = lambda t: t.view(1, -1, 1, 1, 1)
+        xh = (bn_y.float() - v(mean)) * v(invstd)
+        gm = torch.where(xh * v(gamma) + v(beta) > 0, plain.float(), torch.zeros((), device=dev))
+        want = torch.stack([gm.double().sum((0, 2, 3, 4)), (gm * xh).double().sum((0, 2, 3, 4))]).cpu()
+        tol = 2e-3
+    scale = float(want.abs().max())
+    tried = 0
+    for tile in (None, 0, 1, 3):
+        for ring in (1, 2, 3):
+            dx, part = ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, tile=tile, ring=ring,
+                                      bn_stats=(bn_y, mean, invstd, gamma, beta))
+            if part is None:
+                continue
+            tried += 1
+            ref = ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, tile=tile, ring=ring)
+            assert torch.equal(dx.view(torch.int16), ref.view(torch.int16)), (case[0], tile, ring)
+            got = part.double().sum(0).cpu()
+            err = float((got - want).abs().max()) / scale
+            assert err < tol, (case[0], tile, ring, err)
+    assert tried >= 3, "no tile configuration took the fused path"
+    # a residual input or the direct small-channel kernel: no sums, the caller runs the reduce pass
+    r = to_act(rb(torch.randn(x.shape, generator=g)), dev)
+    _, none = ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, residual=r, bn_stats=(bn_y, mean, invstd, gamma, beta))
+    assert none is None

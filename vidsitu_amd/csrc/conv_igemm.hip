@@ -44,7 +44,15 @@ struct ConvP {
   // 1/4 of the rows (no tap at all) for a 1x1 stride-2 one.  ncls = 0: classes off.
   int ncls;
   int cls_tile0[17];          // first M-tile of each class, [ncls] = number of M-tiles
+  // VS_CONV_BNBWD (dgrad whose output is the gradient dz behind a BN + ReLU unit): the epilogue also
+  // emits that BN's backward partial sums per M-tile, stats[tm][0][c] = sum g, [1][c] = sum g * xhat with
+  // xhat = (bny - mean) * invstd and g = dz where gamma * xhat + beta > 0, else 0 -- what
+  // bn_bwd_reduce_kernel<2> computes in a pass of its own over dz and bny
+  const uint16_t* bny;
+  const float *bn_mean, *bn_invstd, *bn_gamma, *bn_beta;
+  int bny_ld;
 };
+#define VS_CONV_BNBWD (1 << 20)
 
 template <int BM, int BN, int NSTAGE = 2>
 struct ConvSmem {
@@ -64,7 +72,9 @@ struct ConvSmem {
 // 3 = no LDS stores in the loop, 4 = no LDS fragment reads (operands stay whatever they were).
 // NS (FAST only): 0 = register-staged pipeline; >= 2 = LDS-DMA ring of NS stages
 // (`buffer_load_dwordx4 ... lds`, NS-1 tiles in flight, one raw barrier per k-step).
-template <int BM, int BN, int WM, int WN, int MODE, bool FAST, int DBG = 0, int NS = 0>
+// BNB: the dgrad variant that also emits the consumer BN's backward sums (VS_CONV_BNBWD); a template flag
+// so that the extra epilogue registers do not count against every other launch's occupancy.
+template <int BM, int BN, int WM, int WN, int MODE, bool FAST, int DBG = 0, int NS = 0, bool BNB = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int AI = BM / 32;
@@ -379,6 +389,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         *(uint4*)(p.y + (long long)m * p.y_ld + n) = v;
       }
     }
+    if (BNB && tid < BN && n0 + tid < p.Ncols) {  // dz = 0: the tile adds nothing
+      float* dst = p.stats + (long long)tm * 2 * p.Ncols;
+      dst[n0 + tid] = 0.f;
+      dst[p.Ncols + n0 + tid] = 0.f;
+    }
     return;
   }
   const int nk_all = (Keff + 63) >> 6;
@@ -564,11 +579,76 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         }
     }
     __syncthreads();
+    if constexpr (BNB) {
+      // copy-out + the consumer BN's backward sums: thread = one 8-channel column x (256 / CPR) row
+      // lanes; the saved conv outputs of all its rows are requested before the first use
+      constexpr int RL = 256 / CPR, IT = BM / RL;
+      static_assert(256 % CPR == 0 && BM % RL == 0, "tile shape");
+      const int c8 = tid % CPR, rl = tid / CPR;
+      const int n = n0 + c8 * 8;
+      const bool nok = n < p.Ncols;
+      const int nn = nok ? n : 0;
+      float mu[8], is[8], ga[8], be[8], sg[8], sx[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        mu[e] = p.bn_mean[nn + e];
+        is[e] = p.bn_invstd[nn + e];
+        ga[e] = p.bn_gamma[nn + e];
+        be[e] = p.bn_beta[nn + e];
+        sg[e] = 0.f;
+        sx[e] = 0.f;
+      }
+      uint4 yv4[IT];
+      int mm[IT];
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int row = rl + i * RL;
+        const int m = (MODE == 2) ? rowpos[row] : (m0 + row < p.M ? m0 + row : -1);
+        mm[i] = nok ? m : -1;
+        yv4[i] = *(const uint4*)(p.bny + (long long)(mm[i] >= 0 ? mm[i] : 0) * p.bny_ld + nn);
+      }
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int row = rl + i * RL;
+        const uint4 v = *(const uint4*)(Eh + row * BN + c8 * 8);
+        if (mm[i] >= 0) {
+          *(uint4*)(p.y + (long long)mm[i] * p.y_ld + n) = v;
+          float g[8], yv[8];
+          unpack8_bf16(v, g);
+          unpack8_bf16(yv4[i], yv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            g[e] = ((yv[e] - mu[e]) * is[e] * ga[e] + be[e]) > 0.f ? g[e] : 0.f;
+            sg[e] += g[e];
+            sx[e] += g[e] * (yv[e] - mu[e]) * is[e];
+          }
+        }
+      }
+      float* red = (float*)(smem + BM * BN * 2);  // behind the bf16 tile
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[tid * 16 + e] = sg[e];
+        red[tid * 16 + 8 + e] = sx[e];
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < p.Ncols) {  // fixed order over the row lanes
+        const int cc = tid >> 3, e = tid & 7;
+        float ts = 0.f, tq = 0.f;
+        for (int r = 0; r < RL; ++r) {
+          ts += red[(r * CPR + cc) * 16 + e];
+          tq += red[(r * CPR + cc) * 16 + 8 + e];
+        }
+        float* dst = p.stats + (long long)tm * 2 * p.Ncols;
+        dst[n0 + tid] = ts;
+        dst[p.Ncols + n0 + tid] = tq;
+      }
+    } else {
     for (int idx = tid; idx < BM * CPR; idx += 256) {
       const int row = idx / CPR, c8 = idx - row * CPR;
       const int m = (MODE == 2) ? rowpos[row] : (m0 + row < p.M ? m0 + row : -1), n = n0 + c8 * 8;
       if (m >= 0 && n < p.Ncols)
         *(uint4*)(p.y + (long long)m * p.y_ld + n) = *(const uint4*)(Eh + row * BN + c8 * 8);
+    }
     }
   } else {
     // (2b) residual add: fp32 tile through LDS, residual read as 16-byte vectors
@@ -1007,22 +1087,35 @@ static TileCfg pick_tile(long long M, int Ncols, int K, int* ring) {
   return c;
 }
 
-template <int BM, int BN, int WM, int WN, int MODE, int NS>
+template <int BM, int BN, int WM, int WN, int MODE, int NS, bool BNB = false>
 static int launch_one(const ConvP& p, int grid, size_t smem, hipStream_t st) {
   static bool attr_done = false;  // dynamic LDS above 64 KiB needs an explicit opt-in, once per kernel
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, MODE, true, 0, NS>,
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, MODE, true, 0, NS, BNB>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MODE, true, 0, NS>), dim3(grid), dim3(256),
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MODE, true, 0, NS, BNB>), dim3(grid), dim3(256),
                      smem, st, p);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }
 
+// tiles for which the BN-backward-sums dgrad is instantiated (what pick_tile produces for >= 32 columns)
+static bool bnb_tile(int bm, int bn) { return (bn == 128 && (bm == 128 || bm == 64)) || (bm == 64 && bn == 64); }
+
 template <int BM, int BN, int WM, int WN, int NS>
 static int launch_mode(const ConvP& p, int mode, int grid, size_t smem, hipStream_t st) {
+  if (p.flags & VS_CONV_BNBWD) {
+    if constexpr ((BN == 128 && (BM == 128 || BM == 64)) || (BM == 64 && BN == 64)) {
+      if (mode == 0) return launch_one<BM, BN, WM, WN, 0, NS, true>(p, grid, smem, st);
+      if (mode == 1) return launch_one<BM, BN, WM, WN, 1, NS, true>(p, grid, smem, st);
+      return launch_one<BM, BN, WM, WN, 2, NS, true>(p, grid, smem, st);
+    } else {
+      vs_set_error("conv: BN-backward sums are not built for the %dx%d tile", BM, BN);
+      return VS_ERR_UNSUPPORTED;
+    }
+  }
   if (mode == 0) return launch_one<BM, BN, WM, WN, 0, NS>(p, grid, smem, st);
   if (mode == 1) return launch_one<BM, BN, WM, WN, 1, NS>(p, grid, smem, st);
   return launch_one<BM, BN, WM, WN, 2, NS>(p, grid, smem, st);
@@ -1143,6 +1236,34 @@ static size_t plan_ws_bytes(const ConvPlan& pl, long long M, int Ncols) {
   return pl.S > 1 ? (size_t)pl.S * M * Ncols * sizeof(float) : 0;
 }
 
+// Stride classes of the transposed gather (MODE 2): tiles are laid out class by class; sets
+// p.ncls / p.cls_tile0 / p.tilesM.
+static void setup_stride_classes(ConvP& p, int bm, int mode, int flags) {
+  p.ncls = 0;
+  if (mode == 2 && p.kT * p.kH * p.kW <= 31 && !(flags & VS_CONV_NOCLASS)) {
+    const int sT = 1 << p.shT, sH = 1 << p.shH, sW = 1 << p.shW;
+    const int ncls = sT * sH * sW;
+    if (ncls > 1 && ncls <= 16) {
+      const int nb = p.M / (p.Rt * p.Rh * p.Rw);
+      auto cnt = [](int R, int q, int off, int st) {
+        const int r0 = ((q - off) % st + st) % st;
+        return r0 < R ? (R - r0 + st - 1) / st : 0;
+      };
+      int t0 = 0;
+      for (int q = 0; q < ncls; ++q) {
+        const int qw = q % sW, qh = (q / sW) % sH, qt = q / (sW * sH);
+        const long long rows = (long long)nb * cnt(p.Rt, qt, p.offT, sT) * cnt(p.Rh, qh, p.offH, sH) *
+                               cnt(p.Rw, qw, p.offW, sW);
+        p.cls_tile0[q] = t0;
+        t0 += (int)((rows + bm - 1) / bm);
+      }
+      p.cls_tile0[ncls] = t0;
+      p.ncls = ncls;
+      p.tilesM = t0;
+    }
+  }
+}
+
 static int launch_conv(ConvP& p, int mode, int naive, int flags, void* ws, size_t ws_bytes,
                        hipStream_t st) {
   p.splitK = 1;
@@ -1160,30 +1281,7 @@ static int launch_conv(ConvP& p, int mode, int naive, int flags, void* ws, size_
   const TileCfg c = pl.tile;
   p.tilesM = (p.M + c.bm - 1) / c.bm;
   p.tilesN = (p.Ncols + c.bn - 1) / c.bn;
-  p.ncls = 0;
-  if (mode == 2 && p.kT * p.kH * p.kW <= 31 && !(flags & VS_CONV_NOCLASS)) {
-    // stride classes of the transposed gather: tiles are laid out class by class
-    const int sT = 1 << p.shT, sH = 1 << p.shH, sW = 1 << p.shW;
-    const int ncls = sT * sH * sW;
-    if (ncls > 1 && ncls <= 16) {
-      const int nb = p.M / (p.Rt * p.Rh * p.Rw);
-      auto cnt = [](int R, int q, int off, int st) {
-        const int r0 = ((q - off) % st + st) % st;
-        return r0 < R ? (R - r0 + st - 1) / st : 0;
-      };
-      int t0 = 0;
-      for (int q = 0; q < ncls; ++q) {
-        const int qw = q % sW, qh = (q / sW) % sH, qt = q / (sW * sH);
-        const long long rows = (long long)nb * cnt(p.Rt, qt, p.offT, sT) * cnt(p.Rh, qh, p.offH, sH) *
-                               cnt(p.Rw, qw, p.offW, sW);
-        p.cls_tile0[q] = t0;
-        t0 += (int)((rows + c.bm - 1) / c.bm);
-      }
-      p.cls_tile0[ncls] = t0;
-      p.ncls = ncls;
-      p.tilesM = t0;
-    }
-  }
+  setup_stride_classes(p, c.bm, mode, flags);
   if (pl.S > 1) {
     if (ws == nullptr || ws_bytes < plan_ws_bytes(pl, p.M, p.Ncols)) {
       vs_set_error("conv: split-K workspace too small (%zu < %zu)", ws_bytes,
@@ -1288,6 +1386,9 @@ extern "C" int vs_conv_fwd(const void* x, const void* w, void* y, const vs_conv_
   p.shift = shift;
   p.res = (const uint16_t*)residual;
   p.stats = stats_partial;
+  p.bny = nullptr;
+  p.bn_mean = p.bn_invstd = p.bn_gamma = p.bn_beta = nullptr;
+  p.bny_ld = 0;
   p.M = d->N * d->To * d->Ho * d->Wo;
   p.Ncols = d->Cout;
   p.K = d->kT * d->kH * d->kW * d->Cin;
@@ -1316,21 +1417,15 @@ extern "C" int vs_conv_fwd(const void* x, const void* w, void* y, const vs_conv_
                      ws_bytes, (hipStream_t)stream);
 }
 
-extern "C" int vs_conv_dgrad(const void* dy, const void* wt, void* dx, const vs_conv_desc* d,
-                             const void* residual, void* workspace, size_t ws_bytes, void* stream) {
-  int rc = check_desc(d);
-  if (rc) return rc;
-  VS_CHECK_ARG(dy && wt && dx, "null tensor");
-  VS_CHECK_ARG(!(d->flags & VS_CONV_RESIDUAL) || residual, "RESIDUAL needs residual");
+// ConvP of a dgrad launch (everything but the tensor pointers); returns the kernel MODE or < 0.
+static int fill_dgrad_params(ConvP& p, const vs_conv_desc* d) {
   const int shT = ilog2_exact(d->sT), shH = ilog2_exact(d->sH), shW = ilog2_exact(d->sW);
-  VS_CHECK_ARG(shT >= 0 && shH >= 0 && shW >= 0, "strides must be powers of two");
-  ConvP p;
-  p.x = (const uint16_t*)dy;
-  p.w = (const uint16_t*)wt;
-  p.y = (uint16_t*)dx;
+  if (shT < 0 || shH < 0 || shW < 0) return -1;
   p.scale = p.shift = nullptr;
-  p.res = (const uint16_t*)residual;
   p.stats = nullptr;
+  p.bny = nullptr;
+  p.bn_mean = p.bn_invstd = p.bn_gamma = p.bn_beta = nullptr;
+  p.bny_ld = 0;
   p.M = d->N * d->Ti * d->Hi * d->Wi;
   p.Ncols = d->Cin;
   p.K = d->kT * d->kH * d->kW * d->Cout;
@@ -1343,13 +1438,6 @@ extern "C" int vs_conv_dgrad(const void* dy, const void* wt, void* dx, const vs_
   p.offT = d->pT; p.offH = d->pH; p.offW = d->pW;
   p.tmul = -1;
   p.shT = shT; p.shH = shH; p.shW = shW;
-  {
-    const long long xb = (long long)d->N * d->To * d->Ho * d->Wo * d->y_ld * 2;
-    const long long wb = (long long)d->Cin * p.K * 2;
-    VS_CHECK_ARG(xb < (1ll << 31) && wb < (1ll << 31), "tensor larger than 2 GiB");
-    p.x_bytes = (unsigned)xb;
-    p.w_bytes = (unsigned)wb;
-  }
   p.y_ld = d->x_ld;
   p.res_ld = d->res_ld;
   p.flags = d->flags & (VS_CONV_NAIVE | VS_CONV_RESIDUAL);
@@ -1357,9 +1445,74 @@ extern "C" int vs_conv_dgrad(const void* dy, const void* wt, void* dx, const vs_
   const bool unit_stride = d->sT == 1 && d->sH == 1 && d->sW == 1;
   const bool pointwise =
       unit_stride && (d->kT * d->kH * d->kW == 1) && d->pT == 0 && d->pH == 0 && d->pW == 0;
-  const int mode = pointwise ? 0 : (unit_stride ? 1 : 2);
+  return pointwise ? 0 : (unit_stride ? 1 : 2);
+}
+
+static int dgrad_impl(const void* dy, const void* wt, void* dx, const vs_conv_desc* d, const void* residual,
+                      void* workspace, size_t ws_bytes, void* stream, const void* bn_y, int bn_y_ld,
+                      const float* mean, const float* invstd, const float* gamma, const float* beta,
+                      float* stats_partial) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  VS_CHECK_ARG(dy && wt && dx, "null tensor");
+  VS_CHECK_ARG(!(d->flags & VS_CONV_RESIDUAL) || residual, "RESIDUAL needs residual");
+  ConvP p;
+  const int mode = fill_dgrad_params(p, d);
+  VS_CHECK_ARG(mode >= 0, "strides must be powers of two");
+  p.x = (const uint16_t*)dy;
+  p.w = (const uint16_t*)wt;
+  p.y = (uint16_t*)dx;
+  p.res = (const uint16_t*)residual;
+  {
+    const long long xb = (long long)d->N * d->To * d->Ho * d->Wo * d->y_ld * 2;
+    const long long wb = (long long)d->Cin * p.K * 2;
+    VS_CHECK_ARG(xb < (1ll << 31) && wb < (1ll << 31), "tensor larger than 2 GiB");
+    p.x_bytes = (unsigned)xb;
+    p.w_bytes = (unsigned)wb;
+  }
+  if (stats_partial) {
+    VS_CHECK_ARG(bn_y && mean && invstd && gamma && beta && bn_y_ld >= d->Cin && bn_y_ld % 8 == 0,
+                 "BN-backward sums need the unit's saved conv output and its mean / invstd / gamma / beta");
+    VS_CHECK_ARG(!(d->flags & (VS_CONV_RESIDUAL | VS_CONV_NAIVE)) && vs_conv_dgrad_bnstats_rows(d) > 0,
+                 "this dgrad cannot emit BN-backward sums (vs_conv_dgrad_bnstats_rows == 0)");
+    p.flags |= VS_CONV_BNBWD;
+    p.stats = stats_partial;
+    p.bny = (const uint16_t*)bn_y;
+    p.bny_ld = bn_y_ld;
+    p.bn_mean = mean;
+    p.bn_invstd = invstd;
+    p.bn_gamma = gamma;
+    p.bn_beta = beta;
+  }
   return launch_conv(p, mode, (d->flags & VS_CONV_NAIVE) != 0, d->flags, workspace, ws_bytes,
                      (hipStream_t)stream);
+}
+
+extern "C" int vs_conv_dgrad_bnstats_rows(const vs_conv_desc* d) {
+  if (d == nullptr || (d->flags & (VS_CONV_RESIDUAL | VS_CONV_NAIVE))) return 0;
+  ConvP p;
+  const int mode = fill_dgrad_params(p, d);
+  if (mode < 0) return 0;
+  const ConvPlan pl = plan_conv(p.M, p.Ncols, p.K, p.kT * p.kH * p.kW, d->flags);
+  if (pl.direct || pl.S > 1 || !bnb_tile(pl.tile.bm, pl.tile.bn) || p.kT * p.kH * p.kW > 31) return 0;
+  p.tilesM = (p.M + pl.tile.bm - 1) / pl.tile.bm;
+  setup_stride_classes(p, pl.tile.bm, mode, d->flags);
+  return p.tilesM;
+}
+
+extern "C" int vs_conv_dgrad(const void* dy, const void* wt, void* dx, const vs_conv_desc* d,
+                             const void* residual, void* workspace, size_t ws_bytes, void* stream) {
+  return dgrad_impl(dy, wt, dx, d, residual, workspace, ws_bytes, stream, nullptr, 0, nullptr, nullptr,
+                    nullptr, nullptr, nullptr);
+}
+
+extern "C" int vs_conv_dgrad_bnstats(const void* dy, const void* wt, void* dx, const vs_conv_desc* d,
+                                     const void* bn_y, int bn_y_ld, const float* mean, const float* invstd,
+                                     const float* gamma, const float* beta, float* stats_partial,
+                                     void* workspace, size_t ws_bytes, void* stream) {
+  VS_CHECK_ARG(stats_partial, "null stats_partial");
+  return dgrad_impl(dy, wt, dx, d, nullptr, workspace, ws_bytes, stream, bn_y, bn_y_ld, mean, invstd, gamma,
+                    beta, stats_partial);
 }
 
 // w [Cout][taps][Cin] -> wt [Cin][taps][Cout]

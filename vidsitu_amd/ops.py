@@ -289,8 +289,11 @@ def transpose_f32_batched(src, dst, table, total, tiled=True):
 
 
 def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=None, ring=0,
-               noclass=False):
-    """dx[xs] = conv_transpose(dy, w) (+ residual).  wt from weight_transpose."""
+               noclass=False, bn_stats=None):
+    """dx[xs] = conv_transpose(dy, w) (+ residual).  wt from weight_transpose.
+    bn_stats = (y, mean, invstd, gamma, beta) of the BatchNorm + ReLU unit (no residual input) whose output
+    this convolution consumed: returns (dx, partial) with partial [rows, 2, Cin] the unit's BN-backward sums
+    emitted by the dgrad epilogue (vs_conv_dgrad_bnstats), or (dx, None) when this dgrad cannot emit them."""
     if out is None:
         out = new_act(*xs, device=dy.device)
     flags = (VS_CONV_NAIVE if naive else 0) | (VS_CONV_RESIDUAL if residual is not None else 0)
@@ -303,9 +306,21 @@ def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=N
                   act_ld(residual) if residual is not None else 0)
     need = _lib.load().vs_conv_workspace_bytes(C.byref(d), 1)
     ws = _workspace(need, dy.device) if need else None
+    want_sums = bn_stats is not None
+    if want_sums:
+        rows = _lib.load().vs_conv_dgrad_bnstats_rows(C.byref(d)) if residual is None else 0
+        if rows <= 0:
+            bn_stats = None
+    if bn_stats is not None:
+        y, mean, invstd, gamma, beta = bn_stats
+        partial = torch.empty((rows, 2, xs[1]), dtype=torch.float32, device=dy.device)
+        _lib.call("vs_conv_dgrad_bnstats", _ptr(dy), _ptr(wt), _ptr(out), C.byref(d), _ptr(y), act_ld(y),
+                  _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(partial), _ptr(ws),
+                  C.c_size_t(ws.numel() if ws is not None else 0), _stream())
+        return out, partial
     _lib.call("vs_conv_dgrad", _ptr(dy), _ptr(wt), _ptr(out), C.byref(d), _ptr(residual), _ptr(ws),
               C.c_size_t(ws.numel() if ws is not None else 0), _stream())
-    return out
+    return (out, None) if want_sums else out
 
 
 _ws_cache = {}
@@ -375,25 +390,31 @@ def bn_apply(y, scale, shift, residual=None, relu=True, out=None, want_bits=Fals
 
 
 def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres, dy_out=None, dgamma=None, dbeta=None,
-           beta=None, zbits=None):
+           beta=None, zbits=None, partial=None):
     """Returns (dy, dres|None, dgamma, dbeta); dgamma / dbeta may be given (param.grad views).
     ReLU mask source, in order of preference: `zbits` (uint8 [rows, C/8] from bn_apply), `z`
     (the unit's output), or -- with `beta` given and both None -- recomputed from y (units
-    without a residual input)."""
+    without a residual input).  `partial`: the sums already emitted by the dgrad that produced dz
+    (conv_dgrad(bn_stats=...), recomputed-mask units only): the reduce pass is skipped."""
     rows, c = act_rows(y), y.shape[1]
     dev = y.device
-    nblk = _lib.load().vs_bn_bwd_reduce_rows(rows, c)
-    if nblk <= 0:
-        raise _lib.VsError("bn_bwd: unsupported channel count")
-    partial = torch.empty((nblk, 2, c), dtype=torch.float32, device=dev)
     mode = int(relu)
     zz = z if relu else None
     z_ld = act_ld(zz) if zz is not None else 0
     if relu and zbits is not None:
         mode, zz, z_ld = 2, zbits, c // 8
-    _lib.call("vs_bn_bwd_reduce", _ptr(dz), _ptr(zz), _ptr(y), _ptr(mean), _ptr(invstd),
-              _ptr(gamma), _ptr(beta), _ptr(partial), rows, c, act_ld(dz), z_ld, act_ld(y),
-              mode, _stream())
+    if partial is not None:
+        if not (relu and zz is None and beta is not None):
+            raise _lib.VsError("bn_bwd: dgrad-emitted sums exist for recomputed-mask units only")
+        nblk = partial.shape[0]
+    else:
+        nblk = _lib.load().vs_bn_bwd_reduce_rows(rows, c)
+        if nblk <= 0:
+            raise _lib.VsError("bn_bwd: unsupported channel count")
+        partial = torch.empty((nblk, 2, c), dtype=torch.float32, device=dev)
+        _lib.call("vs_bn_bwd_reduce", _ptr(dz), _ptr(zz), _ptr(y), _ptr(mean), _ptr(invstd),
+                  _ptr(gamma), _ptr(beta), _ptr(partial), rows, c, act_ld(dz), z_ld, act_ld(y),
+                  mode, _stream())
     if dgamma is None:
         dgamma = torch.empty(c, dtype=torch.float32, device=dev)
     if dbeta is None:

@@ -167,6 +167,9 @@ class _Unit:
     """conv -> BN (-> +residual) (-> ReLU) executed on the HIP kernels."""
 
     trace = None  # debugging: set to a list to record (conv, y, z, mean, invstd) per unit
+    # BN-backward sums of the a / b units of a bottleneck emitted by the consuming convolution's dgrad
+    # epilogue (vs_conv_dgrad_bnstats) instead of a reduce pass of their own; VS_FUSE_BN_SUMS=0 = A/B switch
+    fuse_bn_sums = os.environ.get("VS_FUSE_BN_SUMS", "1") != "0"
 
     @staticmethod
     def fwd(conv, bn, x, relu, residual=None, out=None, train=False, saved=None):
@@ -206,8 +209,11 @@ class _Unit:
         return z
 
     @staticmethod
-    def bwd(rec, dz, need_dx=True, want_dres=False, dx_residual=None, masked=False):
-        """Returns (dx|None, dres|None).  `masked`: dz already carries the ReLU mask."""
+    def bwd(rec, dz, need_dx=True, want_dres=False, dx_residual=None, masked=False, producer=None):
+        """Returns (dx|None, dres|None).  `masked`: dz already carries the ReLU mask.
+        `producer`: the record of the unit whose output is this unit's only input (the a -> b and b -> c
+        links of a bottleneck): this unit's dgrad then also emits the producer's BN-backward sums
+        (`_Unit.fuse_bn_sums`), which spares the producer's reduce pass over dz and y."""
         conv, bn = rec["conv"], rec["bn"]
         relu = rec["relu"] and not masked
         if bn.weight.grad is None:
@@ -219,7 +225,8 @@ class _Unit:
         zmask = rec["z"] if (relu and rec["has_res"] and zbits is None) else None
         dy, dres, _, _ = ops.bn_bwd(
             dz, zmask, rec["y"], rec["mean"], rec["invstd"], bn.weight, relu, want_dres,
-            dgamma=bn.weight.grad, dbeta=bn.bias.grad, beta=bn.bias, zbits=zbits)
+            dgamma=bn.weight.grad, dbeta=bn.bias.grad, beta=bn.bias, zbits=zbits,
+            partial=rec.pop("bwd_partial", None))
         x = rec["x"]
         if conv.bias is not None:  # analytically zero behind a train-mode BN
             if conv.bias.grad is None:
@@ -240,8 +247,18 @@ class _Unit:
             _WgradLanes.run(legacy, dy, x)
         dx = None
         if need_dx:
-            dx = ops.conv_dgrad(dy, conv.wt(), tuple(x.shape), conv.k, conv.s, conv.p,
-                                residual=dx_residual)
+            fuse = (_Unit.fuse_bn_sums and producer is not None and dx_residual is None and producer["relu"]
+                    and not producer["has_res"] and producer.get("zbits") is None and producer["z"] is x)
+            if fuse:
+                pbn = producer["bn"]
+                dx, part = ops.conv_dgrad(dy, conv.wt(), tuple(x.shape), conv.k, conv.s, conv.p,
+                                          bn_stats=(producer["y"], producer["mean"], producer["invstd"],
+                                                    pbn.weight, pbn.bias))
+                if part is not None:
+                    producer["bwd_partial"] = part
+            else:
+                dx = ops.conv_dgrad(dy, conv.wt(), tuple(x.shape), conv.k, conv.s, conv.p,
+                                    residual=dx_residual)
         _WgradLanes.join_all()  # wgrad || dgrad of this unit, no further
         return dx, dres
 
@@ -311,8 +328,8 @@ class ResBlock(nn.Module):
 
     def bwd(self, saved, dout):
         rc, rb, ra = saved.pop(), saved.pop(), saved.pop()
-        db, g = _Unit.bwd(rc, dout, want_dres=True)
-        da, _ = _Unit.bwd(rb, db)
+        db, g = _Unit.bwd(rc, dout, want_dres=True, producer=rb)
+        da, _ = _Unit.bwd(rb, db, producer=ra)
         if self.has_sc:
             dx1, _ = _Unit.bwd(saved.pop(), g, masked=True)
             dx, _ = _Unit.bwd(ra, da, dx_residual=dx1)
