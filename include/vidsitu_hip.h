@@ -118,20 +118,24 @@ int vs_conv_plan(const vs_conv_desc* d, int dgrad, int* out);
 int vs_conv_dgrad(const void* dy, const void* wt, void* dx, const vs_conv_desc* d,
                   const void* residual, void* workspace, size_t ws_bytes, void* stream);
 
-/* The same dgrad for a convolution whose INPUT is the output of a BatchNorm + ReLU unit without a residual
- * input (the a -> b and b -> c links of a bottleneck): dx is that unit's dz, and the epilogue also emits the
- * unit's BN-backward partial sums, one row per M-tile -- stats_partial[rows][2][Cin] fp32,
- * [0] = sum g, [1] = sum g * xhat, xhat = (bn_y - mean) * invstd, g = dz where gamma * xhat + beta > 0 else 0
- * (dz as rounded to bf16) -- so that vs_bn_bwd_finalize(stats_partial, rows, ...) can follow directly and the
- * separate pass of vs_bn_bwd_reduce over dz and bn_y is not needed (slowfast's BatchNorm3d backward,
- * autograd of `resnet_helper.BottleneckTransform.forward`).  bn_y: the unit's saved conv output
- * [positions][bn_y_ld] bf16.  vs_conv_dgrad_bnstats_rows(desc) = rows, or 0 when this dgrad cannot emit the
- * sums (small-channel direct kernel, split-K plan, RESIDUAL / NAIVE flags): use vs_bn_bwd_reduce then. */
+/* The same dgrad for a convolution whose INPUT is the output z of a BatchNorm + ReLU unit and whose dx is that
+ * unit's complete dz: the epilogue also emits the unit's BN-backward partial sums, one row per M-tile --
+ * stats_partial[rows][2][Cin] fp32, [0] = sum g, [1] = sum g * xhat, xhat = (bn_y - mean) * invstd, g = dz
+ * (as rounded to bf16) where the unit's ReLU passed, else 0 -- so that vs_bn_bwd_finalize(stats_partial, rows,
+ * ...) can follow directly and the separate pass of vs_bn_bwd_reduce over dz and bn_y is not needed (slowfast's
+ * BatchNorm3d backward, autograd of `resnet_helper.BottleneckTransform.forward` / `ResBlock.forward`).
+ * Two pairings: no residual input (the a -> b and b -> c links inside a bottleneck): relu_bits NULL, the mask
+ * is recomputed as gamma * xhat + beta > 0; desc.flags has VS_CONV_RESIDUAL (conv a of the next block, dx =
+ * dgrad + the gradient over the identity branch, the unit is the previous block's c unit): relu_bits = the bit
+ * mask vs_bn_apply_mask wrote, [positions][Cin / 8] bytes; gamma / beta unused.
+ * bn_y: the unit's saved conv output [positions][bn_y_ld] bf16.  vs_conv_dgrad_bnstats_rows(desc) = rows, or
+ * 0 when this dgrad cannot emit the sums (small-channel direct kernel, split-K plan, NAIVE, a strided dgrad
+ * with a residual, tiles other than 128x128 / 64x128 / 64x64): use vs_bn_bwd_reduce then. */
 int vs_conv_dgrad_bnstats_rows(const vs_conv_desc* d);
-int vs_conv_dgrad_bnstats(const void* dy, const void* wt, void* dx, const vs_conv_desc* d, const void* bn_y,
-                          int bn_y_ld, const float* mean, const float* invstd, const float* gamma,
-                          const float* beta, float* stats_partial, void* workspace, size_t ws_bytes,
-                          void* stream);
+int vs_conv_dgrad_bnstats(const void* dy, const void* wt, void* dx, const vs_conv_desc* d, const void* residual,
+                          const void* bn_y, int bn_y_ld, const uint8_t* relu_bits, const float* mean,
+                          const float* invstd, const float* gamma, const float* beta, float* stats_partial,
+                          void* workspace, size_t ws_bytes, void* stream);
 int vs_weight_transpose(const void* w, void* wt, int Cout, int taps, int Cin, void* stream);
 /* Every dgrad weight image of a model in one launch: src/dst are bf16 arenas with equal
  * element offsets; table[i] = {offset, Cout, taps, Cin, first flat index} (int64 x 5). */

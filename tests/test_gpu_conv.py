@@ -459,7 +459,39 @@ def test_dgrad_emits_the_producer_bn_backward_sums(case, dev):
             err = float((got - want).abs().max()) / scale
             assert err < tol, (case[0], tile, ring, err)
     assert tried >= 3, "no tile configuration took the fused path"
-    # a residual input or the direct small-channel kernel: no sums, the caller runs the reduce pass
+    # residual input (the gradient over the identity branch) + the unit's ReLU mask as bits: the pairing of
+    # the previous block's c unit.  A recomputed mask with a residual is not built: (dx, None).
     r = to_act(rb(torch.randn(x.shape, generator=g)), dev)
     _, none = ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, residual=r, bn_stats=(bn_y, mean, invstd, gamma, beta))
     assert none is None
+    bits = torch.randint(0, 256, (rows, c // 8), generator=g, dtype=torch.uint8).to(dev)
+
+    def sums_from(dz):  # what the reduce pass computes from this dz (bit-mask mode)
+        if nblk > 0:
+            w_ = torch.empty((nblk, 2, c), dtype=torch.float32, device=dev)
+            ops._lib.call("vs_bn_bwd_reduce", ops._ptr(dz), ops._ptr(bits), ops._ptr(bn_y), ops._ptr(mean),
+                          ops._ptr(invstd), None, None, ops._ptr(w_), rows, c, ops.act_ld(dz), c // 8,
+                          ops.act_ld(bn_y), 2, ops._stream())
+            return w_.double().sum(0).cpu()
+        v = lambda t: t.view(1, -1, 1, 1, 1)
+        xh = (bn_y.float() - v(mean)) * v(invstd)
+        keep = ((bits.view(rows, c // 8, 1) >> torch.arange(8, device=dev, dtype=torch.uint8)) & 1).bool()
+        keep = keep.view(x.shape[0], *x.shape[2:], c).permute(0, 4, 1, 2, 3)
+        gm = torch.where(keep, dz.float(), torch.zeros((), device=dev))
+        return torch.stack([gm.double().sum((0, 2, 3, 4)), (gm * xh).double().sum((0, 2, 3, 4))]).cpu()
+
+    strided = any(v != 1 for v in s)
+    tried = 0
+    for tile in (None, 0, 1, 3):
+        for ring in (1, 2, 3):
+            dx, part = ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, tile=tile, ring=ring, residual=r,
+                                      bn_stats=(bn_y, mean, invstd, None, None, bits))
+            if part is None:
+                continue
+            tried += 1
+            ref = ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, tile=tile, ring=ring, residual=r)
+            assert torch.equal(dx.view(torch.int16), ref.view(torch.int16)), (case[0], tile, ring)
+            want = sums_from(ref)
+            err = float((part.double().sum(0).cpu() - want).abs().max()) / float(want.abs().max())
+            assert err < 1e-5, (case[0], tile, ring, "residual", err)
+    assert tried == 0 if strided else tried >= 3  # a strided dgrad with a residual is not fused

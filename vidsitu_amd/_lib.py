@@ -48,7 +48,7 @@ SIGNATURES = {
     "vs_conv_plan": (_i, [_dp, _i, _p]),
     "vs_conv_dgrad": (_i, [_p, _p, _p, _dp, _p, _p, _sz, _p]),
     "vs_conv_dgrad_bnstats_rows": (_i, [_dp]),
-    "vs_conv_dgrad_bnstats": (_i, [_p, _p, _p, _dp, _p, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "vs_conv_dgrad_bnstats": (_i, [_p, _p, _p, _dp, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "vs_weight_transpose": (_i, [_p, _p, _i, _i, _i, _p]),
     "vs_weight_transpose_batched": (_i, [_p, _p, _p, _i, _i64, _p]),
     "vs_transpose_f32_batched": (_i, [_p, _p, _p, _i, _i64, _p]),

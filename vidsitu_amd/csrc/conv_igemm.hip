@@ -50,6 +50,8 @@ struct ConvP {
   // bn_bwd_reduce_kernel<2> computes in a pass of its own over dz and bny
   const uint16_t* bny;
   const float *bn_mean, *bn_invstd, *bn_gamma, *bn_beta;
+  const uint8_t* bn_bits;  // the unit's ReLU mask as bits [rows][Ncols/8] (units with a residual input:
+                           // the RESIDUAL epilogue), NULL: mask recomputed from gamma / beta
   int bny_ld;
 };
 #define VS_CONV_BNBWD (1 << 20)
@@ -670,6 +672,81 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         }
     }
     __syncthreads();
+    if constexpr (BNB) {
+      // residual add + copy-out + the consumer BN's backward sums (ReLU mask from the unit's bit mask):
+      // same thread layout as the no-residual variant above
+      constexpr int RL = 256 / CPR, IT = BM / RL;
+      static_assert(256 % CPR == 0 && BM % RL == 0, "tile shape");
+      const int c8 = tid % CPR, rl = tid / CPR;
+      const int n = n0 + c8 * 8;
+      const bool nok = n < p.Ncols;
+      const int nn = nok ? n : 0;
+      const int bpr = p.Ncols >> 3;
+      float mu[8], is[8], sg[8], sx[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        mu[e] = p.bn_mean[nn + e];
+        is[e] = p.bn_invstd[nn + e];
+        sg[e] = 0.f;
+        sx[e] = 0.f;
+      }
+      uint4 yv4[IT], rv4[IT];
+      unsigned bits[IT];
+      int mm[IT];
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int row = rl + i * RL;
+        const int m = (MODE == 2) ? rowpos[row] : (m0 + row < p.M ? m0 + row : -1);
+        mm[i] = nok ? m : -1;
+        const long long mc = mm[i] >= 0 ? mm[i] : 0;
+        yv4[i] = *(const uint4*)(p.bny + mc * p.bny_ld + nn);
+        rv4[i] = *(const uint4*)(p.res + mc * p.res_ld + nn);
+        bits[i] = p.bn_bits[mc * bpr + (nn >> 3)];
+      }
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int row = rl + i * RL;
+        const float4 v0 = *(const float4*)(E + row * BN + c8 * 8);
+        const float4 v1 = *(const float4*)(E + row * BN + c8 * 8 + 4);
+        if (mm[i] >= 0) {
+          float v[8], rf[8], g[8], yv[8];
+          v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
+          v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+          unpack8_bf16(rv4[i], rf);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rf[e];
+          const uint4 o = pack8_bf16(v);
+          *(uint4*)(p.y + (long long)mm[i] * p.y_ld + n) = o;
+          unpack8_bf16(o, g);  // the sums see dz as stored
+          unpack8_bf16(yv4[i], yv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            g[e] = ((bits[i] >> e) & 1u) ? g[e] : 0.f;
+            sg[e] += g[e];
+            sx[e] += g[e] * (yv[e] - mu[e]) * is[e];
+          }
+        }
+      }
+      __syncthreads();  // every thread is done with the fp32 tile: its space holds the row-lane sums
+      float* red = (float*)smem;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[tid * 16 + e] = sg[e];
+        red[tid * 16 + 8 + e] = sx[e];
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < p.Ncols) {  // fixed order over the row lanes
+        const int cc = tid >> 3, e = tid & 7;
+        float ts = 0.f, tq = 0.f;
+        for (int r = 0; r < RL; ++r) {
+          ts += red[(r * CPR + cc) * 16 + e];
+          tq += red[(r * CPR + cc) * 16 + 8 + e];
+        }
+        float* dst = p.stats + (long long)tm * 2 * p.Ncols;
+        dst[n0 + tid] = ts;
+        dst[p.Ncols + n0 + tid] = tq;
+      }
+    } else {
     for (int idx = tid; idx < BM * CPR; idx += 256) {
       const int row = idx / CPR, c8 = idx - row * CPR;
       const int m = (MODE == 2) ? rowpos[row] : (m0 + row < p.M ? m0 + row : -1), n = n0 + c8 * 8;
@@ -690,6 +767,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         }
         *(uint4*)(p.y + (long long)m * p.y_ld + n) = pack8_bf16(v);
       }
+    }
     }
   }
   if ((p.flags & VS_CONV_STATS) && tid < BN && n0 + tid < p.Ncols) {
@@ -1388,6 +1466,7 @@ extern "C" int vs_conv_fwd(const void* x, const void* w, void* y, const vs_conv_
   p.stats = stats_partial;
   p.bny = nullptr;
   p.bn_mean = p.bn_invstd = p.bn_gamma = p.bn_beta = nullptr;
+  p.bn_bits = nullptr;
   p.bny_ld = 0;
   p.M = d->N * d->To * d->Ho * d->Wo;
   p.Ncols = d->Cout;
@@ -1425,6 +1504,7 @@ static int fill_dgrad_params(ConvP& p, const vs_conv_desc* d) {
   p.stats = nullptr;
   p.bny = nullptr;
   p.bn_mean = p.bn_invstd = p.bn_gamma = p.bn_beta = nullptr;
+  p.bn_bits = nullptr;
   p.bny_ld = 0;
   p.M = d->N * d->Ti * d->Hi * d->Wi;
   p.Ncols = d->Cin;
@@ -1450,8 +1530,8 @@ static int fill_dgrad_params(ConvP& p, const vs_conv_desc* d) {
 
 static int dgrad_impl(const void* dy, const void* wt, void* dx, const vs_conv_desc* d, const void* residual,
                       void* workspace, size_t ws_bytes, void* stream, const void* bn_y, int bn_y_ld,
-                      const float* mean, const float* invstd, const float* gamma, const float* beta,
-                      float* stats_partial) {
+                      const uint8_t* relu_bits, const float* mean, const float* invstd, const float* gamma,
+                      const float* beta, float* stats_partial) {
   int rc = check_desc(d);
   if (rc) return rc;
   VS_CHECK_ARG(dy && wt && dx, "null tensor");
@@ -1471,9 +1551,12 @@ static int dgrad_impl(const void* dy, const void* wt, void* dx, const vs_conv_de
     p.w_bytes = (unsigned)wb;
   }
   if (stats_partial) {
-    VS_CHECK_ARG(bn_y && mean && invstd && gamma && beta && bn_y_ld >= d->Cin && bn_y_ld % 8 == 0,
-                 "BN-backward sums need the unit's saved conv output and its mean / invstd / gamma / beta");
-    VS_CHECK_ARG(!(d->flags & (VS_CONV_RESIDUAL | VS_CONV_NAIVE)) && vs_conv_dgrad_bnstats_rows(d) > 0,
+    VS_CHECK_ARG(bn_y && mean && invstd && bn_y_ld >= d->Cin && bn_y_ld % 8 == 0,
+                 "BN-backward sums need the unit's saved conv output and its mean / invstd");
+    const bool has_res = (d->flags & VS_CONV_RESIDUAL) != 0;
+    VS_CHECK_ARG(has_res ? relu_bits != nullptr : (relu_bits == nullptr && gamma && beta),
+                 "BN-backward sums: RESIDUAL pairs with the unit's bit mask, no residual with gamma / beta");
+    VS_CHECK_ARG(vs_conv_dgrad_bnstats_rows(d) > 0,
                  "this dgrad cannot emit BN-backward sums (vs_conv_dgrad_bnstats_rows == 0)");
     p.flags |= VS_CONV_BNBWD;
     p.stats = stats_partial;
@@ -1483,16 +1566,20 @@ static int dgrad_impl(const void* dy, const void* wt, void* dx, const vs_conv_de
     p.bn_invstd = invstd;
     p.bn_gamma = gamma;
     p.bn_beta = beta;
+    p.bn_bits = relu_bits;
   }
   return launch_conv(p, mode, (d->flags & VS_CONV_NAIVE) != 0, d->flags, workspace, ws_bytes,
                      (hipStream_t)stream);
 }
 
 extern "C" int vs_conv_dgrad_bnstats_rows(const vs_conv_desc* d) {
-  if (d == nullptr || (d->flags & (VS_CONV_RESIDUAL | VS_CONV_NAIVE))) return 0;
+  if (d == nullptr || (d->flags & VS_CONV_NAIVE)) return 0;
   ConvP p;
   const int mode = fill_dgrad_params(p, d);
   if (mode < 0) return 0;
+  // a strided dgrad with a residual: tiles of stride classes no tap reaches copy the residual without
+  // passing through the epilogue
+  if ((d->flags & VS_CONV_RESIDUAL) && mode == 2) return 0;
   const ConvPlan pl = plan_conv(p.M, p.Ncols, p.K, p.kT * p.kH * p.kW, d->flags);
   if (pl.direct || pl.S > 1 || !bnb_tile(pl.tile.bm, pl.tile.bn) || p.kT * p.kH * p.kW > 31) return 0;
   p.tilesM = (p.M + pl.tile.bm - 1) / pl.tile.bm;
@@ -1503,16 +1590,17 @@ extern "C" int vs_conv_dgrad_bnstats_rows(const vs_conv_desc* d) {
 extern "C" int vs_conv_dgrad(const void* dy, const void* wt, void* dx, const vs_conv_desc* d,
                              const void* residual, void* workspace, size_t ws_bytes, void* stream) {
   return dgrad_impl(dy, wt, dx, d, residual, workspace, ws_bytes, stream, nullptr, 0, nullptr, nullptr,
-                    nullptr, nullptr, nullptr);
+                    nullptr, nullptr, nullptr, nullptr);
 }
 
 extern "C" int vs_conv_dgrad_bnstats(const void* dy, const void* wt, void* dx, const vs_conv_desc* d,
-                                     const void* bn_y, int bn_y_ld, const float* mean, const float* invstd,
+                                     const void* residual, const void* bn_y, int bn_y_ld,
+                                     const uint8_t* relu_bits, const float* mean, const float* invstd,
                                      const float* gamma, const float* beta, float* stats_partial,
                                      void* workspace, size_t ws_bytes, void* stream) {
   VS_CHECK_ARG(stats_partial, "null stats_partial");
-  return dgrad_impl(dy, wt, dx, d, nullptr, workspace, ws_bytes, stream, bn_y, bn_y_ld, mean, invstd, gamma,
-                    beta, stats_partial);
+  return dgrad_impl(dy, wt, dx, d, residual, workspace, ws_bytes, stream, bn_y, bn_y_ld, relu_bits, mean,
+                    invstd, gamma, beta, stats_partial);
 }
 
 // w [Cout][taps][Cin] -> wt [Cin][taps][Cout]

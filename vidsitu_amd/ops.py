@@ -291,9 +291,11 @@ def transpose_f32_batched(src, dst, table, total, tiled=True):
 def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=None, ring=0,
                noclass=False, bn_stats=None):
     """dx[xs] = conv_transpose(dy, w) (+ residual).  wt from weight_transpose.
-    bn_stats = (y, mean, invstd, gamma, beta) of the BatchNorm + ReLU unit (no residual input) whose output
-    this convolution consumed: returns (dx, partial) with partial [rows, 2, Cin] the unit's BN-backward sums
-    emitted by the dgrad epilogue (vs_conv_dgrad_bnstats), or (dx, None) when this dgrad cannot emit them."""
+    bn_stats = (y, mean, invstd, gamma, beta[, relu_bits]) of the BatchNorm + ReLU unit whose output this
+    convolution consumed and whose complete dz this dx is: returns (dx, partial) with partial [rows, 2, Cin]
+    the unit's BN-backward sums emitted by the dgrad epilogue (vs_conv_dgrad_bnstats), or (dx, None) when
+    this dgrad cannot emit them.  Without `residual` the unit's mask is recomputed from gamma / beta; with
+    `residual` the unit's bit mask (relu_bits, from bn_apply(want_bits=True)) is required."""
     if out is None:
         out = new_act(*xs, device=dy.device)
     flags = (VS_CONV_NAIVE if naive else 0) | (VS_CONV_RESIDUAL if residual is not None else 0)
@@ -308,16 +310,16 @@ def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=N
     ws = _workspace(need, dy.device) if need else None
     want_sums = bn_stats is not None
     if want_sums:
-        rows = _lib.load().vs_conv_dgrad_bnstats_rows(C.byref(d)) if residual is None else 0
-        if rows <= 0:
-            bn_stats = None
-    if bn_stats is not None:
-        y, mean, invstd, gamma, beta = bn_stats
-        partial = torch.empty((rows, 2, xs[1]), dtype=torch.float32, device=dy.device)
-        _lib.call("vs_conv_dgrad_bnstats", _ptr(dy), _ptr(wt), _ptr(out), C.byref(d), _ptr(y), act_ld(y),
-                  _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(partial), _ptr(ws),
-                  C.c_size_t(ws.numel() if ws is not None else 0), _stream())
-        return out, partial
+        y, mean, invstd, gamma, beta, bits = (tuple(bn_stats) + (None,))[:6]
+        # pairings the kernel is built for: no residual + recomputed mask, residual + bit mask
+        ok = (bits is not None) if residual is not None else (bits is None and gamma is not None)
+        rows = _lib.load().vs_conv_dgrad_bnstats_rows(C.byref(d)) if ok else 0
+        if rows > 0:
+            partial = torch.empty((rows, 2, xs[1]), dtype=torch.float32, device=dy.device)
+            _lib.call("vs_conv_dgrad_bnstats", _ptr(dy), _ptr(wt), _ptr(out), C.byref(d), _ptr(residual),
+                      _ptr(y), act_ld(y), _ptr(bits), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
+                      _ptr(partial), _ptr(ws), C.c_size_t(ws.numel() if ws is not None else 0), _stream())
+            return out, partial
     _lib.call("vs_conv_dgrad", _ptr(dy), _ptr(wt), _ptr(out), C.byref(d), _ptr(residual), _ptr(ws),
               C.c_size_t(ws.numel() if ws is not None else 0), _stream())
     return (out, None) if want_sums else out
@@ -404,8 +406,8 @@ def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres, dy_out=None, dgamma=N
     if relu and zbits is not None:
         mode, zz, z_ld = 2, zbits, c // 8
     if partial is not None:
-        if not (relu and zz is None and beta is not None):
-            raise _lib.VsError("bn_bwd: dgrad-emitted sums exist for recomputed-mask units only")
+        if not (relu and ((zz is None and beta is not None) or zbits is not None)):
+            raise _lib.VsError("bn_bwd: dgrad-emitted sums exist for recomputed-mask and bit-mask units only")
         nblk = partial.shape[0]
     else:
         nblk = _lib.load().vs_bn_bwd_reduce_rows(rows, c)

@@ -247,13 +247,21 @@ class _Unit:
             _WgradLanes.run(legacy, dy, x)
         dx = None
         if need_dx:
-            fuse = (_Unit.fuse_bn_sums and producer is not None and dx_residual is None and producer["relu"]
-                    and not producer["has_res"] and producer.get("zbits") is None and producer["z"] is x)
+            # the producer's complete dz is this dx when its output feeds this convolution and -- with
+            # dx_residual -- the branch whose gradient arrives as that residual, and nothing else
+            fuse = (_Unit.fuse_bn_sums and producer is not None and "conv" in producer and producer["relu"]
+                    and producer["z"] is x)
+            if fuse and dx_residual is None:
+                fuse = not producer["has_res"] and producer.get("zbits") is None
+            elif fuse:
+                fuse = producer.get("zbits") is not None
+            part = None
             if fuse:
                 pbn = producer["bn"]
                 dx, part = ops.conv_dgrad(dy, conv.wt(), tuple(x.shape), conv.k, conv.s, conv.p,
+                                          residual=dx_residual,
                                           bn_stats=(producer["y"], producer["mean"], producer["invstd"],
-                                                    pbn.weight, pbn.bias))
+                                                    pbn.weight, pbn.bias, producer.get("zbits")))
                 if part is not None:
                     producer["bwd_partial"] = part
             else:
@@ -326,7 +334,10 @@ class ResBlock(nn.Module):
         b = _Unit.fwd(b2.b, b2.b_bn, a, True, train=train, saved=saved)
         return _Unit.fwd(b2.c, b2.c_bn, b, True, residual=sc, out=out, train=train, saved=saved)
 
-    def bwd(self, saved, dout):
+    def bwd(self, saved, dout, chain=False):
+        """chain: this block's input is the previous block's output and nothing else reads it -- the record
+        on top of `saved` after this block's own is then that block's c unit (`_Unit.bwd` checks the tensor
+        identity), whose BN-backward sums come out of this block's conv-a dgrad."""
         rc, rb, ra = saved.pop(), saved.pop(), saved.pop()
         db, g = _Unit.bwd(rc, dout, want_dres=True, producer=rb)
         da, _ = _Unit.bwd(rb, db, producer=ra)
@@ -334,7 +345,7 @@ class ResBlock(nn.Module):
             dx1, _ = _Unit.bwd(saved.pop(), g, masked=True)
             dx, _ = _Unit.bwd(ra, da, dx_residual=dx1)
         else:
-            dx, _ = _Unit.bwd(ra, da, dx_residual=g)
+            dx, _ = _Unit.bwd(ra, da, dx_residual=g, producer=saved[-1] if (chain and saved) else None)
         return dx
 
 
@@ -920,8 +931,11 @@ class VideoTrunk(nn.Module):
         for p in reversed(range(P)):
             with par.on(p):
                 g = d[p]
-                for blk in reversed(stage.blocks(p)):
-                    g = blk.bwd(saved, g)
+                blks = stage.blocks(p)
+                for i in reversed(range(len(blks))):
+                    # chain: the block's input is the previous block's output and has no other consumer
+                    # (a stage's first block shares its input with the lateral connection / the shortcut)
+                    g = blks[i].bwd(saved, g, chain=i > 0) if isinstance(blks[i], ResBlock) else blks[i].bwd(saved, g)
                 d[p] = g
         par.join(keep=d_in)
         st["d"] = d
