@@ -152,3 +152,19 @@ def test_avgpool_cat_fwd_bwd(dev):
     da, db = ops.avgpool_cat_bwd(dout.to(dev), [tuple(a.shape), tuple(b.shape)])
     assert_close(da, (dout[:, :2048] / 18.0).view(3, 2048, 1, 1, 1).expand_as(a), 5e-3, "da")
     assert_close(db, (dout[:, 2048:] / 72.0).view(3, 256, 1, 1, 1).expand_as(b), 5e-3, "db")
+
+
+@pytest.mark.parametrize("nparts,c", [(5, 64), (256, 64), (257, 64), (1568, 64), (1568, 8), (900, 200), (3136, 256)])
+def test_bn_bwd_finalize_sums_any_number_of_partial_rows(nparts, c, dev):
+    """vs_bn_bwd_finalize over [nparts][2][C] partial rows (a few hundred from the reduce pass, one per
+    M-tile -- up to thousands -- when a dgrad epilogue emitted them): fp64 accumulation."""
+    from vidsitu_amd import ops
+
+    g = torch.Generator().manual_seed(nparts + c)
+    part = torch.randn(nparts, 2, c, generator=g).to(dev)
+    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+    ops._lib.call("vs_bn_bwd_finalize", ops._ptr(part), nparts, ops._ptr(dgamma), ops._ptr(dbeta), c, ops._stream())
+    want = part.double().sum(0)
+    assert torch.allclose(dbeta, want[0].float(), rtol=1e-6, atol=1e-6)
+    assert torch.allclose(dgamma, want[1].float(), rtol=1e-6, atol=1e-6)
