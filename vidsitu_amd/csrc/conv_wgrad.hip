@@ -507,20 +507,25 @@ static WgCfg wg_pick(const vs_conv_desc* d) {
   c.tilesM = (d->Cout + c.bm - 1) / c.bm;
   c.tilesN = (Kp + c.bn - 1) / c.bn;
   const long long tiles = (long long)c.tilesM * c.tilesN;
-  // ~512 blocks (2 per CU); every block keeps >= 8 steps (512 positions) so the slab
-  // traffic (S x |dW| fp32, written and re-read) stays small next to the operand reads
+  // ~256 blocks (one per CU); every block keeps >= 8 steps (512 positions) so the slab traffic
+  // (S x |dW| fp32, written and re-read) stays small next to the operand reads.  Alone on the GPU a
+  // weight gradient is fastest with two blocks per CU (512 slots; 384 for pointwise convs), but in the
+  // training step it runs on a side lane beside the same unit's dgrad, where the half-size grid wins
+  // (whole step, A/B on one box: 512 slots 14.18-14.27 ms, 384: 14.10-14.12, 256: 14.07-14.14,
+  // 192: 14.13-14.22, 128: 14.46-14.54) and halves the slab traffic.
   // Skinny outputs (fast pathway, stems: a handful of tiles, 10^5..10^6 positions) are
   // latency bound per 64-position step, so they get up to 2048 blocks.
   static const long long slots = [] {
     const char* e = getenv("VS_WGRAD_SLOTS");  // experiment knob: resident block slots to fill
-    return e ? atoll(e) : 512ll;
+    return e ? atoll(e) : 256ll;
   }();
-  // pointwise convs (one tap, small K'): fewer, longer blocks beat a full residency round
-  // (s4.c 23.3 -> 21.5 us, s3.c 25.4 -> 21.1 us at 384 slots; 3x3 / temporal convs want all 512)
-  const bool dense = d->kT * d->kH * d->kW == 1;
-  const long long target = (d->Cout <= 32) ? 2048 : (dense && !getenv("VS_WGRAD_SLOTS") ? 384 : slots);
-  // two blocks are resident per CU (80 KB of LDS each): 512 slots.  Round the split DOWN so that
-  // the grid fits one residency round -- 528 blocks on 512 slots run as two rounds (s4.a: +45 %)
+  static const long long small_slots = [] {
+    const char* e = getenv("VS_WGRAD_SLOTS_SMALL");
+    return e ? atoll(e) : 2048ll;
+  }();
+  const long long target = (d->Cout <= 32) ? small_slots : slots;
+  // Round the split DOWN so that the grid fits one residency round (two blocks are resident per CU,
+  // 80 KB of LDS each) -- 528 blocks on 512 slots run as two rounds (s4.a: +45 %)
   long long S = (d->Cout <= 32) ? (target + tiles - 1) / tiles : target / tiles;
   const long long maxS = (P + 511) / 512;
   if (S > maxS) S = maxS;
