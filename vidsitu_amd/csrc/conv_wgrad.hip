@@ -507,17 +507,18 @@ static WgCfg wg_pick(const vs_conv_desc* d) {
   c.tilesM = (d->Cout + c.bm - 1) / c.bm;
   c.tilesN = (Kp + c.bn - 1) / c.bn;
   const long long tiles = (long long)c.tilesM * c.tilesN;
-  // ~256 blocks (one per CU); every block keeps >= 8 steps (512 positions) so the slab traffic
+  // ~384 blocks (1.5 per CU); every block keeps >= 8 steps (512 positions) so the slab traffic
   // (S x |dW| fp32, written and re-read) stays small next to the operand reads.  Alone on the GPU a
-  // weight gradient is fastest with two blocks per CU (512 slots; 384 for pointwise convs), but in the
-  // training step it runs on a side lane beside the same unit's dgrad, where the half-size grid wins
-  // (whole step, A/B on one box: 512 slots 14.18-14.27 ms, 384: 14.10-14.12, 256: 14.07-14.14,
-  // 192: 14.13-14.22, 128: 14.46-14.54) and halves the slab traffic.
+  // 3x3 / temporal weight gradient is fastest with two blocks per CU (512 slots; pointwise ones with 384),
+  // but in the training step it runs on a side lane beside the same unit's dgrad, where a smaller grid
+  // is faster for the whole step (A/B on one box: 512 slots 14.18-14.27 ms, 384: 14.10-14.12,
+  // 256: 14.07-14.14, 192: 14.13-14.22, 128: 14.46-14.54) and writes fewer slabs; 384 keeps most of the
+  // stand-alone speed (256 costs the kernel alone 13 %).
   // Skinny outputs (fast pathway, stems: a handful of tiles, 10^5..10^6 positions) are
   // latency bound per 64-position step, so they get up to 2048 blocks.
   static const long long slots = [] {
     const char* e = getenv("VS_WGRAD_SLOTS");  // experiment knob: resident block slots to fill
-    return e ? atoll(e) : 256ll;
+    return e ? atoll(e) : 384ll;
   }();
   static const long long small_slots = [] {
     const char* e = getenv("VS_WGRAD_SLOTS_SMALL");
