@@ -30,6 +30,7 @@ struct WgradP {
   int kT, kH, kW, sT, sH, sW, pT, pH, pW;
   int tilesM, tilesN, S, rows_per_split;
   unsigned x_bytes, dy_bytes;
+  int xcd_order;  // 1: XCD-aware block order (default); 0: round-robin (VS_WGRAD_XCD=0, A/B)
 };
 
 #define WG_OOB 0x80000000u
@@ -54,9 +55,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
   static_assert(WM * WN == 4, "4 waves");
 
   const int tid = threadIdx.x;
+  // XCD-aware order: workgroups b, b + 8, ... share an XCD; each XCD gets a contiguous run of the logical
+  // order [split][tile], so the tiles of one position split -- which read the same x / dY rows -- sit
+  // behind one L2 instead of fetching those rows once per XCD (speed only: every (split, tile) pair is
+  // still computed by exactly one block).
   int bid = blockIdx.x;
-  const int s = bid % p.S;
-  bid /= p.S;
+  if (p.xcd_order) {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+  }
+  const int ntile = p.tilesM * p.tilesN;
+  const int s = bid / ntile;
+  bid -= s * ntile;
   const int tn = bid % p.tilesN, tm = bid / p.tilesN;
   const int m0 = tm * BM, n0 = tn * BN;
   const int pbeg = s * p.rows_per_split;
@@ -260,9 +270,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradP p) {
   static_assert((D - 1) * L <= 63, "vmcnt range");
 
   const int tid = threadIdx.x;
+  // XCD-aware order: workgroups b, b + 8, ... share an XCD; each XCD gets a contiguous run of the logical
+  // order [split][tile], so the tiles of one position split -- which read the same x / dY rows -- sit
+  // behind one L2 instead of fetching those rows once per XCD (speed only: every (split, tile) pair is
+  // still computed by exactly one block).
   int bid = blockIdx.x;
-  const int s = bid % p.S;
-  bid /= p.S;
+  if (p.xcd_order) {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+  }
+  const int ntile = p.tilesM * p.tilesN;
+  const int s = bid / ntile;
+  bid -= s * ntile;
   const int tn = bid % p.tilesN, tm = bid / p.tilesN;
   const int m0 = tm * BM, n0 = tn * BN;
   const int pbeg = s * p.rows_per_split;
@@ -628,6 +647,13 @@ extern "C" int vs_conv_wgrad(const void* dy, const void* x, float* dw, const vs_
   p.tilesM = c.tilesM;
   p.tilesN = c.tilesN;
   p.S = c.S;
+  {
+    static const int xo = [] { const char* e = getenv("VS_WGRAD_XCD"); return e ? atoi(e) : 1; }();
+    // measured per layer (batch 8): a win up to ~16 output tiles (s3.b 43.5 -> 35.4 us, s4.c 22.1 -> 19.7,
+    // s3.c 24.7 -> 21.2, s2.c 29.7 -> 26.4), a loss from 36 tiles on (s4.b 36.7 -> 38.9, s5.b 48.9 -> 52.9), where
+    // one split's tiles no longer fit an XCD's share of the grid anyway
+    p.xcd_order = xo && c.tilesM * c.tilesN <= 32;
+  }
   p.rows_per_split = c.rows_per_split;
   const bool dense = (d->kT * d->kH * d->kW == 1) && d->sT == 1 && d->sH == 1 && d->sW == 1 &&
                      d->pT == 0 && d->pH == 0 && d->pW == 0;
