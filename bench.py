@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--overlap", type=int, default=-1,
                     help="train: split the step into segment graphs and all-reduce finished gradient "
                          "buckets behind the remaining backward (default: on when WORLD_SIZE > 1)")
+    ap.add_argument("--grad-dtype", default="auto", choices=["auto", "fp32", "bf16"],
+                    help="payload of the gradient all-reduce (auto: bf16 when WORLD_SIZE > 1, fp32 master "
+                         "parameters / moments either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -242,35 +245,101 @@ def bench_srl_gen(args, rank, world, dev):
         dist.destroy_process_group()
 
 
-def cpu_baseline(workload, n_vocab):
-    """fp32 torch oracle on the host cores, ONE clip of the batch (bounded sample)."""
+def _cpu_model_string():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _mem_available_gb():
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable"):
+                    return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+def cpu_baseline(workload, n_vocab, budget_s=60.0):
+    """SURVEY.md 8(d) / BASELINE.md 3: the fp32 torch restatement of the reference's path (the oracle;
+    kind "port" -- the reference's own CPU path cannot execute, its arithmetic lives in un-vendored
+    packages) on the host cores, same synthetic inputs as the GPU workload: N = 8 clips,
+    `torch.set_num_threads(os.cpu_count())`, 1 warm-up + 3 timed iterations.
+      feat_fwd        eval forward to the [8, 2304] features
+      sf_txenc_train  SlowFast-R50 + vid_feat_encoder + 6-layer TxEncoder (the reference's per-head-loop
+                      algorithm, oracle/txenc_ref.py) + Linear(1024, V): forward + backward + Adam,
+                      batch statistics over the 8 clips (2 videos x 4 events)
+    Bounded: the sample shrinks to 4 / 2 / 1 clips when the host has too little memory for 8 (fp32
+    autograd keeps about 6 GB of activations per clip), and the timed iterations stop early once
+    `budget_s` seconds are spent; `sample` states what was actually run."""
+    from oracle import txenc_ref
     from oracle.slowfast_ref import SFBaseRef, default_sf_cfg, slow_index
 
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    train = workload != "feat_fwd"
+    n = 8
+    need_gb = (4.0 if train else 1.0)  # measured: 3.8 GB peak RSS for one training clip
+    avail = _mem_available_gb()
+    while n > 1 and avail > 0 and n * need_gb + 8.0 > avail:
+        n //= 2
     torch.manual_seed(0)
     cfg = default_sf_cfg()
     mdl = SFBaseRef(cfg, n_vocab)
     g = torch.Generator().manual_seed(1234)
-    fast = torch.randn(1, 3, 32, 224, 224, generator=g)
+    fast = torch.randn(n, 3, 32, 224, 224, generator=g)
     slow = fast.index_select(2, slow_index(32, 4))
-    cores = torch.get_num_threads()
-    if workload == "feat_fwd":
+    if not train:
         mdl.eval()
-        with torch.no_grad():
-            t0 = time.perf_counter()
-            mdl.forward_feats([slow, fast])
-            dt = time.perf_counter() - t0
-        sample = "1 clip (fast 3x32x224x224 + slow 3x8x224x224), eval forward to [1,2304] features, 1 iteration"
+
+        def it():
+            with torch.no_grad():
+                mdl.forward_feats([slow, fast])
+        what = f"{n} clips (fast 3x32x224x224 + slow 3x8x224x224), eval forward to [{n}, 2304] features"
     else:
         mdl.train()
-        opt = torch.optim.Adam(mdl.parameters(), lr=1e-4, betas=(0.9, 0.99))
-        t0 = time.perf_counter()
-        loss = torch.nn.functional.cross_entropy(mdl([slow, fast]), torch.zeros(1, dtype=torch.long))
-        loss.backward()
-        opt.step()
-        dt = time.perf_counter() - t0
-        sample = "1 clip, SFBase fwd+bwd+Adam (batch-norm over that one clip), 1 iteration, no TxEncoder"
-    return {"value": round(1.0 / dt, 4), "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": sample}
+        n_ev = 4 if n % 4 == 0 else n
+        enc = torch.nn.Sequential(torch.nn.Linear(2304, 1024), torch.nn.ReLU(), torch.nn.Linear(1024, 1024))
+        txw = {k: torch.nn.Parameter(torch.from_numpy(v)) for k, v in txenc_ref.make_weights(1024, 1024, 6, 0).items()}
+        out = torch.nn.Linear(1024, n_vocab)
+        params = list(mdl.sf_mdl.parameters()) + list(enc.parameters()) + list(txw.values()) + list(out.parameters())
+        opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.99))
+        labels = torch.randint(0, n_vocab, (n,), generator=g)
+
+        def it():
+            opt.zero_grad()
+            feats = mdl.forward_feats([slow, fast]).view(n // n_ev, n_ev, -1)
+            x = enc(feats)
+            for i in range(6):
+                x = txenc_ref.encoder_layer(x, txw, f"layers.{i}.", 8)
+            loss = torch.nn.functional.cross_entropy(out(x).view(n, -1), labels)
+            loss.backward()
+            opt.step()
+        what = (f"{n} clips as {n // n_ev} videos x {n_ev} events, SlowFast-R50 + vid_feat_encoder + 6-layer "
+                f"TxEncoder (per-head loop, dropout off) + Linear(1024, {n_vocab}): fwd + bwd + Adam, "
+                f"batch-norm over the {n} clips")
+    t0 = time.perf_counter()
+    it()  # warm-up
+    warm = time.perf_counter() - t0
+    times = []
+    for _ in range(3):
+        if times and (time.perf_counter() - t0) + times[-1] > budget_s:
+            break
+        t1 = time.perf_counter()
+        it()
+        times.append(time.perf_counter() - t1)
+    dt = sorted(times)[len(times) // 2]
+    return {"value": round(n / dt, 4), "unit": "clips/s", "cores": threads, "kind": "port",
+            "cpu_model": _cpu_model_string(),
+            "sample": f"{what}; 1 warm-up ({warm:.1f} s) + {len(times)} timed iteration(s), median "
+                      f"{dt:.2f} s; torch {torch.__version__} fp32, {threads} threads"}
 
 
 def main():
@@ -313,57 +382,19 @@ def main():
                                    device=dev, dtype=torch.bfloat16)
 
     dist_on = world > 1 or (dist.is_available() and dist.is_initialized())
-    gate = {"on": dist_on}  # the rank-0-only instrumented pass must not enter a collective
-    overlap = train and (args.overlap == 1 or (args.overlap < 0 and world > 1))
-    segments = None
+    ts = None
     if train:
+        from vidsitu_amd.train_step import TrainStep
+
         mdl.train()
         arena = ParamArena(mdl)
         arena.broadcast_params(0)
         opt = ArenaAdam(arena, lr=cfg.train.lr, betas=(0.9, 0.99))
-
-        def fwd_bwd():
-            arena.transposes_async()  # dgrad weight images of the last update, beside the forward
-            opt.zero_grad()  # (every gradient is overwritten anyway; the memset overlaps the stems)
-            out = mdl(batch)
-            loss = loss_fn(out, batch)["loss"]
-            loss.backward()
-            arena._join_transposes()  # no-op unless no dgrad ran (keeps a captured graph closed)
-            return loss
-
-        if overlap:
-            # Segment s: [python callable, gradient bucket that is complete after it].  The trunk's
-            # manual backward is deferred out of autograd and run stage group by stage group; the
-            # bucket of a finished group is all-reduced (RCCL, async on its own stream) while the
-            # next group computes.  Arena order = registration order: s1..s3 | s4 | s5 | heads+TxEnc.
-            trunk = mdl.sf_mdl
-            trunk.defer_backward = True
-            segs = list(trunk.BWD_SEGMENTS)
-            ranges = arena.bucket_ranges([trunk.backward_segment_modules(sg) for sg in segs])
-            segments = [(fwd_bwd, ranges[-1])]  # everything outside the trunk is done after autograd
-            for sg, rg in zip(segs, ranges[:-1]):
-                segments.append((lambda sg=sg: trunk.run_backward_segment(sg), rg))
-
-            def step():
-                works = []
-                out = None
-                for fn, (lo, hi) in segments:
-                    r = fn()
-                    out = r if out is None else out
-                    if gate["on"]:
-                        works.append(arena.all_reduce_range(lo, hi, async_op=True))
-                for w in works:
-                    if w is not None:
-                        w.wait()
-                opt.step(world=world, defer_transposes=True)
-                return out
-        else:
-            def step():
-                loss = fwd_bwd()
-                if gate["on"]:
-                    arena.all_reduce()
-                opt.step(world=world, defer_transposes=True)
-                return loss
+        overlap = None if args.overlap < 0 else bool(args.overlap)
+        grad_bf16 = dist_on and (args.grad_dtype == "bf16" or (args.grad_dtype == "auto" and world > 1))
+        ts = TrainStep(mdl, loss_fn, arena, opt, batch, world=world, overlap=overlap, use_dist=dist_on,
+                       grad_bf16=grad_bf16)
+        step = ts.step
     else:
         mdl.eval()
 
@@ -381,53 +412,22 @@ def main():
             out = step()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    seg_graphs = None
-    if args.graph and segments is not None:
-        # one hipGraph per segment + one for Adam; the RCCL calls stay outside the graphs
-        try:
-            seg_graphs, pool = [], None
-            for fn, _ in segments + [(lambda: opt.step(world=world, defer_transposes=True), None)]:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool):
-                    fn()
-                pool = g.pool()
-                seg_graphs.append(g)
-            torch.cuda.synchronize()
-            used_graph = True
-        except Exception as e:
-            if rank == 0:
-                print(f"[bench] segmented hipGraph capture failed, running eagerly: {e!r}", file=sys.stderr)
-            seg_graphs = None
-            mdl.sf_mdl._deferred = None
-            torch.cuda.synchronize()
-    elif args.graph and not (train and dist_on):
-        try:
+    if args.graph:
+        # A failed capture is an error, not a fallback: an eager line under the same metric name
+        # would be a different measurement (the process exits non-zero).
+        if ts is not None:
+            ts.capture()
+        else:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = step()
             graph.replay()
             torch.cuda.synchronize()
-            used_graph = True
-        except Exception as e:  # capture is an optimisation, never a correctness path
-            if rank == 0:
-                print(f"[bench] hipGraph capture failed, running eagerly: {e!r}", file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize()
-
-    def run_segmented():
-        works = []
-        for g, (_, (lo, hi)) in zip(seg_graphs[:-1], segments):
-            g.replay()
-            if dist_on:
-                works.append(arena.all_reduce_range(lo, hi, async_op=True))
-        for w in works:
-            if w is not None:
-                w.wait()
-        seg_graphs[-1].replay()
+        used_graph = True
 
     def run_once():
-        if seg_graphs is not None:
-            run_segmented()
+        if ts is not None:
+            ts.run()
         elif graph is not None:
             graph.replay()
         else:
@@ -455,7 +455,8 @@ def main():
 
     roof = None
     if rank == 0 and not args.no_roofline:
-        gate["on"] = False
+        if ts is not None:
+            ts.collectives = False  # the rank-0-only instrumented pass must not enter a collective
         # per-kernel durations are taken with every launch on ONE stream (the timed region runs the
         # two pathways and the weight gradients on parallel streams, where launches overlap and a
         # launch's wall duration no longer measures the kernel)
@@ -466,7 +467,6 @@ def main():
         step()
         torch.cuda.synchronize()
         eager_ms = (time.perf_counter() - t0) * 1e3  # CPU time to enqueue one eager step
-        gate["on"] = False
         probe = EntryProbe()
         probe.install()
         reps = 3
@@ -508,13 +508,18 @@ def main():
                 out.update({"achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                             "frac": round(ach / PEAK_HBM_GBS, 4)})
             out["algorithmic_bytes_per_launch"] = round(by / n)
-            # PMC table rows whose kernel name starts with this family's name (a family such as
-            # bn_bwd_apply_kernel covers several template instances): launch-weighted mean
+            # PMC table rows of this family: the kernels whose name starts with the family's name are
+            # launched once per entry-point call (a family such as bn_bwd_apply_kernel covers several
+            # template instances): launch-weighted mean; kernels named after a "+" in the label
+            # (wgrad_reduce_kernel behind conv_wgrad, the stem's slab reduce) run behind that call and
+            # their bytes are charged to it
             key = name.split(" (")[0].split(" +")[0]
             rows = [t for k, t in pmc.items() if k.startswith(key) and not k.startswith("_")]
+            extra_names = [e.strip(" )") for e in name.split("+")[1:]]
+            extra = [t for k, t in pmc.items() if any(k.startswith(e) for e in extra_names if e)]
             nl = sum(t["launches"] for t in rows)
             out["traffic"] = round(sum((t["fetch_bytes"] + t["write_bytes"]) * t["launches"]
-                                       for t in rows) / nl) if nl else None
+                                       for t in rows + extra) / nl) if nl else None
             return out
 
         fams = sorted(agg.items(), key=lambda kv: -kv[1][1])
@@ -522,6 +527,9 @@ def main():
         top = next((fam(k, v) for k, v in fams if v[4] is not None), None)
         roof = dict(top)
         roof["probed_ms_per_step"] = round(tot_ms, 3)
+        roof["traffic_source"] = ("profiles/pmc_traffic.json (" + str(pmc.get("_meta", {}).get("build", "build not recorded")) +
+                                  "): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh, "
+                                  "not collected in this run")
         roof["note"] = ("dominant entry point of the step by summed HIP-event time; separate "
                         "instrumented eager pass on one stream (the timed region replays a hipGraph "
                         "whose pathway / wgrad branches run concurrently)")
@@ -550,9 +558,11 @@ def main():
                                     "BASELINE configs[1]: SlowFast-R50 feature extractor only, eval, "
                                     "8 clips x 3x32x224x224 per GPU"),
                        "clips_per_gpu": CLIPS_PER_GPU, "hipgraph": used_graph,
-                       "grad_allreduce": ("bucketed, overlapped with backward (4 segment graphs)"
-                                          if segments is not None else
-                                          ("single" if train else None)),
+                       "grad_allreduce": (None if ts is None else
+                                          (f"{len(ts.segments)} bucket(s), "
+                                           f"{'bf16' if ts.grad_bf16 else 'fp32'} payload, "
+                                           f"{'overlapped with backward' if ts.overlap else 'after backward'}"
+                                           if ts.use_dist else "none (single process)")),
                        "model_tflops": round(value * flop_per_clip / 1e3, 2),
                        "frac_of_bf16_mfma_peak": round(value * flop_per_clip / 1e3 / world /
                                                        PEAK_BF16_TFLOPS, 4)},

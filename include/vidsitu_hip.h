@@ -274,6 +274,12 @@ int vs_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, fl
 int vs_adam_step_dev_cast(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n,
                           float lr, float beta1, float beta2, float eps, int* step_counter,
                           float grad_scale, void* stream);
+/* Same step with the gradients read from a bf16 buffer: the summed payload of a bf16 gradient
+ * all-reduce (the reference's DDP reducer moves fp32 buckets, main_dist.py:68-79; half the xGMI
+ * bytes here).  Parameters and both moments stay fp32. */
+int vs_adam_step_dev_cast_g16(float* p, const void* g_bf16, float* m, float* v, void* p_bf16, int64_t n,
+                              float lr, float beta1, float beta2, float eps, int* step_counter,
+                              float grad_scale, void* stream);
 /* fp32 -> bf16 cast of the parameter arena (weights used by the conv kernels). */
 int vs_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 

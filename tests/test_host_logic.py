@@ -85,3 +85,27 @@ def test_sfbase_builds_with_reference_attribute_names():
     assert tuple(sd["proj_head.2.weight"].shape) == (1564, 128)
     with pytest.raises(Exception):  # no silent CPU fallback on the product path
         mdl(synth_data.synth_batch(cfg, comm, bs=1, n_ev=1, crop=32))
+
+
+REF_CFG = "/root/reference/configs/vsitu_cfg.yml"
+
+
+@pytest.mark.skipif(not __import__("os").path.exists(REF_CFG), reason="reference tree not present (GPU box)")
+def test_reference_cfg_file_loads_unmodified():
+    """Drop-in boundary: the reference's own `configs/vsitu_cfg.yml`, byte for byte, goes
+    through `get_cfg` with the reference's dotted overrides (`README.md:32-42`), and selects the same
+    plugin classes; the keys the hot path reads carry the reference's values."""
+    cfg = get_cfg({"task_type": "vb", "mdl.mdl_name": "sf_base", "train.bs": 8, "train.bsv": 8},
+                  cfg_pth=REF_CFG)
+    assert cfg.mdl.mdl_name == "sf_base" and cfg.task_type == "vb"
+    assert cfg.train.lr == 1e-4 and cfg.train.bs == 8
+    assert cfg.mdl.sf_mdl_name == "slow_fast_nl_r50_8x8" and cfg.sf_mdl.MODEL.ARCH == "slowfast"
+    assert cfg.sf_mdl.DATA.NUM_FRAMES == 32 and cfg.sf_mdl.SLOWFAST.ALPHA == 4
+    assert get_mdl_loss_eval(cfg)["mdl"] is SFBase
+    cfg = get_cfg({"task_type": "vb_arg", "mdl.mdl_name": "sfpret_txe_txd_vbarg", "mdl.tx_enc_type": "new"},
+                  cfg_pth=REF_CFG)
+    assert cfg.gen.beam_size >= 1 and cfg.tx_dec.encoder_layers >= 1
+    from vidsitu_amd.mdl_sf_base import SFPreFeats_TxEncDec
+    assert get_mdl_loss_eval(cfg)["mdl"] is SFPreFeats_TxEncDec
+    with pytest.raises(AssertionError):
+        get_cfg({"mdl.not_a_key": 1}, cfg_pth=REF_CFG)

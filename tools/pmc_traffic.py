@@ -10,6 +10,7 @@ import re
 import sys
 
 out_dir, workload = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "")
+build = sys.argv[3] if len(sys.argv) > 3 else ""
 
 
 def collect(sub, counter):
@@ -33,7 +34,7 @@ for k in sorted(set(fetch) | set(write)):
         "fetch_bytes": round(2.0 * 1024.0 * fetch[k] / max(nf[k], 1)),   # x2: gfx950 correction
         "write_bytes": round(1024.0 * write[k] / max(nw[k], 1)),
     }
-meta = {"_meta": {"workload": workload, "unit": "bytes per launch (average over the launches of one step)",
+meta = {"_meta": {"workload": workload, "build": build, "unit": "bytes per launch (average over the launches of one step)",
                   "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes); "
                             "FETCH_SIZE x 1024 x 2, WRITE_SIZE x 1024"}}
 meta.update(table)

@@ -13,6 +13,6 @@ timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OU
 echo "fetch pass exit $?"
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ARGS > $OUT/write.log 2>&1
 echo "write pass exit $?"
-python3 tools/pmc_traffic.py $OUT $WL
+python3 tools/pmc_traffic.py $OUT $WL "${VS_BUILD_TAG:-untagged}"
 find $OUT -name "*kernel_trace*.csv" -delete
 find $OUT -name "*counter_collection*.csv" -size +30M -delete

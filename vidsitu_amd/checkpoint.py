@@ -1,9 +1,16 @@
 """Checkpoint files of the reference's trainer (`utils/trn_utils.py:631-716`):
 one `torch.save`d dict {"model_state_dict", "optimizer_state_dict", "scheduler_state_dict"?, "num_it",
 "num_epoch", "cfgtxt", "best_met"}.  Model keys and shapes are the reference's (the HIP modules keep the
-upstream parameter names); the optimizer state is `torch.optim.Adam`'s (`ArenaAdam.state_dict`), so files
-written here load into the reference's `Learner` and the other way round, with or without the
-`module.` prefix of a DistributedDataParallel wrapper (`:637-642`)."""
+upstream parameter names); the optimizer state is `torch.optim.Adam`'s, indexed over the reference's
+`mdl.parameters()` order (`ArenaAdam.state_dict`), so files written here load into the reference's
+`Learner` and the other way round, with or without the `module.` prefix of a DistributedDataParallel
+wrapper (`:637-642`).
+
+One asymmetry is bridged here: the upstream SlowFast / ResNet constructor builds a classification head
+`sf_mdl.head.projection.{weight,bias}` that `forward_features` never runs (`mdl_sf_base.py:21-34`), so every
+reference checkpoint carries those two tensors and the reference's strict load expects them; `VideoTrunk`
+does not build them.  `load_model_dict` drops them before the strict check, `save_model_dict` writes
+zero placeholders of the upstream shape (`reference_only_params`)."""
 import json
 import os
 
@@ -16,9 +23,23 @@ def _strip_module(sd):
     return sd
 
 
+def reference_only_keys(mdl):
+    """{state_dict key: shape} of the tensors only the reference's model owns (see the module docstring)."""
+    out = {}
+    for mname, m in mdl.named_modules():
+        fn = getattr(m, "reference_only_params", None)
+        if callable(fn):
+            for suffix, shape in fn():
+                out[(mname + "." if mname else "") + suffix] = tuple(shape)
+    return out
+
+
 def save_model_dict(path, mdl, optimizer=None, num_it=0, num_epoch=0, best_met=None, cfg=None):
     """`Learner.save_model_dict` (`trn_utils.py:699-716`)."""
-    ckpt = {"model_state_dict": {k: v.detach().cpu().contiguous() for k, v in mdl.state_dict().items()},
+    msd = {k: v.detach().cpu().contiguous() for k, v in mdl.state_dict().items()}
+    for k, shape in reference_only_keys(mdl).items():  # placeholders the reference's strict load expects
+        msd.setdefault(k, torch.zeros(shape))
+    ckpt = {"model_state_dict": msd,
             "num_it": int(num_it), "num_epoch": int(num_epoch), "best_met": best_met,
             "cfgtxt": json.dumps(cfg if isinstance(cfg, (dict, type(None))) else str(cfg))}
     if optimizer is not None:
@@ -42,8 +63,16 @@ def load_model_dict(path, mdl, optimizer=None, load_opt=False, strict=True, aren
     if not os.path.exists(path):
         return None
     with open(path, "rb") as f:
-        ckpt = torch.load(f, map_location="cpu", weights_only=False)
-    mdl.load_state_dict(_strip_module(ckpt["model_state_dict"]), strict=strict)
+        # tensors, python scalars / containers only: the reference's files hold nothing else
+        ckpt = torch.load(f, map_location="cpu", weights_only=True)
+    msd = _strip_module(ckpt["model_state_dict"])
+    ref_only = reference_only_keys(mdl)
+    for k, shape in ref_only.items():
+        if k in msd:
+            if tuple(msd[k].shape) != shape:
+                raise ValueError(f"checkpoint tensor {k}: shape {tuple(msd[k].shape)}, the upstream model has {shape}")
+            msd = {kk: v for kk, v in msd.items() if kk != k}
+    mdl.load_state_dict(msd, strict=strict)
     if arena is None and optimizer is not None:
         arena = getattr(optimizer, "arena", None)
     if arena is not None:

@@ -1335,19 +1335,32 @@ extern "C" int vs_adam_step(float* p, const float* g, float* m, float* v, int64_
 __global__ void adam_tick_kernel(int* step) { step[0] += 1; }
 
 // float4-wide; optionally also emits the bf16 kernel copy of the updated parameters (saves the
-// separate cast pass over the arena)
-__global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, uint16_t* pb,
+// separate cast pass over the arena).  G16: the gradients are bf16 (the summed payload of a bf16
+// all-reduce); parameters and both moments stay fp32.
+template <bool G16>
+__global__ void adam_dev_kernel(float* p, const void* gv, float* m, float* v, uint16_t* pb,
                                 long long n4, long long n, float lr, float b1, float b2, float eps,
                                 const int* step, float grad_scale) {
   const float t = (float)step[0];
   const float bc1 = 1.f - powf(b1, t);
   const float bc2_sqrt = sqrtf(1.f - powf(b2, t));
   const float a = lr / bc1;
+  const float* g = (const float*)gv;
+  const uint16_t* gh = (const uint16_t*)gv;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
        i += (long long)gridDim.x * blockDim.x) {
-    const float4 g4 = ((const float4*)g)[i];
+    float gg[4];
+    if (G16) {
+      const uint2 g2 = ((const uint2*)gv)[i];
+      gg[0] = __uint_as_float(g2.x << 16) * grad_scale;
+      gg[1] = __uint_as_float(g2.x & 0xffff0000u) * grad_scale;
+      gg[2] = __uint_as_float(g2.y << 16) * grad_scale;
+      gg[3] = __uint_as_float(g2.y & 0xffff0000u) * grad_scale;
+    } else {
+      const float4 g4 = ((const float4*)gv)[i];
+      gg[0] = g4.x * grad_scale; gg[1] = g4.y * grad_scale; gg[2] = g4.z * grad_scale; gg[3] = g4.w * grad_scale;
+    }
     float4 m4 = ((float4*)m)[i], v4 = ((float4*)v)[i], p4 = ((float4*)p)[i];
-    const float gg[4] = {g4.x * grad_scale, g4.y * grad_scale, g4.z * grad_scale, g4.w * grad_scale};
     float mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
     float pp[4] = {p4.x, p4.y, p4.z, p4.w};
 #pragma unroll
@@ -1365,7 +1378,7 @@ __global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, ui
   // scalar tail (n not a multiple of 4, or unaligned buffers: then n4 == 0 and this is everything)
   for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
-    const float gi = g[i] * grad_scale;
+    const float gi = (G16 ? bf16_to_f32(gh[i]) : g[i]) * grad_scale;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     m[i] = mi;
@@ -1377,19 +1390,24 @@ __global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, ui
   }
 }
 
-static int adam_dev_launch(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n,
+static int adam_dev_launch(float* p, const void* g, bool g16, float* m, float* v, void* p_bf16, int64_t n,
                            float lr, float beta1, float beta2, float eps, int* step_counter,
                            float grad_scale, void* stream) {
-  const bool aligned = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 &&
-                       (((uintptr_t)p_bf16) & 7) == 0;
+  const bool aligned = (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v) & 15) == 0 &&
+                       (((uintptr_t)g) & (g16 ? 7 : 15)) == 0 && (((uintptr_t)p_bf16) & 7) == 0;
   const long long n4 = aligned ? n / 4 : 0;
   long long grid = ((aligned ? n4 : (long long)n) + 255) / 256;
   if (grid > 4096) grid = 4096;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_counter);
-  hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m,
-                     v, (uint16_t*)p_bf16, n4, (long long)n, lr, beta1, beta2, eps,
-                     (const int*)step_counter, grad_scale);
+  if (g16)
+    hipLaunchKernelGGL(adam_dev_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m,
+                       v, (uint16_t*)p_bf16, n4, (long long)n, lr, beta1, beta2, eps,
+                       (const int*)step_counter, grad_scale);
+  else
+    hipLaunchKernelGGL(adam_dev_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m,
+                       v, (uint16_t*)p_bf16, n4, (long long)n, lr, beta1, beta2, eps,
+                       (const int*)step_counter, grad_scale);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }
@@ -1398,14 +1416,22 @@ extern "C" int vs_adam_step_dev(float* p, const float* g, float* m, float* v, in
                                 float beta1, float beta2, float eps, int* step_counter,
                                 float grad_scale, void* stream) {
   VS_CHECK_ARG(p && g && m && v && n > 0 && step_counter, "bad args");
-  return adam_dev_launch(p, g, m, v, nullptr, n, lr, beta1, beta2, eps, step_counter, grad_scale, stream);
+  return adam_dev_launch(p, g, false, m, v, nullptr, n, lr, beta1, beta2, eps, step_counter, grad_scale, stream);
 }
 
 extern "C" int vs_adam_step_dev_cast(float* p, const float* g, float* m, float* v, void* p_bf16,
                                      int64_t n, float lr, float beta1, float beta2, float eps,
                                      int* step_counter, float grad_scale, void* stream) {
   VS_CHECK_ARG(p && g && m && v && p_bf16 && n > 0 && step_counter, "bad args");
-  return adam_dev_launch(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, step_counter, grad_scale, stream);
+  return adam_dev_launch(p, g, false, m, v, p_bf16, n, lr, beta1, beta2, eps, step_counter, grad_scale, stream);
+}
+
+extern "C" int vs_adam_step_dev_cast_g16(float* p, const void* g_bf16, float* m, float* v, void* p_bf16,
+                                         int64_t n, float lr, float beta1, float beta2, float eps,
+                                         int* step_counter, float grad_scale, void* stream) {
+  VS_CHECK_ARG(p && g_bf16 && m && v && p_bf16 && n > 0 && step_counter, "bad args");
+  return adam_dev_launch(p, g_bf16, true, m, v, p_bf16, n, lr, beta1, beta2, eps, step_counter, grad_scale,
+                         stream);
 }
 
 __global__ void cast_f32_bf16_kernel(const float* x, uint16_t* y, long long n) {

@@ -71,6 +71,25 @@ class EvalB_Gen(EvalB):
         self.compute_loss = False
 
     @torch.no_grad()
+    def forward(self, model, loss_fn, dl, dl_name="valid", rank=0, pred_path=None, mb=None):
+        """The generation rows' validation pass (`evl_vsitu.py:77-145` as `EvalB_Gen` runs it): one
+        beam search per batch; the teacher-forced LM loss of the same batches is reported beside it
+        (these models return `{"loss", "logits"}`, not `mdl_out`).  The caption metrics named in
+        `met_keys` need the external scorers and are out of scope: what comes back are the counts of
+        the generated token sequences."""
+        model.eval()
+        loss_sum, nb, n_seq, n_tok = 0.0, 0, 0, 0
+        for batch in dl:
+            loss_sum += float(loss_fn(model(batch), batch)["loss"])
+            nb += 1
+            for rec in self.forward_one_batch(model, batch):
+                for ev in rec["vb_output"].values():
+                    n_seq += 1
+                    n_tok += len(ev["tokens"])
+        return ({"loss": loss_sum / max(nb, 1)},
+                {"generated_sequences": n_seq, "tokens_per_sequence": n_tok / max(n_seq, 1)})
+
+    @torch.no_grad()
     def forward_one_batch(self, mdl, inp):
         from .seq_gen import SeqGenCustom
 

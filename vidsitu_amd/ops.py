@@ -687,6 +687,15 @@ def adam_step_dev_cast(p, g, m, v, p_bf16, lr, beta1, beta2, eps, step_counter, 
               float(grad_scale), _stream())
 
 
+def adam_step_dev_cast_g16(p, g16, m, v, p_bf16, lr, beta1, beta2, eps, step_counter, grad_scale=1.0):
+    """adam_step_dev_cast with the gradients read from a bf16 buffer (bf16 all-reduce payload)."""
+    if g16.dtype != BF16:
+        raise _lib.VsError("adam_step_dev_cast_g16: bf16 gradients expected")
+    _lib.call("vs_adam_step_dev_cast_g16", _ptr(p), _ptr(g16), _ptr(m), _ptr(v), _ptr(p_bf16), p.numel(),
+              float(lr), float(beta1), float(beta2), float(eps), _ptr(step_counter),
+              float(grad_scale), _stream())
+
+
 def cast_bf16(src_f32, dst_bf16):
     _lib.call("vs_cast_f32_to_bf16", _ptr(src_f32), _ptr(dst_bf16), src_f32.numel(), _stream())
 

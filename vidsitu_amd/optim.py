@@ -28,12 +28,40 @@ def _dense_view(buf, off, p):
     return flat.view(p.shape)
 
 
+def reference_param_order(model):
+    """[(name, parameter | None)] in the order of the reference model's `parameters()`: this build's
+    `named_parameters()` with the parameters only the reference constructs inserted where the reference
+    registers them.  A module announces those through `reference_only_params() -> [(suffix, shape)]`
+    (VideoTrunk: the upstream `head.projection` that `SlowFast_FeatModel` / `ResNet_FeatModel` build but
+    `forward_features` never calls, `mdl_sf_base.py:21-34,133-135`)."""
+    phantoms = {}
+    for mname, m in model.named_modules():
+        fn = getattr(m, "reference_only_params", None)
+        if callable(fn):
+            lst = fn()
+            if lst:
+                phantoms[mname] = lst
+    named = list(model.named_parameters())
+    out = []
+    for i, (n, p) in enumerate(named):
+        out.append((n, p))
+        for prefix, lst in phantoms.items():
+            pre = prefix + "." if prefix else ""
+            nxt = named[i + 1][0] if i + 1 < len(named) else None
+            if n.startswith(pre) and not (nxt is not None and nxt.startswith(pre)):
+                out.extend((pre + suffix, None) for suffix, _ in lst)
+    return out
+
+
 class ParamArena:
     def __init__(self, model, adopt_conv=True):
         """adopt_conv=False keeps only the flat fp32 parameter / gradient bookkeeping (what the
         CPU gloo tests exercise); True also moves the bf16 kernel weights into arenas (GPU)."""
         self.model = model
         self.params = [p for p in model.parameters() if p.requires_grad]
+        # every parameter in `model.parameters()` order, trainable or not: the index space of the
+        # reference's `torch.optim.Adam(mdl.parameters())` state (ArenaAdam.state_dict)
+        self.all_named = list(model.named_parameters())
         dev = self.params[0].device
         sizes = [(p.numel() + 3) // 4 * 4 for p in self.params]  # keep 16-byte alignment
         self.offsets = [0]
@@ -50,6 +78,7 @@ class ParamArena:
                 p.grad = _dense_view(self.grad, off, p)
                 p._vs_direct_grad = True  # HIP backward kernels may write p.grad in place
         self.numel = total
+        self.grad16 = None  # bf16 image of the gradient arena (bf16 all-reduce payload), on demand
         self._tr_table, self._loose_convs, self.data_bf16 = None, [], None
         self._tr_stream, self._tr_pending = None, False
         self._lin_table, self.wt_f32 = None, None
@@ -200,11 +229,35 @@ class ParamArena:
             out.append((lo, hi))
         return out
 
-    def all_reduce_range(self, lo, hi, async_op=False):
+    def pack_grad_bf16(self, lo, hi):
+        """grad[lo:hi] (fp32) -> grad16[lo:hi] (bf16), the payload of a bf16 gradient all-reduce.
+        GPU: one launch of the cast kernel (captured at the end of a segment's hipGraph); the CPU
+        bookkeeping mode of the gloo tests uses a torch cast."""
+        if hi <= lo:
+            return
+        if self.grad16 is None:
+            self.grad16 = torch.zeros(self.numel, dtype=torch.bfloat16, device=self.grad.device)
+        if self.grad.is_cuda:
+            ops.cast_bf16(self.grad[lo:hi], self.grad16[lo:hi])
+        else:
+            self.grad16[lo:hi].copy_(self.grad[lo:hi])
+
+    def unpack_grad_bf16(self, lo, hi):
+        """grad16[lo:hi] -> grad[lo:hi] (consumers that read fp32 gradients: the CPU mode and
+        torch optimizers; the GPU Adam kernel reads grad16 directly)."""
+        if hi > lo:
+            self.grad[lo:hi].copy_(self.grad16[lo:hi])
+
+    def all_reduce_range(self, lo, hi, async_op=False, bf16=False, packed=False):
         """All-reduce grad[lo:hi] (SUM).  Returns the work handle when async_op (None if nothing
-        to do: single process or empty range)."""
+        to do: single process or empty range).  bf16: the payload is the bf16 image grad16[lo:hi]
+        (`packed`: the caller has already run pack_grad_bf16 for the range); the sum stays in grad16."""
         if hi <= lo or not (dist.is_available() and dist.is_initialized()):
             return None
+        if bf16:
+            if not packed:
+                self.pack_grad_bf16(lo, hi)
+            return dist.all_reduce(self.grad16[lo:hi], op=dist.ReduceOp.SUM, async_op=async_op)
         return dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, async_op=async_op)
 
     def broadcast_params(self, src=0):
@@ -255,12 +308,15 @@ class ParamArena:
         with torch.cuda.stream(self._tr_stream):
             self._run_transposes()
         self._tr_pending = True
-        Conv3dP._wt_guard = self._join_transposes
+        Conv3dP._pending_arenas.add(self)  # every arena with a refresh in flight is joined by wt()
 
     def _join_transposes(self):
         if self._tr_pending:
             torch.cuda.current_stream().wait_stream(self._tr_stream)
             self._tr_pending = False
+            from .trunk import Conv3dP
+
+            Conv3dP._pending_arenas.discard(self)
 
 class ArenaAdam:
     """torch.optim.Adam semantics (lr, betas, eps; no weight decay) on the arena."""
@@ -275,38 +331,64 @@ class ArenaAdam:
         self.arena.zero_grad(fill)
 
     # ---- torch.optim.Adam's checkpoint format (`utils/trn_utils.py:699-716` saves
-    #      `optimizer.state_dict()`; `:689-697` loads it): parameter i of `mdl.parameters()` order
-    #      -> {"step", "exp_avg", "exp_avg_sq"} in the parameter's logical shape -----------------
+    #      `optimizer.state_dict()`; `:689-697` loads it).  The reference builds
+    #      `Adam(mdl.parameters())` (`main_dist.py:50`): index i = position in `mdl.parameters()`
+    #      order over ALL parameters -- frozen ones (`embed_tokens.weight` of TxEncoderOld / new_conc)
+    #      and the never-used upstream `sf_mdl.head.projection.{weight,bias}` included -- and a state
+    #      entry {"step", "exp_avg", "exp_avg_sq"} exists only for parameters that received a gradient.
+    def _reference_index(self):
+        """[(name, parameter | None)] in the reference's `mdl.parameters()` order; None marks a
+        parameter the reference model owns and this build never constructs."""
+        return reference_param_order(self.arena.model)
+
     def state_dict(self):
         a = self.arena
+        off_of = {id(p): off for p, off in zip(a.params, a.offsets)}
         step = float(int(self.t.item()))
-        state = {}
-        for i, (p, off) in enumerate(zip(a.params, a.offsets)):
+        state, index = {}, self._reference_index()
+        for i, (_, p) in enumerate(index):
+            if p is None or id(p) not in off_of:  # reference-only or frozen: no state, index kept
+                continue
+            off = off_of[id(p)]
             state[i] = {"step": torch.tensor(step),
                         "exp_avg": _dense_view(self.m, off, p).detach().clone().contiguous(),
                         "exp_avg_sq": _dense_view(self.v, off, p).detach().clone().contiguous()}
         group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0,
-                 "amsgrad": False, "params": list(range(len(a.params)))}
+                 "amsgrad": False, "params": list(range(len(index)))}
         return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
         a = self.arena
         groups = sd["param_groups"]
         order = [i for g in groups for i in g["params"]]
-        if len(order) != len(a.params):
-            raise ValueError(f"optimizer state has {len(order)} parameters, the model {len(a.params)}")
+        index = self._reference_index()
+        real = [(n, p) for n, p in index if p is not None]
+        if len(order) == len(index):
+            slots = index
+        elif len(order) == len(real):  # a state written over the parameters this build constructs
+            slots = real
+        else:
+            raise ValueError(f"optimizer state has {len(order)} parameters; the model has {len(index)} in the "
+                             f"reference's order ({len(real)} of them built here)")
         g0 = groups[0]
         self.lr, self.betas, self.eps = g0["lr"], tuple(g0["betas"]), g0["eps"]
         if any(g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) for g in groups):
             raise ValueError("weight_decay / amsgrad are not implemented by the fused Adam kernel")
+        off_of = {id(p): off for p, off in zip(a.params, a.offsets)}
         self.m.zero_()
         self.v.zero_()
         steps = set()
         with torch.no_grad():
-            for key, p, off in zip(order, a.params, a.offsets):
+            for key, (name, p) in zip(order, slots):
                 st = sd["state"].get(key)
-                if st is None:  # a parameter that never received a gradient
+                if st is None or p is None:  # never received a gradient / not built here
                     continue
+                if id(p) not in off_of:
+                    continue  # frozen here: its moments are never read
+                off = off_of[id(p)]
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state of {name}: shape {tuple(st['exp_avg'].shape)} "
+                                     f"!= parameter {tuple(p.shape)}")
                 _dense_view(self.m, off, p).copy_(st["exp_avg"].to(self.m.device))
                 _dense_view(self.v, off, p).copy_(st["exp_avg_sq"].to(self.v.device))
                 steps.add(int(float(st["step"])))
@@ -314,15 +396,23 @@ class ArenaAdam:
             raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): one shared counter here")
         self.t.fill_(steps.pop() if steps else 0)
 
-    def step(self, world=1, defer_transposes=False):
+    def step(self, world=1, defer_transposes=False, grad_bf16=False):
         """defer_transposes: leave the dgrad weight images stale; the caller refreshes them with
-        `arena.transposes_async()` at the start of the next step (bench.py)."""
+        `arena.transposes_async()` at the start of the next step (bench.py).
+        grad_bf16: the (all-reduced) gradients are read from the bf16 arena `arena.grad16`."""
         a = self.arena
         if a.data_bf16 is not None:
-            ops.adam_step_dev_cast(a.data, a.grad, self.m, self.v, a.data_bf16, self.lr, self.betas[0],
-                                   self.betas[1], self.eps, self.t, grad_scale=1.0 / world)
+            if grad_bf16:
+                ops.adam_step_dev_cast_g16(a.data, a.grad16, self.m, self.v, a.data_bf16, self.lr,
+                                           self.betas[0], self.betas[1], self.eps, self.t,
+                                           grad_scale=1.0 / world)
+            else:
+                ops.adam_step_dev_cast(a.data, a.grad, self.m, self.v, a.data_bf16, self.lr, self.betas[0],
+                                       self.betas[1], self.eps, self.t, grad_scale=1.0 / world)
             a.refresh(cast=False, transposes=not defer_transposes)
         else:
+            if grad_bf16:
+                a.unpack_grad_bf16(0, a.numel)
             ops.adam_step_dev(a.data, a.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1],
                               self.eps, self.t, grad_scale=1.0 / world)
             a.refresh()

@@ -1,0 +1,140 @@
+"""The data-parallel training step: forward + backward + gradient all-reduce + Adam.
+
+What the reference gets from `torch.nn.parallel.DistributedDataParallel` (`main_dist.py:68-79`:
+bucketed gradient all-reduce overlapped with the backward pass) and `Learner.train_epoch`
+(`utils/trn_utils.py:590-615`: zero_grad -> forward -> loss -> backward -> optimizer.step), built for
+one process per MI355X over RCCL:
+
+  * the step is cut into SEGMENTS -- [forward + heads/TxEncoder backward], trunk s5, trunk s4, the
+    rest -- each captured in its own hipGraph; the gradient bucket a segment completes (a contiguous
+    range of the fp32 gradient arena, `ParamArena.bucket_ranges`) is all-reduced asynchronously on
+    RCCL's stream while the next segment computes; Adam (one more graph) waits for the buckets;
+  * `overlap=False` is the same mechanism with ONE segment (whole forward + backward, one all-reduce);
+  * without a process group the whole step, Adam included, is one hipGraph;
+  * `grad_bf16=True`: the bucket payload is bf16 (half the xGMI bytes: 153 MB instead of 305 MB for
+    SlowFast-R50 + 6-layer TxEncoder) -- a segment's graph ends with the cast of its bucket into a
+    bf16 arena, RCCL sums that, and the Adam kernel reads the bf16 sums against its fp32 master
+    parameters and moments (`vs_adam_step_dev_cast_g16`).
+
+A failed hipGraph capture RAISES (bench.py then exits non-zero): a silently eager multi-GPU line
+would be a different measurement under the same name.
+"""
+import torch
+import torch.distributed as dist
+
+
+class TrainStep:
+    def __init__(self, mdl, loss_fn, arena, opt, batch, world=1, overlap=None, use_dist=None,
+                 grad_bf16=False):
+        self.mdl, self.loss_fn, self.arena, self.opt, self.batch = mdl, loss_fn, arena, opt, batch
+        self.world = world
+        self.use_dist = (dist.is_available() and dist.is_initialized()) if use_dist is None else use_dist
+        self.collectives = self.use_dist  # bench.py's rank-0-only instrumented pass switches them off
+        self.grad_bf16 = bool(grad_bf16) and self.use_dist
+        self.trunk = getattr(mdl, "sf_mdl", None)
+        can_overlap = self.trunk is not None and hasattr(self.trunk, "BWD_SEGMENTS")
+        self.overlap = (self.use_dist and world > 1 if overlap is None else bool(overlap)) and can_overlap
+        self.loss = None
+        self.graphs = None  # segment graphs + the Adam graph, or [whole-step graph]
+        self.segments = self._build_segments()
+
+    # ---- pieces ------------------------------------------------------------------------------
+    def fwd_bwd(self):
+        a = self.arena
+        a.transposes_async()  # dgrad weight images of the last update, beside the forward pass
+        self.opt.zero_grad()  # (every gradient is overwritten anyway; the memset overlaps the stems)
+        out = self.mdl(self.batch)
+        loss = self.loss_fn(out, self.batch)["loss"]
+        loss.backward()
+        a._join_transposes()  # no-op unless no dgrad ran (keeps a captured graph closed)
+        self.loss = loss.detach()
+        return loss
+
+    def _adam(self):
+        self.opt.step(world=self.world, defer_transposes=True, grad_bf16=self.grad_bf16)
+
+    def _build_segments(self):
+        """[(callable, (lo, hi))]: after `callable` the gradients in arena.grad[lo:hi] are final."""
+        a = self.arena
+        if not self.overlap:
+            if self.trunk is not None:
+                self.trunk.defer_backward = False
+            return [(self.fwd_bwd, (0, a.numel))]
+        trunk = self.trunk
+        trunk.defer_backward = True
+        segs = list(trunk.BWD_SEGMENTS)
+        ranges = a.bucket_ranges([trunk.backward_segment_modules(sg) for sg in segs])
+        out = [(self.fwd_bwd, ranges[-1])]  # everything outside the trunk is done after autograd
+        for sg, rg in zip(segs, ranges[:-1]):
+            out.append((lambda sg=sg: trunk.run_backward_segment(sg), rg))
+        return out
+
+    def _reduce(self, lo, hi):
+        if not (self.collectives and self.use_dist):
+            return None
+        return self.arena.all_reduce_range(lo, hi, async_op=True, bf16=self.grad_bf16, packed=True)
+
+    def _pack(self, lo, hi):
+        if self.grad_bf16:
+            self.arena.pack_grad_bf16(lo, hi)
+
+    # ---- eager ---------------------------------------------------------------------------------
+    def step(self):
+        works = []
+        for fn, (lo, hi) in self.segments:
+            fn()
+            self._pack(lo, hi)
+            works.append(self._reduce(lo, hi))
+        for w in works:
+            if w is not None:
+                w.wait()
+        self._adam()
+        return self.loss
+
+    # ---- hipGraph ------------------------------------------------------------------------------
+    def capture(self):
+        """Capture the step.  Call after at least one eager `step()` on a side stream (allocator and
+        lane-stream warm-up).  Raises RuntimeError when a capture fails."""
+        try:
+            if not self.use_dist:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.step()
+                self.graphs = [g]
+            else:
+                graphs, pool = [], None
+                fns = [(lambda fn=fn, r=r: (fn(), self._pack(*r))) for fn, r in self.segments] + [self._adam]
+                for fn in fns:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=pool):
+                        fn()
+                    pool = g.pool()
+                    graphs.append(g)
+                self.graphs = graphs
+            torch.cuda.synchronize()
+        except Exception as e:
+            self.graphs = None
+            if self.trunk is not None:
+                self.trunk._deferred = None
+            raise RuntimeError(f"hipGraph capture of the training step failed: {e!r}") from e
+
+    def replay(self):
+        if self.graphs is None:
+            raise RuntimeError("replay() before capture()")
+        if not self.use_dist:
+            self.graphs[0].replay()
+            return
+        works = []
+        for g, (_, (lo, hi)) in zip(self.graphs[:-1], self.segments):
+            g.replay()
+            works.append(self._reduce(lo, hi))
+        for w in works:
+            if w is not None:
+                w.wait()
+        self.graphs[-1].replay()
+
+    def run(self):
+        if self.graphs is not None:
+            self.replay()
+        else:
+            self.step()

@@ -46,8 +46,8 @@ class LinearFn(torch.autograd.Function):
         if wt is not None:
             from .trunk import Conv3dP
 
-            if Conv3dP._wt_guard is not None:  # an asynchronous refresh may still be in flight
-                Conv3dP._wt_guard()
+            if Conv3dP._pending_arenas:  # an asynchronous refresh may still be in flight
+                Conv3dP.join_pending_refresh()
         dx, dw, db = ops.linear_bwd(
             dy2.contiguous(), x2, w, need_dx=ctx.needs_input_grad[0], has_bias=ctx.has_bias,
             dw_out=ctx.w_param.grad if direct else None,
@@ -103,8 +103,8 @@ class FusedQKVAttnFn(torch.autograd.Function):
         if wt is not None:
             from .trunk import Conv3dP
 
-            if Conv3dP._wt_guard is not None:  # an asynchronous refresh of the images may be in flight
-                Conv3dP._wt_guard()
+            if Conv3dP._pending_arenas:  # an asynchronous refresh of the images may be in flight
+                Conv3dP.join_pending_refresh()
         for w, g in zip(f["weights"], f["grads"]):  # re-attach if something replaced .grad
             if w.grad is None or w.grad.data_ptr() != g.data_ptr():
                 w.grad = g

@@ -87,11 +87,18 @@ class Conv3dP(nn.Module):
         else:
             self.wt_bf16 = None
 
-    _wt_guard = None  # set by ParamArena while an asynchronous refresh of the images is pending
+    # ParamArenas whose asynchronous refresh of the dgrad images is in flight (one entry per arena: two
+    # models in one process each join their own side stream)
+    _pending_arenas = set()
+
+    @staticmethod
+    def join_pending_refresh():
+        for a in list(Conv3dP._pending_arenas):
+            a._join_transposes()
 
     def wt(self):
-        if Conv3dP._wt_guard is not None:
-            Conv3dP._wt_guard()
+        if Conv3dP._pending_arenas:
+            Conv3dP.join_pending_refresh()
         if self.wt_bf16 is None:
             self.wt_bf16 = ops.weight_transpose(self.w_bf16)
         return self.wt_bf16
@@ -699,6 +706,16 @@ class VideoTrunk(nn.Module):
         self._folds_version = None
         self._stats_epoch = 0  # bumped whenever a train-mode pass rewrites running stats
         self.debug_taps = None  # set to a dict to record the activations after every stage
+        self.num_classes = int(getattr(cfg.MODEL, "NUM_CLASSES", 400))
+
+    def reference_only_params(self):
+        """Parameters the reference's `sf_mdl` owns and this trunk never builds: the upstream
+        classification head `head.projection` (Linear(sum(dim_out), NUM_CLASSES)), constructed by
+        `SlowFast` / `ResNet` but never executed by `forward_features` (`mdl_sf_base.py:21-34`).
+        They sit in every reference checkpoint and in the reference's optimizer parameter order
+        (`checkpoint.py`, `optim.reference_param_order`)."""
+        return [("head.projection.weight", (self.num_classes, sum(self.dim_out))),
+                ("head.projection.bias", (self.num_classes,))]
 
     # ---- weights ----------------------------------------------------------------
     def _convs(self):
