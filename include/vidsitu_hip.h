@@ -136,6 +136,32 @@ int vs_conv_dgrad_bnstats(const void* dy, const void* wt, void* dx, const vs_con
                           const void* bn_y, int bn_y_ld, const uint8_t* relu_bits, const float* mean,
                           const float* invstd, const float* gamma, const float* beta, float* stats_partial,
                           void* workspace, size_t ws_bytes, void* stream);
+
+/* The general form of the two calls above: every optional epilogue operand of a data gradient in one POD
+ * (zero-initialise it; unused members stay NULL / 0).
+ *   residual        the gradient arriving over the other branch of a fan-out (desc.flags must carry
+ *                   VS_CONV_RESIDUAL, pitch desc.res_ld).  It may alias dx: an accumulating dgrad, the
+ *                   form the strided shortcut convolution of a ResBlock uses -- dx already holds conv a's
+ *                   data gradient and only the positions the stride reaches are read and rewritten
+ *                   (autograd's accumulation of the two branches of `ResBlock.forward`'s `x`).
+ *   residual_bits   residual is an UNMASKED gradient dz of a BatchNorm + ReLU unit and this its ReLU bit
+ *                   mask [positions][Cin / 8] (vs_bn_apply_mask): dz is added where the bit is set, which
+ *                   spares the unit's backward-apply pass the write of a masked copy.
+ *   bn_y ... stats_partial   as vs_conv_dgrad_bnstats. */
+typedef struct vs_dgrad_epilogue {
+  const void* residual;
+  const uint8_t* residual_bits;
+  const void* bn_y;
+  int bn_y_ld;
+  const uint8_t* relu_bits;
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+  float* stats_partial;
+} vs_dgrad_epilogue;
+int vs_conv_dgrad_ex(const void* dy, const void* wt, void* dx, const vs_conv_desc* d,
+                     const vs_dgrad_epilogue* ep, void* workspace, size_t ws_bytes, void* stream);
 int vs_weight_transpose(const void* w, void* wt, int Cout, int taps, int Cin, void* stream);
 /* Every dgrad weight image of a model in one launch: src/dst are bf16 arenas with equal
  * element offsets; table[i] = {offset, Cout, taps, Cin, first flat index} (int64 x 5). */

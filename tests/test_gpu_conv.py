@@ -495,3 +495,85 @@ def test_dgrad_emits_the_producer_bn_backward_sums(case, dev):
             err = float((part.double().sum(0).cpu() - want).abs().max()) / float(want.abs().max())
             assert err < 1e-5, (case[0], tile, ring, "residual", err)
     assert tried == 0 if strided else tried >= 3  # a strided dgrad with a residual is not fused
+
+
+def _unpack_bits(bits, shape):
+    """uint8 [rows, C/8] -> bool mask of logical shape [N, C, T, H, W]."""
+    n, c, t, h, w = shape
+    rows = n * t * h * w
+    keep = ((bits.view(rows, c // 8, 1) >> torch.arange(8, device=bits.device, dtype=torch.uint8)) & 1).bool()
+    return keep.view(n, t, h, w, c).permute(0, 4, 1, 2, 3)
+
+
+MR_CASES = [CASES[i] for i in (0, 1, 4, 5, 9, 10, 14, 17)] + STRIDED[:5]
+
+
+@pytest.mark.parametrize("case", MR_CASES, ids=[c[0] for c in MR_CASES])
+def test_dgrad_masked_residual_and_inplace_accumulate(case, dev):
+    """vs_conv_dgrad_ex: (1) `residual_bits` -- the residual is an unmasked gradient and the epilogue applies the
+    unit's ReLU bit mask to it: bitwise the plain dgrad fed the pre-masked residual, on every tile / staging
+    variant, the small-channel direct kernel included, and together with the BN-backward-sums epilogue;
+    (2) `inplace` -- out aliases the residual (an accumulating dgrad): bitwise the out-of-place result,
+    including strided dgrads whose zero-tap stride classes are skipped."""
+    from vidsitu_amd import ops
+
+    x, w, k, s, p = _mk(case, seed=51)
+    cin = x.shape[1]
+    y = F.conv3d(x, w, stride=s, padding=p)
+    g = torch.Generator().manual_seed(52)
+    dya = to_act(rb(torch.randn(y.shape, generator=g)), dev)
+    wt = ops.weight_transpose(to_w(w, dev))
+    r = to_act(rb(torch.randn(x.shape, generator=g)), dev)
+    xs = tuple(x.shape)
+    rows = ops.act_rows(r)
+    bits = torch.randint(0, 256, (rows, cin // 8), generator=g, dtype=torch.uint8).to(dev)
+    keep = _unpack_bits(bits, xs)
+    r_masked = ops.new_act(*xs, device=dev)
+    r_masked.copy_(torch.where(keep, r, torch.zeros((), device=dev, dtype=r.dtype)))
+    for tile in (None, 0, 1, 3):
+        for ring in (1, 2, 3):
+            want = ops.conv_dgrad(dya, wt, xs, k, s, p, tile=tile, ring=ring, residual=r_masked)
+            got = ops.conv_dgrad(dya, wt, xs, k, s, p, tile=tile, ring=ring, residual=r, residual_bits=bits)
+            assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (case[0], tile, ring, "mask")
+            plain = ops.conv_dgrad(dya, wt, xs, k, s, p, tile=tile, ring=ring, residual=r)
+            acc = ops.new_act(*xs, device=dev)
+            acc.copy_(r)
+            out = ops.conv_dgrad(dya, wt, xs, k, s, p, tile=tile, ring=ring, residual=acc, inplace=True)
+            assert out.data_ptr() == acc.data_ptr()
+            assert torch.equal(out.view(torch.int16), plain.view(torch.int16)), (case[0], tile, ring, "inplace")
+    # with the producer's BN-backward sums in the same epilogue (unit-stride only: see vs_conv_dgrad_bnstats_rows)
+    bn_y = to_act(rb(torch.randn(x.shape, generator=g)), dev)
+    mean = (torch.randn(cin, generator=g) * 0.2).to(dev)
+    invstd = (torch.rand(cin, generator=g) + 0.5).to(dev)
+    pbits = torch.randint(0, 256, (rows, cin // 8), generator=g, dtype=torch.uint8).to(dev)
+    dx1, p1 = ops.conv_dgrad(dya, wt, xs, k, s, p, residual=r_masked, bn_stats=(bn_y, mean, invstd, None, None, pbits))
+    dx2, p2 = ops.conv_dgrad(dya, wt, xs, k, s, p, residual=r, residual_bits=bits,
+                             bn_stats=(bn_y, mean, invstd, None, None, pbits))
+    assert torch.equal(dx1.view(torch.int16), dx2.view(torch.int16))
+    assert (p1 is None) == (p2 is None)
+    if p1 is not None:
+        assert torch.equal(p1, p2)
+
+
+def test_direct_kernel_masked_residual(dev):
+    """The register-resident small-channel kernel (N <= 32 columns) applies residual_bits as well."""
+    from vidsitu_amd import ops
+
+    g = torch.Generator().manual_seed(61)
+    n, cin, t, h, w, cout, k, s, p = 2, 32, 4, 12, 12, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1)
+    wgt = rb(torch.randn(cout, cin, *k, generator=g) * 0.1)
+    dya = to_act(rb(torch.randn(n, cout, t, h, w, generator=g)), dev)
+    wt = ops.weight_transpose(to_w(wgt, dev))
+    xs = (n, cin, t, h, w)
+    r = to_act(rb(torch.randn(xs, generator=g)), dev)
+    bits = torch.randint(0, 256, (n * t * h * w, cin // 8), generator=g, dtype=torch.uint8).to(dev)
+    r_masked = ops.new_act(*xs, device=dev)
+    r_masked.copy_(torch.where(_unpack_bits(bits, xs), r, torch.zeros((), device=dev, dtype=r.dtype)))
+    import ctypes as C
+    d = ops.make_desc(xs, cin, dya.shape, cout, k, s, p, 0)
+    out = (C.c_int * 5)()
+    ops._lib.load().vs_conv_plan(C.byref(d), 1, out)
+    assert out[4] == 1, "expected the direct kernel for this shape"
+    want = ops.conv_dgrad(dya, wt, xs, k, s, p, residual=r_masked)
+    got = ops.conv_dgrad(dya, wt, xs, k, s, p, residual=r, residual_bits=bits)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))

@@ -10,6 +10,13 @@
     activation and output gradient (bf16-rounded), so nothing upstream or downstream amplifies a
     difference: output, input gradient and every parameter gradient of the block within 1e-2
     (relative L2).  A wrong term in the BN backward of one unit cannot hide in a chaos band here.
+    The oracle block is evaluated with the roundings of the HIP unit (`_unit_as_the_kernels_compute_it`:
+    fp32 autograd arithmetic, conv outputs / unit outputs and the gradients arriving at them stored in
+    bf16, batch statistics from the fp32 conv output), because a ReLU mask is a discontinuity: against a
+    pure-fp32 block 0.3 % of the masks flip on rounding alone, a 5-9 % relative-L2 difference of every
+    cancellation-dominated sum behind them, and even `emulate_bf16_storage` (statistics from the ROUNDED
+    conv output) sits 2.5e-3 from the kernels' forward and 3-6 % from their gradients -- both measured on
+    earlier versions of this test, and neither says anything about the kernels.
 """
 import pytest
 import torch
@@ -108,6 +115,41 @@ def _block_list(trunk, ref):
     return out
 
 
+def _round_ste(t):
+    """bf16 rounding in the forward pass, identity in the backward pass; the gradient ARRIVING at the rounded
+    tensor is rounded to bf16 as well -- both are what a kernel that stores this tensor in bf16 does."""
+    out = t + (rb(t) - t).detach()
+    if out.requires_grad:
+        out.register_hook(rb)
+    return out
+
+
+def _unit_as_the_kernels_compute_it(x, conv, bn, relu, res=None):
+    """The oracle's conv -> BatchNorm3d(train) (-> + residual) (-> ReLU) with the roundings of the HIP unit:
+    batch statistics from the fp32 conv output (the conv epilogue sums its fp32 accumulators), normalisation of
+    the bf16-stored conv output, one rounding of the unit's output."""
+    import torch.nn.functional as F
+
+    y32 = F.conv3d(x, conv.weight, stride=conv.stride, padding=conv.padding)
+    mean = y32.mean((0, 2, 3, 4))
+    var = y32.var((0, 2, 3, 4), unbiased=False)
+    v = lambda t: t.view(1, -1, 1, 1, 1)
+    z = (_round_ste(y32) - v(mean)) * v((var + bn.eps).rsqrt()) * v(bn.weight) + v(bn.bias)
+    if res is not None:
+        z = z + res
+    return _round_ste(z.relu() if relu else z)
+
+
+def _block_as_the_kernels_compute_it(blk, x):
+    b2 = blk.branch2
+    sc = x
+    if hasattr(blk, "branch1"):
+        sc = _unit_as_the_kernels_compute_it(x, blk.branch1, blk.branch1_bn, False)
+    a = _unit_as_the_kernels_compute_it(x, b2.a, b2.a_bn, True)
+    b = _unit_as_the_kernels_compute_it(a, b2.b, b2.b_bn, True)
+    return _unit_as_the_kernels_compute_it(b, b2.c, b2.c_bn, True, res=sc)
+
+
 @pytest.mark.parametrize("arch,depth,hw,n", [("slowfast", 50, 64, 2), ("i3d", 50, 64, 2)])
 def test_every_resblock_fwd_bwd_matches_oracle_on_the_oracles_own_tensors(arch, depth, hw, n, dev):
     import copy
@@ -121,15 +163,17 @@ def test_every_resblock_fwd_bwd_matches_oracle_on_the_oracles_own_tensors(arch, 
     ref = RefTrunk(cfg)
     randomize_bn(ref, 7)
     g = torch.Generator().manual_seed(11)
-    for m in ref.modules():  # ZERO_INIT_FINAL_BN would zero every block's residual branch
-        if getattr(m, "transform_final_bn", False):
+    for m in ref.modules():
+        if getattr(m, "transform_final_bn", False):  # ZERO_INIT_FINAL_BN would zero every residual branch
             m.weight.data.copy_(0.5 + torch.rand(m.num_features, generator=g))
+        if isinstance(m, torch.nn.Conv3d):  # bf16-representable weights: both sides multiply the same numbers
+            m.weight.data = rb(m.weight.data)
     ours = VideoTrunk(cfg)
     ours.load_state_dict(ref.state_dict(), strict=True)
     ours = ours.to(dev).train()
     ours.refresh_weights()
     ref.train()
-    # the oracle's own activations / gradients at every block boundary
+    # the oracle's own activations / gradients at every block boundary (plain fp32 pass)
     fast = torch.randn(n, 3, frames, hw, hw, generator=g)
     xs = [fast.index_select(2, slow_index(frames, 4)), fast] if arch == "slowfast" else [fast]
     cap = {}
@@ -151,12 +195,12 @@ def test_every_resblock_fwd_bwd_matches_oracle_on_the_oracles_own_tensors(arch, 
         assert isinstance(oblk, ResBlock)
         x = rb(cap[name]["x"])
         dout = rb(cap[name]["dout"])
-        # oracle block alone, on the rounded tensors
+        # oracle block alone on the rounded tensors, storing in bf16 what the kernels store in bf16
         rb2 = copy.deepcopy(rblk).train()
         for p in rb2.parameters():
             p.grad = None
         xr = x.clone().requires_grad_(True)
-        zr = rb2(xr)
+        zr = _block_as_the_kernels_compute_it(rb2, xr)
         zr.backward(dout)
         # HIP block alone
         for p in oblk.parameters():
@@ -172,8 +216,9 @@ def test_every_resblock_fwd_bwd_matches_oracle_on_the_oracles_own_tensors(arch, 
             assert po[k].grad is not None, f"{name}.{k}: no gradient"
             rows.append((k, rel_l2(po[k].grad, pr.grad)))
         bad = [(k, e) for k, e in rows if not e < 1e-2]
-        worst.append((max(e for _, e in rows), name, max(rows, key=lambda r: r[1])[0]))
-        assert not bad, f"{name}: {bad}"
-    worst.sort(reverse=True)
-    print("worst per-block rel_l2 (z / dx / parameter gradients):\n" +
-          "\n".join(f"  {e:.3e} {n} ({k})" for e, n, k in worst[:8]))
+        worst.append((max(e for _, e in rows), name, max(rows, key=lambda r: r[1])[0], rows[0][1], rows[1][1], bad))
+    worst.sort(reverse=True, key=lambda r: r[0])
+    print("per-block rel_l2, worst first (worst tensor | z | dx):\n" +
+          "\n".join(f"  {e:.3e} {n} ({k}) | z {ez:.3e} | dx {edx:.3e}" for e, n, k, ez, edx, _ in worst))
+    failed = [(n, bad) for _, n, _, _, _, bad in worst if bad]
+    assert not failed, f"{len(failed)} of {len(worst)} blocks beyond 1e-2: {failed[:3]}"

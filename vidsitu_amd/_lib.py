@@ -29,6 +29,15 @@ class ConvDesc(C.Structure):
     ]
 
 
+class DgradEpilogue(C.Structure):
+    """vs_dgrad_epilogue (include/vidsitu_hip.h)."""
+
+    _fields_ = [("residual", C.c_void_p), ("residual_bits", C.c_void_p), ("bn_y", C.c_void_p),
+                ("bn_y_ld", C.c_int32), ("relu_bits", C.c_void_p), ("mean", C.c_void_p),
+                ("invstd", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("stats_partial", C.c_void_p)]
+
+
 _p, _i, _i64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
 _dp = C.POINTER(ConvDesc)
 
@@ -49,6 +58,7 @@ SIGNATURES = {
     "vs_conv_dgrad": (_i, [_p, _p, _p, _dp, _p, _p, _sz, _p]),
     "vs_conv_dgrad_bnstats_rows": (_i, [_dp]),
     "vs_conv_dgrad_bnstats": (_i, [_p, _p, _p, _dp, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "vs_conv_dgrad_ex": (_i, [_p, _p, _p, _dp, C.POINTER(DgradEpilogue), _p, _sz, _p]),
     "vs_weight_transpose": (_i, [_p, _p, _i, _i, _i, _p]),
     "vs_weight_transpose_batched": (_i, [_p, _p, _p, _i, _i64, _p]),
     "vs_transpose_f32_batched": (_i, [_p, _p, _p, _i, _i64, _p]),

@@ -17,44 +17,7 @@
 // staged through LDS so stores are whole 16-byte channel vectors.
 #include "common.h"
 
-struct ConvP {
-  const uint16_t* x;
-  const uint16_t* w;
-  uint16_t* y;
-  const float* scale;
-  const float* shift;
-  const uint16_t* res;
-  float* stats;
-  int M, Ncols, K, Cg, g_ld;
-  int Rt, Rh, Rw;  // row space per clip
-  int Gt, Gh, Gw;  // gathered tensor dims per clip
-  int kT, kH, kW;
-  int mulT, mulH, mulW;
-  int offT, offH, offW;
-  int tmul;
-  int shT, shH, shW;  // log2(stride) for the transposed gather
-  int y_ld, res_ld, flags;
-  int tilesM, tilesN;
-  unsigned x_bytes, w_bytes;  // extents for the buffer resources (FAST path)
-  int splitK;                 // > 1: blocks (tile, s) write fp32 partial tiles to `slab`
-  float* slab;                // [splitK][M][Ncols]
-  // MODE 2 (dgrad of a strided conv), stride classes: rows whose coordinate (r + pad) has the same
-  // residues mod (sT, sH, sW) use the same subset of taps (dd == residue mod s); tiles never mix
-  // classes, so a tile walks only ITS taps -- 9/4 instead of 9 for a 3x3 stride-(1,2,2) conv,
-  // 1/4 of the rows (no tap at all) for a 1x1 stride-2 one.  ncls = 0: classes off.
-  int ncls;
-  int cls_tile0[17];          // first M-tile of each class, [ncls] = number of M-tiles
-  // VS_CONV_BNBWD (dgrad whose output is the gradient dz behind a BN + ReLU unit): the epilogue also
-  // emits that BN's backward partial sums per M-tile, stats[tm][0][c] = sum g, [1][c] = sum g * xhat with
-  // xhat = (bny - mean) * invstd and g = dz where gamma * xhat + beta > 0, else 0 -- what
-  // bn_bwd_reduce_kernel<2> computes in a pass of its own over dz and bny
-  const uint16_t* bny;
-  const float *bn_mean, *bn_invstd, *bn_gamma, *bn_beta;
-  const uint8_t* bn_bits;  // the unit's ReLU mask as bits [rows][Ncols/8] (units with a residual input:
-                           // the RESIDUAL epilogue), NULL: mask recomputed from gamma / beta
-  int bny_ld;
-};
-#define VS_CONV_BNBWD (1 << 20)
+#include "conv_tile.h"
 
 template <int BM, int BN, int NSTAGE = 2>
 struct ConvSmem {
@@ -62,8 +25,6 @@ struct ConvSmem {
   static constexpr int EPI = BM * BN * 4;
   static constexpr int MAIN = (NSTAGE * STAGE > EPI) ? NSTAGE * STAGE : EPI;
 };
-
-#define VS_OOB 0x80000000u  // byte offset beyond any tensor: buffer_load returns zeros
 
 // FAST (taps <= 32, every conv of the trunk but the Cin-padded stems): per row a bitmask of
 // valid taps and a base byte offset are computed ONCE; per k-step a load is
@@ -113,9 +74,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   int qT = 0, qH = 0, qW = 0, ntT = p.kT, ntH = p.kH, ntW = p.kW;  // taps: dd = q + st * i
   if (cls) {
     stT = 1 << p.shT; stH = 1 << p.shH; stW = 1 << p.shW;
-    int cq = 0;
-    while (cq + 1 < p.ncls && tm >= p.cls_tile0[cq + 1]) ++cq;
-    m0 = (tm - p.cls_tile0[cq]) * BM;
+    const int cq = tm % p.ncls, ti = tm / p.ncls;
+    if (ti >= p.cls_tiles[cq]) {  // empty slot of the class-interleaved numbering
+      if (BNB && tid < BN && n0 + tid < p.Ncols) {
+        float* dst = p.stats + (long long)tm * 2 * p.Ncols;
+        dst[n0 + tid] = 0.f;
+        dst[p.Ncols + n0 + tid] = 0.f;
+      }
+      return;
+    }
+    m0 = ti * BM;
     qW = cq % stW; qH = (cq / stW) % stH; qT = cq / (stW * stH);
     auto first = [](int q, int off, int st) { return ((q - off) % st + st) % st; };
     auto count = [](int R, int r0, int st) { return r0 < R ? (R - r0 + st - 1) / st : 0; };
@@ -379,7 +347,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 
   if (MODE == 2 && cls && Keff == 0) {
     // no tap reaches this stride class (e.g. odd positions of a 1x1 stride-2 conv): the gradient
-    // is zero, the tile is a copy of the residual (or zeros) -- no staging, no MFMA, no LDS tile
+    // is zero, the tile is a copy of the residual (or zeros) -- no staging, no MFMA, no LDS tile.
+    // In place (residual == output, an accumulating dgrad): nothing to do at all.
+    if ((p.flags & VS_CONV_RESIDUAL) && p.res == p.y && p.res_bits == nullptr) {
+      if (BNB && tid < BN && n0 + tid < p.Ncols) {
+        float* dst = p.stats + (long long)tm * 2 * p.Ncols;
+        dst[n0 + tid] = 0.f;
+        dst[p.Ncols + n0 + tid] = 0.f;
+      }
+      return;
+    }
     __syncthreads();  // rowpos
     constexpr int CPRz = BN / 8;
     for (int idx = tid; idx < BM * CPRz; idx += 256) {
@@ -387,7 +364,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
       const int m = rowpos[row], n = n0 + c8 * 8;
       if (m >= 0 && n < p.Ncols) {
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (p.flags & VS_CONV_RESIDUAL) v = *(const uint4*)(p.res + (long long)m * p.res_ld + n);
+        if (p.flags & VS_CONV_RESIDUAL) {
+          v = *(const uint4*)(p.res + (long long)m * p.res_ld + n);
+          if (p.res_bits) v = mask8_bf16(v, p.res_bits[(long long)m * (p.Ncols >> 3) + (n >> 3)]);
+        }
         *(uint4*)(p.y + (long long)m * p.y_ld + n) = v;
       }
     }
@@ -530,257 +510,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   }
 
   // ---------------- epilogue ----------------
-  // (1) BN batch-statistic partials from the fp32 accumulators (tail rows are
-  //     zero-filled, so they add nothing).
-  if (p.flags & VS_CONV_STATS) {
-#pragma unroll
-    for (int b = 0; b < NR; ++b) {
-      float s = 0.f, q = 0.f;
-#pragma unroll
-      for (int a = 0; a < MR; ++a)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = acc[a][b][r];
-          s += v;
-          q += v * v;
-        }
-      s += __shfl_xor(s, 16, 64);
-      q += __shfl_xor(q, 16, 64);
-      s += __shfl_xor(s, 32, 64);
-      q += __shfl_xor(q, 32, 64);
-      if (lq == 0) {
-        const int col = wn * TN + b * 16 + lr;
-        statbuf[wm * BN + col] = s;
-        statbuf[WM * BN + wm * BN + col] = q;
-      }
-    }
-  }
-  constexpr int CPR = BN / 8;
-  const bool has_res = (p.flags & VS_CONV_RESIDUAL) != 0;
-  if (!has_res) {
-    // (2a) no residual: affine + ReLU in registers, bf16 straight into an LDS tile, then
-    //      whole 16-byte channel vectors are copied out (no unpack / repack pass).
-    uint16_t* Eh = (uint16_t*)smem;
-    const bool relu = (p.flags & VS_CONV_RELU) != 0;
-#pragma unroll
-    for (int b = 0; b < NR; ++b) {
-      const int col = wn * TN + b * 16 + lr;
-      float sc = 1.f, sh = 0.f;
-      if ((p.flags & VS_CONV_AFFINE) && (n0 + col < p.Ncols)) {
-        sc = p.scale[n0 + col];
-        sh = p.shift[n0 + col];
-      }
-#pragma unroll
-      for (int a = 0; a < MR; ++a)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = wm * TM + a * 16 + lq * 4 + r;
-          float v = acc[a][b][r] * sc + sh;
-          if (relu) v = fmaxf(v, 0.f);
-          Eh[row * BN + col] = f32_to_bf16(v);
-        }
-    }
-    __syncthreads();
-    if constexpr (BNB) {
-      // copy-out + the consumer BN's backward sums: thread = one 8-channel column x (256 / CPR) row
-      // lanes; the saved conv outputs of all its rows are requested before the first use
-      constexpr int RL = 256 / CPR, IT = BM / RL;
-      static_assert(256 % CPR == 0 && BM % RL == 0, "tile shape");
-      const int c8 = tid % CPR, rl = tid / CPR;
-      const int n = n0 + c8 * 8;
-      const bool nok = n < p.Ncols;
-      const int nn = nok ? n : 0;
-      float mu[8], is[8], ga[8], be[8], sg[8], sx[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        mu[e] = p.bn_mean[nn + e];
-        is[e] = p.bn_invstd[nn + e];
-        ga[e] = p.bn_gamma[nn + e];
-        be[e] = p.bn_beta[nn + e];
-        sg[e] = 0.f;
-        sx[e] = 0.f;
-      }
-      uint4 yv4[IT];
-      int mm[IT];
-#pragma unroll
-      for (int i = 0; i < IT; ++i) {
-        const int row = rl + i * RL;
-        const int m = (MODE == 2) ? rowpos[row] : (m0 + row < p.M ? m0 + row : -1);
-        mm[i] = nok ? m : -1;
-        yv4[i] = *(const uint4*)(p.bny + (long long)(mm[i] >= 0 ? mm[i] : 0) * p.bny_ld + nn);
-      }
-#pragma unroll
-      for (int i = 0; i < IT; ++i) {
-        const int row = rl + i * RL;
-        const uint4 v = *(const uint4*)(Eh + row * BN + c8 * 8);
-        if (mm[i] >= 0) {
-          *(uint4*)(p.y + (long long)mm[i] * p.y_ld + n) = v;
-          float g[8], yv[8];
-          unpack8_bf16(v, g);
-          unpack8_bf16(yv4[i], yv);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            g[e] = ((yv[e] - mu[e]) * is[e] * ga[e] + be[e]) > 0.f ? g[e] : 0.f;
-            sg[e] += g[e];
-            sx[e] += g[e] * (yv[e] - mu[e]) * is[e];
-          }
-        }
-      }
-      float* red = (float*)(smem + BM * BN * 2);  // behind the bf16 tile
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        red[tid * 16 + e] = sg[e];
-        red[tid * 16 + 8 + e] = sx[e];
-      }
-      __syncthreads();
-      if (tid < BN && n0 + tid < p.Ncols) {  // fixed order over the row lanes
-        const int cc = tid >> 3, e = tid & 7;
-        float ts = 0.f, tq = 0.f;
-        for (int r = 0; r < RL; ++r) {
-          ts += red[(r * CPR + cc) * 16 + e];
-          tq += red[(r * CPR + cc) * 16 + 8 + e];
-        }
-        float* dst = p.stats + (long long)tm * 2 * p.Ncols;
-        dst[n0 + tid] = ts;
-        dst[p.Ncols + n0 + tid] = tq;
-      }
-    } else {
-    for (int idx = tid; idx < BM * CPR; idx += 256) {
-      const int row = idx / CPR, c8 = idx - row * CPR;
-      const int m = (MODE == 2) ? rowpos[row] : (m0 + row < p.M ? m0 + row : -1), n = n0 + c8 * 8;
-      if (m >= 0 && n < p.Ncols)
-        *(uint4*)(p.y + (long long)m * p.y_ld + n) = *(const uint4*)(Eh + row * BN + c8 * 8);
-    }
-    }
-  } else {
-    // (2b) residual add: fp32 tile through LDS, residual read as 16-byte vectors
-    float* E = (float*)smem;
-#pragma unroll
-    for (int b = 0; b < NR; ++b) {
-      const int col = wn * TN + b * 16 + lr;
-      float sc = 1.f, sh = 0.f;
-      if ((p.flags & VS_CONV_AFFINE) && (n0 + col < p.Ncols)) {
-        sc = p.scale[n0 + col];
-        sh = p.shift[n0 + col];
-      }
-#pragma unroll
-      for (int a = 0; a < MR; ++a)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = wm * TM + a * 16 + lq * 4 + r;
-          E[row * BN + col] = acc[a][b][r] * sc + sh;
-        }
-    }
-    __syncthreads();
-    if constexpr (BNB) {
-      // residual add + copy-out + the consumer BN's backward sums (ReLU mask from the unit's bit mask):
-      // same thread layout as the no-residual variant above
-      constexpr int RL = 256 / CPR, IT = BM / RL;
-      static_assert(256 % CPR == 0 && BM % RL == 0, "tile shape");
-      const int c8 = tid % CPR, rl = tid / CPR;
-      const int n = n0 + c8 * 8;
-      const bool nok = n < p.Ncols;
-      const int nn = nok ? n : 0;
-      const int bpr = p.Ncols >> 3;
-      float mu[8], is[8], sg[8], sx[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        mu[e] = p.bn_mean[nn + e];
-        is[e] = p.bn_invstd[nn + e];
-        sg[e] = 0.f;
-        sx[e] = 0.f;
-      }
-      uint4 yv4[IT], rv4[IT];
-      unsigned bits[IT];
-      int mm[IT];
-#pragma unroll
-      for (int i = 0; i < IT; ++i) {
-        const int row = rl + i * RL;
-        const int m = (MODE == 2) ? rowpos[row] : (m0 + row < p.M ? m0 + row : -1);
-        mm[i] = nok ? m : -1;
-        const long long mc = mm[i] >= 0 ? mm[i] : 0;
-        yv4[i] = *(const uint4*)(p.bny + mc * p.bny_ld + nn);
-        rv4[i] = *(const uint4*)(p.res + mc * p.res_ld + nn);
-        bits[i] = p.bn_bits[mc * bpr + (nn >> 3)];
-      }
-#pragma unroll
-      for (int i = 0; i < IT; ++i) {
-        const int row = rl + i * RL;
-        const float4 v0 = *(const float4*)(E + row * BN + c8 * 8);
-        const float4 v1 = *(const float4*)(E + row * BN + c8 * 8 + 4);
-        if (mm[i] >= 0) {
-          float v[8], rf[8], g[8], yv[8];
-          v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
-          v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-          unpack8_bf16(rv4[i], rf);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += rf[e];
-          const uint4 o = pack8_bf16(v);
-          *(uint4*)(p.y + (long long)mm[i] * p.y_ld + n) = o;
-          unpack8_bf16(o, g);  // the sums see dz as stored
-          unpack8_bf16(yv4[i], yv);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            g[e] = ((bits[i] >> e) & 1u) ? g[e] : 0.f;
-            sg[e] += g[e];
-            sx[e] += g[e] * (yv[e] - mu[e]) * is[e];
-          }
-        }
-      }
-      __syncthreads();  // every thread is done with the fp32 tile: its space holds the row-lane sums
-      float* red = (float*)smem;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        red[tid * 16 + e] = sg[e];
-        red[tid * 16 + 8 + e] = sx[e];
-      }
-      __syncthreads();
-      if (tid < BN && n0 + tid < p.Ncols) {  // fixed order over the row lanes
-        const int cc = tid >> 3, e = tid & 7;
-        float ts = 0.f, tq = 0.f;
-        for (int r = 0; r < RL; ++r) {
-          ts += red[(r * CPR + cc) * 16 + e];
-          tq += red[(r * CPR + cc) * 16 + 8 + e];
-        }
-        float* dst = p.stats + (long long)tm * 2 * p.Ncols;
-        dst[n0 + tid] = ts;
-        dst[p.Ncols + n0 + tid] = tq;
-      }
-    } else {
-    for (int idx = tid; idx < BM * CPR; idx += 256) {
-      const int row = idx / CPR, c8 = idx - row * CPR;
-      const int m = (MODE == 2) ? rowpos[row] : (m0 + row < p.M ? m0 + row : -1), n = n0 + c8 * 8;
-      if (m >= 0 && n < p.Ncols) {
-        float v[8];
-        const float4 v0 = *(const float4*)(E + row * BN + c8 * 8);
-        const float4 v1 = *(const float4*)(E + row * BN + c8 * 8 + 4);
-        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
-        v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-        const uint4 rv = *(const uint4*)(p.res + (long long)m * p.res_ld + n);
-        float rf[8];
-        unpack8_bf16(rv, rf);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += rf[e];
-        if (p.flags & VS_CONV_RELU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        *(uint4*)(p.y + (long long)m * p.y_ld + n) = pack8_bf16(v);
-      }
-    }
-    }
-  }
-  if ((p.flags & VS_CONV_STATS) && tid < BN && n0 + tid < p.Ncols) {
-    float s = 0.f, q = 0.f;
-#pragma unroll
-    for (int w = 0; w < WM; ++w) {
-      s += statbuf[w * BN + tid];
-      q += statbuf[WM * BN + w * BN + tid];
-    }
-    float* dst = p.stats + (long long)tm * 2 * p.Ncols;
-    dst[n0 + tid] = s;
-    dst[p.Ncols + n0 + tid] = q;
-  }
+  conv_tile_epilogue<BM, BN, WM, WN, BNB>(p, acc, smem, statbuf, tm, n0, [&](int row) {
+    return (MODE == 2) ? rowpos[row] : (m0 + row < p.M ? m0 + row : -1);
+  });
 }
 
 // Sum of the split-K slabs (fixed order) + the whole fused epilogue.  Block = 64 rows x all
@@ -1022,6 +754,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p, int tiles_per
           float f[8], g[8];
           unpack8_bf16(v, f);
           unpack8_bf16(*(const uint4*)(p.res + (long long)mm * p.res_ld + n), g);
+          if (p.res_bits) mask8(g, p.res_bits[(long long)mm * (p.Ncols >> 3) + (n >> 3)]);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             f[e] += g[e];
@@ -1121,7 +854,10 @@ __global__ void conv_naive_kernel(ConvP p, int transposed) {
       }
   float v = acc;
   if (p.flags & VS_CONV_AFFINE) v = v * p.scale[n] + p.shift[n];
-  if (p.flags & VS_CONV_RESIDUAL) v += bf16_to_f32(p.res[(long long)m * p.res_ld + n]);
+  if (p.flags & VS_CONV_RESIDUAL) {
+    const bool on = !p.res_bits || ((p.res_bits[(long long)m * (p.Ncols >> 3) + (n >> 3)] >> (n & 7)) & 1);
+    if (on) v += bf16_to_f32(p.res[(long long)m * p.res_ld + n]);
+  }
   if (p.flags & VS_CONV_RELU) v = fmaxf(v, 0.f);
   p.y[(long long)m * p.y_ld + n] = f32_to_bf16(v);
 }
@@ -1315,7 +1051,7 @@ static size_t plan_ws_bytes(const ConvPlan& pl, long long M, int Ncols) {
 }
 
 // Stride classes of the transposed gather (MODE 2): tiles are laid out class by class; sets
-// p.ncls / p.cls_tile0 / p.tilesM.
+// p.ncls / p.cls_tiles / p.tilesM.
 static void setup_stride_classes(ConvP& p, int bm, int mode, int flags) {
   p.ncls = 0;
   if (mode == 2 && p.kT * p.kH * p.kW <= 31 && !(flags & VS_CONV_NOCLASS)) {
@@ -1327,15 +1063,15 @@ static void setup_stride_classes(ConvP& p, int bm, int mode, int flags) {
         const int r0 = ((q - off) % st + st) % st;
         return r0 < R ? (R - r0 + st - 1) / st : 0;
       };
-      int t0 = 0;
+      int tmax = 0;
       for (int q = 0; q < ncls; ++q) {
         const int qw = q % sW, qh = (q / sW) % sH, qt = q / (sW * sH);
         const long long rows = (long long)nb * cnt(p.Rt, qt, p.offT, sT) * cnt(p.Rh, qh, p.offH, sH) *
                                cnt(p.Rw, qw, p.offW, sW);
-        p.cls_tile0[q] = t0;
-        t0 += (int)((rows + bm - 1) / bm);
+        p.cls_tiles[q] = (int)((rows + bm - 1) / bm);
+        if (p.cls_tiles[q] > tmax) tmax = p.cls_tiles[q];
       }
-      p.cls_tile0[ncls] = t0;
+      const int t0 = tmax * ncls;
       p.ncls = ncls;
       p.tilesM = t0;
     }
@@ -1361,6 +1097,10 @@ static int launch_conv(ConvP& p, int mode, int naive, int flags, void* ws, size_
   p.tilesN = (p.Ncols + c.bn - 1) / c.bn;
   setup_stride_classes(p, c.bm, mode, flags);
   if (pl.S > 1) {
+    if (p.res_bits) {
+      vs_set_error("conv: the split-K plan has no masked-residual epilogue");
+      return VS_ERR_UNSUPPORTED;
+    }
     if (ws == nullptr || ws_bytes < plan_ws_bytes(pl, p.M, p.Ncols)) {
       vs_set_error("conv: split-K workspace too small (%zu < %zu)", ws_bytes,
                    plan_ws_bytes(pl, p.M, p.Ncols));
@@ -1468,6 +1208,7 @@ extern "C" int vs_conv_fwd(const void* x, const void* w, void* y, const vs_conv_
   p.bn_mean = p.bn_invstd = p.bn_gamma = p.bn_beta = nullptr;
   p.bn_bits = nullptr;
   p.bny_ld = 0;
+  p.res_bits = nullptr;
   p.M = d->N * d->To * d->Ho * d->Wo;
   p.Ncols = d->Cout;
   p.K = d->kT * d->kH * d->kW * d->Cin;
@@ -1506,6 +1247,7 @@ static int fill_dgrad_params(ConvP& p, const vs_conv_desc* d) {
   p.bn_mean = p.bn_invstd = p.bn_gamma = p.bn_beta = nullptr;
   p.bn_bits = nullptr;
   p.bny_ld = 0;
+  p.res_bits = nullptr;
   p.M = d->N * d->Ti * d->Hi * d->Wi;
   p.Ncols = d->Cin;
   p.K = d->kT * d->kH * d->kW * d->Cout;
@@ -1529,6 +1271,7 @@ static int fill_dgrad_params(ConvP& p, const vs_conv_desc* d) {
 }
 
 static int dgrad_impl(const void* dy, const void* wt, void* dx, const vs_conv_desc* d, const void* residual,
+                      const uint8_t* residual_bits,
                       void* workspace, size_t ws_bytes, void* stream, const void* bn_y, int bn_y_ld,
                       const uint8_t* relu_bits, const float* mean, const float* invstd, const float* gamma,
                       const float* beta, float* stats_partial) {
@@ -1543,6 +1286,8 @@ static int dgrad_impl(const void* dy, const void* wt, void* dx, const vs_conv_de
   p.w = (const uint16_t*)wt;
   p.y = (uint16_t*)dx;
   p.res = (const uint16_t*)residual;
+  VS_CHECK_ARG(!residual_bits || (residual && d->Cin % 8 == 0), "a residual mask needs a residual");
+  p.res_bits = residual_bits;
   {
     const long long xb = (long long)d->N * d->To * d->Ho * d->Wo * d->y_ld * 2;
     const long long wb = (long long)d->Cin * p.K * 2;
@@ -1589,8 +1334,16 @@ extern "C" int vs_conv_dgrad_bnstats_rows(const vs_conv_desc* d) {
 
 extern "C" int vs_conv_dgrad(const void* dy, const void* wt, void* dx, const vs_conv_desc* d,
                              const void* residual, void* workspace, size_t ws_bytes, void* stream) {
-  return dgrad_impl(dy, wt, dx, d, residual, workspace, ws_bytes, stream, nullptr, 0, nullptr, nullptr,
+  return dgrad_impl(dy, wt, dx, d, residual, nullptr, workspace, ws_bytes, stream, nullptr, 0, nullptr, nullptr,
                     nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" int vs_conv_dgrad_ex(const void* dy, const void* wt, void* dx, const vs_conv_desc* d,
+                                const vs_dgrad_epilogue* ep, void* workspace, size_t ws_bytes, void* stream) {
+  VS_CHECK_ARG(ep != nullptr, "null epilogue description");
+  VS_CHECK_ARG(!ep->stats_partial || ep->bn_y, "stats_partial needs the BN unit's operands");
+  return dgrad_impl(dy, wt, dx, d, ep->residual, ep->residual_bits, workspace, ws_bytes, stream, ep->bn_y,
+                    ep->bn_y_ld, ep->relu_bits, ep->mean, ep->invstd, ep->gamma, ep->beta, ep->stats_partial);
 }
 
 extern "C" int vs_conv_dgrad_bnstats(const void* dy, const void* wt, void* dx, const vs_conv_desc* d,
@@ -1599,7 +1352,7 @@ extern "C" int vs_conv_dgrad_bnstats(const void* dy, const void* wt, void* dx, c
                                      const float* gamma, const float* beta, float* stats_partial,
                                      void* workspace, size_t ws_bytes, void* stream) {
   VS_CHECK_ARG(stats_partial, "null stats_partial");
-  return dgrad_impl(dy, wt, dx, d, residual, workspace, ws_bytes, stream, bn_y, bn_y_ld, relu_bits, mean,
+  return dgrad_impl(dy, wt, dx, d, residual, nullptr, workspace, ws_bytes, stream, bn_y, bn_y_ld, relu_bits, mean,
                     invstd, gamma, beta, stats_partial);
 }
 

@@ -1,0 +1,338 @@
+// Shared between the convolution kernels (conv_igemm.hip, conv_halo.hip): the launch parameter block and the
+// tile epilogue.  gfx950 only.
+#pragma once
+#include "common.h"
+
+struct ConvP {
+  const uint16_t* x;
+  const uint16_t* w;
+  uint16_t* y;
+  const float* scale;
+  const float* shift;
+  const uint16_t* res;
+  float* stats;
+  int M, Ncols, K, Cg, g_ld;
+  int Rt, Rh, Rw;  // row space per clip
+  int Gt, Gh, Gw;  // gathered tensor dims per clip
+  int kT, kH, kW;
+  int mulT, mulH, mulW;
+  int offT, offH, offW;
+  int tmul;
+  int shT, shH, shW;  // log2(stride) for the transposed gather
+  int y_ld, res_ld, flags;
+  int tilesM, tilesN;
+  unsigned x_bytes, w_bytes;  // extents for the buffer resources (FAST path)
+  int splitK;                 // > 1: blocks (tile, s) write fp32 partial tiles to `slab`
+  float* slab;                // [splitK][M][Ncols]
+  // MODE 2 (dgrad of a strided conv), stride classes: rows whose coordinate (r + pad) has the same
+  // residues mod (sT, sH, sW) use the same subset of taps (dd == residue mod s); tiles never mix
+  // classes, so a tile walks only ITS taps -- 9/4 instead of 9 for a 3x3 stride-(1,2,2) conv,
+  // 1/4 of the rows (no tap at all) for a 1x1 stride-2 one.  ncls = 0: classes off.
+  // M-tiles are numbered class-interleaved: logical tile u = (i, class u % ncls), i = u / ncls, valid while
+  // i < cls_tiles[class] (slots beyond a smaller class's last tile exit at once).  A class-major numbering put
+  // each class on its own pair of XCDs under the XCD-contiguous block order -- a 1x1 stride-2 dgrad (one class of
+  // four has taps) then ran on 2 of the 8 XCDs.
+  int ncls;
+  int cls_tiles[16];          // M-tiles of each class
+  // VS_CONV_BNBWD (dgrad whose output is the gradient dz behind a BN + ReLU unit): the epilogue also
+  // emits that BN's backward partial sums per M-tile, stats[tm][0][c] = sum g, [1][c] = sum g * xhat with
+  // xhat = (bny - mean) * invstd and g = dz where gamma * xhat + beta > 0, else 0 -- what
+  // bn_bwd_reduce_kernel<2> computes in a pass of its own over dz and bny
+  const uint16_t* bny;
+  const float *bn_mean, *bn_invstd, *bn_gamma, *bn_beta;
+  const uint8_t* bn_bits;  // the unit's ReLU mask as bits [rows][Ncols/8] (units with a residual input:
+                           // the RESIDUAL epilogue), NULL: mask recomputed from gamma / beta
+  int bny_ld;
+  // RESIDUAL with a mask: the residual operand is an UNMASKED gradient dz and res_bits the ReLU mask of the
+  // unit it belongs to (bits [rows][Ncols/8]); the epilogue adds dz where the bit is set.  Spares the
+  // BN-backward apply kernel of a bottleneck's last unit the write of its masked copy of dz (`dres`).
+  const uint8_t* res_bits;
+};
+#define VS_CONV_BNBWD (1 << 20)
+
+#define VS_OOB 0x80000000u  // byte offset beyond any tensor: buffer_load returns zeros
+
+__device__ __forceinline__ void mask8(float* f, unsigned bits) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = ((bits >> e) & 1u) ? f[e] : 0.f;
+}
+__device__ __forceinline__ uint4 mask8_bf16(uint4 v, unsigned bits) {
+  v.x &= ((bits & 1u) ? 0x0000ffffu : 0u) | ((bits & 2u) ? 0xffff0000u : 0u);
+  v.y &= ((bits & 4u) ? 0x0000ffffu : 0u) | ((bits & 8u) ? 0xffff0000u : 0u);
+  v.z &= ((bits & 16u) ? 0x0000ffffu : 0u) | ((bits & 32u) ? 0xffff0000u : 0u);
+  v.w &= ((bits & 64u) ? 0x0000ffffu : 0u) | ((bits & 128u) ? 0xffff0000u : 0u);
+  return v;
+}
+
+// -----------------------------------------------------------------------------------------------
+// Tile epilogue shared by the implicit-GEMM kernel and the halo-image kernel (conv_halo.hip): fp32
+// accumulators of a BM x BN tile (4 waves, WM x WN, wave tile TM x TN) -> BN batch-statistic partials,
+// affine, residual (optionally masked by bits), ReLU, bf16 stores as 16-byte channel vectors, and -- BNB --
+// the BN-backward sums of the unit this dx belongs to.  `rowm(row)` maps a tile row to its output position
+// (or -1).  `smem` is the block's staging area (free once the main loop is done), `statbuf` [2][WM][BN].
+// -----------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, bool BNB, typename RowMap>
+__device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16],
+                                                   char* smem, float* statbuf, int tm, int n0, RowMap rowm) {
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MR = TM / 16, NR = TN / 16;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane & 15, lq = lane >> 4;
+  // (1) BN batch-statistic partials from the fp32 accumulators (tail rows are
+  //     zero-filled, so they add nothing).
+  if (p.flags & VS_CONV_STATS) {
+#pragma unroll
+    for (int b = 0; b < NR; ++b) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int a = 0; a < MR; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[a][b][r];
+          s += v;
+          q += v * v;
+        }
+      s += __shfl_xor(s, 16, 64);
+      q += __shfl_xor(q, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 32, 64);
+      if (lq == 0) {
+        const int col = wn * TN + b * 16 + lr;
+        statbuf[wm * BN + col] = s;
+        statbuf[WM * BN + wm * BN + col] = q;
+      }
+    }
+  }
+  constexpr int CPR = BN / 8;
+  const bool has_res = (p.flags & VS_CONV_RESIDUAL) != 0;
+  if (!has_res) {
+    // (2a) no residual: affine + ReLU in registers, bf16 straight into an LDS tile, then
+    //      whole 16-byte channel vectors are copied out (no unpack / repack pass).
+    uint16_t* Eh = (uint16_t*)smem;
+    const bool relu = (p.flags & VS_CONV_RELU) != 0;
+#pragma unroll
+    for (int b = 0; b < NR; ++b) {
+      const int col = wn * TN + b * 16 + lr;
+      float sc = 1.f, sh = 0.f;
+      if ((p.flags & VS_CONV_AFFINE) && (n0 + col < p.Ncols)) {
+        sc = p.scale[n0 + col];
+        sh = p.shift[n0 + col];
+      }
+#pragma unroll
+      for (int a = 0; a < MR; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wm * TM + a * 16 + lq * 4 + r;
+          float v = acc[a][b][r] * sc + sh;
+          if (relu) v = fmaxf(v, 0.f);
+          Eh[row * BN + col] = f32_to_bf16(v);
+        }
+    }
+    __syncthreads();
+    if constexpr (BNB) {
+      // copy-out + the consumer BN's backward sums: thread = one 8-channel column x (256 / CPR) row
+      // lanes; the saved conv outputs of all its rows are requested before the first use
+      constexpr int RL = 256 / CPR, IT = BM / RL;
+      static_assert(256 % CPR == 0 && BM % RL == 0, "tile shape");
+      const int c8 = tid % CPR, rl = tid / CPR;
+      const int n = n0 + c8 * 8;
+      const bool nok = n < p.Ncols;
+      const int nn = nok ? n : 0;
+      float mu[8], is[8], ga[8], be[8], sg[8], sx[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        mu[e] = p.bn_mean[nn + e];
+        is[e] = p.bn_invstd[nn + e];
+        ga[e] = p.bn_gamma[nn + e];
+        be[e] = p.bn_beta[nn + e];
+        sg[e] = 0.f;
+        sx[e] = 0.f;
+      }
+      uint4 yv4[IT];
+      int mm[IT];
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int row = rl + i * RL;
+        const int m = rowm(row);
+        mm[i] = nok ? m : -1;
+        yv4[i] = *(const uint4*)(p.bny + (long long)(mm[i] >= 0 ? mm[i] : 0) * p.bny_ld + nn);
+      }
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int row = rl + i * RL;
+        const uint4 v = *(const uint4*)(Eh + row * BN + c8 * 8);
+        if (mm[i] >= 0) {
+          *(uint4*)(p.y + (long long)mm[i] * p.y_ld + n) = v;
+          float g[8], yv[8];
+          unpack8_bf16(v, g);
+          unpack8_bf16(yv4[i], yv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            g[e] = ((yv[e] - mu[e]) * is[e] * ga[e] + be[e]) > 0.f ? g[e] : 0.f;
+            sg[e] += g[e];
+            sx[e] += g[e] * (yv[e] - mu[e]) * is[e];
+          }
+        }
+      }
+      float* red = (float*)(smem + BM * BN * 2);  // behind the bf16 tile
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[tid * 16 + e] = sg[e];
+        red[tid * 16 + 8 + e] = sx[e];
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < p.Ncols) {  // fixed order over the row lanes
+        const int cc = tid >> 3, e = tid & 7;
+        float ts = 0.f, tq = 0.f;
+        for (int r = 0; r < RL; ++r) {
+          ts += red[(r * CPR + cc) * 16 + e];
+          tq += red[(r * CPR + cc) * 16 + 8 + e];
+        }
+        float* dst = p.stats + (long long)tm * 2 * p.Ncols;
+        dst[n0 + tid] = ts;
+        dst[p.Ncols + n0 + tid] = tq;
+      }
+    } else {
+    for (int idx = tid; idx < BM * CPR; idx += 256) {
+      const int row = idx / CPR, c8 = idx - row * CPR;
+      const int m = rowm(row), n = n0 + c8 * 8;
+      if (m >= 0 && n < p.Ncols)
+        *(uint4*)(p.y + (long long)m * p.y_ld + n) = *(const uint4*)(Eh + row * BN + c8 * 8);
+    }
+    }
+  } else {
+    // (2b) residual add: fp32 tile through LDS, residual read as 16-byte vectors
+    float* E = (float*)smem;
+#pragma unroll
+    for (int b = 0; b < NR; ++b) {
+      const int col = wn * TN + b * 16 + lr;
+      float sc = 1.f, sh = 0.f;
+      if ((p.flags & VS_CONV_AFFINE) && (n0 + col < p.Ncols)) {
+        sc = p.scale[n0 + col];
+        sh = p.shift[n0 + col];
+      }
+#pragma unroll
+      for (int a = 0; a < MR; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wm * TM + a * 16 + lq * 4 + r;
+          E[row * BN + col] = acc[a][b][r] * sc + sh;
+        }
+    }
+    __syncthreads();
+    if constexpr (BNB) {
+      // residual add + copy-out + the consumer BN's backward sums (ReLU mask from the unit's bit mask):
+      // same thread layout as the no-residual variant above
+      constexpr int RL = 256 / CPR, IT = BM / RL;
+      static_assert(256 % CPR == 0 && BM % RL == 0, "tile shape");
+      const int c8 = tid % CPR, rl = tid / CPR;
+      const int n = n0 + c8 * 8;
+      const bool nok = n < p.Ncols;
+      const int nn = nok ? n : 0;
+      const int bpr = p.Ncols >> 3;
+      float mu[8], is[8], sg[8], sx[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        mu[e] = p.bn_mean[nn + e];
+        is[e] = p.bn_invstd[nn + e];
+        sg[e] = 0.f;
+        sx[e] = 0.f;
+      }
+      uint4 yv4[IT], rv4[IT];
+      unsigned bits[IT], rbits[IT];
+      int mm[IT];
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int row = rl + i * RL;
+        const int m = rowm(row);
+        mm[i] = nok ? m : -1;
+        const long long mc = mm[i] >= 0 ? mm[i] : 0;
+        yv4[i] = *(const uint4*)(p.bny + mc * p.bny_ld + nn);
+        rv4[i] = *(const uint4*)(p.res + mc * p.res_ld + nn);
+        bits[i] = p.bn_bits[mc * bpr + (nn >> 3)];
+        rbits[i] = p.res_bits ? (unsigned)p.res_bits[mc * bpr + (nn >> 3)] : 0xffu;
+      }
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int row = rl + i * RL;
+        const float4 v0 = *(const float4*)(E + row * BN + c8 * 8);
+        const float4 v1 = *(const float4*)(E + row * BN + c8 * 8 + 4);
+        if (mm[i] >= 0) {
+          float v[8], rf[8], g[8], yv[8];
+          v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
+          v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+          unpack8_bf16(rv4[i], rf);
+          mask8(rf, rbits[i]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rf[e];
+          const uint4 o = pack8_bf16(v);
+          *(uint4*)(p.y + (long long)mm[i] * p.y_ld + n) = o;
+          unpack8_bf16(o, g);  // the sums see dz as stored
+          unpack8_bf16(yv4[i], yv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            g[e] = ((bits[i] >> e) & 1u) ? g[e] : 0.f;
+            sg[e] += g[e];
+            sx[e] += g[e] * (yv[e] - mu[e]) * is[e];
+          }
+        }
+      }
+      __syncthreads();  // every thread is done with the fp32 tile: its space holds the row-lane sums
+      float* red = (float*)smem;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[tid * 16 + e] = sg[e];
+        red[tid * 16 + 8 + e] = sx[e];
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < p.Ncols) {  // fixed order over the row lanes
+        const int cc = tid >> 3, e = tid & 7;
+        float ts = 0.f, tq = 0.f;
+        for (int r = 0; r < RL; ++r) {
+          ts += red[(r * CPR + cc) * 16 + e];
+          tq += red[(r * CPR + cc) * 16 + 8 + e];
+        }
+        float* dst = p.stats + (long long)tm * 2 * p.Ncols;
+        dst[n0 + tid] = ts;
+        dst[p.Ncols + n0 + tid] = tq;
+      }
+    } else {
+    for (int idx = tid; idx < BM * CPR; idx += 256) {
+      const int row = idx / CPR, c8 = idx - row * CPR;
+      const int m = rowm(row), n = n0 + c8 * 8;
+      if (m >= 0 && n < p.Ncols) {
+        float v[8];
+        const float4 v0 = *(const float4*)(E + row * BN + c8 * 8);
+        const float4 v1 = *(const float4*)(E + row * BN + c8 * 8 + 4);
+        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
+        v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+        const uint4 rv = *(const uint4*)(p.res + (long long)m * p.res_ld + n);
+        float rf[8];
+        unpack8_bf16(rv, rf);
+        if (p.res_bits) mask8(rf, p.res_bits[(long long)m * (p.Ncols >> 3) + (n >> 3)]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rf[e];
+        if (p.flags & VS_CONV_RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        *(uint4*)(p.y + (long long)m * p.y_ld + n) = pack8_bf16(v);
+      }
+    }
+    }
+  }
+  if ((p.flags & VS_CONV_STATS) && tid < BN && n0 + tid < p.Ncols) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) {
+      s += statbuf[w * BN + tid];
+      q += statbuf[WM * BN + w * BN + tid];
+    }
+    float* dst = p.stats + (long long)tm * 2 * p.Ncols;
+    dst[n0 + tid] = s;
+    dst[p.Ncols + n0 + tid] = q;
+  }
+}
+

@@ -289,13 +289,20 @@ def transpose_f32_batched(src, dst, table, total, tiled=True):
 
 
 def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=None, ring=0,
-               noclass=False, bn_stats=None):
+               noclass=False, bn_stats=None, residual_bits=None, inplace=False):
     """dx[xs] = conv_transpose(dy, w) (+ residual).  wt from weight_transpose.
     bn_stats = (y, mean, invstd, gamma, beta[, relu_bits]) of the BatchNorm + ReLU unit whose output this
     convolution consumed and whose complete dz this dx is: returns (dx, partial) with partial [rows, 2, Cin]
     the unit's BN-backward sums emitted by the dgrad epilogue (vs_conv_dgrad_bnstats), or (dx, None) when
     this dgrad cannot emit them.  Without `residual` the unit's mask is recomputed from gamma / beta; with
-    `residual` the unit's bit mask (relu_bits, from bn_apply(want_bits=True)) is required."""
+    `residual` the unit's bit mask (relu_bits, from bn_apply(want_bits=True)) is required.
+    residual_bits: `residual` is an unmasked gradient and this the ReLU bit mask [rows, Cin/8] to apply to it.
+    inplace: accumulate into `residual` (out = residual): a strided dgrad then only touches the positions its
+    stride reaches."""
+    if inplace:
+        if residual is None or out is not None:
+            raise _lib.VsError("conv_dgrad(inplace=True) accumulates into `residual`")
+        out = residual
     if out is None:
         out = new_act(*xs, device=dy.device)
     flags = (VS_CONV_NAIVE if naive else 0) | (VS_CONV_RESIDUAL if residual is not None else 0)
@@ -306,9 +313,17 @@ def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=N
         flags |= 1 << 19  # VS_CONV_NOCLASS
     d = make_desc(xs, act_ld(out), dy.shape, act_ld(dy), k, s, p, flags,
                   act_ld(residual) if residual is not None else 0)
+    if residual_bits is not None:
+        if residual is None or tuple(residual_bits.shape) != (xs[0] * xs[2] * xs[3] * xs[4], xs[1] // 8) \
+                or residual_bits.dtype != torch.uint8:
+            raise _lib.VsError("residual_bits must be uint8 [rows, Cin / 8] beside a residual")
     need = _lib.load().vs_conv_workspace_bytes(C.byref(d), 1)
     ws = _workspace(need, dy.device) if need else None
     want_sums = bn_stats is not None
+    ep = _lib.DgradEpilogue()
+    ep.residual = residual.data_ptr() if residual is not None else None
+    ep.residual_bits = residual_bits.data_ptr() if residual_bits is not None else None
+    partial = None
     if want_sums:
         y, mean, invstd, gamma, beta, bits = (tuple(bn_stats) + (None,))[:6]
         # pairings the kernel is built for: no residual + recomputed mask, residual + bit mask
@@ -316,13 +331,17 @@ def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=N
         rows = _lib.load().vs_conv_dgrad_bnstats_rows(C.byref(d)) if ok else 0
         if rows > 0:
             partial = torch.empty((rows, 2, xs[1]), dtype=torch.float32, device=dy.device)
-            _lib.call("vs_conv_dgrad_bnstats", _ptr(dy), _ptr(wt), _ptr(out), C.byref(d), _ptr(residual),
-                      _ptr(y), act_ld(y), _ptr(bits), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
-                      _ptr(partial), _ptr(ws), C.c_size_t(ws.numel() if ws is not None else 0), _stream())
-            return out, partial
-    _lib.call("vs_conv_dgrad", _ptr(dy), _ptr(wt), _ptr(out), C.byref(d), _ptr(residual), _ptr(ws),
+            ep.bn_y, ep.bn_y_ld = y.data_ptr(), act_ld(y)
+            ep.relu_bits = bits.data_ptr() if bits is not None else None
+            ep.mean, ep.invstd = mean.data_ptr(), invstd.data_ptr()
+            ep.gamma = gamma.data_ptr() if gamma is not None else None
+            ep.beta = beta.data_ptr() if beta is not None else None
+            ep.stats_partial = partial.data_ptr()
+    for t in (dy, wt, out, residual, residual_bits):
+        _ptr(t)  # GPU-tensor check (the struct carries raw addresses)
+    _lib.call("vs_conv_dgrad_ex", _ptr(dy), _ptr(wt), _ptr(out), C.byref(d), C.byref(ep), _ptr(ws),
               C.c_size_t(ws.numel() if ws is not None else 0), _stream())
-    return (out, None) if want_sums else out
+    return (out, partial) if want_sums else out
 
 
 _ws_cache = {}

@@ -106,7 +106,9 @@ class TrainStep:
                 fns = [(lambda fn=fn, r=r: (fn(), self._pack(*r))) for fn, r in self.segments] + [self._adam]
                 for fn in fns:
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=pool):
+                    # thread_local: the process group's watchdog thread polls its events meanwhile, which
+                    # the default (global) capture mode treats as an illegal call and invalidates the capture
+                    with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                         fn()
                     pool = g.pool()
                     graphs.append(g)

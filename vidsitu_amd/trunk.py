@@ -216,11 +216,16 @@ class _Unit:
         return z
 
     @staticmethod
-    def bwd(rec, dz, need_dx=True, want_dres=False, dx_residual=None, masked=False, producer=None):
+    def bwd(rec, dz, need_dx=True, want_dres=False, dx_residual=None, masked=False, producer=None,
+            dz_bits=None, dx_residual_bits=None, inplace=False):
         """Returns (dx|None, dres|None).  `masked`: dz already carries the ReLU mask.
         `producer`: the record of the unit whose output is this unit's only input (the a -> b and b -> c
         links of a bottleneck): this unit's dgrad then also emits the producer's BN-backward sums
-        (`_Unit.fuse_bn_sums`), which spares the producer's reduce pass over dz and y."""
+        (`_Unit.fuse_bn_sums`), which spares the producer's reduce pass over dz and y.
+        `dz_bits`: dz is an UNMASKED gradient and these the ReLU bits to apply to it (the shortcut unit of a
+        ResBlock reads the block's output gradient through the block's own mask instead of a masked copy).
+        `dx_residual_bits`: the same for the gradient added in the dgrad epilogue.
+        `inplace`: the dgrad accumulates into dx_residual."""
         conv, bn = rec["conv"], rec["bn"]
         relu = rec["relu"] and not masked
         if bn.weight.grad is None:
@@ -230,6 +235,9 @@ class _Unit:
         # without a residual input the ReLU mask is recomputed from y (z is not read)
         zbits = rec.get("zbits") if relu else None
         zmask = rec["z"] if (relu and rec["has_res"] and zbits is None) else None
+        if dz_bits is not None:
+            assert not rec["relu"], "dz_bits belongs to a unit without a ReLU of its own"
+            relu, zbits, zmask = True, dz_bits, None
         dy, dres, _, _ = ops.bn_bwd(
             dz, zmask, rec["y"], rec["mean"], rec["invstd"], bn.weight, relu, want_dres,
             dgamma=bn.weight.grad, dbeta=bn.bias.grad, beta=bn.bias, zbits=zbits,
@@ -266,14 +274,14 @@ class _Unit:
             if fuse:
                 pbn = producer["bn"]
                 dx, part = ops.conv_dgrad(dy, conv.wt(), tuple(x.shape), conv.k, conv.s, conv.p,
-                                          residual=dx_residual,
+                                          residual=dx_residual, residual_bits=dx_residual_bits,
                                           bn_stats=(producer["y"], producer["mean"], producer["invstd"],
                                                     pbn.weight, pbn.bias, producer.get("zbits")))
                 if part is not None:
                     producer["bwd_partial"] = part
             else:
                 dx = ops.conv_dgrad(dy, conv.wt(), tuple(x.shape), conv.k, conv.s, conv.p,
-                                    residual=dx_residual)
+                                    residual=dx_residual, residual_bits=dx_residual_bits, inplace=inplace)
         _WgradLanes.join_all()  # wgrad || dgrad of this unit, no further
         return dx, dres
 
@@ -346,14 +354,37 @@ class ResBlock(nn.Module):
         on top of `saved` after this block's own is then that block's c unit (`_Unit.bwd` checks the tensor
         identity), whose BN-backward sums come out of this block's conv-a dgrad."""
         rc, rb, ra = saved.pop(), saved.pop(), saved.pop()
-        db, g = _Unit.bwd(rc, dout, want_dres=True, producer=rb)
+        # The gradient over the identity / shortcut branch is dout under the block's ReLU mask.  With the mask
+        # kept as bits (`zbits`, written by the forward apply) its two readers take (dout, bits) and the c unit's
+        # backward apply does not write a masked copy (`dres`: one block-output-sized tensor per block).
+        cbits = rc.get("zbits") if ResBlock.mask_by_bits else None
+        db, g = _Unit.bwd(rc, dout, want_dres=cbits is None, producer=rb)
         da, _ = _Unit.bwd(rb, db, producer=ra)
         if self.has_sc:
-            dx1, _ = _Unit.bwd(saved.pop(), g, masked=True)
-            dx, _ = _Unit.bwd(ra, da, dx_residual=dx1)
+            rsc = saved.pop()
+            if ResBlock.accumulate_shortcut:
+                # conv a's (unit-stride) data gradient first; the shortcut's dgrad then accumulates into it in
+                # place -- a strided shortcut touches only the positions its stride reaches, instead of writing
+                # a block-input-sized tensor that is 3/4 zeros and re-reading it as a residual
+                dxa, _ = _Unit.bwd(ra, da)
+                if cbits is not None:
+                    dx, _ = _Unit.bwd(rsc, dout, dz_bits=cbits, dx_residual=dxa, inplace=True)
+                else:
+                    dx, _ = _Unit.bwd(rsc, g, masked=True, dx_residual=dxa, inplace=True)
+            else:
+                dx1, _ = (_Unit.bwd(rsc, dout, dz_bits=cbits) if cbits is not None
+                          else _Unit.bwd(rsc, g, masked=True))
+                dx, _ = _Unit.bwd(ra, da, dx_residual=dx1)
+        elif cbits is not None:
+            dx, _ = _Unit.bwd(ra, da, dx_residual=dout, dx_residual_bits=cbits,
+                              producer=saved[-1] if (chain and saved) else None)
         else:
             dx, _ = _Unit.bwd(ra, da, dx_residual=g, producer=saved[-1] if (chain and saved) else None)
         return dx
+
+    # A/B switches (VS_MASK_BY_BITS=0 / VS_ACC_SHORTCUT=0: the round-1 data flow)
+    mask_by_bits = os.environ.get("VS_MASK_BY_BITS", "1") != "0"
+    accumulate_shortcut = os.environ.get("VS_ACC_SHORTCUT", "1") != "0"
 
 
 class Nonlocal(nn.Module):
