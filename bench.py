@@ -94,6 +94,8 @@ class EntryProbe:
             unit = d.sT == 1 and d.sH == 1 and d.sW == 1
             pw = taps == 1 and d.pT == 0 and d.pH == 0 and d.pW == 0
             mode = (0 if (pw and unit) else (1 if unit else 2)) if dgrad else (0 if pw else 1)
+            if direct == 2:  # halo-image kernel (conv_halo.hip): wave tile in 16-row / 16-column units
+                return f"conv_halo_kernel<{bm // 32}, {bn // 32}, {'true' if bnb else 'false'}>"
             if direct:
                 ncols = d.Cin if dgrad else d.Cout
                 K = taps * (d.Cout if dgrad else d.Cin)

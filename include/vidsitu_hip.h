@@ -49,6 +49,8 @@ typedef enum vs_status {
 #define VS_CONV_RING(ns) (((ns) & 7) << 16) /* staging: 0 heuristic, 1 register pipeline, 2..4 LDS-DMA ring stages */
 #define VS_CONV_NOCLASS (1 << 19) /* dgrad of a strided conv: disable the stride-class tiling (debug / A-B) */
 #define VS_CONV_SPLITK (1 << 15) /* allow the split-K plan (fp32 slabs + fused reduce/epilogue) */
+#define VS_CONV_NOHALO (1 << 21) /* keep a unit-stride [kT,1,1] / [1,kH,kW] conv on the implicit-GEMM kernel (A/B, tests) */
+#define VS_CONV_FORCEHALO (1 << 22) /* run it on the halo-image kernel whenever the shape is eligible (A/B, tests) */
 
 /* Geometry of one Conv3d (bias-free, groups 1, dilation 1).
  * Replaces nn.Conv3d reached from vidsitu_code/mdl_sf_base.py:22-33 (s1..s5,

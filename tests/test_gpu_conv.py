@@ -577,3 +577,106 @@ def test_direct_kernel_masked_residual(dev):
     want = ops.conv_dgrad(dya, wt, xs, k, s, p, residual=r_masked)
     got = ops.conv_dgrad(dya, wt, xs, k, s, p, residual=r, residual_bits=bits)
     assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+
+
+# name, N, Cin, T, H, W, Cout, k, p   (unit stride, "same" padding): shapes the halo-image kernel takes
+HALO_CASES = [
+    ("s4b_3x3_256", 2, 256, 8, 14, 14, 256, (1, 3, 3), (0, 1, 1)),
+    ("s4a_t3_1024_256", 2, 1024, 8, 14, 14, 256, (3, 1, 1), (1, 0, 0)),
+    ("s5b_3x3_512", 8, 512, 8, 7, 7, 512, (1, 3, 3), (0, 1, 1)),
+    ("s5a_t3_1024_512", 8, 1024, 8, 7, 7, 512, (3, 1, 1), (1, 0, 0)),
+    ("s3b_3x3_128", 1, 128, 8, 28, 28, 128, (1, 3, 3), (0, 1, 1)),
+    ("s2b_3x3_64", 1, 64, 4, 56, 56, 64, (1, 3, 3), (0, 1, 1)),
+    ("odd_3x3_64_72", 4, 64, 5, 13, 11, 72, (1, 3, 3), (0, 1, 1)),
+    ("odd_t3_128_64", 12, 128, 6, 5, 7, 64, (3, 1, 1), (1, 0, 0)),
+    ("t5_64_64", 4, 64, 8, 9, 9, 64, (5, 1, 1), (2, 0, 0)),
+    ("5x5_64_64", 2, 64, 4, 20, 20, 64, (1, 5, 5), (0, 2, 2)),
+    ("3x1_64_136", 2, 64, 4, 20, 20, 136, (1, 3, 1), (0, 1, 0)),
+    ("fast_t32_3x3", 2, 64, 32, 7, 7, 64, (1, 3, 3), (0, 1, 1)),
+]
+
+
+def _plan(ops, xs, ys, x_ld, y_ld, k, s, p, dgrad, flags=1 << 22):  # VS_CONV_FORCEHALO
+    import ctypes as C
+    d = ops.make_desc(xs, x_ld, ys, y_ld, k, s, p, flags)
+    out = (C.c_int * 5)()
+    ops._lib.load().vs_conv_plan(C.byref(d), dgrad, out)
+    return list(out)
+
+
+@pytest.mark.parametrize("case", HALO_CASES, ids=[c[0] for c in HALO_CASES])
+def test_halo_image_kernel_fwd_and_dgrad(case, dev):
+    """conv_halo.hip (unit-stride [kT,1,1] / [1,kH,kW] convs, the activation patch incl. its halo staged once
+    per 64-channel chunk): forward with every epilogue (BN-stat partials, affine + ReLU, residual) and the data
+    gradient (plain, + residual, + masked residual, + the producer's BN-backward sums) against torch and
+    against the implicit-GEMM kernel (VS_CONV_NOHALO) -- ragged line / spatial groups, 3, 5, 9 and 25 taps."""
+    from vidsitu_amd import ops
+
+    name, n, cin, t, h, w, cout, k, p = case
+    s = (1, 1, 1)
+    g = torch.Generator().manual_seed(71)
+    x = rb(torch.randn(n, cin, t, h, w, generator=g))
+    wgt = rb(torch.randn(cout, cin, *k, generator=g) / (cin * k[0] * k[1] * k[2]) ** 0.5)
+    xa, wa = to_act(x, dev), to_w(wgt, dev)
+    ys = (n, cout, t, h, w)
+    assert _plan(ops, tuple(x.shape), ys, cin, cout, k, s, p, 0)[4] == 2, "forward did not take the halo kernel"
+    # (the data gradient reduces over Cout in 64-channel chunks: 72 / 136 output channels stay on the other kernel)
+    assert (_plan(ops, tuple(x.shape), ys, cin, cout, k, s, p, 1)[4] == 2) == (cout % 64 == 0), "dgrad kernel choice"
+    ref = F.conv3d(x, wgt, stride=s, padding=p)
+    # forward: raw + BN-stat partials
+    y, part = ops.conv_fwd(xa, wa, k, s, p, stats=True, halo="force")
+    assert_close(y, ref, TOL, name + " fwd")
+    y0, part0 = ops.conv_fwd(xa, wa, k, s, p, stats=True, halo=False)
+    assert_close(y, y0.float(), 4e-3, name + " fwd vs implicit GEMM")
+    tot, tot0 = part.double().sum(0).cpu(), part0.double().sum(0).cpu()
+    assert torch.allclose(tot, tot0, rtol=2e-3, atol=2e-3 * float(tot0.abs().max()))
+    assert torch.allclose(tot[0], ref.double().sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=2e-2)
+    # forward: folded BN + residual + ReLU into a wider (concat) buffer
+    sc = (torch.rand(cout, generator=g) + 0.5).to(dev)
+    sh = torch.randn(cout, generator=g).to(dev)
+    r = rb(torch.randn(ref.shape, generator=g))
+    buf = ops.new_act(n, cout + 16, t, h, w, dev, zero=True)
+    out = ops.channel_slice(buf, 8, cout)
+    ops.conv_fwd(xa, wa, k, s, p, out=out, scale=sc, shift=sh, residual=to_act(r, dev), relu=True, halo="force")
+    want = (ref * sc.cpu().view(1, -1, 1, 1, 1) + sh.cpu().view(1, -1, 1, 1, 1) + r).relu()
+    assert_close(out, want, TOL, name + " fwd epilogue")
+    assert float(buf[:, :8].abs().max()) == 0.0 and float(buf[:, 8 + cout:].abs().max()) == 0.0
+    # data gradient
+    xg = x.clone().requires_grad_()
+    yy = F.conv3d(xg, wgt, stride=s, padding=p)
+    dy = rb(torch.randn(yy.shape, generator=g))
+    (dx_ref,) = torch.autograd.grad(yy, xg, dy)
+    wt = ops.weight_transpose(wa)
+    dya = to_act(dy, dev)
+    dx = ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, halo="force")
+    assert_close(dx, dx_ref, TOL, name + " dgrad")
+    assert_close(dx, ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, halo=False).float(), 4e-3,
+                 name + " dgrad vs implicit GEMM")
+    rr = rb(torch.randn(x.shape, generator=g))
+    rra = to_act(rr, dev)
+    dxr = ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, residual=rra, halo="force")
+    assert_close(dxr, dx_ref + rr, TOL, name + " dgrad + residual")
+    rows = ops.act_rows(rra)
+    bits = torch.randint(0, 256, (rows, cin // 8), generator=g, dtype=torch.uint8).to(dev)
+    keep = _unpack_bits(bits, tuple(x.shape))
+    dxm = ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, residual=rra, residual_bits=bits, halo="force")
+    assert_close(dxm, dx_ref + torch.where(keep.cpu(), rr, torch.zeros(())), TOL, name + " dgrad + masked residual")
+    # + the BN-backward sums of the unit this dx belongs to: dx bitwise the plain launch, sums = the reduce pass
+    bn_y = to_act(rb(torch.randn(x.shape, generator=g)), dev)
+    mean = (torch.randn(cin, generator=g) * 0.2).to(dev)
+    invstd = (torch.rand(cin, generator=g) + 0.5).to(dev)
+    gamma, beta = torch.randn(cin, generator=g).to(dev), (torch.randn(cin, generator=g) * 0.3).to(dev)
+    dxs, psum = ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, bn_stats=(bn_y, mean, invstd, gamma, beta), halo="force")
+    assert psum is not None and torch.equal(dxs.view(torch.int16), dx.view(torch.int16))
+    v = lambda a: a.view(1, -1, 1, 1, 1)
+    xh = (bn_y.float() - v(mean)) * v(invstd)
+    gm = torch.where(xh * v(gamma) + v(beta) > 0, dx.float(), torch.zeros((), device=dev))
+    want = torch.stack([gm.double().sum((0, 2, 3, 4)), (gm * xh).double().sum((0, 2, 3, 4))]).cpu()
+    got = psum.double().sum(0).cpu()
+    assert float((got - want).abs().max()) / float(want.abs().max()) < 2e-3
+    dxb, psb = ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, residual=rra, bn_stats=(bn_y, mean, invstd, None, None, bits),
+                                halo="force")
+    assert psb is not None and torch.equal(dxb.view(torch.int16), dxr.view(torch.int16))
+    gm = torch.where(keep, dxr.float(), torch.zeros((), device=dev))
+    want = torch.stack([gm.double().sum((0, 2, 3, 4)), (gm * xh).double().sum((0, 2, 3, 4))]).cpu()
+    assert float((psb.double().sum(0).cpu() - want).abs().max()) / float(want.abs().max()) < 1e-5

@@ -9,7 +9,8 @@ from vidsitu_amd import ops
 from tools.layer_table import rows
 
 dev = torch.device("cuda:0")
-kinds = sys.argv[1:] or ["fwd"]
+kinds = [a for a in sys.argv[1:] if not a.startswith("--")] or ["fwd"]
+HALO = "force" if "--halo" in sys.argv else (False if "--nohalo" in sys.argv else True)
 REPS = 20
 
 
@@ -62,12 +63,12 @@ for (M, N, K, k, s), (cnt, name, xin) in sorted(agg.items(), key=lambda kv: -2.0
     for kd in kinds:
         if kd == "fwd":
             out = ops.new_act(*ys, device=dev)
-            fn = lambda: ops.conv_fwd(x, wt, k, s, p, out=out, scale=sc, shift=sh, relu=True)
+            fn = lambda: ops.conv_fwd(x, wt, k, s, p, out=out, scale=sc, shift=sh, relu=True, halo=HALO)
         elif kd == "dgrad":
             dy = ops.new_act(*ys, device=dev); dy.normal_()
             wtt = ops.weight_transpose(wt)
             dx = ops.new_act(*x.shape, device=dev)
-            fn = lambda: ops.conv_dgrad(dy, wtt, tuple(x.shape), k, s, p, out=dx)
+            fn = lambda: ops.conv_dgrad(dy, wtt, tuple(x.shape), k, s, p, out=dx, halo=HALO)
         else:
             dy = ops.new_act(*ys, device=dev); dy.normal_()
             dw = torch.empty((N, *k, cin), dtype=torch.float32, device=dev).permute(0, 4, 1, 2, 3)

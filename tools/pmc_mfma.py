@@ -11,7 +11,7 @@ import collections, csv, glob, json, sys
 
 out_dir, build = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "")
 plan = json.load(open(f"{out_dir}/plan.json"))
-KEEP = ("conv_igemm_kernel", "conv_wgrad_ring_kernel", "conv_wgrad_kernel", "conv_direct_kernel")
+KEEP = ("conv_igemm_kernel", "conv_wgrad_ring_kernel", "conv_wgrad_kernel", "conv_direct_kernel", "conv_halo_kernel")
 
 
 def rows_of(sub):
@@ -62,6 +62,8 @@ for p in plan:
                      ("wait_inst_lds", "SQ_WAIT_INST_LDS"), ("active", "SQ_ACTIVE_INST_ANY")):
             if b in ent:
                 ent[a] = round(ent[b] / wc, 4)
+    if ent.get("SQ_LDS_IDX_ACTIVE"):
+        ent["lds_conflict"] = round(ent.get("SQ_LDS_BANK_CONFLICT", 0.0) / ent["SQ_LDS_IDX_ACTIVE"], 4)
     result.append(ent)
 meta = {"_meta": {"build": build, "method": "rocprofv3 --kernel-trace --pmc, two SQ passes + GRBM_GUI_ACTIVE; each (layer, kind) "
                   "launched alone, eager, 3x; counters averaged over the launches; see tools/pmc_mfma.sh",
@@ -70,4 +72,5 @@ meta = {"_meta": {"build": build, "method": "rocprofv3 --kernel-trace --pmc, two
 json.dump(meta, open(f"{out_dir}/pmc_mfma.json", "w"), indent=1)
 for e in result:
     print(f"{e['layer']:26s} {e['kind']:6s} mfma_busy {e.get('mfma_busy', float('nan')):6.3f} wait_any {e.get('wait_any', float('nan')):6.3f} "
-          f"wait_inst {e.get('wait_inst_any', float('nan')):6.3f} lds {e.get('wait_inst_lds', float('nan')):6.3f} active {e.get('active', float('nan')):6.3f}  {e.get('kernel', '')[:60]}")
+          f"wait_inst {e.get('wait_inst_any', float('nan')):6.3f} lds {e.get('wait_inst_lds', float('nan')):6.3f} active {e.get('active', float('nan')):6.3f} "
+          f"ldsconf {e.get('lds_conflict', float('nan')):5.2f} us {e.get('kernel_cycles', 0) / 2100.0:6.1f}  {e.get('kernel', '')[:58]}")

@@ -1089,6 +1089,14 @@ static int launch_conv(ConvP& p, int mode, int naive, int flags, void* ws, size_
     VS_CHECK_LAUNCH();
     return VS_OK;
   }
+  {
+    HaloGeo hg;
+    if (vs_halo_plan(p, mode, p.tmul < 0, flags, &hg)) {  // unit-stride [kT,1,1] / [1,kH,kW]: halo-image kernel
+      p.tilesM = hg.tilesM;
+      p.tilesN = hg.tilesN;
+      return vs_halo_launch(p, hg, st);
+    }
+  }
   const ConvPlan pl = plan_conv(p.M, p.Ncols, p.K, p.kT * p.kH * p.kW, flags);
   if (pl.direct)
     return p.Ncols <= 16 ? launch_direct<1>(p, mode, st) : launch_direct<2>(p, mode, st);
@@ -1149,7 +1157,49 @@ static int check_desc(const vs_conv_desc* d) {
   return VS_OK;
 }
 
+static int fill_dgrad_params(ConvP& p, const vs_conv_desc* d);
+
+// ConvP of a forward launch (everything but the tensor pointers and byte extents); returns the kernel MODE.
+static int fill_fwd_params(ConvP& p, const vs_conv_desc* d) {
+  p.x = p.w = nullptr;
+  p.y = nullptr;
+  p.scale = p.shift = nullptr;
+  p.res = nullptr;
+  p.stats = nullptr;
+  p.bny = nullptr;
+  p.bn_mean = p.bn_invstd = p.bn_gamma = p.bn_beta = nullptr;
+  p.bn_bits = nullptr;
+  p.bny_ld = 0;
+  p.res_bits = nullptr;
+  p.M = d->N * d->To * d->Ho * d->Wo;
+  p.Ncols = d->Cout;
+  p.K = d->kT * d->kH * d->kW * d->Cin;
+  p.Cg = d->Cin;
+  p.g_ld = d->x_ld;
+  p.Rt = d->To; p.Rh = d->Ho; p.Rw = d->Wo;
+  p.Gt = d->Ti; p.Gh = d->Hi; p.Gw = d->Wi;
+  p.kT = d->kT; p.kH = d->kH; p.kW = d->kW;
+  p.mulT = d->sT; p.mulH = d->sH; p.mulW = d->sW;
+  p.offT = -d->pT; p.offH = -d->pH; p.offW = -d->pW;
+  p.tmul = 1;
+  p.shT = p.shH = p.shW = 0;
+  p.x_bytes = p.w_bytes = 0;
+  p.y_ld = d->y_ld;
+  p.res_ld = d->res_ld;
+  p.flags = d->flags & 0x70ff;  // epilogue bits + debug ablation
+  p.tilesM = p.tilesN = 0;
+  p.ncls = 0;
+  const bool pointwise = (d->kT * d->kH * d->kW == 1) && d->pT == 0 && d->pH == 0 && d->pW == 0;
+  return pointwise ? 0 : 1;
+}
+
 extern "C" int vs_conv_stats_rows(const vs_conv_desc* d) {
+  {
+    ConvP p;
+    HaloGeo hg;
+    const int mode = fill_fwd_params(p, d);
+    if (!(d->flags & VS_CONV_NAIVE) && vs_halo_plan(p, mode, 0, d->flags, &hg)) return hg.tilesM;
+  }
   const long long M = (long long)d->N * d->To * d->Ho * d->Wo;
   const ConvPlan pl = plan_conv(M, d->Cout, d->kT * d->kH * d->kW * d->Cin, d->kT * d->kH * d->kW,
                                 d->flags);
@@ -1161,6 +1211,19 @@ extern "C" int vs_conv_stats_rows(const vs_conv_desc* d) {
 extern "C" int vs_conv_plan(const vs_conv_desc* d, int dgrad, int* out) {
   VS_CHECK_ARG(d != nullptr && out != nullptr, "null argument");
   const int taps = d->kT * d->kH * d->kW;
+  {
+    ConvP p;
+    HaloGeo hg;
+    const int mode = dgrad ? fill_dgrad_params(p, d) : fill_fwd_params(p, d);
+    if (mode >= 0 && !(d->flags & VS_CONV_NAIVE) && vs_halo_plan(p, mode, dgrad, d->flags, &hg)) {
+      out[0] = 32 * hg.mrw;
+      out[1] = 32 * hg.nrw;
+      out[2] = 3;
+      out[3] = 1;
+      out[4] = 2;  // halo-image kernel
+      return VS_OK;
+    }
+  }
   ConvPlan pl;
   if (dgrad) {
     const long long M = (long long)d->N * d->Ti * d->Hi * d->Wi;
@@ -1197,6 +1260,7 @@ extern "C" int vs_conv_fwd(const void* x, const void* w, void* y, const vs_conv_
   VS_CHECK_ARG(!(d->flags & VS_CONV_RESIDUAL) || residual, "RESIDUAL needs residual");
   VS_CHECK_ARG(!(d->flags & VS_CONV_STATS) || stats_partial, "STATS needs stats_partial");
   ConvP p;
+  const int mode = fill_fwd_params(p, d);
   p.x = (const uint16_t*)x;
   p.w = (const uint16_t*)w;
   p.y = (uint16_t*)y;
@@ -1204,23 +1268,6 @@ extern "C" int vs_conv_fwd(const void* x, const void* w, void* y, const vs_conv_
   p.shift = shift;
   p.res = (const uint16_t*)residual;
   p.stats = stats_partial;
-  p.bny = nullptr;
-  p.bn_mean = p.bn_invstd = p.bn_gamma = p.bn_beta = nullptr;
-  p.bn_bits = nullptr;
-  p.bny_ld = 0;
-  p.res_bits = nullptr;
-  p.M = d->N * d->To * d->Ho * d->Wo;
-  p.Ncols = d->Cout;
-  p.K = d->kT * d->kH * d->kW * d->Cin;
-  p.Cg = d->Cin;
-  p.g_ld = d->x_ld;
-  p.Rt = d->To; p.Rh = d->Ho; p.Rw = d->Wo;
-  p.Gt = d->Ti; p.Gh = d->Hi; p.Gw = d->Wi;
-  p.kT = d->kT; p.kH = d->kH; p.kW = d->kW;
-  p.mulT = d->sT; p.mulH = d->sH; p.mulW = d->sW;
-  p.offT = -d->pT; p.offH = -d->pH; p.offW = -d->pW;
-  p.tmul = 1;
-  p.shT = p.shH = p.shW = 0;
   {
     const long long xb = (long long)d->N * d->Ti * d->Hi * d->Wi * d->x_ld * 2;
     const long long wb = (long long)d->Cout * p.K * 2;
@@ -1228,13 +1275,8 @@ extern "C" int vs_conv_fwd(const void* x, const void* w, void* y, const vs_conv_
     p.x_bytes = (unsigned)xb;
     p.w_bytes = (unsigned)wb;
   }
-  p.y_ld = d->y_ld;
-  p.res_ld = d->res_ld;
-  p.flags = d->flags & 0x70ff;  // epilogue bits + debug ablation
-  p.tilesM = p.tilesN = 0;
-  const bool pointwise = (d->kT * d->kH * d->kW == 1) && d->pT == 0 && d->pH == 0 && d->pW == 0;
-  return launch_conv(p, pointwise ? 0 : 1, (d->flags & VS_CONV_NAIVE) != 0, d->flags, workspace,
-                     ws_bytes, (hipStream_t)stream);
+  return launch_conv(p, mode, (d->flags & VS_CONV_NAIVE) != 0, d->flags, workspace, ws_bytes,
+                     (hipStream_t)stream);
 }
 
 // ConvP of a dgrad launch (everything but the tensor pointers); returns the kernel MODE or < 0.
@@ -1325,6 +1367,10 @@ extern "C" int vs_conv_dgrad_bnstats_rows(const vs_conv_desc* d) {
   // a strided dgrad with a residual: tiles of stride classes no tap reaches copy the residual without
   // passing through the epilogue
   if ((d->flags & VS_CONV_RESIDUAL) && mode == 2) return 0;
+  {
+    HaloGeo hg;
+    if (vs_halo_plan(p, mode, 1, d->flags, &hg)) return hg.tilesM;
+  }
   const ConvPlan pl = plan_conv(p.M, p.Ncols, p.K, p.kT * p.kH * p.kW, d->flags);
   if (pl.direct || pl.S > 1 || !bnb_tile(pl.tile.bm, pl.tile.bn) || p.kT * p.kH * p.kW > 31) return 0;
   p.tilesM = (p.M + pl.tile.bm - 1) / pl.tile.bm;

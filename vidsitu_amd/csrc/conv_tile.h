@@ -336,3 +336,24 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
   }
 }
 
+// ---- halo-image kernel (conv_halo.hip): tile geometry, planned on the host ----
+struct HaloGeo {
+  int kind;           // 0: taps along T, 1: taps in the H/W plane
+  int G, D1, D2, O1, O2;
+  int O2p;            // output row pitch along axis 2 (>= O2: lines padded to 16 rows, kind 1)
+  int k1, k2, p1, p2;
+  int flip;           // dgrad
+  int T, H, W, HW;    // extents of the (equal) input / output position grids
+  int per;            // groups per clip (kind 0) / line chunks per frame (kind 1)
+  int ngroups;        // groups in the whole tensor
+  int RA;             // G * D1 * D2
+  int rows;           // G * O1 * O2 (valid tile rows)
+  int tilesM, tilesN;
+  int mrw, nrw;       // wave tile in 16-row / 16-column units
+};
+
+
+// Geometry of the halo kernel for this launch (mode = kernel MODE, dgrad: mirrored taps, flags = desc.flags),
+// or false when the implicit-GEMM kernel runs it.
+bool vs_halo_plan(const ConvP& p, int mode, int dgrad, int flags, HaloGeo* out);
+int vs_halo_launch(const ConvP& p, const HaloGeo& g, hipStream_t st);

@@ -145,7 +145,7 @@ def tile_flag(kind, M, ncols, K, k, s, force=None):
 
 
 def conv_fwd(x, w, k, s, p, out=None, scale=None, shift=None, residual=None, relu=False,
-             stats=False, naive=False, tile=None, dbg=0, splitk=False, ring=0):
+             stats=False, naive=False, tile=None, dbg=0, splitk=False, ring=0, halo=True):
     """y = conv3d(x, w) [*scale+shift] [+residual] [relu]; optional BN-stat partials.
     Returns (y, partials|None)."""
     cout = w.shape[0]
@@ -174,6 +174,10 @@ def conv_fwd(x, w, k, s, p, out=None, scale=None, shift=None, residual=None, rel
     if splitk:
         flags |= 1 << 15  # VS_CONV_SPLITK
     flags |= (ring & 7) << 16  # VS_CONV_RING
+    if not halo:
+        flags |= 1 << 21  # VS_CONV_NOHALO
+    elif halo == "force":
+        flags |= 1 << 22  # VS_CONV_FORCEHALO
     d = make_desc(x.shape, act_ld(x), ys, act_ld(out), k, s, p, flags,
                   act_ld(residual) if residual is not None else 0)
     partials = None
@@ -289,7 +293,7 @@ def transpose_f32_batched(src, dst, table, total, tiled=True):
 
 
 def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=None, ring=0,
-               noclass=False, bn_stats=None, residual_bits=None, inplace=False):
+               noclass=False, bn_stats=None, residual_bits=None, inplace=False, halo=True):
     """dx[xs] = conv_transpose(dy, w) (+ residual).  wt from weight_transpose.
     bn_stats = (y, mean, invstd, gamma, beta[, relu_bits]) of the BatchNorm + ReLU unit whose output this
     convolution consumed and whose complete dz this dx is: returns (dx, partial) with partial [rows, 2, Cin]
@@ -311,6 +315,10 @@ def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=N
     flags |= (ring & 7) << 16  # VS_CONV_RING
     if noclass:
         flags |= 1 << 19  # VS_CONV_NOCLASS
+    if not halo:
+        flags |= 1 << 21  # VS_CONV_NOHALO
+    elif halo == "force":
+        flags |= 1 << 22  # VS_CONV_FORCEHALO
     d = make_desc(xs, act_ld(out), dy.shape, act_ld(dy), k, s, p, flags,
                   act_ld(residual) if residual is not None else 0)
     if residual_bits is not None:

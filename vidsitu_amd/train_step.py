@@ -95,10 +95,13 @@ class TrainStep:
     def capture(self):
         """Capture the step.  Call after at least one eager `step()` on a side stream (allocator and
         lane-stream warm-up).  Raises RuntimeError when a capture fails."""
+        # A process group's watchdog thread polls its events while this thread captures; the default
+        # (global) capture mode treats that as an illegal call and invalidates the capture.
+        mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
         try:
             if not self.use_dist:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode=mode):
                     self.step()
                 self.graphs = [g]
             else:
@@ -106,9 +109,7 @@ class TrainStep:
                 fns = [(lambda fn=fn, r=r: (fn(), self._pack(*r))) for fn, r in self.segments] + [self._adam]
                 for fn in fns:
                     g = torch.cuda.CUDAGraph()
-                    # thread_local: the process group's watchdog thread polls its events meanwhile, which
-                    # the default (global) capture mode treats as an illegal call and invalidates the capture
-                    with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                    with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
                         fn()
                     pool = g.pool()
                     graphs.append(g)
