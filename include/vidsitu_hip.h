@@ -184,6 +184,18 @@ int vs_weight_transpose_tiled(const void* src, void* dst, const int64_t* table, 
 size_t vs_conv_wgrad_workspace_bytes(const vs_conv_desc* d);
 int vs_conv_wgrad(const void* dy, const void* x, float* dw, const vs_conv_desc* d,
                   void* workspace, size_t ws_bytes, void* stream);
+/* The same weight gradient without its slab reduce: the position-split partials stay in `slabs`
+ * ([*splits][Cout][taps*Cin] fp32, vs_conv_wgrad_workspace_bytes(desc) bytes, owned by the caller until the
+ * reduce) and *splits says how many there are; *splits == 1 means dw was written directly and slabs is
+ * untouched.  vs_wgrad_reduce_batched then sums the slabs of MANY layers in one launch, in exactly
+ * vs_conv_wgrad's order (bitwise the same dw): table[i] = {slab address, dw address, elements, splits, first
+ * block}, first block = running sum of vs_wgrad_reduce_blocks(elements).  Autograd accumulates one weight
+ * gradient per layer behind each convolution's backward; here the 108 per-layer reduce launches of a
+ * SlowFast-R50 step become one per backward segment. */
+int vs_conv_wgrad_partial(const void* dy, const void* x, float* dw, const vs_conv_desc* d, void* slabs,
+                          size_t slab_bytes, int* splits, void* stream);
+int64_t vs_wgrad_reduce_blocks(int64_t elements);
+int vs_wgrad_reduce_batched(const int64_t* table, int n_entries, int64_t total_blocks, void* stream);
 
 /* BatchNorm3d (mdl_sf_base.py:22-33 via slowfast BN modules; eps 1e-5, mom 0.1).
  * finalize: reduce conv-epilogue partials -> batch mean / biased var ->

@@ -680,3 +680,35 @@ def test_halo_image_kernel_fwd_and_dgrad(case, dev):
     gm = torch.where(keep, dxr.float(), torch.zeros((), device=dev))
     want = torch.stack([gm.double().sum((0, 2, 3, 4)), (gm * xh).double().sum((0, 2, 3, 4))]).cpu()
     assert float((psb.double().sum(0).cpu() - want).abs().max()) / float(want.abs().max()) < 1e-5
+
+
+def test_batched_wgrad_slab_reduce_is_bitwise_the_per_layer_reduce(dev):
+    """ops.WgradBatch: the position-split partials of several layers stay in per-layer slabs and ONE launch
+    (vs_wgrad_reduce_batched) sums them -- bit for bit what vs_conv_wgrad's own reduce writes; the device table
+    is built once and reused (second round), layers without a split (S = 1) bypass it."""
+    from vidsitu_amd import ops
+
+    cases = [WG_CASES[i] for i in range(min(6, len(WG_CASES)))] + [
+        ("big_3x3", 2, 64, 4, 28, 28, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+        ("big_pw", 2, 128, 4, 28, 28, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ]
+    batch = ops.WgradBatch()
+    prepared = []
+    for ci, case in enumerate(cases):
+        x, w, k, s, p = _mk(case, seed=80 + ci)
+        y = F.conv3d(x, w, stride=s, padding=p)
+        dya = to_act(rb(torch.randn(y.shape, generator=torch.Generator().manual_seed(90 + ci))), dev)
+        xa = to_act(x, dev)
+        out = torch.empty((w.shape[0], *k, w.shape[1]), dtype=torch.float32, device=dev).permute(0, 4, 1, 2, 3)
+        prepared.append((dya, xa, k, s, p, out))
+    for rnd in range(2):
+        for dya, xa, k, s, p, out in prepared:
+            out.fill_(float("nan"))
+            ops.conv_wgrad(dya, xa, k, s, p, out=out, batch=batch)
+        n_pending = len(batch.pending)
+        batch.flush()
+        assert not batch.pending and len(batch.tables) == 1
+        for dya, xa, k, s, p, out in prepared:
+            want = ops.conv_wgrad(dya, xa, k, s, p)
+            assert torch.equal(out, want)
+    assert n_pending >= 2, "expected several split layers in the batch"

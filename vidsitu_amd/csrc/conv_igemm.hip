@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   int qT = 0, qH = 0, qW = 0, ntT = p.kT, ntH = p.kH, ntW = p.kW;  // taps: dd = q + st * i
   if (cls) {
     stT = 1 << p.shT; stH = 1 << p.shH; stW = 1 << p.shW;
-    const int cq = tm % p.ncls, ti = tm / p.ncls;
+    const int cq = p.cls_ids[tm % p.nslots], ti = tm / p.nslots;
     if (ti >= p.cls_tiles[cq]) {  // empty slot of the class-interleaved numbering
       if (BNB && tid < BN && n0 + tid < p.Ncols) {
         float* dst = p.stats + (long long)tm * 2 * p.Ncols;
@@ -1053,7 +1053,7 @@ static size_t plan_ws_bytes(const ConvPlan& pl, long long M, int Ncols) {
 // Stride classes of the transposed gather (MODE 2): tiles are laid out class by class; sets
 // p.ncls / p.cls_tiles / p.tilesM.
 static void setup_stride_classes(ConvP& p, int bm, int mode, int flags) {
-  p.ncls = 0;
+  p.ncls = p.nslots = 0;
   if (mode == 2 && p.kT * p.kH * p.kW <= 31 && !(flags & VS_CONV_NOCLASS)) {
     const int sT = 1 << p.shT, sH = 1 << p.shH, sW = 1 << p.shW;
     const int ncls = sT * sH * sW;
@@ -1063,17 +1063,23 @@ static void setup_stride_classes(ConvP& p, int bm, int mode, int flags) {
         const int r0 = ((q - off) % st + st) % st;
         return r0 < R ? (R - r0 + st - 1) / st : 0;
       };
-      int tmax = 0;
+      // accumulating in place: the tiles of classes no tap reaches would only copy the residual onto itself
+      const bool inplace = (p.flags & VS_CONV_RESIDUAL) && p.res != nullptr && p.res == p.y && p.res_bits == nullptr &&
+                           !(p.flags & VS_CONV_BNBWD);
+      int tmax = 0, nslots = 0;
       for (int q = 0; q < ncls; ++q) {
         const int qw = q % sW, qh = (q / sW) % sH, qt = q / (sW * sH);
         const long long rows = (long long)nb * cnt(p.Rt, qt, p.offT, sT) * cnt(p.Rh, qh, p.offH, sH) *
                                cnt(p.Rw, qw, p.offW, sW);
         p.cls_tiles[q] = (int)((rows + bm - 1) / bm);
+        const bool has_taps = qt < p.kT && qh < p.kH && qw < p.kW;
+        if (inplace && !has_taps) continue;
+        p.cls_ids[nslots++] = q;
         if (p.cls_tiles[q] > tmax) tmax = p.cls_tiles[q];
       }
-      const int t0 = tmax * ncls;
       p.ncls = ncls;
-      p.tilesM = t0;
+      p.nslots = nslots;
+      p.tilesM = tmax * nslots;
     }
   }
 }
@@ -1188,7 +1194,7 @@ static int fill_fwd_params(ConvP& p, const vs_conv_desc* d) {
   p.res_ld = d->res_ld;
   p.flags = d->flags & 0x70ff;  // epilogue bits + debug ablation
   p.tilesM = p.tilesN = 0;
-  p.ncls = 0;
+  p.ncls = p.nslots = 0;
   const bool pointwise = (d->kT * d->kH * d->kW == 1) && d->pT == 0 && d->pH == 0 && d->pW == 0;
   return pointwise ? 0 : 1;
 }

@@ -32,8 +32,11 @@ struct ConvP {
   // i < cls_tiles[class] (slots beyond a smaller class's last tile exit at once).  A class-major numbering put
   // each class on its own pair of XCDs under the XCD-contiguous block order -- a 1x1 stride-2 dgrad (one class of
   // four has taps) then ran on 2 of the 8 XCDs.
-  int ncls;
+  // An accumulating dgrad (residual == output) launches only the classes that have taps: nslots < ncls, cls_ids
+  // lists them (a 1x1 stride-2 shortcut: one class of four).
+  int ncls, nslots;
   int cls_tiles[16];          // M-tiles of each class
+  int cls_ids[16];            // slot -> class
   // VS_CONV_BNBWD (dgrad whose output is the gradient dz behind a BN + ReLU unit): the epilogue also
   // emits that BN's backward partial sums per M-tile, stats[tm][0][c] = sum g, [1][c] = sum g * xhat with
   // xhat = (bny - mean) * invstd and g = dz where gamma * xhat + beta > 0, else 0 -- what

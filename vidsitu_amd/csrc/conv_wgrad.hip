@@ -512,6 +512,77 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, f
   }
 }
 
+// The same reduce for MANY layers in one launch (the slabs of every weight gradient of a backward segment are
+// kept -- 288 GB of HBM: 1.5 GB of slabs per step is nothing -- and summed by one launch at the end of the
+// segment instead of one 6 us launch behind every wgrad).  table[i] = {slab base, dw base (addresses), n
+// elements, S, first block}; a block finds its entry by one binary search; then exactly wgrad_reduce_kernel's
+// order (bitwise the per-layer reduce).
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const long long* __restrict__ table, int nent) {
+  __shared__ float4 part[16][17];
+  const long long b = blockIdx.x;
+  int lo = 0, hi = nent - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid * 5 + 4] <= b) lo = mid; else hi = mid - 1;
+  }
+  const float* slabs = (const float*)table[lo * 5 + 0];
+  float* dw = (float*)table[lo * 5 + 1];
+  const long long n = table[lo * 5 + 2];
+  const int S = (int)table[lo * 5 + 3];
+  const long long blk = b - table[lo * 5 + 4];
+  const long long n4 = n >> 2;
+  const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long long i = blk * 16 + col;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    const int per = (S + 15) / 16;
+    const int s0 = sl * per, s1 = min(S, s0 + per);
+    int s = s0;
+    for (; s + 8 <= s1; s += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(slabs + (long long)(s + u) * n + i * 4);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc.x += v[u].x;
+        acc.y += v[u].y;
+        acc.z += v[u].z;
+        acc.w += v[u].w;
+      }
+    }
+    for (; s < s1; ++s) {
+      const float4 v = *(const float4*)(slabs + (long long)s * n + i * 4);
+      acc.x += v.x;
+      acc.y += v.y;
+      acc.z += v.z;
+      acc.w += v.w;
+    }
+  }
+  part[sl][col] = acc;
+  __syncthreads();
+  if (sl == 0 && i < n4) {
+    float4 t = part[0][col];
+    for (int k = 1; k < 16; ++k) {
+      const float4 v = part[k][col];
+      t.x += v.x;
+      t.y += v.y;
+      t.z += v.z;
+      t.w += v.w;
+    }
+    *(float4*)(dw + i * 4) = t;
+  }
+}
+
+extern "C" int vs_wgrad_reduce_batched(const int64_t* table, int n_entries, int64_t total_blocks, void* stream) {
+  VS_CHECK_ARG(table && n_entries > 0 && total_blocks > 0, "bad args");
+  hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const long long*)table, n_entries);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+extern "C" int64_t vs_wgrad_reduce_blocks(int64_t n) { return (n / 4 + 15) / 16; }
+
 // ------------------------------ host side ------------------------------------
 struct WgCfg {
   int bm, bn, S, rows_per_split, tilesM, tilesN;
@@ -609,9 +680,8 @@ static int wg_launch(const WgradP& p, int mode, int ring, hipStream_t st) {
   return VS_OK;
 }
 
-extern "C" int vs_conv_wgrad(const void* dy, const void* x, float* dw, const vs_conv_desc* d,
-                             void* workspace,
-                             size_t ws_bytes, void* stream) {
+static int wgrad_impl(const void* dy, const void* x, float* dw, const vs_conv_desc* d, void* workspace,
+                      size_t ws_bytes, void* stream, bool reduce_now, int* splits_out) {
   VS_CHECK_ARG(d && dy && x && dw, "null argument");
   VS_CHECK_ARG(d->Cin % 8 == 0 && d->Cout % 8 == 0, "Cin and Cout must be multiples of 8");
   VS_CHECK_ARG(d->x_ld % 8 == 0 && d->y_ld % 8 == 0, "row pitches must be multiples of 8");
@@ -675,7 +745,8 @@ extern "C" int vs_conv_wgrad(const void* dy, const void* x, float* dw, const vs_
   else if (c.bn == 128) rc = wg_launch<16, 128, 1, 4>(p, mode, ring, st);
   else rc = wg_launch<16, 64, 1, 4>(p, mode, ring, st);
   if (rc) return rc;
-  if (c.S > 1) {
+  if (splits_out) *splits_out = c.S;
+  if (c.S > 1 && reduce_now) {
     const long long n = (long long)d->Cout * p.Kp;
     const long long grid = (n / 4 + 15) / 16;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, st,
@@ -683,4 +754,16 @@ extern "C" int vs_conv_wgrad(const void* dy, const void* x, float* dw, const vs_
     VS_CHECK_LAUNCH();
   }
   return VS_OK;
+}
+
+extern "C" int vs_conv_wgrad(const void* dy, const void* x, float* dw, const vs_conv_desc* d,
+                             void* workspace,
+                             size_t ws_bytes, void* stream) {
+  return wgrad_impl(dy, x, dw, d, workspace, ws_bytes, stream, true, nullptr);
+}
+
+extern "C" int vs_conv_wgrad_partial(const void* dy, const void* x, float* dw, const vs_conv_desc* d, void* slabs,
+                                     size_t slab_bytes, int* splits, void* stream) {
+  VS_CHECK_ARG(splits != nullptr, "null splits");
+  return wgrad_impl(dy, x, dw, d, slabs, slab_bytes, stream, false, splits);
 }

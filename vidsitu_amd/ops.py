@@ -364,14 +364,64 @@ def _workspace(nbytes, device):
     return ws
 
 
-def conv_wgrad(dy, x, k, s, p, out=None, ring=0):
+class WgradBatch:
+    """Weight-gradient slabs of many layers, reduced by ONE launch (`flush`) instead of one small launch behind
+    every wgrad.  Each layer (keyed by its gradient's address) owns a persistent slab buffer -- 1.5 GB in all for a
+    SlowFast-R50 step, on a 288 GB device -- so the set of (slab, dw) pairs is the same every step and the device
+    table the batched kernel reads is built once (hipGraph-safe: nothing is allocated or uploaded in a replay)."""
+
+    def __init__(self):
+        self.slabs = {}      # dw address -> (uint8 slab tensor, nbytes)
+        self.pending = []    # (slab address, dw address, elements, splits) since the last flush
+        self.tables = {}     # tuple(pending) -> (device table, entries, total blocks)
+
+    def wgrad(self, dy, x, k, s, p, out, ring=0):
+        d = make_desc(x.shape, act_ld(x), dy.shape, act_ld(dy), k, s, p, (ring & 7) << 16)
+        need = int(_lib.load().vs_conv_wgrad_workspace_bytes(C.byref(d)))
+        key = out.data_ptr()
+        slab = None
+        if need:
+            slab, have = self.slabs.get(key, (None, 0))
+            if have < need:
+                slab = torch.empty(need, dtype=torch.uint8, device=x.device)
+                self.slabs[key] = (slab, need)
+        splits = C.c_int(0)
+        _lib.call("vs_conv_wgrad_partial", _ptr(dy), _ptr(x), _ptr(out), C.byref(d), _ptr(slab),
+                  C.c_size_t(need), C.byref(splits), _stream())
+        if splits.value > 1:
+            self.pending.append((slab.data_ptr(), key, out.numel(), splits.value))
+        return out
+
+    def flush(self):
+        """Sum every pending layer's slabs into its dw (one launch on the current stream)."""
+        if not self.pending:
+            return
+        sig = tuple(self.pending)
+        ent = self.tables.get(sig)
+        if ent is None:
+            rows, first = [], 0
+            lib = _lib.load()
+            for slab_ptr, dw_ptr, n, S in self.pending:
+                rows.append([slab_ptr, dw_ptr, n, S, first])
+                first += int(lib.vs_wgrad_reduce_blocks(n))
+            dev = torch.device("cuda", torch.cuda.current_device())
+            ent = self.tables[sig] = (torch.tensor(rows, dtype=torch.int64, device=dev), len(rows), first)
+        table, n_ent, blocks = ent
+        _lib.call("vs_wgrad_reduce_batched", _ptr(table), n_ent, blocks, _stream())
+        self.pending = []
+
+
+def conv_wgrad(dy, x, k, s, p, out=None, ring=0, batch=None):
     """dw fp32, logical [Cout,Cin,kT,kH,kW], memory [Cout][taps][Cin].
-    ring: 0 heuristic, 1 register-staged pipeline, 2 / 3 LDS-DMA ring stages (VS_CONV_RING)."""
+    ring: 0 heuristic, 1 register-staged pipeline, 2 / 3 LDS-DMA ring stages (VS_CONV_RING).
+    batch: a WgradBatch -- the split partials stay in the batch's slabs until `batch.flush()`."""
     cout, cin = dy.shape[1], x.shape[1]
     if out is None:
         out = torch.empty((cout, *k, cin), dtype=torch.float32, device=x.device).permute(0, 4, 1, 2, 3)
     elif not out.permute(0, 2, 3, 4, 1).is_contiguous() or out.dtype != torch.float32:
         raise _lib.VsError("conv_wgrad out must be fp32 with [Cout][taps][Cin] memory")
+    if batch is not None:
+        return batch.wgrad(dy, x, k, s, p, out, ring)
     d = make_desc(x.shape, act_ld(x), dy.shape, act_ld(dy), k, s, p, (ring & 7) << 16)
     need = _lib.load().vs_conv_wgrad_workspace_bytes(C.byref(d))
     ws = _workspace(need, x.device) if need else None

@@ -174,6 +174,7 @@ class _Unit:
     """conv -> BN (-> +residual) (-> ReLU) executed on the HIP kernels."""
 
     trace = None  # debugging: set to a list to record (conv, y, z, mean, invstd) per unit
+    wgrad_batch = None  # the running trunk backward's ops.WgradBatch (set by VideoTrunk._backward_segment)
     # BN-backward sums of the a / b units of a bottleneck emitted by the consuming convolution's dgrad
     # epilogue (vs_conv_dgrad_bnstats) instead of a reduce pass of their own; VS_FUSE_BN_SUMS=0 = A/B switch
     fuse_bn_sums = os.environ.get("VS_FUSE_BN_SUMS", "1") != "0"
@@ -253,8 +254,11 @@ class _Unit:
         elif conv.cin_pad == conv.cin:
             if conv.weight.grad is None:
                 conv.weight.grad = torch.empty_like(conv.weight)
-            _WgradLanes.run(lambda: ops.conv_wgrad(dy, x, conv.k, conv.s, conv.p, out=conv.weight.grad),
-                            dy, x)
+            # gradients that live in a ParamArena keep their address: their position-split partials go to the
+            # trunk's WgradBatch and are summed by one launch per backward segment (VideoTrunk._flush_wgrads)
+            batch = _Unit.wgrad_batch if getattr(conv.weight, "_vs_direct_grad", False) else None
+            _WgradLanes.run(lambda: ops.conv_wgrad(dy, x, conv.k, conv.s, conv.p, out=conv.weight.grad,
+                                                   batch=batch), dy, x)
         else:
             def legacy():
                 dwp = ops.conv_wgrad(dy, x, conv.k, conv.s, conv.p)
@@ -737,6 +741,7 @@ class VideoTrunk(nn.Module):
         self._folds_version = None
         self._stats_epoch = 0  # bumped whenever a train-mode pass rewrites running stats
         self.debug_taps = None  # set to a dict to record the activations after every stage
+        self._wgrad_batch, self._reduce_pending = None, False
         self.num_classes = int(getattr(cfg.MODEL, "NUM_CLASSES", 400))
 
     def reference_only_params(self):
@@ -946,7 +951,46 @@ class VideoTrunk(nn.Module):
                  "rest": ["s1", "s1_fuse", "s2", "s2_fuse", "s3", "s3_fuse"]}[seg]
         return [getattr(self, n) for n in names if hasattr(self, n)]
 
+    # One slab-reduce launch per backward segment instead of one behind every weight gradient (108 launches of
+    # ~6 us per SlowFast-R50 step).  Measured SLOWER (A/B on one box, 30 steps: 14.00 ms batched vs 13.77 ms): the
+    # per-layer reduce reads slabs its wgrad wrote microseconds earlier (L2 / Infinity Cache), the batched one
+    # reads 1.45 GB back from HBM and competes with the BN passes.  Kept behind VS_WGRAD_BATCH=1.
+    batch_wgrads = os.environ.get("VS_WGRAD_BATCH", "0") == "1"
+    _reduce_streams = {}
+
+    def _flush_wgrads(self, last):
+        """Sum the pending weight-gradient slabs.  The launch goes to a side stream beside the next segment; it
+        is joined at the end of the backward pass -- or at once when the segments are driven from outside
+        (`defer_backward`: the caller all-reduces the segment's gradients right behind it)."""
+        batch = self._wgrad_batch
+        if batch is None or (not batch.pending and not self._reduce_pending):
+            return
+        main = torch.cuda.current_stream()
+        key = main.device.index
+        rs = VideoTrunk._reduce_streams.get(key)
+        if rs is None:
+            rs = VideoTrunk._reduce_streams[key] = torch.cuda.Stream(device=main.device)
+        if batch.pending:
+            rs.wait_stream(main)
+            with torch.cuda.stream(rs):
+                batch.flush()
+            self._reduce_pending = True
+        if self._reduce_pending and (last or self.defer_backward):
+            main.wait_stream(rs)
+            self._reduce_pending = False
+
     def _backward_segment(self, st, seg):
+        if self.batch_wgrads and st["d"][0].is_cuda:
+            if self._wgrad_batch is None:
+                self._wgrad_batch = ops.WgradBatch()
+            _Unit.wgrad_batch = self._wgrad_batch
+        try:
+            self._backward_segment_body(st, seg)
+        finally:
+            _Unit.wgrad_batch = None
+        self._flush_wgrads(last=seg == self.BWD_SEGMENTS[-1])
+
+    def _backward_segment_body(self, st, seg):
         for k in {"s5": (5,), "s4": (4,), "rest": (3, 2)}[seg]:
             self._backward_stage(st, k)
         if seg == "rest":
