@@ -94,8 +94,9 @@ class EntryProbe:
             unit = d.sT == 1 and d.sH == 1 and d.sW == 1
             pw = taps == 1 and d.pT == 0 and d.pH == 0 and d.pW == 0
             mode = (0 if (pw and unit) else (1 if unit else 2)) if dgrad else (0 if pw else 1)
-            if direct == 2:  # halo-image kernel (conv_halo.hip): wave tile in 16-row / 16-column units
-                return f"conv_halo_kernel<{bm // 32}, {bn // 32}, {'true' if bnb else 'false'}>"
+            if direct == 2:  # halo-image kernel (conv_halo.hip): wave tile in 16-row / 16-column units,
+                # weight-ring depth (reported in the `ring` slot), unrolled taps (in the `split` slot)
+                return f"conv_halo_kernel<{bm // 32}, {bn // 32}, {'true' if bnb else 'false'}, {ring}, {S}>"
             if direct:
                 ncols = d.Cin if dgrad else d.Cout
                 K = taps * (d.Cout if dgrad else d.Cin)
@@ -108,7 +109,7 @@ class EntryProbe:
 
         def describe(name, a):
             """-> (family label, bound, algorithmic flops, algorithmic bytes)"""
-            if name in ("vs_conv_fwd", "vs_conv_dgrad", "vs_conv_wgrad", "vs_conv_dgrad_bnstats"):
+            if name in ("vs_conv_fwd", "vs_conv_dgrad", "vs_conv_wgrad", "vs_conv_dgrad_bnstats", "vs_conv_dgrad_ex"):
                 d = a[3]._obj
                 taps = d.kT * d.kH * d.kW
                 mo = d.N * d.To * d.Ho * d.Wo
@@ -121,6 +122,11 @@ class EntryProbe:
                     byts += 2.0 * mo * d.Cout
                 if name == "vs_conv_dgrad_bnstats":  # + the producer's saved conv output, read by the epilogue
                     return conv_label(d, 1, True), "mfma", flops, byts + 2.0 * mi * d.Cin
+                if name == "vs_conv_dgrad_ex":
+                    ep = a[4]._obj
+                    bnb = bool(ep.stats_partial)
+                    extra = (2.0 if ep.residual else 0.0) + (2.0 if bnb else 0.0) + (0.125 if ep.residual_bits else 0.0)
+                    return conv_label(d, 1, bnb), "mfma", flops, byts + extra * mi * d.Cin
                 return conv_label(d, 1 if name == "vs_conv_dgrad" else 0), "mfma", flops, byts
             if name in ("vs_stem_conv_fwd", "vs_stem_conv_wgrad"):
                 n, t, h, w, cout, kt = [_v(x) for x in a[3:9]]
@@ -132,6 +138,9 @@ class EntryProbe:
             if name == "vs_bn_apply":
                 rows, c = _v(a[5]), _v(a[6])
                 return "bn_apply_cols_kernel", "hbm", 0.0, 2.0 * rows * c * (2 + _nn(a[3]))
+            if name == "vs_bn_apply_mask":  # the same kernel, + the ReLU bit mask (1 bit per element)
+                rows, c = _v(a[6]), _v(a[7])
+                return "bn_apply_cols_kernel", "hbm", 0.0, 2.0 * rows * c * (2 + _nn(a[3])) + rows * c / 8.0
             if name == "vs_bn_bwd_reduce":
                 rows, c = _v(a[8]), _v(a[9])
                 return "bn_bwd_reduce_kernel", "hbm", 0.0, 2.0 * rows * c * (2 + _nn(a[1]))

@@ -109,7 +109,8 @@ int vs_conv_stats_rows(const vs_conv_desc* d);
 size_t vs_conv_workspace_bytes(const vs_conv_desc* d, int dgrad);
 /* The launch plan the library picks for this descriptor (dgrad = 1: for vs_conv_dgrad):
  * out[5] = {tile rows, tile cols, LDS-DMA ring stages (0 = register-staged), split-K factor,
- * 1 if the register-resident small-channel kernel runs}.  Profiling / attribution only. */
+ * 1 if the register-resident small-channel kernel runs}; out[4] == 2: the halo-image kernel (conv_halo.hip),
+ * out[0..1] its tile, out[2] its weight-ring depth, out[3] its unrolled tap count.  Profiling / attribution only. */
 int vs_conv_plan(const vs_conv_desc* d, int dgrad, int* out);
 
 /* Data gradient: dx[N,Ti,Hi,Wi,Cin] = conv_transpose(dy, w) (+ residual when

@@ -440,17 +440,32 @@ static int halo_launch_depth(const ConvP& p, const HaloGeo& g, hipStream_t st) {
   return VS_OK;
 }
 
+// Kernel variant of a geometry: weight-ring depth D and the unrolled tap count (0 = generic tap loop).
+// 9 taps: unrolled, deep weight ring where it fits LDS (64-column tiles); 3 taps: unrolled; else generic.
+// The 224 x 128 tile has no registers left for the per-tap address table (it spills): generic path.
+void vs_halo_variant(const HaloGeo& g, int* depth, int* taps_unrolled) {
+  const int taps = g.k1 * g.k2;
+  *depth = 3;
+  *taps_unrolled = 0;
+  if (g.mrw == 7 && g.nrw == 4) return;
+  if (taps == 9) {
+    *taps_unrolled = 9;
+    if (g.nrw == 2) *depth = 7;
+  } else if (taps == 3) {
+    *taps_unrolled = 3;
+  }
+}
+
 template <int MRW, int NRW, bool BNB>
 static int halo_launch_one(const ConvP& p, const HaloGeo& g, hipStream_t st) {
-  const int taps = g.k1 * g.k2;
-  // 9 taps: unrolled, deep weight ring where it fits LDS (64-column tiles); 3 taps: unrolled; else generic.
-  // The 224 x 128 tile has no registers left for the per-tap address table (it spills): generic path.
+  int depth, tu;
+  vs_halo_variant(g, &depth, &tu);
   if constexpr (MRW == 7 && NRW == 4) return halo_launch_depth<MRW, NRW, BNB, 3, 0>(p, g, st);
-  if (taps == 9) {
+  if (tu == 9) {
     if constexpr (NRW == 2) return halo_launch_depth<MRW, NRW, BNB, 7, 9>(p, g, st);
     else return halo_launch_depth<MRW, NRW, BNB, 3, 9>(p, g, st);
   }
-  if (taps == 3) return halo_launch_depth<MRW, NRW, BNB, 3, 3>(p, g, st);
+  if (tu == 3) return halo_launch_depth<MRW, NRW, BNB, 3, 3>(p, g, st);
   return halo_launch_depth<MRW, NRW, BNB, 3, 0>(p, g, st);
 }
 

@@ -1224,8 +1224,7 @@ extern "C" int vs_conv_plan(const vs_conv_desc* d, int dgrad, int* out) {
     if (mode >= 0 && !(d->flags & VS_CONV_NAIVE) && vs_halo_plan(p, mode, dgrad, d->flags, &hg)) {
       out[0] = 32 * hg.mrw;
       out[1] = 32 * hg.nrw;
-      out[2] = 3;
-      out[3] = 1;
+      vs_halo_variant(hg, &out[2], &out[3]);  // weight-ring depth, unrolled taps (0 = generic)
       out[4] = 2;  // halo-image kernel
       return VS_OK;
     }

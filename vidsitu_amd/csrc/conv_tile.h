@@ -360,3 +360,4 @@ struct HaloGeo {
 // or false when the implicit-GEMM kernel runs it.
 bool vs_halo_plan(const ConvP& p, int mode, int dgrad, int flags, HaloGeo* out);
 int vs_halo_launch(const ConvP& p, const HaloGeo& g, hipStream_t st);
+void vs_halo_variant(const HaloGeo& g, int* depth, int* taps_unrolled);

@@ -135,8 +135,11 @@ class _WgradLanes:
     segfault on ROCm 7.2, so launches issued from that stream stay inline.  VS_WGRAD_LANES=0: off."""
 
     enabled = os.environ.get("VS_WGRAD_LANES", "1") != "0"
-    # device index -> [issuing stream, lane stream, keepalive list, pending].  Lane streams are
-    # created once (never inside a hipGraph capture, where creating a stream is an unsafe call).
+    # units the lane may lag behind the issuing stream before that stream waits for it (0: joined right after
+    # the unit's dgrad).  VS_WGRAD_LAG: A/B knob.
+    lag = int(os.environ.get("VS_WGRAD_LAG", "0"))
+    # device index -> [issuing stream, lane stream, queue of (event, keepalive) per launched unit].  Lane streams
+    # are created once (never inside a hipGraph capture, where creating a stream is an unsafe call).
     lanes = {}
 
     @classmethod
@@ -150,24 +153,33 @@ class _WgradLanes:
             return fn()  # issued from the fast pathway's stream: no nested fork
         lane = cls.lanes.get(dev)
         if lane is None:
-            lane = cls.lanes[dev] = [main, torch.cuda.Stream(device=main.device), [], False]
-        if lane[3] and lane[0].cuda_stream != main.cuda_stream:  # never leave a lane un-joined
-            lane[0].wait_stream(lane[1])
-            lane[2].clear()
+            lane = cls.lanes[dev] = [main, torch.cuda.Stream(device=main.device), []]
+        if lane[2] and lane[0].cuda_stream != main.cuda_stream:  # never leave a lane un-joined
+            cls._drain(lane, 0)
         lane[0] = main
         lane[1].wait_stream(main)
         with torch.cuda.stream(lane[1]):
             fn()
-        lane[2].extend(keep)
-        lane[3] = True
+            ev = torch.cuda.Event()
+            ev.record(lane[1])
+        lane[2].append((ev, keep))
+
+    @staticmethod
+    def _drain(lane, lag):
+        while len(lane[2]) > lag:
+            ev, _ = lane[2].pop(0)
+            lane[0].wait_event(ev)
+
+    @classmethod
+    def join_unit(cls):
+        """After a unit's dgrad: wait for the weight gradients launched more than `lag` units ago."""
+        for lane in cls.lanes.values():
+            cls._drain(lane, cls.lag)
 
     @classmethod
     def join_all(cls):
         for lane in cls.lanes.values():
-            if lane[3]:
-                lane[0].wait_stream(lane[1])
-                lane[2].clear()
-                lane[3] = False
+            cls._drain(lane, 0)
 
 
 class _Unit:
@@ -286,7 +298,7 @@ class _Unit:
             else:
                 dx = ops.conv_dgrad(dy, conv.wt(), tuple(x.shape), conv.k, conv.s, conv.p,
                                     residual=dx_residual, residual_bits=dx_residual_bits, inplace=inplace)
-        _WgradLanes.join_all()  # wgrad || dgrad of this unit, no further
+        _WgradLanes.join_unit()  # wgrad || dgrad of this unit (and, with a lag, of the next units)
         return dx, dres
 
 
