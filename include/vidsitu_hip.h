@@ -196,6 +196,9 @@ int vs_conv_wgrad(const void* dy, const void* x, float* dw, const vs_conv_desc* 
 int vs_conv_wgrad_partial(const void* dy, const void* x, float* dw, const vs_conv_desc* d, void* slabs,
                           size_t slab_bytes, int* splits, void* stream);
 int64_t vs_wgrad_reduce_blocks(int64_t elements);
+/* The reduce of ONE layer's slabs (what vs_conv_wgrad launches behind its kernel): callers that split the two
+ * launches can release the wgrad's operands -- and let a stream that waits for them go on -- before the reduce. */
+int vs_wgrad_reduce(const float* slabs, float* dw, int64_t elements, int splits, void* stream);
 int vs_wgrad_reduce_batched(const int64_t* table, int n_entries, int64_t total_blocks, void* stream);
 
 /* BatchNorm3d (mdl_sf_base.py:22-33 via slowfast BN modules; eps 1e-5, mom 0.1).

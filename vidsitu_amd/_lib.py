@@ -67,6 +67,7 @@ SIGNATURES = {
     "vs_conv_wgrad": (_i, [_p, _p, _p, _dp, _p, _sz, _p]),
     "vs_conv_wgrad_partial": (_i, [_p, _p, _p, _dp, _p, _sz, C.POINTER(C.c_int), _p]),
     "vs_wgrad_reduce_blocks": (_i64, [_i64]),
+    "vs_wgrad_reduce": (_i, [_p, _p, _i64, _i, _p]),
     "vs_wgrad_reduce_batched": (_i, [_p, _i, _i64, _p]),
     "vs_bn_finalize": (_i, [_p, _i, _d, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i, _p]),
     "vs_bn_partials_reduce": (_i, [_p, _i, _p, _i, _i, _p]),

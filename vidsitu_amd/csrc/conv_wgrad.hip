@@ -583,10 +583,20 @@ extern "C" int vs_wgrad_reduce_batched(const int64_t* table, int n_entries, int6
 
 extern "C" int64_t vs_wgrad_reduce_blocks(int64_t n) { return (n / 4 + 15) / 16; }
 
+extern "C" int vs_wgrad_reduce(const float* slabs, float* dw, int64_t n, int splits, void* stream) {
+  VS_CHECK_ARG(slabs && dw && n > 0 && splits > 1, "bad args");
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, (hipStream_t)stream, slabs,
+                     dw, (long long)n, splits);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
 // ------------------------------ host side ------------------------------------
 struct WgCfg {
   int bm, bn, S, rows_per_split, tilesM, tilesN;
 };
+
+static const int kWgTiles[8][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128}, {32, 64}, {16, 128}, {16, 64}};
 
 static WgCfg wg_pick(const vs_conv_desc* d) {
   WgCfg c;
@@ -594,6 +604,14 @@ static WgCfg wg_pick(const vs_conv_desc* d) {
   const long long P = (long long)d->N * d->To * d->Ho * d->Wo;
   c.bm = d->Cout >= 128 ? 128 : (d->Cout >= 64 ? 64 : (d->Cout >= 32 ? 32 : 16));
   c.bn = Kp >= 128 ? 128 : 64;
+  // (Tried: for the few-position layers of slow s5 -- 3 136 positions, 2-12 MB of dW -- output tiles small enough to
+  // fill the chip with no position split at all (64 x 128 / 64 x 64, no slabs, no reduce): slower, 52 vs 43-48 us
+  // on s5.b, 29.6 vs 23 us on s5.c -- tools/wgrad_sweep.py, profiles/r02_wgrad_sweep.txt.)
+  const int forced = (d->flags >> 8) & 0xf;  // experiments / tests: tile id + 1 in bits 8..11
+  if (forced >= 1 && forced <= 8) {
+    c.bm = kWgTiles[forced - 1][0];
+    c.bn = kWgTiles[forced - 1][1];
+  }
   c.tilesM = (d->Cout + c.bm - 1) / c.bm;
   c.tilesN = (Kp + c.bn - 1) / c.bn;
   const long long tiles = (long long)c.tilesM * c.tilesN;
@@ -614,7 +632,9 @@ static WgCfg wg_pick(const vs_conv_desc* d) {
     const char* e = getenv("VS_WGRAD_SLOTS_SMALL");
     return e ? atoll(e) : 2048ll;
   }();
-  const long long target = (d->Cout <= 32) ? small_slots : slots;
+  long long target = (d->Cout <= 32) ? small_slots : slots;
+  const int forced_slots = (d->flags >> 24) & 0xff;  // experiments: resident block slots / 8 in bits 24..31
+  if (forced_slots) target = 8ll * forced_slots;
   // Round the split DOWN so that the grid fits one residency round (two blocks are resident per CU,
   // 80 KB of LDS each) -- 528 blocks on 512 slots run as two rounds (s4.a: +45 %)
   long long S = (d->Cout <= 32) ? (target + tiles - 1) / tiles : target / tiles;

@@ -411,7 +411,28 @@ class WgradBatch:
         self.pending = []
 
 
-def conv_wgrad(dy, x, k, s, p, out=None, ring=0, batch=None):
+WG_TILES = [(128, 128), (128, 64), (64, 128), (64, 64), (32, 128), (32, 64), (16, 128), (16, 64)]
+
+
+def conv_wgrad_split(dy, x, k, s, p, out, ring=0):
+    """conv_wgrad as its two launches: runs the wgrad kernel now and returns the slab reduce as a callable (None when
+    the plan has no position split and `out` is already complete).  The reduce reads only the stream's workspace and
+    writes `out`, so a caller may release dy / x -- and signal whoever waits for them -- before it runs."""
+    if not out.permute(0, 2, 3, 4, 1).is_contiguous() or out.dtype != torch.float32:
+        raise _lib.VsError("conv_wgrad out must be fp32 with [Cout][taps][Cin] memory")
+    d = make_desc(x.shape, act_ld(x), dy.shape, act_ld(dy), k, s, p, (ring & 7) << 16)
+    need = int(_lib.load().vs_conv_wgrad_workspace_bytes(C.byref(d)))
+    ws = _workspace(need, x.device) if need else None
+    splits = C.c_int(0)
+    _lib.call("vs_conv_wgrad_partial", _ptr(dy), _ptr(x), _ptr(out), C.byref(d), _ptr(ws), C.c_size_t(need),
+              C.byref(splits), _stream())
+    if splits.value <= 1:
+        return None
+    n, S = out.numel(), splits.value
+    return lambda: _lib.call("vs_wgrad_reduce", _ptr(ws), _ptr(out), n, S, _stream())
+
+
+def conv_wgrad(dy, x, k, s, p, out=None, ring=0, batch=None, tile=None, slots=0):
     """dw fp32, logical [Cout,Cin,kT,kH,kW], memory [Cout][taps][Cin].
     ring: 0 heuristic, 1 register-staged pipeline, 2 / 3 LDS-DMA ring stages (VS_CONV_RING).
     batch: a WgradBatch -- the split partials stay in the batch's slabs until `batch.flush()`."""
@@ -422,7 +443,9 @@ def conv_wgrad(dy, x, k, s, p, out=None, ring=0, batch=None):
         raise _lib.VsError("conv_wgrad out must be fp32 with [Cout][taps][Cin] memory")
     if batch is not None:
         return batch.wgrad(dy, x, k, s, p, out, ring)
-    d = make_desc(x.shape, act_ld(x), dy.shape, act_ld(dy), k, s, p, (ring & 7) << 16)
+    # tile: index into WG_TILES, slots: block slots to fill (multiple of 8) -- tuning knobs, 0 / None = the plan
+    flags = ((ring & 7) << 16) | (((tile + 1) << 8) if tile is not None else 0) | (((slots // 8) & 0xff) << 24)
+    d = make_desc(x.shape, act_ld(x), dy.shape, act_ld(dy), k, s, p, flags)
     need = _lib.load().vs_conv_wgrad_workspace_bytes(C.byref(d))
     ws = _workspace(need, x.device) if need else None
     _lib.call("vs_conv_wgrad", _ptr(dy), _ptr(x), _ptr(out), C.byref(d), _ptr(ws),
@@ -433,6 +456,10 @@ def conv_wgrad(dy, x, k, s, p, out=None, ring=0, batch=None):
 # ----------------------------------------------------------------------------
 # batch norm
 # ----------------------------------------------------------------------------
+import os as _os
+_BN_TWO_LEVEL = int(_os.environ.get("VS_BN_TWO_LEVEL", "512"))  # partial rows above which a level-1 reduce runs first
+
+
 def bn_finalize(partials, count, gamma, beta, running_mean, running_var, momentum, eps, train):
     c = gamma.numel()
     dev = gamma.device
@@ -441,7 +468,7 @@ def bn_finalize(partials, count, gamma, beta, running_mean, running_var, momentu
     mean = torch.empty(c, dtype=torch.float32, device=dev)
     invstd = torch.empty(c, dtype=torch.float32, device=dev)
     nparts = partials.shape[0] if train else 0
-    if train and nparts > 512:  # two-level reduction keeps the finalize launch short
+    if train and nparts > _BN_TWO_LEVEL:  # two-level reduction keeps the finalize launch short
         lvl1 = torch.empty((32, 2, c), dtype=torch.float32, device=dev)
         _lib.call("vs_bn_partials_reduce", _ptr(partials), nparts, _ptr(lvl1), c, 32, _stream())
         partials, nparts = lvl1, 32

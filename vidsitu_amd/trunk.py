@@ -144,24 +144,32 @@ class _WgradLanes:
 
     @classmethod
     def run(cls, fn, *keep):
+        """fn runs on the lane; if it returns a callable (the slab reduce of ops.conv_wgrad_split) that runs on the
+        lane too, but BEHIND the event the issuing stream waits for: the reduce reads no operand of the unit, so the
+        issuing stream goes on as soon as the wgrad kernel itself is done (~7 us per unit off its critical path)."""
         if not cls.enabled or not keep[0].is_cuda:
-            return fn()
+            tail = fn()
+            return tail() if callable(tail) else None
         main = torch.cuda.current_stream()
         dev = main.device.index
         side = VideoTrunk._side_streams.get(dev)
         if side is not None and side.cuda_stream == main.cuda_stream:
-            return fn()  # issued from the fast pathway's stream: no nested fork
+            tail = fn()  # issued from the fast pathway's stream: no nested fork
+            return tail() if callable(tail) else None
         lane = cls.lanes.get(dev)
         if lane is None:
-            lane = cls.lanes[dev] = [main, torch.cuda.Stream(device=main.device), []]
+            lane = cls.lanes[dev] = [main, torch.cuda.Stream(device=main.device), [], False]
         if lane[2] and lane[0].cuda_stream != main.cuda_stream:  # never leave a lane un-joined
             cls._drain(lane, 0)
         lane[0] = main
         lane[1].wait_stream(main)
         with torch.cuda.stream(lane[1]):
-            fn()
+            tail = fn()
             ev = torch.cuda.Event()
             ev.record(lane[1])
+            if callable(tail):
+                tail()
+                lane[3] = True  # work behind the last event: a full join waits for the stream, not the event
         lane[2].append((ev, keep))
 
     @staticmethod
@@ -180,6 +188,9 @@ class _WgradLanes:
     def join_all(cls):
         for lane in cls.lanes.values():
             cls._drain(lane, 0)
+            if lane[3]:
+                lane[0].wait_stream(lane[1])
+                lane[3] = False
 
 
 class _Unit:
@@ -187,6 +198,12 @@ class _Unit:
 
     trace = None  # debugging: set to a list to record (conv, y, z, mean, invstd) per unit
     wgrad_batch = None  # the running trunk backward's ops.WgradBatch (set by VideoTrunk._backward_segment)
+    # VS_WGRAD_TAIL=1: the slab reduce of a weight gradient runs behind the event its unit's stream waits for (the
+    # reduce reads no operand of the unit).  Measured: 16.3 ms vs 13.5 ms per step under hipGraph replay -- like the
+    # lagged join (`_WgradLanes.lag`), ANY lane work that is still running when the issuing stream starts the next
+    # unit's BN kernels costs ~25 us per unit; the replay then takes as long as the one-stream graph (17.0 ms).
+    # Eager (host-bound, 24-26 ms) does not show it.  Off.
+    split_wgrad_reduce = os.environ.get("VS_WGRAD_TAIL", "0") == "1"
     # BN-backward sums of the a / b units of a bottleneck emitted by the consuming convolution's dgrad
     # epilogue (vs_conv_dgrad_bnstats) instead of a reduce pass of their own; VS_FUSE_BN_SUMS=0 = A/B switch
     fuse_bn_sums = os.environ.get("VS_FUSE_BN_SUMS", "1") != "0"
@@ -262,15 +279,21 @@ class _Unit:
             else:
                 conv.bias.grad.zero_()
         if conv.is_stem:
-            _WgradLanes.run(lambda: _set_grad(conv.weight, ops.stem_conv_wgrad(dy, x, conv.k[0])), dy, x)
+            _WgradLanes.run(lambda: _set_grad(conv.weight, ops.stem_conv_wgrad(dy, x, conv.k[0])) and None, dy, x)
         elif conv.cin_pad == conv.cin:
             if conv.weight.grad is None:
                 conv.weight.grad = torch.empty_like(conv.weight)
             # gradients that live in a ParamArena keep their address: their position-split partials go to the
             # trunk's WgradBatch and are summed by one launch per backward segment (VideoTrunk._flush_wgrads)
             batch = _Unit.wgrad_batch if getattr(conv.weight, "_vs_direct_grad", False) else None
-            _WgradLanes.run(lambda: ops.conv_wgrad(dy, x, conv.k, conv.s, conv.p, out=conv.weight.grad,
-                                                   batch=batch), dy, x)
+            if batch is not None:
+                _WgradLanes.run(lambda: (ops.conv_wgrad(dy, x, conv.k, conv.s, conv.p, out=conv.weight.grad,
+                                                        batch=batch), None)[1], dy, x)
+            elif _Unit.split_wgrad_reduce:
+                _WgradLanes.run(lambda: ops.conv_wgrad_split(dy, x, conv.k, conv.s, conv.p, conv.weight.grad), dy, x)
+            else:
+                _WgradLanes.run(lambda: (ops.conv_wgrad(dy, x, conv.k, conv.s, conv.p, out=conv.weight.grad),
+                                         None)[1], dy, x)
         else:
             def legacy():
                 dwp = ops.conv_wgrad(dy, x, conv.k, conv.s, conv.p)
