@@ -427,6 +427,11 @@ int vs_gpt2_embed_bwd(const int64_t* tokens, const float* dh, float* dwte, float
 int vs_xent_ignore_grad(const float* logits, const int64_t* labels, const float* loss_out,
                         float* dlogits, int rows, int V, int64_t ld, int ignore_index, float grad_scale,
                         void* stream);
+/* The same with the upstream gradient of the scalar loss read from device memory (autograd hands it over as a
+ * 0-dim device tensor): no host synchronisation in the backward pass, so the step can be captured in a hipGraph. */
+int vs_xent_ignore_grad_dev(const float* logits, const int64_t* labels, const float* loss_out,
+                            float* dlogits, int rows, int V, int64_t ld, int ignore_index,
+                            const float* grad_scale_dev, void* stream);
 
 /* Device-side beam-search bookkeeping of one step (SeqGenCustom._generate between two decoder
  * calls, seq_gen.py:368-520, and finalize_hypos :579-697), one block per sentence, no host sync:

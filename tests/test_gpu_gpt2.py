@@ -529,3 +529,68 @@ def test_new_gpt2_only_row_trains_and_generates(dev):
     assert sents.view(10, -1).shape == ref.shape and (sents.view(10, -1).cpu().numpy() == ref).all()
     res = sel["evl"](cfg, comm, dev).forward_one_batch(mdl, batch)
     assert len(res) == 2 and set(res[0]["vb_output"]) == {f"Ev{i}" for i in range(1, 6)}
+
+
+def _close(a, b):
+    # the embedding backward accumulates rows with atomics: equal up to fp32 summation order
+    return bool(((a - b).abs().max() <= 1e-5 * a.abs().max().clamp_min(1e-12)).item())
+
+
+def test_lm_loss_backward_has_no_host_sync_and_two_forwards_keep_their_own_state(dev):
+    """(1) Two forwards before the backwards: each autograd node carries its own saved activations.
+    (2) `_XentIgnoreFn.backward` hands the upstream gradient to the kernel as a device pointer: it runs under
+    torch's sync-debug mode "error" (a `float(go)` would raise) and equals torch's cross entropy."""
+    from vidsitu_amd.hf_gpt2_fseq import _GPT2TrainFn, lm_loss
+
+    path = [p for p in GOLD if "medium" not in p][0]
+    z, _, _, m = _model_from_golden(path, dev)
+    m.train()
+    pad = int(z["pad"])
+    for p in m.parameters():
+        p.grad = torch.zeros_like(p)
+    t0 = torch.from_numpy(z["tokens"]).to(dev)
+    toks = [t0, torch.roll(t0, 1, dims=0).flip(1).contiguous()]
+    mask = [t.ne(pad) for t in toks]
+
+    def run(tk, mk, scale):
+        tick = torch.zeros(1, device=dev, requires_grad=True)
+        logits = _GPT2TrainFn.apply(m, tk, mk, tick)
+        return lm_loss(logits, tk, pad) * scale
+
+    # two forwards, then the two backwards in the opposite order == each pair alone
+    want = []
+    for i in range(2):
+        for p in m.parameters():
+            p.grad.zero_()
+        run(toks[i], mask[i], 1.0 + i).backward()
+        want.append([p.grad.clone() for p in m.parameters()])
+    la, lb = run(toks[0], mask[0], 1.0), run(toks[1], mask[1], 2.0)
+    for p in m.parameters():
+        p.grad.zero_()
+    lb.backward()
+    got_b = [p.grad.clone() for p in m.parameters()]
+    for p in m.parameters():
+        p.grad.zero_()
+    la.backward()
+    got_a = [p.grad.clone() for p in m.parameters()]
+    for w, gt in zip(want[0], got_a):
+        assert _close(w, gt)
+    for w, gt in zip(want[1], got_b):
+        assert _close(w, gt)
+    # the loss node's backward reads the upstream gradient on the device: no host synchronisation
+    logits = torch.randn(6, 9, 50, device=dev, requires_grad=True)
+    tk = torch.randint(0, 49, (6, 9), device=dev)
+    loss = lm_loss(logits, tk, 49) * 3.0
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        loss.backward()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    ref = torch.nn.functional.cross_entropy(logits.detach()[:, :-1].reshape(-1, 50).requires_grad_(),
+                                            tk[:, 1:].reshape(-1), ignore_index=49)
+    lg = logits.detach().clone().requires_grad_()
+    (torch.nn.functional.cross_entropy(lg[:, :-1].reshape(-1, 50), tk[:, 1:].reshape(-1), ignore_index=49)
+     * 3.0).backward()
+    assert abs(float(ref) * 3.0 - float(loss)) < 1e-5 * abs(float(loss))
+    assert _close(lg.grad, logits.grad)

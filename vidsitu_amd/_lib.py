@@ -135,6 +135,7 @@ SIGNATURES = {
     "vs_attn_causal_bwd": (_i, [_p, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _p]),
     "vs_gpt2_embed_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vs_xent_ignore_grad": (_i, [_p, _p, _p, _p, _i, _i, _i64, _i, _f, _p]),
+    "vs_xent_ignore_grad_dev": (_i, [_p, _p, _p, _p, _i, _i, _i64, _i, _p, _p]),
 }
 
 

@@ -1183,9 +1183,11 @@ __global__ __launch_bounds__(256) void xent_ignore_grad_kernel(const float* logi
                                                                const int64_t* labels,
                                                                const float* loss_out, float* dlogits,
                                                                int V, long long ld, int ignore,
-                                                               float gscale) {
+                                                               float gscale_host, const float* gscale_dev) {
   __shared__ float red[256];
   const int r = blockIdx.x, tid = threadIdx.x;
+  // the upstream gradient of the scalar loss: a host number, or (graph-safe, no host sync) read from the device
+  const float gscale = gscale_dev ? gscale_host * gscale_dev[0] : gscale_host;
   const long long lb = labels[r];
   float* dst = dlogits + (long long)r * ld;
   if (lb == ignore) {
@@ -1220,7 +1222,16 @@ extern "C" int vs_xent_ignore_grad(const float* logits, const int64_t* labels, c
                                    float grad_scale, void* stream) {
   VS_CHECK_ARG(logits && labels && loss_out && dlogits && rows > 0 && V > 0 && ld >= V, "bad args");
   hipLaunchKernelGGL(xent_ignore_grad_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits,
-                     labels, loss_out, dlogits, V, (long long)ld, ignore_index, grad_scale);
+                     labels, loss_out, dlogits, V, (long long)ld, ignore_index, grad_scale, (const float*)nullptr);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+extern "C" int vs_xent_ignore_grad_dev(const float* logits, const int64_t* labels, const float* loss_out,
+                                       float* dlogits, int rows, int V, int64_t ld, int ignore_index,
+                                       const float* grad_scale_dev, void* stream) {
+  VS_CHECK_ARG(logits && labels && loss_out && dlogits && grad_scale_dev && rows > 0 && V > 0 && ld >= V, "bad args");
+  hipLaunchKernelGGL(xent_ignore_grad_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits,
+                     labels, loss_out, dlogits, V, (long long)ld, ignore_index, 1.0f, grad_scale_dev);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }

@@ -357,10 +357,14 @@ class _TxDecTrainFn(torch.autograd.Function):
     def forward(ctx, model, tokens, enc2d, _tick):
         ctx.model = model
         ctx.has_enc = enc2d is not None
-        return model.forward_train(tokens, None if enc2d is None else enc2d.detach())
+        out = model.forward_train(tokens, None if enc2d is None else enc2d.detach())
+        # the saved activations of THIS forward travel with the node (several forwards may precede a backward)
+        ctx.saved_state, model._saved = model._saved, None
+        return out
 
     @staticmethod
     def backward(ctx, dlogits):
+        ctx.model._saved = ctx.saved_state
         denc = ctx.model.backward(dlogits.contiguous())
         return None, None, (denc if ctx.has_enc else None), None
 

@@ -345,6 +345,15 @@ class GPT2LMHeadModelHip(nn.Module):
         ops.gpt2_embed_bwd(tokens, dh, dwte, dwpe)  # adds the embedding rows onto the lm_head gradient
         self._drop_wt()  # the optimizer is about to change the parameters
 
+    def take_train_state(self):
+        """The activations `forward_train` saved for `backward`, detached from the module (the autograd node keeps
+        them: several forwards may precede a backward)."""
+        st, self._saved = self._saved, None
+        return st
+
+    def put_train_state(self, st):
+        self._saved = st
+
     def reorder_state(self, state: KVCacheState, new_order):
         """fairseq reorder_incremental_state: row r of the cache becomes old row new_order[r]."""
         if state.k is None:
@@ -368,10 +377,16 @@ class _GPT2TrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, tokens, mask, _tick):
         ctx.model = model
-        return model.forward_train(tokens, mask)
+        out = model.forward_train(tokens, mask)
+        # the saved activations of THIS forward travel with the node: a second forward before the backward
+        # (two losses, gradient accumulation) must not replace them
+        ctx.saved_state = model.take_train_state() if hasattr(model, "take_train_state") else None
+        return out
 
     @staticmethod
     def backward(ctx, dlogits):
+        if ctx.saved_state is not None:
+            ctx.model.put_train_state(ctx.saved_state)
         ctx.model.backward(dlogits.contiguous())
         return None, None, None, None
 
@@ -387,7 +402,7 @@ class _XentIgnoreFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, go):
         logits2d, labels, pair = ctx.saved_tensors
-        return ops.xent_ignore_grad(logits2d, labels, pair, ctx.ignore_index, float(go)), None, None
+        return ops.xent_ignore_grad(logits2d, labels, pair, ctx.ignore_index, go), None, None  # go stays on the device
 
 
 class HuggingFaceGPT2Decoder(nn.Module):

@@ -1041,9 +1041,15 @@ def gpt2_embed_bwd(tokens, dh, dwte, dwpe, pos0=0):
 
 
 def xent_ignore_grad(logits, labels, loss_out, ignore_index, grad_scale=1.0):
+    """grad_scale: a python number, or a 0-dim / 1-element fp32 device tensor (read by the kernel: no host sync)."""
     logits = _f32c(logits)
     rows, v = logits.shape
     dl = torch.empty_like(logits)
+    if torch.is_tensor(grad_scale):
+        gs = grad_scale.reshape(1).to(torch.float32).contiguous()
+        _lib.call("vs_xent_ignore_grad_dev", _ptr(logits), _ptr(labels.contiguous()), _ptr(loss_out), _ptr(dl),
+                  rows, v, v, int(ignore_index), _ptr(gs), _stream())
+        return dl
     _lib.call("vs_xent_ignore_grad", _ptr(logits), _ptr(labels.contiguous()), _ptr(loss_out), _ptr(dl), rows,
               v, v, int(ignore_index), float(grad_scale), _stream())
     return dl
