@@ -51,6 +51,10 @@ typedef enum vs_status {
 #define VS_CONV_SPLITK (1 << 15) /* allow the split-K plan (fp32 slabs + fused reduce/epilogue) */
 #define VS_CONV_NOHALO (1 << 21) /* keep a unit-stride [kT,1,1] / [1,kH,kW] conv on the implicit-GEMM kernel (A/B, tests) */
 #define VS_CONV_FORCEHALO (1 << 22) /* run it on the halo-image kernel whenever the shape is eligible (A/B, tests) */
+#define VS_CONV_NOPW (1 << 23) /* keep a shallow-K pointwise conv on the implicit-GEMM kernel instead of the persistent
+                                  weight-resident kernel (A/B, tests) */
+#define VS_CONV_FORCEPW (1 << 24) /* run it on that kernel whenever the shape is eligible, also where the plan would
+                                     not (one block per CU; A/B, tests) */
 
 /* Geometry of one Conv3d (bias-free, groups 1, dilation 1).
  * Replaces nn.Conv3d reached from vidsitu_code/mdl_sf_base.py:22-33 (s1..s5,

@@ -712,3 +712,105 @@ def test_batched_wgrad_slab_reduce_is_bitwise_the_per_layer_reduce(dev):
             want = ops.conv_wgrad(dya, xa, k, s, p)
             assert torch.equal(out, want)
     assert n_pending >= 2, "expected several split layers in the batch"
+
+
+# name, N, Cin, T, H, W, Cout, stride   (1x1x1, no padding): shapes the persistent pointwise kernel takes
+PW_CASES = [
+    ("s2c_64_256", 2, 64, 8, 56, 56, 256, (1, 1, 1)),
+    ("s3c_128_512", 2, 128, 8, 28, 28, 512, (1, 1, 1)),
+    ("s4c_256_1024", 8, 256, 8, 14, 14, 1024, (1, 1, 1)),
+    ("s5c_512_2048", 8, 512, 8, 7, 7, 2048, (1, 1, 1)),
+    ("s2sc_80_256", 1, 80, 8, 56, 56, 256, (1, 1, 1)),          # K tail: 80 = 64 + 16
+    ("s3sc_320_512_s2", 2, 320, 8, 56, 56, 512, (1, 2, 2)),     # strided rows
+    ("s2a_256_64", 2, 256, 8, 56, 56, 64, (1, 1, 1)),
+    ("s3a_dgradlike_128_320", 1, 128, 8, 28, 28, 320, (1, 1, 1)),  # columns not a multiple of the slice
+    ("ragged_72_200", 3, 72, 5, 13, 11, 200, (1, 1, 1)),         # M % 64 != 0, K % 64 != 0, N % 64 != 0
+    ("ragged_s2_136_72", 8, 136, 4, 15, 17, 72, (1, 2, 2)),
+]
+
+
+@pytest.mark.parametrize("case", PW_CASES, ids=[c[0] for c in PW_CASES])
+def test_persistent_pointwise_kernel_fwd_and_dgrad(case, dev):
+    """conv_pw.hip (1x1x1 convs with K <= 512: weight slice resident in LDS, activation chunks streamed through an
+    LDS-DMA ring across tile boundaries): forward with every epilogue and the unit-stride data gradient with every
+    epilogue, against torch and BITWISE against the implicit-GEMM kernel (VS_CONV_NOPW) -- the two kernels run the
+    same MFMA sequence per accumulator and share the epilogue."""
+    from vidsitu_amd import ops
+
+    name, n, cin, t, h, w, cout, s = case
+    k, p = (1, 1, 1), (0, 0, 0)
+    g = torch.Generator().manual_seed(83)
+    x = rb(torch.randn(n, cin, t, h, w, generator=g))
+    wgt = rb(torch.randn(cout, cin, 1, 1, 1, generator=g) / cin ** 0.5)
+    xa, wa = to_act(x, dev), to_w(wgt, dev)
+    ref = F.conv3d(x, wgt, stride=s)
+    ys = tuple(ref.shape)
+    bits16 = lambda a: a.view(torch.int16)
+    assert _plan(ops, tuple(x.shape), ys, cin, cout, k, s, p, 0, flags=1 << 24)[4] == 3, "forward did not take the pointwise kernel"
+    y, part = ops.conv_fwd(xa, wa, k, s, p, stats=True, pw="force")
+    assert_close(y, ref, TOL, name + " fwd")
+    y0, part0 = ops.conv_fwd(xa, wa, k, s, p, stats=True, pw=False)
+    assert torch.equal(bits16(y), bits16(y0))
+    tot, tot0 = part.double().sum(0).cpu(), part0.double().sum(0).cpu()
+    assert torch.allclose(tot, tot0, rtol=1e-5, atol=1e-5 * float(tot0.abs().max()))
+    assert torch.allclose(tot[0], ref.double().sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=2e-2)
+    # folded BN + masked residual + ReLU into a wider (concat) buffer
+    sc = (torch.rand(cout, generator=g) + 0.5).to(dev)
+    sh = torch.randn(cout, generator=g).to(dev)
+    r = rb(torch.randn(ref.shape, generator=g))
+    ra = to_act(r, dev)
+    outs = []
+    for pw in ("force", False):
+        buf = ops.new_act(ys[0], cout + 16, *ys[2:], dev, zero=True)
+        out = ops.channel_slice(buf, 8, cout)
+        ops.conv_fwd(xa, wa, k, s, p, out=out, scale=sc, shift=sh, residual=ra, relu=True, pw=pw)
+        assert float(buf[:, :8].abs().max()) == 0.0 and float(buf[:, 8 + cout:].abs().max()) == 0.0
+        outs.append(out)
+    want = (ref * sc.cpu().view(1, -1, 1, 1, 1) + sh.cpu().view(1, -1, 1, 1, 1) + r).relu()
+    assert_close(outs[0], want, TOL, name + " fwd epilogue")
+    assert torch.equal(bits16(outs[0].contiguous()), bits16(outs[1].contiguous()))
+    ya, _ = ops.conv_fwd(xa, wa, k, s, p, scale=sc, shift=sh, relu=True, pw="force")
+    yb, _ = ops.conv_fwd(xa, wa, k, s, p, scale=sc, shift=sh, relu=True, pw=False)
+    assert torch.equal(bits16(ya), bits16(yb))
+    if s != (1, 1, 1):
+        return  # the strided data gradient is the transposed-gather kernel's
+    # data gradient (a 1x1x1 conv's dgrad is the same GEMM with the transposed weight): rows = input positions
+    xg = x.clone().requires_grad_()
+    yy = F.conv3d(xg, wgt)
+    dy = rb(torch.randn(yy.shape, generator=g))
+    (dx_ref,) = torch.autograd.grad(yy, xg, dy)
+    wt = ops.weight_transpose(wa)
+    dya = to_act(dy, dev)
+    if cout <= 512:
+        assert _plan(ops, tuple(x.shape), ys, cin, cout, k, s, p, 1, flags=1 << 24)[4] == (3 if cin >= 64 else 0)
+    dx = ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, pw="force")
+    assert_close(dx, dx_ref, TOL, name + " dgrad")
+    assert torch.equal(bits16(dx), bits16(ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, pw=False)))
+    rr = rb(torch.randn(x.shape, generator=g))
+    rra = to_act(rr, dev)
+    rows = ops.act_rows(rra)
+    bits = torch.randint(0, 256, (rows, cin // 8), generator=g, dtype=torch.uint8).to(dev)
+    keep = _unpack_bits(bits, tuple(x.shape))
+    dxm = ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, residual=rra, residual_bits=bits, pw="force")
+    assert_close(dxm, dx_ref + torch.where(keep.cpu(), rr, torch.zeros(())), TOL, name + " dgrad + masked residual")
+    assert torch.equal(bits16(dxm), bits16(ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, residual=rra,
+                                                          residual_bits=bits, pw=False)))
+    # + the BN-backward sums of the unit this dx belongs to
+    bn_y = to_act(rb(torch.randn(x.shape, generator=g)), dev)
+    mean = (torch.randn(cin, generator=g) * 0.2).to(dev)
+    invstd = (torch.rand(cin, generator=g) + 0.5).to(dev)
+    gamma, beta = torch.randn(cin, generator=g).to(dev), (torch.randn(cin, generator=g) * 0.3).to(dev)
+    dxs, psum = ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, bn_stats=(bn_y, mean, invstd, gamma, beta), pw="force")
+    assert psum is not None and torch.equal(bits16(dxs), bits16(dx))
+    v = lambda a: a.view(1, -1, 1, 1, 1)
+    xh = (bn_y.float() - v(mean)) * v(invstd)
+    gm = torch.where(xh * v(gamma) + v(beta) > 0, dx.float(), torch.zeros((), device=dev))
+    want = torch.stack([gm.double().sum((0, 2, 3, 4)), (gm * xh).double().sum((0, 2, 3, 4))]).cpu()
+    assert float((psum.double().sum(0).cpu() - want).abs().max()) / float(want.abs().max()) < 2e-3
+    dxr = ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, residual=rra, pw="force")
+    dxb, psb = ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, residual=rra,
+                              bn_stats=(bn_y, mean, invstd, None, None, bits), pw="force")
+    assert psb is not None and torch.equal(bits16(dxb), bits16(dxr))
+    gm = torch.where(keep, dxr.float(), torch.zeros((), device=dev))
+    want = torch.stack([gm.double().sum((0, 2, 3, 4)), (gm * xh).double().sum((0, 2, 3, 4))]).cpu()
+    assert float((psb.double().sum(0).cpu() - want).abs().max()) / float(want.abs().max()) < 1e-5

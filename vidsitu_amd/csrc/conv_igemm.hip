@@ -608,9 +608,12 @@ __device__ __forceinline__ void fast_divmod(int x, int d, float rcp, int& q, int
   if (r >= d) { r -= d; ++q; }
 }
 
-template <int NT, int KS, int MODE>
+// TB = 16-row tiles a wave keeps in flight: the gathers of all TB tiles are issued before the first MFMA.  One
+// tile per round trip moved 256..1024 unique bytes per wave per memory latency (~1 TB/s over the chip for the
+// 8-channel layers of the fast pathway); see profiles/r02_direct_tb.txt for the sweep.
+template <int NT, int KS, int MODE, int TB>
 __global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p, int tiles_per_wave) {
-  __shared__ __attribute__((aligned(16))) uint16_t tbuf[4][16 * 16 * NT];
+  __shared__ __attribute__((aligned(16))) uint16_t tbuf[4][TB * 16 * 16 * NT];
   __shared__ float sstat[2][4][16 * NT];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 15, lq = lane >> 4;
@@ -669,86 +672,102 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p, int tiles_per
   uint16_t* tb = tbuf[wave];
   const int tile0 = (blockIdx.x * 4 + wave) * tiles_per_wave;
 
-  for (int it = 0; it < tiles_per_wave; ++it) {
-    const int m0 = (tile0 + it) * 16;
-    if (m0 >= p.M) break;
-    const int m = m0 + lr;
-    unsigned roff = VS_OOB, vmask = 0u;
-    if (m < p.M) {
-      int rw, t1, rh, t2, rt, n;
-      fast_divmod(m, p.Rw, rcpW, t1, rw);
-      fast_divmod(t1, p.Rh, rcpH, t2, rh);
-      fast_divmod(t2, p.Rt, rcpT, n, rt);
-      if (MODE == 0) {
-        const long long pos =
-            ((long long)(n * p.Gt + rt * p.mulT) * p.Gh + rh * p.mulH) * p.Gw + rw * p.mulW;
-        roff = (unsigned)(pos * p.g_ld * 2);
-        vmask = 1u;
-      } else {
-        const int ct = rt * p.mulT + p.offT, ch = rh * p.mulH + p.offH, cw = rw * p.mulW + p.offW;
-        long long pos0 = (long long)n * p.Gt * p.Gh * p.Gw;
-        if (MODE == 1) pos0 += ((long long)ct * p.Gh + ch) * p.Gw + cw;
-        else pos0 += ((long long)(ct >> p.shT) * p.Gh + (ch >> p.shH)) * p.Gw + (cw >> p.shW);
-        roff = (unsigned)(pos0 * p.g_ld * 2);
-        auto axis_mask = [&](int c, int kk, int shf, int G) {
-          unsigned mm = 0u;
-          for (int dd = 0; dd < kk; ++dd) {
-            int v = c + p.tmul * dd;
-            bool ok = true;
-            if (MODE == 2) {
-              ok = (v & ((1 << shf) - 1)) == 0;
-              v >>= shf;
+  for (int it = 0; it < tiles_per_wave; it += TB) {
+    if ((tile0 + it) * 16 >= p.M) break;
+    unsigned roff[TB], vmask[TB];
+#pragma unroll
+    for (int u = 0; u < TB; ++u) {
+      const int m = (tile0 + it + u) * 16 + lr;
+      roff[u] = VS_OOB;
+      vmask[u] = 0u;
+      if (m < p.M && it + u < tiles_per_wave) {
+        int rw, t1, rh, t2, rt, n;
+        fast_divmod(m, p.Rw, rcpW, t1, rw);
+        fast_divmod(t1, p.Rh, rcpH, t2, rh);
+        fast_divmod(t2, p.Rt, rcpT, n, rt);
+        if (MODE == 0) {
+          const long long pos =
+              ((long long)(n * p.Gt + rt * p.mulT) * p.Gh + rh * p.mulH) * p.Gw + rw * p.mulW;
+          roff[u] = (unsigned)(pos * p.g_ld * 2);
+          vmask[u] = 1u;
+        } else {
+          const int ct = rt * p.mulT + p.offT, ch = rh * p.mulH + p.offH, cw = rw * p.mulW + p.offW;
+          long long pos0 = (long long)n * p.Gt * p.Gh * p.Gw;
+          if (MODE == 1) pos0 += ((long long)ct * p.Gh + ch) * p.Gw + cw;
+          else pos0 += ((long long)(ct >> p.shT) * p.Gh + (ch >> p.shH)) * p.Gw + (cw >> p.shW);
+          roff[u] = (unsigned)(pos0 * p.g_ld * 2);
+          auto axis_mask = [&](int c, int kk, int shf, int G) {
+            unsigned mm = 0u;
+            for (int dd = 0; dd < kk; ++dd) {
+              int v = c + p.tmul * dd;
+              bool ok = true;
+              if (MODE == 2) {
+                ok = (v & ((1 << shf) - 1)) == 0;
+                v >>= shf;
+              }
+              ok = ok && ((unsigned)v < (unsigned)G);
+              mm |= (ok ? 1u : 0u) << dd;
             }
-            ok = ok && ((unsigned)v < (unsigned)G);
-            mm |= (ok ? 1u : 0u) << dd;
-          }
-          return mm;
-        };
-        const unsigned mt = axis_mask(ct, p.kT, p.shT, p.Gt), mh = axis_mask(ch, p.kH, p.shH, p.Gh),
-                       mw = axis_mask(cw, p.kW, p.shW, p.Gw);
-        int tap = 0;
-        for (int dt = 0; dt < p.kT; ++dt)
-          for (int dh = 0; dh < p.kH; ++dh) {
-            const unsigned th = (mt >> dt) & (mh >> dh) & 1u;
-            vmask |= (th ? mw : 0u) << tap;
-            tap += p.kW;
-          }
+            return mm;
+          };
+          const unsigned mt = axis_mask(ct, p.kT, p.shT, p.Gt), mh = axis_mask(ch, p.kH, p.shH, p.Gh),
+                         mw = axis_mask(cw, p.kW, p.shW, p.Gw);
+          int tap = 0;
+          unsigned vm = 0u;
+          for (int dt = 0; dt < p.kT; ++dt)
+            for (int dh = 0; dh < p.kH; ++dh) {
+              const unsigned th = (mt >> dt) & (mh >> dh) & 1u;
+              vm |= (th ? mw : 0u) << tap;
+              tap += p.kW;
+            }
+          vmask[u] = vm;
+        }
       }
     }
-    f32x4 acc[NT];
+    bf16x8 af[TB][KS];
 #pragma unroll
-    for (int b = 0; b < NT; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < TB; ++u)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const unsigned ok = (vmask >> ktap[ks]) & 1u;
-      const unsigned off = ok ? roff + (unsigned)kdel[ks] : VS_OOB;
-      const bf16x8 af =
-          __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0));
+      for (int ks = 0; ks < KS; ++ks) {
+        const unsigned ok = (vmask[u] >> ktap[ks]) & 1u;
+        const unsigned off = ok ? roff[u] + (unsigned)kdel[ks] : VS_OOB;
+        af[u][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0));
+      }
 #pragma unroll
-      for (int b = 0; b < NT; ++b)
-        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[ks][b], acc[b], 0, 0, 0);
-    }
-    // D[row = lq*4 + r][col = lr]; rows beyond M were zero-filled
+    for (int u = 0; u < TB; ++u) {
+      f32x4 acc[NT];
 #pragma unroll
-    for (int b = 0; b < NT; ++b) {
+      for (int b = 0; b < NT; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float a = acc[b][r];
-        ssum[b] += a;
-        ssq[b] += a * a;
-        float v = a * sc[b] + sh[b];
-        if (relu && !has_res) v = fmaxf(v, 0.f);
-        tb[(lq * 4 + r) * (16 * NT) + b * 16 + lr] = f32_to_bf16(v);
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+          acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][ks], bfr[ks][b], acc[b], 0, 0, 0);
+      // D[row = lq*4 + r][col = lr]; rows beyond M were zero-filled
+#pragma unroll
+      for (int b = 0; b < NT; ++b) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = acc[b][r];
+          ssum[b] += a;
+          ssq[b] += a * a;
+          float v = a * sc[b] + sh[b];
+          if (relu && !has_res) v = fmaxf(v, 0.f);
+          tb[(u * 16 + lq * 4 + r) * (16 * NT) + b * 16 + lr] = f32_to_bf16(v);
+        }
       }
     }
-    // the wave's own 16 x (16*NT) bf16 tile -> 16-byte channel vectors (wave-local LDS hand-off)
+    // the wave's own (TB*16) x (16*NT) bf16 tile -> 16-byte channel vectors (wave-local LDS hand-off)
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's ds_writes have landed
     __builtin_amdgcn_wave_barrier();
     constexpr int CPRW = 2 * NT;  // chunks per row
-    for (int c = lane; c < 16 * CPRW; c += 64) {
+    const int m0 = (tile0 + it) * 16;
+    const int nrows = 16 * min(TB, tiles_per_wave - it);
+#pragma unroll
+    for (int c = lane; c < TB * 16 * CPRW; c += 64) {
       const int row = c / CPRW, c8 = c - row * CPRW;
       const int mm = m0 + row, n = c8 * 8;
-      if (mm < p.M && n < p.Ncols) {
+      if (row < nrows && mm < p.M && n < p.Ncols) {
         uint4 v = *(const uint4*)(tb + row * (16 * NT) + c8 * 8);
         if (has_res) {
           float f[8], g[8];
@@ -766,7 +785,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p, int tiles_per
       }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();  // reads done before the next tile overwrites tb
+    __builtin_amdgcn_wave_barrier();  // reads done before the next batch overwrites tb
   }
   if (p.flags & VS_CONV_STATS) {
 #pragma unroll
@@ -796,17 +815,36 @@ static int direct_blocks(long long M) {
   return (int)((M + 16 * 4 * VS_DIRECT_TPW - 1) / (16 * 4 * VS_DIRECT_TPW));
 }
 
-template <int NT, int KS>
-static int launch_direct_ks(const ConvP& p, int mode, hipStream_t st) {
+template <int NT, int KS, int TB>
+static int launch_direct_tb(const ConvP& p, int mode, hipStream_t st) {
   const int grid = direct_blocks(p.M);
   if (mode == 0)
-    hipLaunchKernelGGL((conv_direct_kernel<NT, KS, 0>), dim3(grid), dim3(256), 0, st, p, VS_DIRECT_TPW);
+    hipLaunchKernelGGL((conv_direct_kernel<NT, KS, 0, TB>), dim3(grid), dim3(256), 0, st, p, VS_DIRECT_TPW);
   else if (mode == 1)
-    hipLaunchKernelGGL((conv_direct_kernel<NT, KS, 1>), dim3(grid), dim3(256), 0, st, p, VS_DIRECT_TPW);
+    hipLaunchKernelGGL((conv_direct_kernel<NT, KS, 1, TB>), dim3(grid), dim3(256), 0, st, p, VS_DIRECT_TPW);
   else
-    hipLaunchKernelGGL((conv_direct_kernel<NT, KS, 2>), dim3(grid), dim3(256), 0, st, p, VS_DIRECT_TPW);
+    hipLaunchKernelGGL((conv_direct_kernel<NT, KS, 2, TB>), dim3(grid), dim3(256), 0, st, p, VS_DIRECT_TPW);
   VS_CHECK_LAUNCH();
   return VS_OK;
+}
+
+// tiles in flight per wave: VS_DIRECT_TB=1|2|4 overrides the rule (A/B runs)
+static int direct_tb(int nt, int ks) {
+  static const int forced = [] {
+    const char* e = getenv("VS_DIRECT_TB");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 1 || forced == 2 || forced == 4) return forced;
+  return (nt * ks <= 6) ? 4 : 2;
+}
+
+template <int NT, int KS>
+static int launch_direct_ks(const ConvP& p, int mode, hipStream_t st) {
+  switch (direct_tb(NT, KS)) {
+    case 1: return launch_direct_tb<NT, KS, 1>(p, mode, st);
+    case 2: return launch_direct_tb<NT, KS, 2>(p, mode, st);
+    default: return launch_direct_tb<NT, KS, 4>(p, mode, st);
+  }
 }
 
 template <int NT>
@@ -1102,6 +1140,12 @@ static int launch_conv(ConvP& p, int mode, int naive, int flags, void* ws, size_
       p.tilesN = hg.tilesN;
       return vs_halo_launch(p, hg, st);
     }
+    PwGeo pg;
+    if (vs_pw_plan(p, mode, flags, &pg)) {  // shallow-K pointwise: persistent weight-resident kernel
+      p.tilesM = pg.tilesM;
+      p.tilesN = pg.nsl;
+      return vs_pw_launch(p, pg, st);
+    }
   }
   const ConvPlan pl = plan_conv(p.M, p.Ncols, p.K, p.kT * p.kH * p.kW, flags);
   if (pl.direct)
@@ -1205,6 +1249,9 @@ extern "C" int vs_conv_stats_rows(const vs_conv_desc* d) {
     HaloGeo hg;
     const int mode = fill_fwd_params(p, d);
     if (!(d->flags & VS_CONV_NAIVE) && vs_halo_plan(p, mode, 0, d->flags, &hg)) return hg.tilesM;
+    PwGeo pg;
+    p.flags |= d->flags & VS_CONV_RESIDUAL;
+    if (vs_pw_plan(p, mode, d->flags, &pg)) return pg.tilesM;
   }
   const long long M = (long long)d->N * d->To * d->Ho * d->Wo;
   const ConvPlan pl = plan_conv(M, d->Cout, d->kT * d->kH * d->kW * d->Cin, d->kT * d->kH * d->kW,
@@ -1226,6 +1273,15 @@ extern "C" int vs_conv_plan(const vs_conv_desc* d, int dgrad, int* out) {
       out[1] = 32 * hg.nrw;
       vs_halo_variant(hg, &out[2], &out[3]);  // weight-ring depth, unrolled taps (0 = generic)
       out[4] = 2;  // halo-image kernel
+      return VS_OK;
+    }
+    PwGeo pg;
+    if (mode >= 0 && vs_pw_plan(p, mode, d->flags, &pg)) {
+      out[0] = 64;
+      out[1] = pg.bn;
+      out[2] = pg.nslot;  // activation ring slots
+      out[3] = 1;
+      out[4] = 3;  // persistent pointwise kernel
       return VS_OK;
     }
   }
@@ -1375,6 +1431,9 @@ extern "C" int vs_conv_dgrad_bnstats_rows(const vs_conv_desc* d) {
   {
     HaloGeo hg;
     if (vs_halo_plan(p, mode, 1, d->flags, &hg)) return hg.tilesM;
+    PwGeo pg;
+    p.flags |= VS_CONV_BNBWD;
+    if (vs_pw_plan(p, mode, d->flags, &pg)) return pg.tilesM;
   }
   const ConvPlan pl = plan_conv(p.M, p.Ncols, p.K, p.kT * p.kH * p.kW, d->flags);
   if (pl.direct || pl.S > 1 || !bnb_tile(pl.tile.bm, pl.tile.bn) || p.kT * p.kH * p.kW > 31) return 0;

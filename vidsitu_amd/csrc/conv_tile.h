@@ -74,7 +74,21 @@ __device__ __forceinline__ uint4 mask8_bf16(uint4 v, unsigned bits) {
 // the BN-backward sums of the unit this dx belongs to.  `rowm(row)` maps a tile row to its output position
 // (or -1).  `smem` is the block's staging area (free once the main loop is done), `statbuf` [2][WM][BN].
 // -----------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool BNB, typename RowMap>
+// RAWSYNC: the barriers between the staging writes and reads order LDS traffic only (lgkmcnt + s_barrier).  A
+// kernel that keeps asynchronous global->LDS copies in flight across the epilogue (conv_pw.hip) asks for it:
+// __syncthreads() also waits vmcnt(0), i.e. one full memory latency for the copies issued a moment ago.
+template <bool RAW>
+__device__ __forceinline__ void tile_sync() {
+  if constexpr (RAW) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  } else {
+    __syncthreads();
+  }
+}
+
+template <int BM, int BN, int WM, int WN, bool BNB, bool RAWSYNC = false, typename RowMap>
 __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16],
                                                    char* smem, float* statbuf, int tm, int n0, RowMap rowm) {
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -133,7 +147,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
           Eh[row * BN + col] = f32_to_bf16(v);
         }
     }
-    __syncthreads();
+    tile_sync<RAWSYNC>();
     if constexpr (BNB) {
       // copy-out + the consumer BN's backward sums: thread = one 8-channel column x (256 / CPR) row
       // lanes; the saved conv outputs of all its rows are requested before the first use
@@ -185,7 +199,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
         red[tid * 16 + e] = sg[e];
         red[tid * 16 + 8 + e] = sx[e];
       }
-      __syncthreads();
+      tile_sync<RAWSYNC>();
       if (tid < BN && n0 + tid < p.Ncols) {  // fixed order over the row lanes
         const int cc = tid >> 3, e = tid & 7;
         float ts = 0.f, tq = 0.f;
@@ -224,7 +238,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
           E[row * BN + col] = acc[a][b][r] * sc + sh;
         }
     }
-    __syncthreads();
+    tile_sync<RAWSYNC>();
     if constexpr (BNB) {
       // residual add + copy-out + the consumer BN's backward sums (ReLU mask from the unit's bit mask):
       // same thread layout as the no-residual variant above
@@ -282,14 +296,14 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
           }
         }
       }
-      __syncthreads();  // every thread is done with the fp32 tile: its space holds the row-lane sums
+      tile_sync<RAWSYNC>();  // every thread is done with the fp32 tile: its space holds the row-lane sums
       float* red = (float*)smem;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         red[tid * 16 + e] = sg[e];
         red[tid * 16 + 8 + e] = sx[e];
       }
-      __syncthreads();
+      tile_sync<RAWSYNC>();
       if (tid < BN && n0 + tid < p.Ncols) {  // fixed order over the row lanes
         const int cc = tid >> 3, e = tid & 7;
         float ts = 0.f, tq = 0.f;
@@ -361,3 +375,21 @@ struct HaloGeo {
 bool vs_halo_plan(const ConvP& p, int mode, int dgrad, int flags, HaloGeo* out);
 int vs_halo_launch(const ConvP& p, const HaloGeo& g, hipStream_t st);
 void vs_halo_variant(const HaloGeo& g, int* depth, int* taps_unrolled);
+
+// ---- persistent pointwise kernel (conv_pw.hip): shallow-K 1x1x1 convs, weight slice resident in LDS ----
+struct PwGeo {
+  int bn;         // columns per weight slice (64 / 128)
+  int nsl;        // weight slices
+  int gx;         // tile lists per XCD
+  int ngroups;    // tile lists (8 * gx): list q walks row tiles q, q + ngroups, ...
+  int tilesM;     // 64-row tiles (= rows of the batch-statistic partials)
+  int nk;         // 64-wide k-chunks
+  int nslot;      // activation ring slots (nslot - 1 chunks in flight)
+  int epi_bytes;  // epilogue staging area
+  int smem;       // dynamic LDS of the launch
+  int dense;      // rows are consecutive positions of the gathered tensor
+  int dbg;        // VS_PW_DBG ablations (wrong results; tools only)
+};
+bool vs_pw_plan(const ConvP& p, int mode, int flags, PwGeo* out);
+int vs_pw_launch(const ConvP& p, const PwGeo& g, hipStream_t st);
+
