@@ -334,7 +334,11 @@ def test_pack_input_layout(dev):
 
 
 @pytest.mark.parametrize("cout,kt,t,h,w", [(64, 1, 2, 32, 32), (8, 5, 6, 32, 32), (64, 1, 1, 36, 44),
-                                           (8, 5, 3, 20, 52), (32, 3, 4, 64, 64)])
+                                           (8, 5, 3, 20, 52), (32, 3, 4, 64, 64),
+                                           # <= 8 channels: two output frames per pass (stem_pair_kernel): frame
+                                           # chunks of 8, odd frame counts, one frame, 3 temporal taps, tile tails
+                                           (8, 5, 17, 40, 44), (8, 5, 1, 32, 32), (8, 3, 9, 24, 70),
+                                           (8, 5, 32, 64, 64)])
 def test_stem_kernel_matches_torch(cout, kt, t, h, w, dev):
     """Dedicated Cin=3 stem kernel (conv_stem.hip): patch-in-LDS implicit GEMM, incl. tile tails,
     temporal padding, fused affine+ReLU and the BN partials."""
@@ -360,7 +364,10 @@ def test_stem_kernel_matches_torch(cout, kt, t, h, w, dev):
 
 
 @pytest.mark.parametrize("cout,kt,t,h,w", [(64, 1, 2, 32, 32), (8, 5, 6, 32, 32), (64, 1, 1, 36, 44),
-                                           (8, 5, 5, 20, 52), (16, 3, 4, 32, 48)])
+                                           (8, 5, 5, 20, 52), (16, 3, 4, 32, 48),
+                                           # <= 8 channels: two output frames per pass (stem_wgrad_pair_kernel)
+                                           (8, 5, 17, 40, 44), (8, 5, 1, 32, 32), (8, 3, 9, 24, 70),
+                                           (8, 5, 32, 64, 64)])
 def test_stem_wgrad_matches_autograd(cout, kt, t, h, w, dev):
     from vidsitu_amd import ops
 

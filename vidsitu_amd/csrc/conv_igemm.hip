@@ -59,9 +59,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int ksplit = swz % p.splitK;  // the splits of one tile are neighbours (same XCD run)
-  const int tile_id = swz / p.splitK;
-  const int tn = tile_id % p.tilesN, tm = tile_id / p.tilesN;
+  // (uniform integer divisions by launch parameters cost ~35 scalar instructions each, 64-bit ones ~100: with
+  //  1..4 k-steps per block the prologue was longer than the main loop -- the common cases take no division)
+  const int ksplit = (p.splitK == 1) ? 0 : swz % p.splitK;  // the splits of one tile are neighbours (same XCD run)
+  const int tile_id = (p.splitK == 1) ? swz : swz / p.splitK;
+  int tn = 0, tm = tile_id;
+  if (p.tilesN == 2) {
+    tn = tile_id & 1;
+    tm = tile_id >> 1;
+  } else if (p.tilesN == 4) {
+    tn = tile_id & 3;
+    tm = tile_id >> 2;
+  } else if (p.tilesN != 1) {
+    tn = tile_id % p.tilesN;
+    tm = tile_id / p.tilesN;
+  }
   const int n0 = tn * BN;
   const int kc = tid & 7, lrow = tid >> 3;
 
@@ -137,6 +149,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   int rT[AI], rH[AI], rW[AI];
   long long rbase[AI];
   unsigned roff[AI], vmask[AI];
+  // row -> (clip, t, h, w): float-reciprocal division (exact below 2^24 rows, two fix-ups) instead of three
+  // ~40-instruction integer divisions per row
+  const bool small_rows = Mloc < (1 << 24);
+  const float rcpW = 1.0f / (float)cW, rcpH = 1.0f / (float)cH, rcpT = 1.0f / (float)cT;
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
     const int m = m0 + lrow + 32 * i;
@@ -146,16 +162,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     vmask[i] = 0u;
     if (MODE == 2 && kc == 0) rowpos[lrow + 32 * i] = -1;
     if (m < Mloc) {
-      int rw = m % cW, t1 = m / cW;
-      int rh = t1 % cH, t2 = t1 / cH;
-      int rt = t2 % cT, n = t2 / cT;
+      int rw, t1, rh, t2, rt, n;
+      if (MODE == 0 && p.dense) {  // rows are consecutive positions of the gathered tensor: nothing to decode
+        rw = m; rh = 0; rt = 0; n = 0;
+      } else if (small_rows) {
+        fast_divmod(m, cW, rcpW, t1, rw);
+        fast_divmod(t1, cH, rcpH, t2, rh);
+        fast_divmod(t2, cT, rcpT, n, rt);
+      } else {
+        rw = m % cW; t1 = m / cW;
+        rh = t1 % cH; t2 = t1 / cH;
+        rt = t2 % cT; n = t2 / cT;
+      }
       rw = r0W + stW * rw;  // (identity unless the tile belongs to a stride class)
       rh = r0H + stH * rh;
       rt = r0T + stT * rt;
       if (MODE == 2 && kc == 0)
         rowpos[lrow + 32 * i] = ((n * p.Rt + rt) * p.Rh + rh) * p.Rw + rw;
       if (MODE == 0) {
-        const long long pos =
+        const long long pos = p.dense ? (long long)m :
             ((long long)(n * p.Gt + rt * p.mulT) * p.Gh + rh * p.mulH) * p.Gw + rw * p.mulW;
         rbase[i] = pos * p.g_ld;
         roff[i] = (unsigned)(pos * p.g_ld * 2);
@@ -379,8 +404,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     return;
   }
   const int nk_all = (Keff + 63) >> 6;
-  const int kbeg = (int)((long long)nk_all * ksplit / p.splitK);
-  const int nk = (int)((long long)nk_all * (ksplit + 1) / p.splitK) - kbeg;  // this block's k-steps
+  int kbeg = 0, nk = nk_all;  // this block's k-steps
+  if (p.splitK != 1) {
+    kbeg = (int)((unsigned)(nk_all * ksplit) / (unsigned)p.splitK);
+    nk = (int)((unsigned)(nk_all * (ksplit + 1)) / (unsigned)p.splitK) - kbeg;
+  }
   __syncthreads();  // ktab visible
   if constexpr (NS > 0) {
     // LDS-DMA ring.  One wave-instruction copies 64 x 16 B = eight 128-byte tile rows straight
@@ -601,13 +629,6 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(
 // buffer_load, each wave streams `tiles_per_wave` consecutive 16-row tiles, and the only
 // LDS use is a 512-byte per-wave transpose so that stores are whole channel vectors.
 // =============================================================================
-__device__ __forceinline__ void fast_divmod(int x, int d, float rcp, int& q, int& r) {
-  q = (int)((float)x * rcp);
-  r = x - q * d;
-  if (r < 0) { r += d; --q; }
-  if (r >= d) { r -= d; ++q; }
-}
-
 // TB = 16-row tiles a wave keeps in flight: the gathers of all TB tiles are issued before the first MFMA.  One
 // tile per round trip moved 256..1024 unique bytes per wave per memory latency (~1 TB/s over the chip for the
 // 8-channel layers of the fast pathway); see profiles/r02_direct_tb.txt for the sweep.
@@ -1240,6 +1261,7 @@ static int fill_fwd_params(ConvP& p, const vs_conv_desc* d) {
   p.tilesM = p.tilesN = 0;
   p.ncls = p.nslots = 0;
   const bool pointwise = (d->kT * d->kH * d->kW == 1) && d->pT == 0 && d->pH == 0 && d->pW == 0;
+  p.dense = (pointwise && d->sT == 1 && d->sH == 1 && d->sW == 1) ? 1 : 0;
   return pointwise ? 0 : 1;
 }
 
@@ -1370,6 +1392,7 @@ static int fill_dgrad_params(ConvP& p, const vs_conv_desc* d) {
   const bool unit_stride = d->sT == 1 && d->sH == 1 && d->sW == 1;
   const bool pointwise =
       unit_stride && (d->kT * d->kH * d->kW == 1) && d->pT == 0 && d->pH == 0 && d->pW == 0;
+  p.dense = pointwise ? 1 : 0;
   return pointwise ? 0 : (unit_stride ? 1 : 2);
 }
 

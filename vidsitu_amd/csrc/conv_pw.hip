@@ -214,16 +214,18 @@ bool vs_pw_plan(const ConvP& p, int mode, int flags, PwGeo* out) {
   const int fixed = g.nk * g.bn * 128 + g.epi_bytes + 2 * 2 * 128 * 4;
   // Measured (profiles/r02_pw_ab.txt): a block's epilogue is ~1 us of serial VALU / LDS work per tile and only a
   // second resident block hides it -- one block per CU loses to the tile kernel at every shape, a deeper ring
-  // buys nothing (3 slots = 5 = 8 at equal occupancy).  So: 3 slots, and the launch is taken only when two
-  // blocks fit a CU, which is K <= 128 (the c / shortcut units of s2, s3 and their a-unit data gradients).
-  // VS_CONV_PW=2 / VS_PW_*: every eligible shape (A/B runs).
+  // buys nothing (3 slots = 5 = 8 at equal occupancy).  After the tile kernel's prologue lost its integer
+  // divisions the launch wins only at K <= 128 with unit stride and >= 128 columns (s2 / s3 c units and the
+  // first shortcut, their a units' data gradients: 33.7 vs 38.2, 39.3 vs 41.2 us); everywhere else the tile
+  // kernel is as fast or faster.  VS_CONV_PW=2 / VS_CONV_FORCEPW / VS_PW_*: every eligible shape (A/B, tests).
   int nslot = 3;
   if (f_ns >= 3 && f_ns <= 8) nslot = f_ns;
   if (f_occ == 1 && f_ns == 0) nslot = 8;
   while (nslot > 3 && fixed + nslot * PW_SLOT > 160 * 1024) --nslot;
   if (fixed + nslot * PW_SLOT > 160 * 1024) return false;
   const int occ = (fixed + nslot * PW_SLOT) * 2 <= 160 * 1024 ? 2 : 1;
-  if (occ < 2 && on != 2 && !(flags & VS_CONV_FORCEPW) && !f_ns && !f_occ && !f_bn) return false;
+  const bool forced = on == 2 || (flags & VS_CONV_FORCEPW) || f_ns || f_occ || f_bn;
+  if (!forced && (occ < 2 || g.nk > 2 || !p.dense || p.Ncols < 128)) return false;
   g.nslot = nslot;
   g.smem = fixed + nslot * PW_SLOT;
   g.nsl = (p.Ncols + g.bn - 1) / g.bn;

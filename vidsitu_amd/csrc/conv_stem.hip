@@ -217,6 +217,209 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemP p) {
   }    // item
 }
 
+// =============================================================================
+// Stem with <= 8 output channels (the fast pathway: 3 -> 8, [5,7,7]).  16 MFMA columns for 8 channels wasted
+// half of every MFMA and every A-fragment read, and the kernel above is LDS-read bound on this shape (3 x 1 KB
+// fragment reads per 2 MFMAs: 134 us of LDS time in a 196 us launch).  Here
+//   * the 16 columns are (frame offset j in {0,1}) x (8 channels): one pass over kT + 1 input frames yields TWO
+//     consecutive output frames (the weight image in LDS holds W[dt] in columns j = 0 and W[dt - 1] in j = 1):
+//     (kT + 1) / (2 kT) of the k-steps;
+//   * a wave owns two output rows whose 7-row windows overlap: 9 A fragments feed 14 MFMAs per input frame;
+//   * tile = 16 x 16 positions, 8 waves; the two input frames the next pair needs are fetched into registers
+//     before this pair's MFMAs and written into the ring slots the pair no longer reads.
+// Batch-statistic partial rows keep the 8 x 16 tile numbering of vs_stem_stats_rows (waves 0-3 / 4-7).
+// =============================================================================
+#define SP_TH 16
+#define SP_PH 37                 // 2*16 + 5 input rows
+#define SP_FRAMEB (SP_PH * ST_ROWB)
+#define SP_TC 8                  // consecutive output frames per work item (4 pairs)
+
+__global__ __launch_bounds__(512) void stem_pair_kernel(StemP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int kT = p.kT, KT1 = kT + 1, pT = kT >> 1;
+  const int K = kT * 7 * 32, K2 = KT1 * 7 * 32;
+  const int wpitch = K2 * 2 + 16;
+  char* wlds = smem;                                                   // [16][wpitch]
+  char* patch = smem + ((16 * wpitch + 15) & ~15);                     // [KT1][37][40] x 8 B
+  float* E = (float*)(patch + ((KT1 * SP_FRAMEB + 15) & ~15));         // [256][16] fp32
+  float* statbuf = E + 256 * 16;                                       // [2][8][16]
+  const int tid = threadIdx.x;
+  {  // pair-packed weight image: column n = j * 8 + co takes W[co][dt' - j]
+    const int cpr = K2 / 8;  // 16-byte chunks per row
+    for (int i = tid; i < 16 * cpr; i += 512) {
+      const int r = i / cpr, c = i - r * cpr;
+      const int ks = c >> 2, sub = c & 3;
+      const int dtp = ks / 7, dh = ks - dtp * 7;
+      const int j = r >> 3, co = r & 7, dt = dtp - j;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (dt >= 0 && dt < kT && co < p.Cout)
+        v = *(const u32x4*)(p.w + (long long)co * K + ((dt * 7 + dh) * 32 + sub * 8));
+      *(u32x4*)(wlds + r * wpitch + c * 16) = v;
+    }
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int tilesH16 = (p.Ho + SP_TH - 1) / SP_TH;
+
+  auto slot_of = [&](int ti) { return ((ti % KT1) + KT1) % KT1; };
+  auto frame_load = [&](int n, int ti, int hi0, int wi0, uint2* v) __attribute__((always_inline)) {
+    const bool tin = (unsigned)ti < (unsigned)p.T;
+    const uint16_t* src = p.x + (((long long)n * p.T + (tin ? ti : 0)) * p.H) * (long long)p.W * 4;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {  // 37 * 40 = 1480 pixels: 3 per thread
+      const int i = tid + u * 512;
+      const int r = i / ST_PW, c = i - r * ST_PW;
+      const int hi = hi0 + r, wi = wi0 + c;
+      v[u] = make_uint2(0u, 0u);
+      if (i < SP_PH * ST_PW && tin && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+        v[u] = *(const uint2*)(src + ((long long)hi * p.W + wi) * 4);
+    }
+  };
+  auto frame_store = [&](int ti, const uint2* v) __attribute__((always_inline)) {
+    char* dst = patch + slot_of(ti) * SP_FRAMEB;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = tid + u * 512;
+      if (i < SP_PH * ST_PW) *(uint2*)(dst + i * 8) = v[u];
+    }
+  };
+
+  for (int item = blockIdx.x; item < p.ntiles; item += gridDim.x) {
+    int t = item;
+    const int tc = t % p.tchunks;
+    t /= p.tchunks;
+    const int tw = t % p.tilesW;
+    t /= p.tilesW;
+    const int th = t % tilesH16;
+    const int n = t / tilesH16;
+    const int ho0 = th * SP_TH, wo0 = tw * ST_TW;
+    const int hi0 = 2 * ho0 - 3, wi0 = 2 * wo0 - 3;
+    const int to_beg = tc * SP_TC, to_end = min(p.T, to_beg + SP_TC);
+    __syncthreads();  // previous item's ring / E are free; the weight image is in place
+    for (int f = 0; f < KT1; ++f) {
+      uint2 v[3];
+      frame_load(n, to_beg - pT + f, hi0, wi0, v);
+      frame_store(to_beg - pT + f, v);
+    }
+    __syncthreads();
+    for (int to0 = to_beg; to0 < to_end; to0 += 2) {
+      const bool more = to0 + 2 < to_end;
+      uint2 nf0[3], nf1[3];
+      if (more) {  // the two frames the next pair adds: in flight during this pair's MFMAs
+        frame_load(n, to0 - pT + KT1, hi0, wi0, nf0);
+        frame_load(n, to0 - pT + KT1 + 1, hi0, wi0, nf1);
+      }
+      f32x4 acc[2];
+      acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      int slot = slot_of(to0 - pT);
+      const char* wrow = wlds + lr * wpitch + lq * 16;
+      for (int dtp = 0; dtp < KT1; ++dtp) {
+        const char* fbase = patch + slot * SP_FRAMEB + (2 * lr + 2 * lq) * 8 + (4 * wave) * ST_ROWB;
+        bf16x8 af[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) af[r] = *(const bf16x8*)(fbase + r * ST_ROWB);
+#pragma unroll
+        for (int dh = 0; dh < 7; ++dh) {
+          const bf16x8 bfr = *(const bf16x8*)(wrow + (dtp * 7 + dh) * 64);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dh], bfr, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dh + 2], bfr, acc[1], 0, 0, 0);
+        }
+        if (++slot == KT1) slot = 0;
+      }
+      // ---- epilogue: D[row = lq*4 + r -> wo_l][col = lr -> (j, co)] ----
+      const int j = lr >> 3, co = lr & 7;
+      const bool fok = to0 + j < p.T && co < p.Cout;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int ho = ho0 + wave * 2 + a;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int wo = wo0 + lq * 4 + r;
+          if (ho >= p.Ho || wo >= p.Wo || !fok) acc[a][r] = 0.f;  // tile tail: keep out of the stats
+        }
+      }
+      if (p.flags & VS_CONV_STATS) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = acc[a][r];
+            s += v;
+            q += v * v;
+          }
+        s += __shfl_xor(s, 16, 64);
+        q += __shfl_xor(q, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        q += __shfl_xor(q, 32, 64);
+        if (lq == 0) {
+          statbuf[wave * 16 + lr] = s;
+          statbuf[8 * 16 + wave * 16 + lr] = q;
+        }
+      }
+      {
+        float sc = 1.f, sh = 0.f;
+        if ((p.flags & VS_CONV_AFFINE) && co < p.Cout) {
+          sc = p.scale[co];
+          sh = p.shift[co];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) E[((wave * 2 + a) * 16 + lq * 4 + r) * 16 + lr] = acc[a][r] * sc + sh;
+      }
+      __syncthreads();
+      if ((p.flags & VS_CONV_STATS) && tid < 32) {
+        const int h = tid >> 4, col = tid & 15, jj = col >> 3, cc = col & 7;
+        const int th8 = 2 * th + h;
+        if (cc < p.Cout && to0 + jj < p.T && th8 < p.tilesH) {
+          float s = 0.f, q = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            s += statbuf[(4 * h + w) * 16 + col];
+            q += statbuf[8 * 16 + (4 * h + w) * 16 + col];
+          }
+          const int tile = ((n * p.T + to0 + jj) * p.tilesH + th8) * p.tilesW + tw;  // stats row
+          float* dst = p.stats + (long long)tile * 2 * p.Cout;
+          dst[cc] = s;
+          dst[p.Cout + cc] = q;
+        }
+      }
+      {  // one 16-byte channel vector per (position, frame)
+        const int row = tid >> 1, jj = tid & 1;
+        const int ho = ho0 + (row >> 4), wo = wo0 + (row & 15);
+        if (ho < p.Ho && wo < p.Wo && to0 + jj < p.T) {
+          float v[8];
+          const float4 v0 = *(const float4*)(E + row * 16 + jj * 8);
+          const float4 v1 = *(const float4*)(E + row * 16 + jj * 8 + 4);
+          v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
+          v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+          if (p.flags & VS_CONV_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          const long long pos = (((long long)n * p.T + to0 + jj) * p.Ho + ho) * p.Wo + wo;
+          *(uint4*)(p.y + pos * p.y_ld) = pack8_bf16(v);
+        }
+      }
+      __syncthreads();  // every wave is done with the ring slots of the pair's two oldest frames, and with E
+      if (more) {
+        frame_store(to0 - pT + KT1, nf0);
+        frame_store(to0 - pT + KT1 + 1, nf1);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+static size_t stem_pair_smem(int kT) {
+  const int K2 = (kT + 1) * 7 * 32;
+  const size_t w = ((size_t)16 * (K2 * 2 + 16) + 15) & ~(size_t)15;
+  const size_t patch = ((size_t)(kT + 1) * SP_FRAMEB + 15) & ~(size_t)15;
+  return w + patch + (size_t)256 * 16 * 4 + (size_t)2 * 8 * 16 * 4;
+}
+
 static size_t stem_smem(int CP, int kT) {
   const int K = kT * 7 * 32;
   const size_t w = ((size_t)CP * (K * 2 + 16) + 15) & ~(size_t)15;
@@ -254,9 +457,23 @@ extern "C" int vs_stem_conv_fwd(const void* x4, const void* wp, void* y, int N, 
   p.tchunks = (T + ST_TC - 1) / ST_TC;
   p.ntiles = N * p.tilesH * p.tilesW * p.tchunks;
   const int CP = (Cout + 15) / 16 * 16;
+  hipStream_t st = (hipStream_t)stream;
+  static const int pair_on = [] { const char* e = getenv("VS_STEM_PAIR"); return e ? atoi(e) : 1; }();
+  if (pair_on && Cout == 8 && kT >= 3 && T >= 2) {  // two output frames per pass (fast-pathway stem)
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute((const void*)stem_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_done = true;
+    }
+    p.tchunks = (T + SP_TC - 1) / SP_TC;
+    p.ntiles = N * ((p.Ho + SP_TH - 1) / SP_TH) * p.tilesW * p.tchunks;
+    const int grid2 = p.ntiles < 256 ? p.ntiles : 256;  // one persistent 8-wave block per CU
+    hipLaunchKernelGGL(stem_pair_kernel, dim3(grid2), dim3(512), stem_pair_smem(kT), st, p);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+  }
   const size_t smem = stem_smem(CP, kT);
   int grid = p.ntiles < 512 ? p.ntiles : 512;  // 2 persistent blocks per CU
-  hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_STEM(NT_)                                                                         \
   do {                                                                                           \
     static bool attr_done = false;                                                               \
@@ -428,6 +645,139 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgP p) {
     }
 }
 
+// Weight gradient of a stem with <= 8 output channels: the pair packing of stem_pair_kernel applied to dW.  The 16
+// MFMA rows are (frame offset j) x (8 channels): the dY image holds output frames t0 and t0 + 1 side by side, one
+// pass over the kT + 1 input frames of the pair feeds (kT + 1) * 14 n-tiles, and the accumulator of n-tile
+// (dt', dh, half) carries dW[.][dt'] in rows j = 0 and dW[.][dt' - 1] in rows j = 1 -- written to two slabs per
+// block, summed by the fixed-order slab reduce.  The next pair's two input frames and its dY image are fetched
+// into registers before this pair's MFMAs (the kernel above waits out one memory latency per output frame).
+template <int KT>
+__global__ __launch_bounds__(256) void stem_wgrad_pair_kernel(StemWgP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KT1 = KT + 1, pT = KT >> 1;
+  constexpr int NTN = KT1 * 14, NTW = (NTN + 3) / 4;
+  char* patch = smem;                                           // [KT1][21][40] x 8 B
+  char* dyl = smem + ((KT1 * ST_FRAMEB + 15) & ~15);            // [128 pos][(j, co)] bf16
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, p4 = li & 3;
+
+  f32x4 acc[NTW];
+#pragma unroll
+  for (int b = 0; b < NTW; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto slot_of = [](int ti) { return ((ti % KT1) + KT1) % KT1; };
+  auto frame_load = [&](int n, int ti, int hi0, int wi0, uint2* v) __attribute__((always_inline)) {
+    const bool tin = (unsigned)ti < (unsigned)p.T;
+    const uint16_t* src = p.x + (((long long)n * p.T + (tin ? ti : 0)) * p.H) * (long long)p.W * 4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + u * 256;
+      const int r = i / ST_PW, c = i - r * ST_PW;
+      const int hi = hi0 + r, wi = wi0 + c;
+      v[u] = make_uint2(0u, 0u);
+      if (i < ST_PH * ST_PW && tin && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+        v[u] = *(const uint2*)(src + ((long long)hi * p.W + wi) * 4);
+    }
+  };
+  auto frame_store = [&](int ti, const uint2* v) __attribute__((always_inline)) {
+    char* dst = patch + slot_of(ti) * ST_FRAMEB;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + u * 256;
+      if (i < ST_PH * ST_PW) *(uint2*)(dst + i * 8) = v[u];
+    }
+  };
+  // thread -> (position, frame of the pair): 8 channels = 16 bytes of dY (zeros outside the image / the clip)
+  auto dy_load = [&](int n, int to0, int ho0, int wo0) __attribute__((always_inline)) {
+    const int jj = tid & 1, pos = tid >> 1;
+    const int ho = ho0 + (pos >> 4), wo = wo0 + (pos & 15);
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (ho < p.Ho && wo < p.Wo && to0 + jj < p.T)
+      v = *(const u32x4*)(p.dy + ((((long long)n * p.T + to0 + jj) * p.Ho + ho) * p.Wo + wo) * p.dy_ld);
+    return v;
+  };
+  auto dy_store = [&](const u32x4& v) __attribute__((always_inline)) {
+    *(u32x4*)(dyl + (tid >> 1) * 32 + (tid & 1) * 16) = v;
+  };
+
+  for (int item = blockIdx.x; item < p.nitems; item += gridDim.x) {
+    int t = item;
+    const int tc = t % p.tchunks;
+    t /= p.tchunks;
+    const int tw = t % p.tilesW;
+    t /= p.tilesW;
+    const int th = t % p.tilesH;
+    const int n = t / p.tilesH;
+    const int ho0 = th * ST_TH, wo0 = tw * ST_TW;
+    const int hi0 = 2 * ho0 - 3, wi0 = 2 * wo0 - 3;
+    const int to_beg = tc * SP_TC, to_end = min(p.T, to_beg + SP_TC);
+    __syncthreads();  // the previous item's readers are done
+    for (int f = 0; f < KT1; ++f) {
+      uint2 v[4];
+      frame_load(n, to_beg - pT + f, hi0, wi0, v);
+      frame_store(to_beg - pT + f, v);
+    }
+    dy_store(dy_load(n, to_beg, ho0, wo0));
+    __syncthreads();
+    for (int to0 = to_beg; to0 < to_end; to0 += 2) {
+      const bool more = to0 + 2 < to_end;
+      uint2 nf0[4], nf1[4];
+      u32x4 ndy = {0u, 0u, 0u, 0u};
+      if (more) {
+        frame_load(n, to0 - pT + KT1, hi0, wi0, nf0);
+        frame_load(n, to0 - pT + KT1 + 1, hi0, wi0, nf1);
+        ndy = dy_load(n, to0 + 2, ho0, wo0);
+      }
+      const int slot0 = slot_of(to0 - pT);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int k = ks * 32 + 8 * g + q;  // this lane supplies position k (and k + 4)
+        const char* aptr = dyl + k * 32 + p4 * 8;
+        const bf16x8 af = st_tr_pair(aptr, aptr + 4 * 32);
+        const char* bbase = patch + (2 * (k >> 4)) * ST_ROWB + (2 * (k & 15)) * 8 + p4 * 8;
+#pragma unroll
+        for (int b = 0; b < NTW; ++b) {
+          const int nt = wave + 4 * b;  // wave-uniform
+          if (nt < NTN) {
+            const int half = nt & 1, row = nt >> 1;
+            const int dtp = row / 7, dh = row - dtp * 7;
+            int sl = slot0 + dtp;
+            if (sl >= KT1) sl -= KT1;
+            const char* ptr = bbase + sl * ST_FRAMEB + dh * ST_ROWB + half * 32;
+            const bf16x8 bf = st_tr_pair(ptr, ptr + 4 * 16);  // +4 positions = +64 bytes
+            acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[b], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();  // the pair's two oldest frames and the dY image are free
+      if (more) {
+        frame_store(to0 - pT + KT1, nf0);
+        frame_store(to0 - pT + KT1 + 1, nf1);
+        dy_store(ndy);
+      }
+      __syncthreads();
+    }
+  }
+  // D[row = g*4 + r -> (j, co)][col = li]: rows j of n-tile (dt', dh, half) are dW[co][dt' - j][dh][half*16 + li]
+  const int Kpad = KT * 7 * 32;
+#pragma unroll
+  for (int b = 0; b < NTW; ++b) {
+    const int nt = wave + 4 * b;
+    if (nt < NTN) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = g * 4 + r, j = m >> 3, co = m & 7;
+        const int ntd = nt - 14 * j;  // the n-tile of (dt' - j, dh, half)
+        if (ntd >= 0 && ntd < KT * 14 && co < p.Cout) {
+          float* dst = p.slabs + ((long long)blockIdx.x * 2 + j) * p.Cout * Kpad;
+          dst[(long long)co * Kpad + ntd * 16 + li] = acc[b][r];
+        }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void stem_slab_reduce_kernel(const float* slabs, float* dw,
                                                               long long n, int S) {
   __shared__ float4 part[16][17];
@@ -457,10 +807,17 @@ __global__ __launch_bounds__(256) void stem_slab_reduce_kernel(const float* slab
 
 static int stem_wg_grid(int nitems) { return nitems < 512 ? nitems : 512; }
 
+static bool stem_wg_pair(int T, int Cout, int kT) {
+  static const int on = [] { const char* e = getenv("VS_STEM_PAIR"); return e ? atoi(e) : 1; }();
+  return on && Cout == 8 && (kT == 3 || kT == 5) && T >= 2;
+}
+
 extern "C" size_t vs_stem_wgrad_workspace_bytes(int N, int T, int H, int W, int Cout, int kT) {
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
-  const int nitems = N * ((Ho + ST_TH - 1) / ST_TH) * ((Wo + ST_TW - 1) / ST_TW) * ((T + ST_TC - 1) / ST_TC);
-  return (size_t)stem_wg_grid(nitems) * Cout * kT * 7 * 32 * sizeof(float);
+  const bool pair = stem_wg_pair(T, Cout, kT);
+  const int tc = pair ? SP_TC : ST_TC;
+  const int nitems = N * ((Ho + ST_TH - 1) / ST_TH) * ((Wo + ST_TW - 1) / ST_TW) * ((T + tc - 1) / tc);
+  return (size_t)stem_wg_grid(nitems) * (pair ? 2 : 1) * Cout * kT * 7 * 32 * sizeof(float);
 }
 
 extern "C" int vs_stem_conv_wgrad(const void* dy, const void* x4, float* dwp, int N, int T, int H,
@@ -487,8 +844,22 @@ extern "C" int vs_stem_conv_wgrad(const void* dy, const void* x4, float* dwp, in
     return VS_ERR_WORKSPACE;
   }
   const int MTv = (Cout + 15) / 16;
-  const size_t smem = (((size_t)kT * ST_FRAMEB + 15) & ~(size_t)15) + (size_t)MTv * 128 * 32;
   hipStream_t st = (hipStream_t)stream;
+  if (stem_wg_pair(T, Cout, kT)) {  // two output frames per pass (fast-pathway stem)
+    p.tchunks = (T + SP_TC - 1) / SP_TC;
+    p.nitems = N * p.tilesH * p.tilesW * p.tchunks;
+    const int grid2 = stem_wg_grid(p.nitems);
+    const size_t smem2 = (((size_t)(kT + 1) * ST_FRAMEB + 15) & ~(size_t)15) + (size_t)128 * 32;
+    if (kT == 5) hipLaunchKernelGGL(stem_wgrad_pair_kernel<5>, dim3(grid2), dim3(256), smem2, st, p);
+    else hipLaunchKernelGGL(stem_wgrad_pair_kernel<3>, dim3(grid2), dim3(256), smem2, st, p);
+    VS_CHECK_LAUNCH();
+    const long long n2 = (long long)Cout * kT * 7 * 32;
+    hipLaunchKernelGGL(stem_slab_reduce_kernel, dim3((unsigned)((n2 / 4 + 15) / 16)), dim3(256), 0, st,
+                       (const float*)workspace, dwp, n2, 2 * grid2);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+  }
+  const size_t smem = (((size_t)kT * ST_FRAMEB + 15) & ~(size_t)15) + (size_t)MTv * 128 * 32;
   const int ntw = (kT * 14 + 3) / 4;  // 4 (kT=1), 11 (kT=3), 18 (kT=5)
 #define LAUNCH_SWG(MT_, NTW_)                                                                    \
   hipLaunchKernelGGL((stem_wgrad_kernel<MT_, NTW_>), dim3(grid), dim3(256), smem, st, p)

@@ -50,10 +50,19 @@ struct ConvP {
   // unit it belongs to (bits [rows][Ncols/8]); the epilogue adds dz where the bit is set.  Spares the
   // BN-backward apply kernel of a bottleneck's last unit the write of its masked copy of dz (`dres`).
   const uint8_t* res_bits;
+  int dense;  // pointwise, unit stride: row m is position m of the gathered tensor (no row decode)
 };
 #define VS_CONV_BNBWD (1 << 20)
 
 #define VS_OOB 0x80000000u  // byte offset beyond any tensor: buffer_load returns zeros
+
+// x = q * d + r for 0 <= x < 2^24, rcp = 1.0f / d (float quotient, two fix-ups)
+__device__ __forceinline__ void fast_divmod(int x, int d, float rcp, int& q, int& r) {
+  q = (int)((float)x * rcp);
+  r = x - q * d;
+  if (r < 0) { r += d; --q; }
+  if (r >= d) { r -= d; ++q; }
+}
 
 __device__ __forceinline__ void mask8(float* f, unsigned bits) {
 #pragma unroll
@@ -129,6 +138,18 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
     //      whole 16-byte channel vectors are copied out (no unpack / repack pass).
     uint16_t* Eh = (uint16_t*)smem;
     const bool relu = (p.flags & VS_CONV_RELU) != 0;
+    if (!(p.flags & (VS_CONV_AFFINE | VS_CONV_RELU))) {
+      // raw outputs (every training-mode launch): no multiply-add, no clamp -- with 1..4 k-steps per tile the
+      // epilogue's instruction count is a first-order cost
+#pragma unroll
+      for (int b = 0; b < NR; ++b) {
+        const int col = wn * TN + b * 16 + lr;
+#pragma unroll
+        for (int a = 0; a < MR; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Eh[(wm * TM + a * 16 + lq * 4 + r) * BN + col] = f32_to_bf16(acc[a][b][r]);
+      }
+    } else {
 #pragma unroll
     for (int b = 0; b < NR; ++b) {
       const int col = wn * TN + b * 16 + lr;
@@ -146,6 +167,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
           if (relu) v = fmaxf(v, 0.f);
           Eh[row * BN + col] = f32_to_bf16(v);
         }
+    }
     }
     tile_sync<RAWSYNC>();
     if constexpr (BNB) {

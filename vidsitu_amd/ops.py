@@ -465,6 +465,7 @@ def conv_wgrad(dy, x, k, s, p, out=None, ring=0, batch=None, tile=None, slots=0)
 # batch norm
 # ----------------------------------------------------------------------------
 import os as _os
+_WHATIF = int(_os.environ.get("VS_WHATIF", "0"))  # tools only: skip launches to measure what they cost on the step
 _BN_TWO_LEVEL = int(_os.environ.get("VS_BN_TWO_LEVEL", "512"))  # partial rows above which a level-1 reduce runs first
 
 
@@ -476,6 +477,8 @@ def bn_finalize(partials, count, gamma, beta, running_mean, running_var, momentu
     mean = torch.empty(c, dtype=torch.float32, device=dev)
     invstd = torch.empty(c, dtype=torch.float32, device=dev)
     nparts = partials.shape[0] if train else 0
+    if train and _WHATIF & 1:  # timing experiment only (garbage statistics)
+        return scale.zero_().add_(1.0), shift.zero_(), mean.zero_(), invstd.zero_().add_(1.0)
     if train and nparts > _BN_TWO_LEVEL:  # two-level reduction keeps the finalize launch short
         lvl1 = torch.empty((32, 2, c), dtype=torch.float32, device=dev)
         _lib.call("vs_bn_partials_reduce", _ptr(partials), nparts, _ptr(lvl1), c, 32, _stream())
@@ -533,7 +536,8 @@ def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres, dy_out=None, dgamma=N
         dgamma = torch.empty(c, dtype=torch.float32, device=dev)
     if dbeta is None:
         dbeta = torch.empty(c, dtype=torch.float32, device=dev)
-    _lib.call("vs_bn_bwd_finalize", _ptr(partial), nblk, _ptr(dgamma), _ptr(dbeta), c, _stream())
+    if not (_WHATIF & 2):
+        _lib.call("vs_bn_bwd_finalize", _ptr(partial), nblk, _ptr(dgamma), _ptr(dbeta), c, _stream())
     dy = new_act(*y.shape, device=dev) if dy_out is None else dy_out
     dres = new_act(*y.shape, device=dev) if want_dres else None
     _lib.call("vs_bn_bwd_apply", _ptr(dz), _ptr(zz), _ptr(y), _ptr(mean), _ptr(invstd),
