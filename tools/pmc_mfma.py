@@ -11,7 +11,8 @@ import collections, csv, glob, json, sys
 
 out_dir, build = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "")
 plan = json.load(open(f"{out_dir}/plan.json"))
-KEEP = ("conv_igemm_kernel", "conv_wgrad_ring_kernel", "conv_wgrad_kernel", "conv_direct_kernel", "conv_halo_kernel")
+KEEP = ("conv_igemm_kernel", "conv_wgrad_ring_kernel", "conv_wgrad_kernel", "conv_direct_kernel", "conv_halo_kernel",
+        "conv_pw_kernel")
 
 
 def rows_of(sub):

@@ -1,0 +1,37 @@
+"""Timeline statistics of one replayed step from a rocprofv3 --kernel-trace CSV: wall span, summed kernel time, busy
+time (>= 1 kernel running), overlapped time (>= 2), idle gaps, and the kernels that follow the longest gaps.
+usage: python tools/trace_overlap.py kernel_trace.csv [n_last_kernels_per_step]"""
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+ks = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows), key=lambda x: x[0])
+# steps are separated by the largest idle gaps (host sync between replays): split at gaps > 200 us
+steps, cur = [], [ks[0]]
+for a, b in zip(ks, ks[1:]):
+    if b[0] - max(x[1] for x in cur[-8:]) > 200_000:
+        steps.append(cur); cur = []
+    cur.append(b)
+steps.append(cur)
+big = [s for s in steps if len(s) > 50]
+print(f"{len(ks)} dispatches, {len(steps)} bursts, {len(big)} with > 50 kernels")
+for s in big[-3:]:
+    t0, t1 = s[0][0], max(x[1] for x in s)
+    ev = []
+    for a, b, _ in s:
+        ev.append((a, 1)); ev.append((b, -1))
+    ev.sort()
+    busy = over = 0; depth = 0; last = t0
+    for t, d in ev:
+        if depth >= 1: busy += t - last
+        if depth >= 2: over += t - last
+        depth += d; last = t
+    tot = sum(b - a for a, b, _ in s)
+    print(f"step: {len(s)} kernels, span {(t1 - t0) / 1e3:.1f} us, sum {tot / 1e3:.1f} us, busy {busy / 1e3:.1f} us, "
+          f"overlapped {over / 1e3:.1f} us, idle {(t1 - t0 - busy) / 1e3:.1f} us")
+s = big[-1]
+agg = collections.defaultdict(lambda: [0, 0])
+for a, b, n in s:
+    k = n.split("(")[0][:70]
+    agg[k][0] += b - a; agg[k][1] += 1
+print("top kernels by in-situ time (last step):")
+for k, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:25]:
+    print(f"  {t / 1e3:8.1f} us {c:4d} x {t / c / 1e3:7.1f}  {k}")
