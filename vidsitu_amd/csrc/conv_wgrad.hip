@@ -604,6 +604,11 @@ static WgCfg wg_pick(const vs_conv_desc* d) {
   const long long P = (long long)d->N * d->To * d->Ho * d->Wo;
   c.bm = d->Cout >= 128 ? 128 : (d->Cout >= 64 ? 64 : (d->Cout >= 32 ? 32 : 16));
   c.bn = Kp >= 128 ? 128 : 64;
+  // <= 16 output channels (fast pathway s2 / s3): a 128-column tile as soon as Kp > 64 -- 72 or 96 columns as 64 + a
+  // nearly empty second tile doubled the blocks that re-read dY; 32 channels: 64 columns (tools/wgrad_small_sweep.py,
+  // profiles/r02_wgrad_small_sweep.txt: s2.p1.b 41.6 -> 27.1 us, s2.p1.a 45.7 -> 29.4, s4.p1.a 15.3 -> 13.7)
+  if (d->Cout <= 16) c.bn = Kp > 64 ? 128 : 64;
+  else if (d->Cout <= 32) c.bn = 64;
   // (Tried: for the few-position layers of slow s5 -- 3 136 positions, 2-12 MB of dW -- output tiles small enough to
   // fill the chip with no position split at all (64 x 128 / 64 x 64, no slabs, no reduce): slower, 52 vs 43-48 us
   // on s5.b, 29.6 vs 23 us on s5.c -- tools/wgrad_sweep.py, profiles/r02_wgrad_sweep.txt.)
@@ -622,22 +627,22 @@ static WgCfg wg_pick(const vs_conv_desc* d) {
   // is faster for the whole step (A/B on one box: 512 slots 14.18-14.27 ms, 384: 14.10-14.12,
   // 256: 14.07-14.14, 192: 14.13-14.22, 128: 14.46-14.54) and writes fewer slabs; 384 keeps most of the
   // stand-alone speed (256 costs the kernel alone 13 %).
-  // Skinny outputs (fast pathway, stems: a handful of tiles, 10^5..10^6 positions) are
-  // latency bound per 64-position step, so they get up to 2048 blocks.
+  // Skinny outputs (fast pathway: a handful of tiles, 10^5..10^6 positions) get one residency round too: 512
+  // blocks (2048, several rounds of short blocks, was 25-50 % slower; 256 / 384 / 768 slower as well).
   static const long long slots = [] {
     const char* e = getenv("VS_WGRAD_SLOTS");  // experiment knob: resident block slots to fill
     return e ? atoll(e) : 384ll;
   }();
   static const long long small_slots = [] {
     const char* e = getenv("VS_WGRAD_SLOTS_SMALL");
-    return e ? atoll(e) : 2048ll;
+    return e ? atoll(e) : 512ll;
   }();
   long long target = (d->Cout <= 32) ? small_slots : slots;
   const int forced_slots = (d->flags >> 24) & 0xff;  // experiments: resident block slots / 8 in bits 24..31
   if (forced_slots) target = 8ll * forced_slots;
   // Round the split DOWN so that the grid fits one residency round (two blocks are resident per CU,
   // 80 KB of LDS each) -- 528 blocks on 512 slots run as two rounds (s4.a: +45 %)
-  long long S = (d->Cout <= 32) ? (target + tiles - 1) / tiles : target / tiles;
+  long long S = target / tiles;
   const long long maxS = (P + 511) / 512;
   if (S > maxS) S = maxS;
   const long long slab_cap = (64ll << 20) / ((long long)d->Cout * Kp * 4);  // <= 64 MB of slabs
