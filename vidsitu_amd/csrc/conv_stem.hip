@@ -413,6 +413,183 @@ __global__ __launch_bounds__(512) void stem_pair_kernel(StemP p) {
   }
 }
 
+// The same pair packing with the WEIGHTS IN REGISTERS: a lane's B fragments of all (kT + 1) * 7 k-steps (16 bytes
+// each, 168 VGPRs for kT = 5) are loaded once per persistent block, so the only LDS reads of the main loop are the
+// 9 A rows per input frame (54 per pair instead of 96) and the LDS holds nothing but the frame ring (40 KB): two
+// 4-wave blocks per CU, tile 8 x 16.  VS_STEM_PAIR=2 selects stem_pair_kernel (weights in LDS) for A/B runs.
+template <int KT>
+__global__ __launch_bounds__(256) void stem_pair_reg_kernel(StemP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KT1 = KT + 1, pT = KT >> 1, NKS = KT1 * 7;
+  constexpr int K = KT * 7 * 32;
+  char* patch = smem;                                                  // [KT1][21][40] x 8 B
+  float* E = (float*)(patch + ((KT1 * ST_FRAMEB + 15) & ~15));         // [128][16] fp32
+  float* statbuf = E + 128 * 16;                                       // [2][4][16]
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int j = lr >> 3, co = lr & 7;
+
+  bf16x8 bfr[NKS];  // column lr = (j, co): W[co][dt' - j][dh][lq*8 .. +8]
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int dtp = ks / 7, dh = ks - dtp * 7;
+    const int dt = dtp - j;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (dt >= 0 && dt < KT && co < p.Cout)
+      v = *(const u32x4*)(p.w + (long long)co * K + ((dt * 7 + dh) * 32 + lq * 8));
+    bfr[ks] = __builtin_bit_cast(bf16x8, v);
+  }
+
+  auto slot_of = [](int ti) { return ((ti % KT1) + KT1) % KT1; };
+  auto frame_load = [&](int n, int ti, int hi0, int wi0, uint2* v) __attribute__((always_inline)) {
+    const bool tin = (unsigned)ti < (unsigned)p.T;
+    const uint16_t* src = p.x + (((long long)n * p.T + (tin ? ti : 0)) * p.H) * (long long)p.W * 4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // 21 * 40 = 840 pixels: 4 per thread
+      const int i = tid + u * 256;
+      const int r = i / ST_PW, c = i - r * ST_PW;
+      const int hi = hi0 + r, wi = wi0 + c;
+      v[u] = make_uint2(0u, 0u);
+      if (i < ST_PH * ST_PW && tin && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+        v[u] = *(const uint2*)(src + ((long long)hi * p.W + wi) * 4);
+    }
+  };
+  auto frame_store = [&](int ti, const uint2* v) __attribute__((always_inline)) {
+    char* dst = patch + slot_of(ti) * ST_FRAMEB;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + u * 256;
+      if (i < ST_PH * ST_PW) *(uint2*)(dst + i * 8) = v[u];
+    }
+  };
+
+  for (int item = blockIdx.x; item < p.ntiles; item += gridDim.x) {
+    int t = item;
+    const int tc = t % p.tchunks;
+    t /= p.tchunks;
+    const int tw = t % p.tilesW;
+    t /= p.tilesW;
+    const int th = t % p.tilesH;
+    const int n = t / p.tilesH;
+    const int ho0 = th * ST_TH, wo0 = tw * ST_TW;
+    const int hi0 = 2 * ho0 - 3, wi0 = 2 * wo0 - 3;
+    const int to_beg = tc * SP_TC, to_end = min(p.T, to_beg + SP_TC);
+    __syncthreads();  // previous item's ring / E are free
+    for (int f = 0; f < KT1; ++f) {
+      uint2 v[4];
+      frame_load(n, to_beg - pT + f, hi0, wi0, v);
+      frame_store(to_beg - pT + f, v);
+    }
+    __syncthreads();
+    for (int to0 = to_beg; to0 < to_end; to0 += 2) {
+      const bool more = to0 + 2 < to_end;
+      uint2 nf0[4], nf1[4];
+      if (more) {  // the two frames the next pair adds: in flight during this pair's MFMAs
+        frame_load(n, to0 - pT + KT1, hi0, wi0, nf0);
+        frame_load(n, to0 - pT + KT1 + 1, hi0, wi0, nf1);
+      }
+      f32x4 acc[2];
+      acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      int slot = slot_of(to0 - pT);
+#pragma unroll
+      for (int dtp = 0; dtp < KT1; ++dtp) {
+        const char* fbase = patch + slot * ST_FRAMEB + (2 * lr + 2 * lq) * 8 + (4 * wave) * ST_ROWB;
+        bf16x8 af[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) af[r] = *(const bf16x8*)(fbase + r * ST_ROWB);
+#pragma unroll
+        for (int dh = 0; dh < 7; ++dh) {
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dh], bfr[dtp * 7 + dh], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[dh + 2], bfr[dtp * 7 + dh], acc[1], 0, 0, 0);
+        }
+        if (++slot == KT1) slot = 0;
+      }
+      // ---- epilogue: D[row = lq*4 + r -> wo_l][col = lr -> (j, co)] ----
+      const bool fok = to0 + j < p.T && co < p.Cout;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int ho = ho0 + wave * 2 + a;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int wo = wo0 + lq * 4 + r;
+          if (ho >= p.Ho || wo >= p.Wo || !fok) acc[a][r] = 0.f;  // tile tail: keep out of the stats
+        }
+      }
+      if (p.flags & VS_CONV_STATS) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = acc[a][r];
+            s += v;
+            q += v * v;
+          }
+        s += __shfl_xor(s, 16, 64);
+        q += __shfl_xor(q, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        q += __shfl_xor(q, 32, 64);
+        if (lq == 0) {
+          statbuf[wave * 16 + lr] = s;
+          statbuf[4 * 16 + wave * 16 + lr] = q;
+        }
+      }
+      {
+        float sc = 1.f, sh = 0.f;
+        if ((p.flags & VS_CONV_AFFINE) && co < p.Cout) {
+          sc = p.scale[co];
+          sh = p.shift[co];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) E[((wave * 2 + a) * 16 + lq * 4 + r) * 16 + lr] = acc[a][r] * sc + sh;
+      }
+      __syncthreads();
+      if ((p.flags & VS_CONV_STATS) && tid < 16) {
+        const int jj = tid >> 3, cc = tid & 7;
+        if (cc < p.Cout && to0 + jj < p.T) {
+          float s = 0.f, q = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            s += statbuf[w * 16 + tid];
+            q += statbuf[4 * 16 + w * 16 + tid];
+          }
+          const int tile = ((n * p.T + to0 + jj) * p.tilesH + th) * p.tilesW + tw;  // stats row
+          float* dst = p.stats + (long long)tile * 2 * p.Cout;
+          dst[cc] = s;
+          dst[p.Cout + cc] = q;
+        }
+      }
+      {  // one 16-byte channel vector per (position, frame)
+        const int row = tid >> 1, jj = tid & 1;
+        const int ho = ho0 + (row >> 4), wo = wo0 + (row & 15);
+        if (ho < p.Ho && wo < p.Wo && to0 + jj < p.T) {
+          float v[8];
+          const float4 v0 = *(const float4*)(E + row * 16 + jj * 8);
+          const float4 v1 = *(const float4*)(E + row * 16 + jj * 8 + 4);
+          v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
+          v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+          if (p.flags & VS_CONV_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          const long long pos = (((long long)n * p.T + to0 + jj) * p.Ho + ho) * p.Wo + wo;
+          *(uint4*)(p.y + pos * p.y_ld) = pack8_bf16(v);
+        }
+      }
+      __syncthreads();  // every wave is done with the ring slots of the pair's two oldest frames, and with E
+      if (more) {
+        frame_store(to0 - pT + KT1, nf0);
+        frame_store(to0 - pT + KT1 + 1, nf1);
+      }
+      __syncthreads();
+    }
+  }
+}
+
 static size_t stem_pair_smem(int kT) {
   const int K2 = (kT + 1) * 7 * 32;
   const size_t w = ((size_t)16 * (K2 * 2 + 16) + 15) & ~(size_t)15;
@@ -459,6 +636,16 @@ extern "C" int vs_stem_conv_fwd(const void* x4, const void* wp, void* y, int N, 
   const int CP = (Cout + 15) / 16 * 16;
   hipStream_t st = (hipStream_t)stream;
   static const int pair_on = [] { const char* e = getenv("VS_STEM_PAIR"); return e ? atoi(e) : 1; }();
+  if (pair_on == 1 && Cout == 8 && kT >= 3 && T >= 2) {  // two output frames per pass, weights in registers
+    p.tchunks = (T + SP_TC - 1) / SP_TC;
+    p.ntiles = N * p.tilesH * p.tilesW * p.tchunks;
+    const int grid2 = p.ntiles < 512 ? p.ntiles : 512;  // two persistent 4-wave blocks per CU
+    const size_t smem2 = (((size_t)(kT + 1) * ST_FRAMEB + 15) & ~(size_t)15) + (size_t)128 * 16 * 4 + 2 * 4 * 16 * 4;
+    if (kT == 5) hipLaunchKernelGGL(stem_pair_reg_kernel<5>, dim3(grid2), dim3(256), smem2, st, p);
+    else hipLaunchKernelGGL(stem_pair_reg_kernel<3>, dim3(grid2), dim3(256), smem2, st, p);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+  }
   if (pair_on && Cout == 8 && kT >= 3 && T >= 2) {  // two output frames per pass (fast-pathway stem)
     static bool attr_done = false;
     if (!attr_done) {

@@ -1000,6 +1000,9 @@ class VideoTrunk(nn.Module):
         batch = self._wgrad_batch
         if batch is None or (not batch.pending and not self._reduce_pending):
             return
+        if ops._WHATIF & 4:  # timing experiment only: the slabs are never summed (garbage gradients)
+            batch.pending.clear() if hasattr(batch.pending, "clear") else None
+            return
         main = torch.cuda.current_stream()
         key = main.device.index
         rs = VideoTrunk._reduce_streams.get(key)
