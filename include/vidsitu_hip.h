@@ -328,6 +328,14 @@ int vs_adam_step_dev_cast(float* p, const float* g, float* m, float* v, void* p_
 int vs_adam_step_dev_cast_g16(float* p, const void* g_bf16, float* m, float* v, void* p_bf16, int64_t n,
                               float lr, float beta1, float beta2, float eps, int* step_counter,
                               float grad_scale, void* stream);
+/* The same update for ONE RANGE of the arena, without touching the step count: a step whose gradient ranges
+ * become final at different times (the segments of vidsitu_amd/train_step.py) ticks once (vs_adam_tick) and then
+ * updates each range as soon as it is final, beside the rest of the backward pass.  g: fp32, or bf16 when
+ * g_is_bf16; p_bf16 may be NULL.  Replaces the same optimizer.step() of utils/trn_utils.py:590-615. */
+int vs_adam_tick(int* step_counter, void* stream);
+int vs_adam_step_dev_range(float* p, const void* g, int g_is_bf16, float* m, float* v, void* p_bf16, int64_t n,
+                           float lr, float beta1, float beta2, float eps, const int* step_counter,
+                           float grad_scale, void* stream);
 /* fp32 -> bf16 cast of the parameter arena (weights used by the conv kernels). */
 int vs_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 

@@ -1,0 +1,81 @@
+"""The single-process training step of `vidsitu_amd.train_step.TrainStep` (`utils/trn_utils.py:590-615`:
+zero_grad -> forward -> loss -> backward -> optimizer.step): the variant that starts Adam early -- one tick of the
+step count, then the update of each gradient range on a side stream as soon as its backward segment is done --
+must leave bitwise the gradients, parameters, moments and step count of the plain step (one Adam launch at the
+end), eager and replayed from a hipGraph."""
+import gc
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ranged_adam_beside_the_backward_pass_is_bitwise_the_plain_step(dev):
+    from vidsitu_amd import synth_data
+    from vidsitu_amd.extended_config import get_cfg
+    from vidsitu_amd.mdl_selector import get_mdl_loss_eval
+    from vidsitu_amd.optim import ArenaAdam, ParamArena
+    from vidsitu_amd.train_step import TrainStep
+
+    cfg = get_cfg({"mdl.mdl_name": "sf_base_txenc", "mdl.sf_mdl_name": "slow_fast_mini", "synth.num_verbs": 31,
+                   "tx_dec.encoder_layers": 2, "tx_dec.dropout": 0.0})
+    comm = synth_data.make_comm(cfg)
+    torch.manual_seed(0)
+    sel = get_mdl_loss_eval(cfg)
+    mdl = sel["mdl"](cfg=cfg, comm=comm).to(dev).train()
+    loss_fn = sel["loss"](cfg, comm)
+    arena = ParamArena(mdl)
+    opt = ArenaAdam(arena, lr=1e-3)
+    batch = synth_data.synth_batch(cfg, comm, bs=2, n_ev=2, crop=64, device=dev, dtype=torch.bfloat16)
+    init = arena.data.clone()
+    bufs = {k: v.clone() for k, v in mdl.named_buffers()}
+
+    def reset():
+        arena.data.copy_(init)
+        opt.m.zero_(); opt.v.zero_(); opt.t.zero_()
+        for k, v in mdl.named_buffers():
+            v.copy_(bufs[k])
+        arena.refresh()
+        torch.cuda.synchronize()
+
+    def state():
+        return [t.clone() for t in (arena.grad, arena.data, opt.m, opt.v, opt.t)]
+
+    def run(ts):
+        gc.collect()
+        torch.cuda.synchronize()
+        reset()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ts.step()
+            ts.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        eager = state()
+        ts.capture()
+        reset()
+        for _ in range(2):
+            arena.grad.fill_(float("nan"))
+            ts.replay()
+        torch.cuda.synchronize()
+        replayed = state() + [ts.loss.clone()]
+        ts.graphs = None
+        return eager, replayed
+
+    plain = TrainStep(mdl, loss_fn, arena, opt, batch, adam_overlap=False)
+    assert not plain.adam_overlap and len(plain.segments) == 1
+    e0, r0 = run(plain)
+    early = TrainStep(mdl, loss_fn, arena, opt, batch, adam_overlap=True)
+    assert early.adam_overlap and len(early.segments) == 4
+    lo_hi = sorted(r for _, r in early.segments)
+    assert lo_hi[0][0] == 0 and lo_hi[-1][1] == arena.numel and all(a[1] == b[0] for a, b in zip(lo_hi, lo_hi[1:]))
+    e1, r1 = run(early)
+    assert int(r0[4]) == 2 and not torch.equal(r0[1], init) and torch.isfinite(r0[0]).all()
+    for name, a, b in zip(("grad", "param", "exp_avg", "exp_avg_sq", "step", "loss"), r0, r1):
+        assert torch.equal(a, b), f"replayed {name} differs"
+    for name, a, b in zip(("grad", "param", "exp_avg", "exp_avg_sq", "step"), e0, e1):
+        assert torch.equal(a, b), f"eager {name} differs"
+    for name, a, b in zip(("grad", "param", "exp_avg", "exp_avg_sq", "step"), e0, r0):
+        assert torch.equal(a, b), f"eager vs replayed {name} differs"

@@ -100,6 +100,8 @@ SIGNATURES = {
     "vs_adam_step_dev": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _p, _f, _p]),
     "vs_adam_step_dev_cast": (_i, [_p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _p, _f, _p]),
     "vs_adam_step_dev_cast_g16": (_i, [_p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _p, _f, _p]),
+    "vs_adam_tick": (_i, [_p, _p]),
+    "vs_adam_step_dev_range": (_i, [_p, _p, _i, _p, _p, _p, _i64, _f, _f, _f, _f, _p, _f, _p]),
     "vs_cast_f32_to_bf16": (_i, [_p, _p, _i64, _p]),
     "vs_gemm_nt_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vs_gpt2_embed": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

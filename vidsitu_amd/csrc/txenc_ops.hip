@@ -1392,14 +1392,14 @@ __global__ void adam_dev_kernel(float* p, const void* gv, float* m, float* v, ui
 
 static int adam_dev_launch(float* p, const void* g, bool g16, float* m, float* v, void* p_bf16, int64_t n,
                            float lr, float beta1, float beta2, float eps, int* step_counter,
-                           float grad_scale, void* stream) {
+                           float grad_scale, void* stream, bool tick = true) {
   const bool aligned = (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v) & 15) == 0 &&
                        (((uintptr_t)g) & (g16 ? 7 : 15)) == 0 && (((uintptr_t)p_bf16) & 7) == 0;
   const long long n4 = aligned ? n / 4 : 0;
   long long grid = ((aligned ? n4 : (long long)n) + 255) / 256;
   if (grid > 4096) grid = 4096;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_counter);
+  if (tick) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_counter);
   if (g16)
     hipLaunchKernelGGL(adam_dev_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m,
                        v, (uint16_t*)p_bf16, n4, (long long)n, lr, beta1, beta2, eps,
@@ -1432,6 +1432,21 @@ extern "C" int vs_adam_step_dev_cast_g16(float* p, const void* g_bf16, float* m,
   VS_CHECK_ARG(p && g_bf16 && m && v && p_bf16 && n > 0 && step_counter, "bad args");
   return adam_dev_launch(p, g_bf16, true, m, v, p_bf16, n, lr, beta1, beta2, eps, step_counter, grad_scale,
                          stream);
+}
+
+extern "C" int vs_adam_tick(int* step_counter, void* stream) {
+  VS_CHECK_ARG(step_counter, "null counter");
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_counter);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+extern "C" int vs_adam_step_dev_range(float* p, const void* g, int g_is_bf16, float* m, float* v, void* p_bf16,
+                                      int64_t n, float lr, float beta1, float beta2, float eps,
+                                      const int* step_counter, float grad_scale, void* stream) {
+  VS_CHECK_ARG(p && g && m && v && n > 0 && step_counter, "bad args");
+  return adam_dev_launch(p, g, g_is_bf16 != 0, m, v, p_bf16, n, lr, beta1, beta2, eps, (int*)step_counter,
+                         grad_scale, stream, false);
 }
 
 __global__ void cast_f32_bf16_kernel(const float* x, uint16_t* y, long long n) {

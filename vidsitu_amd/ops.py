@@ -812,6 +812,18 @@ def adam_step_dev_cast_g16(p, g16, m, v, p_bf16, lr, beta1, beta2, eps, step_cou
               float(grad_scale), _stream())
 
 
+def adam_tick(step_counter):
+    _lib.call("vs_adam_tick", _ptr(step_counter), _stream())
+
+
+def adam_step_dev_range(p, g, m, v, p_bf16, lr, beta1, beta2, eps, step_counter, grad_scale=1.0):
+    """The Adam update of one arena range (views of equal length) against an already ticked step count;
+    g fp32 or bf16; p_bf16 None or the bf16 copy's view."""
+    _lib.call("vs_adam_step_dev_range", _ptr(p), _ptr(g), int(g.dtype == BF16), _ptr(m), _ptr(v), _ptr(p_bf16),
+              p.numel(), float(lr), float(beta1), float(beta2), float(eps), _ptr(step_counter),
+              float(grad_scale), _stream())
+
+
 def cast_bf16(src_f32, dst_bf16):
     _lib.call("vs_cast_f32_to_bf16", _ptr(src_f32), _ptr(dst_bf16), src_f32.numel(), _stream())
 

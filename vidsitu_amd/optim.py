@@ -396,6 +396,28 @@ class ArenaAdam:
             raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): one shared counter here")
         self.t.fill_(steps.pop() if steps else 0)
 
+    def tick(self):
+        """Start of a ranged step: the step count (device memory) goes up once."""
+        ops.adam_tick(self.t)
+
+    def step_range(self, lo, hi, world=1, grad_bf16=False):
+        """The update of arena elements [lo, hi) against the count `tick()` set; no refresh of derived weight
+        images (the caller runs `finish_ranged()` once every range is done)."""
+        a = self.arena
+        if hi <= lo:
+            return
+        g = (a.grad16 if grad_bf16 else a.grad)[lo:hi]
+        pb = a.data_bf16[lo:hi] if a.data_bf16 is not None else None
+        ops.adam_step_dev_range(a.data[lo:hi], g, self.m[lo:hi], self.v[lo:hi], pb, self.lr, self.betas[0],
+                                self.betas[1], self.eps, self.t, grad_scale=1.0 / world)
+
+    def finish_ranged(self, defer_transposes=False):
+        a = self.arena
+        if a.data_bf16 is not None:
+            a.refresh(cast=False, transposes=not defer_transposes)
+        else:
+            a.refresh()
+
     def step(self, world=1, defer_transposes=False, grad_bf16=False):
         """defer_transposes: leave the dgrad weight images stale; the caller refreshes them with
         `arena.transposes_async()` at the start of the next step (bench.py).

@@ -10,7 +10,12 @@ one process per MI355X over RCCL:
     range of the fp32 gradient arena, `ParamArena.bucket_ranges`) is all-reduced asynchronously on
     RCCL's stream while the next segment computes; Adam (one more graph) waits for the buckets;
   * `overlap=False` is the same mechanism with ONE segment (whole forward + backward, one all-reduce);
-  * without a process group the whole step, Adam included, is one hipGraph;
+  * without a process group the whole step, Adam included, is one hipGraph.  `adam_overlap=True` /
+    `VS_ADAM_OVERLAP=1` uses the same segments to start Adam EARLY -- the step count ticks once, and the update
+    of a segment's arena range runs on a side stream as soon as that segment's gradients are final -- bitwise the
+    plain step (tests/test_gpu_train_step.py).  Measured on MI355X, batch 8: 13.39-13.41 ms against 13.11-13.13
+    for one launch at the end (the segmented backward alone: 13.13-13.15): the update is a 2.3 GB HBM stream
+    and the kernels it runs beside lose more to the contention than the overlap hides, so it is OFF by default;
   * `grad_bf16=True`: the bucket payload is bf16 (half the xGMI bytes: 153 MB instead of 305 MB for
     SlowFast-R50 + 6-layer TxEncoder) -- a segment's graph ends with the cast of its bucket into a
     bf16 arena, RCCL sums that, and the Adam kernel reads the bf16 sums against its fp32 master
@@ -19,13 +24,15 @@ one process per MI355X over RCCL:
 A failed hipGraph capture RAISES (bench.py then exits non-zero): a silently eager multi-GPU line
 would be a different measurement under the same name.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
 class TrainStep:
     def __init__(self, mdl, loss_fn, arena, opt, batch, world=1, overlap=None, use_dist=None,
-                 grad_bf16=False):
+                 grad_bf16=False, adam_overlap=None):
         self.mdl, self.loss_fn, self.arena, self.opt, self.batch = mdl, loss_fn, arena, opt, batch
         self.world = world
         self.use_dist = (dist.is_available() and dist.is_initialized()) if use_dist is None else use_dist
@@ -34,6 +41,11 @@ class TrainStep:
         self.trunk = getattr(mdl, "sf_mdl", None)
         can_overlap = self.trunk is not None and hasattr(self.trunk, "BWD_SEGMENTS")
         self.overlap = (self.use_dist and world > 1 if overlap is None else bool(overlap)) and can_overlap
+        # single process: ranged Adam beside the backward pass (needs the segmented backward and the arena on a GPU)
+        want = os.environ.get("VS_ADAM_OVERLAP", "0") not in ("0", "") if adam_overlap is None else bool(adam_overlap)
+        self.adam_overlap = (want and not self.use_dist and can_overlap and arena.data.is_cuda
+                             and hasattr(opt, "step_range"))
+        self._adam_stream = None
         self.loss = None
         self.graphs = None  # segment graphs + the Adam graph, or [whole-step graph]
         self.segments = self._build_segments()
@@ -56,7 +68,7 @@ class TrainStep:
     def _build_segments(self):
         """[(callable, (lo, hi))]: after `callable` the gradients in arena.grad[lo:hi] are final."""
         a = self.arena
-        if not self.overlap:
+        if not (self.overlap or self.adam_overlap):
             if self.trunk is not None:
                 self.trunk.defer_backward = False
             return [(self.fwd_bwd, (0, a.numel))]
@@ -79,7 +91,30 @@ class TrainStep:
             self.arena.pack_grad_bf16(lo, hi)
 
     # ---- eager ---------------------------------------------------------------------------------
+    def _step_adam_overlapped(self):
+        main = torch.cuda.current_stream()
+        if self._adam_stream is None:
+            self._adam_stream = torch.cuda.Stream(device=self.arena.data.device)
+        side = self._adam_stream
+        self.opt.tick()
+        late = os.environ.get("VS_ADAM_OVERLAP") == "2"  # A/B: the segmented backward, every range updated at the end
+        for fn, (lo, hi) in self.segments:
+            fn()
+            if late:
+                continue
+            side.wait_stream(main)  # this range's gradients are final; its parameters have no reader left
+            with torch.cuda.stream(side):
+                self.opt.step_range(lo, hi, world=self.world)
+        if late:
+            for _, (lo, hi) in self.segments:
+                self.opt.step_range(lo, hi, world=self.world)
+        main.wait_stream(side)
+        self.opt.finish_ranged(defer_transposes=True)
+        return self.loss
+
     def step(self):
+        if self.adam_overlap:
+            return self._step_adam_overlapped()
         works = []
         for fn, (lo, hi) in self.segments:
             fn()
