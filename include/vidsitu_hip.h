@@ -53,6 +53,8 @@ typedef enum vs_status {
 #define VS_CONV_FORCEHALO (1 << 22) /* run it on the halo-image kernel whenever the shape is eligible (A/B, tests) */
 #define VS_CONV_NOPW (1 << 23) /* keep a shallow-K pointwise conv on the implicit-GEMM kernel instead of the persistent
                                   weight-resident kernel (A/B, tests) */
+#define VS_CONV_DIRECTBNB (1 << 25) /* dgrad on the small-channel kernel: let it emit the BN-backward sums (measured
+                                       slower in the step than the separate reduce pass; A/B, tests) */
 #define VS_CONV_FORCEPW (1 << 24) /* run it on that kernel whenever the shape is eligible, also where the plan would
                                      not (one block per CU; A/B, tests) */
 

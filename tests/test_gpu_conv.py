@@ -821,3 +821,59 @@ def test_persistent_pointwise_kernel_fwd_and_dgrad(case, dev):
     gm = torch.where(keep, dxr.float(), torch.zeros((), device=dev))
     want = torch.stack([gm.double().sum((0, 2, 3, 4)), (gm * xh).double().sum((0, 2, 3, 4))]).cpu()
     assert float((psb.double().sum(0).cpu() - want).abs().max()) / float(want.abs().max()) < 1e-5
+
+
+# name, N, Cin, T, H, W, Cout, k, s, p : data gradients the small-channel (register-resident weights) kernel takes
+DIRECT_BNB_CASES = [
+    ("s2b_8_8_3x3", 2, 8, 8, 40, 40, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("s2a_32_8_t3", 1, 32, 16, 24, 24, 8, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ("s2c_8_32_pw", 2, 8, 8, 36, 36, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("s3b_16_16_3x3", 2, 16, 6, 30, 26, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("s3b0_16_16_s2", 2, 16, 6, 30, 26, 16, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ("s3c_16_64_pw_ragged", 3, 16, 5, 13, 11, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+]
+
+
+@pytest.mark.parametrize("case", DIRECT_BNB_CASES, ids=[c[0] for c in DIRECT_BNB_CASES])
+def test_small_channel_dgrad_emits_bn_backward_sums(case, dev):
+    """conv_direct_kernel<.., BNB>: the data gradient of a small-channel conv also emits the BN-backward sums of the
+    unit whose complete dz it is (both mask forms) -- dx bitwise the plain launch, sums = what the separate reduce
+    pass computes over the stored dx.  (Opt-in, VS_CONV_DIRECTBNB: slower in the step than the reduce pass.)"""
+    from vidsitu_amd import ops
+
+    name, n, cin, t, h, w, cout, k, s, p = case
+    g = torch.Generator().manual_seed(97)
+    x_shape = (n, cin, t, h, w)
+    wgt = rb(torch.randn(cout, cin, *k, generator=g) / (cin * k[0] * k[1] * k[2]) ** 0.5)
+    ys = ops.conv_out_shape(x_shape, cout, k, s, p)
+    assert _plan(ops, x_shape, ys, cin, cout, k, s, p, 1, flags=0)[4] == 1, "dgrad did not take the small-channel kernel"
+    dya = to_act(rb(torch.randn(ys, generator=g)), dev)
+    wt = ops.weight_transpose(to_w(wgt, dev))
+    bits16 = lambda a: a.view(torch.int16)
+    dx = ops.conv_dgrad(dya, wt, x_shape, k, s, p)
+    bn_y = to_act(rb(torch.randn(x_shape, generator=g)), dev)
+    mean = (torch.randn(cin, generator=g) * 0.2).to(dev)
+    invstd = (torch.rand(cin, generator=g) + 0.5).to(dev)
+    gamma, beta = torch.randn(cin, generator=g).to(dev), (torch.randn(cin, generator=g) * 0.3).to(dev)
+    v = lambda a: a.view(1, -1, 1, 1, 1)
+    xh = (bn_y.float() - v(mean)) * v(invstd)
+    # no residual: the unit's ReLU mask recomputed from gamma / beta
+    dxs, psum = ops.conv_dgrad(dya, wt, x_shape, k, s, p, bn_stats=(bn_y, mean, invstd, gamma, beta), direct_bnb=True)
+    assert psum is not None and torch.equal(bits16(dxs), bits16(dx))
+    gm = torch.where(xh * v(gamma) + v(beta) > 0, dx.float(), torch.zeros((), device=dev))
+    want = torch.stack([gm.double().sum((0, 2, 3, 4)), (gm * xh).double().sum((0, 2, 3, 4))]).cpu()
+    assert float((psum.double().sum(0).cpu() - want).abs().max()) / float(want.abs().max()) < 2e-5
+    if s != (1, 1, 1):
+        return  # (a strided dgrad with a residual does not emit the sums)
+    # masked residual + the unit's bit mask
+    rr = to_act(rb(torch.randn(x_shape, generator=g)), dev)
+    rows = ops.act_rows(rr)
+    rbits = torch.randint(0, 256, (rows, cin // 8), generator=g, dtype=torch.uint8).to(dev)
+    ubits = torch.randint(0, 256, (rows, cin // 8), generator=g, dtype=torch.uint8).to(dev)
+    dxr = ops.conv_dgrad(dya, wt, x_shape, k, s, p, residual=rr, residual_bits=rbits)
+    dxb, psb = ops.conv_dgrad(dya, wt, x_shape, k, s, p, residual=rr, residual_bits=rbits,
+                              bn_stats=(bn_y, mean, invstd, None, None, ubits), direct_bnb=True)
+    assert psb is not None and torch.equal(bits16(dxb), bits16(dxr))
+    gm = torch.where(_unpack_bits(ubits, x_shape), dxr.float(), torch.zeros((), device=dev))
+    want = torch.stack([gm.double().sum((0, 2, 3, 4)), (gm * xh).double().sum((0, 2, 3, 4))]).cpu()
+    assert float((psb.double().sum(0).cpu() - want).abs().max()) / float(want.abs().max()) < 2e-5

@@ -632,10 +632,14 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(
 // TB = 16-row tiles a wave keeps in flight: the gathers of all TB tiles are issued before the first MFMA.  One
 // tile per round trip moved 256..1024 unique bytes per wave per memory latency (~1 TB/s over the chip for the
 // 8-channel layers of the fast pathway); see profiles/r02_direct_tb.txt for the sweep.
-template <int NT, int KS, int MODE, int TB>
+// BNB (dgrad launches): the copy-out also emits the BN-backward sums of the unit this dx is the complete dz of --
+// the two variants of conv_tile_epilogue (no residual: mask recomputed from gamma / beta; residual: the unit's bit
+// mask) -- one partial row per block (fixed order: a lane's rows in order, then waves x lanes through LDS).
+template <int NT, int KS, int MODE, int TB, bool BNB = false>
 __global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p, int tiles_per_wave) {
   __shared__ __attribute__((aligned(16))) uint16_t tbuf[4][TB * 16 * 16 * NT];
   __shared__ float sstat[2][4][16 * NT];
+  __shared__ float bnred[BNB ? 4 * 64 * 16 : 1];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 15, lq = lane >> 4;
   const int K8 = p.K >> 3, C8 = p.Cg >> 3;
@@ -690,6 +694,23 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p, int tiles_per
     }
   }
   const bool relu = (p.flags & VS_CONV_RELU) != 0, has_res = (p.flags & VS_CONV_RESIDUAL) != 0;
+  // BNB: this lane's fixed 8-channel chunk (64 % chunks-per-row == 0) and the unit's per-channel constants
+  constexpr int CPRW_ = 2 * NT;
+  const int bn_c8 = lane % CPRW_, bn_n = bn_c8 * 8;
+  const bool bn_ok = BNB && bn_n < p.Ncols;
+  float bmu[8], bis[8], bga[8], bbe[8], bsg[8], bsx[8];
+  if (BNB) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = bn_ok ? bn_n + e : 0;
+      bmu[e] = p.bn_mean[c];
+      bis[e] = p.bn_invstd[c];
+      bga[e] = has_res ? 0.f : p.bn_gamma[c];
+      bbe[e] = has_res ? 0.f : p.bn_beta[c];
+      bsg[e] = 0.f;
+      bsx[e] = 0.f;
+    }
+  }
   uint16_t* tb = tbuf[wave];
   const int tile0 = (blockIdx.x * 4 + wave) * tiles_per_wave;
 
@@ -803,10 +824,45 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p, int tiles_per
           v = pack8_bf16(f);
         }
         *(uint4*)(p.y + (long long)mm * p.y_ld + n) = v;
+        if (BNB) {  // the sums see dz as stored
+          float gq[8], yv[8];
+          unpack8_bf16(v, gq);
+          unpack8_bf16(*(const uint4*)(p.bny + (long long)mm * p.bny_ld + n), yv);
+          const unsigned bits = has_res ? (unsigned)p.bn_bits[(long long)mm * (p.Ncols >> 3) + (n >> 3)] : 0u;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xh = (yv[e] - bmu[e]) * bis[e];
+            const bool on = has_res ? ((bits >> e) & 1u) != 0 : (xh * bga[e] + bbe[e]) > 0.f;
+            const float ge = on ? gq[e] : 0.f;
+            bsg[e] += ge;
+            bsx[e] += ge * xh;
+          }
+        }
       }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();  // reads done before the next batch overwrites tb
+  }
+  if (BNB) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      bnred[(wave * 64 + lane) * 16 + e] = bsg[e];
+      bnred[(wave * 64 + lane) * 16 + 8 + e] = bsx[e];
+    }
+    __syncthreads();
+    if (tid < p.Ncols) {  // fixed order: waves, then the lanes that own this channel's chunk
+      const int cc = tid >> 3, e = tid & 7;
+      float ts = 0.f, tq = 0.f;
+      for (int w = 0; w < 4; ++w)
+        for (int l = cc; l < 64; l += CPRW_) {
+          ts += bnred[(w * 64 + l) * 16 + e];
+          tq += bnred[(w * 64 + l) * 16 + 8 + e];
+        }
+      float* dst = p.stats + (long long)blockIdx.x * 2 * p.Ncols;
+      dst[tid] = ts;
+      dst[p.Ncols + tid] = tq;
+    }
+    return;
   }
   if (p.flags & VS_CONV_STATS) {
 #pragma unroll
@@ -861,6 +917,17 @@ static int direct_tb(int nt, int ks) {
 
 template <int NT, int KS>
 static int launch_direct_ks(const ConvP& p, int mode, hipStream_t st) {
+  if (p.flags & VS_CONV_BNBWD) {  // dgrad + the producer's BN-backward sums: two tiles in flight (register budget)
+    const int grid = direct_blocks(p.M);
+    if (mode == 0)
+      hipLaunchKernelGGL((conv_direct_kernel<NT, KS, 0, 2, true>), dim3(grid), dim3(256), 0, st, p, VS_DIRECT_TPW);
+    else if (mode == 1)
+      hipLaunchKernelGGL((conv_direct_kernel<NT, KS, 1, 2, true>), dim3(grid), dim3(256), 0, st, p, VS_DIRECT_TPW);
+    else
+      hipLaunchKernelGGL((conv_direct_kernel<NT, KS, 2, 2, true>), dim3(grid), dim3(256), 0, st, p, VS_DIRECT_TPW);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+  }
   switch (direct_tb(NT, KS)) {
     case 1: return launch_direct_tb<NT, KS, 1>(p, mode, st);
     case 2: return launch_direct_tb<NT, KS, 2>(p, mode, st);
@@ -1459,7 +1526,15 @@ extern "C" int vs_conv_dgrad_bnstats_rows(const vs_conv_desc* d) {
     if (vs_pw_plan(p, mode, d->flags, &pg)) return pg.tilesM;
   }
   const ConvPlan pl = plan_conv(p.M, p.Ncols, p.K, p.kT * p.kH * p.kW, d->flags);
-  if (pl.direct || pl.S > 1 || !bnb_tile(pl.tile.bm, pl.tile.bn) || p.kT * p.kH * p.kW > 31) return 0;
+  if (pl.direct) {
+    // The small-channel kernel can emit them too (one partial row per block), but it is bound by instruction
+    // issue, not by bandwidth: with the mask / sum arithmetic in its copy-out the step is 0.1-0.2 ms SLOWER
+    // than the plain launch plus the separate (bandwidth-bound) reduce pass -- 13.05 / 13.19 vs 12.83 / 13.08 ms,
+    // A/B on one box.  Opt-in: VS_CONV_DIRECTBNB in desc.flags, or VS_DIRECT_BNB=1.
+    static const int on = [] { const char* e = getenv("VS_DIRECT_BNB"); return e ? atoi(e) : 0; }();
+    return (on || (d->flags & VS_CONV_DIRECTBNB)) ? direct_blocks(p.M) : 0;
+  }
+  if (pl.S > 1 || !bnb_tile(pl.tile.bm, pl.tile.bn) || p.kT * p.kH * p.kW > 31) return 0;
   p.tilesM = (p.M + pl.tile.bm - 1) / pl.tile.bm;
   setup_stride_classes(p, pl.tile.bm, mode, d->flags);
   return p.tilesM;

@@ -297,7 +297,8 @@ def transpose_f32_batched(src, dst, table, total, tiled=True):
 
 
 def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=None, ring=0,
-               noclass=False, bn_stats=None, residual_bits=None, inplace=False, halo=True, pw=True):
+               noclass=False, bn_stats=None, residual_bits=None, inplace=False, halo=True, pw=True,
+               direct_bnb=False):
     """dx[xs] = conv_transpose(dy, w) (+ residual).  wt from weight_transpose.
     bn_stats = (y, mean, invstd, gamma, beta[, relu_bits]) of the BatchNorm + ReLU unit whose output this
     convolution consumed and whose complete dz this dx is: returns (dx, partial) with partial [rows, 2, Cin]
@@ -327,6 +328,8 @@ def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=N
         flags |= 1 << 23  # VS_CONV_NOPW
     elif pw == "force":
         flags |= 1 << 24  # VS_CONV_FORCEPW
+    if direct_bnb:
+        flags |= 1 << 25  # VS_CONV_DIRECTBNB
     d = make_desc(xs, act_ld(out), dy.shape, act_ld(dy), k, s, p, flags,
                   act_ld(residual) if residual is not None else 0)
     if residual_bits is not None:
