@@ -716,13 +716,14 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p, int tiles_per
 
   for (int it = 0; it < tiles_per_wave; it += TB) {
     if ((tile0 + it) * 16 >= p.M) break;
-    unsigned roff[TB], vmask[TB];
-#pragma unroll
-    for (int u = 0; u < TB; ++u) {
-      const int m = (tile0 + it + u) * 16 + lr;
-      roff[u] = VS_OOB;
-      vmask[u] = 0u;
-      if (m < p.M && it + u < tiles_per_wave) {
+    // Row decode ONCE per row: lane l decodes row l of the batch (TB * 16 <= 64 rows: position -> (clip, t, h, w),
+    // base byte offset, bitmask of valid taps -- ~80 vector instructions), and the 4 lanes x TB tiles that need a
+    // row fetch its two words with a cross-lane read.  Decoding per (tile, lane) repeated every row four times
+    // over and made the kernel instruction-issue bound.
+    unsigned roff_own = VS_OOB, vmask_own = 0u;
+    {
+      const int m = (tile0 + it) * 16 + lane;
+      if (lane < TB * 16 && m < p.M && it + (lane >> 4) < tiles_per_wave) {
         int rw, t1, rh, t2, rt, n;
         fast_divmod(m, p.Rw, rcpW, t1, rw);
         fast_divmod(t1, p.Rh, rcpH, t2, rh);
@@ -730,14 +731,14 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p, int tiles_per
         if (MODE == 0) {
           const long long pos =
               ((long long)(n * p.Gt + rt * p.mulT) * p.Gh + rh * p.mulH) * p.Gw + rw * p.mulW;
-          roff[u] = (unsigned)(pos * p.g_ld * 2);
-          vmask[u] = 1u;
+          roff_own = (unsigned)(pos * p.g_ld * 2);
+          vmask_own = 1u;
         } else {
           const int ct = rt * p.mulT + p.offT, ch = rh * p.mulH + p.offH, cw = rw * p.mulW + p.offW;
           long long pos0 = (long long)n * p.Gt * p.Gh * p.Gw;
           if (MODE == 1) pos0 += ((long long)ct * p.Gh + ch) * p.Gw + cw;
           else pos0 += ((long long)(ct >> p.shT) * p.Gh + (ch >> p.shH)) * p.Gw + (cw >> p.shW);
-          roff[u] = (unsigned)(pos0 * p.g_ld * 2);
+          roff_own = (unsigned)(pos0 * p.g_ld * 2);
           auto axis_mask = [&](int c, int kk, int shf, int G) {
             unsigned mm = 0u;
             for (int dd = 0; dd < kk; ++dd) {
@@ -762,9 +763,15 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p, int tiles_per
               vm |= (th ? mw : 0u) << tap;
               tap += p.kW;
             }
-          vmask[u] = vm;
+          vmask_own = vm;
         }
       }
+    }
+    unsigned roff[TB], vmask[TB];
+#pragma unroll
+    for (int u = 0; u < TB; ++u) {
+      roff[u] = (unsigned)__shfl((int)roff_own, u * 16 + lr, 64);
+      vmask[u] = (unsigned)__shfl((int)vmask_own, u * 16 + lr, 64);
     }
     bf16x8 af[TB][KS];
 #pragma unroll
