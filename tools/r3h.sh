@@ -1,0 +1,4 @@
+#!/bin/bash
+cd /root/repo
+timeout 900 python -m pytest tests/test_gpu_bn_pool.py tests/test_gpu_trunk.py -q -m gpu -x 2>&1 | tail -3
+for rep in 1 2; do timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline 2> /dev/null | grep -o '"ms_per_step": [0-9.]*'; timeout 300 python bench.py --workload feat_fwd --steps 50 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'; done

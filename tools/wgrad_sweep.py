@@ -31,17 +31,22 @@ SH = [
     ("s3.b 128->128 [1,3,3]", 128, 8, 28, 28, 128, (1, 3, 3), (0, 1, 1)),
     ("s3.c 128->512 [1,1,1]", 128, 8, 28, 28, 512, (1, 1, 1), (0, 0, 0)),
 ]
-for name, cin, t, h, w, cout, k, p in SH:
-    x = ops.new_act(8, cin, t, h, w, dev); x.normal_()
-    dy = ops.new_act(8, cout, t, h, w, dev); dy.normal_()
-    dw = torch.empty((cout, *k, cin), dtype=torch.float32, device=dev).permute(0, 4, 1, 2, 3)
-    row = f"{name:24s} plan {gt(lambda: ops.conv_wgrad(dy, x, k, (1, 1, 1), p, out=dw)):6.1f} |"
-    for tile in (0, 1, 2, 3):
-        for slots in (192, 256, 384, 512):
-            try:
-                us = gt(lambda: ops.conv_wgrad(dy, x, k, (1, 1, 1), p, out=dw, tile=tile, slots=slots))
-                row += f" t{tile}s{slots}:{us:6.1f}"
-            except Exception as e:
-                row += f" t{tile}s{slots}:  ERR"
-        row += " |"
-    print(row, flush=True)
+def main():
+  for name, cin, t, h, w, cout, k, p in SH:
+      x = ops.new_act(8, cin, t, h, w, dev); x.normal_()
+      dy = ops.new_act(8, cout, t, h, w, dev); dy.normal_()
+      dw = torch.empty((cout, *k, cin), dtype=torch.float32, device=dev).permute(0, 4, 1, 2, 3)
+      row = f"{name:24s} plan {gt(lambda: ops.conv_wgrad(dy, x, k, (1, 1, 1), p, out=dw)):6.1f} |"
+      for tile in (0, 1, 2, 3):
+          for slots in (192, 256, 384, 512):
+              try:
+                  us = gt(lambda: ops.conv_wgrad(dy, x, k, (1, 1, 1), p, out=dw, tile=tile, slots=slots))
+                  row += f" t{tile}s{slots}:{us:6.1f}"
+              except Exception as e:
+                  row += f" t{tile}s{slots}:  ERR"
+          row += " |"
+      print(row, flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -44,9 +44,10 @@ __global__ void pack_input_kernel(const void* xin, uint16_t* y, int N, int C, lo
 // (0.84 TB/s on the 32 x 224 x 224 fast-pathway input).
 template <bool IN_BF16>
 __global__ void pack_input_c4x8_kernel(const void* xin, uint16_t* y, int N, int C, long long THW8) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // n * THW8 + s8
-  if (i >= (long long)N * THW8) return;
-  const long long n = i / THW8, s8 = i - n * THW8;
+  // grid = (chunks of a clip, clips): no division (a 64-bit one per thread was a third of this kernel's instructions)
+  const long long n = blockIdx.y, s8 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s8 >= THW8) return;
+  const long long i = n * THW8 + s8;
   float v[3][8];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -76,9 +77,8 @@ extern "C" int vs_pack_input(const void* x, int x_is_bf16, void* y, int N, int C
   VS_CHECK_ARG(x && y, "null tensor");
   VS_CHECK_ARG((Cpad % 8 == 0 || Cpad == 4) && Cpad >= C, "Cpad must be 4 or a multiple of 8, >= C");
   const long long THW = (long long)T * H * W, total = THW * N;
-  if (Cpad == 4 && C <= 3 && (THW & 7) == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
-    const long long t8 = total / 8;
-    const dim3 g8((unsigned)((t8 + 255) / 256));
+  if (Cpad == 4 && C <= 3 && (THW & 7) == 0 && N <= 65535 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+    const dim3 g8((unsigned)((THW / 8 + 255) / 256), (unsigned)N);
     if (x_is_bf16)
       hipLaunchKernelGGL(pack_input_c4x8_kernel<true>, g8, dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)y, N,
                          C, THW / 8);
@@ -801,18 +801,33 @@ extern "C" int vs_bn_bwd_apply(const void* dz, const void* z, const void* y, con
 // ----------------------------------------------------------------------------
 // MaxPool3d([1,3,3], s[1,2,2], p[0,1,1]); idx = first max in (kh,kw) scan order
 // ----------------------------------------------------------------------------
+// (SMALL: fewer than 2^24 elements -- every tensor of the bench step: the element index is split with float-reciprocal
+//  divisions; three 64-bit integer divisions per 16-byte element made these kernels instruction bound)
+template <bool SMALL>
 __global__ void maxpool_hw_fwd_kernel(const uint16_t* x, uint16_t* y, uint8_t* idx, int NT, int H,
                                       int W, int Ho, int Wo, int C, int x_ld, int y_ld) {
   const int cpr = C >> 3;
   const long long total = (long long)NT * Ho * Wo * cpr;
+  const float rcp_c = 1.0f / (float)cpr, rcp_w = 1.0f / (float)Wo, rcp_h = 1.0f / (float)Ho;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % cpr) * 8;
-    long long pos = i / cpr;
-    const int wo = (int)(pos % Wo);
-    pos /= Wo;
-    const int ho = (int)(pos % Ho);
-    const long long nt = pos / Ho;
+    int c, wo, ho;
+    long long nt;
+    if (SMALL) {
+      int p1, p2, p3, cb;
+      fast_divmod((int)i, cpr, rcp_c, p1, cb);
+      fast_divmod(p1, Wo, rcp_w, p2, wo);
+      fast_divmod(p2, Ho, rcp_h, p3, ho);
+      c = cb * 8;
+      nt = p3;
+    } else {
+      c = (int)(i % cpr) * 8;
+      long long pos = i / cpr;
+      wo = (int)(pos % Wo);
+      pos /= Wo;
+      ho = (int)(pos % Ho);
+      nt = pos / Ho;
+    }
     float best[8];
     int bi[8];
 #pragma unroll
@@ -853,26 +868,44 @@ extern "C" int vs_maxpool_hw3s2_fwd(const void* x, void* y, uint8_t* idx, int N,
   VS_CHECK_ARG(C % 8 == 0 && x_ld % 8 == 0 && y_ld % 8 == 0, "C / pitches multiple of 8");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const long long total = (long long)N * T * Ho * Wo * (C / 8);
-  hipLaunchKernelGGL(maxpool_hw_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0,
-                     (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, idx, N * T, H, W, Ho,
-                     Wo, C, x_ld, y_ld);
+  if (total < (1ll << 24))
+    hipLaunchKernelGGL(maxpool_hw_fwd_kernel<true>, dim3(ew_grid(total)), dim3(256), 0,
+                       (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, idx, N * T, H, W, Ho,
+                       Wo, C, x_ld, y_ld);
+  else
+    hipLaunchKernelGGL(maxpool_hw_fwd_kernel<false>, dim3(ew_grid(total)), dim3(256), 0,
+                       (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, idx, N * T, H, W, Ho,
+                       Wo, C, x_ld, y_ld);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }
 
 // gather form: every input element sums dy of the (<= 4) windows whose argmax it is
+template <bool SMALL>
 __global__ void maxpool_hw_bwd_kernel(const uint16_t* dy, const uint8_t* idx, uint16_t* dx, int NT,
                                       int H, int W, int Ho, int Wo, int C, int dy_ld, int dx_ld) {
   const int cpr = C >> 3;
   const long long total = (long long)NT * H * W * cpr;
+  const float rcp_c = 1.0f / (float)cpr, rcp_w = 1.0f / (float)W, rcp_h = 1.0f / (float)H;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % cpr) * 8;
-    long long pos = i / cpr;
-    const int w = (int)(pos % W);
-    pos /= W;
-    const int h = (int)(pos % H);
-    const long long nt = pos / H;
+    int c, w, h;
+    long long nt;
+    if (SMALL) {
+      int p1, p2, p3, cb;
+      fast_divmod((int)i, cpr, rcp_c, p1, cb);
+      fast_divmod(p1, W, rcp_w, p2, w);
+      fast_divmod(p2, H, rcp_h, p3, h);
+      c = cb * 8;
+      nt = p3;
+    } else {
+      c = (int)(i % cpr) * 8;
+      long long pos = i / cpr;
+      w = (int)(pos % W);
+      pos /= W;
+      h = (int)(pos % H);
+      nt = pos / H;
+    }
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
@@ -907,9 +940,14 @@ extern "C" int vs_maxpool_hw3s2_bwd(const void* dy, const uint8_t* idx, void* dx
   VS_CHECK_ARG(C % 8 == 0 && dy_ld % 8 == 0 && dx_ld % 8 == 0, "C / pitches multiple of 8");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const long long total = (long long)N * T * H * W * (C / 8);
-  hipLaunchKernelGGL(maxpool_hw_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0,
-                     (hipStream_t)stream, (const uint16_t*)dy, idx, (uint16_t*)dx, N * T, H, W, Ho,
-                     Wo, C, dy_ld, dx_ld);
+  if (total < (1ll << 24))
+    hipLaunchKernelGGL(maxpool_hw_bwd_kernel<true>, dim3(ew_grid(total)), dim3(256), 0,
+                       (hipStream_t)stream, (const uint16_t*)dy, idx, (uint16_t*)dx, N * T, H, W, Ho,
+                       Wo, C, dy_ld, dx_ld);
+  else
+    hipLaunchKernelGGL(maxpool_hw_bwd_kernel<false>, dim3(ew_grid(total)), dim3(256), 0,
+                       (hipStream_t)stream, (const uint16_t*)dy, idx, (uint16_t*)dx, N * T, H, W, Ho,
+                       Wo, C, dy_ld, dx_ld);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }

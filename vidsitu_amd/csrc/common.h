@@ -61,6 +61,15 @@ __device__ __forceinline__ uint4 pack8_bf16(const float* f) {
   return v;
 }
 
+// x = q * d + r for 0 <= x < 2^24, rcp = 1.0f / d (float quotient, two fix-ups): ~8 instructions where a runtime
+// 32-bit integer division is ~40 and a 64-bit one ~100+
+__device__ __forceinline__ void fast_divmod(int x, int d, float rcp, int& q, int& r) {
+  q = (int)((float)x * rcp);
+  r = x - q * d;
+  if (r < 0) { r += d; --q; }
+  if (r >= d) { r -= d; ++q; }
+}
+
 __device__ __forceinline__ float wave_reduce_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

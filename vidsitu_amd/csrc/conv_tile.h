@@ -56,13 +56,6 @@ struct ConvP {
 
 #define VS_OOB 0x80000000u  // byte offset beyond any tensor: buffer_load returns zeros
 
-// x = q * d + r for 0 <= x < 2^24, rcp = 1.0f / d (float quotient, two fix-ups)
-__device__ __forceinline__ void fast_divmod(int x, int d, float rcp, int& q, int& r) {
-  q = (int)((float)x * rcp);
-  r = x - q * d;
-  if (r < 0) { r += d; --q; }
-  if (r >= d) { r -= d; ++q; }
-}
 
 __device__ __forceinline__ void mask8(float* f, unsigned bits) {
 #pragma unroll
