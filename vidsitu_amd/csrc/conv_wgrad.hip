@@ -201,9 +201,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
         const int pp = chunk0 + i;
         int4 e = make_int4(0, -(1 << 20), -(1 << 20), -(1 << 20));
         if (pp < cend) {
-          const int wo = pp % p.Wo, t1 = pp / p.Wo;
-          const int ho = t1 % p.Ho, t2 = t1 / p.Ho;
-          const int to = t2 % p.To, n = t2 / p.To;
+          int wo, t1, ho, t2, to, n;
+          if (p.P < (1 << 24)) {
+            fast_divmod(pp, p.Wo, 1.0f / (float)p.Wo, t1, wo);
+            fast_divmod(t1, p.Ho, 1.0f / (float)p.Ho, t2, ho);
+            fast_divmod(t2, p.To, 1.0f / (float)p.To, n, to);
+          } else {
+            wo = pp % p.Wo; t1 = pp / p.Wo;
+            ho = t1 % p.Ho; t2 = t1 / p.Ho;
+            to = t2 % p.To; n = t2 / p.To;
+          }
           e.y = to * p.sT - p.pT;
           e.z = ho * p.sH - p.pH;
           e.w = wo * p.sW - p.pW;
@@ -326,6 +333,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradP p) {
                  : "memory");
   };
 
+  const bool small_p = p.P < (1 << 24);
+  const float rcpWo = 1.0f / (float)p.Wo, rcpHo = 1.0f / (float)p.Ho, rcpTo = 1.0f / (float)p.To;
   auto build_tab = [&](int chunk) __attribute__((always_inline)) {
     int2* tab = rowtab + (chunk & 1) * WG_ROWTAB;
     const int base = pbeg + chunk * WG_ROWTAB;
@@ -333,9 +342,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradP p) {
       const int pp = base + i;
       int2 e = make_int2(0, 0);
       if (pp < pend) {
-        const int wo = pp % p.Wo, t1 = pp / p.Wo;
-        const int ho = t1 % p.Ho, t2 = t1 / p.Ho;
-        const int to = t2 % p.To, n = t2 / p.To;
+        int wo, t1, ho, t2, to, n;
+        if (small_p) {  // float-reciprocal split (exact below 2^24 positions) instead of three integer divisions
+          fast_divmod(pp, p.Wo, rcpWo, t1, wo);
+          fast_divmod(t1, p.Ho, rcpHo, t2, ho);
+          fast_divmod(t2, p.To, rcpTo, n, to);
+        } else {
+          wo = pp % p.Wo; t1 = pp / p.Wo;
+          ho = t1 % p.Ho; t2 = t1 / p.Ho;
+          to = t2 % p.To; n = t2 / p.To;
+        }
         const int ti0 = to * p.sT - p.pT, hi0 = ho * p.sH - p.pH, wi0 = wo * p.sW - p.pW;
         const long long pos0 = (((long long)n * p.Ti + ti0) * p.Hi + hi0) * p.Wi + wi0;
         e.x = (int)(unsigned)(pos0 * p.x_ld * 2);  // exact modulo 2^32 whenever the tap is valid
