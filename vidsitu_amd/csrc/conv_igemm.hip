@@ -463,14 +463,59 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     };
 #pragma unroll
     for (int d = 0; d < D; ++d) dma(kbeg + d, d);
+    // A/B on one box (profiles/r02_ring_frags_first.txt): -8..-11 % on the long reductions (s4 / s5 first-block conv a
+    // both directions, [3,1,1] dgrads), +2 % on the 9..18-step 3x3 layers: on from 20 k-steps.  VS_RING_FRAGS_FIRST=0|1
+    // (bits 13 / 14 of the launch flags) forces it off / on.
+    const bool frags_first = (p.flags & (1 << 14)) != 0 || (!(p.flags & (1 << 13)) && nk >= 20);
     int st_c = 0, st_l = D;  // stage computed / stage refilled this step
     for (int kt = 0; kt < nk; ++kt) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"i"((D - 1) * L) : "memory");  // my part of tile kt landed
       __builtin_amdgcn_s_barrier();  // everyone's did; stage st_l (tile kt-1) is no longer read
       __builtin_amdgcn_sched_barrier(0);
-      dma(kbeg + kt + D, st_l);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(st_c);
+      if (frags_first) {
+        // the first fragment reads of this tile are issued BEFORE the copies of tile kt + D: the ~30 instructions
+        // of copy address arithmetic and issue run under the LDS latency instead of in front of it
+        const char* A = smem + st_c * STAGE;
+        const char* B = A + BM * 128;
+        bf16x8 af0[MR], bf0[NR], af1[MR], bf1[NR];
+#pragma unroll
+        for (int a = 0; a < MR; ++a) {
+          const int row = wm * TM + a * 16 + lr;
+          af0[a] = *(const bf16x8*)(A + row * 128 + ((lq ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int b = 0; b < NR; ++b) {
+          const int row = wn * TN + b * 16 + lr;
+          bf0[b] = *(const bf16x8*)(B + row * 128 + ((lq ^ ((row >> 1) & 7)) << 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        dma(kbeg + kt + D, st_l);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < MR; ++a) {
+          const int row = wm * TM + a * 16 + lr;
+          af1[a] = *(const bf16x8*)(A + row * 128 + (((4 + lq) ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int b = 0; b < NR; ++b) {
+          const int row = wn * TN + b * 16 + lr;
+          bf1[b] = *(const bf16x8*)(B + row * 128 + (((4 + lq) ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int a = 0; a < MR; ++a)
+#pragma unroll
+          for (int b = 0; b < NR; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0[a], bf0[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < MR; ++a)
+#pragma unroll
+          for (int b = 0; b < NR; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1[a], bf1[b], acc[a][b], 0, 0, 0);
+      } else {
+        dma(kbeg + kt + D, st_l);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(st_c);
+      }
       __builtin_amdgcn_sched_barrier(0);
       st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
       st_l = (st_l + 1 == NS) ? 0 : st_l + 1;
@@ -1219,6 +1264,10 @@ static void setup_stride_classes(ConvP& p, int bm, int mode, int flags) {
 
 static int launch_conv(ConvP& p, int mode, int naive, int flags, void* ws, size_t ws_bytes,
                        hipStream_t st) {
+  static const int frags_first = [] { const char* e = getenv("VS_RING_FRAGS_FIRST"); return e ? atoi(e) : -1; }();
+  p.flags &= ~(3 << 13);
+  if (frags_first == 1) p.flags |= 1 << 14;
+  if (frags_first == 0) p.flags |= 1 << 13;
   p.splitK = 1;
   p.slab = nullptr;
   if (naive) {
