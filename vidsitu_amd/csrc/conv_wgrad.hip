@@ -31,6 +31,8 @@ struct WgradP {
   int tilesM, tilesN, S, rows_per_split;
   unsigned x_bytes, dy_bytes;
   int xcd_order;  // 1: XCD-aware block order (default); 0: round-robin (VS_WGRAD_XCD=0, A/B)
+  int dbg;        // VS_WGRAD_DBG ablations of the ring kernel (wrong results; tools only): 1 no MFMA, 2 no copies in
+                  // the loop, 4 no vmcnt wait, 8 no barrier, 16 no fragment reads, 32 no table rebuild, 64 no epilogue
 };
 
 #define WG_OOB 0x80000000u
@@ -450,19 +452,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradP p) {
   for (int d = 0; d < D; ++d) dma(d, d);
   int st_c = 0, st_l = D;
   for (int st = 0; st < nsteps; ++st) {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"((D - 1) * L) : "memory");
-    __builtin_amdgcn_s_barrier();  // tile st landed everywhere; stage st_l and the old table are free
+    if (!(p.dbg & 4)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"((D - 1) * L) : "memory");
+    if (!(p.dbg & 8)) __builtin_amdgcn_s_barrier();  // tile st landed everywhere; stage st_l and the old table are free
     __builtin_amdgcn_sched_barrier(0);
-    if (MODE == 1 && (st & 15) == 0 && pbeg + ((st >> 4) + 1) * WG_ROWTAB < pend)
+    if (MODE == 1 && (st & 15) == 0 && pbeg + ((st >> 4) + 1) * WG_ROWTAB < pend && !(p.dbg & 32))
       build_tab((st >> 4) + 1);  // next chunk's table, first read >= 13 steps from now
-    dma(st + D, st_l);
+    if (!(p.dbg & 2)) dma(st + D, st_l);
     __builtin_amdgcn_sched_barrier(0);
-    compute(st_c);
+    if (!(p.dbg & 1)) compute(st_c);
     __builtin_amdgcn_sched_barrier(0);
     st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
     st_l = (st_l + 1 == NS) ? 0 : st_l + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if ((p.dbg & 64) && acc[0][0][0] != 123.456f) return;
 
   float* dst = p.out + (long long)s * p.Cout * p.Kp;
 #pragma unroll
@@ -764,6 +767,8 @@ static int wgrad_impl(const void* dy, const void* x, float* dw, const vs_conv_de
     // s3.c 24.7 -> 21.2, s2.c 29.7 -> 26.4), a loss from 36 tiles on (s4.b 36.7 -> 38.9, s5.b 48.9 -> 52.9), where
     // one split's tiles no longer fit an XCD's share of the grid anyway
     p.xcd_order = xo && c.tilesM * c.tilesN <= 32;
+    static const int dbg = [] { const char* e = getenv("VS_WGRAD_DBG"); return e ? atoi(e) : 0; }();
+    p.dbg = dbg;
   }
   p.rows_per_split = c.rows_per_split;
   const bool dense = (d->kT * d->kH * d->kW == 1) && d->sT == 1 && d->sH == 1 && d->sW == 1 &&
