@@ -41,7 +41,7 @@ print(f"{'layer':14s} {'x':>2s} {'M':>7s} {'N':>5s} {'K':>5s} " + " ".join(f"{kd
 for (M, N, K, k, s), (cnt, name, xin) in sorted(agg.items(), key=lambda kv: -2.0 * kv[0][0] * kv[0][1] * kv[0][2] * kv[1][0]):
     if "stem" in name:
         continue
-    if "--small" in sys.argv and not (N <= 32 and K <= 160):  # the register-resident small-channel kernel's layers
+    if "--small" in sys.argv and not (N <= 32 and K <= 192):  # the register-resident small-channel kernel's layers
         continue
     taps = k[0] * k[1] * k[2]
     cin = K // taps

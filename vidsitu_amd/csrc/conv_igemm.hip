@@ -666,7 +666,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(
 }
 
 // =============================================================================
-// Direct kernel for small-channel layers (fast pathway: N <= 32, K <= 160, taps <= 31).
+// Direct kernel for small-channel layers (fast pathway: N <= 32, K <= 192, taps <= 31).
 // Those GEMMs are a few MFMAs per 16 rows, so the tiled kernel above is all prologue /
 // barrier / epilogue.  Here there is no block-level cooperation at all: the whole weight
 // matrix sits in registers as B fragments, every lane fetches its A fragment (16 bytes =
@@ -994,7 +994,8 @@ static int launch_direct(const ConvP& p, int mode, hipStream_t st) {
     case 2: return launch_direct_ks<NT, 2>(p, mode, st);
     case 3: return launch_direct_ks<NT, 3>(p, mode, st);
     case 4: return launch_direct_ks<NT, 4>(p, mode, st);
-    default: return launch_direct_ks<NT, 5>(p, mode, st);
+    case 5: return launch_direct_ks<NT, 5>(p, mode, st);
+    default: return launch_direct_ks<NT, 6>(p, mode, st);
   }
 }
 
@@ -1200,7 +1201,8 @@ static ConvPlan plan_conv(long long M, int Ncols, int K, int taps, int flags) {
     pl.tile = kTileTable[forced - 1];
     return pl;
   }
-  if (Ncols <= 32 && K <= 160 && taps <= 31 && M >= 64) {
+  // (K <= 192: s3's fast-pathway conv a, 64 -> 16 [3,1,1], 24.1 us on the 256 x 16 tile, joins the register-resident kernel)
+  if (Ncols <= 32 && K <= 192 && taps <= 31 && M >= 64) {
     pl.direct = true;
     pl.tile = kTileTable[5];
     return pl;
