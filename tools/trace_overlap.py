@@ -35,3 +35,23 @@ for a, b, n in s:
 print("top kernels by in-situ time (last step):")
 for k, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:25]:
     print(f"  {t / 1e3:8.1f} us {c:4d} x {t / c / 1e3:7.1f}  {k}")
+
+# the encoder / head section of a train step: from the end of the last average pool (forward) to the start of the
+# first average-pool backward -- one stream, nothing else running
+names = [n for _, _, n in s]
+try:
+    i1 = min(i for i, n in enumerate(names) if n.startswith("avgpool_bwd"))
+    i0 = max(i for i, n in enumerate(names[:i1]) if n.startswith("avgpool_fwd"))
+    sec = s[i0 + 1:i1]
+    span = s[i1][0] - s[i0][1]
+    busy = sum(b - a for a, b, _ in sec)
+    print(f"encoder / head section: {len(sec)} kernels, span {span / 1e3:.1f} us, kernel time {busy / 1e3:.1f} us, "
+          f"gaps {(span - busy) / 1e3:.1f} us")
+    agg2 = collections.defaultdict(lambda: [0, 0])
+    for a, b, n in sec:
+        k = n.split("(")[0][:60]
+        agg2[k][0] += b - a; agg2[k][1] += 1
+    for k, (t, c) in sorted(agg2.items(), key=lambda kv: -kv[1][0])[:14]:
+        print(f"  {t / 1e3:7.1f} us {c:3d} x {t / c / 1e3:6.1f}  {k}")
+except ValueError:
+    pass

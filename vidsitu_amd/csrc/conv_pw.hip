@@ -225,7 +225,9 @@ bool vs_pw_plan(const ConvP& p, int mode, int flags, PwGeo* out) {
   if (fixed + nslot * PW_SLOT > 160 * 1024) return false;
   const int occ = (fixed + nslot * PW_SLOT) * 2 <= 160 * 1024 ? 2 : 1;
   const bool forced = on == 2 || (flags & VS_CONV_FORCEPW) || f_ns || f_occ || f_bn;
-  if (!forced && (occ < 2 || g.nk > 2 || !p.dense || p.Ncols < 128)) return false;
+  // (not the dgrad + BN-backward-sums form: its epilogue reads two more tensors per tile with nothing to hide them behind --
+  //  123 us per launch in the step's timeline against ~40 on the tile kernel)
+  if (!forced && (occ < 2 || g.nk > 2 || !p.dense || p.Ncols < 128 || bnb)) return false;
   g.nslot = nslot;
   g.smem = fixed + nslot * PW_SLOT;
   g.nsl = (p.Ncols + g.bn - 1) / g.bn;
