@@ -279,6 +279,14 @@ int vs_linear_bwd_data(const float* dy, const float* wt, float* dx, int M, int N
                        void* stream);
 int vs_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, int M, int N,
                          int K, void* stream);
+/* Both of the above behind ONE launch for M <= 8 rows (N % 4 == 0, N <= 4096, 16-byte aligned dy / relu_y / wt):
+ * dx = dy_eff . W from the transposed image wt [K][N], dW = dy_eff^T x, db = column sums of dy_eff, where
+ * dy_eff = dy * (relu_y > 0) if relu_y (the layer's ReLU output) is given, else dy.  Bitwise the separate
+ * launches (relu backward, vs_linear_bwd_data, vs_linear_bwd_weight): the 8-token encoder / head section is a
+ * chain of ~6 us launches on the critical path of the step (LinearFn.backward of utils/transformer_code.py:61-75's
+ * Linear layers).  VS_ERR_UNSUPPORTED outside that envelope. */
+int vs_linear_bwd_fused(const float* dy, const float* relu_y, const float* x, const float* wt, float* dx,
+                        float* dw, float* db, int M, int N, int K, void* stream);
 
 /* softmax(Q_h K_h^T / scale) V_h for short sequences (L <= 16), per head.
  * q,k,v,o: [B, L, H*dh] fp32.  utils/transformer_code.py:33-48,60-68 --

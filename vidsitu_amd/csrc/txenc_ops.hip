@@ -107,15 +107,16 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
 // barrier) and every weight chunk of the wave's row is requested before anything is waited for.
 // The chunked kernel above pays a global-load latency plus two barriers per 256-wide K chunk,
 // which at M = 8 (TxEncoder tokens of one rank) left each launch at ~10 us for 4 MB of weights.
+// (xmask: the rows of x are multiplied by (xmask > 0) while they are staged -- the ReLU backward of the layer whose
+//  output gradient x is, fused into the data-gradient product; bid: the block's index within this product)
 template <int MT, int KC>  // KC = number of 256-wide K chunks held in registers (K <= 256 * KC)
-__global__ __launch_bounds__(256) void linear_fullx_kernel(const float* __restrict__ x,
-                                                           const float* __restrict__ w,
-                                                           const float* __restrict__ b,
-                                                           const float* res, float* y, int M, int N,
-                                                           int K, int act) {
+__device__ __forceinline__ void linear_fullx_body(const float* __restrict__ x, const float* __restrict__ xmask,
+                                                  const float* __restrict__ w, const float* __restrict__ b,
+                                                  const float* res, float* y, int M, int N, int K, int act,
+                                                  int bid) {
   extern __shared__ float4 xs4[];  // [MT][K/4]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + wave;
+  const int n = bid * 4 + wave;
   const int K4 = K >> 2;
   float4 wv[KC];
 #pragma unroll
@@ -133,7 +134,12 @@ __global__ __launch_bounds__(256) void linear_fullx_kernel(const float* __restri
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const bool ok = m < M && k4 < K4;
-      const float4 v = *(const float4*)(x + (ok ? (long long)m * K + k4 * 4 : 0));
+      float4 v = *(const float4*)(x + (ok ? (long long)m * K + k4 * 4 : 0));
+      if (xmask) {
+        const float4 mk = *(const float4*)(xmask + (ok ? (long long)m * K + k4 * 4 : 0));
+        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+        v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+      }
       t[m] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (k4 < K4) {
@@ -173,6 +179,15 @@ __global__ __launch_bounds__(256) void linear_fullx_kernel(const float* __restri
     if (res) s += res[(long long)lane * N + n];
     y[(long long)lane * N + n] = s;
   }
+}
+
+template <int MT, int KC>
+__global__ __launch_bounds__(256) void linear_fullx_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ w,
+                                                           const float* __restrict__ b,
+                                                           const float* res, float* y, int M, int N,
+                                                           int K, int act) {
+  linear_fullx_body<MT, KC>(x, nullptr, w, b, res, y, M, N, K, act, blockIdx.x);
 }
 
 template <int MT, int KC>
@@ -606,12 +621,13 @@ extern "C" int vs_linear_bwd_data(const float* dy, const float* wt, float* dx, i
 // of a batch in flight before the first use (a row-at-a-time loop with the vector / scalar choice made at
 // run time was a chain of M memory latencies: 7.5 us at M = 8, on the critical path of the train step).
 template <bool VEC>
-__global__ void linear_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                         float* dw, float* db, int M, int N, int K) {
+__device__ __forceinline__ void linear_bwd_weight_body(const float* __restrict__ dy, const float* __restrict__ dymask,
+                                                       const float* __restrict__ x, float* dw, float* db, int M,
+                                                       int N, int K, int bid, int nblocks) {
   const int K4 = (K + 3) / 4;
   const long long total = (long long)N * K4;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
+  for (long long i = (long long)bid * blockDim.x + threadIdx.x; i < total;
+       i += (long long)nblocks * blockDim.x) {
     const int n = (int)(i / K4);
     const int k = (int)(i - (long long)n * K4) * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -623,6 +639,7 @@ __global__ void linear_bwd_weight_kernel(const float* __restrict__ dy, const flo
       for (int u = 0; u < 8; ++u) {
         const int m = m0 + u < M ? m0 + u : 0;  // clamped: branch-free loads
         dd[u] = dy[(long long)m * N + n];
+        if (dymask) dd[u] = dymask[(long long)m * N + n] > 0.f ? dd[u] : 0.f;
         const float* src = x + (long long)m * K + k;
         if (VEC) {
           xv[u] = *(const float4*)src;
@@ -655,6 +672,72 @@ __global__ void linear_bwd_weight_kernel(const float* __restrict__ dy, const flo
     }
     if (db && k == 0) db[n] = bsum;
   }
+}
+
+template <bool VEC>
+__global__ void linear_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                         float* dw, float* db, int M, int N, int K) {
+  linear_bwd_weight_body<VEC>(dy, nullptr, x, dw, db, M, N, K, blockIdx.x, gridDim.x);
+}
+
+// Both gradients of y = x W^T (+ b) behind ONE launch for the few-row case (the 8 tokens of the encoder / heads):
+// blocks [0, g1) are the data-gradient product dx = dy_eff . W on the transposed image wt (linear_fullx_body),
+// blocks [g1, g1 + g2) the weight gradient dW = dy_eff^T x, db = colsum dy_eff (linear_bwd_weight_body), with
+// dy_eff = dy * (relu_y > 0) when the layer had a ReLU -- bitwise the three launches (relu_bwd, bwd_data,
+// bwd_weight) this replaces; every launch of this section is ~6 us of pure latency on the step's critical path.
+template <int MT, int KC, bool VEC>
+__global__ __launch_bounds__(256) void linear_bwd_fused_kernel(const float* __restrict__ dy,
+                                                               const float* __restrict__ relu_y,
+                                                               const float* __restrict__ x,
+                                                               const float* __restrict__ wt, float* dx, float* dw,
+                                                               float* db, int M, int N, int K, int g1, int g2) {
+  if ((int)blockIdx.x < g1)
+    linear_fullx_body<MT, KC>(dy, relu_y, wt, nullptr, nullptr, dx, M, K, N, 0, blockIdx.x);
+  else
+    linear_bwd_weight_body<VEC>(dy, relu_y, x, dw, db, M, N, K, blockIdx.x - g1, g2);
+}
+
+template <int KC, bool VEC>
+static void launch_bwd_fused(const float* dy, const float* relu_y, const float* x, const float* wt, float* dx,
+                             float* dw, float* db, int M, int N, int K, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)linear_bwd_fused_kernel<8, KC, VEC>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  size_t smem = (size_t)8 * N * 4;  // the staged dy rows (the product's inner dimension is N)
+  if (smem < (size_t)4 * 8 * 65 * 4) smem = (size_t)4 * 8 * 65 * 4;
+  const int g1 = (K + 3) / 4;  // four output columns (of dx) per block
+  long long g2 = ((long long)N * ((K + 3) / 4) + 255) / 256;
+  if (g2 > 4096) g2 = 4096;
+  hipLaunchKernelGGL((linear_bwd_fused_kernel<8, KC, VEC>), dim3((unsigned)(g1 + g2)), dim3(256), smem, st, dy,
+                     relu_y, x, wt, dx, dw, db, M, N, K, g1, (int)g2);
+}
+
+extern "C" int vs_linear_bwd_fused(const float* dy, const float* relu_y, const float* x, const float* wt, float* dx,
+                                   float* dw, float* db, int M, int N, int K, void* stream) {
+  VS_CHECK_ARG(dy && x && wt && dx && dw && M > 0 && N > 0 && K > 0, "bad args");
+  const uintptr_t al = (uintptr_t)dy | (uintptr_t)relu_y | (uintptr_t)wt;
+  if (M > 8 || (N & 3) || N > 4096 || (al & 15)) {
+    vs_set_error("vs_linear_bwd_fused: M <= 8, N %% 4 == 0, N <= 4096 and 16-byte aligned dy / relu_y / wt "
+                 "(use vs_linear_bwd_data + vs_linear_bwd_weight)");
+    return VS_ERR_UNSUPPORTED;
+  }
+  const bool vec = (K & 3) == 0 && ((((uintptr_t)x | (uintptr_t)dw)) & 15) == 0;
+  hipStream_t st = (hipStream_t)stream;
+#define VS_LBF(KC_) (vec ? launch_bwd_fused<KC_, true>(dy, relu_y, x, wt, dx, dw, db, M, N, K, st) \
+                         : launch_bwd_fused<KC_, false>(dy, relu_y, x, wt, dx, dw, db, M, N, K, st))
+  if (N <= 1024) VS_LBF(4);
+  else if (N <= 2048) VS_LBF(8);
+  else VS_LBF(16);
+#undef VS_LBF
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    vs_set_error("vs_linear_bwd_fused: launch failed: %s", hipGetErrorString(e));
+    return VS_ERR_LAUNCH;
+  }
+  return VS_OK;
 }
 
 extern "C" int vs_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, int M,
@@ -1034,13 +1117,12 @@ __global__ void add_layernorm_bwd_param_kernel(const float* dy, const float* x, 
 
 // D % 4 == 0: 16-byte branch-free loads, everything in flight before the first use (the scalar kernel's
 // `if (d < D)` loads were serialised round trips: 18 us for 8 x 1024)
-__global__ __launch_bounds__(256) void add_layernorm_bwd_dx_vec_kernel(
+template <int NE>  // float4 columns per lane: D <= 256 * NE
+__device__ __forceinline__ void add_layernorm_bwd_dx_vec_body(
     const float* dy, const float* x, const float* r, const float* rmask, const float* gamma,
-    const float* mean, const float* rstd, float* dx, float* dr, int rows, int D) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const float* mean, const float* rstd, float* dx, float* dr, int rows, int D, int row) {
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
-  constexpr int NE = LN_MAXE / 4;
   const int D4 = D >> 2;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const long long base = (long long)row * D4;
@@ -1100,15 +1182,22 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_dx_vec_kernel(
   }
 }
 
+__global__ __launch_bounds__(256) void add_layernorm_bwd_dx_vec_kernel(
+    const float* dy, const float* x, const float* r, const float* rmask, const float* gamma,
+    const float* mean, const float* rstd, float* dx, float* dr, int rows, int D) {
+  add_layernorm_bwd_dx_vec_body<LN_MAXE / 4>(dy, x, r, rmask, gamma, mean, rstd, dx, dr, rows, D,
+                                             blockIdx.x * 4 + (threadIdx.x >> 6));
+}
+
 // dgamma / dbeta: a block owns 64 columns, its 16 waves take rows w, w+16, ... (256-byte row pieces,
 // four rows of loads in flight), partial sums meet in LDS in wave order (bitwise reproducible).  The
 // one-thread-per-column loop over all rows was a chain of rows x latency (600-row decoder batches).
-__global__ __launch_bounds__(1024) void add_layernorm_bwd_param_rows_kernel(
+__device__ __forceinline__ void add_layernorm_bwd_param_rows_body(
     const float* dy, const float* x, const float* r, const float* rmask, const float* mean,
-    const float* rstd, float* dgamma, float* dbeta, int rows, int D) {
+    const float* rstd, float* dgamma, float* dbeta, int rows, int D, int bid) {
   __shared__ float sg[16][64], sb[16][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int d = blockIdx.x * 64 + lane;
+  const int d = bid * 64 + lane;
   const bool okd = d < D;
   const int dc = okd ? d : 0;
   float ag = 0.f, ab = 0.f;
@@ -1147,6 +1236,25 @@ __global__ __launch_bounds__(1024) void add_layernorm_bwd_param_rows_kernel(
   }
 }
 
+__global__ __launch_bounds__(1024) void add_layernorm_bwd_param_rows_kernel(
+    const float* dy, const float* x, const float* r, const float* rmask, const float* mean,
+    const float* rstd, float* dgamma, float* dbeta, int rows, int D) {
+  add_layernorm_bwd_param_rows_body(dy, x, r, rmask, mean, rstd, dgamma, dbeta, rows, D, blockIdx.x);
+}
+
+// Both passes behind one launch (few rows: the encoder's 8 tokens): blocks [0, g1) are the input-gradient pass with
+// 16 rows per 1024-thread block, blocks [g1, ..) the parameter-gradient pass -- the same bodies, bitwise the two
+// launches; one ~6 us launch less per LayerNorm on the step's critical path.
+__global__ __launch_bounds__(1024) void add_layernorm_bwd_fused_kernel(
+    const float* dy, const float* x, const float* r, const float* rmask, const float* gamma, const float* mean,
+    const float* rstd, float* dx, float* dr, float* dgamma, float* dbeta, int rows, int D, int g1) {
+  if ((int)blockIdx.x < g1)
+    add_layernorm_bwd_dx_vec_body<4>(dy, x, r, rmask, gamma, mean, rstd, dx, dr, rows, D,  // D <= 1024: 128 VGPRs
+                                     blockIdx.x * 16 + (threadIdx.x >> 6));
+  else
+    add_layernorm_bwd_param_rows_body(dy, x, r, rmask, mean, rstd, dgamma, dbeta, rows, D, blockIdx.x - g1);
+}
+
 extern "C" int vs_add_layernorm_bwd(const float* dy, const float* x, const float* r,
                                     const float* rmask, const float* gamma, const float* mean,
                                     const float* rstd, float* dx, float* dr, float* dgamma,
@@ -1155,6 +1263,14 @@ extern "C" int vs_add_layernorm_bwd(const float* dy, const float* x, const float
   VS_CHECK_ARG(D >= 1 && D <= 64 * LN_MAXE, "D <= 2048");
   const uintptr_t al = (uintptr_t)dy | (uintptr_t)x | (uintptr_t)r | (uintptr_t)rmask | (uintptr_t)gamma |
                        (uintptr_t)dx | (uintptr_t)dr;
+  static const int fuse = [] { const char* e = getenv("VS_LN_BWD_FUSED"); return e ? atoi(e) : 1; }();
+  if (fuse && (D & 3) == 0 && D <= 1024 && (al & 15) == 0 && rows <= 64) {
+    const int g1 = (rows + 15) / 16;
+    hipLaunchKernelGGL(add_layernorm_bwd_fused_kernel, dim3(g1 + (D + 63) / 64), dim3(1024), 0, (hipStream_t)stream,
+                       dy, x, r, rmask, gamma, mean, rstd, dx, dr, dgamma, dbeta, rows, D, g1);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+  }
   if ((D & 3) == 0 && (al & 15) == 0)
     hipLaunchKernelGGL(add_layernorm_bwd_dx_vec_kernel, dim3((rows + 3) / 4), dim3(256), 0,
                        (hipStream_t)stream, dy, x, r, rmask, gamma, mean, rstd, dx, dr, rows, D);

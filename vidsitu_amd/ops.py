@@ -634,13 +634,34 @@ def linear_fwd(x, w, b=None, relu=False):
     return y
 
 
-def linear_bwd(dy, x, w, need_dx=True, has_bias=True, dw_out=None, db_out=None, wt=None):
+_LINEAR_BWD_FUSED = _os.environ.get("VS_LINEAR_BWD_FUSED", "1") != "0"  # A/B: 0 = relu_bwd + bwd_data + bwd_weight launches
+
+
+def linear_bwd(dy, x, w, need_dx=True, has_bias=True, dw_out=None, db_out=None, wt=None, relu_y=None):
     """dw_out / db_out: write the parameter gradients in place (gradient-arena views).
-    wt: an up-to-date [K][N] image of w (the parameter arena keeps one); else transposed here."""
+    wt: an up-to-date [K][N] image of w (the parameter arena keeps one); else transposed here.
+    relu_y: the layer's ReLU output -- dy is masked by (relu_y > 0) inside the kernels (no relu_bwd launch)."""
     dy, x, w = _f32c(dy), _f32c(x), _f32c(w)
     m, n = dy.shape
     k = x.shape[1]
     dx = None
+    if need_dx and _LINEAR_BWD_FUSED and m <= 8 and n % 4 == 0 and n <= 4096 and dy.data_ptr() % 16 == 0 \
+            and (relu_y is None or relu_y.data_ptr() % 16 == 0):
+        # few rows (the encoder / head section of the step): both gradients and the ReLU mask behind one launch
+        if wt is None:
+            wt = torch.empty((k, n), dtype=torch.float32, device=x.device)
+            _lib.call("vs_transpose_f32", _ptr(w), _ptr(wt), n, k, _stream())
+        if wt.data_ptr() % 16 == 0:
+            dx = torch.empty((m, k), dtype=torch.float32, device=x.device)
+            dw = dw_out if dw_out is not None else torch.empty((n, k), dtype=torch.float32, device=x.device)
+            db = None
+            if has_bias:
+                db = db_out if db_out is not None else torch.empty(n, dtype=torch.float32, device=x.device)
+            _lib.call("vs_linear_bwd_fused", _ptr(dy), _ptr(relu_y), _ptr(x), _ptr(wt), _ptr(dx), _ptr(dw), _ptr(db),
+                      m, n, k, _stream())
+            return dx, dw, db
+    if relu_y is not None:
+        dy = relu_bwd(dy, relu_y)
     if need_dx:
         if wt is None:
             wt = torch.empty((k, n), dtype=torch.float32, device=x.device)

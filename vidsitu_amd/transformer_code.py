@@ -38,8 +38,6 @@ class LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x2, w, y = ctx.saved_tensors
         dy2 = dy.reshape(-1, w.shape[0])
-        if ctx.relu:
-            dy2 = ops.relu_bwd(dy2, y)  # one launch (compare + cast + multiply were three)
         direct = ctx.w_param is not None and ctx.w_param.grad is not None and \
             (not ctx.has_bias or (ctx.b_param is not None and ctx.b_param.grad is not None))
         wt = ctx.w_wt  # the arena's transposed image (refreshed once per step)
@@ -51,7 +49,8 @@ class LinearFn(torch.autograd.Function):
         dx, dw, db = ops.linear_bwd(
             dy2.contiguous(), x2, w, need_dx=ctx.needs_input_grad[0], has_bias=ctx.has_bias,
             dw_out=ctx.w_param.grad if direct else None,
-            db_out=ctx.b_param.grad if (direct and ctx.has_bias) else None, wt=wt)
+            db_out=ctx.b_param.grad if (direct and ctx.has_bias) else None, wt=wt,
+            relu_y=y if ctx.relu else None)  # the ReLU mask is applied inside the gradient kernels
         dx = dx.reshape(ctx.shp) if dx is not None else None
         if direct:
             return dx, None, None, None
