@@ -55,6 +55,8 @@ typedef enum vs_status {
                                   weight-resident kernel (A/B, tests) */
 #define VS_CONV_DIRECTBNB (1 << 25) /* dgrad on the small-channel kernel: let it emit the BN-backward sums (measured
                                        slower in the step than the separate reduce pass; A/B, tests) */
+#define VS_CONV_BNB2 (1 << 26) /* dgrad that emits the sums of TWO BN units (vs_dgrad_epilogue.bn_y2 ...): set it in the desc
+                                  of both vs_conv_dgrad_bnstats_rows and the launch (the tile kernel's variant only) */
 #define VS_CONV_FORCEPW (1 << 24) /* run it on that kernel whenever the shape is eligible, also where the plan would
                                      not (one block per CU; A/B, tests) */
 
@@ -168,6 +170,14 @@ typedef struct vs_dgrad_epilogue {
   const float* gamma;
   const float* beta;
   float* stats_partial;
+  /* A second BN unit fed by the same masked gradient (RESIDUAL form, unit-stride dgrads): the shortcut unit of the
+   * ResBlock whose c unit is described above -- its saved conv output, mean, invstd; stats_partial2 gets
+   * [rows][2][Cin] with the same sum(g) and this unit's sum(g * xhat).  All NULL / 0: off. */
+  const void* bn_y2;
+  int bn_y2_ld;
+  const float* mean2;
+  const float* invstd2;
+  float* stats_partial2;
 } vs_dgrad_epilogue;
 int vs_conv_dgrad_ex(const void* dy, const void* wt, void* dx, const vs_conv_desc* d,
                      const vs_dgrad_epilogue* ep, void* workspace, size_t ws_bytes, void* stream);

@@ -877,3 +877,47 @@ def test_small_channel_dgrad_emits_bn_backward_sums(case, dev):
     gm = torch.where(_unpack_bits(ubits, x_shape), dxr.float(), torch.zeros((), device=dev))
     want = torch.stack([gm.double().sum((0, 2, 3, 4)), (gm * xh).double().sum((0, 2, 3, 4))]).cpu()
     assert float((psb.double().sum(0).cpu() - want).abs().max()) / float(want.abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("case", [("pw_256_64", 2, 256, 4, 28, 28, 64, (1, 1, 1), (0, 0, 0)),
+                                  ("t3_256_64", 1, 256, 8, 14, 14, 64, (3, 1, 1), (1, 0, 0)),
+                                  ("pw_64_16_small", 2, 64, 8, 20, 20, 16, (1, 1, 1), (0, 0, 0))],
+                         ids=lambda c: c[0])
+def test_dgrad_emits_the_sums_of_two_bn_units_fed_by_one_gradient(case, dev):
+    """`vs_dgrad_epilogue.bn_y2 ...`: the conv-a data gradient of the block BEHIND a shortcut block is the complete
+    masked output gradient of that block -- of its c unit and of its shortcut unit alike.  One epilogue emits both
+    units' BN-backward sums: the same sum(g), each unit's sum(g * xhat); dx and the first unit's sums bitwise the
+    single-unit launch."""
+    from vidsitu_amd import ops
+
+    name, n, cin, t, h, w, cout, k, p = case
+    s = (1, 1, 1)
+    g = torch.Generator().manual_seed(131)
+    x_shape = (n, cin, t, h, w)
+    wgt = rb(torch.randn(cout, cin, *k, generator=g) / (cin * k[0] * k[1] * k[2]) ** 0.5)
+    ys = ops.conv_out_shape(x_shape, cout, k, s, p)
+    dya = to_act(rb(torch.randn(ys, generator=g)), dev)
+    wt = ops.weight_transpose(to_w(wgt, dev))
+    rr = to_act(rb(torch.randn(x_shape, generator=g)), dev)
+    rows = ops.act_rows(rr)
+    rbits = torch.randint(0, 256, (rows, cin // 8), generator=g, dtype=torch.uint8).to(dev)
+    ubits = torch.randint(0, 256, (rows, cin // 8), generator=g, dtype=torch.uint8).to(dev)
+    y1 = to_act(rb(torch.randn(x_shape, generator=g)), dev)
+    y2 = to_act(rb(torch.randn(x_shape, generator=g)), dev)
+    m1, m2 = (torch.randn(cin, generator=g) * 0.2).to(dev), (torch.randn(cin, generator=g) * 0.2).to(dev)
+    i1, i2 = (torch.rand(cin, generator=g) + 0.5).to(dev), (torch.rand(cin, generator=g) + 0.5).to(dev)
+    one = ops.conv_dgrad(dya, wt, x_shape, k, s, p, residual=rr, residual_bits=rbits,
+                         bn_stats=(y1, m1, i1, None, None, ubits))
+    if one[1] is None:
+        pytest.skip("this plan does not emit BN-backward sums")
+    dx, p1, p2 = ops.conv_dgrad(dya, wt, x_shape, k, s, p, residual=rr, residual_bits=rbits,
+                                bn_stats=(y1, m1, i1, None, None, ubits), bn_stats2=(y2, m2, i2))
+    assert p2 is not None and tuple(p2.shape) == tuple(p1.shape)
+    assert torch.equal(dx.view(torch.int16), one[0].view(torch.int16)) and torch.equal(p1, one[1])
+    assert torch.equal(p2[:, 0], p1[:, 0])  # the same sum(g)
+    v = lambda a: a.view(1, -1, 1, 1, 1)
+    gm = torch.where(_unpack_bits(ubits, x_shape), dx.float(), torch.zeros((), device=dev))
+    xh2 = (y2.float() - v(m2)) * v(i2)
+    want = (gm * xh2).double().sum((0, 2, 3, 4)).cpu()
+    got = p2[:, 1].double().sum(0).cpu()
+    assert float((got - want).abs().max()) / float(want.abs().max()) < 1e-5

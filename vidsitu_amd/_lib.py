@@ -35,7 +35,8 @@ class DgradEpilogue(C.Structure):
     _fields_ = [("residual", C.c_void_p), ("residual_bits", C.c_void_p), ("bn_y", C.c_void_p),
                 ("bn_y_ld", C.c_int32), ("relu_bits", C.c_void_p), ("mean", C.c_void_p),
                 ("invstd", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
-                ("stats_partial", C.c_void_p)]
+                ("stats_partial", C.c_void_p), ("bn_y2", C.c_void_p), ("bn_y2_ld", C.c_int32),
+                ("mean2", C.c_void_p), ("invstd2", C.c_void_p), ("stats_partial2", C.c_void_p)]
 
 
 _p, _i, _i64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t

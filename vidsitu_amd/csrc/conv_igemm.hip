@@ -37,7 +37,8 @@ struct ConvSmem {
 // (`buffer_load_dwordx4 ... lds`, NS-1 tiles in flight, one raw barrier per k-step).
 // BNB: the dgrad variant that also emits the consumer BN's backward sums (VS_CONV_BNBWD); a template flag
 // so that the extra epilogue registers do not count against every other launch's occupancy.
-template <int BM, int BN, int WM, int WN, int MODE, bool FAST, int DBG = 0, int NS = 0, bool BNB = false>
+template <int BM, int BN, int WM, int WN, int MODE, bool FAST, int DBG = 0, int NS = 0, bool BNB = false,
+          bool BNB2 = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int AI = BM / 32;
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   }
 
   // ---------------- epilogue ----------------
-  conv_tile_epilogue<BM, BN, WM, WN, BNB>(p, acc, smem, statbuf, tm, n0, [&](int row) {
+  conv_tile_epilogue<BM, BN, WM, WN, BNB, false, BNB2>(p, acc, smem, statbuf, tm, n0, [&](int row) {
     return (MODE == 2) ? rowpos[row] : (m0 + row < p.M ? m0 + row : -1);
   });
 }
@@ -1080,15 +1081,15 @@ static TileCfg pick_tile(long long M, int Ncols, int K, int* ring) {
   return c;
 }
 
-template <int BM, int BN, int WM, int WN, int MODE, int NS, bool BNB = false>
+template <int BM, int BN, int WM, int WN, int MODE, int NS, bool BNB = false, bool BNB2 = false>
 static int launch_one(const ConvP& p, int grid, size_t smem, hipStream_t st) {
   static bool attr_done = false;  // dynamic LDS above 64 KiB needs an explicit opt-in, once per kernel
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, MODE, true, 0, NS, BNB>,
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, MODE, true, 0, NS, BNB, BNB2>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MODE, true, 0, NS, BNB>), dim3(grid), dim3(256),
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, MODE, true, 0, NS, BNB, BNB2>), dim3(grid), dim3(256),
                      smem, st, p);
   VS_CHECK_LAUNCH();
   return VS_OK;
@@ -1101,6 +1102,10 @@ template <int BM, int BN, int WM, int WN, int NS>
 static int launch_mode(const ConvP& p, int mode, int grid, size_t smem, hipStream_t st) {
   if (p.flags & VS_CONV_BNBWD) {
     if constexpr ((BN == 128 && (BM == 128 || BM == 64)) || (BM == 64 && BN == 64)) {
+      if (p.bny2) {  // + the shortcut unit's sums (unit-stride dgrads only: dgrad_impl checks)
+        if (mode == 0) return launch_one<BM, BN, WM, WN, 0, NS, true, true>(p, grid, smem, st);
+        return launch_one<BM, BN, WM, WN, 1, NS, true, true>(p, grid, smem, st);
+      }
       if (mode == 0) return launch_one<BM, BN, WM, WN, 0, NS, true>(p, grid, smem, st);
       if (mode == 1) return launch_one<BM, BN, WM, WN, 1, NS, true>(p, grid, smem, st);
       return launch_one<BM, BN, WM, WN, 2, NS, true>(p, grid, smem, st);
@@ -1281,6 +1286,7 @@ static int launch_conv(ConvP& p, int mode, int naive, int flags, void* ws, size_
   }
   {
     HaloGeo hg;
+    if (flags & VS_CONV_BNB2) flags |= VS_CONV_NOHALO | VS_CONV_NOPW;  // two-unit sums: the tile kernel's variant only
     if (vs_halo_plan(p, mode, p.tmul < 0, flags, &hg)) {  // unit-stride [kT,1,1] / [1,kH,kW]: halo-image kernel
       p.tilesM = hg.tilesM;
       p.tilesN = hg.tilesN;
@@ -1367,6 +1373,7 @@ static int fill_fwd_params(ConvP& p, const vs_conv_desc* d) {
   p.bn_bits = nullptr;
   p.bny_ld = 0;
   p.res_bits = nullptr;
+  p.bny2 = nullptr; p.bn_mean2 = p.bn_invstd2 = nullptr; p.stats2 = nullptr; p.bny2_ld = 0;
   p.M = d->N * d->To * d->Ho * d->Wo;
   p.Ncols = d->Cout;
   p.K = d->kT * d->kH * d->kW * d->Cin;
@@ -1498,6 +1505,7 @@ static int fill_dgrad_params(ConvP& p, const vs_conv_desc* d) {
   p.bn_bits = nullptr;
   p.bny_ld = 0;
   p.res_bits = nullptr;
+  p.bny2 = nullptr; p.bn_mean2 = p.bn_invstd2 = nullptr; p.stats2 = nullptr; p.bny2_ld = 0;
   p.M = d->N * d->Ti * d->Hi * d->Wi;
   p.Ncols = d->Cin;
   p.K = d->kT * d->kH * d->kW * d->Cout;
@@ -1525,7 +1533,9 @@ static int dgrad_impl(const void* dy, const void* wt, void* dx, const vs_conv_de
                       const uint8_t* residual_bits,
                       void* workspace, size_t ws_bytes, void* stream, const void* bn_y, int bn_y_ld,
                       const uint8_t* relu_bits, const float* mean, const float* invstd, const float* gamma,
-                      const float* beta, float* stats_partial) {
+                      const float* beta, float* stats_partial, const void* bn_y2 = nullptr, int bn_y2_ld = 0,
+                      const float* mean2 = nullptr, const float* invstd2 = nullptr,
+                      float* stats_partial2 = nullptr) {
   int rc = check_desc(d);
   if (rc) return rc;
   VS_CHECK_ARG(dy && wt && dx, "null tensor");
@@ -1563,6 +1573,16 @@ static int dgrad_impl(const void* dy, const void* wt, void* dx, const vs_conv_de
     p.bn_gamma = gamma;
     p.bn_beta = beta;
     p.bn_bits = relu_bits;
+    if (stats_partial2) {
+      VS_CHECK_ARG(has_res && bn_y2 && mean2 && invstd2 && bn_y2_ld >= d->Cin && bn_y2_ld % 8 == 0,
+                   "second BN unit: RESIDUAL form only, with its saved conv output, mean and invstd");
+      VS_CHECK_ARG(mode != 2, "second BN unit: unit-stride data gradients only");
+      p.bny2 = (const uint16_t*)bn_y2;
+      p.bny2_ld = bn_y2_ld;
+      p.bn_mean2 = mean2;
+      p.bn_invstd2 = invstd2;
+      p.stats2 = stats_partial2;
+    }
   }
   return launch_conv(p, mode, (d->flags & VS_CONV_NAIVE) != 0, d->flags, workspace, ws_bytes,
                      (hipStream_t)stream);
@@ -1578,10 +1598,11 @@ extern "C" int vs_conv_dgrad_bnstats_rows(const vs_conv_desc* d) {
   if ((d->flags & VS_CONV_RESIDUAL) && mode == 2) return 0;
   {
     HaloGeo hg;
-    if (vs_halo_plan(p, mode, 1, d->flags, &hg)) return hg.tilesM;
+    const int pf = (d->flags & VS_CONV_BNB2) ? (d->flags | VS_CONV_NOHALO | VS_CONV_NOPW) : d->flags;
+    if (vs_halo_plan(p, mode, 1, pf, &hg)) return hg.tilesM;
     PwGeo pg;
     p.flags |= VS_CONV_BNBWD;
-    if (vs_pw_plan(p, mode, d->flags, &pg)) return pg.tilesM;
+    if (vs_pw_plan(p, mode, pf, &pg)) return pg.tilesM;
   }
   const ConvPlan pl = plan_conv(p.M, p.Ncols, p.K, p.kT * p.kH * p.kW, d->flags);
   if (pl.direct) {
@@ -1608,8 +1629,10 @@ extern "C" int vs_conv_dgrad_ex(const void* dy, const void* wt, void* dx, const 
                                 const vs_dgrad_epilogue* ep, void* workspace, size_t ws_bytes, void* stream) {
   VS_CHECK_ARG(ep != nullptr, "null epilogue description");
   VS_CHECK_ARG(!ep->stats_partial || ep->bn_y, "stats_partial needs the BN unit's operands");
+  VS_CHECK_ARG(!ep->stats_partial2 || ep->stats_partial, "stats_partial2 rides on stats_partial");
   return dgrad_impl(dy, wt, dx, d, ep->residual, ep->residual_bits, workspace, ws_bytes, stream, ep->bn_y,
-                    ep->bn_y_ld, ep->relu_bits, ep->mean, ep->invstd, ep->gamma, ep->beta, ep->stats_partial);
+                    ep->bn_y_ld, ep->relu_bits, ep->mean, ep->invstd, ep->gamma, ep->beta, ep->stats_partial,
+                    ep->bn_y2, ep->bn_y2_ld, ep->mean2, ep->invstd2, ep->stats_partial2);
 }
 
 extern "C" int vs_conv_dgrad_bnstats(const void* dy, const void* wt, void* dx, const vs_conv_desc* d,

@@ -51,6 +51,12 @@ struct ConvP {
   // BN-backward apply kernel of a bottleneck's last unit the write of its masked copy of dz (`dres`).
   const uint8_t* res_bits;
   int dense;  // pointwise, unit stride: row m is position m of the gathered tensor (no row decode)
+  // VS_CONV_BNBWD with RESIDUAL, second unit: a ResBlock's shortcut unit receives the same masked gradient as its c
+  // unit (one sum(g), two sum(g * xhat)): stats2[tm][0][c] = sum g, [1][c] = sum g * (bny2 - mean2) * invstd2
+  const uint16_t* bny2;
+  const float *bn_mean2, *bn_invstd2;
+  float* stats2;
+  int bny2_ld;
 };
 #define VS_CONV_BNBWD (1 << 20)
 
@@ -90,7 +96,7 @@ __device__ __forceinline__ void tile_sync() {
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool BNB, bool RAWSYNC = false, typename RowMap>
+template <int BM, int BN, int WM, int WN, bool BNB, bool RAWSYNC = false, bool TWO = false, typename RowMap>
 __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16],
                                                    char* smem, float* statbuf, int tm, int n0, RowMap rowm) {
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -264,15 +270,20 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
       const bool nok = n < p.Ncols;
       const int nn = nok ? n : 0;
       const int bpr = p.Ncols >> 3;
-      float mu[8], is[8], sg[8], sx[8];
+      constexpr bool two = TWO;  // also the shortcut unit's sums (same gradient, same mask); a template flag: the
+      // 54 extra registers of this path must not count against every other BN-sums launch's occupancy
+      float mu[8], is[8], sg[8], sx[8], mu2[8], is2[8], sx2[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         mu[e] = p.bn_mean[nn + e];
         is[e] = p.bn_invstd[nn + e];
+        mu2[e] = two ? p.bn_mean2[nn + e] : 0.f;
+        is2[e] = two ? p.bn_invstd2[nn + e] : 0.f;
         sg[e] = 0.f;
         sx[e] = 0.f;
+        sx2[e] = 0.f;
       }
-      uint4 yv4[IT], rv4[IT];
+      uint4 yv4[IT], rv4[IT], yw4[IT];
       unsigned bits[IT], rbits[IT];
       int mm[IT];
 #pragma unroll
@@ -282,6 +293,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
         mm[i] = nok ? m : -1;
         const long long mc = mm[i] >= 0 ? mm[i] : 0;
         yv4[i] = *(const uint4*)(p.bny + mc * p.bny_ld + nn);
+        yw4[i] = two ? *(const uint4*)(p.bny2 + mc * p.bny2_ld + nn) : make_uint4(0u, 0u, 0u, 0u);
         rv4[i] = *(const uint4*)(p.res + mc * p.res_ld + nn);
         bits[i] = p.bn_bits[mc * bpr + (nn >> 3)];
         rbits[i] = p.res_bits ? (unsigned)p.res_bits[mc * bpr + (nn >> 3)] : 0xffu;
@@ -309,6 +321,12 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
             sg[e] += g[e];
             sx[e] += g[e] * (yv[e] - mu[e]) * is[e];
           }
+          if (two) {
+            float yw[8];
+            unpack8_bf16(yw4[i], yw);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sx2[e] += g[e] * (yw[e] - mu2[e]) * is2[e];
+          }
         }
       }
       tile_sync<RAWSYNC>();  // every thread is done with the fp32 tile: its space holds the row-lane sums
@@ -319,6 +337,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
         red[tid * 16 + 8 + e] = sx[e];
       }
       tile_sync<RAWSYNC>();
+      float ts_keep = 0.f;
       if (tid < BN && n0 + tid < p.Ncols) {  // fixed order over the row lanes
         const int cc = tid >> 3, e = tid & 7;
         float ts = 0.f, tq = 0.f;
@@ -329,6 +348,21 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
         float* dst = p.stats + (long long)tm * 2 * p.Ncols;
         dst[n0 + tid] = ts;
         dst[p.Ncols + n0 + tid] = tq;
+        ts_keep = ts;
+      }
+      if (two) {  // the second unit: the same sum(g), its own sum(g * xhat) through the same staging space
+        tile_sync<RAWSYNC>();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[tid * 16 + 8 + e] = sx2[e];
+        tile_sync<RAWSYNC>();
+        if (tid < BN && n0 + tid < p.Ncols) {
+          const int cc = tid >> 3, e = tid & 7;
+          float tq = 0.f;
+          for (int r = 0; r < RL; ++r) tq += red[(r * CPR + cc) * 16 + 8 + e];
+          float* dst = p.stats2 + (long long)tm * 2 * p.Ncols;
+          dst[n0 + tid] = ts_keep;
+          dst[p.Ncols + n0 + tid] = tq;
+        }
       }
     } else {
     for (int idx = tid; idx < BM * CPR; idx += 256) {

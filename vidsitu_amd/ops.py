@@ -298,7 +298,7 @@ def transpose_f32_batched(src, dst, table, total, tiled=True):
 
 def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=None, ring=0,
                noclass=False, bn_stats=None, residual_bits=None, inplace=False, halo=True, pw=True,
-               direct_bnb=False):
+               direct_bnb=False, bn_stats2=None):
     """dx[xs] = conv_transpose(dy, w) (+ residual).  wt from weight_transpose.
     bn_stats = (y, mean, invstd, gamma, beta[, relu_bits]) of the BatchNorm + ReLU unit whose output this
     convolution consumed and whose complete dz this dx is: returns (dx, partial) with partial [rows, 2, Cin]
@@ -330,6 +330,9 @@ def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=N
         flags |= 1 << 24  # VS_CONV_FORCEPW
     if direct_bnb:
         flags |= 1 << 25  # VS_CONV_DIRECTBNB
+    two = bn_stats2 is not None and bn_stats is not None and residual is not None and tuple(s) == (1, 1, 1)
+    if two:
+        flags |= 1 << 26  # VS_CONV_BNB2
     d = make_desc(xs, act_ld(out), dy.shape, act_ld(dy), k, s, p, flags,
                   act_ld(residual) if residual is not None else 0)
     if residual_bits is not None:
@@ -342,7 +345,7 @@ def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=N
     ep = _lib.DgradEpilogue()
     ep.residual = residual.data_ptr() if residual is not None else None
     ep.residual_bits = residual_bits.data_ptr() if residual_bits is not None else None
-    partial = None
+    partial = partial2 = None
     if want_sums:
         y, mean, invstd, gamma, beta, bits = (tuple(bn_stats) + (None,))[:6]
         # pairings the kernel is built for: no residual + recomputed mask, residual + bit mask
@@ -356,10 +359,20 @@ def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=N
             ep.gamma = gamma.data_ptr() if gamma is not None else None
             ep.beta = beta.data_ptr() if beta is not None else None
             ep.stats_partial = partial.data_ptr()
+            # a second unit fed by the same masked gradient (a ResBlock's shortcut unit beside its c unit):
+            # bn_stats2 = (y2, mean2, invstd2); residual + bit-mask form, unit stride
+            if two:
+                y2, mean2, invstd2 = bn_stats2
+                partial2 = torch.empty((rows, 2, xs[1]), dtype=torch.float32, device=dy.device)
+                ep.bn_y2, ep.bn_y2_ld = y2.data_ptr(), act_ld(y2)
+                ep.mean2, ep.invstd2 = mean2.data_ptr(), invstd2.data_ptr()
+                ep.stats_partial2 = partial2.data_ptr()
     for t in (dy, wt, out, residual, residual_bits):
         _ptr(t)  # GPU-tensor check (the struct carries raw addresses)
     _lib.call("vs_conv_dgrad_ex", _ptr(dy), _ptr(wt), _ptr(out), C.byref(d), C.byref(ep), _ptr(ws),
               C.c_size_t(ws.numel() if ws is not None else 0), _stream())
+    if bn_stats2 is not None:
+        return out, partial, partial2
     return (out, partial) if want_sums else out
 
 

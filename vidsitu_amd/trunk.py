@@ -207,6 +207,7 @@ class _Unit:
     # BN-backward sums of the a / b units of a bottleneck emitted by the consuming convolution's dgrad
     # epilogue (vs_conv_dgrad_bnstats) instead of a reduce pass of their own; VS_FUSE_BN_SUMS=0 = A/B switch
     fuse_bn_sums = os.environ.get("VS_FUSE_BN_SUMS", "1") != "0"
+    fuse_sc_sums = os.environ.get("VS_FUSE_SC_SUMS", "1") != "0"  # the shortcut unit's sums from the same epilogue
 
     @staticmethod
     def fwd(conv, bn, x, relu, residual=None, out=None, train=False, saved=None):
@@ -312,12 +313,19 @@ class _Unit:
             part = None
             if fuse:
                 pbn = producer["bn"]
-                dx, part = ops.conv_dgrad(dy, conv.wt(), tuple(x.shape), conv.k, conv.s, conv.p,
-                                          residual=dx_residual, residual_bits=dx_residual_bits,
-                                          bn_stats=(producer["y"], producer["mean"], producer["invstd"],
-                                                    pbn.weight, pbn.bias, producer.get("zbits")))
+                # the producer's block may have a shortcut unit: it receives the same masked gradient (one more
+                # sum(g * xhat) from the same epilogue instead of a reduce pass of its own over dz and its y)
+                sc = producer.get("sc_rec") if (_Unit.fuse_sc_sums and dx_residual is not None) else None
+                res = ops.conv_dgrad(dy, conv.wt(), tuple(x.shape), conv.k, conv.s, conv.p,
+                                     residual=dx_residual, residual_bits=dx_residual_bits,
+                                     bn_stats=(producer["y"], producer["mean"], producer["invstd"],
+                                               pbn.weight, pbn.bias, producer.get("zbits")),
+                                     bn_stats2=(sc["y"], sc["mean"], sc["invstd"]) if sc is not None else None)
+                dx, part = res[0], res[1]
                 if part is not None:
                     producer["bwd_partial"] = part
+                    if sc is not None and res[2] is not None:
+                        sc["bwd_partial"] = res[2]
             else:
                 dx = ops.conv_dgrad(dy, conv.wt(), tuple(x.shape), conv.k, conv.s, conv.p,
                                     residual=dx_residual, residual_bits=dx_residual_bits, inplace=inplace)
@@ -386,7 +394,10 @@ class ResBlock(nn.Module):
             sc = _Unit.fwd(self.branch1, self.branch1_bn, x, False, train=train, saved=saved)
         a = _Unit.fwd(b2.a, b2.a_bn, x, True, train=train, saved=saved)
         b = _Unit.fwd(b2.b, b2.b_bn, a, True, train=train, saved=saved)
-        return _Unit.fwd(b2.c, b2.c_bn, b, True, residual=sc, out=out, train=train, saved=saved)
+        z = _Unit.fwd(b2.c, b2.c_bn, b, True, residual=sc, out=out, train=train, saved=saved)
+        if self.has_sc and train and saved is not None and len(saved) >= 4:
+            saved[-1]["sc_rec"] = saved[-4]  # the next block's conv-a dgrad also emits the shortcut unit's BN sums
+        return z
 
     def bwd(self, saved, dout, chain=False):
         """chain: this block's input is the previous block's output and nothing else reads it -- the record
