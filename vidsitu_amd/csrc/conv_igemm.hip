@@ -87,7 +87,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   int qT = 0, qH = 0, qW = 0, ntT = p.kT, ntH = p.kH, ntW = p.kW;  // taps: dd = q + st * i
   if (cls) {
     stT = 1 << p.shT; stH = 1 << p.shH; stW = 1 << p.shW;
-    const int cq = p.cls_ids[tm % p.nslots], ti = tm / p.nslots;
+    // (strides are powers of two: residues, first rows and counts are masks and shifts -- as written with % and /
+    //  on run-time values this block was ~15 scalar divisions, ~500 instructions in front of a 1..2-step main loop)
+    int slot, ti;
+    fast_divmod(tm, p.nslots, 1.0f / (float)p.nslots, ti, slot);  // tm < 2^24
+    ti = __builtin_amdgcn_readfirstlane(ti);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    const int cq = p.cls_ids[slot];
     if (ti >= p.cls_tiles[cq]) {  // empty slot of the class-interleaved numbering
       if (BNB && tid < BN && n0 + tid < p.Ncols) {
         float* dst = p.stats + (long long)tm * 2 * p.Ncols;
@@ -97,15 +103,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
       return;
     }
     m0 = ti * BM;
-    qW = cq % stW; qH = (cq / stW) % stH; qT = cq / (stW * stH);
-    auto first = [](int q, int off, int st) { return ((q - off) % st + st) % st; };
-    auto count = [](int R, int r0, int st) { return r0 < R ? (R - r0 + st - 1) / st : 0; };
+    qW = cq & (stW - 1); qH = (cq >> p.shW) & (stH - 1); qT = cq >> (p.shW + p.shH);
+    auto first = [](int q, int off, int st) { return (q - off) & (st - 1); };  // two's complement: also for q < off
+    auto count = [](int R, int r0, int st, int sh) { return r0 < R ? (R - r0 + st - 1) >> sh : 0; };
     r0T = first(qT, p.offT, stT); r0H = first(qH, p.offH, stH); r0W = first(qW, p.offW, stW);
-    cT = count(p.Rt, r0T, stT); cH = count(p.Rh, r0H, stH); cW = count(p.Rw, r0W, stW);
-    Mloc = (p.M / (p.Rt * p.Rh * p.Rw)) * cT * cH * cW;
-    ntT = qT < p.kT ? (p.kT - qT + stT - 1) / stT : 0;
-    ntH = qH < p.kH ? (p.kH - qH + stH - 1) / stH : 0;
-    ntW = qW < p.kW ? (p.kW - qW + stW - 1) / stW : 0;
+    cT = count(p.Rt, r0T, stT, p.shT); cH = count(p.Rh, r0H, stH, p.shH); cW = count(p.Rw, r0W, stW, p.shW);
+    Mloc = p.nclips * cT * cH * cW;
+    ntT = qT < p.kT ? (p.kT - qT + stT - 1) >> p.shT : 0;
+    ntH = qH < p.kH ? (p.kH - qH + stH - 1) >> p.shH : 0;
+    ntW = qW < p.kW ? (p.kW - qW + stW - 1) >> p.shW : 0;
   }
   const int Keff = cls ? ntT * ntH * ntW * p.Cg : p.K;  // this tile's reduction length
   const int K8 = Keff >> 3;
@@ -116,23 +122,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 
   if (MODE != 0) {
     const int C8 = p.Cg >> 3;
+    const float rcpC8 = 1.0f / (float)C8, rcpkW = 1.0f / (float)p.kW, rcpkH = 1.0f / (float)p.kH;
     const int K8pad = (((Keff + 63) >> 6) + (NS > 0 ? NS - 1 : 0)) << 3;  // + the ring's run-ahead
     for (int k8 = tid; k8 < K8pad; k8 += 256) {
       if (k8 >= K8) {  // K tail: tap 31 is never valid (FAST requires <= 31 taps)
         ktab[k8] = FAST ? make_int2(31, 0) : make_int2(0, 0);
         continue;
       }
-      int tap = k8 / C8;
-      const int c8 = k8 - tap * C8;
+      int tap, c8;
+      fast_divmod(k8, C8, rcpC8, tap, c8);  // k8 < 2^24: float-reciprocal splits (three integer divisions per entry before)
       int dw, dh, dt;
       if (cls) {  // enumerate only the taps of this class
-        const int iw = tap % ntW, t2 = tap / ntW;
-        dw = qW + stW * iw; dh = qH + stH * (t2 % ntH); dt = qT + stT * (t2 / ntH);
+        int iw, t2, ih, it;
+        fast_divmod(tap, ntW, 1.0f / (float)ntW, t2, iw);
+        fast_divmod(t2, ntH, 1.0f / (float)ntH, it, ih);
+        dw = qW + stW * iw; dh = qH + stH * ih; dt = qT + stT * it;
         tap = (dt * p.kH + dh) * p.kW + dw;
       } else {
-        dw = tap % p.kW;
-        const int t2 = tap / p.kW;
-        dh = t2 % p.kH; dt = t2 / p.kH;
+        int t2;
+        fast_divmod(tap, p.kW, rcpkW, t2, dw);
+        fast_divmod(t2, p.kH, rcpkH, dt, dh);
       }
       if (FAST) {
         long long dpos;
@@ -1375,6 +1384,7 @@ static int fill_fwd_params(ConvP& p, const vs_conv_desc* d) {
   p.res_bits = nullptr;
   p.bny2 = nullptr; p.bn_mean2 = p.bn_invstd2 = nullptr; p.stats2 = nullptr; p.bny2_ld = 0;
   p.M = d->N * d->To * d->Ho * d->Wo;
+  p.nclips = d->N;
   p.Ncols = d->Cout;
   p.K = d->kT * d->kH * d->kW * d->Cin;
   p.Cg = d->Cin;
@@ -1507,6 +1517,7 @@ static int fill_dgrad_params(ConvP& p, const vs_conv_desc* d) {
   p.res_bits = nullptr;
   p.bny2 = nullptr; p.bn_mean2 = p.bn_invstd2 = nullptr; p.stats2 = nullptr; p.bny2_ld = 0;
   p.M = d->N * d->Ti * d->Hi * d->Wi;
+  p.nclips = d->N;
   p.Ncols = d->Cin;
   p.K = d->kT * d->kH * d->kW * d->Cout;
   p.Cg = d->Cout;

@@ -51,6 +51,7 @@ struct ConvP {
   // BN-backward apply kernel of a bottleneck's last unit the write of its masked copy of dz (`dres`).
   const uint8_t* res_bits;
   int dense;  // pointwise, unit stride: row m is position m of the gathered tensor (no row decode)
+  int nclips;  // M / (Rt * Rh * Rw)
   // VS_CONV_BNBWD with RESIDUAL, second unit: a ResBlock's shortcut unit receives the same masked gradient as its c
   // unit (one sum(g), two sum(g * xhat)): stats2[tm][0][c] = sum g, [1][c] = sum g * (bny2 - mean2) * invstd2
   const uint16_t* bny2;
