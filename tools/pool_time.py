@@ -22,12 +22,17 @@ def gt(fn):
 
 
 dev = torch.device("cuda:0")
-for name, c, t in (("slow", 64, 8), ("fast", 8, 32)):
-    x = ops.new_act(8, c, t, 112, 112, dev); x.normal_()
-    y, idx = ops.maxpool_hw(x, want_idx=True)
-    f = gt(lambda: ops.maxpool_hw(x, out=y, want_idx=True))
-    dy = ops.new_act(*y.shape, device=dev); dy.normal_()
-    b = gt(lambda: ops.maxpool_hw_bwd(dy, idx, tuple(x.shape)))
-    xin = torch.randn(8, 3, t, 224, 224, device=dev).to(torch.bfloat16)
-    pk = gt(lambda: ops.pack_input(xin, 4))
-    print(f"{name}: maxpool fwd {f:6.1f} us  bwd {b:6.1f} us   pack_input(bf16 -> c4) {pk:6.1f} us", flush=True)
+def main():
+    for name, c, t in (("slow", 64, 8), ("fast", 8, 32)):
+        x = ops.new_act(8, c, t, 112, 112, dev); x.normal_()
+        y, idx = ops.maxpool_hw(x, want_idx=True)
+        f = gt(lambda: ops.maxpool_hw(x, out=y, want_idx=True))
+        dy = ops.new_act(*y.shape, device=dev); dy.normal_()
+        b = gt(lambda: ops.maxpool_hw_bwd(dy, idx, tuple(x.shape)))
+        xin = torch.randn(8, 3, t, 224, 224, device=dev).to(torch.bfloat16)
+        pk = gt(lambda: ops.pack_input(xin, 4))
+        print(f"{name}: maxpool fwd {f:6.1f} us  bwd {b:6.1f} us   pack_input(bf16 -> c4) {pk:6.1f} us", flush=True)
+
+
+if __name__ == "__main__":
+    main()
