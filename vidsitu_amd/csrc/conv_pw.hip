@@ -36,7 +36,7 @@ __device__ __forceinline__ void pw_wait_vm(int n) {
   }
 }
 
-template <int BN, bool BNB>
+template <int BN, bool BNB, int EDBG = 0>
 __global__ __launch_bounds__(256) void conv_pw_kernel(ConvP p, PwGeo g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = PW_BM;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(ConvP p, PwGeo g) {
       if (acc[0][0][0] == 123.456f) epi[tid] = 1;  // keep the accumulators alive
       continue;
     }
-    conv_tile_epilogue<BM, BN, WM, WN, BNB, true>(p, acc, epi, statbuf, tm, n0, [&](int row) {
+    conv_tile_epilogue<BM, BN, WM, WN, BNB, true, false, EDBG>(p, acc, epi, statbuf, tm, n0, [&](int row) {
       return (m0 + row < p.M && !(g.dbg & 1)) ? m0 + row : -1;
     });
   }
@@ -256,8 +256,23 @@ static int pw_launch_one(const ConvP& p, const PwGeo& g, hipStream_t st) {
   return VS_OK;
 }
 
+template <int EDBG>
+static int pw_launch_edbg(const ConvP& p, const PwGeo& g, hipStream_t st) {
+  (void)hipFuncSetAttribute((const void*)conv_pw_kernel<128, false, EDBG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+  hipLaunchKernelGGL((conv_pw_kernel<128, false, EDBG>), dim3(8 * g.nsl * g.gx), dim3(256), g.smem, st, p, g);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
 int vs_pw_launch(const ConvP& p, const PwGeo& g, hipStream_t st) {
   const bool bnb = (p.flags & VS_CONV_BNBWD) != 0;
+  static const int edbg = pw_env("VS_PW_EDBG", 0);  // epilogue ablations (tools only): 1 no statistics, 2 no staging writes
+  if (edbg && g.bn == 128 && !bnb) {
+    if (edbg == 1) return pw_launch_edbg<1>(p, g, st);
+    if (edbg == 2) return pw_launch_edbg<2>(p, g, st);
+    return pw_launch_edbg<3>(p, g, st);
+  }
   if (g.bn == 128) return bnb ? pw_launch_one<128, true>(p, g, st) : pw_launch_one<128, false>(p, g, st);
   return bnb ? pw_launch_one<64, true>(p, g, st) : pw_launch_one<64, false>(p, g, st);
 }

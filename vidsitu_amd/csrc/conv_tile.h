@@ -97,7 +97,7 @@ __device__ __forceinline__ void tile_sync() {
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool BNB, bool RAWSYNC = false, bool TWO = false, typename RowMap>
+template <int BM, int BN, int WM, int WN, bool BNB, bool RAWSYNC = false, bool TWO = false, int EDBG = 0, typename RowMap>
 __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16],
                                                    char* smem, float* statbuf, int tm, int n0, RowMap rowm) {
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -108,7 +108,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
   const int lr = lane & 15, lq = lane >> 4;
   // (1) BN batch-statistic partials from the fp32 accumulators (tail rows are
   //     zero-filled, so they add nothing).
-  if (p.flags & VS_CONV_STATS) {
+  if ((p.flags & VS_CONV_STATS) && !(EDBG & 1)) {  // EDBG: ablations (tools only, wrong results)
 #pragma unroll
     for (int b = 0; b < NR; ++b) {
       float s = 0.f, q = 0.f;
@@ -147,7 +147,10 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
 #pragma unroll
         for (int a = 0; a < MR; ++a)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) Eh[(wm * TM + a * 16 + lq * 4 + r) * BN + col] = f32_to_bf16(acc[a][b][r]);
+          for (int r = 0; r < 4; ++r) {
+            if (EDBG & 2) asm volatile("" ::"v"(acc[a][b][r]));
+            else Eh[(wm * TM + a * 16 + lq * 4 + r) * BN + col] = f32_to_bf16(acc[a][b][r]);
+          }
       }
     } else {
 #pragma unroll
@@ -234,11 +237,24 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
         dst[p.Ncols + n0 + tid] = tq;
       }
     } else {
-    for (int idx = tid; idx < BM * CPR; idx += 256) {
+    // every LDS read of the thread's vectors is issued before the first store (a read -> store loop was a chain of
+    // LDS latencies: ~0.2 us of a ~1.3 us epilogue, which on 1..4-step layers is a third of the block)
+    constexpr int CO = (BM * CPR + 255) / 256;
+    uint4 cv[CO];
+    int cm[CO];
+#pragma unroll
+    for (int u = 0; u < CO; ++u) {
+      const int idx = tid + u * 256;
       const int row = idx / CPR, c8 = idx - row * CPR;
-      const int m = rowm(row), n = n0 + c8 * 8;
-      if (m >= 0 && n < p.Ncols)
-        *(uint4*)(p.y + (long long)m * p.y_ld + n) = *(const uint4*)(Eh + row * BN + c8 * 8);
+      const bool in = idx < BM * CPR;
+      const int m = in ? rowm(row) : -1;
+      cm[u] = (m >= 0 && n0 + c8 * 8 < p.Ncols) ? m : -1;
+      cv[u] = *(const uint4*)(Eh + (in ? row : 0) * BN + c8 * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < CO; ++u) {
+      const int c8 = (tid + u * 256) % CPR;
+      if (cm[u] >= 0) *(uint4*)(p.y + (long long)cm[u] * p.y_ld + n0 + c8 * 8) = cv[u];
     }
     }
   } else {
@@ -366,26 +382,44 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
         }
       }
     } else {
-    for (int idx = tid; idx < BM * CPR; idx += 256) {
+    // the thread's residual vectors (global) and mask bytes are all requested before the first use: the
+    // load -> add -> store loop was a chain of memory latencies per tile
+    constexpr int CO = (BM * CPR + 255) / 256;
+    uint4 rv[CO];
+    unsigned rb[CO];
+    int cm[CO];
+#pragma unroll
+    for (int u = 0; u < CO; ++u) {
+      const int idx = tid + u * 256;
       const int row = idx / CPR, c8 = idx - row * CPR;
-      const int m = rowm(row), n = n0 + c8 * 8;
-      if (m >= 0 && n < p.Ncols) {
+      const int m = idx < BM * CPR ? rowm(row) : -1;
+      const int n = n0 + c8 * 8;
+      cm[u] = (m >= 0 && n < p.Ncols) ? m : -1;
+      const long long mc = cm[u] >= 0 ? cm[u] : 0;
+      const int nc = cm[u] >= 0 ? n : 0;
+      rv[u] = *(const uint4*)(p.res + mc * p.res_ld + nc);
+      rb[u] = p.res_bits ? (unsigned)p.res_bits[mc * (p.Ncols >> 3) + (nc >> 3)] : 0xffu;
+    }
+#pragma unroll
+    for (int u = 0; u < CO; ++u) {
+      const int idx = tid + u * 256;
+      const int row = idx / CPR, c8 = idx - row * CPR;
+      if (cm[u] >= 0) {
         float v[8];
         const float4 v0 = *(const float4*)(E + row * BN + c8 * 8);
         const float4 v1 = *(const float4*)(E + row * BN + c8 * 8 + 4);
         v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
         v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-        const uint4 rv = *(const uint4*)(p.res + (long long)m * p.res_ld + n);
         float rf[8];
-        unpack8_bf16(rv, rf);
-        if (p.res_bits) mask8(rf, p.res_bits[(long long)m * (p.Ncols >> 3) + (n >> 3)]);
+        unpack8_bf16(rv[u], rf);
+        if (p.res_bits) mask8(rf, rb[u]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += rf[e];
         if (p.flags & VS_CONV_RELU) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        *(uint4*)(p.y + (long long)m * p.y_ld + n) = pack8_bf16(v);
+        *(uint4*)(p.y + (long long)cm[u] * p.y_ld + n0 + c8 * 8) = pack8_bf16(v);
       }
     }
     }
