@@ -62,7 +62,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvP p, HaloGeo q) {
   unsigned* aoff_tab = (unsigned*)(smem + MAIN);          // [HALO_RA_MAX] byte offset of image row j
   int* orow = (int*)(smem + MAIN + HALO_RA_MAX * 4);      // [BM] output position of tile row r, or -1
   int* abase = orow + BM;                                 // [BM] image row of tile row r at tap (0, 0)
-  float* statbuf = (float*)(abase + BM);                  // [2][2][BN]
+  float* statbuf = (float*)(abase + BM);                  // [2][4 * 2][BN]
 
   // ---- tables (every row decoded once per block) ----
   const int ipg = q.D1 * q.D2, opg = q.O1 * q.O2p;
@@ -423,7 +423,7 @@ static size_t halo_smem_bytes(int mrw, int nrw, int depth) {
   const size_t bm = 32 * mrw, bn = 32 * nrw;
   const size_t staging = 2 * (size_t)HALO_RA_MAX * 128 + (size_t)(depth + 1) * bn * 128;
   const size_t epi = bm * bn * 4 + 256 * 16 * 4;
-  return (staging > epi ? staging : epi) + HALO_RA_MAX * 4 + 2 * bm * 4 + 2 * 2 * bn * 4;
+  return (staging > epi ? staging : epi) + HALO_RA_MAX * 4 + 2 * bm * 4 + 2 * 8 * bn * 4;  // .. + statbuf [2][4 * WM][BN], WM = 2
 }
 
 template <int MRW, int NRW, bool BNB, int D, int TAPS>

@@ -116,9 +116,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   const int Keff = cls ? ntT * ntH * ntW * p.Cg : p.K;  // this tile's reduction length
   const int K8 = Keff >> 3;
 
-  float* statbuf = (float*)(smem + MAIN);               // [2][WM][BN]
-  int* rowpos = (int*)(smem + MAIN + 2 * WM * BN * 4);  // [BM] output position of each tile row
-  int2* ktab = (int2*)(smem + MAIN + 2 * WM * BN * 4 + (MODE == 2 ? BM * 4 : 0));  // [K8]
+  float* statbuf = (float*)(smem + MAIN);               // [2][4 * WM][BN]
+  int* rowpos = (int*)(smem + MAIN + 8 * WM * BN * 4);  // [BM] output position of each tile row
+  int2* ktab = (int2*)(smem + MAIN + 8 * WM * BN * 4 + (MODE == 2 ? BM * 4 : 0));  // [K8]
 
   if (MODE != 0) {
     const int C8 = p.Cg >> 3;
@@ -1133,7 +1133,7 @@ static size_t conv_smem_bytes(int bm, int bn, int wm, int ns, int mode, int K) {
   const size_t ring = (size_t)(ns > 2 ? ns : 2) * stage;
   const size_t tab = mode ? (size_t)(((K + 63) >> 6) + (ns > 0 ? ns - 1 : 0)) * 64 : 0;
   const size_t rowpos = mode == 2 ? (size_t)bm * 4 : 0;
-  return (ring > epi ? ring : epi) + (size_t)2 * wm * bn * 4 + rowpos + tab;
+  return (ring > epi ? ring : epi) + (size_t)8 * wm * bn * 4 + rowpos + tab;
 }
 
 // ring: 0 = register-staged pipeline, 2..4 = LDS-DMA ring with that many stages

@@ -211,7 +211,7 @@ bool vs_pw_plan(const ConvP& p, int mode, int flags, PwGeo* out) {
   if (f_bn == 64 || (f_bn == 128 && p.Ncols >= 128 && g.nk <= 4)) g.bn = f_bn;
   const bool has_res = (p.flags & VS_CONV_RESIDUAL) != 0, bnb = (p.flags & VS_CONV_BNBWD) != 0;
   g.epi_bytes = has_res ? PW_BM * g.bn * 4 : (bnb ? PW_BM * g.bn * 2 + 16384 : PW_BM * g.bn * 2);
-  const int fixed = g.nk * g.bn * 128 + g.epi_bytes + 2 * 2 * 128 * 4;
+  const int fixed = g.nk * g.bn * 128 + g.epi_bytes + 2 * 8 * 128 * 4;  // + statbuf [2][4 * WM][BN]
   // Measured (profiles/r02_pw_ab.txt): a block's epilogue is ~1 us of serial VALU / LDS work per tile and only a
   // second resident block hides it -- one block per CU loses to the tile kernel at every shape, a deeper ring
   // buys nothing (3 slots = 5 = 8 at equal occupancy).  After the tile kernel's prologue lost its integer

@@ -81,7 +81,7 @@ __device__ __forceinline__ uint4 mask8_bf16(uint4 v, unsigned bits) {
 // accumulators of a BM x BN tile (4 waves, WM x WN, wave tile TM x TN) -> BN batch-statistic partials,
 // affine, residual (optionally masked by bits), ReLU, bf16 stores as 16-byte channel vectors, and -- BNB --
 // the BN-backward sums of the unit this dx belongs to.  `rowm(row)` maps a tile row to its output position
-// (or -1).  `smem` is the block's staging area (free once the main loop is done), `statbuf` [2][WM][BN].
+// (or -1).  `smem` is the block's staging area (free once the main loop is done), `statbuf` [2][4 * WM][BN] floats.
 // -----------------------------------------------------------------------------------------------
 // RAWSYNC: the barriers between the staging writes and reads order LDS traffic only (lgkmcnt + s_barrier).  A
 // kernel that keeps asynchronous global->LDS copies in flight across the epilogue (conv_pw.hip) asks for it:
@@ -120,15 +120,12 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
           s += v;
           q += v * v;
         }
-      s += __shfl_xor(s, 16, 64);
-      q += __shfl_xor(q, 16, 64);
-      s += __shfl_xor(s, 32, 64);
-      q += __shfl_xor(q, 32, 64);
-      if (lq == 0) {
-        const int col = wn * TN + b * 16 + lr;
-        statbuf[wm * BN + col] = s;
-        statbuf[WM * BN + wm * BN + col] = q;
-      }
+      // every lane quarter parks its partial in LDS and the column's owner adds the 4 x WM of them behind the
+      // barrier the staging needs anyway -- no cross-lane exchange here (two dependent ds_bpermute round trips per
+      // sum: ~0.35 us of a ~1.3 us epilogue in the ablation, profiles/r02_pw_ab.txt)
+      const int col = wn * TN + b * 16 + lr;
+      statbuf[(wm * 4 + lq) * BN + col] = s;
+      statbuf[(WM * 4 + wm * 4 + lq) * BN + col] = q;
     }
   }
   constexpr int CPR = BN / 8;
@@ -427,9 +424,9 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
   if ((p.flags & VS_CONV_STATS) && tid < BN && n0 + tid < p.Ncols) {
     float s = 0.f, q = 0.f;
 #pragma unroll
-    for (int w = 0; w < WM; ++w) {
+    for (int w = 0; w < 4 * WM; ++w) {  // fixed order: wave rows, lane quarters
       s += statbuf[w * BN + tid];
-      q += statbuf[WM * BN + w * BN + tid];
+      q += statbuf[(4 * WM + w) * BN + tid];
     }
     float* dst = p.stats + (long long)tm * 2 * p.Ncols;
     dst[n0 + tid] = s;
