@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvidsitu_hip.so")
+# VS_LIB_PATH: A/B runs of two builds of the same ABI in one GPU session (tools/); never a fallback.
+LIB_PATH = os.environ.get("VS_LIB_PATH") or os.path.join(_HERE, "libvidsitu_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 VS_CONV_AFFINE = 1
