@@ -73,6 +73,8 @@ def main():
         reset()
         for _ in range(replays):
             arena.grad.fill_(float("nan"))
+            for off, nxt, q in zip(arena.offsets, arena.offsets[1:], arena.params):  # alignment gaps stay zero
+                arena.grad[off + q.numel():nxt].zero_()
             ts.replay()
         torch.cuda.synchronize()
         out = (arena.grad.clone(), arena.data.clone(), ts.loss.clone())

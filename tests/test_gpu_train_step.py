@@ -11,6 +11,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+def _poison(arena):
+    """NaN in every parameter's gradient; the alignment gaps between parameters stay zero (nothing writes them
+    after the arena's construction, and the optimizer runs over the whole arena)."""
+    arena.grad.fill_(float("nan"))
+    for off, nxt, p in zip(arena.offsets, arena.offsets[1:], arena.params):
+        arena.grad[off + p.numel():nxt].zero_()
+
+
 def test_ranged_adam_beside_the_backward_pass_is_bitwise_the_plain_step(dev):
     from vidsitu_amd import synth_data
     from vidsitu_amd.extended_config import get_cfg
@@ -57,7 +65,7 @@ def test_ranged_adam_beside_the_backward_pass_is_bitwise_the_plain_step(dev):
         ts.capture()
         reset()
         for _ in range(2):
-            arena.grad.fill_(float("nan"))
+            _poison(arena)
             ts.replay()
         torch.cuda.synchronize()
         replayed = state() + [ts.loss.clone()]
@@ -79,3 +87,73 @@ def test_ranged_adam_beside_the_backward_pass_is_bitwise_the_plain_step(dev):
         assert torch.equal(a, b), f"eager {name} differs"
     for name, a, b in zip(("grad", "param", "exp_avg", "exp_avg_sq", "step"), e0, r0):
         assert torch.equal(a, b), f"eager vs replayed {name} differs"
+
+
+def test_gradient_fill_is_skipped_only_where_the_backward_overwrites(dev):
+    """`TrainStep(grad_fill=None)`: the first eager step fills the gradient arena and learns which parameters get
+    their gradient through autograd's AccumulateGrad; later steps zero only those.  (a) the HIP model: none is
+    learned, and steps from NaN-poisoned gradients are bitwise the steps of a TrainStep that fills every time,
+    eager and replayed; (b) a model with torch-native parameters: all of them are learned and the trajectory is
+    the filled one as well (without the zeroing their gradients would pile up step after step)."""
+    from vidsitu_amd import synth_data
+    from vidsitu_amd.extended_config import get_cfg
+    from vidsitu_amd.mdl_selector import get_mdl_loss_eval
+    from vidsitu_amd.optim import ArenaAdam, ParamArena
+    from vidsitu_amd.train_step import TrainStep
+
+    def trajectory(mdl, loss_fn, batch, grad_fill, graph):
+        arena = ParamArena(mdl)
+        opt = ArenaAdam(arena, lr=1e-3)
+        ts = TrainStep(mdl, loss_fn, arena, opt, batch, grad_fill=grad_fill, adam_overlap=False)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ts.step()
+            if graph:
+                ts.capture()
+            for _ in range(2):
+                _poison(arena)
+                ts.run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        return ts, [arena.grad.clone(), arena.data.clone(), opt.m.clone(), opt.v.clone(), ts.loss.clone()]
+
+    # (a) SlowFast mini + TxEncoder, no dropout (two model instances from one seed: same weights)
+    def hip_model():
+        cfg = get_cfg({"mdl.mdl_name": "sf_base_txenc", "mdl.sf_mdl_name": "slow_fast_mini", "synth.num_verbs": 31,
+                       "tx_dec.encoder_layers": 2, "tx_dec.dropout": 0.0})
+        comm = synth_data.make_comm(cfg)
+        torch.manual_seed(0)
+        sel = get_mdl_loss_eval(cfg)
+        mdl = sel["mdl"](cfg=cfg, comm=comm).to(dev).train()
+        batch = synth_data.synth_batch(cfg, comm, bs=2, n_ev=2, crop=64, device=dev, dtype=torch.bfloat16)
+        return mdl, sel["loss"](cfg, comm), batch
+
+    for graph in (False, True):
+        _, ref = trajectory(*hip_model(), True, graph)
+        ts, got = trajectory(*hip_model(), None, graph)
+        assert ts._accumulated == [], [tuple(p.shape) for p in ts._accumulated]
+        assert torch.isfinite(got[0]).all()
+        for name, a, b in zip(("grad", "param", "exp_avg", "exp_avg_sq", "loss"), ref, got):
+            assert torch.equal(a, b), f"graph={graph}: {name} differs without the per-step fill"
+
+    # (b) torch-native parameters
+    class Plain(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = torch.nn.Linear(16, 32), torch.nn.Linear(32, 4)
+
+        def forward(self, batch):
+            return self.b(torch.tanh(self.a(batch["x"])))
+
+    def plain_model():
+        torch.manual_seed(1)
+        mdl = Plain().to(dev)
+        batch = {"x": torch.randn(8, 16, device=dev), "y": torch.randint(0, 4, (8,), device=dev)}
+        return mdl, (lambda out, b: {"loss": torch.nn.functional.cross_entropy(out, b["y"])}), batch
+
+    _, ref = trajectory(*plain_model(), True, False)
+    ts, got = trajectory(*plain_model(), None, False)
+    assert len(ts._accumulated) == 4
+    for name, a, b in zip(("grad", "param", "exp_avg", "exp_avg_sq", "loss"), ref, got):
+        assert torch.equal(a, b), f"torch-native model: {name} differs"

@@ -32,7 +32,7 @@ import torch.distributed as dist
 
 class TrainStep:
     def __init__(self, mdl, loss_fn, arena, opt, batch, world=1, overlap=None, use_dist=None,
-                 grad_bf16=False, adam_overlap=None):
+                 grad_bf16=False, adam_overlap=None, grad_fill=None):
         self.mdl, self.loss_fn, self.arena, self.opt, self.batch = mdl, loss_fn, arena, opt, batch
         self.world = world
         self.use_dist = (dist.is_available() and dist.is_initialized()) if use_dist is None else use_dist
@@ -47,6 +47,15 @@ class TrainStep:
                              and hasattr(opt, "step_range"))
         self._adam_stream = None
         self.loss = None
+        # The per-step memset of the gradient arena (300 MB for SlowFast-R50 + TxEncoder) is only needed by
+        # parameters whose gradient arrives through autograd's AccumulateGrad (p.grad += g).  The HIP modules
+        # WRITE p.grad in place and return None for it, so AccumulateGrad never runs for them.  grad_fill=None:
+        # the first step fills the arena and watches which parameters AccumulateGrad touches
+        # (tensor hooks: called with None when a backward returned no gradient); later steps zero only those.  True: memset every step.  False: never.
+        if grad_fill is None and os.environ.get("VS_GRAD_FILL", "") in ("0", "1"):
+            grad_fill = os.environ["VS_GRAD_FILL"] == "1"
+        self.grad_fill = grad_fill
+        self._accumulated = None  # learned: parameters that need a zero gradient before every backward pass
         self.graphs = None  # segment graphs + the Adam graph, or [whole-step graph]
         self.segments = self._build_segments()
 
@@ -54,13 +63,38 @@ class TrainStep:
     def fwd_bwd(self):
         a = self.arena
         a.transposes_async()  # dgrad weight images of the last update, beside the forward pass
-        self.opt.zero_grad()  # (every gradient is overwritten anyway; the memset overlaps the stems)
+        hooks = self._zero_grads()
         out = self.mdl(self.batch)
         loss = self.loss_fn(out, self.batch)["loss"]
         loss.backward()
+        for h in hooks:
+            h.remove()
         a._join_transposes()  # no-op unless no dgrad ran (keeps a captured graph closed)
         self.loss = loss.detach()
         return loss
+
+    def _zero_grads(self):
+        """Before the forward pass: what `optimizer.zero_grad()` has to do for this model (see `grad_fill`).
+        Returns the hook handles of a learning step."""
+        if self.grad_fill is True:
+            self.opt.zero_grad()
+            return []
+        if self.grad_fill is False or self._accumulated is not None:
+            self.opt.zero_grad(fill=False)  # only re-attaches replaced gradients
+            for p in (self._accumulated or ()):
+                p.grad.zero_()
+            return []
+        if self.arena.data.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("TrainStep: run one eager step() before capture() (it learns which gradients "
+                               "need the per-step zero fill)")
+        self.opt.zero_grad()
+        seen = []
+        self._accumulated = seen
+
+        def note(g, q):  # autograd calls a tensor hook with None when the backward returned no gradient for q
+            if g is not None and not any(q is r for r in seen):
+                seen.append(q)
+        return [p.register_hook(lambda g, q=p: note(g, q)) for p in self.arena.params]
 
     def _adam(self):
         self.opt.step(world=self.world, defer_transposes=True, grad_bf16=self.grad_bf16)
