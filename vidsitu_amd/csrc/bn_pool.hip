@@ -3,6 +3,8 @@
 // consecutive channels per lane, fp32 math, wave-shuffle / LDS reductions.
 // Reference call sites: vidsitu_code/mdl_sf_base.py:22-33 (trunk modules),
 // :97-113 (AdaptiveAvgPool3d + cat), dat_loader.py:454-501 (input contract).
+#include <stdlib.h>
+
 #include "common.h"
 
 // ----------------------------------------------------------------------------
@@ -326,12 +328,17 @@ static inline int ew_grid(long long total) {
 #define BNA_BATCH 4
 
 static int bn_rows_batches(long long rows, int C, int target_blocks) {
+  // VS_BN_TARGET / VS_BN_NBMAX: sweep knobs (tools/bn_time.py); the defaults are what the sweep kept
+  static const int env_target = getenv("VS_BN_TARGET") ? atoi(getenv("VS_BN_TARGET")) : 0;
+  static const int env_nbmax = getenv("VS_BN_NBMAX") ? atoi(getenv("VS_BN_NBMAX")) : 0;
+  if (env_target > 0) target_blocks = env_target;
+  const int nbmax = env_nbmax > 0 ? env_nbmax : 4;
   const int cpr = C / 8;
   const int ncol = cpr < 256 ? cpr : 256;
   const long long rl = 256 / ncol;
   long long nb = (rows + rl * BNA_BATCH * target_blocks - 1) / (rl * BNA_BATCH * target_blocks);
   if (nb < 1) nb = 1;
-  if (nb > 4) nb = 4;
+  if (nb > nbmax) nb = nbmax;
   return (int)nb;
 }
 
