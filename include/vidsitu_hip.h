@@ -298,6 +298,25 @@ int vs_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, 
 int vs_linear_bwd_fused(const float* dy, const float* relu_y, const float* x, const float* wt, float* dx,
                         float* dw, float* db, int M, int N, int K, void* stream);
 
+/* A chain of few-row stages behind ONE launch (utils/transformer_code.py:215-250: the EncoderLayer stack on the
+ * 8 event tokens of a rank; forward = 7 stages per layer, backward = 7).  `stages`: device array of
+ *   struct { int64 op, M, N, K, ia, ib; const void* p[10]; }           (128 bytes per stage)
+ * op 1 LIN      y = act(x . w^T + b) (+ res): p = x, w, b, res, y; ia = act (vs_gemm_nt_f32_res codes); M <= 8
+ *    2 LINBWD   vs_linear_bwd_fused: p = dy, relu_y, x, wt, dx (null: no dx), dw, db; ia = weight-gradient blocks
+ *    3 ATTN_FWD vs_attn_small_fwd on a fused [rows, 3 D] q|k|v buffer: p = qkv, o, probs, drop_mask;
+ *               M = B, N = H, K = dh, ia = L, ib = float bits of 1 / scale
+ *    4 ATTN_BWD vs_attn_small_bwd: p = qkv, dout, probs, drop_mask, dqkv (same fields)
+ *    5 LN_FWD   vs_add_layernorm_fwd: p = x, r, rmask, gamma, beta, y, mean, rstd; M rows, N = D, ib = eps bits
+ *    6 LN_BWD   vs_add_layernorm_bwd with the output gradient given as dy (+ dy2): p = dy, dy2, x, r, rmask,
+ *               gamma, mean, rstd, dx, dr; ia / ib = dgamma / dbeta pointers; M <= 16 rows
+ *    7 ADD      y = a + b: p = a, b, y; N = number of float4s
+ * Every stage runs the body of the stand-alone kernel over virtual blocks (bitwise the launches it replaces);
+ * between stages the persistent grid (`grid` blocks of 256 threads, <= one per CU so that all are resident)
+ * meets at a barrier.  `barriers`: nstages * 129 + 16 uint32 words; word [nstages] is an error flag the kernel sets if
+ * a barrier wait exceeds its iteration cap (the blocks then leave instead of hanging the GPU).
+ * `smem_bytes`: dynamic LDS = 32 bytes x the widest inner dimension of a LIN / LINBWD stage (>= 8320). */
+int vs_txenc_stack_run(const void* stages, int nstages, void* barriers, int grid, int smem_bytes, void* stream);
+
 /* softmax(Q_h K_h^T / scale) V_h for short sequences (L <= 16), per head.
  * q,k,v,o: [B, L, H*dh] fp32.  utils/transformer_code.py:33-48,60-68 --
  * scale is sqrt(d_model) there, passed explicitly. */

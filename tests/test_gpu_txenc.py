@@ -261,3 +261,49 @@ def test_adam_with_fused_bf16_cast_and_arena_refresh(dev):
     ops.cast_bf16(pa, ref_bf)
     assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
     assert torch.equal(bf.view(torch.int16), ref_bf.view(torch.int16)) and int(tb) == 3
+
+
+@pytest.mark.parametrize("layers,b,l,drop", [(2, 2, 4, 0.1), (6, 2, 4, 0.1), (3, 1, 5, 0.0), (2, 1, 8, 0.1)])
+def test_encoder_stack_in_one_launch_is_bitwise_the_per_op_path(layers, b, l, drop, dev, monkeypatch):
+    """`EncoderStackFn` (all layers' forward behind one `vs_txenc_stack_run` launch, the backward behind another) runs
+    the bodies of the per-op kernels over virtual blocks: output, every layer output, input gradient and every
+    parameter gradient are bit for bit those of the per-op autograd path, with the same dropout masks."""
+    from vidsitu_amd import transformer_code as T
+    from vidsitu_amd.optim import ParamArena
+
+    d = 1024
+    torch.manual_seed(3)
+    mdl = T.Transformer(d_model=d, n_vocab_src=0, vocab_trg=0, d_hidden=d, n_layers=layers, n_heads=8,
+                        drop_ratio=drop, pe=False).to(dev).train()
+    arena = ParamArena(mdl)
+    x0 = torch.randn(b, l, d, device=dev)
+    dy = torch.randn(b, l, d, device=dev)
+
+    def run(stack):
+        monkeypatch.setenv("VS_TXENC_STACK", "1" if stack else "0")
+        used = []
+        orig = T.EncoderStackFn.forward
+        monkeypatch.setattr(T.EncoderStackFn, "forward", staticmethod(lambda ctx, x, enc: (used.append(1), orig(ctx, x, enc))[1]))
+        arena.grad.fill_(float("nan"))
+        for off, nxt, p in zip(arena.offsets, arena.offsets[1:], arena.params):
+            arena.grad[off + p.numel():nxt].zero_()
+        torch.manual_seed(11)
+        T._masks.__init__()  # same mask plan state on both sides
+        x = x0.clone().requires_grad_()
+        outs = mdl.encoder(x)
+        outs[-1].backward(dy)
+        torch.cuda.synchronize()
+        monkeypatch.setattr(T.EncoderStackFn, "forward", orig)
+        assert bool(used) == stack
+        return [o.detach().clone() for o in outs[1:]], x.grad.clone(), arena.grad.clone()
+
+    o0, dx0, g0 = run(False)
+    o1, dx1, g1 = run(True)
+    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    for i, (a, c) in enumerate(zip(o0, o1)):
+        assert torch.equal(a, c), f"layer {i} output: max diff {float((a - c).abs().max()):.3e}"
+    bad = [f"{k} ({float((g0[off:off + p.numel()] - g1[off:off + p.numel()]).abs().max()):.1e})"
+           for (k, p), off in zip(mdl.named_parameters(), arena.offsets)
+           if not torch.equal(g0[off:off + p.numel()], g1[off:off + p.numel()])]
+    assert not bad, f"parameter gradients differ: {bad}"
+    assert torch.equal(dx0, dx1), f"dx: max diff {float((dx0 - dx1).abs().max()):.3e}"

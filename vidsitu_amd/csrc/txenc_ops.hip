@@ -158,7 +158,13 @@ __device__ __forceinline__ void linear_fullx_body(const float* __restrict__ x, c
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const float4 xv = xs4[m * K4 + k4];
-        acc[m] += xv.x * wv[u].x + xv.y * wv[u].y + xv.z * wv[u].z + xv.w * wv[u].w;
+        // explicit fused multiply-adds: left to the compiler's contraction the four products were fused
+        // differently in different kernels that inline this body (stand-alone launch vs the encoder stack)
+        float a = acc[m];
+        a = __fmaf_rn(xv.x, wv[u].x, a);
+        a = __fmaf_rn(xv.y, wv[u].y, a);
+        a = __fmaf_rn(xv.z, wv[u].z, a);
+        acc[m] = __fmaf_rn(xv.w, wv[u].w, a);
       }
     }
   }
@@ -764,16 +770,16 @@ extern "C" int vs_linear_bwd_weight(const float* dy, const float* x, float* dw, 
 // ----------------------------------------------------------------------------
 #define ATT_MAXL 16
 
-__global__ __launch_bounds__(256) void attn_small_fwd_kernel(const float* q, const float* k,
-                                                             const float* v, float* o, float* probs,
-                                                             const float* drop_mask, int L, int H,
-                                                             int dh, float inv_scale, int ld) {
-  extern __shared__ __attribute__((aligned(16))) char smem_att[];
+// (bid: the block's (batch, head) index -- blockIdx.x of the stand-alone launch, a virtual block of the
+//  one-launch encoder stack below)
+__device__ __forceinline__ void attn_small_fwd_body(const float* q, const float* k, const float* v, float* o,
+                                                    float* probs, const float* drop_mask, int L, int H, int dh,
+                                                    float inv_scale, int ld, int bid, char* smem_att) {
   float* qs = (float*)smem_att;  // [L][dh]
   float* ks = qs + L * dh;
   float* vs = ks + L * dh;
   float* ps = vs + L * dh;  // [L][L]
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int b = bid / H, h = bid % H;
   const int D = H * dh;
   for (int i = threadIdx.x; i < L * dh; i += 256) {
     const int r = i / dh, d = i - r * dh;
@@ -817,6 +823,14 @@ __global__ __launch_bounds__(256) void attn_small_fwd_kernel(const float* q, con
   }
 }
 
+__global__ __launch_bounds__(256) void attn_small_fwd_kernel(const float* q, const float* k,
+                                                             const float* v, float* o, float* probs,
+                                                             const float* drop_mask, int L, int H,
+                                                             int dh, float inv_scale, int ld) {
+  extern __shared__ __attribute__((aligned(16))) char smem_att[];
+  attn_small_fwd_body(q, k, v, o, probs, drop_mask, L, H, dh, inv_scale, ld, blockIdx.x, smem_att);
+}
+
 extern "C" int vs_attn_small_fwd(const float* q, const float* k, const float* v, float* o,
                                  float* probs, const float* drop_mask, int B, int L, int H, int dh,
                                  int ld_qkv, float scale, void* stream) {
@@ -830,12 +844,10 @@ extern "C" int vs_attn_small_fwd(const float* q, const float* k, const float* v,
   return VS_OK;
 }
 
-__global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* q, const float* k,
-                                                             const float* v, const float* probs,
-                                                             const float* dout, float* dq, float* dk,
-                                                             float* dv, const float* drop_mask,
-                                                             int L, int H, int dh, float inv_scale, int ld) {
-  extern __shared__ __attribute__((aligned(16))) char smem_att[];
+__device__ __forceinline__ void attn_small_bwd_body(const float* q, const float* k, const float* v,
+                                                    const float* probs, const float* dout, float* dq, float* dk,
+                                                    float* dv, const float* drop_mask, int L, int H, int dh,
+                                                    float inv_scale, int ld, int bid, char* smem_att) {
   float* qs = (float*)smem_att;  // [L][dh]
   float* ks = qs + L * dh;
   float* vs = ks + L * dh;
@@ -843,7 +855,7 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* q, con
   float* ps = dos + L * dh;  // [L][L]  pre-dropout probabilities
   float* dss = ps + L * L;   // [L][L]
   float* ms = dss + L * L;   // [L][L]  dropout mask (1 when absent)
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int b = bid / H, h = bid % H;
   const int D = H * dh;
   for (int i = threadIdx.x; i < L * dh; i += 256) {
     const int r = i / dh, d = i - r * dh;
@@ -887,6 +899,15 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* q, con
     dk[off] = ak;
     dv[off] = av;
   }
+}
+
+__global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* q, const float* k,
+                                                             const float* v, const float* probs,
+                                                             const float* dout, float* dq, float* dk,
+                                                             float* dv, const float* drop_mask,
+                                                             int L, int H, int dh, float inv_scale, int ld) {
+  extern __shared__ __attribute__((aligned(16))) char smem_att[];
+  attn_small_bwd_body(q, k, v, probs, dout, dq, dk, dv, drop_mask, L, H, dh, inv_scale, ld, blockIdx.x, smem_att);
 }
 
 extern "C" int vs_attn_small_bwd(const float* q, const float* k, const float* v,
@@ -961,10 +982,9 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* x, 
 // D % 4 == 0: 16-byte accesses, every load of the row issued before the first use and no load inside
 // a divergent branch (the scalar kernel's `if (d < D)` loads were 16 serialised round trips: 12.5 us
 // for 50 x 1024)
-__global__ __launch_bounds__(256) void add_layernorm_fwd_vec_kernel(
+__device__ __forceinline__ void add_layernorm_fwd_vec_body(
     const float* x, const float* r, const float* rmask, const float* gamma, const float* beta, float* y,
-    float* mean, float* rstd, int rows, int D, float eps, int ypk) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    float* mean, float* rstd, int rows, int D, float eps, int ypk, int row) {
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
   constexpr int NE = LN_MAXE / 4;
@@ -1028,6 +1048,13 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_vec_kernel(
     if (mean) mean[row] = mu;
     if (rstd) rstd[row] = rs;
   }
+}
+
+__global__ __launch_bounds__(256) void add_layernorm_fwd_vec_kernel(
+    const float* x, const float* r, const float* rmask, const float* gamma, const float* beta, float* y,
+    float* mean, float* rstd, int rows, int D, float eps, int ypk) {
+  add_layernorm_fwd_vec_body(x, r, rmask, gamma, beta, y, mean, rstd, rows, D, eps, ypk,
+                             blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
 extern "C" int vs_add_layernorm_fwd(const float* x, const float* r, const float* rmask,
@@ -1120,7 +1147,8 @@ __global__ void add_layernorm_bwd_param_kernel(const float* dy, const float* x, 
 template <int NE>  // float4 columns per lane: D <= 256 * NE
 __device__ __forceinline__ void add_layernorm_bwd_dx_vec_body(
     const float* dy, const float* x, const float* r, const float* rmask, const float* gamma,
-    const float* mean, const float* rstd, float* dx, float* dr, int rows, int D, int row) {
+    const float* mean, const float* rstd, float* dx, float* dr, int rows, int D, int row,
+    const float* dy2 = nullptr) {  // dy2: a second addend of the output gradient (the encoder stack's fan-ins)
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
   const int D4 = D >> 2;
@@ -1134,7 +1162,11 @@ __device__ __forceinline__ void add_layernorm_bwd_dx_vec_body(
     const bool ok = d < D4;
     const long long i = base + (ok ? d : 0);
     const float4 xv = ((const float4*)x)[ok ? i : 0];
-    const float4 dv = ((const float4*)dy)[ok ? i : 0];
+    float4 dv = ((const float4*)dy)[ok ? i : 0];
+    if (dy2) {
+      const float4 d2 = ((const float4*)dy2)[ok ? i : 0];
+      dv.x += d2.x; dv.y += d2.y; dv.z += d2.z; dv.w += d2.w;
+    }
     const float4 gv = ((const float4*)gamma)[ok ? d : 0];
     v[e] = ok ? xv : z4;
     g[e] = ok ? make_float4(gv.x * dv.x, gv.y * dv.y, gv.z * dv.z, gv.w * dv.w) : z4;
@@ -1279,6 +1311,226 @@ extern "C" int vs_add_layernorm_bwd(const float* dy, const float* x, const float
                        (hipStream_t)stream, dy, x, r, rmask, gamma, mean, rstd, dx, dr, rows, D);
   hipLaunchKernelGGL(add_layernorm_bwd_param_rows_kernel, dim3((D + 63) / 64), dim3(1024), 0,
                      (hipStream_t)stream, dy, x, r, rmask, mean, rstd, dgamma, dbeta, rows, D);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// ----------------------------------------------------------------------------
+// One launch for a chain of few-row stages: the TxEncoder's 6 layers on the 8 tokens of a rank run 42
+// forward and ~50 backward launches of ~6 us each, every one depending on the one before -- 1.1 ms of a
+// 12.5 ms step with the chip idle.  Here one persistent grid (one 256-thread block per CU) walks a table
+// of stages; a stage is the body of the stand-alone kernel (same arithmetic, same order: bitwise the
+// launches it replaces) run over "virtual blocks" strided by the grid, and between two stages the grid
+// meets at a barrier (one counter per stage, agent-scope release / acquire fences around it: the L2s of the
+// eight XCDs are not coherent with each other -- MI355X_MICROARCH, memory model).  The spin has an iteration
+// cap: a block that waits too long sets the error word and leaves, so a bug here cannot hang the GPU.
+// ----------------------------------------------------------------------------
+struct TxStage {
+  long long op, M, N, K, ia, ib;  // ia / ib: op-specific integers (or float bit patterns)
+  const void* p[10];
+};
+enum { TX_LIN = 1, TX_LINBWD = 2, TX_ATTN_FWD = 3, TX_ATTN_BWD = 4, TX_LN_FWD = 5, TX_LN_BWD = 6, TX_ADD = 7 };
+
+// mode (VS_TX_BAR; default 3): bit 0 = the agent-scope fences by the first wave of a block only (every wave first waits
+// for its own stores to be acknowledged, the block meets, then one release covers them all; after the wait one
+// acquire invalidates the CU's L1 and the XCD's L2 for everybody) instead of by every wave; bit 1 = two-level
+// counters (the blocks of an XCD -- blockIdx % 8 -- meet on their own word, the last of each adds to the grid's
+// word: 32 + 8 contended atomics per word instead of 256); bit 2 = NO fences (timing experiments only, results
+// undefined).  Per barrier: 37 us (0), 14 us (1), 9.4 us (3), 2.9 us (6) -- profiles/r02_txenc_stack.txt.
+__device__ __forceinline__ bool tx_grid_barrier(unsigned* ctr, unsigned* xcd_ctr, unsigned nblocks, unsigned* err,
+                                                int mode) {
+  __shared__ int tx_timed_out;
+  const bool fence = !(mode & 4), first_wave_only = (mode & 1) != 0;
+  if (fence) {
+    if (first_wave_only) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached L2
+    else __threadfence();
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    if (fence && first_wave_only) __threadfence();  // release: the block's stores leave the XCD's L2
+    if (threadIdx.x == 0) {
+      tx_timed_out = 0;
+      if (mode & 2) {
+        const unsigned x = blockIdx.x & 7u;
+        const unsigned per = (nblocks + 7u - x) / 8u;  // blocks with this blockIdx % 8
+        const unsigned old =
+            __hip_atomic_fetch_add(xcd_ctr + x * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1 == per) __hip_atomic_fetch_add(ctr, per, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      unsigned spins = 0;
+      while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nblocks) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 20)) {
+          tx_timed_out = 1;
+          __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+    if (fence && first_wave_only) __threadfence();  // acquire (the L1 is the CU's, the L2 the XCD's: one wave's does)
+  }
+  __syncthreads();
+  if (fence && !first_wave_only) __threadfence();
+  return tx_timed_out == 0;
+}
+
+// dgamma / dbeta of a LayerNorm over <= 16 rows, one thread per column: the 16-wave kernel above gives every row
+// its own wave there and adds the per-wave terms in wave order -- i.e. sum over rows, in order, of
+// round(round(dy * (v - mean)) * rstd): the same sum, term by term, without contraction.
+__device__ __forceinline__ void tx_ln_bwd_param_body(const float* dy, const float* dy2, const float* x,
+                                                     const float* r, const float* rmask, const float* mean,
+                                                     const float* rstd, float* dgamma, float* dbeta, int rows,
+                                                     int D, int vb) {
+  const int d = vb * 256 + threadIdx.x;
+  if (d >= D) return;
+  float vv[16], gg[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const bool ok = u < rows;
+    const long long i = (long long)(ok ? u : 0) * D + d;
+    float v = x[i];
+    if (r) v += rmask ? r[i] * rmask[i] : r[i];
+    float g = dy[i];
+    if (dy2) g += dy2[i];
+    vv[u] = v;
+    gg[u] = ok ? g : 0.f;
+  }
+  float a = 0.f, b = 0.f;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    if (u < rows) {
+      a = __fadd_rn(a, __fmul_rn(__fmul_rn(gg[u], vv[u] - mean[u]), rstd[u]));
+      b = __fadd_rn(b, gg[u]);
+    }
+  }
+  dgamma[d] = a;
+  dbeta[d] = b;
+}
+
+template <int MT>
+__device__ __forceinline__ void tx_fullx(const float* x, const float* xmask, const float* w, const float* b,
+                                         const float* res, float* y, int M, int N, int K, int act, int vb) {
+  if (K <= 1024) linear_fullx_body<MT, 4>(x, xmask, w, b, res, y, M, N, K, act, vb);
+  else if (K <= 2048) linear_fullx_body<MT, 8>(x, xmask, w, b, res, y, M, N, K, act, vb);
+  else linear_fullx_body<MT, 16>(x, xmask, w, b, res, y, M, N, K, act, vb);
+}
+
+__global__ __launch_bounds__(256) void txenc_stack_kernel(const TxStage* __restrict__ stages, int nstages,
+                                                          unsigned* bars, int mode) {
+  extern __shared__ __attribute__((aligned(16))) char tx_smem[];
+  const int G = gridDim.x;
+  for (int s = 0; s < nstages; ++s) {
+    const TxStage& st = stages[s];
+    const int op = (int)st.op, M = (int)st.M, N = (int)st.N, K = (int)st.K;
+    if (op == TX_LIN) {  // y[M,N] = act(x[M,K] . w[N,K]^T + b) (+ res)
+      const int nvb = (N + 3) / 4;
+      for (int vb = blockIdx.x; vb < nvb; vb += G) {
+        tx_fullx<8>((const float*)st.p[0], nullptr, (const float*)st.p[1], (const float*)st.p[2],
+                    (const float*)st.p[3], (float*)st.p[4], M, N, K, (int)st.ia, vb);
+        __syncthreads();
+      }
+    } else if (op == TX_LINBWD) {  // dx = (dy * (relu_y > 0)) . W on wt ; dW = dy_eff^T x ; db
+      const float* dy = (const float*)st.p[0];
+      const float* relu_y = (const float*)st.p[1];
+      const int g1 = st.p[4] ? (K + 3) / 4 : 0;
+      const int g2 = (int)st.ia;
+      for (int vb = blockIdx.x; vb < g1 + g2; vb += G) {
+        if (vb < g1)
+          tx_fullx<8>(dy, relu_y, (const float*)st.p[3], nullptr, nullptr, (float*)st.p[4], M, K, N, 0, vb);
+        else
+          linear_bwd_weight_body<true>(dy, relu_y, (const float*)st.p[2], (float*)st.p[5], (float*)st.p[6], M, N, K,
+                                       vb - g1, g2);
+        __syncthreads();
+      }
+    } else if (op == TX_ATTN_FWD) {  // M = B, N = H, K = dh, ia = L, ib = float bits of 1 / scale
+      const int L = (int)st.ia, D = N * K;
+      const float* qkv = (const float*)st.p[0];
+      for (int vb = blockIdx.x; vb < M * N; vb += G) {
+        attn_small_fwd_body(qkv, qkv + D, qkv + 2 * D, (float*)st.p[1], (float*)st.p[2], (const float*)st.p[3], L, N,
+                            K, __int_as_float((int)st.ib), 3 * D, vb, tx_smem);
+        __syncthreads();
+      }
+    } else if (op == TX_ATTN_BWD) {
+      const int L = (int)st.ia, D = N * K;
+      const float* qkv = (const float*)st.p[0];
+      float* dqkv = (float*)st.p[4];
+      for (int vb = blockIdx.x; vb < M * N; vb += G) {
+        attn_small_bwd_body(qkv, qkv + D, qkv + 2 * D, (const float*)st.p[2], (const float*)st.p[1], dqkv, dqkv + D,
+                            dqkv + 2 * D, (const float*)st.p[3], L, N, K, __int_as_float((int)st.ib), 3 * D, vb,
+                            tx_smem);
+        __syncthreads();
+      }
+    } else if (op == TX_LN_FWD) {  // M rows, N = D, ib = float bits of eps
+      const int nvb = (M + 3) / 4;
+      for (int vb = blockIdx.x; vb < nvb; vb += G)
+        add_layernorm_fwd_vec_body((const float*)st.p[0], (const float*)st.p[1], (const float*)st.p[2],
+                                   (const float*)st.p[3], (const float*)st.p[4], (float*)st.p[5], (float*)st.p[6],
+                                   (float*)st.p[7], M, N, __int_as_float((int)st.ib), 0, vb * 4 + (threadIdx.x >> 6));
+    } else if (op == TX_LN_BWD) {  // p: dy, dy2, x, r, rmask, gamma, mean, rstd, dx, dr ; dgamma / dbeta behind dx
+      const int g1 = (M + 3) / 4, g2 = (N + 255) / 256;
+      float* dgamma = (float*)(size_t)st.ia;
+      float* dbeta = (float*)(size_t)st.ib;
+      for (int vb = blockIdx.x; vb < g1 + g2; vb += G) {
+        if (vb < g1) {
+          const int row = vb * 4 + (threadIdx.x >> 6);
+          if (N <= 1024)
+            add_layernorm_bwd_dx_vec_body<4>((const float*)st.p[0], (const float*)st.p[2], (const float*)st.p[3],
+                                             (const float*)st.p[4], (const float*)st.p[5], (const float*)st.p[6],
+                                             (const float*)st.p[7], (float*)st.p[8], (float*)st.p[9], M, N, row,
+                                             (const float*)st.p[1]);
+          else
+            add_layernorm_bwd_dx_vec_body<LN_MAXE / 4>(
+                (const float*)st.p[0], (const float*)st.p[2], (const float*)st.p[3], (const float*)st.p[4],
+                (const float*)st.p[5], (const float*)st.p[6], (const float*)st.p[7], (float*)st.p[8],
+                (float*)st.p[9], M, N, row, (const float*)st.p[1]);
+        } else {
+          tx_ln_bwd_param_body((const float*)st.p[0], (const float*)st.p[1], (const float*)st.p[2],
+                               (const float*)st.p[3], (const float*)st.p[4], (const float*)st.p[6],
+                               (const float*)st.p[7], dgamma, dbeta, M, N, vb - g1);
+        }
+      }
+    } else if (op == TX_ADD) {  // y = a + b, N float4s
+      const float4* a = (const float4*)st.p[0];
+      const float4* b = (const float4*)st.p[1];
+      float4* y = (float4*)st.p[2];
+      for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)G * 256) {
+        const float4 u = a[i], v = b[i];
+        y[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+      }
+    }
+    if (s + 1 < nstages &&
+        !tx_grid_barrier(bars + s, bars + nstages + 16 + s * 128, (unsigned)G, bars + nstages, mode))
+      return;
+  }
+}
+
+// stages: TxStage[nstages] in device memory; barriers: nstages * 129 + 16 words, zeroed here (word [nstages] = error
+// flag, then 8 x 16 words per stage for the two-level counters);
+// smem_bytes: the largest dynamic LDS any stage needs (8 rows x the widest inner dimension x 4 bytes).
+extern "C" int vs_txenc_stack_run(const void* stages, int nstages, void* barriers, int grid, int smem_bytes,
+                                  void* stream) {
+  VS_CHECK_ARG(stages && barriers && nstages > 0 && grid > 0 && grid <= 1024, "bad args");
+  VS_CHECK_ARG(smem_bytes >= 4 * 8 * 65 * 4 && smem_bytes <= 159 * 1024, "dynamic LDS size");
+  static bool attr = false;
+  if (!attr) {
+    // (the kernel also has a few bytes of static LDS: the cap is dynamic + static <= 160 KB)
+    if (hipFuncSetAttribute((const void*)txenc_stack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            159 * 1024) != hipSuccess) {
+      vs_set_error("vs_txenc_stack_run: hipFuncSetAttribute failed");
+      return VS_ERR_LAUNCH;
+    }
+    attr = true;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  static const int mode = getenv("VS_TX_BAR") ? atoi(getenv("VS_TX_BAR")) : 3;
+  if (hipMemsetAsync(barriers, 0, (size_t)(nstages + 16 + nstages * 128) * 4, st) != hipSuccess) {
+    vs_set_error("vs_txenc_stack_run: memset failed");
+    return VS_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(txenc_stack_kernel, dim3(grid), dim3(256), (size_t)smem_bytes, st, (const TxStage*)stages,
+                     nstages, (unsigned*)barriers, mode);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }

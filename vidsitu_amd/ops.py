@@ -776,6 +776,119 @@ def attn_small_bwd_fused(qkv, probs, do, b, l, n_heads, scale, drop_mask=None):
     return dqkv
 
 
+class TxStack:
+    """Stage list of `vs_txenc_stack_run` (include/vidsitu_hip.h): a chain of few-row kernels behind one launch.
+    Build with the methods below (each = the stand-alone op of the same name, same arguments, M <= 8 rows), then
+    `run()`.  The table travels host (pinned) -> device with an asynchronous copy on the current stream, which a
+    hipGraph capture records as a memcpy node; the object keeps every tensor it points to alive."""
+
+    GRID = 256  # one 256-thread block per CU: every block resident, the barrier cannot starve
+
+    def __init__(self, device):
+        self.device, self.rows, self.keep, self.smem = device, [], [], 4 * 8 * 65 * 4
+        self.table = self.host = self.bars = None
+
+    @staticmethod
+    def _fbits(v):
+        import struct
+
+        return struct.unpack("<i", struct.pack("<f", float(v)))[0]
+
+    def _add(self, op, m, n, k, ia, ib, tensors):
+        ptrs = [0 if t is None else int(t.data_ptr()) for t in tensors]
+        self.keep.extend(t for t in tensors if t is not None)
+        self.rows.append([op, m, n, k, ia, ib] + ptrs + [0] * (10 - len(ptrs)))
+
+    def linear(self, x, w, b, y, act=0, res=None):
+        m, k = x.shape
+        n = w.shape[0]
+        if m > 8 or k % 4 or k > 4096:
+            raise _lib.VsError("TxStack.linear: M <= 8, K % 4 == 0, K <= 4096")
+        self.smem = max(self.smem, 32 * k)
+        self._add(1, m, n, k, int(act), 0, [x, w, b, res, y])
+
+    def linear_bwd(self, dy, relu_y, x, wt, dx, dw, db):
+        m, n = dy.shape
+        k = x.shape[1]
+        if m > 8 or n % 4 or n > 4096 or k % 4:
+            raise _lib.VsError("TxStack.linear_bwd: M <= 8, N % 4 == 0, N <= 4096, K % 4 == 0")
+        self.smem = max(self.smem, 32 * n)
+        g2 = min(4096, (n * (k // 4) + 255) // 256)
+        self._add(2, m, n, k, g2, 0, [dy, relu_y, x, wt, dx, dw, db])
+
+    def attn_fwd(self, qkv, o, probs, drop_mask, b, l, heads, scale):
+        import numpy as np
+
+        dh = qkv.shape[1] // 3 // heads
+        self.smem = max(self.smem, (3 * l * dh + l * l) * 4)
+        self._add(3, b, heads, dh, l, self._fbits(np.float32(1.0) / np.float32(scale)), [qkv, o, probs, drop_mask])
+
+    def attn_bwd(self, qkv, dout, probs, drop_mask, dqkv, b, l, heads, scale):
+        import numpy as np
+
+        dh = qkv.shape[1] // 3 // heads
+        self.smem = max(self.smem, (4 * l * dh + 3 * l * l) * 4)
+        self._add(4, b, heads, dh, l, self._fbits(np.float32(1.0) / np.float32(scale)),
+                  [qkv, dout, probs, drop_mask, dqkv])
+
+    def add_layernorm(self, x, r, rmask, gamma, beta, y, mean, rstd, eps):
+        rows, d = x.shape
+        if d % 4 or d > 2048:
+            raise _lib.VsError("TxStack.add_layernorm: D % 4 == 0, D <= 2048")
+        self._add(5, rows, d, 0, 0, self._fbits(eps), [x, r, rmask, gamma, beta, y, mean, rstd])
+
+    def add_layernorm_bwd(self, dy, dy2, x, r, rmask, gamma, mean, rstd, dx, dr, dgamma, dbeta):
+        rows, d = x.shape
+        if rows > 16 or d % 4 or d > 2048:
+            raise _lib.VsError("TxStack.add_layernorm_bwd: rows <= 16, D % 4 == 0, D <= 2048")
+        self.keep.extend((dgamma, dbeta))
+        self._add(6, rows, d, 0, int(dgamma.data_ptr()), int(dbeta.data_ptr()),
+                  [dy, dy2, x, r, rmask, gamma, mean, rstd, dx, dr])
+
+    def add(self, a, b, y):
+        if a.numel() % 4:
+            raise _lib.VsError("TxStack.add: numel % 4 == 0")
+        self._add(7, 0, a.numel() // 4, 0, 0, 0, [a, b, y])
+
+    # pinned staging slots for the tables, allocated once (a pinned allocation is not allowed while a stream
+    # captures): eager runs cycle through them, a slot handed out during a capture is never reused
+    SLOT_STAGES, NSLOTS = 128, 96
+    _pin = {"buf": None, "next": 0, "frozen": set()}
+
+    @classmethod
+    def _slot(cls, n):
+        if n > cls.SLOT_STAGES:
+            raise _lib.VsError(f"TxStack: at most {cls.SLOT_STAGES} stages per launch")
+        st = cls._pin
+        capturing = torch.cuda.is_current_stream_capturing()
+        if st["buf"] is None:
+            if capturing:
+                raise _lib.VsError("TxStack: run once eagerly before capturing (pinned staging buffer)")
+            st["buf"] = torch.empty((cls.NSLOTS, cls.SLOT_STAGES, 16), dtype=torch.int64).pin_memory()
+        for _ in range(cls.NSLOTS):
+            i = st["next"]
+            st["next"] = (i + 1) % cls.NSLOTS
+            if i not in st["frozen"]:
+                if capturing:
+                    st["frozen"].add(i)
+                return st["buf"][i, :n]
+        raise _lib.VsError("TxStack: every pinned staging slot belongs to a captured graph")
+
+    def run(self):
+        n = len(self.rows)
+        if self.table is None:
+            self.host = self._slot(n)
+            self.host.copy_(torch.tensor(self.rows, dtype=torch.int64))
+            self.table = torch.empty((n, 16), dtype=torch.int64, device=self.device)
+            self.bars = torch.empty(n * 129 + 16, dtype=torch.int32, device=self.device)
+        self.table.copy_(self.host, non_blocking=True)
+        _lib.call("vs_txenc_stack_run", _ptr(self.table), n, _ptr(self.bars), self.GRID, int(self.smem), _stream())
+
+    def failed(self):
+        """True if a barrier of a past run gave up (synchronises)."""
+        return bool(int(self.bars[len(self.rows)].item()) != 0)
+
+
 def add_layernorm_fwd(x, r, gamma, beta, eps=1e-5, rmask=None):
     x = _f32c(x)
     r = _f32c(r) if r is not None else None

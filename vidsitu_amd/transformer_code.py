@@ -9,6 +9,7 @@ reductions).  Parity trap kept: the softmax scale is sqrt(d_model), not
 sqrt(head_dim) (`utils/transformer_code.py:36,54`).
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -141,6 +142,144 @@ class AddLayerNormFn(torch.autograd.Function):
 _masks = ops.DropoutPool()  # one generator launch per encoder pass
 
 
+class EncoderStackFn(torch.autograd.Function):
+    """All `EncoderLayer`s of an `Encoder` on <= 8 token rows as TWO launches (forward, backward) instead of 7 + ~9 per
+    layer: `ops.TxStack` / `vs_txenc_stack_run` walks the same kernels' bodies stage by stage behind grid barriers
+    -- bitwise the per-op path (tests/test_gpu_txenc.py).  Off by default (VS_TXENC_STACK=1 switches it on): a grid
+    barrier that is correct across the eight XCDs costs 9.4 us (2.9 us without its fences) against the 1.5 us of a
+    kernel boundary, and one resident block per CU hides less latency than eight: the step is 0.9 ms slower with it.  Parameter gradients are written in place (arena
+    parameters only, like LinearFn / AddLayerNormFn); the intermediate layer outputs it also returns are not
+    differentiable."""
+
+    @staticmethod
+    def eligible(enc, x, mask):
+        # opt-in: measured SLOWER than the per-op launches (profiles/r02_txenc_stack.txt) -- kept as the ablation
+        if os.environ.get("VS_TXENC_STACK", "0") != "1" or mask is not None or enc.pe:
+            return False
+        if not (x.is_cuda and x.dim() == 3 and torch.is_grad_enabled() and x.requires_grad and len(enc.layers) > 0):
+            return False
+        b, l, d = x.shape
+        if b * l > 8 or l > 16 or d % 4 or d > 2048:
+            return False
+        for layer in enc.layers:
+            mh, ff = layer.selfattn.layer, layer.feedforward.layer
+            f = mh._qkv
+            if f is None or f["w"].data_ptr() != mh.wq.weight.data_ptr() or f["w"].shape != (3 * d, d):
+                return False
+            if not all(w._version == v for w, v in zip(f["weights"], f["versions"])):
+                return False
+            if d % mh.n_heads or ff.linear1.weight.shape[0] % 4 or ff.linear1.weight.shape[0] > 4096:
+                return False
+            for w in (mh.wo.weight, ff.linear1.weight, ff.linear2.weight):
+                if getattr(w, "_vs_wt", None) is None or getattr(w, "_vs_wt_version", None) != w._version:
+                    return False
+            ps = [mh.wo.weight, ff.linear1.weight, ff.linear1.bias, ff.linear2.weight, ff.linear2.bias,
+                  layer.selfattn.layernorm.weight, layer.selfattn.layernorm.bias,
+                  layer.feedforward.layernorm.weight, layer.feedforward.layernorm.bias] + list(f["weights"])
+            if not all(getattr(p, "_vs_direct_grad", False) and p.grad is not None for p in ps):
+                return False
+        return True
+
+    @staticmethod
+    def forward(ctx, x, enc):
+        b, l, d = x.shape
+        rows, dev = b * l, x.device
+        x2 = x.reshape(rows, d)
+        st = ops.TxStack(dev)
+        saved = []
+        f32 = dict(dtype=torch.float32, device=dev)
+        xin = x2
+        for layer in enc.layers:
+            sa, fb = layer.selfattn, layer.feedforward
+            mh, ff = sa.layer, fb.layer
+            h_dim = ff.linear1.weight.shape[0]
+            training = enc.training
+            # the masks in the order the per-op path asks for them (same generator stream, same masks)
+            pa, p1, p2 = mh.attention.dropout.p, sa.dropout.p, fb.dropout.p
+            am = _masks.get((b, mh.n_heads, l, l), pa, dev) if training and pa > 0 else None
+            m1 = _masks.get((rows, d), p1, dev) if training and p1 > 0 else None
+            m2 = _masks.get((rows, d), p2, dev) if training and p2 > 0 else None
+            buf = torch.empty(rows * (3 * d + 5 * d + h_dim) + b * mh.n_heads * l * l + 4 * rows, **f32)
+            o = 0
+
+            def take(n, shape):
+                nonlocal o
+                t = buf[o:o + n].view(shape)
+                o += n
+                return t
+            qkv, att, br = take(rows * 3 * d, (rows, 3 * d)), take(rows * d, (rows, d)), take(rows * d, (rows, d))
+            y1, hh = take(rows * d, (rows, d)), take(rows * h_dim, (rows, h_dim))
+            ffo, y2 = take(rows * d, (rows, d)), take(rows * d, (rows, d))
+            probs = take(b * mh.n_heads * l * l, (b, mh.n_heads, l, l))
+            mean1, rstd1, mean2, rstd2 = (take(rows, (rows,)) for _ in range(4))
+            fq = mh._qkv
+            st.linear(xin, fq["w"], None, qkv)
+            st.attn_fwd(qkv, att, probs, am, b, l, mh.n_heads, mh.attention.scale)
+            st.linear(att, mh.wo.weight, None, br)
+            st.add_layernorm(xin, br, m1, sa.layernorm.weight, sa.layernorm.bias, y1, mean1, rstd1, sa.layernorm.eps)
+            st.linear(y1, ff.linear1.weight, ff.linear1.bias, hh, act=1)
+            st.linear(hh, ff.linear2.weight, ff.linear2.bias, ffo)
+            st.add_layernorm(y1, ffo, m2, fb.layernorm.weight, fb.layernorm.bias, y2, mean2, rstd2,
+                             fb.layernorm.eps)
+            saved.append(dict(xin=xin, qkv=qkv, att=att, br=br, y1=y1, hh=hh, ffo=ffo, y2=y2, probs=probs, am=am,
+                              m1=m1, m2=m2, mean1=mean1, rstd1=rstd1, mean2=mean2, rstd2=rstd2))
+            xin = y2
+        st.run()
+        ctx.enc, ctx.saved, ctx.bl, ctx.fwd_stack = enc, saved, (b, l, d), st
+        outs = tuple(r["y2"].view(b, l, d) for r in saved)
+        ctx.mark_non_differentiable(*outs[:-1])
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        enc, saved = ctx.enc, ctx.saved
+        b, l, d = ctx.bl
+        rows = b * l
+        g = gouts[-1].reshape(rows, d).contiguous()
+        dev = g.device
+        from .trunk import Conv3dP
+
+        if Conv3dP._pending_arenas:  # the [K][N] weight images are refreshed on a side stream at the step's start
+            Conv3dP.join_pending_refresh()
+        st = ops.TxStack(dev)
+        ga, gb = g, None
+        for layer, r in zip(reversed(enc.layers), reversed(saved)):
+            sa, fb = layer.selfattn, layer.feedforward
+            mh, ff = sa.layer, fb.layer
+            fq = mh._qkv
+            for w, gr in zip(fq["weights"], fq["grads"]):  # re-attach if something replaced .grad
+                if w.grad is None or w.grad.data_ptr() != gr.data_ptr():
+                    w.grad = gr
+            h_dim = ff.linear1.weight.shape[0]
+            buf = torch.empty(rows * (7 * d + h_dim + 3 * d), dtype=torch.float32, device=dev)
+            o = 0
+
+            def take(n, shape):
+                nonlocal o
+                t = buf[o:o + n].view(shape)
+                o += n
+                return t
+            d_y1a, d_f, d_y1b, d_xa, d_br, d_o, d_xb = (take(rows * d, (rows, d)) for _ in range(7))
+            d_h, dqkv = take(rows * h_dim, (rows, h_dim)), take(rows * 3 * d, (rows, 3 * d))
+            st.add_layernorm_bwd(ga, gb, r["y1"], r["ffo"], r["m2"], fb.layernorm.weight, r["mean2"], r["rstd2"],
+                                 d_y1a, d_f, fb.layernorm.weight.grad, fb.layernorm.bias.grad)
+            st.linear_bwd(d_f, None, r["hh"], ff.linear2.weight._vs_wt, d_h, ff.linear2.weight.grad,
+                          ff.linear2.bias.grad)
+            st.linear_bwd(d_h, r["hh"], r["y1"], ff.linear1.weight._vs_wt, d_y1b, ff.linear1.weight.grad,
+                          ff.linear1.bias.grad)
+            st.add_layernorm_bwd(d_y1a, d_y1b, r["xin"], r["br"], r["m1"], sa.layernorm.weight, r["mean1"],
+                                 r["rstd1"], d_xa, d_br, sa.layernorm.weight.grad, sa.layernorm.bias.grad)
+            st.linear_bwd(d_br, None, r["att"], mh.wo.weight._vs_wt, d_o, mh.wo.weight.grad, None)
+            st.attn_bwd(r["qkv"], d_o, r["probs"], r["am"], dqkv, b, l, mh.n_heads, mh.attention.scale)
+            st.linear_bwd(dqkv, None, r["xin"], fq["wt"], d_xb, fq["dw"], None)
+            ga, gb = d_xa, d_xb
+        dx = torch.empty((rows, d), dtype=torch.float32, device=dev)
+        st.add(ga, gb, dx)
+        st.run()
+        ctx.saved = None
+        return dx.view(b, l, d), None
+
+
 def hip_linear(mod, x, relu=False):
     return LinearFn.apply(x, mod.weight, mod.bias, relu)
 
@@ -242,6 +381,8 @@ class Encoder(nn.Module):
         if mask is not None:
             x = x * mask
         encoding = [x]
+        if EncoderStackFn.eligible(self, x, mask):
+            return encoding + list(EncoderStackFn.apply(x, self))
         for layer in self.layers:
             x = layer(x)
             if mask is not None:
