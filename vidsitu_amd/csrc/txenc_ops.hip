@@ -114,7 +114,7 @@ __device__ __forceinline__ void linear_fullx_body(const float* __restrict__ x, c
                                                   const float* __restrict__ w, const float* __restrict__ b,
                                                   const float* res, float* y, int M, int N, int K, int act,
                                                   int bid) {
-  extern __shared__ float4 xs4[];  // [MT][K/4]
+  extern __shared__ float4 xs4[];  // [MT][min(K, 1024) / 4]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = bid * 4 + wave;
   const int K4 = K >> 2;
@@ -126,9 +126,18 @@ __device__ __forceinline__ void linear_fullx_body(const float* __restrict__ x, c
     const float4 v = *(const float4*)(w + (ok ? (long long)n * K + k4 * 4 : 0));
     wv[u] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  // staging: thread t owns float4 columns t, t+256, ...; all MT loads of a column in flight at once
+  // x goes through LDS 1024 columns (one float4 column per thread) at a time: thread t owns column c * 256 + t of
+  // chunk c, all MT loads of it in flight at once.  (Staging all of a 3072-wide x -- the q|k|v projection's data
+  // gradient -- took 96 KB: one block per CU for the whole launch, its horizontally fused weight-gradient blocks
+  // included: 22.6 us against 9.)  The weights of every chunk are requested up front; the sums run over the
+  // chunks in order, i.e. in the same order as with x staged whole.
+  constexpr int NCH = (KC + 3) / 4;
+  const int CW4 = NCH == 1 ? K4 : 256;  // row pitch of the staged chunk, in float4s
+  float acc[MT];
 #pragma unroll
-  for (int h = 0; h < (KC + 3) / 4; ++h) {
+  for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+#pragma unroll
+  for (int h = 0; h < NCH; ++h) {
     const int k4 = h * 256 + threadIdx.x;
     float4 t[MT];
 #pragma unroll
@@ -142,29 +151,30 @@ __device__ __forceinline__ void linear_fullx_body(const float* __restrict__ x, c
       }
       t[m] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if (h) __syncthreads();  // the previous chunk has been consumed
     if (k4 < K4) {
 #pragma unroll
-      for (int m = 0; m < MT; ++m) xs4[m * K4 + k4] = t[m];
+      for (int m = 0; m < MT; ++m) xs4[m * CW4 + threadIdx.x] = t[m];
     }
-  }
-  __syncthreads();
-  float acc[MT];
+    __syncthreads();
 #pragma unroll
-  for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+    for (int uu = 0; uu < 4; ++uu) {
+      const int u = h * 4 + uu;
+      if (u < KC) {
+        const int k4u = u * 64 + lane;
+        if (k4u < K4) {
 #pragma unroll
-  for (int u = 0; u < KC; ++u) {
-    const int k4 = u * 64 + lane;
-    if (k4 < K4) {
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const float4 xv = xs4[m * K4 + k4];
-        // explicit fused multiply-adds: left to the compiler's contraction the four products were fused
-        // differently in different kernels that inline this body (stand-alone launch vs the encoder stack)
-        float a = acc[m];
-        a = __fmaf_rn(xv.x, wv[u].x, a);
-        a = __fmaf_rn(xv.y, wv[u].y, a);
-        a = __fmaf_rn(xv.z, wv[u].z, a);
-        acc[m] = __fmaf_rn(xv.w, wv[u].w, a);
+          for (int m = 0; m < MT; ++m) {
+            const float4 xv = xs4[m * CW4 + uu * 64 + lane];
+            // explicit fused multiply-adds: left to the compiler's contraction the four products were fused
+            // differently in different kernels that inline this body (stand-alone launch vs the encoder stack)
+            float a = acc[m];
+            a = __fmaf_rn(xv.x, wv[u].x, a);
+            a = __fmaf_rn(xv.y, wv[u].y, a);
+            a = __fmaf_rn(xv.z, wv[u].z, a);
+            acc[m] = __fmaf_rn(xv.w, wv[u].w, a);
+          }
+        }
       }
     }
   }
@@ -205,7 +215,7 @@ static void launch_fullx(const float* x, const float* w, const float* b, const f
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  size_t smem = (size_t)MT * K * 4;
+  size_t smem = (size_t)MT * (K < 1024 ? K : 1024) * 4;  // one 1024-column chunk of x
   if (smem < (size_t)4 * MT * 65 * 4) smem = (size_t)4 * MT * 65 * 4;
   hipLaunchKernelGGL((linear_fullx_kernel<MT, KC>), dim3((N + 3) / 4), dim3(256), smem, st, x, w, b,
                      res, y, M, N, K, act);
@@ -712,7 +722,7 @@ static void launch_bwd_fused(const float* dy, const float* relu_y, const float* 
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  size_t smem = (size_t)8 * N * 4;  // the staged dy rows (the product's inner dimension is N)
+  size_t smem = (size_t)8 * (N < 1024 ? N : 1024) * 4;  // one staged chunk of the dy rows (inner dimension N)
   if (smem < (size_t)4 * 8 * 65 * 4) smem = (size_t)4 * 8 * 65 * 4;
   const int g1 = (K + 3) / 4;  // four output columns (of dx) per block
   long long g2 = ((long long)N * ((K + 3) / 4) + 255) / 256;

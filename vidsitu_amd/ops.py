@@ -804,7 +804,7 @@ class TxStack:
         n = w.shape[0]
         if m > 8 or k % 4 or k > 4096:
             raise _lib.VsError("TxStack.linear: M <= 8, K % 4 == 0, K <= 4096")
-        self.smem = max(self.smem, 32 * k)
+        self.smem = max(self.smem, 32 * min(k, 1024))
         self._add(1, m, n, k, int(act), 0, [x, w, b, res, y])
 
     def linear_bwd(self, dy, relu_y, x, wt, dx, dw, db):
@@ -812,7 +812,7 @@ class TxStack:
         k = x.shape[1]
         if m > 8 or n % 4 or n > 4096 or k % 4:
             raise _lib.VsError("TxStack.linear_bwd: M <= 8, N % 4 == 0, N <= 4096, K % 4 == 0")
-        self.smem = max(self.smem, 32 * n)
+        self.smem = max(self.smem, 32 * min(n, 1024))
         g2 = min(4096, (n * (k // 4) + 255) // 256)
         self._add(2, m, n, k, g2, 0, [dy, relu_y, x, wt, dx, dw, db])
 
