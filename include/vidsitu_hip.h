@@ -297,6 +297,11 @@ int vs_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, 
  * Linear layers).  VS_ERR_UNSUPPORTED outside that envelope. */
 int vs_linear_bwd_fused(const float* dy, const float* relu_y, const float* x, const float* wt, float* dx,
                         float* dw, float* db, int M, int N, int K, void* stream);
+/* The same with dx = dy_eff . W + dx_res (dx_res [M,K], nullable): the gradient that reaches the layer's input over a
+ * residual connection (utils/transformer_code.py:26-31, ResidualBlock: x + dropout(layer(x))) joins in the product's
+ * epilogue instead of in an add launch of autograd's -- the same single rounding. */
+int vs_linear_bwd_fused_res(const float* dy, const float* relu_y, const float* x, const float* wt, const float* dx_res,
+                            float* dx, float* dw, float* db, int M, int N, int K, void* stream);
 
 /* A chain of few-row stages behind ONE launch (utils/transformer_code.py:215-250: the EncoderLayer stack on the
  * 8 event tokens of a rank; forward = 7 stages per layer, backward = 7).  `stages`: device array of

@@ -307,3 +307,48 @@ def test_encoder_stack_in_one_launch_is_bitwise_the_per_op_path(layers, b, l, dr
            if not torch.equal(g0[off:off + p.numel()], g1[off:off + p.numel()])]
     assert not bad, f"parameter gradients differ: {bad}"
     assert torch.equal(dx0, dx1), f"dx: max diff {float((dx0 - dx1).abs().max()):.3e}"
+
+
+@pytest.mark.parametrize("arena_on", [True, False], ids=["arena", "loose"])
+def test_residual_gradient_joins_in_the_linear_epilogue_bitwise(arena_on, dev, monkeypatch):
+    """`ResidualBlock.route_grads`: the LayerNorm's dx reaches the wrapped layer's first op through a side channel and
+    is added in that op's data-gradient epilogue (`vs_linear_bwd_fused_res`) instead of by an add launch of
+    autograd's: input gradient and parameter gradients bit for bit, with and without a parameter arena (without one
+    the q / k / v projections are three ops and the attention block keeps autograd's add)."""
+    from vidsitu_amd import transformer_code as T
+    from vidsitu_amd.optim import ParamArena
+
+    d, layers, b, l = 1024, 3, 2, 4
+    torch.manual_seed(5)
+    mdl = T.Transformer(d_model=d, n_vocab_src=0, vocab_trg=0, d_hidden=d, n_layers=layers, n_heads=8,
+                        drop_ratio=0.1, pe=False).to(dev).train()
+    if arena_on:
+        ParamArena(mdl)
+    x0, dy = torch.randn(b, l, d, device=dev), torch.randn(b, l, d, device=dev)
+    monkeypatch.setenv("VS_TXENC_STACK", "0")
+
+    def run(route):
+        monkeypatch.setattr(T.ResidualBlock, "route_grads", route)
+        n_adds = []
+        orig = T.ops.linear_bwd
+        monkeypatch.setattr(T.ops, "linear_bwd", lambda *a, **k: (n_adds.append(k.get("dx_res") is not None), orig(*a, **k))[1])
+        for p in mdl.parameters():
+            if p.grad is not None:
+                p.grad.fill_(float("nan")) if arena_on else None
+            if not arena_on:
+                p.grad = None
+        torch.manual_seed(11)
+        T._masks.__init__()
+        x = x0.clone().requires_grad_()
+        out = mdl.encoder(x)[-1]
+        out.backward(dy)
+        torch.cuda.synchronize()
+        monkeypatch.setattr(T.ops, "linear_bwd", orig)
+        return out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in mdl.parameters()], sum(n_adds)
+
+    o0, dx0, g0, n0 = run(False)
+    o1, dx1, g1, n1 = run(True)
+    assert n0 == 0 and n1 == (2 if arena_on else 1) * layers
+    assert torch.equal(o0, o1) and torch.equal(dx0, dx1)
+    bad = [k for (k, _), a, c in zip(mdl.named_parameters(), g0, g1) if not torch.equal(a, c)]
+    assert not bad, bad

@@ -94,6 +94,7 @@ SIGNATURES = {
     "vs_linear_bwd_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "vs_linear_bwd_fused": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "vs_txenc_stack_run": (_i, [_p, _i, _p, _i, _i, _p]),
+    "vs_linear_bwd_fused_res": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "vs_attn_small_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "vs_attn_small_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "vs_add_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),

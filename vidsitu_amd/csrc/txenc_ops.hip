@@ -706,16 +706,17 @@ __global__ __launch_bounds__(256) void linear_bwd_fused_kernel(const float* __re
                                                                const float* __restrict__ relu_y,
                                                                const float* __restrict__ x,
                                                                const float* __restrict__ wt, float* dx, float* dw,
-                                                               float* db, int M, int N, int K, int g1, int g2) {
+                                                               float* db, int M, int N, int K, int g1, int g2,
+                                                               const float* dx_res) {
   if ((int)blockIdx.x < g1)
-    linear_fullx_body<MT, KC>(dy, relu_y, wt, nullptr, nullptr, dx, M, K, N, 0, blockIdx.x);
+    linear_fullx_body<MT, KC>(dy, relu_y, wt, nullptr, dx_res, dx, M, K, N, 0, blockIdx.x);
   else
     linear_bwd_weight_body<VEC>(dy, relu_y, x, dw, db, M, N, K, blockIdx.x - g1, g2);
 }
 
 template <int KC, bool VEC>
 static void launch_bwd_fused(const float* dy, const float* relu_y, const float* x, const float* wt, float* dx,
-                             float* dw, float* db, int M, int N, int K, hipStream_t st) {
+                             float* dw, float* db, int M, int N, int K, hipStream_t st, const float* dx_res) {
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)linear_bwd_fused_kernel<8, KC, VEC>,
@@ -728,11 +729,12 @@ static void launch_bwd_fused(const float* dy, const float* relu_y, const float* 
   long long g2 = ((long long)N * ((K + 3) / 4) + 255) / 256;
   if (g2 > 4096) g2 = 4096;
   hipLaunchKernelGGL((linear_bwd_fused_kernel<8, KC, VEC>), dim3((unsigned)(g1 + g2)), dim3(256), smem, st, dy,
-                     relu_y, x, wt, dx, dw, db, M, N, K, g1, (int)g2);
+                     relu_y, x, wt, dx, dw, db, M, N, K, g1, (int)g2, dx_res);
 }
 
-extern "C" int vs_linear_bwd_fused(const float* dy, const float* relu_y, const float* x, const float* wt, float* dx,
-                                   float* dw, float* db, int M, int N, int K, void* stream) {
+extern "C" int vs_linear_bwd_fused_res(const float* dy, const float* relu_y, const float* x, const float* wt,
+                                       const float* dx_res, float* dx, float* dw, float* db, int M, int N, int K,
+                                       void* stream) {
   VS_CHECK_ARG(dy && x && wt && dx && dw && M > 0 && N > 0 && K > 0, "bad args");
   const uintptr_t al = (uintptr_t)dy | (uintptr_t)relu_y | (uintptr_t)wt;
   if (M > 8 || (N & 3) || N > 4096 || (al & 15)) {
@@ -742,8 +744,8 @@ extern "C" int vs_linear_bwd_fused(const float* dy, const float* relu_y, const f
   }
   const bool vec = (K & 3) == 0 && ((((uintptr_t)x | (uintptr_t)dw)) & 15) == 0;
   hipStream_t st = (hipStream_t)stream;
-#define VS_LBF(KC_) (vec ? launch_bwd_fused<KC_, true>(dy, relu_y, x, wt, dx, dw, db, M, N, K, st) \
-                         : launch_bwd_fused<KC_, false>(dy, relu_y, x, wt, dx, dw, db, M, N, K, st))
+#define VS_LBF(KC_) (vec ? launch_bwd_fused<KC_, true>(dy, relu_y, x, wt, dx, dw, db, M, N, K, st, dx_res) \
+                         : launch_bwd_fused<KC_, false>(dy, relu_y, x, wt, dx, dw, db, M, N, K, st, dx_res))
   if (N <= 1024) VS_LBF(4);
   else if (N <= 2048) VS_LBF(8);
   else VS_LBF(16);
@@ -754,6 +756,11 @@ extern "C" int vs_linear_bwd_fused(const float* dy, const float* relu_y, const f
     return VS_ERR_LAUNCH;
   }
   return VS_OK;
+}
+
+extern "C" int vs_linear_bwd_fused(const float* dy, const float* relu_y, const float* x, const float* wt, float* dx,
+                                   float* dw, float* db, int M, int N, int K, void* stream) {
+  return vs_linear_bwd_fused_res(dy, relu_y, x, wt, nullptr, dx, dw, db, M, N, K, stream);
 }
 
 extern "C" int vs_linear_bwd_weight(const float* dy, const float* x, float* dw, float* db, int M,

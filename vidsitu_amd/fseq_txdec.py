@@ -468,10 +468,10 @@ class _FseqEncoderLayer(nn.Module):
     def forward(self, x):
         a = self.self_attn(x)
         ln = self.self_attn_layer_norm
-        x = AddLayerNormFn.apply(x, a, ln.weight, ln.bias, ln.eps, self._mask(a))
+        x = AddLayerNormFn.apply(x, a, ln.weight, ln.bias, ln.eps, self._mask(a), None)
         f = hip_linear(self.fc2, hip_linear(self.fc1, x, relu=True))
         ln = self.final_layer_norm
-        return AddLayerNormFn.apply(x, f, ln.weight, ln.bias, ln.eps, self._mask(f))
+        return AddLayerNormFn.apply(x, f, ln.weight, ln.bias, ln.eps, self._mask(f), None)
 
 
 class TxEncoderOld(nn.Module):

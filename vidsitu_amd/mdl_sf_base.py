@@ -93,7 +93,7 @@ class HipMLP(nn.Sequential):
             m = mods[i]
             if isinstance(m, nn.Linear):
                 relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-                x = LinearFn.apply(x, m.weight, m.bias, relu)
+                x = LinearFn.apply(x, m.weight, m.bias, relu, None)
                 i += 2 if relu else 1
             else:
                 raise NotImplementedError(type(m))

@@ -650,10 +650,11 @@ def linear_fwd(x, w, b=None, relu=False):
 _LINEAR_BWD_FUSED = _os.environ.get("VS_LINEAR_BWD_FUSED", "1") != "0"  # A/B: 0 = relu_bwd + bwd_data + bwd_weight launches
 
 
-def linear_bwd(dy, x, w, need_dx=True, has_bias=True, dw_out=None, db_out=None, wt=None, relu_y=None):
+def linear_bwd(dy, x, w, need_dx=True, has_bias=True, dw_out=None, db_out=None, wt=None, relu_y=None, dx_res=None):
     """dw_out / db_out: write the parameter gradients in place (gradient-arena views).
     wt: an up-to-date [K][N] image of w (the parameter arena keeps one); else transposed here.
-    relu_y: the layer's ReLU output -- dy is masked by (relu_y > 0) inside the kernels (no relu_bwd launch)."""
+    relu_y: the layer's ReLU output -- dy is masked by (relu_y > 0) inside the kernels (no relu_bwd launch).
+    dx_res [M, K]: added to dx (a gradient arriving over a residual connection around the layer)."""
     dy, x, w = _f32c(dy), _f32c(x), _f32c(w)
     m, n = dy.shape
     k = x.shape[1]
@@ -670,8 +671,10 @@ def linear_bwd(dy, x, w, need_dx=True, has_bias=True, dw_out=None, db_out=None, 
             db = None
             if has_bias:
                 db = db_out if db_out is not None else torch.empty(n, dtype=torch.float32, device=x.device)
-            _lib.call("vs_linear_bwd_fused", _ptr(dy), _ptr(relu_y), _ptr(x), _ptr(wt), _ptr(dx), _ptr(dw), _ptr(db),
-                      m, n, k, _stream())
+            if dx_res is not None and (dx_res.dtype != torch.float32 or not dx_res.is_contiguous()):
+                dx_res = _f32c(dx_res)
+            _lib.call("vs_linear_bwd_fused_res", _ptr(dy), _ptr(relu_y), _ptr(x), _ptr(wt), _ptr(dx_res), _ptr(dx),
+                      _ptr(dw), _ptr(db), m, n, k, _stream())
             return dx, dw, db
     if relu_y is not None:
         dy = relu_bwd(dy, relu_y)
@@ -686,6 +689,8 @@ def linear_bwd(dy, x, w, need_dx=True, has_bias=True, dw_out=None, db_out=None, 
     if has_bias:
         db = db_out if db_out is not None else torch.empty(n, dtype=torch.float32, device=x.device)
     _lib.call("vs_linear_bwd_weight", _ptr(dy), _ptr(x), _ptr(dw), _ptr(db), m, n, k, _stream())
+    if dx_res is not None and dx is not None:
+        dx = dx + dx_res.reshape(dx.shape)
     return dx, dw, db
 
 

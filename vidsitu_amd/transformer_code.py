@@ -21,7 +21,8 @@ class LinearFn(torch.autograd.Function):
     """y = act(x @ W^T + b) on vs_linear_*  (x: [..., K] fp32)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu):
+    def forward(ctx, x, w, b, relu, route):
+        ctx.route = route  # see ResidualBlock: the residual path's gradient joins this layer's dx in the kernel
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         y = ops.linear_fwd(x2, w, b, relu)
@@ -51,11 +52,12 @@ class LinearFn(torch.autograd.Function):
             dy2.contiguous(), x2, w, need_dx=ctx.needs_input_grad[0], has_bias=ctx.has_bias,
             dw_out=ctx.w_param.grad if direct else None,
             db_out=ctx.b_param.grad if (direct and ctx.has_bias) else None, wt=wt,
-            relu_y=y if ctx.relu else None)  # the ReLU mask is applied inside the gradient kernels
+            relu_y=y if ctx.relu else None,  # the ReLU mask is applied inside the gradient kernels
+            dx_res=ctx.route.pop("dx", None) if ctx.route is not None else None)
         dx = dx.reshape(ctx.shp) if dx is not None else None
         if direct:
-            return dx, None, None, None
-        return dx, dw, db, None
+            return dx, None, None, None, None
+        return dx, dw, db, None, None
 
 
 class AttnSmallFn(torch.autograd.Function):
@@ -84,7 +86,8 @@ class FusedQKVAttnFn(torch.autograd.Function):
     -- the encoder runs on 8 tokens, every launch is pure latency on the critical path of the step."""
 
     @staticmethod
-    def forward(ctx, x, fused, n_heads, scale, drop_mask):
+    def forward(ctx, x, fused, n_heads, scale, drop_mask, route):
+        ctx.route = route
         b, l, d = x.shape
         x2 = x.reshape(b * l, d)
         qkv = ops.linear_fwd(x2, fused["w"], None, False)
@@ -108,15 +111,17 @@ class FusedQKVAttnFn(torch.autograd.Function):
         for w, g in zip(f["weights"], f["grads"]):  # re-attach if something replaced .grad
             if w.grad is None or w.grad.data_ptr() != g.data_ptr():
                 w.grad = g
-        dx, _, _ = ops.linear_bwd(dqkv, x2, f["w"], need_dx=True, has_bias=False, dw_out=f["dw"], wt=wt)
-        return dx.reshape(b, l, -1), None, None, None, None
+        dx, _, _ = ops.linear_bwd(dqkv, x2, f["w"], need_dx=True, has_bias=False, dw_out=f["dw"], wt=wt,
+                                  dx_res=ctx.route.pop("dx", None) if ctx.route is not None else None)
+        return dx.reshape(b, l, -1), None, None, None, None, None
 
 
 class AddLayerNormFn(torch.autograd.Function):
     """LayerNorm(x + r * rmask) (vs_add_layernorm_*); rmask = residual-dropout mask or None."""
 
     @staticmethod
-    def forward(ctx, x, r, gamma, beta, eps, rmask):
+    def forward(ctx, x, r, gamma, beta, eps, rmask, route):
+        ctx.route = route
         shp = x.shape
         x2, r2 = x.reshape(-1, shp[-1]).contiguous(), r.reshape(-1, shp[-1]).contiguous()
         y, mean, rstd = ops.add_layernorm_fwd(x2, r2, gamma, beta, eps, rmask)
@@ -134,9 +139,13 @@ class AddLayerNormFn(torch.autograd.Function):
         dx, dr, dg, db = ops.add_layernorm_bwd(
             dy.reshape(x2.shape), x2, r2, gamma, mean, rstd, rmask,
             dg_out=ctx.params[0].grad if direct else None, db_out=ctx.params[1].grad if direct else None)
+        gx = dx.reshape(ctx.shp)
+        if ctx.route is not None:  # x's other consumer adds it to its own input gradient (no add launch)
+            ctx.route["dx"] = dx
+            gx = None
         if direct:
-            return dx.reshape(ctx.shp), dr.reshape(ctx.shp), None, None, None, None
-        return dx.reshape(ctx.shp), dr.reshape(ctx.shp), dg, db, None, None
+            return gx, dr.reshape(ctx.shp), None, None, None, None, None
+        return gx, dr.reshape(ctx.shp), dg, db, None, None, None
 
 
 _masks = ops.DropoutPool()  # one generator launch per encoder pass
@@ -280,8 +289,16 @@ class EncoderStackFn(torch.autograd.Function):
         return dx.view(b, l, d), None
 
 
-def hip_linear(mod, x, relu=False):
-    return LinearFn.apply(x, mod.weight, mod.bias, relu)
+def hip_linear(mod, x, relu=False, route=None):
+    return LinearFn.apply(x, mod.weight, mod.bias, relu, route)
+
+
+def _take_route(mod):
+    """The gradient route a ResidualBlock offers the layer it wraps (`_route`), accepted: marked armed."""
+    route = getattr(mod, "_route", None)
+    if route is not None:
+        route["armed"] = True
+    return route
 
 
 class Attention(nn.Module):
@@ -313,7 +330,7 @@ class MultiHead(nn.Module):
                 and fused["w"].data_ptr() == self.wq.weight.data_ptr():
             b, l, _ = query.shape
             mask = _masks.get((b, self.n_heads, l, l), p, query.device) if self.training and p > 0 else None
-            o = FusedQKVAttnFn.apply(query, fused, self.n_heads, self.attention.scale, mask)
+            o = FusedQKVAttnFn.apply(query, fused, self.n_heads, self.attention.scale, mask, _take_route(self))
             return hip_linear(self.wo, o)
         q, k, v = hip_linear(self.wq, query), hip_linear(self.wk, key), hip_linear(self.wv, value)
         mask = None
@@ -331,7 +348,7 @@ class FeedForward(nn.Module):
         self.linear2 = nn.Linear(d_hidden, d_model)
 
     def forward(self, x):
-        return hip_linear(self.linear2, hip_linear(self.linear1, x, relu=True))
+        return hip_linear(self.linear2, hip_linear(self.linear1, x, relu=True, route=_take_route(self)))
 
 
 class ResidualBlock(nn.Module):
@@ -341,14 +358,30 @@ class ResidualBlock(nn.Module):
         self.dropout = nn.Dropout(drop_ratio)
         self.layernorm = nn.LayerNorm(d_model)
 
+    # x feeds the wrapped layer and the residual add: autograd would sum the two gradients of x with an add
+    # launch (12 per step on the critical path of the 8-token section).  Instead the LayerNorm's backward hands its
+    # dx to the layer's first op (a dict both hold), whose data-gradient kernel adds it in its epilogue
+    # (`vs_linear_bwd_fused_res`): the same sum, rounded once.  VS_RESIDUAL_ROUTE=0 = autograd's add.
+    route_grads = os.environ.get("VS_RESIDUAL_ROUTE", "1") != "0"
+
     def forward(self, *x):
-        branch = self.layer(*x)
+        route = None
+        if ResidualBlock.route_grads and torch.is_grad_enabled() and x[0].requires_grad and x[0].is_cuda \
+                and all(t is x[0] for t in x):
+            route = {"armed": False}
+        self.layer._route = route
+        try:
+            branch = self.layer(*x)
+        finally:
+            self.layer._route = None
+        if route is not None and not route["armed"]:
+            route = None
         rmask = None
         if self.training and self.dropout.p > 0:  # transformer_code.py:30 x + dropout(layer(x))
             rmask = _masks.get((branch.numel() // branch.shape[-1], branch.shape[-1]),
                                 self.dropout.p, branch.device)
         return AddLayerNormFn.apply(x[0], branch, self.layernorm.weight, self.layernorm.bias,
-                                    self.layernorm.eps, rmask)
+                                    self.layernorm.eps, rmask, route)
 
 
 class EncoderLayer(nn.Module):
