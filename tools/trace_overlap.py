@@ -55,3 +55,22 @@ try:
         print(f"  {t / 1e3:7.1f} us {c:3d} x {t / c / 1e3:6.1f}  {k}")
 except ValueError:
     pass
+
+# idle time (no kernel running) attributed to the kernel that ends the gap, and to the one that ran before it
+ev = sorted(s, key=lambda x: x[0])
+end_max, prev_name = ev[0][1], ev[0][2]
+by_next, by_pair = collections.defaultdict(lambda: [0, 0]), collections.defaultdict(lambda: [0, 0])
+for a, b, n in ev[1:]:
+    if a > end_max:
+        k = n.split("(")[0][:50]
+        by_next[k][0] += a - end_max; by_next[k][1] += 1
+        kp = prev_name.split("(")[0][:40] + " -> " + k[:40]
+        by_pair[kp][0] += a - end_max; by_pair[kp][1] += 1
+    if b > end_max:
+        end_max, prev_name = b, n
+print("idle before (last burst):")
+for k, (t, c) in sorted(by_next.items(), key=lambda kv: -kv[1][0])[:14]:
+    print(f"  {t / 1e3:7.1f} us {c:4d} gaps {t / c / 1e3:5.1f} us each  {k}")
+print("idle by (kernel that ended last -> kernel that starts):")
+for k, (t, c) in sorted(by_pair.items(), key=lambda kv: -kv[1][0])[:14]:
+    print(f"  {t / 1e3:7.1f} us {c:4d} x {t / c / 1e3:5.1f}  {k}")
