@@ -86,7 +86,7 @@ class EntryProbe:
         probe = self
         import ctypes as C
 
-        def conv_label(d, dgrad, bnb=False):
+        def conv_label(d, dgrad, bnb=False, bnb2=False):
             out = (C.c_int * 5)()
             lib.vs_conv_plan(C.byref(d), dgrad, out)
             bm, bn, ring, S, direct = list(out)
@@ -94,16 +94,20 @@ class EntryProbe:
             unit = d.sT == 1 and d.sH == 1 and d.sW == 1
             pw = taps == 1 and d.pT == 0 and d.pH == 0 and d.pW == 0
             mode = (0 if (pw and unit) else (1 if unit else 2)) if dgrad else (0 if pw else 1)
+            tf = lambda v: "true" if v else "false"
             if direct == 2:  # halo-image kernel (conv_halo.hip): wave tile in 16-row / 16-column units,
                 # weight-ring depth (reported in the `ring` slot), unrolled taps (in the `split` slot)
-                return f"conv_halo_kernel<{bm // 32}, {bn // 32}, {'true' if bnb else 'false'}, {ring}, {S}>"
-            if direct:
+                return f"conv_halo_kernel<{bm // 32}, {bn // 32}, {tf(bnb)}, {ring}, {S}>"
+            if direct == 3:  # persistent pointwise kernel (conv_pw.hip): column tile, BN sums, ablation switch
+                return f"conv_pw_kernel<{bn}, {tf(bnb)}, 0>"
+            if direct:  # small-channel kernel: column tiles, 32-wide K steps, mode, 16-row tiles in flight, BN sums
                 ncols = d.Cin if dgrad else d.Cout
                 K = taps * (d.Cout if dgrad else d.Cin)
-                return f"conv_direct_kernel<{1 if ncols <= 16 else 2}, {min((K + 31) // 32, 5)}, {mode}>"
+                nt, ks = (1 if ncols <= 16 else 2), min((K + 31) // 32, 6)
+                return f"conv_direct_kernel<{nt}, {ks}, {mode}, {4 if nt * ks <= 6 else 2}, false>"
             wm, wn = _WAVES[(bm, bn)]
             fast = "true" if taps <= 31 else "false"
-            tail = f", 0, {ring}, {'true' if bnb else 'false'}" if taps <= 31 else ""
+            tail = f", 0, {ring}, {tf(bnb)}, {tf(bnb2)}" if taps <= 31 else ""
             name = f"conv_igemm_kernel<{bm}, {bn}, {wm}, {wn}, {mode}, {fast}{tail}>"
             return name + (f" +splitk{S}" if S > 1 else "")
 
@@ -124,9 +128,10 @@ class EntryProbe:
                     return conv_label(d, 1, True), "mfma", flops, byts + 2.0 * mi * d.Cin
                 if name == "vs_conv_dgrad_ex":
                     ep = a[4]._obj
-                    bnb = bool(ep.stats_partial)
-                    extra = (2.0 if ep.residual else 0.0) + (2.0 if bnb else 0.0) + (0.125 if ep.residual_bits else 0.0)
-                    return conv_label(d, 1, bnb), "mfma", flops, byts + extra * mi * d.Cin
+                    bnb, bnb2 = bool(ep.stats_partial), bool(ep.stats_partial2)
+                    extra = (2.0 if ep.residual else 0.0) + (2.0 if bnb else 0.0) + (2.0 if bnb2 else 0.0) + \
+                        (0.125 if ep.residual_bits else 0.0)
+                    return conv_label(d, 1, bnb, bnb2), "mfma", flops, byts + extra * mi * d.Cin
                 return conv_label(d, 1 if name == "vs_conv_dgrad" else 0), "mfma", flops, byts
             if name in ("vs_stem_conv_fwd", "vs_stem_conv_wgrad"):
                 n, t, h, w, cout, kt = [_v(x) for x in a[3:9]]
@@ -192,10 +197,12 @@ def park_gpu(ms):
     torch.cuda._sleep(int(ms / park_gpu.per_mcycle * 1e6))
 
 
-def load_pmc_traffic():
+def load_pmc_traffic(workload="sf_txenc_train"):
     """HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/pmc_traffic.sh ->
-    profiles/pmc_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    profiles/pmc_traffic.json, profiles/pmc_traffic_feat_fwd.json for the forward workload; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json" if workload == "sf_txenc_train"
+                        else f"pmc_traffic_{workload}.json")
     try:
         with open(path) as f:
             return json.load(f)
@@ -523,7 +530,7 @@ def main():
             probe.remove()
             _trunk.VideoTrunk.dual_stream, _trunk._WgradLanes.enabled = saved_modes
         agg = probe.summary()
-        pmc = load_pmc_traffic()
+        pmc = load_pmc_traffic(args.workload)
 
         def fam(name, v):
             n, ms, fl, by, bound = v
@@ -568,7 +575,7 @@ def main():
         top = next((fam(k, v) for k, v in fams if v[4] is not None), None)
         roof = dict(top)
         roof["probed_ms_per_step"] = round(tot_ms, 3)
-        roof["traffic_source"] = ("profiles/pmc_traffic.json (" + str(pmc.get("_meta", {}).get("build", "build not recorded")) +
+        roof["traffic_source"] = ("profiles/pmc_traffic" + ("" if train else "_" + args.workload) + ".json (" + str(pmc.get("_meta", {}).get("build", "build not recorded")) +
                                   "): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh, "
                                   "not collected in this run")
         roof["note"] = ("dominant entry point of the step by summed HIP-event time; separate "
