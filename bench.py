@@ -590,7 +590,7 @@ def main():
         roof["families"] = [fam(k, v) for k, v in fams[:16]]
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # a reported baseline of the N = 1 line only
         cpu = cpu_baseline(args.workload, len(comm.vb_id_vocab))
 
     if rank == 0:
