@@ -352,3 +352,63 @@ def test_residual_gradient_joins_in_the_linear_epilogue_bitwise(arena_on, dev, m
     assert torch.equal(o0, o1) and torch.equal(dx0, dx1)
     bad = [k for (k, _), a, c in zip(mdl.named_parameters(), g0, g1) if not torch.equal(a, c)]
     assert not bad, bad
+
+
+def test_txstack_stage_kinds_are_bitwise_the_stand_alone_ops(dev):
+    """Every stage kind of `vs_txenc_stack_run` against the entry point whose body it runs, bit for bit -- alone and
+    chained (a stage reading what the stage before it wrote on other CUs / XCDs: the grid barrier's fences)."""
+    from vidsitu_amd import ops
+
+    torch.manual_seed(0)
+    rows, d, n3 = 8, 1024, 3072
+    f = dict(device=dev, dtype=torch.float32)
+    a, b2, x, r = (torch.randn(rows, d, **f) for _ in range(4))
+    rmask = F.dropout(torch.ones(rows, d, **f), 0.1, True)
+    gamma, beta = torch.randn(d, **f), torch.randn(d, **f)
+    w3 = torch.randn(n3, d, **f) * 0.02
+    wt3 = w3.t().contiguous()
+    bias = torch.randn(n3, **f)
+
+    def run(build):
+        st = ops.TxStack(dev)
+        outs = build(st)
+        st.run()
+        torch.cuda.synchronize()
+        assert not st.failed(), "a grid barrier gave up"
+        return outs
+
+    # forward kinds: linear (+bias, ReLU), add + LayerNorm, attention on a fused q|k|v buffer
+    y_ref = ops.linear_fwd(x, w3, bias, True)
+    ln_ref, mean, rstd = ops.add_layernorm_fwd(x, r, gamma, beta, 1e-5, rmask)
+    o_ref, p_ref = ops.attn_small_fwd_fused(y_ref, 2, 4, 8, 32.0, None)
+
+    def fwd(st):
+        y, ln = torch.empty(rows, n3, **f), torch.empty(rows, d, **f)
+        mu, rs = torch.empty(rows, **f), torch.empty(rows, **f)
+        o, p = torch.empty(rows, d, **f), torch.empty(2, 8, 4, 4, **f)
+        st.linear(x, w3, bias, y, act=1)
+        st.add_layernorm(x, r, rmask, gamma, beta, ln, mu, rs, 1e-5)
+        st.attn_fwd(y, o, p, None, 2, 4, 8, 32.0)  # reads the first stage's output
+        return y, ln, mu, rs, o, p
+    for name, got, ref in zip(("linear", "layernorm", "mean", "rstd", "attention", "probs"), run(fwd),
+                              (y_ref, ln_ref, mean, rstd, o_ref.reshape(rows, d), p_ref)):
+        assert torch.equal(got, ref), name
+
+    # backward kinds, chained: linear_bwd (inner dimension 3072) -> add + LayerNorm backward with two addends -> add
+    dyq = torch.randn(rows, n3, **f)
+    dx_ref, dw_ref, _ = ops.linear_bwd(dyq, x, w3, need_dx=True, has_bias=False, wt=wt3)
+    dxl, drl, dg_ref, db_ref = ops.add_layernorm_bwd(a + dx_ref, x, r, gamma, mean, rstd, rmask)
+    dq_ref = ops.attn_small_bwd_fused(y_ref, p_ref, a.reshape(2, 4, d), 2, 4, 8, 32.0, None)
+
+    def bwd(st):
+        dx, dw = torch.empty(rows, d, **f), torch.empty(n3, d, **f)
+        dx2, dr2, dg, db = torch.empty(rows, d, **f), torch.empty(rows, d, **f), torch.empty(d, **f), torch.empty(d, **f)
+        s, dq = torch.empty(rows, d, **f), torch.empty(rows, n3, **f)
+        st.linear_bwd(dyq, None, x, wt3, dx, dw, None)
+        st.add_layernorm_bwd(a, dx, x, r, rmask, gamma, mean, rstd, dx2, dr2, dg, db)
+        st.add(dx2, dr2, s)
+        st.attn_bwd(y_ref, a, p_ref, None, dq, 2, 4, 8, 32.0)
+        return dx, dw, dx2, dr2, dg, db, s, dq
+    refs = (dx_ref, dw_ref, dxl, drl, dg_ref, db_ref, dxl + drl, dq_ref)
+    for name, got, ref in zip(("dx", "dw", "ln dx", "ln dr", "dgamma", "dbeta", "add", "dqkv"), run(bwd), refs):
+        assert torch.equal(got, ref), name
