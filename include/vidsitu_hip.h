@@ -264,6 +264,21 @@ int vs_maxpool_hw3s2_fwd(const void* x, void* y, uint8_t* idx, int N, int T, int
                          int x_ld, int y_ld, void* stream);
 int vs_maxpool_hw3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int T, int H, int W,
                          int C, int dy_ld, int dx_ld, void* stream);
+/* The stem's BatchNorm + ReLU + max-pool [1,3,3] / [1,2,2] / pad [0,1,1] (upstream ResNetBasicStem; mdl_sf_base.py:22
+ * runs it as s1) without the full-resolution normalised tensor: one forward pass from the conv output to the pooled
+ * tensor (+ argmax bytes), and the two BN-backward passes with the pool's gradient gathered from (d_pooled, idx)
+ * instead of read from a dense tensor.  Bitwise vs_bn_apply + vs_maxpool_hw3s2_fwd and vs_maxpool_hw3s2_bwd +
+ * vs_bn_bwd_reduce / vs_bn_bwd_apply (relu = 1, mask recomputed from y).  Fewer than 2^24 positions, C/8 a power
+ * of two; VS_ERR_UNSUPPORTED / VS_ERR_BAD_ARG otherwise. */
+int vs_bn_apply_maxpool(const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, int N, int T,
+                        int H, int W, int C, int y_ld, int out_ld, void* stream);
+int vs_bn_bwd_reduce_pool(const void* d_pooled, const uint8_t* idx, const void* y, const float* mean,
+                          const float* invstd, const float* gamma, const float* beta, float* partial, int N, int T,
+                          int H, int W, int C, int dp_ld, int y_ld, void* stream);
+int vs_bn_bwd_apply_pool(const void* d_pooled, const uint8_t* idx, const void* y, const float* mean,
+                         const float* invstd, const float* gamma, const float* beta, const float* dgamma,
+                         const float* dbeta, void* dy, int N, int T, int H, int W, int C, int dp_ld, int y_ld,
+                         int dy_ld, void* stream);
 /* MaxPool3d k=s=[kt,1,1] (pathway0_pool of c2d / i3d, mdl_sf_base.py:49-51). */
 int vs_maxpool_t_fwd(const void* x, void* y, uint8_t* idx, int N, int T, int HW, int C, int kt,
                      void* stream);

@@ -168,3 +168,27 @@ def test_bn_bwd_finalize_sums_any_number_of_partial_rows(nparts, c, dev):
     want = part.double().sum(0)
     assert torch.allclose(dbeta, want[0].float(), rtol=1e-6, atol=1e-6)
     assert torch.allclose(dgamma, want[1].float(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("c,n,t,h,w", [(8, 2, 3, 16, 16), (64, 2, 2, 14, 18), (16, 1, 1, 7, 9), (64, 1, 2, 112, 112)])
+def test_stem_bn_relu_maxpool_in_one_pass_is_bitwise_the_three_launches(c, n, t, h, w, dev):
+    """`bn_apply_maxpool` = bn_apply + maxpool_hw, `bn_bwd(pool_src=...)` = maxpool_hw_bwd + bn_bwd (mask recomputed
+    from y): pooled tensor, argmax bytes, dy, dgamma and dbeta bit for bit (odd sizes: clipped windows; ReLU: ties)."""
+    from vidsitu_amd import ops
+
+    g = torch.Generator().manual_seed(9)
+    y = to_act(rb(torch.randn(n, c, t, h, w, generator=g)), dev)
+    scale = (torch.rand(c, generator=g) + 0.5).to(dev)
+    shift = (torch.randn(c, generator=g) * 0.3).to(dev)
+    z = ops.bn_apply(y, scale, shift, None, True)
+    p_ref, i_ref = ops.maxpool_hw(z, want_idx=True)
+    p, i = ops.bn_apply_maxpool(y, scale, shift)
+    assert torch.equal(p, p_ref) and torch.equal(i, i_ref)
+    # backward: gamma / beta / mean / invstd such that gamma * xhat + beta reproduces the forward mask
+    mean, invstd = (torch.randn(c, generator=g) * 0.1).to(dev), (torch.rand(c, generator=g) + 0.5).to(dev)
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).to(dev), (torch.randn(c, generator=g) * 0.3).to(dev)
+    dp = to_act(rb(torch.randn(tuple(p.shape), generator=g)), dev)
+    dz = ops.maxpool_hw_bwd(dp, i_ref, tuple(y.shape))
+    dy_ref, _, dg_ref, db_ref = ops.bn_bwd(dz, None, y, mean, invstd, gamma, True, False, beta=beta)
+    dy, _, dg, db = ops.bn_bwd(None, None, y, mean, invstd, gamma, True, False, beta=beta, pool_src=(dp, i_ref))
+    assert torch.equal(dy, dy_ref) and torch.equal(dg, dg_ref) and torch.equal(db, db_ref)

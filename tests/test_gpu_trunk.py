@@ -554,3 +554,47 @@ def test_overfit_one_batch_end_to_end(dev):
     mdl.eval()
     _, mets = sel["evl"](cfg, comm, dev)(mdl, loss_fn, [batch])
     assert mets["Per_Ev_Top_1"] >= 0.9, mets
+
+
+@pytest.mark.parametrize("arch,bwd", [("slowfast", False), ("slowfast", True), ("i3d", True)])
+def test_fused_stem_pool_step_is_bitwise_the_unfused_step(arch, bwd, dev):
+    """`ResNetBasicStem.fuse_pool`: features and every gradient of a train-mode pass are bit for bit those of the pass
+    with bn_apply, maxpool_hw and maxpool_hw_bwd as separate launches."""
+    from oracle.slowfast_ref import default_sf_cfg
+    from vidsitu_amd import trunk as T
+
+    torch.manual_seed(3)
+    frames = 32 if arch == "slowfast" else 8
+    cfg = default_sf_cfg(arch, 50, 64, frames)
+    mdl = T.VideoTrunk(cfg).to(dev).train()
+    g = torch.Generator().manual_seed(4)
+    fast = torch.randn(2, 3, frames, 64, 64, generator=g).to(dev)
+    xs = [fast[:, :, ::4].contiguous(), fast] if arch == "slowfast" else [fast]
+    bufs = {k: v.clone() for k, v in mdl.named_buffers()}
+
+    calls = []
+    orig = T.ops.bn_apply_maxpool
+
+    def run(fuse):
+        T.ResNetBasicStem.fuse_pool, T.ResNetBasicStem.fuse_pool_bwd = fuse, bwd
+        T.ops.bn_apply_maxpool = lambda *a, **k: (calls.append(fuse), orig(*a, **k))[1]
+        for k, v in mdl.named_buffers():
+            v.copy_(bufs[k])
+        for p in mdl.parameters():
+            p.grad = None
+        feats = mdl.forward_features([x.clone() for x in xs])
+        gg = torch.Generator().manual_seed(5)
+        sum((f.float() * torch.randn(f.shape, generator=gg).to(dev)).sum() for f in feats).backward()
+        torch.cuda.synchronize()
+        return [f.detach().clone() for f in feats], {k: p.grad.clone() for k, p in mdl.named_parameters()}
+
+    try:
+        f0, g0 = run(False)
+        f1, g1 = run(True)
+    finally:
+        T.ResNetBasicStem.fuse_pool, T.ResNetBasicStem.fuse_pool_bwd = True, False
+        T.ops.bn_apply_maxpool = orig
+    assert calls == [True] * len(xs)  # one fused pass per stem, only in the fused run
+    assert all(torch.equal(a, b) for a, b in zip(f0, f1))
+    bad = [k for k in g0 if not torch.equal(g0[k], g1[k])]
+    assert not bad, bad[:5]

@@ -84,6 +84,9 @@ SIGNATURES = {
     ),
     "vs_maxpool_hw3s2_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "vs_maxpool_hw3s2_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "vs_bn_apply_maxpool": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "vs_bn_bwd_reduce_pool": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "vs_bn_bwd_apply_pool": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "vs_maxpool_t_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vs_maxpool_t_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vs_avgpool_fwd": (_i, [_p, _p, _i, _i64, _i, _i, _i, _i, _p]),

@@ -450,6 +450,119 @@ extern "C" int vs_bn_apply_mask(const void* y, const float* scale, const float* 
 }
 
 // ----------------------------------------------------------------------------
+// The stems: BN + ReLU + max-pool [1,3,3] / [1,2,2] / pad [0,1,1] as ONE forward pass over the conv output (the
+// normalised full-resolution tensor is never written: its only reader was the pool) and, in the backward passes,
+// the pool's gradient gathered on the fly from the pooled gradient and the argmax bytes instead of read from a
+// dense tensor a pool-backward launch wrote.  The arithmetic is the separate kernels' (values rounded to bf16
+// where they were stored as bf16, same comparison and summation order): bitwise the unfused path.
+// ----------------------------------------------------------------------------
+struct PoolSrc {
+  const uint16_t* dp;  // gradient of the pooled tensor [NT, Ho, Wo, C]
+  const uint8_t* idx;  // argmax tap (dh * 3 + dw) per pooled element
+  int H, W, Ho, Wo, dp_ld;
+  float rcp_w, rcp_h;
+};
+
+// dz of one full-resolution row (< 2^24 rows) and 8 channels, as the bf16 vector vs_maxpool_hw3s2_bwd would have stored
+__device__ __forceinline__ uint4 pool_grad8(const PoolSrc& ps, int row, int c, int C) {
+  int p1, w, nt, h;
+  fast_divmod(row, ps.W, ps.rcp_w, p1, w);
+  fast_divmod(p1, ps.H, ps.rcp_h, nt, h);
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  const int ho_lo = h >> 1, ho_hi = (h + 1) >> 1;
+  const int wo_lo = w >> 1, wo_hi = (w + 1) >> 1;
+  for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+    if (ho >= ps.Ho) continue;
+    const int dh = h - (2 * ho - 1);
+    for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+      if (wo >= ps.Wo) continue;
+      const int tap = dh * 3 + (w - (2 * wo - 1));
+      const long long opos = ((long long)nt * ps.Ho + ho) * ps.Wo + wo;
+      const uint2 pk = *(const uint2*)(ps.idx + opos * C + c);
+      float g[8];
+      unpack8_bf16(*(const uint4*)(ps.dp + opos * ps.dp_ld + c), g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const unsigned b = ((e < 4 ? pk.x : pk.y) >> ((e & 3) * 8)) & 0xff;
+        if ((int)b == tap) acc[e] += g[e];
+      }
+    }
+  }
+  return pack8_bf16(acc);
+}
+
+__global__ void bn_apply_maxpool_kernel(const uint16_t* y, const float* scale, const float* shift, uint16_t* out,
+                                        uint8_t* idx, int NT, int H, int W, int Ho, int Wo, int C, int y_ld,
+                                        int out_ld) {
+  const int cpr = C >> 3;
+  const int total = NT * Ho * Wo * cpr;  // < 2^24 (checked by the launcher)
+  const float rcp_c = 1.0f / (float)cpr, rcp_w = 1.0f / (float)Wo, rcp_h = 1.0f / (float)Ho;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int p1, p2, nt, cb, wo, ho;
+    fast_divmod(i, cpr, rcp_c, p1, cb);
+    fast_divmod(p1, Wo, rcp_w, p2, wo);
+    fast_divmod(p2, Ho, rcp_h, nt, ho);
+    const int c = cb * 8;
+    float sc[8], sh[8], best[8];
+    int bi[8];
+    *(float4*)(sc) = *(const float4*)(scale + c);
+    *(float4*)(sc + 4) = *(const float4*)(scale + c + 4);
+    *(float4*)(sh) = *(const float4*)(shift + c);
+    *(float4*)(sh + 4) = *(const float4*)(shift + c + 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      best[e] = -INFINITY;
+      bi[e] = 0;
+    }
+    for (int dh = 0; dh < 3; ++dh) {
+      const int h = 2 * ho - 1 + dh;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int dw = 0; dw < 3; ++dw) {
+        const int w = 2 * wo - 1 + dw;
+        if ((unsigned)w >= (unsigned)W) continue;
+        float v[8];
+        unpack8_bf16(*(const uint4*)(y + (((long long)nt * H + h) * W + w) * y_ld + c), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] * sc[e] + sh[e], 0.f);
+        unpack8_bf16(pack8_bf16(v), v);  // what bn_apply stores and the pool reads
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (v[e] > best[e] || (v[e] != v[e] && best[e] == best[e])) {
+            best[e] = v[e];
+            bi[e] = dh * 3 + dw;
+          }
+      }
+    }
+    const long long opos = ((long long)nt * Ho + ho) * Wo + wo;
+    *(uint4*)(out + opos * out_ld + c) = pack8_bf16(best);
+    if (idx) {
+      uint2 pk;
+      pk.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+      pk.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+      *(uint2*)(idx + opos * C + c) = pk;
+    }
+  }
+}
+
+extern "C" int vs_bn_apply_maxpool(const void* y, const float* scale, const float* shift, void* out, uint8_t* idx,
+                                   int N, int T, int H, int W, int C, int y_ld, int out_ld, void* stream) {
+  VS_CHECK_ARG(y && scale && shift && out, "null tensor");
+  VS_CHECK_ARG(C % 8 == 0 && y_ld % 8 == 0 && out_ld % 8 == 0, "C / pitches multiple of 8");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long long total = (long long)N * T * Ho * Wo * (C / 8);
+  if (total >= (1ll << 24) || (long long)N * T * H * W >= (1ll << 24)) {
+    vs_set_error("vs_bn_apply_maxpool: fewer than 2^24 rows (use vs_bn_apply + vs_maxpool_hw3s2_fwd)");
+    return VS_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(bn_apply_maxpool_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)y, scale, shift, (uint16_t*)out, idx, N * T, H, W, Ho, Wo, C, y_ld, out_ld);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// ----------------------------------------------------------------------------
 // BN backward.  g = dz * [z > 0] (relu) ; xhat = (y - mean) * invstd
 //   reduce : partial[blk][2][C] = (sum g, sum g*xhat) over the block's row slab
 //   apply  : dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M) ; dres = g
@@ -473,11 +586,11 @@ static int bnb_batches(long long rows, int C) {
 // MASK 0: no relu; 1: relu mask from z; 2: mask recomputed as gamma*xhat + beta > 0 (units
 // without a residual input), which drops one of the three reads of each pass; 3: `z` is the
 // bit mask written by vs_bn_apply_mask ([rows][C/8] bytes): one byte instead of 16 per load.
-template <int MASK>
+template <int MASK, bool POOL = false>  // POOL: dz gathered from (pooled gradient, argmax bytes) -- see PoolSrc
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const uint16_t* dz, const uint16_t* z, const uint16_t* y, const float* mean,
     const float* invstd, const float* gamma, const float* beta, float* partial, long long rows,
-    int C, int dz_ld, int z_ld, int y_ld, int nbatch) {
+    int C, int dz_ld, int z_ld, int y_ld, int nbatch, PoolSrc ps = PoolSrc()) {
   __shared__ float red[256 * 16];
   const int cpr = C >> 3;
   const int ncol = cpr < 256 ? cpr : 256;  // chunk columns handled per pass
@@ -504,7 +617,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
         const long long row = r0 + (long long)(b * BNB_BATCH + u) * rl + lane_r;
         const bool ok = row < rows;
         const long long rr = ok ? row : 0;
-        vg[u] = *(const uint4*)(dz + rr * dz_ld + c);
+        vg[u] = POOL ? pool_grad8(ps, (int)rr, c, C) : *(const uint4*)(dz + rr * dz_ld + c);
         vy[u] = *(const uint4*)(y + rr * y_ld + c);
         if (MASK == 1) vz[u] = *(const uint4*)(z + rr * z_ld + c);
         if (MASK == 3) vz[u].x = ((const uint8_t*)z)[rr * cpr + cb];
@@ -698,12 +811,12 @@ __global__ void bn_bwd_apply_kernel(const uint16_t* dz, const uint16_t* z, const
 
 // Column-owner form of the backward apply (see bn_apply_cols_kernel): per-channel constants
 // a = gamma*invstd, b1 = dbeta/M, b2 = dgamma/M live in registers.
-template <int MASK, bool DRES>
+template <int MASK, bool DRES, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_cols_kernel(
     const uint16_t* dz, const uint16_t* z, const uint16_t* y, const float* mean, const float* invstd,
     const float* gamma, const float* beta, const float* dgamma, const float* dbeta, uint16_t* dy,
     uint16_t* dres, long long rows, int C, int dz_ld, int z_ld, int y_ld, int dy_ld, int dres_ld,
-    int nbatch) {
+    int nbatch, PoolSrc ps = PoolSrc()) {
   const int cpr = C >> 3;
   const int ncol = cpr < 256 ? cpr : 256;
   const int rl = 256 / ncol;
@@ -729,7 +842,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cols_kernel(
       for (int u = 0; u < BNA_BATCH; ++u) {
         row[u] = r0 + (long long)(b * BNA_BATCH + u) * rl + lane_r;
         const long long rr = row[u] < rows ? row[u] : 0;
-        vg[u] = *(const uint4*)(dz + rr * dz_ld + c);
+        vg[u] = POOL ? pool_grad8(ps, (int)rr, c, C) : *(const uint4*)(dz + rr * dz_ld + c);
         vy[u] = *(const uint4*)(y + rr * y_ld + c);
         if (MASK == 1) vz[u] = *(const uint4*)(z + rr * z_ld + c);
         if (MASK == 3) vz[u].x = ((const uint8_t*)z)[rr * cpr + cb];
@@ -801,6 +914,57 @@ extern "C" int vs_bn_bwd_apply(const void* dz, const void* z, const void* y, con
   else if (z) hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, grid, block, 0, st, BNB_ARGS);
   else hipLaunchKernelGGL(bn_bwd_apply_kernel<2>, grid, block, 0, st, BNB_ARGS);
 #undef BNB_ARGS
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+static int pool_src(PoolSrc& ps, const void* dp, const uint8_t* idx, int N, int T, int H, int W, int C, int dp_ld) {
+  if (!dp || !idx || C % 8 != 0 || dp_ld % 8 != 0 || !bnb_check(C) || (long long)N * T * H * W >= (1ll << 24))
+    return 0;
+  ps.dp = (const uint16_t*)dp;
+  ps.idx = idx;
+  ps.H = H;
+  ps.W = W;
+  ps.Ho = (H + 2 - 3) / 2 + 1;
+  ps.Wo = (W + 2 - 3) / 2 + 1;
+  ps.dp_ld = dp_ld;
+  ps.rcp_w = 1.0f / (float)W;
+  ps.rcp_h = 1.0f / (float)H;
+  return 1;
+}
+
+// vs_bn_bwd_reduce / vs_bn_bwd_apply of a unit whose output went through the [1,3,3] / [1,2,2] max-pool and nothing
+// else (the stems; ReLU mask recomputed from y): the output gradient is (d_pooled, idx) instead of a dense tensor.
+extern "C" int vs_bn_bwd_reduce_pool(const void* d_pooled, const uint8_t* idx, const void* y, const float* mean,
+                                     const float* invstd, const float* gamma, const float* beta, float* partial,
+                                     int N, int T, int H, int W, int C, int dp_ld, int y_ld, void* stream) {
+  VS_CHECK_ARG(y && mean && invstd && gamma && beta && partial, "null tensor");
+  PoolSrc ps;
+  VS_CHECK_ARG(pool_src(ps, d_pooled, idx, N, T, H, W, C, dp_ld), "C/8 a power of two, fewer than 2^24 rows");
+  const long long rows = (long long)N * T * H * W;
+  const int nblk = vs_bn_bwd_reduce_rows(rows, C);
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<2, true>), dim3(nblk), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)nullptr, (const uint16_t*)nullptr, (const uint16_t*)y, mean, invstd, gamma,
+                     beta, partial, rows, C, 0, 0, y_ld, bnb_batches(rows, C), ps);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+extern "C" int vs_bn_bwd_apply_pool(const void* d_pooled, const uint8_t* idx, const void* y, const float* mean,
+                                    const float* invstd, const float* gamma, const float* beta, const float* dgamma,
+                                    const float* dbeta, void* dy, int N, int T, int H, int W, int C, int dp_ld,
+                                    int y_ld, int dy_ld, void* stream) {
+  VS_CHECK_ARG(y && mean && invstd && gamma && beta && dgamma && dbeta && dy, "null tensor");
+  PoolSrc ps;
+  VS_CHECK_ARG(pool_src(ps, d_pooled, idx, N, T, H, W, C, dp_ld), "C/8 a power of two, fewer than 2^24 rows");
+  const long long rows = (long long)N * T * H * W;
+  const int nb = bn_rows_batches(rows, C, 2048);
+  const int cpr = C / 8, ncol = cpr < 256 ? cpr : 256;
+  const long long rpb = (long long)(256 / ncol) * BNA_BATCH * nb;
+  hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<2, false, true>), dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256),
+                     0, (hipStream_t)stream, (const uint16_t*)nullptr, (const uint16_t*)nullptr, (const uint16_t*)y,
+                     mean, invstd, gamma, beta, dgamma, dbeta, (uint16_t*)dy, (uint16_t*)nullptr, rows, C, 0, 0, y_ld,
+                     dy_ld, 0, nb, ps);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }

@@ -522,8 +522,27 @@ def bn_apply(y, scale, shift, residual=None, relu=True, out=None, want_bits=Fals
     return (out, None) if want_bits else out
 
 
+def bn_apply_maxpool(y, scale, shift, out=None, want_idx=True):
+    """maxpool_hw(relu(y * scale + shift)) in one pass (the stems): -> (pooled, idx | None).  Bitwise bn_apply +
+    maxpool_hw; the full-resolution normalised tensor is not written."""
+    n, c, t, h, w = y.shape
+    ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    if out is None:
+        out = new_act(n, c, t, ho, wo, y.device)
+    idx = torch.empty((n, t, ho, wo, c), dtype=torch.uint8, device=y.device) if want_idx else None
+    _lib.call("vs_bn_apply_maxpool", _ptr(y), _ptr(scale), _ptr(shift), _ptr(out), _ptr(idx), n, t, h, w, c,
+              act_ld(y), act_ld(out), _stream())
+    return out, idx
+
+
+def bn_apply_maxpool_ok(y):
+    n, c, t, h, w = y.shape
+    cpr = c // 8
+    return c % 8 == 0 and cpr & (cpr - 1) == 0 and n * t * h * w < (1 << 24)
+
+
 def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres, dy_out=None, dgamma=None, dbeta=None,
-           beta=None, zbits=None, partial=None):
+           beta=None, zbits=None, partial=None, pool_src=None):
     """Returns (dy, dres|None, dgamma, dbeta); dgamma / dbeta may be given (param.grad views).
     ReLU mask source, in order of preference: `zbits` (uint8 [rows, C/8] from bn_apply), `z`
     (the unit's output), or -- with `beta` given and both None -- recomputed from y (units
@@ -531,6 +550,25 @@ def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres, dy_out=None, dgamma=N
     (conv_dgrad(bn_stats=...), recomputed-mask units only): the reduce pass is skipped."""
     rows, c = act_rows(y), y.shape[1]
     dev = y.device
+    if pool_src is not None:
+        # dz = maxpool_hw_bwd(d_pooled, idx), gathered inside the two passes (the stems: vs_bn_bwd_*_pool)
+        if dz is not None or z is not None or zbits is not None or partial is not None or not relu or beta is None \
+                or want_dres:
+            raise _lib.VsError("bn_bwd(pool_src=...): a ReLU unit without residual input whose mask is recomputed")
+        dp, pidx = pool_src
+        n, _, t, h, w = y.shape
+        nblk = _lib.load().vs_bn_bwd_reduce_rows(rows, c)
+        partial = torch.empty((nblk, 2, c), dtype=torch.float32, device=dev)
+        _lib.call("vs_bn_bwd_reduce_pool", _ptr(dp), _ptr(pidx), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma),
+                  _ptr(beta), _ptr(partial), n, t, h, w, c, act_ld(dp), act_ld(y), _stream())
+        dgamma = torch.empty(c, dtype=torch.float32, device=dev) if dgamma is None else dgamma
+        dbeta = torch.empty(c, dtype=torch.float32, device=dev) if dbeta is None else dbeta
+        _lib.call("vs_bn_bwd_finalize", _ptr(partial), nblk, _ptr(dgamma), _ptr(dbeta), c, _stream())
+        dy = new_act(*y.shape, device=dev) if dy_out is None else dy_out
+        _lib.call("vs_bn_bwd_apply_pool", _ptr(dp), _ptr(pidx), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma),
+                  _ptr(beta), _ptr(dgamma), _ptr(dbeta), _ptr(dy), n, t, h, w, c, act_ld(dp), act_ld(y), act_ld(dy),
+                  _stream())
+        return dy, None, dgamma, dbeta
     mode = int(relu)
     zz = z if relu else None
     z_ld = act_ld(zz) if zz is not None else 0

@@ -210,7 +210,9 @@ class _Unit:
     fuse_sc_sums = os.environ.get("VS_FUSE_SC_SUMS", "1") != "0"  # the shortcut unit's sums from the same epilogue
 
     @staticmethod
-    def fwd(conv, bn, x, relu, residual=None, out=None, train=False, saved=None):
+    def fwd(conv, bn, x, relu, residual=None, out=None, train=False, saved=None, pool=False):
+        """pool (train mode, the stems): the unit's output goes through the [1,3,3] max-pool and nowhere else --
+        BN + ReLU + pool run as one pass, the record gets the argmax bytes (`pool_idx`) and no `z`."""
         if not train:
             scale, shift = bn.fold
             if conv.bias is not None:  # BN(conv + b) folded: the bias joins the shift
@@ -236,6 +238,13 @@ class _Unit:
             with torch.no_grad():
                 bn.running_mean.add_(conv.bias.detach() * bn.momentum)
         # a unit with a residual input cannot recompute its ReLU mask from y alone: keep it as bits
+        if pool and not ops.bn_apply_maxpool_ok(y):
+            pool, out = False, None  # the caller pools z itself (`out` was meant for the pooled tensor)
+        if pool:
+            pooled, pidx = ops.bn_apply_maxpool(y, scale, shift, out=out)
+            saved.append(dict(conv=conv, bn=bn, x=x, y=y, z=None, zbits=None, mean=mean, invstd=invstd,
+                              relu=True, has_res=False, pool_idx=pidx))
+            return pooled
         want_bits = relu and residual is not None and y.shape[1] % 8 == 0 and \
             ((y.shape[1] // 8) & (y.shape[1] // 8 - 1)) == 0
         z, zbits = ops.bn_apply(y, scale, shift, residual, relu, out=out, want_bits=True) if want_bits \
@@ -269,10 +278,11 @@ class _Unit:
         if dz_bits is not None:
             assert not rec["relu"], "dz_bits belongs to a unit without a ReLU of its own"
             relu, zbits, zmask = True, dz_bits, None
+        pidx = rec.get("pool_idx")  # a stem unit run with pool=True: dz is the POOLED tensor's gradient
         dy, dres, _, _ = ops.bn_bwd(
-            dz, zmask, rec["y"], rec["mean"], rec["invstd"], bn.weight, relu, want_dres,
+            None if pidx is not None else dz, zmask, rec["y"], rec["mean"], rec["invstd"], bn.weight, relu, want_dres,
             dgamma=bn.weight.grad, dbeta=bn.bias.grad, beta=bn.bias, zbits=zbits,
-            partial=rec.pop("bwd_partial", None))
+            partial=rec.pop("bwd_partial", None), pool_src=(dz, pidx) if pidx is not None else None)
         x = rec["x"]
         if conv.bias is not None:  # analytically zero behind a train-mode BN
             if conv.bias.grad is None:
@@ -339,8 +349,23 @@ class ResNetBasicStem(nn.Module):
         self.conv = Conv3dP(cin, cout, (kt, 7, 7), (1, 2, 2), (kt // 2, 3, 3))
         self.bn = BN3dP(cout, eps, mom)
 
+    # train mode: BN + ReLU + pool in one pass (ops.bn_apply_maxpool): the full-resolution normalised tensor -- 154 MB for
+    # the two stems of SlowFast-R50 at 8 clips -- is neither written nor re-read.  VS_STEM_POOL_FUSE=0: separate launches.
+    # (The pool's backward inside the BN-backward passes, ops.bn_bwd(pool_src=...), exists as well.)
+    fuse_pool = os.environ.get("VS_STEM_POOL_FUSE", "1") != "0"
+    # the backward half is off by default: measured alone (tools/stem_pool_time.py) the forward pass is 62 vs 80 us
+    # (slow stem) and 26 vs 42 us (fast stem), but gathering the pool's gradient inside BOTH backward passes costs
+    # more instructions than the dense tensor costs bytes: 202 vs 149 us and 126 vs 83 us.  VS_STEM_POOL_FUSE_BWD=1.
+    fuse_pool_bwd = os.environ.get("VS_STEM_POOL_FUSE_BWD", "0") == "1"
+
     def fwd(self, x, out, train, saved):
-        z = _Unit.fwd(self.conv, self.bn, x, True, train=train, saved=saved)
+        if train and ResNetBasicStem.fuse_pool and _Unit.trace is None:
+            z = _Unit.fwd(self.conv, self.bn, x, True, out=out, train=True, saved=saved, pool=True)
+            if saved[-1].get("pool_idx") is not None:  # fused: z is the pooled tensor
+                saved.append(dict(fused_pool=True))
+                return z
+        else:
+            z = _Unit.fwd(self.conv, self.bn, x, True, train=train, saved=saved)
         y, idx = ops.maxpool_hw(z, out=out, want_idx=train)
         if train:
             saved.append(dict(pool_idx=idx, pool_in=tuple(z.shape)))
@@ -348,6 +373,12 @@ class ResNetBasicStem(nn.Module):
 
     def bwd(self, saved, dy):
         rec = saved.pop()
+        if rec.get("fused_pool"):
+            unit = saved.pop()
+            if not ResNetBasicStem.fuse_pool_bwd:
+                dy = ops.maxpool_hw_bwd(dy, unit.pop("pool_idx"), tuple(unit["y"].shape))
+            _Unit.bwd(unit, dy, need_dx=False)
+            return
         dz = ops.maxpool_hw_bwd(dy, rec["pool_idx"], rec["pool_in"])
         _Unit.bwd(saved.pop(), dz, need_dx=False)
 
