@@ -473,10 +473,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     };
 #pragma unroll
     for (int d = 0; d < D; ++d) dma(kbeg + d, d);
-    // A/B on one box (profiles/r02_ring_frags_first.txt): -8..-11 % on the long reductions (s4 / s5 first-block conv a
-    // both directions, [3,1,1] dgrads), +2 % on the 9..18-step 3x3 layers: on from 20 k-steps.  VS_RING_FRAGS_FIRST=0|1
-    // (bits 13 / 14 of the launch flags) forces it off / on.
-    const bool frags_first = (p.flags & (1 << 14)) != 0 || (!(p.flags & (1 << 13)) && nk >= 20);
+    // Optional order of the ring loop: the first fragment reads of a k-step issued before the copies of tile kt + D.
+    // OFF by default.  Measured cleanly (profiles/r02_ring_frags_first.txt, VS_RING_FF_MIN / VS_RING_FF_MAX, same box,
+    // alternating) it costs 0..7 % on the long reductions and changes nothing in the step.  (An earlier A/B that showed
+    // -8..-11 % was void: its on / off switch travelled in launch-flag bits 13 / 14, which the launcher also reads as
+    // the diagnostic-variant selector of the 128 x 128 tile -- the two arms ran two different diagnostic kernels.)
+    const bool frags_first = nk >= p.ff_min && nk <= p.ff_max;
     int st_c = 0, st_l = D;  // stage computed / stage refilled this step
     for (int kt = 0; kt < nk; ++kt) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"i"((D - 1) * L) : "memory");  // my part of tile kt landed
@@ -1280,10 +1282,13 @@ static void setup_stride_classes(ConvP& p, int bm, int mode, int flags) {
 
 static int launch_conv(ConvP& p, int mode, int naive, int flags, void* ws, size_t ws_bytes,
                        hipStream_t st) {
-  static const int frags_first = [] { const char* e = getenv("VS_RING_FRAGS_FIRST"); return e ? atoi(e) : -1; }();
-  p.flags &= ~(3 << 13);
-  if (frags_first == 1) p.flags |= 1 << 14;
-  if (frags_first == 0) p.flags |= 1 << 13;
+  // fragment-first ring order (off by default, see the ring loop): VS_RING_FRAGS_FIRST=1 switches it on everywhere,
+  // VS_RING_FF_MIN / VS_RING_FF_MAX bound the k-step counts it is used for
+  static const int frags_first = [] { const char* e = getenv("VS_RING_FRAGS_FIRST"); return e ? atoi(e) : 0; }();
+  static const int ff_min = [] { const char* e = getenv("VS_RING_FF_MIN"); return e ? atoi(e) : -1; }();
+  static const int ff_max = [] { const char* e = getenv("VS_RING_FF_MAX"); return e ? atoi(e) : 1 << 30; }();
+  p.ff_min = ff_min >= 0 ? ff_min : (frags_first == 1 ? 0 : 1 << 30);
+  p.ff_max = ff_max;
   p.splitK = 1;
   p.slab = nullptr;
   if (naive) {

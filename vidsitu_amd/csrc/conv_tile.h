@@ -52,6 +52,7 @@ struct ConvP {
   const uint8_t* res_bits;
   int dense;  // pointwise, unit stride: row m is position m of the gathered tensor (no row decode)
   int nclips;  // M / (Rt * Rh * Rw)
+  int ff_min, ff_max;  // ring loop: fragment reads before the copy issue for ff_min <= k-steps <= ff_max
   // VS_CONV_BNBWD with RESIDUAL, second unit: a ResBlock's shortcut unit receives the same masked gradient as its c
   // unit (one sum(g), two sum(g * xhat)): stats2[tm][0][c] = sum g, [1][c] = sum g * (bny2 - mean2) * invstd2
   const uint16_t* bny2;

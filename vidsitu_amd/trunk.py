@@ -438,7 +438,7 @@ class ResBlock(nn.Module):
         # The gradient over the identity / shortcut branch is dout under the block's ReLU mask.  With the mask
         # kept as bits (`zbits`, written by the forward apply) its two readers take (dout, bits) and the c unit's
         # backward apply does not write a masked copy (`dres`: one block-output-sized tensor per block).
-        cbits = rc.get("zbits") if ResBlock.mask_by_bits else None
+        cbits = rc.get("zbits")  # None for channel counts whose mask is not kept as bits
         db, g = _Unit.bwd(rc, dout, want_dres=cbits is None, producer=rb)
         da, _ = _Unit.bwd(rb, db, producer=ra)
         if self.has_sc:
@@ -463,8 +463,7 @@ class ResBlock(nn.Module):
             dx, _ = _Unit.bwd(ra, da, dx_residual=g, producer=saved[-1] if (chain and saved) else None)
         return dx
 
-    # A/B switches (VS_MASK_BY_BITS=0 / VS_ACC_SHORTCUT=0: the round-1 data flow)
-    mask_by_bits = os.environ.get("VS_MASK_BY_BITS", "1") != "0"
+    # A/B switch (VS_ACC_SHORTCUT=0: the round-1 data flow of the shortcut's gradient)
     accumulate_shortcut = os.environ.get("VS_ACC_SHORTCUT", "1") != "0"
 
 
