@@ -62,9 +62,22 @@ class TrainStep:
     # ---- pieces ------------------------------------------------------------------------------
     def fwd_bwd(self):
         a = self.arena
-        a.transposes_async()  # dgrad weight images of the last update, beside the forward pass
+        mod = getattr(self.mdl, "vid_feat_encoder", None)
+        fired, tr_hook = [], None
+        if TrainStep.late_transposes and isinstance(mod, torch.nn.Module):
+            def refresh(m, inp):  # (a forward pre-hook's return value replaces the input: return None)
+                if not fired:
+                    fired.append(1)
+                    a.transposes_async()
+            tr_hook = mod.register_forward_pre_hook(refresh)
+        else:
+            a.transposes_async()  # dgrad weight images of the last update, beside the forward pass
         hooks = self._zero_grads()
         out = self.mdl(self.batch)
+        if tr_hook is not None:
+            tr_hook.remove()
+            if not fired:
+                a.transposes_async()
         loss = self.loss_fn(out, self.batch)["loss"]
         loss.backward()
         for h in hooks:
@@ -95,6 +108,13 @@ class TrainStep:
             if g is not None and not any(q is r for r in seen):
                 seen.append(q)
         return [p.register_hook(lambda g, q=p: note(g, q)) for p in self.arena.params]
+
+    # The refresh of the transposed weight images (0.2 ms of HBM-bound side-stream kernels) has no reader before the
+    # backward pass.  Beside the stems it competes with the heaviest streaming kernels of the step; the 8-token encoder
+    # section between the trunk's forward and backward leaves the chip idle -- so, when the model has a
+    # `vid_feat_encoder` (the first module behind the trunk), the refresh is launched from a forward pre-hook on it
+    # (and right after the forward pass if that module never ran).  VS_TRANSPOSE_LATE=0: at the start of the step.
+    late_transposes = os.environ.get("VS_TRANSPOSE_LATE", "1") != "0"
 
     def _adam(self):
         self.opt.step(world=self.world, defer_transposes=True, grad_bf16=self.grad_bf16)
