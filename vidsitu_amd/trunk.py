@@ -142,12 +142,17 @@ class _WgradLanes:
     # are created once (never inside a hipGraph capture, where creating a stream is an unsafe call).
     lanes = {}
 
+    # A fork + join pair costs ~17 us in a replayed hipGraph on this system (tools/graph_edge_cost.py): a weight
+    # gradient only goes to the lane when its convolution is at least this large (GFLOP of the unit's GEMM);
+    # smaller ones run inline in front of the dgrad.  VS_WGRAD_LANE_MIN_GFLOP: sweep knob.
+    min_gflop = float(os.environ.get("VS_WGRAD_LANE_MIN_GFLOP", "0"))
+
     @classmethod
-    def run(cls, fn, *keep):
+    def run(cls, fn, *keep, gflop=None):
         """fn runs on the lane; if it returns a callable (the slab reduce of ops.conv_wgrad_split) that runs on the
         lane too, but BEHIND the event the issuing stream waits for: the reduce reads no operand of the unit, so the
         issuing stream goes on as soon as the wgrad kernel itself is done (~7 us per unit off its critical path)."""
-        if not cls.enabled or not keep[0].is_cuda:
+        if not cls.enabled or not keep[0].is_cuda or (gflop is not None and gflop < cls.min_gflop):
             tail = fn()
             return tail() if callable(tail) else None
         main = torch.cuda.current_stream()
@@ -297,14 +302,16 @@ class _Unit:
             # gradients that live in a ParamArena keep their address: their position-split partials go to the
             # trunk's WgradBatch and are summed by one launch per backward segment (VideoTrunk._flush_wgrads)
             batch = _Unit.wgrad_batch if getattr(conv.weight, "_vs_direct_grad", False) else None
+            gf = 2e-9 * dy.numel() * conv.cin * conv.k[0] * conv.k[1] * conv.k[2]  # the unit's GEMM, GFLOP
             if batch is not None:
                 _WgradLanes.run(lambda: (ops.conv_wgrad(dy, x, conv.k, conv.s, conv.p, out=conv.weight.grad,
-                                                        batch=batch), None)[1], dy, x)
+                                                        batch=batch), None)[1], dy, x, gflop=gf)
             elif _Unit.split_wgrad_reduce:
-                _WgradLanes.run(lambda: ops.conv_wgrad_split(dy, x, conv.k, conv.s, conv.p, conv.weight.grad), dy, x)
+                _WgradLanes.run(lambda: ops.conv_wgrad_split(dy, x, conv.k, conv.s, conv.p, conv.weight.grad), dy, x,
+                                gflop=gf)
             else:
                 _WgradLanes.run(lambda: (ops.conv_wgrad(dy, x, conv.k, conv.s, conv.p, out=conv.weight.grad),
-                                         None)[1], dy, x)
+                                         None)[1], dy, x, gflop=gf)
         else:
             def legacy():
                 dwp = ops.conv_wgrad(dy, x, conv.k, conv.s, conv.p)
