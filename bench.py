@@ -509,8 +509,9 @@ def main():
         # two pathways and the weight gradients on parallel streams, where launches overlap and a
         # launch's wall duration no longer measures the kernel)
         from vidsitu_amd import trunk as _trunk
-        saved_modes = (_trunk.VideoTrunk.dual_stream, _trunk._WgradLanes.enabled)
-        _trunk.VideoTrunk.dual_stream, _trunk._WgradLanes.enabled = False, False
+        # one stream, no lanes, no (dgrad, wgrad) pair launches: an event pair then brackets exactly one entry point's kernels
+        saved_modes = (_trunk.VideoTrunk.dual_stream, _trunk._WgradLanes.enabled, _trunk._Unit.pair_launch)
+        _trunk.VideoTrunk.dual_stream, _trunk._WgradLanes.enabled, _trunk._Unit.pair_launch = False, False, False
         t0 = time.perf_counter()
         step()
         torch.cuda.synchronize()
@@ -528,7 +529,7 @@ def main():
                 torch.cuda.synchronize()
         finally:
             probe.remove()
-            _trunk.VideoTrunk.dual_stream, _trunk._WgradLanes.enabled = saved_modes
+            _trunk.VideoTrunk.dual_stream, _trunk._WgradLanes.enabled, _trunk._Unit.pair_launch = saved_modes
         agg = probe.summary()
         pmc = load_pmc_traffic(args.workload)
 

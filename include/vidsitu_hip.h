@@ -318,6 +318,18 @@ int vs_linear_bwd_fused(const float* dy, const float* relu_y, const float* x, co
 int vs_linear_bwd_fused_res(const float* dy, const float* relu_y, const float* x, const float* wt, const float* dx_res,
                             float* dx, float* dw, float* db, int M, int N, int K, void* stream);
 
+/* One launch for a unit's data gradient and weight gradient (the backward of a conv + BN unit runs both on the same dy;
+ * slowfast ResBlock / BottleneckTransform backward via mdl_sf_base.py:21-34).  Between vs_conv_pair_begin() and
+ * vs_conv_pair_end() the conv entry points RECORD an eligible launch (dgrad on the 128 x 128 tile with the two-stage
+ * ring, no split-K; weight gradient on the 128 x 128 two-stage ring) instead of issuing it; _end issues the two as
+ * ONE grid -- first the dgrad's tiles, then the weight gradient's blocks -- followed by the weight gradient's slab
+ * reduce, or issues what was recorded alone.  Bitwise the separate launches.  Why: a fork + join pair inside a
+ * replayed hipGraph costs ~17 us (profiles/r02_graph_edge_cost.txt).  Thread-local state; always call _end.
+ * vs_conv_pair_count(): launches so far that held both kernels. */
+int vs_conv_pair_begin(void);
+int vs_conv_pair_end(void);
+int64_t vs_conv_pair_count(void);
+
 /* A chain of few-row stages behind ONE launch (utils/transformer_code.py:215-250: the EncoderLayer stack on the
  * 8 event tokens of a rank; forward = 7 stages per layer, backward = 7).  `stages`: device array of
  *   struct { int64 op, M, N, K, ia, ib; const void* p[10]; }           (128 bytes per stage)

@@ -598,3 +598,43 @@ def test_fused_stem_pool_step_is_bitwise_the_unfused_step(arch, bwd, dev):
     assert all(torch.equal(a, b) for a, b in zip(f0, f1))
     bad = [k for k in g0 if not torch.equal(g0[k], g1[k])]
     assert not bad, bad[:5]
+
+
+def test_pair_launch_of_dgrad_and_wgrad_is_bitwise_the_separate_launches(dev):
+    """`_Unit.pair_launch`: a unit's data gradient and weight gradient as one launch (csrc/conv_pair.hip) where both run
+    on the 128 x 128 ring kernels -- features and every gradient of a SlowFast-R50 train-mode pass at 112^2 bit for
+    bit those of the pass with separate launches; and pairs are actually issued."""
+    from oracle.slowfast_ref import default_sf_cfg
+    from vidsitu_amd import ops, trunk as T
+
+    torch.manual_seed(3)
+    cfg = default_sf_cfg("slowfast", 50, 64, 32)
+    mdl = T.VideoTrunk(cfg).to(dev).train()
+    g = torch.Generator().manual_seed(4)
+    fast = torch.randn(2, 3, 32, 112, 112, generator=g).to(dev)
+    xs = [fast[:, :, ::4].contiguous(), fast]
+    bufs = {k: v.clone() for k, v in mdl.named_buffers()}
+
+    def run(pair):
+        T._Unit.pair_launch = pair
+        for k, v in mdl.named_buffers():
+            v.copy_(bufs[k])
+        for p in mdl.parameters():
+            p.grad = None
+        n0 = ops.conv_pair_count()
+        feats = mdl.forward_features([x.clone() for x in xs])
+        gg = torch.Generator().manual_seed(5)
+        sum((f.float() * torch.randn(f.shape, generator=gg).to(dev)).sum() for f in feats).backward()
+        torch.cuda.synchronize()
+        return ([f.detach().clone() for f in feats], {k: p.grad.clone() for k, p in mdl.named_parameters()},
+                ops.conv_pair_count() - n0)
+
+    try:
+        f0, g0, n_off = run(False)
+        f1, g1, n_on = run(True)
+    finally:
+        T._Unit.pair_launch = True
+    assert n_off == 0 and n_on >= 1, (n_off, n_on)
+    assert all(torch.equal(a, b) for a, b in zip(f0, f1))
+    bad = [k for k in g0 if not torch.equal(g0[k], g1[k])]
+    assert not bad, bad[:5]

@@ -4,7 +4,7 @@
 # domain besides --kernel-trace, the program itself after `--`.
 #   bash tools/pmc_traffic.sh [workload]   -> gpurun_out/pmc_traffic/{pmc_traffic.json,*.log}
 export TMPDIR=/tmp
-export VS_DUAL_STREAM=0 VS_WGRAD_LANES=0
+export VS_DUAL_STREAM=0 VS_WGRAD_LANES=0 VS_CONV_PAIR=0
 WL=${1:-sf_txenc_train}
 OUT=gpurun_out/pmc_traffic
 mkdir -p $OUT

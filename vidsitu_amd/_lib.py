@@ -97,6 +97,9 @@ SIGNATURES = {
     "vs_linear_bwd_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "vs_linear_bwd_fused": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "vs_txenc_stack_run": (_i, [_p, _i, _p, _i, _i, _p]),
+    "vs_conv_pair_begin": (_i, []),
+    "vs_conv_pair_end": (_i, []),
+    "vs_conv_pair_count": (_i64, []),
     "vs_linear_bwd_fused_res": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "vs_attn_small_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "vs_attn_small_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),

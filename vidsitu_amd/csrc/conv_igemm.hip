@@ -39,7 +39,9 @@ struct ConvSmem {
 // so that the extra epilogue registers do not count against every other launch's occupancy.
 template <int BM, int BN, int WM, int WN, int MODE, bool FAST, int DBG = 0, int NS = 0, bool BNB = false,
           bool BNB2 = false>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
+__device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, const int nblk) {
+  // (blk / nblk: this block's index and the block count of THIS convolution's grid -- blockIdx.x / gridDim.x of the
+  //  stand-alone launch, a sub-range of the grid in the dgrad + wgrad pair launch of conv_pair.hip)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int AI = BM / 32;
   constexpr int BJ = (BN + 31) / 32;
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   // XCD a contiguous run of tiles so neighbouring N-tiles re-read A from its L2.
   int swz;
   {
-    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int nwg = nblk, bid = blk;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
@@ -600,6 +602,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   });
 }
 
+template <int BM, int BN, int WM, int WN, int MODE, bool FAST, int DBG = 0, int NS = 0, bool BNB = false,
+          bool BNB2 = false>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
+  conv_igemm_body<BM, BN, WM, WN, MODE, FAST, DBG, NS, BNB, BNB2>(p, blockIdx.x, gridDim.x);
+}
+
 // Sum of the split-K slabs (fixed order) + the whole fused epilogue.  Block = 64 rows x all
 // columns; thread = one 8-channel chunk column x (256 / chunks) row lanes.
 __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(
@@ -1092,8 +1100,14 @@ static TileCfg pick_tile(long long M, int Ncols, int K, int* ring) {
   return c;
 }
 
+// conv_pair.hip: between vs_conv_pair_begin / _end a 128 x 128 ring-2 tile launch is recorded instead of issued
+static bool pair_take_dgrad(const ConvP& p, int grid, size_t smem, int mode, bool bnb, hipStream_t st);
+
 template <int BM, int BN, int WM, int WN, int MODE, int NS, bool BNB = false, bool BNB2 = false>
 static int launch_one(const ConvP& p, int grid, size_t smem, hipStream_t st) {
+  if constexpr (BM == 128 && BN == 128 && WM == 2 && WN == 2 && NS == 2 && !BNB2) {
+    if (pair_take_dgrad(p, grid, smem, MODE, BNB, st)) return VS_OK;
+  }
   static bool attr_done = false;  // dynamic LDS above 64 KiB needs an explicit opt-in, once per kernel
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, MODE, true, 0, NS, BNB, BNB2>,

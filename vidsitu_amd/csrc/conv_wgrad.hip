@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
 // (the register-staged kernel restarts it every 1024 positions).
 // ---------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int MODE, int NS>
-__global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradP p) {
+__device__ __forceinline__ void conv_wgrad_ring_body(const WgradP& p, const int blk, const int nblk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MR = TM / 16, NR = TN / 16;
@@ -283,10 +283,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradP p) {
   // order [split][tile], so the tiles of one position split -- which read the same x / dY rows -- sit
   // behind one L2 instead of fetching those rows once per XCD (speed only: every (split, tile) pair is
   // still computed by exactly one block).
-  int bid = blockIdx.x;
+  int bid = blk;
   if (p.xcd_order) {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    const int nwg = nblk, q = nwg >> 3, r = nwg & 7, xcd = blk & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blk >> 3);
   }
   const int ntile = p.tilesM * p.tilesN;
   const int s = bid / ntile;
@@ -479,6 +479,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradP p) {
         if (row < p.Cout && col < p.Kp) dst[(long long)row * p.Kp + col] = acc[a][b][r];
       }
     }
+}
+
+template <int BM, int BN, int WM, int WN, int MODE, int NS>
+__global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradP p) {
+  conv_wgrad_ring_body<BM, BN, WM, WN, MODE, NS>(p, blockIdx.x, gridDim.x);
 }
 
 // dw[i] = sum_s slab[s][i], bitwise reproducible: block = 16 float4 columns x 16 slab slices,
@@ -682,6 +687,11 @@ extern "C" size_t vs_conv_wgrad_workspace_bytes(const vs_conv_desc* d) {
   return (size_t)c.S * d->Cout * d->kT * d->kH * d->kW * d->Cin * sizeof(float);
 }
 
+// conv_pair.hip: between vs_conv_pair_begin / _end a 128 x 128 two-stage ring launch (and the slab reduce behind it) is
+// recorded instead of issued
+static bool pair_take_wgrad(const WgradP& p, int grid, size_t smem, int mode, hipStream_t st);
+static bool pair_defer_reduce(const float* slabs, float* dw, long long n, int splits);
+
 template <int BM, int BN, int WM, int WN>
 static int wg_launch(const WgradP& p, int mode, int ring, hipStream_t st) {
   const int grid = p.tilesM * p.tilesN * p.S;
@@ -704,6 +714,9 @@ static int wg_launch(const WgradP& p, int mode, int ring, hipStream_t st) {
   if (ring >= 2) {
     const size_t tab = mode ? 2 * WG_ROWTAB * sizeof(int2) : 0;
     const size_t smem = (size_t)ring * 2 * 64 * 256 + tab;
+    if constexpr (BM == 128 && BN == 128) {
+      if (ring == 2 && pair_take_wgrad(p, grid, smem, mode, st)) return VS_OK;
+    }
     if (ring == 2 && mode == 0)
       hipLaunchKernelGGL((conv_wgrad_ring_kernel<BM, BN, WM, WN, 0, 2>), dim3(grid), dim3(256), smem, st, p);
     else if (ring == 2)
@@ -795,9 +808,11 @@ static int wgrad_impl(const void* dy, const void* x, float* dw, const vs_conv_de
   if (c.S > 1 && reduce_now) {
     const long long n = (long long)d->Cout * p.Kp;
     const long long grid = (n / 4 + 15) / 16;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, st,
-                       (const float*)workspace, dw, n, c.S);
-    VS_CHECK_LAUNCH();
+    if (!pair_defer_reduce((const float*)workspace, dw, n, c.S)) {
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, st,
+                         (const float*)workspace, dw, n, c.S);
+      VS_CHECK_LAUNCH();
+    }
   }
   return VS_OK;
 }

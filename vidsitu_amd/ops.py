@@ -819,6 +819,23 @@ def attn_small_bwd_fused(qkv, probs, do, b, l, n_heads, scale, drop_mask=None):
     return dqkv
 
 
+class conv_pair:
+    """`with conv_pair():` -- an eligible data gradient and weight gradient issued inside the block leave as ONE launch at
+    its end (vs_conv_pair_begin / _end, csrc/conv_pair.hip); anything else is launched as usual."""
+
+    def __enter__(self):
+        _lib.call("vs_conv_pair_begin")
+        return self
+
+    def __exit__(self, *exc):
+        _lib.call("vs_conv_pair_end")
+        return False
+
+
+def conv_pair_count():
+    return int(_lib.load().vs_conv_pair_count())
+
+
 class TxStack:
     """Stage list of `vs_txenc_stack_run` (include/vidsitu_hip.h): a chain of few-row kernels behind one launch.
     Build with the methods below (each = the stand-alone op of the same name, same arguments, M <= 8 rows), then

@@ -16,6 +16,7 @@ tensors handed back keep the reference's logical NCDHW shape.
          conv dgrad / wgrad) and writes parameter gradients straight into
          `param.grad` (one fp32 arena), so DDP-style averaging is one all-reduce.
 """
+import contextlib
 import os
 
 import torch
@@ -213,6 +214,9 @@ class _Unit:
     # epilogue (vs_conv_dgrad_bnstats) instead of a reduce pass of their own; VS_FUSE_BN_SUMS=0 = A/B switch
     fuse_bn_sums = os.environ.get("VS_FUSE_BN_SUMS", "1") != "0"
     fuse_sc_sums = os.environ.get("VS_FUSE_SC_SUMS", "1") != "0"  # the shortcut unit's sums from the same epilogue
+    # data gradient + weight gradient of a unit as ONE launch where both run on the 128 x 128 ring kernels
+    # (ops.conv_pair): no side lane, hence no fork / join edge pair (~17 us in a replayed graph).  VS_CONV_PAIR=0: lanes.
+    pair_launch = os.environ.get("VS_CONV_PAIR", "1") != "0"
 
     @staticmethod
     def fwd(conv, bn, x, relu, residual=None, out=None, train=False, saved=None, pool=False):
@@ -294,6 +298,22 @@ class _Unit:
                 conv.bias.grad = torch.zeros_like(conv.bias)
             else:
                 conv.bias.grad.zero_()
+        # one launch for the unit's two gradients where both kernels allow it (`pair_launch`): the weight gradient is
+        # then issued inline (recorded, like the data gradient below) instead of on the lane
+        pair = (_Unit.pair_launch and need_dx and not conv.is_stem and conv.cin_pad == conv.cin and dy.is_cuda
+                and _Unit.wgrad_batch is None and not _Unit.split_wgrad_reduce)
+        pair_ctx = ops.conv_pair() if pair else contextlib.nullcontext()
+        pair_ctx.__enter__()
+        try:
+            dx = _Unit._bwd_convs(conv, dy, x, need_dx, producer, dx_residual, dx_residual_bits, inplace, pair)
+        finally:
+            pair_ctx.__exit__(None, None, None)
+        _WgradLanes.join_unit()  # wgrad || dgrad of this unit (and, with a lag, of the next units)
+        return dx, dres
+
+    @staticmethod
+    def _bwd_convs(conv, dy, x, need_dx, producer, dx_residual, dx_residual_bits, inplace, pair):
+        """The unit's weight gradient (side lane, or inline when `pair`) and data gradient."""
         if conv.is_stem:
             _WgradLanes.run(lambda: _set_grad(conv.weight, ops.stem_conv_wgrad(dy, x, conv.k[0])) and None, dy, x)
         elif conv.cin_pad == conv.cin:
@@ -303,6 +323,8 @@ class _Unit:
             # trunk's WgradBatch and are summed by one launch per backward segment (VideoTrunk._flush_wgrads)
             batch = _Unit.wgrad_batch if getattr(conv.weight, "_vs_direct_grad", False) else None
             gf = 2e-9 * dy.numel() * conv.cin * conv.k[0] * conv.k[1] * conv.k[2]  # the unit's GEMM, GFLOP
+            if pair:
+                gf = -1.0  # inline
             if batch is not None:
                 _WgradLanes.run(lambda: (ops.conv_wgrad(dy, x, conv.k, conv.s, conv.p, out=conv.weight.grad,
                                                         batch=batch), None)[1], dy, x, gflop=gf)
@@ -346,8 +368,7 @@ class _Unit:
             else:
                 dx = ops.conv_dgrad(dy, conv.wt(), tuple(x.shape), conv.k, conv.s, conv.p,
                                     residual=dx_residual, residual_bits=dx_residual_bits, inplace=inplace)
-        _WgradLanes.join_unit()  # wgrad || dgrad of this unit (and, with a lag, of the next units)
-        return dx, dres
+        return dx
 
 
 class ResNetBasicStem(nn.Module):
