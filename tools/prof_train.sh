@@ -1,5 +1,5 @@
 #!/bin/bash
-export TMPDIR=/tmp VS_DUAL_STREAM=0 VS_WGRAD_LANES=0
+export TMPDIR=/tmp VS_DUAL_STREAM=0 VS_WGRAD_LANES=0 VS_CONV_PAIR=0
 # one-stream rocprofv3 kernel stats of the training step -> gpurun_out/prof_train/kernel_stats.csv
 OUT=gpurun_out/${1:-prof_train}
 mkdir -p $OUT
