@@ -1102,6 +1102,9 @@ static TileCfg pick_tile(long long M, int Ncols, int K, int* ring) {
 
 // conv_pair.hip: between vs_conv_pair_begin / _end a 128 x 128 ring-2 tile launch is recorded instead of issued
 static bool pair_take_dgrad(const ConvP& p, int grid, size_t smem, int mode, bool bnb, hipStream_t st);
+#ifndef VS_CONV_PAIR_TU  // compiled on its own (not through conv_pair.hip): nothing is ever recorded
+static bool pair_take_dgrad(const ConvP&, int, size_t, int, bool, hipStream_t) { return false; }
+#endif
 
 template <int BM, int BN, int WM, int WN, int MODE, int NS, bool BNB = false, bool BNB2 = false>
 static int launch_one(const ConvP& p, int grid, size_t smem, hipStream_t st) {

@@ -13,6 +13,7 @@
 // _end issues the pair as one launch (or whatever was recorded, alone), then the weight gradient's slab reduce.
 // Everything else launched in between is issued as usual.  The two .hip files are compiled as part of this
 // translation unit (the pair kernel needs both bodies).
+#define VS_CONV_PAIR_TU 1
 #include "conv_igemm.hip"
 #include "conv_wgrad.hip"
 

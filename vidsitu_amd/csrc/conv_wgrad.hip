@@ -691,6 +691,10 @@ extern "C" size_t vs_conv_wgrad_workspace_bytes(const vs_conv_desc* d) {
 // recorded instead of issued
 static bool pair_take_wgrad(const WgradP& p, int grid, size_t smem, int mode, hipStream_t st);
 static bool pair_defer_reduce(const float* slabs, float* dw, long long n, int splits);
+#ifndef VS_CONV_PAIR_TU  // compiled on its own (not through conv_pair.hip): nothing is ever recorded
+static bool pair_take_wgrad(const WgradP&, int, size_t, int, hipStream_t) { return false; }
+static bool pair_defer_reduce(const float*, float*, long long, int) { return false; }
+#endif
 
 template <int BM, int BN, int WM, int WN>
 static int wg_launch(const WgradP& p, int mode, int ring, hipStream_t st) {
