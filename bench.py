@@ -392,14 +392,30 @@ def cpu_baseline(workload, n_vocab, budget_s=60.0):
 
 def main():
     args = parse()
+    from vidsitu_amd import dist_launch
+
+    # VS_BENCH_FORCE_DIST=1: initialise RCCL even for one rank (exercises the launcher and the distributed
+    # step on a single-GPU box)
+    force_dist = os.environ.get("VS_BENCH_FORCE_DIST") == "1"
+    try:
+        world, spawn = dist_launch.world_from_env(args.gpus)
+    except ValueError as e:  # WORLD_SIZE from a launcher disagrees with --gpus: never a silent N' != N line
+        sys.exit(f"bench.py: {e}")
+    if os.environ.get("WORLD_SIZE") in (None, "") and (spawn or force_dist):
+        # `python bench.py --gpus N` without a launcher: THIS process becomes the launcher.  It has not
+        # touched the GPU (importing torch does not) and never will: N fresh children, one per GPU, rank
+        # environment + a free rendezvous port; rank 0's JSON line passes through; any failing rank fails
+        # the job (the reference: `launch_job`, utils/trn_dist_utils.py:32-39).
+        sys.exit(dist_launch.launch_ranks(world, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    # VS_BENCH_FORCE_DIST=1: initialise RCCL even for one rank (exercises the distributed step on
-    # a single-GPU box)
-    if world > 1 or os.environ.get("VS_BENCH_FORCE_DIST") == "1":
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        if "MASTER_PORT" not in os.environ:
+            sys.exit("bench.py: WORLD_SIZE is set but MASTER_PORT is not (launch through torch.distributed.run "
+                     "or plain `python bench.py --gpus N`)")
+        if torch.cuda.device_count() <= local_rank:
+            sys.exit(f"bench.py: rank {rank} wants cuda:{local_rank} but {torch.cuda.device_count()} GPU(s) are visible")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
@@ -441,7 +457,7 @@ def main():
         overlap = None if args.overlap < 0 else bool(args.overlap)
         grad_bf16 = dist_on and (args.grad_dtype == "bf16" or (args.grad_dtype == "auto" and world > 1))
         ts = TrainStep(mdl, loss_fn, arena, opt, batch, world=world, overlap=overlap, use_dist=dist_on,
-                       grad_bf16=grad_bf16)
+                       grad_bf16=grad_bf16, grad_fill="learn")
         step = ts.step
     else:
         mdl.eval()
@@ -509,6 +525,13 @@ def main():
         # two pathways and the weight gradients on parallel streams, where launches overlap and a
         # launch's wall duration no longer measures the kernel)
         from vidsitu_amd import trunk as _trunk
+        from vidsitu_amd import _lib as _vslib
+        # kernel launches of one step as the timed region runs it (default modes: two streams, pair launches);
+        # the captured graph replays exactly this sequence
+        n0 = _vslib.load().vs_launch_count()
+        step()
+        torch.cuda.synchronize()
+        launches_per_step = int(_vslib.load().vs_launch_count() - n0)
         # one stream, no lanes, no (dgrad, wgrad) pair launches: an event pair then brackets exactly one entry point's kernels
         saved_modes = (_trunk.VideoTrunk.dual_stream, _trunk._WgradLanes.enabled, _trunk._Unit.pair_launch)
         _trunk.VideoTrunk.dual_stream, _trunk._WgradLanes.enabled, _trunk._Unit.pair_launch = False, False, False
@@ -584,10 +607,28 @@ def main():
                         "whose pathway / wgrad branches run concurrently)")
         conv = [v for k, v in fams if v[4] == "mfma"]
         cms, cfl, cby = sum(v[1] for v in conv), sum(v[2] for v in conv), sum(v[3] for v in conv)
+        roof["launches_per_step"] = launches_per_step  # library kernels of one step (a few torch-native fills / copies not counted)
         roof["all_conv"] = {"ms_per_step": round(cms / reps, 3),
                             "achieved_tflops": round(cfl / (cms * 1e-3) / 1e12, 2),
+                            "frac_of_bf16_mfma_peak": round(cfl / (cms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                             "algorithmic_gbs": round(cby / (cms * 1e-3) / 1e9, 1),
                             "flop_per_byte": round(cfl / max(cby, 1), 1)}
+        # every batch-norm pass and its glue (finalize / partial reduces are entry points without a byte model)
+        bn = [(k, v) for k, v in fams if k.startswith("bn_")]
+        if bn:
+            bms, bby, bn_l = sum(v[1] for _, v in bn), sum(v[3] for _, v in bn), sum(v[0] for _, v in bn)
+            pmc_b = 0.0
+            for k, v in bn:  # PMC bytes per launch (launch-weighted over the family's template instances) x launches
+                key = k.split(" (")[0]
+                rows = [t for kk, t in pmc.items() if kk.startswith(key) and not kk.startswith("_")]
+                nl = sum(t["launches"] for t in rows)
+                if nl:
+                    pmc_b += sum((t["fetch_bytes"] + t["write_bytes"]) * t["launches"] for t in rows) / nl * v[0]
+            roof["bn_all"] = {"ms_per_step": round(bms / reps, 3), "launches_per_step": bn_l // reps,
+                              "algorithmic_gb_per_step": round(bby / reps / 1e9, 3),
+                              "pmc_gb_per_step": round(pmc_b / reps / 1e9, 3) if pmc_b else None,
+                              "algorithmic_gbs": round(bby / (bms * 1e-3) / 1e9, 1),
+                              "tiny_launches_per_step": sum(v[0] for k, v in bn if v[4] is None) // reps}
         roof["families"] = [fam(k, v) for k, v in fams[:16]]
 
     cpu = None
@@ -598,7 +639,9 @@ def main():
         line = {
             "metric": "clips/s (10s@32x224x224) SlowFast+TxEnc fwd+bwd" if train
             else "clips/s (10s@32x224x224) SlowFast-R50 feature extractor fwd",
-            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 2), "unit": "clips/s", "n_gpus": world,
+            "rccl_ranks": dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else None,
+            "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",

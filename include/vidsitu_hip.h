@@ -77,6 +77,10 @@ typedef struct vs_conv_desc {
 
 const char* vs_last_error_string(void);
 int vs_version(void);
+/* Kernel launches issued by this library so far (process-wide, relaxed atomic; every launch site counts).
+ * bench.py reports launches per step from it -- the reference's step is a chain of cuDNN / ATen launches
+ * (utils/trn_utils.py:590-615), the length of that chain is what bounds the batch-8 step here. */
+int64_t vs_launch_count(void);
 
 /* NCDHW (f32 or bf16) -> NDHWC bf16 with channels zero-padded to Cpad.
  * Replaces the implicit layout of the A0 batch contract

@@ -1,0 +1,85 @@
+"""The boundary's command line on hardware (reference `main_dist.py:132-172`, `utils/trn_dist_utils.py:5-42`):
+`python main_dist.py <uid> --dotted.key=value` trains through `TrainStep` (eager step, hipGraph capture, replays),
+writes the reference-format checkpoint and resumes from it; and `python bench.py --gpus N` goes through the rank
+launcher (`vidsitu_amd/dist_launch.py`): a forced 1-rank RCCL job prints a line that names its rank count, `--gpus 2`
+on a 1-GPU box fails loudly instead of printing a 1-rank line.  Each run is a fresh child process, as a user's is."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(cmd, extra_env=None, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(extra_env or {})
+    r = subprocess.run([sys.executable] + cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    err = "\n".join(ln for ln in r.stderr.splitlines() if "frame #" not in ln)
+    return r.returncode, r.stdout, err[-6000:]
+
+
+MINI = ["--mdl.sf_mdl_name=slow_fast_mini", "--sf_mdl.DATA.TRAIN_CROP_SIZE=64", "--synth.num_verbs=31",
+        "--train.bs=2", "--ds.vsitu.num_ev=2", "--train.lr=1e-3", "--overfit_batch=True"]
+
+
+def _losses(out):
+    m = re.search(r"loss ([-\d.e]+) -> ([-\d.e]+)", out)
+    assert m, out
+    return float(m.group(1)), float(m.group(2))
+
+
+def test_main_dist_trains_through_the_graph_step_saves_and_resumes(dev, tmp_path):
+    args = ["main_dist.py", "t_md"] + MINI + [f"--misc.tmp_path={tmp_path}", "--steps=6"]
+    rc, out, err = _run(args)
+    assert rc == 0, out[-3000:] + err
+    assert "hipGraph replay" in out and "world 1" in out, out
+    first, last = _losses(out)
+    assert last < first, out  # one batch, lr 1e-3: the loss goes down
+    ck = tmp_path / "models" / "t_md.pth"
+    assert ck.exists() and "valid" in out
+    # resume: picks the file up, continues from iteration 6
+    rc, out2, err = _run(args + ["--train.resume=True"])
+    assert rc == 0, out2[-3000:] + err
+    assert "resumed" in out2 and "at iteration 6" in out2, out2
+    assert _losses(out2)[0] < first
+    # the eager loop is the same TrainStep
+    rc, out3, err = _run(args + ["--graph=0"])
+    assert rc == 0 and "(eager" in out3, out3[-2000:] + err
+    e_first, e_last = _losses(out3)
+    assert abs(e_first - first) < 1e-6 and abs(e_last - last) < 5e-3 * max(1.0, abs(last))
+
+
+def test_main_dist_forced_one_rank_rccl_job(dev, tmp_path):
+    """VS_FORCE_DIST=1: the parent starts ONE rank through the launcher; the rank initialises RCCL and runs the
+    segmented step (one graph per backward segment, bucket all-reduces behind them)."""
+    rc, out, err = _run(["main_dist.py", "t_md1"] + MINI + [f"--misc.tmp_path={tmp_path}", "--steps=4", "--num_gpus=1"],
+                        {"VS_FORCE_DIST": "1"})
+    assert rc == 0, out[-3000:] + err
+    assert "hipGraph replay" in out and "segment(s)" in out, out
+    first, last = _losses(out)
+    assert last < first
+
+
+def test_bench_through_the_launcher_names_its_ranks(dev):
+    rc, out, err = _run(["bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                         "--no-roofline"], {"VS_BENCH_FORCE_DIST": "1"}, timeout=1500)
+    assert rc == 0, out[-2000:] + err
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["value"] > 0
+    assert "bucket" in line["config"]["grad_allreduce"]
+
+
+def test_bench_gpus_2_on_a_one_gpu_box_fails_loudly(dev):
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    rc, out, err = _run(["bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1"])
+    assert rc != 0 and out.strip() == "" and "not launching" in err

@@ -90,7 +90,7 @@ def test_ranged_adam_beside_the_backward_pass_is_bitwise_the_plain_step(dev):
 
 
 def test_gradient_fill_is_skipped_only_where_the_backward_overwrites(dev):
-    """`TrainStep(grad_fill=None)`: the first eager step fills the gradient arena and learns which parameters get
+    """`TrainStep(grad_fill="learn")` (bench.py; the default is a full fill every step): the first eager step fills the gradient arena and learns which parameters get
     their gradient through autograd's AccumulateGrad; later steps zero only those.  (a) the HIP model: none is
     learned, and steps from NaN-poisoned gradients are bitwise the steps of a TrainStep that fills every time,
     eager and replayed; (b) a model with torch-native parameters: all of them are learned and the trajectory is
@@ -131,7 +131,7 @@ def test_gradient_fill_is_skipped_only_where_the_backward_overwrites(dev):
 
     for graph in (False, True):
         _, ref = trajectory(*hip_model(), True, graph)
-        ts, got = trajectory(*hip_model(), None, graph)
+        ts, got = trajectory(*hip_model(), "learn", graph)
         assert ts._accumulated == [], [tuple(p.shape) for p in ts._accumulated]
         assert torch.isfinite(got[0]).all()
         for name, a, b in zip(("grad", "param", "exp_avg", "exp_avg_sq", "loss"), ref, got):
@@ -153,7 +153,75 @@ def test_gradient_fill_is_skipped_only_where_the_backward_overwrites(dev):
         return mdl, (lambda out, b: {"loss": torch.nn.functional.cross_entropy(out, b["y"])}), batch
 
     _, ref = trajectory(*plain_model(), True, False)
-    ts, got = trajectory(*plain_model(), None, False)
+    ts, got = trajectory(*plain_model(), "learn", False)
     assert len(ts._accumulated) == 4
     for name, a, b in zip(("grad", "param", "exp_avg", "exp_avg_sq", "loss"), ref, got):
         assert torch.equal(a, b), f"torch-native model: {name} differs"
+
+
+def test_learned_fill_set_raises_when_a_later_step_routes_a_gradient_through_autograd(dev):
+    """with grad_fill="learn" the first eager step decides which gradients get zeroed.  A parameter whose
+    gradient starts arriving through AccumulateGrad on a LATER step (here: a module switched from a path that writes
+    p.grad itself to plain autograd) must not silently accumulate -- the step raises, eagerly and at capture; with the
+    default grad_fill=True the same switch is harmless (trajectory == a model that used autograd from the start)."""
+    from vidsitu_amd.optim import ArenaAdam, ParamArena
+    from vidsitu_amd.train_step import TrainStep
+
+    class WritesOwnGrad(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            return x @ w.t()
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, w = ctx.saved_tensors
+            w.grad.copy_(dy.t() @ x)  # overwrite semantics, like the HIP modules
+            return dy @ w, None
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(16, 4, bias=False)
+            self.direct = True
+
+        def forward(self, batch):
+            if self.direct:
+                return WritesOwnGrad.apply(batch["x"], self.lin.weight)
+            return self.lin(batch["x"])
+
+    def make(direct):
+        torch.manual_seed(3)
+        m = M().to(dev)
+        m.direct = direct
+        batch = {"x": torch.randn(8, 16, device=dev, requires_grad=True), "y": torch.randint(0, 4, (8,), device=dev)}
+        loss = (lambda out, b: {"loss": torch.nn.functional.cross_entropy(out, b["y"])})
+        arena = ParamArena(m)
+        return m, arena, TrainStep(m, loss, arena, ArenaAdam(arena, lr=1e-2), batch,
+                                   grad_fill=make.fill, adam_overlap=False)
+
+    make.fill = "learn"
+    m, arena, ts = make(True)
+    ts.step()
+    assert ts._accumulated == []
+    ts.step()
+    m.direct = False
+    with pytest.raises(RuntimeError, match="lin.weight"):
+        ts.step()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with pytest.raises(RuntimeError, match="lin.weight"):
+            ts.capture()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    # default: a full fill every step -- switching paths changes nothing
+    make.fill = True
+    m, arena, ts = make(True)
+    ts.step()
+    m.direct = False
+    ts.step(); ts.step()
+    m2, arena2, ts2 = make(False)
+    ts2.step(); ts2.step(); ts2.step()
+    torch.cuda.synchronize()
+    assert torch.equal(arena.data, arena2.data) and torch.equal(arena.grad, arena2.grad)

@@ -47,6 +47,7 @@ _dp = C.POINTER(ConvDesc)
 SIGNATURES = {
     "vs_last_error_string": (C.c_char_p, []),
     "vs_version": (_i, []),
+    "vs_launch_count": (_i64, []),
     "vs_pack_input": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "vs_frames_u8_pack": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p]),
     "vs_stem_conv_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),

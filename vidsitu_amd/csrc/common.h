@@ -13,6 +13,16 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 void vs_set_error(const char* fmt, ...);
 
+// Every kernel launch of the library goes through this macro: one relaxed atomic add per launch feeds
+// vs_launch_count() (bench.py reports kernel launches per step from it; tests count the glue launches).
+void vs_count_launch(void);
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, ...)                    \
+  do {                                                         \
+    vs_count_launch();                                         \
+    hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__);     \
+  } while (0)
+
 #define VS_CHECK_ARG(cond, msg)                   \
   do {                                            \
     if (!(cond)) {                                \

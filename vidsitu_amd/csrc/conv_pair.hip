@@ -14,6 +14,9 @@
 // Everything else launched in between is issued as usual.  The two .hip files are compiled as part of this
 // translation unit (the pair kernel needs both bodies).
 #define VS_CONV_PAIR_TU 1
+#include <atomic>
+#include <mutex>
+
 #include "conv_igemm.hip"
 #include "conv_wgrad.hip"
 
@@ -33,12 +36,13 @@ struct PairState {
   hipStream_t st = nullptr;
 };
 thread_local PairState g_pair;
-long long g_pairs_issued = 0;  // launches that held both kernels (tests)
+std::atomic<long long> g_pairs_issued{0};  // launches that held both kernels (tests); any thread may issue one
 }  // namespace
 
 static bool pair_take_dgrad(const ConvP& p, int grid, size_t smem, int mode, bool bnb, hipStream_t st) {
   PairState& s = g_pair;
   if (!s.active || s.have_d || p.splitK != 1) return false;
+  if (s.have_w && s.st != st) return false;  // one launch = one stream
   s.dp = p; s.d_grid = grid; s.d_smem = smem; s.d_mode = mode; s.d_bnb = bnb; s.st = st;
   s.have_d = true;
   return true;
@@ -47,6 +51,7 @@ static bool pair_take_dgrad(const ConvP& p, int grid, size_t smem, int mode, boo
 static bool pair_take_wgrad(const WgradP& p, int grid, size_t smem, int mode, hipStream_t st) {
   PairState& s = g_pair;
   if (!s.active || s.have_w) return false;
+  if (s.have_d && s.st != st) return false;
   s.wp = p; s.w_grid = grid; s.w_smem = smem; s.w_mode = mode; s.st = st;
   s.have_w = true;
   return true;
@@ -55,6 +60,7 @@ static bool pair_take_wgrad(const WgradP& p, int grid, size_t smem, int mode, hi
 static bool pair_defer_reduce(const float* slabs, float* dw, long long n, int splits) {
   PairState& s = g_pair;
   if (!s.active || !s.have_w || s.have_r) return false;
+  if ((const float*)s.wp.out != slabs) return false;  // only the reduce of the RECORDED weight gradient's slabs waits for _end
   s.slabs = slabs; s.dw = dw; s.n = n; s.splits = splits;
   s.have_r = true;
   return true;
@@ -70,12 +76,11 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(ConvP dp, WgradP wp, int
 
 template <int DMODE, bool BNB, int WMODE>
 static void pair_launch(const PairState& s) {
-  static bool attr = false;
-  if (!attr) {
+  static std::once_flag attr;  // the autograd thread and the main thread may both get here first
+  std::call_once(attr, [] {
     (void)hipFuncSetAttribute((const void*)conv_pair_kernel<DMODE, BNB, WMODE>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
+  });
   const size_t smem = s.d_smem > s.w_smem ? s.d_smem : s.w_smem;
   hipLaunchKernelGGL((conv_pair_kernel<DMODE, BNB, WMODE>), dim3(s.d_grid + s.w_grid), dim3(256), smem, s.st, s.dp,
                      s.wp, s.d_grid);
@@ -83,6 +88,12 @@ static void pair_launch(const PairState& s) {
 
 template <int DMODE, bool BNB>
 static void dgrad_alone(const PairState& s) {
+  // a dgrad recorded inside a pair block never reached launch_one's own opt-in: > 64 KiB of dynamic LDS needs it
+  static std::once_flag attr;
+  std::call_once(attr, [] {
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<128, 128, 2, 2, DMODE, true, 0, 2, BNB, false>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
   hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 2, DMODE, true, 0, 2, BNB, false>), dim3(s.d_grid), dim3(256),
                      s.d_smem, s.st, s.dp);
 }
@@ -132,8 +143,8 @@ extern "C" int vs_conv_pair_end(void) {
     vs_set_error("vs_conv_pair_end: launch failed: %s", hipGetErrorString(e));
     return VS_ERR_LAUNCH;
   }
-  if (s.have_d && s.have_w) ++g_pairs_issued;
+  if (s.have_d && s.have_w) g_pairs_issued.fetch_add(1, std::memory_order_relaxed);
   return VS_OK;
 }
 
-extern "C" int64_t vs_conv_pair_count(void) { return g_pairs_issued; }
+extern "C" int64_t vs_conv_pair_count(void) { return g_pairs_issued.load(std::memory_order_relaxed); }

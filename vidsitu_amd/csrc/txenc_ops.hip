@@ -1862,3 +1862,8 @@ void vs_set_error(const char* fmt, ...) {
 }
 extern "C" const char* vs_last_error_string(void) { return g_err; }
 extern "C" int vs_version(void) { return 1; }
+
+#include <atomic>
+static std::atomic<long long> g_launches{0};
+void vs_count_launch(void) { g_launches.fetch_add(1, std::memory_order_relaxed); }
+extern "C" int64_t vs_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }

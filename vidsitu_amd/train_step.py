@@ -32,7 +32,7 @@ import torch.distributed as dist
 
 class TrainStep:
     def __init__(self, mdl, loss_fn, arena, opt, batch, world=1, overlap=None, use_dist=None,
-                 grad_bf16=False, adam_overlap=None, grad_fill=None):
+                 grad_bf16=False, adam_overlap=None, grad_fill=True):
         self.mdl, self.loss_fn, self.arena, self.opt, self.batch = mdl, loss_fn, arena, opt, batch
         self.world = world
         self.use_dist = (dist.is_available() and dist.is_initialized()) if use_dist is None else use_dist
@@ -49,11 +49,21 @@ class TrainStep:
         self.loss = None
         # The per-step memset of the gradient arena (300 MB for SlowFast-R50 + TxEncoder) is only needed by
         # parameters whose gradient arrives through autograd's AccumulateGrad (p.grad += g).  The HIP modules
-        # WRITE p.grad in place and return None for it, so AccumulateGrad never runs for them.  grad_fill=None:
-        # the first step fills the arena and watches which parameters AccumulateGrad touches
-        # (tensor hooks: called with None when a backward returned no gradient); later steps zero only those.  True: memset every step.  False: never.
-        if grad_fill is None and os.environ.get("VS_GRAD_FILL", "") in ("0", "1"):
-            grad_fill = os.environ["VS_GRAD_FILL"] == "1"
+        # WRITE p.grad in place and return None for it, so AccumulateGrad never runs for them.
+        #   True (default): memset every step -- what `optimizer.zero_grad()` means (utils/trn_utils.py:596).
+        #   "learn" (bench.py): the first step fills the arena and watches which parameters AccumulateGrad
+        #       touches (tensor hooks: called with None when a backward returned no gradient); later steps zero
+        #       only those, and every later python-level step -- eager steps and the pass a hipGraph is captured
+        #       from -- keeps watching: a gradient arriving for a parameter outside the learned set RAISES
+        #       instead of being added onto the previous step's (a replayed graph is exactly its captured pass,
+        #       so a clean capture covers every replay).
+        #   False: never.
+        # VS_GRAD_FILL=0 / 1 / learn overrides (A/B runs).
+        env = os.environ.get("VS_GRAD_FILL", "")
+        if env in ("0", "1", "learn"):
+            grad_fill = {"0": False, "1": True, "learn": "learn"}[env]
+        if grad_fill is None:  # round-2 spelling of "learn"
+            grad_fill = "learn"
         self.grad_fill = grad_fill
         self._accumulated = None  # learned: parameters that need a zero gradient before every backward pass
         self.graphs = None  # segment graphs + the Adam graph, or [whole-step graph]
@@ -92,11 +102,25 @@ class TrainStep:
         if self.grad_fill is True:
             self.opt.zero_grad()
             return []
-        if self.grad_fill is False or self._accumulated is not None:
+        if self.grad_fill is False:
             self.opt.zero_grad(fill=False)  # only re-attaches replaced gradients
-            for p in (self._accumulated or ()):
-                p.grad.zero_()
             return []
+        if self._accumulated is not None:
+            self.opt.zero_grad(fill=False)
+            known = self._accumulated
+            for p in known:
+                p.grad.zero_()
+
+            def guard(g, q):
+                if g is not None and not any(q is r for r in known):
+                    name = next((n for n, r in self.mdl.named_parameters() if r is q), "?")
+                    raise RuntimeError(
+                        f"TrainStep(grad_fill='learn'): parameter {name} received its gradient through autograd "
+                        "on this step but not on the step the zero-fill set was learned from; its gradient would "
+                        "accumulate across steps.  Use grad_fill=True, or build a new TrainStep after changing "
+                        "which modules run.")
+            return [p.register_hook(lambda g, q=p: guard(g, q)) for p in self.arena.params
+                    if not any(p is r for r in known)]
         if self.arena.data.is_cuda and torch.cuda.is_current_stream_capturing():
             raise RuntimeError("TrainStep: run one eager step() before capture() (it learns which gradients "
                                "need the per-step zero fill)")
