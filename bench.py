@@ -28,6 +28,19 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+_JSON_FD = None  # set in a rank of a distributed job: the real stdout (see main)
+
+
+def emit(line):
+    """The bench line: the only thing this process writes to its real stdout."""
+    text = json.dumps(line) + "\n"
+    if _JSON_FD is None:
+        sys.stdout.write(text)
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, text.encode())
+
+
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 GFLOP_PER_CLIP_FWD = 100.615  # SURVEY.md 8(d): 50.308 GMAC conv, 2 FLOP/MAC
@@ -248,7 +261,7 @@ def bench_srl_gen(args, rank, world, dev):
         dt = float(t.item())
     ntok = sum(len(v["tokens"]) for r in out for v in r["vb_output"].values())
     if rank == 0:
-        print(json.dumps({
+        emit(({
             "metric": f"clips/s SRL caption generation, beam 5 x {max_len} tokens, {dec} decoder",
             "value": round(CLIPS_PER_GPU * world * args.steps / dt, 2), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -409,7 +422,13 @@ def main():
         sys.exit(dist_launch.launch_ranks(world, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    global _JSON_FD
     if world > 1 or force_dist:
+        # RCCL prints to the process's stdout ("Librccl path : ..."): the contract is ONE JSON line there.  Keep a
+        # private copy of the real stdout for that line and point fd 1 at stderr for everything else.
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
             sys.exit("bench.py: WORLD_SIZE is set but MASTER_PORT is not (launch through torch.distributed.run "
@@ -607,7 +626,9 @@ def main():
                         "whose pathway / wgrad branches run concurrently)")
         conv = [v for k, v in fams if v[4] == "mfma"]
         cms, cfl, cby = sum(v[1] for v in conv), sum(v[2] for v in conv), sum(v[3] for v in conv)
-        roof["launches_per_step"] = launches_per_step  # library kernels of one step (a few torch-native fills / copies not counted)
+        # library kernels of one step (a few torch-native fills / copies not counted); the family's own count stays in
+        # `launches_per_step`
+        roof["total_launches_per_step"] = launches_per_step
         roof["all_conv"] = {"ms_per_step": round(cms / reps, 3),
                             "achieved_tflops": round(cfl / (cms * 1e-3) / 1e12, 2),
                             "frac_of_bf16_mfma_peak": round(cfl / (cms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
@@ -660,7 +681,7 @@ def main():
                                                        PEAK_BF16_TFLOPS, 4)},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
+        emit(line)
     if dist.is_available() and dist.is_initialized():
         dist.barrier()  # rank 0 is still in its instrumented pass / CPU baseline: leave together
         dist.destroy_process_group()

@@ -244,6 +244,18 @@ int vs_bn_apply(const void* y, const float* scale, const float* shift, const voi
 int vs_bn_apply_mask(const void* y, const float* scale, const float* shift, const void* residual,
                      void* out, uint8_t* relu_bits, int64_t rows, int C, int y_ld, int res_ld,
                      int out_ld, void* stream);
+/* vs_bn_finalize + vs_bn_apply / vs_bn_apply_mask as ONE launch (round 3): the apply kernel is tiled over (column
+ * group of <= 64 channels) x (row slab) and every block reduces the partial rows of its own column group in its
+ * prologue -- same slices, same fp64 order, same closing arithmetic as vs_bn_finalize, so bitwise its scale / shift;
+ * the blocks of row slab 0 store mean / invstd (for the backward) and update the running statistics.  For at most
+ * 256 partial rows and C/8 a power of two (vs_bn_fin_fusable; layers with thousands of rows run
+ * vs_bn_partials_reduce first and pass its 32 rows).  relu_bits may be NULL.  Replaces the train-mode forward of
+ * slowfast's BatchNorm3d (+ residual add + ReLU) inside BottleneckTransform / ResBlock (mdl_sf_base.py:21-34). */
+int vs_bn_fin_fusable(int nparts, int C);
+int vs_bn_apply_fin(const float* partials, int nparts, double count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                    float* invstd, const void* y, const void* residual, void* out, uint8_t* relu_bits,
+                    int64_t rows, int C, int y_ld, int res_ld, int out_ld, int relu, void* stream);
 /* Backward of z = relu?(bn(y) (+res)):  g = dz * [z>0];
  *   pass 1 (reduce): partial[blk][2][C] = (sum g, sum g*xhat), xhat=(y-mean)*invstd
  *   pass 2 (apply):  dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M); dres = g. */
@@ -260,6 +272,13 @@ int vs_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* m
                     const float* dgamma, const float* dbeta, void* dy, void* dres, int64_t rows,
                     int C, int dz_ld, int z_ld, int y_ld, int dy_ld, int dres_ld, int relu,
                     void* stream);
+/* vs_bn_bwd_finalize + vs_bn_bwd_apply as ONE launch (see vs_bn_apply_fin): dgamma / dbeta come out of the kernel's
+ * prologue (bitwise vs_bn_bwd_finalize) and are stored by the blocks of row slab 0.  `partial` = the rows of
+ * vs_bn_bwd_reduce or of a dgrad epilogue (vs_conv_dgrad_bnstats / vs_conv_dgrad_ex); vs_bn_fin_fusable(nparts, C). */
+int vs_bn_bwd_apply_fin(const float* partial, int nparts, const void* dz, const void* z, const void* y,
+                        const float* mean, const float* invstd, const float* gamma, const float* beta,
+                        float* dgamma, float* dbeta, void* dy, void* dres, int64_t rows, int C, int dz_ld,
+                        int z_ld, int y_ld, int dy_ld, int dres_ld, int relu, void* stream);
 
 /* MaxPool3d([1,3,3], s[1,2,2], p[0,1,1]) of the stems (slowfast stem_helper via
  * mdl_sf_base.py:22).  idx: uint8 argmax tap (first max in (kh,kw) scan order,

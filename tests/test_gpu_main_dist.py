@@ -71,7 +71,9 @@ def test_bench_through_the_launcher_names_its_ranks(dev):
     rc, out, err = _run(["bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                          "--no-roofline"], {"VS_BENCH_FORCE_DIST": "1"}, timeout=1500)
     assert rc == 0, out[-2000:] + err
-    line = json.loads(out.strip().splitlines()[-1])
+    lines = out.strip().splitlines()
+    assert len(lines) == 1, out  # ONE JSON line on stdout, nothing else (RCCL's own chatter goes to stderr)
+    line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["value"] > 0
     assert "bucket" in line["config"]["grad_allreduce"]
 

@@ -505,6 +505,51 @@ def bn_finalize(partials, count, gamma, beta, running_mean, running_var, momentu
     return scale, shift, mean, invstd
 
 
+# Apply kernels that finalize for themselves (vs_bn_apply_fin / vs_bn_bwd_apply_fin): no finalize launch on the
+# step's dependency chain; results bitwise the separate launches (tests/test_gpu_bn_pool.py).  Built in round 3 on
+# the round-2 review's item 2 and MEASURED SLOWER: 12.62 vs 12.46 ms per train step (three alternating pairs, one box,
+# profiles/r03_bn_fin_fuse.txt).  Per layer (tools/bn_fin_time.py, dependent chains in a hipGraph): a finalize launch
+# costs ~4 us on the chain, and the fused pass pays about that in every block's prologue (100 KB of partial rows per
+# 64-channel column group from L2, two load rounds, an LDS tree) while its body, tiled over column groups, streams
+# worse than the column-owner kernel on the large tensors (s3.c 36.8 -> 49.3 us, s4.c 21.4 -> 25.6); only the
+# smallest layers gain (s5.b 6.8 -> 5.4 us).  OFF by default; VS_BN_FIN_FUSE=1 switches it on.
+BN_FIN_FUSE = _os.environ.get("VS_BN_FIN_FUSE", "0") == "1"
+_BN_FIN_MAXPARTS = 256
+
+
+def bn_fin_fusable(nparts, c):
+    """Whether `bn_apply_fin` takes these partial rows: directly (<= 256 rows) or behind the level-1 reduce that
+    `bn_finalize` would run as well (> _BN_TWO_LEVEL rows -> 32).  In between the separate finalize launch stays
+    (its one-level fp64 sum over up to 512 rows is what the results are pinned to)."""
+    cpr = c // 8
+    return (BN_FIN_FUSE and c % 8 == 0 and cpr > 0 and cpr & (cpr - 1) == 0
+            and (nparts <= _BN_FIN_MAXPARTS or nparts > _BN_TWO_LEVEL))
+
+
+def bn_apply_fin(partials, count, bn, y, residual=None, relu=True, out=None, want_bits=False):
+    """bn_finalize(train) + bn_apply as one launch: -> (out, bits | None, mean, invstd); running statistics of `bn`
+    updated in place.  Bitwise the two launches."""
+    c = bn.weight.numel()
+    dev = y.device
+    nparts = partials.shape[0]
+    if nparts > _BN_TWO_LEVEL:
+        lvl1 = torch.empty((32, 2, c), dtype=torch.float32, device=dev)
+        _lib.call("vs_bn_partials_reduce", _ptr(partials), nparts, _ptr(lvl1), c, 32, _stream())
+        partials, nparts = lvl1, 32
+    mean = torch.empty(c, dtype=torch.float32, device=dev)
+    invstd = torch.empty(c, dtype=torch.float32, device=dev)
+    if out is None:
+        out = new_act(*y.shape, device=dev)
+    bits = None
+    if want_bits and relu:
+        bits = torch.empty((act_rows(y), c // 8), dtype=torch.uint8, device=dev)
+    _lib.call("vs_bn_apply_fin", _ptr(partials), nparts, float(count), _ptr(bn.weight), _ptr(bn.bias),
+              _ptr(bn.running_mean), _ptr(bn.running_var), float(bn.momentum), float(bn.eps), _ptr(mean),
+              _ptr(invstd), _ptr(y), _ptr(residual), _ptr(out), _ptr(bits), act_rows(y), c, act_ld(y),
+              act_ld(residual) if residual is not None else 0, act_ld(out), int(relu), _stream())
+    return out, bits, mean, invstd
+
+
 def bn_apply(y, scale, shift, residual=None, relu=True, out=None, want_bits=False):
     """out = relu?(y * scale + shift (+ residual)).  want_bits (with relu): also returns the ReLU
     mask as bits, uint8 [rows, C/8], for the backward passes (vs_bn_apply_mask)."""
@@ -590,10 +635,16 @@ def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres, dy_out=None, dgamma=N
         dgamma = torch.empty(c, dtype=torch.float32, device=dev)
     if dbeta is None:
         dbeta = torch.empty(c, dtype=torch.float32, device=dev)
-    if not (_WHATIF & 2):
-        _lib.call("vs_bn_bwd_finalize", _ptr(partial), nblk, _ptr(dgamma), _ptr(dbeta), c, _stream())
     dy = new_act(*y.shape, device=dev) if dy_out is None else dy_out
     dres = new_act(*y.shape, device=dev) if want_dres else None
+    if BN_FIN_FUSE and nblk <= _BN_FIN_MAXPARTS and _lib.load().vs_bn_fin_fusable(nblk, c):
+        # the apply pass sums the partial rows itself (bitwise vs_bn_bwd_finalize): one launch fewer on the chain
+        _lib.call("vs_bn_bwd_apply_fin", _ptr(partial), nblk, _ptr(dz), _ptr(zz), _ptr(y), _ptr(mean), _ptr(invstd),
+                  _ptr(gamma), _ptr(beta), _ptr(dgamma), _ptr(dbeta), _ptr(dy), _ptr(dres), rows, c,
+                  act_ld(dz), z_ld, act_ld(y), act_ld(dy), act_ld(dres) if want_dres else 0, mode, _stream())
+        return dy, dres, dgamma, dbeta
+    if not (_WHATIF & 2):
+        _lib.call("vs_bn_bwd_finalize", _ptr(partial), nblk, _ptr(dgamma), _ptr(dbeta), c, _stream())
     _lib.call("vs_bn_bwd_apply", _ptr(dz), _ptr(zz), _ptr(y), _ptr(mean), _ptr(invstd),
               _ptr(gamma), _ptr(beta), _ptr(dgamma), _ptr(dbeta), _ptr(dy), _ptr(dres), rows, c,
               act_ld(dz), z_ld, act_ld(y), act_ld(dy), act_ld(dres) if want_dres else 0,

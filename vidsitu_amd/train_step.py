@@ -211,11 +211,19 @@ class TrainStep:
         # A process group's watchdog thread polls its events while this thread captures; the default
         # (global) capture mode treats that as an illegal call and invalidates the capture.
         mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+        inner = []  # an exception raised by the step itself: ending the aborted capture fails too, with a less useful error
+
+        def guarded(fn):
+            try:
+                fn()
+            except Exception as e:  # noqa: BLE001
+                inner.append(e)
+                raise
         try:
             if not self.use_dist:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode=mode):
-                    self.step()
+                    guarded(self.step)
                 self.graphs = [g]
             else:
                 graphs, pool = [], None
@@ -223,12 +231,13 @@ class TrainStep:
                 for fn in fns:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
-                        fn()
+                        guarded(fn)
                     pool = g.pool()
                     graphs.append(g)
                 self.graphs = graphs
             torch.cuda.synchronize()
         except Exception as e:
+            e = inner[0] if inner else e
             self.graphs = None
             if self.trunk is not None:
                 self.trunk._deferred = None

@@ -238,9 +238,14 @@ class _Unit:
             x = x[0]  # the stem wgrad kernel reads the same C=4 packed input
         else:
             y, partials = ops.conv_fwd(x, conv.w_bf16, conv.k, conv.s, conv.p, stats=True)
-        scale, shift, mean, invstd = ops.bn_finalize(
-            partials, ops.act_rows(y), bn.weight, bn.bias, bn.running_mean, bn.running_var,
-            bn.momentum, bn.eps, train=True)
+        # the apply pass finalizes for itself where the partial-row count allows it (ops.bn_apply_fin: no finalize
+        # launch on the chain); the pooled stems and debug traces keep the separate launches
+        fin_fused = (not pool and _Unit.trace is None and y.is_cuda
+                     and ops.bn_fin_fusable(partials.shape[0], y.shape[1]))
+        if not fin_fused:
+            scale, shift, mean, invstd = ops.bn_finalize(
+                partials, ops.act_rows(y), bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                bn.momentum, bn.eps, train=True)
         if conv.bias is not None:
             # train-mode BN removes a per-channel constant exactly, so the conv ran without its bias;
             # only the running mean sees it: mean(conv + b) = mean(conv) + b
@@ -256,8 +261,13 @@ class _Unit:
             return pooled
         want_bits = relu and residual is not None and y.shape[1] % 8 == 0 and \
             ((y.shape[1] // 8) & (y.shape[1] // 8 - 1)) == 0
-        z, zbits = ops.bn_apply(y, scale, shift, residual, relu, out=out, want_bits=True) if want_bits \
-            else (ops.bn_apply(y, scale, shift, residual, relu, out=out), None)
+        if fin_fused:
+            z, zbits, mean, invstd = ops.bn_apply_fin(partials, ops.act_rows(y), bn, y, residual, relu, out=out,
+                                                      want_bits=want_bits)
+        elif want_bits:
+            z, zbits = ops.bn_apply(y, scale, shift, residual, relu, out=out, want_bits=True)
+        else:
+            z, zbits = ops.bn_apply(y, scale, shift, residual, relu, out=out), None
         if _Unit.trace is not None:
             _Unit.trace.append((conv, y.float().cpu(), z.float().cpu(), mean.cpu(), invstd.cpu()))
         saved.append(dict(conv=conv, bn=bn, x=x, y=y, z=z, zbits=zbits, mean=mean, invstd=invstd,
