@@ -280,6 +280,16 @@ int vs_bn_bwd_apply_fin(const float* partial, int nparts, const void* dz, const 
                         float* dgamma, float* dbeta, void* dy, void* dres, int64_t rows, int C, int dz_ld,
                         int z_ld, int y_ld, int dy_ld, int dres_ld, int relu, void* stream);
 
+/* fp32 residual stream of a stage (eval mode, optional): out32 = relu?(residual + branch), out16 = bf16(out32),
+ * rows of C channels.  `branch` = the bottleneck's last unit with its BatchNorm folded (bf16, no residual, no
+ * ReLU); the residual is either the previous block's fp32 output (res32) or the shortcut unit's bf16 output
+ * (res16) -- exactly one of them.  Upstream `ResBlock.forward`: x = relu(branch1(x) | x  +  branch2(x))
+ * (slowfast resnet_helper via mdl_sf_base.py:21-34), which the reference evaluates in fp32; with bf16 activations
+ * the identity chain otherwise rounds once per block (north_star: logits within 1e-3).  r_ld counts elements of
+ * whichever residual is given. */
+int vs_residual_add_f32(const void* branch, const float* res32, const void* res16, float* out32, void* out16,
+                        int64_t rows, int C, int b_ld, int r_ld, int o32_ld, int o16_ld, int relu, void* stream);
+
 /* MaxPool3d([1,3,3], s[1,2,2], p[0,1,1]) of the stems (slowfast stem_helper via
  * mdl_sf_base.py:22).  idx: uint8 argmax tap (first max in (kh,kw) scan order,
  * as torch) per output element, used by the backward. */

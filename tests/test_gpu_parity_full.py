@@ -78,7 +78,7 @@ def test_configs0_i3d_tiny_112_logits_and_indices(dev):
     with torch.no_grad():
         lr = ref([batch["frms_ev_fast_tensor"].flatten(0, 1)])
         lo = mdl({k: v.to(dev) for k, v in batch.items()})["mdl_out"].float().cpu().view(4, -1)
-    err = _check_logits(lo, lr, 2e-2, "i3d_tiny 4x3x8x112x112")
+    err = _check_logits(lo, lr, 6e-3, "i3d_tiny 4x3x8x112x112")  # measured 2.1e-3
     _check_top5(lo, lr, err)
 
 
@@ -99,15 +99,71 @@ def test_slowfast_r50_one_clip_224_eval_logits(dev):
         fo = mdl.head(mdl.forward_encoder(gb)).float().cpu().view(1, -1)
     print(f"features [1, 2304]: rel_l2 {rel_l2(fo, fr.view(1, -1)):.3e}, max-normalised "
           f"{rel_err(fo, fr.view(1, -1)):.3e}")
-    assert rel_l2(fo, fr.view(1, -1)) < 2e-2
-    err = _check_logits(lo, lr, 2e-2, "SlowFast-R50 1 clip 224^2")
+    # measured: features rel_l2 3.4e-3, logits 2.8e-3 relative (bf16 residual stream through 53 convolutions); the
+    # bounds are ~2x that, so a regression shows.  north_star's 1e-3 is NOT met in this mode -- see
+    # test_slowfast_r50_one_clip_224_eval_logits_fp32_residual_stream for the mode that is built for it.
+    assert rel_l2(fo, fr.view(1, -1)) < 8e-3
+    err = _check_logits(lo, lr, 6e-3, "SlowFast-R50 1 clip 224^2")
     _check_top5(lo, lr, err)
 
 
+def test_slowfast_r50_one_clip_224_eval_logits_fp32_residual_stream(dev, monkeypatch):
+    """The same clip with the identity chain of every stage kept in fp32 (`ResBlock.residual_fp32`, VS_RESIDUAL_FP32=1;
+    vs_residual_add_f32): north_star asks for logits within 1e-3 of the reference.  Prints both modes' errors; the fp32
+    stream must be closer than the bf16 one, and the bound below is ~1.5x what was measured when the mode was built
+    (DESIGN.md section 4 records the figure and the mode's clips/s cost)."""
+    from vidsitu_amd import synth_data
+    from vidsitu_amd.trunk import ResBlock
+
+    cfg, comm, ref, mdl = _sfbase_pair("slow_fast_nl_r50_8x8", 1564, dev)
+    batch = synth_data.synth_batch(cfg, comm, bs=1, n_ev=1, seed=1234)
+    with torch.no_grad():
+        lr = ref([batch["frms_ev_slow_tensor"].flatten(0, 1), batch["frms_ev_fast_tensor"].flatten(0, 1)])
+        gb = {k: v.to(dev) for k, v in batch.items()}
+        lo16 = mdl(gb)["mdl_out"].float().cpu().view(1, -1)
+        monkeypatch.setattr(ResBlock, "residual_fp32", True)
+        lo32 = mdl(gb)["mdl_out"].float().cpu().view(1, -1)
+        # where the distance comes from: the oracle with the SAME bf16-representable conv weights (what is left is
+        # the rounding of activations), against the oracle proper (fp32 weights)
+        import copy
+        ref_w16 = copy.deepcopy(ref)
+        for m in ref_w16.modules():
+            if isinstance(m, torch.nn.Conv3d):
+                m.weight.data = rb(m.weight.data)
+        lr_w16 = ref_w16([batch["frms_ev_slow_tensor"].flatten(0, 1), batch["frms_ev_fast_tensor"].flatten(0, 1)])
+    scale = float(lr.abs().max())
+    rel = lambda a, b: float((a - b).abs().max()) / scale
+    e16, e32 = rel(lo16, lr), rel(lo32, lr)
+    print(f"SlowFast-R50 1 clip 224^2, logits relative error: bf16 residual stream {e16:.3e} (rel_l2 "
+          f"{rel_l2(lo16, lr):.3e}), fp32 residual stream {e32:.3e} (rel_l2 {rel_l2(lo32, lr):.3e}); north_star 1e-3")
+    print(f"  decomposition: fp32 oracle with bf16-rounded conv weights vs fp32 oracle {rel(lr_w16, lr):.3e}; "
+          f"HIP vs that oracle: bf16 stream {rel(lo16, lr_w16):.3e}, fp32 stream {rel(lo32, lr_w16):.3e}")
+    # Measured when the mode was built (round 3): 3.02e-3 (bf16 stream) vs 3.03e-3 (fp32 stream) -- the identity chain's
+    # rounding is NOT what separates the bf16 path from north_star's 1e-3; the operands' own rounding (weights and
+    # activations, ~1e-3 per convolution, 53 of them) is.  The mode stays (opt-in, 2 413 vs 3 329 clips/s): it must not
+    # be worse than the default, and both stay within 2x the measured figure.
+    assert e32 < 1.15 * e16 + 1e-4
+    assert e32 < 6e-3
+    _check_top5(lo32, lr, e32 * scale)
+    # ... and the mode that does meet it: split bf16 weights (W_hi + W_lo, every convolution twice)
+    from vidsitu_amd.trunk import _Unit
+    monkeypatch.setattr(ResBlock, "residual_fp32", False)
+    monkeypatch.setattr(_Unit, "split_weights", True)
+    with torch.no_grad():
+        lo_sw = mdl(gb)["mdl_out"].float().cpu().view(1, -1)
+        fo_sw = mdl.head(mdl.forward_encoder(gb)).float().cpu().view(1, -1)
+        fr = ref.forward_feats([batch["frms_ev_slow_tensor"].flatten(0, 1), batch["frms_ev_fast_tensor"].flatten(0, 1)])
+    e_sw = rel(lo_sw, lr)
+    print(f"  split bf16 weights (VS_EVAL_SPLIT_WEIGHTS=1): logits relative error {e_sw:.3e} (rel_l2 {rel_l2(lo_sw, lr):.3e}), "
+          f"features rel_l2 {rel_l2(fo_sw, fr.view(1, -1)):.3e}")
+    assert e_sw < 1e-3, "north_star: logits within 1e-3 of the reference"
+    assert _check_top5(lo_sw, lr, e_sw * scale) >= 0
+
+
 # ---------------------------------------------------------------------------------------------------
-def _block_list(trunk, ref):
+def _block_list(trunk, ref, stages=(2, 3, 4, 5)):
     out = []
-    for k in range(2, 6):
+    for k in stages:
         so, sr = getattr(trunk, f"s{k}"), getattr(ref, f"s{k}")
         for p in range(trunk.num_pathways):
             for i in range(so.num_blocks[p]):
@@ -151,8 +207,12 @@ def _block_as_the_kernels_compute_it(blk, x):
     return _unit_as_the_kernels_compute_it(b, b2.c, b2.c_bn, True, res=sc)
 
 
-@pytest.mark.parametrize("arch,depth,hw,n", [("slowfast", 50, 64, 2), ("i3d", 50, 64, 2)])
-def test_every_resblock_fwd_bwd_matches_oracle_on_the_oracles_own_tensors(arch, depth, hw, n, dev):
+# The third case is ONE clip at full resolution (fast 32 x 224^2 + slow 8 x 224^2; batch norm over the one clip on both
+# sides) for the s2 / s3 blocks: the large-M plans the bench step actually runs (persistent pointwise kernel, 128 x 128
+# ring tiles, the small-channel direct kernel at 10^5..10^6 rows) -- at the 64^2 crop those layers have 16x fewer rows.
+@pytest.mark.parametrize("arch,depth,hw,n,stages", [("slowfast", 50, 64, 2, (2, 3, 4, 5)), ("i3d", 50, 64, 2, (2, 3, 4, 5)),
+                                                    ("slowfast", 50, 224, 1, (2, 3))])
+def test_every_resblock_fwd_bwd_matches_oracle_on_the_oracles_own_tensors(arch, depth, hw, n, stages, dev):
     import copy
 
     from oracle.slowfast_ref import VideoTrunk as RefTrunk, default_sf_cfg, randomize_bn, slow_index
@@ -185,7 +245,7 @@ def test_every_resblock_fwd_bwd_matches_oracle_on_the_oracles_own_tensors(arch, 
             out.register_hook(lambda gr, name=name: cap[name].__setitem__("dout", gr.detach().clone()))
         return fwd_hook
 
-    blocks = _block_list(ours, ref)
+    blocks = _block_list(ours, ref, stages)
     hooks = [rblk.register_forward_hook(mk(name)) for name, _, rblk in blocks]
     feats = ref.forward_features(xs)
     sum((f * torch.randn(f.shape, generator=g)).sum() for f in feats).backward()
@@ -230,7 +290,16 @@ def test_every_resblock_fwd_bwd_matches_oracle_on_the_oracles_own_tensors(arch, 
     # So: every tensor of every block within 4e-2 (a wrong or missing term of a backward formula is an O(1)
     # error on the tensors behind it), the median block's worst tensor within 1e-2, at least half of the
     # blocks entirely within 1e-2 and nine in ten entirely within 2e-2.
-    gross = [(n, [(k, e) for k, e in bad if not e < 4e-2]) for _, n, _, _, _, bad in worst]
+    # Full-resolution case: the two weight gradients that read the INPUT of the fast pathway's first block (8 channels,
+    # 100 352 positions, a post-ReLU / max-pool tensor with a large mean) against an output gradient that sums to zero
+    # per channel are cancellation-dominated; the operands of the two sides differ by their own bf16 roundings and the
+    # sums move by 7-9 % (round 3).  The kernel itself is exact on equal operands at that shape: 2-7e-7 against fp64
+    # (tools/probes/wgrad_bigP.py, profiles/r03_wgrad_bigP.txt).  Those tensors get 1.5e-1 here, everything else 4e-2.
+    def limit(block, tensor):
+        if hw >= 224 and block.endswith("_res0") and tensor in ("branch1.weight", "branch2.a.weight"):
+            return 1.5e-1
+        return 4e-2
+    gross = [(n, [(k, e) for k, e in bad if not e < limit(n, k)]) for _, n, _, _, _, bad in worst]
     gross = [(n, b) for n, b in gross if b]
     assert not gross, f"tensors beyond 4e-2: {gross[:3]}"
     errs = sorted(r[0] for r in worst)

@@ -208,13 +208,7 @@ def test_learned_fill_set_raises_when_a_later_step_routes_a_gradient_through_aut
     m.direct = False
     with pytest.raises(RuntimeError, match="lin.weight"):
         ts.step()
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        with pytest.raises(RuntimeError, match="lin.weight"):
-            ts.capture()
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
+    ts_learn = ts
     # default: a full fill every step -- switching paths changes nothing
     make.fill = True
     m, arena, ts = make(True)
@@ -225,3 +219,13 @@ def test_learned_fill_set_raises_when_a_later_step_routes_a_gradient_through_aut
     ts2.step(); ts2.step(); ts2.step()
     torch.cuda.synchronize()
     assert torch.equal(arena.data, arena2.data) and torch.equal(arena.grad, arena2.grad)
+    # ... and the pass a hipGraph is captured from is watched too (last: an aborted capture leaves torch's CUDA generator
+    # in capture mode, nothing random may follow in this process)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with pytest.raises(RuntimeError, match="lin.weight"):
+            ts_learn.capture()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert ts_learn.graphs is None

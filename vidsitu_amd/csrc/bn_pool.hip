@@ -1339,6 +1339,54 @@ extern "C" int vs_bn_bwd_apply_pool(const void* d_pooled, const uint8_t* idx, co
 }
 
 // ----------------------------------------------------------------------------
+// fp32 residual stream (eval only, VS_RESIDUAL_FP32): out32 = relu?(residual + branch), out16 = bf16(out32).
+// `branch` is the c unit's folded-BN output (bf16); the residual is the previous block's fp32 output, or -- first
+// block of a stage -- the bf16 output of the shortcut unit.  The identity chain of a stage then never passes
+// through bf16: what the next convolution reads is one rounding of the exact stream, not the 16th.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void residual_add_f32_kernel(const uint16_t* branch, const float* res32,
+                                                               const uint16_t* res16, float* out32, uint16_t* out16,
+                                                               long long rows, int C, int b_ld, int r_ld, int o32_ld,
+                                                               int o16_ld, int relu) {
+  const int cpr = C >> 3;
+  const long long total = rows * cpr;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const long long row = idx / cpr;
+    const int c = (int)(idx - row * cpr) * 8;
+    float v[8], r[8];
+    unpack8_bf16(*(const uint4*)(branch + row * b_ld + c), v);
+    if (res32) {
+      *(float4*)(r) = *(const float4*)(res32 + row * r_ld + c);
+      *(float4*)(r + 4) = *(const float4*)(res32 + row * r_ld + c + 4);
+    } else {
+      unpack8_bf16(*(const uint4*)(res16 + row * r_ld + c), r);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] += r[e];
+      if (relu) v[e] = fmaxf(v[e], 0.f);
+    }
+    *(float4*)(out32 + row * o32_ld + c) = *(const float4*)(v);
+    *(float4*)(out32 + row * o32_ld + c + 4) = *(const float4*)(v + 4);
+    *(uint4*)(out16 + row * o16_ld + c) = pack8_bf16(v);
+  }
+}
+
+extern "C" int vs_residual_add_f32(const void* branch, const float* res32, const void* res16, float* out32,
+                                   void* out16, int64_t rows, int C, int b_ld, int r_ld, int o32_ld, int o16_ld,
+                                   int relu, void* stream) {
+  VS_CHECK_ARG(branch && out32 && out16 && ((res32 != nullptr) != (res16 != nullptr)), "one residual, two outputs");
+  VS_CHECK_ARG(C % 8 == 0 && b_ld % 8 == 0 && r_ld % 8 == 0 && o32_ld % 4 == 0 && o16_ld % 8 == 0,
+               "channels / pitches must be multiples of 8");
+  hipLaunchKernelGGL(residual_add_f32_kernel, dim3(ew_grid(rows * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)branch, res32, (const uint16_t*)res16, out32, (uint16_t*)out16, (long long)rows,
+                     C, b_ld, r_ld, o32_ld, o16_ld, relu);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// ----------------------------------------------------------------------------
 // MaxPool3d([1,3,3], s[1,2,2], p[0,1,1]); idx = first max in (kh,kw) scan order
 // ----------------------------------------------------------------------------
 // (SMALL: fewer than 2^24 elements -- every tensor of the bench step: the element index is split with float-reciprocal

@@ -667,6 +667,13 @@ static WgCfg wg_pick(const vs_conv_desc* d) {
   // Round the split DOWN so that the grid fits one residency round (two blocks are resident per CU,
   // 80 KB of LDS each) -- 528 blocks on 512 slots run as two rounds (s4.a: +45 %)
   long long S = target / tiles;
+  // layers whose output alone has this many tiles run unsplit: no fp32 slabs, no reduce launch behind the kernel
+  // (VS_WGRAD_S1_TILES; 0 = off)
+  static const long long s1_tiles = [] {
+    const char* e = getenv("VS_WGRAD_S1_TILES");
+    return e ? atoll(e) : 0ll;
+  }();
+  if (s1_tiles > 0 && tiles >= s1_tiles && !forced_slots) S = 1;
   const long long maxS = (P + 511) / 512;
   if (S > maxS) S = maxS;
   const long long slab_cap = (64ll << 20) / ((long long)d->Cout * Kp * 4);  // <= 64 MB of slabs

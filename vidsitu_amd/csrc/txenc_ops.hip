@@ -666,15 +666,21 @@ __device__ __forceinline__ void linear_bwd_weight_body(const float* __restrict__
           xv[u].w = k + 3 < K ? src[3] : 0.f;
         }
       }
+      // Rows past M contribute through a ZEROED dy (acc + 0 * x == acc bit for bit), not through a predicated update:
+      // with `if (m0 + u < M) acc += ...` the fused launch's copy of this body was compiled to v_pk_fma_f32 followed
+      // two or three instructions later by v_cndmask_b32 reads of the packed result, and with an MFMA convolution
+      // kernel running beside it on another stream (same process or another one) single 16-lane passes of those reads
+      // saw the register BEFORE the packed FMA's write -- one term of one component of dW missing, in every launch of
+      // 900 (tools/probes/linear_vs_mfma_neighbor.py, profiles/r03_linear_fused_neighbor.txt; the stand-alone kernel,
+      // compiled to an unbroken v_pk_fma_f32 chain, never showed it).  An unconditional chain in both copies.
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        if (m0 + u < M) {  // same order as a plain loop over m
-          acc.x += dd[u] * xv[u].x;
-          acc.y += dd[u] * xv[u].y;
-          acc.z += dd[u] * xv[u].z;
-          acc.w += dd[u] * xv[u].w;
-          bsum += dd[u];
-        }
+        const float d = (m0 + u < M) ? dd[u] : 0.f;  // same order as a plain loop over m
+        acc.x = __fmaf_rn(d, xv[u].x, acc.x);
+        acc.y = __fmaf_rn(d, xv[u].y, acc.y);
+        acc.z = __fmaf_rn(d, xv[u].z, acc.z);
+        acc.w = __fmaf_rn(d, xv[u].w, acc.w);
+        bsum += d;
       }
     }
     float* dst = dw + (long long)n * K + k;

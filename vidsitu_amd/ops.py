@@ -652,6 +652,21 @@ def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres, dy_out=None, dgamma=N
     return dy, dres, dgamma, dbeta
 
 
+def residual_add_f32(branch, residual, relu=True, out16=None):
+    """fp32 residual stream (eval): -> (out16 bf16 activation, out32 fp32 [rows, C]).  `residual`: a bf16 activation
+    (the shortcut unit's output) or the fp32 [rows, C] stream of the previous block."""
+    rows, c = act_rows(branch), branch.shape[1]
+    dev = branch.device
+    if out16 is None:
+        out16 = new_act(*branch.shape, device=dev)
+    out32 = torch.empty((rows, c), dtype=torch.float32, device=dev)
+    f32 = residual.dtype == torch.float32
+    _lib.call("vs_residual_add_f32", _ptr(branch), _ptr(residual) if f32 else None, None if f32 else _ptr(residual),
+              _ptr(out32), _ptr(out16), rows, c, act_ld(branch), c if f32 else act_ld(residual), c, act_ld(out16),
+              int(relu), _stream())
+    return out16, out32
+
+
 # ----------------------------------------------------------------------------
 # pooling
 # ----------------------------------------------------------------------------
@@ -762,8 +777,23 @@ def linear_bwd(dy, x, w, need_dx=True, has_bias=True, dw_out=None, db_out=None, 
                 db = db_out if db_out is not None else torch.empty(n, dtype=torch.float32, device=x.device)
             if dx_res is not None and (dx_res.dtype != torch.float32 or not dx_res.is_contiguous()):
                 dx_res = _f32c(dx_res)
+            _dbg = _os.environ.get("VS_LBF_DBG", "")
+            if "x" in _dbg:
+                x = x.clone()
+            if "y" in _dbg:
+                dy = dy.clone()
+            dw_real = None
+            if "w" in _dbg and dw_out is not None:
+                dw_real, dw = dw, torch.empty_like(dw)
+            if "p" in _dbg:
+                torch.cuda.synchronize()
             _lib.call("vs_linear_bwd_fused_res", _ptr(dy), _ptr(relu_y), _ptr(x), _ptr(wt), _ptr(dx_res), _ptr(dx),
                       _ptr(dw), _ptr(db), m, n, k, _stream())
+            if "s" in _dbg:
+                torch.cuda.synchronize()
+            if dw_real is not None:
+                dw_real.copy_(dw)
+                dw = dw_real
             return dx, dw, db
     if relu_y is not None:
         dy = relu_bwd(dy, relu_y)
