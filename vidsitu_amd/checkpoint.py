@@ -62,9 +62,22 @@ def load_model_dict(path, mdl, optimizer=None, load_opt=False, strict=True, aren
     parameters live in -- its bf16 / transposed kernel copies are refreshed after the load."""
     if not os.path.exists(path):
         return None
+    import pickle
+
     with open(path, "rb") as f:
-        # tensors, python scalars / containers only: the reference's files hold nothing else
-        ckpt = torch.load(f, map_location="cpu", weights_only=True)
+        # tensors, python scalars / containers only: the reference's files hold nothing else -- except that its
+        # `best_met` / scheduler bookkeeping may be a numpy scalar (`utils/trn_utils.py:699-716` saves whatever the
+        # metric function returned).  Such a file is refused by the safe unpickler: say so, and how to load it.
+        try:
+            ckpt = torch.load(f, map_location="cpu", weights_only=True)
+        except pickle.UnpicklingError as e:
+            if os.environ.get("VS_CKPT_UNSAFE_LOAD") != "1":
+                raise RuntimeError(
+                    f"{path}: the checkpoint holds objects the safe (weights_only) loader refuses -- typically a numpy "
+                    f"scalar in `best_met` written by the reference trainer.  If the file is trusted, set "
+                    f"VS_CKPT_UNSAFE_LOAD=1 to load it with the full unpickler.  ({e})") from e
+            f.seek(0)
+            ckpt = torch.load(f, map_location="cpu", weights_only=False)
     msd = _strip_module(ckpt["model_state_dict"])
     ref_only = reference_only_keys(mdl)
     for k, shape in ref_only.items():

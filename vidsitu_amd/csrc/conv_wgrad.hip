@@ -667,11 +667,14 @@ static WgCfg wg_pick(const vs_conv_desc* d) {
   // Round the split DOWN so that the grid fits one residency round (two blocks are resident per CU,
   // 80 KB of LDS each) -- 528 blocks on 512 slots run as two rounds (s4.a: +45 %)
   long long S = target / tiles;
-  // layers whose output alone has this many tiles run unsplit: no fp32 slabs, no reduce launch behind the kernel
-  // (VS_WGRAD_S1_TILES; 0 = off)
+  // Layers whose output alone has >= 128 tiles (slow s5: conv a 192, conv b 144) run UNSPLIT: the split of 2 they used
+  // to get wrote and re-read two fp32 slabs of a 9-13 MB dW and put a reduce launch behind the kernel; with their
+  // dgrad's tiles in the same grid (conv_pair.hip) the chip is full either way.  Train step 12.311-12.314 ms against
+  // 12.321-12.361 (alternating, one box: profiles/r03_wgrad_unsplit.txt); a threshold of 96 tiles is slower (12.43).
+  // VS_WGRAD_S1_TILES overrides (0 = never).
   static const long long s1_tiles = [] {
     const char* e = getenv("VS_WGRAD_S1_TILES");
-    return e ? atoll(e) : 0ll;
+    return e ? atoll(e) : 128ll;
   }();
   if (s1_tiles > 0 && tiles >= s1_tiles && !forced_slots) S = 1;
   const long long maxS = (P + 511) / 512;
