@@ -1271,9 +1271,9 @@ __device__ __forceinline__ void add_layernorm_bwd_param_rows_body(
       rs[u] = rstd[ok ? row : 0];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      ag += gg[u] * (vv[u] - mu[u]) * rs[u];
-      ab += gg[u];
+    for (int u = 0; u < 4; ++u) {  // spelled out: the one-launch stack's copy (tx_ln_bwd_param_body) must round alike
+      ag = __fadd_rn(ag, __fmul_rn(__fmul_rn(gg[u], vv[u] - mu[u]), rs[u]));
+      ab = __fadd_rn(ab, gg[u]);
     }
   }
   sg[wave][lane] = ag;

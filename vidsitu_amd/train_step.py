@@ -218,6 +218,14 @@ class TrainStep:
                 fn()
             except Exception as e:  # noqa: BLE001
                 inner.append(e)
+                # The step died half way: streams it forked into the capture (transposes, the fast pathway's, the
+                # weight-gradient lane) are still un-joined, and ending such a capture fails in a way that leaves the
+                # process unusable for any later capture (ROCm 7.2: "legacy stream depends on a capturing blocking
+                # stream" from then on).  Join them so that the capture ends legally; the graph is discarded.
+                try:
+                    self._join_forked_streams()
+                except Exception:  # noqa: BLE001
+                    pass
                 raise
         try:
             if not self.use_dist:
@@ -242,6 +250,25 @@ class TrainStep:
             if self.trunk is not None:
                 self.trunk._deferred = None
             raise RuntimeError(f"hipGraph capture of the training step failed: {e!r}") from e
+
+    def _join_forked_streams(self):
+        """Make the current (capturing) stream wait for every side stream of this package that is part of the capture."""
+        from . import trunk as _trunk
+
+        main = torch.cuda.current_stream()
+        cands = [getattr(self.arena, "_tr_stream", None), self._adam_stream]
+        cands += list(_trunk.VideoTrunk._side_streams.values()) + list(_trunk.VideoTrunk._reduce_streams.values())
+        cands += [lane[1] for lane in _trunk._WgradLanes.lanes.values()]
+        for st in cands:
+            if st is None or st.cuda_stream == main.cuda_stream:
+                continue
+            with torch.cuda.stream(st):
+                capturing = torch.cuda.is_current_stream_capturing()
+            if capturing:
+                main.wait_stream(st)
+        _trunk._WgradLanes.join_all()
+        if getattr(self.arena, "_tr_pending", False):
+            self.arena._join_transposes()
 
     def replay(self):
         if self.graphs is None:
