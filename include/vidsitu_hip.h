@@ -220,6 +220,15 @@ int64_t vs_wgrad_reduce_blocks(int64_t elements);
  * launches can release the wgrad's operands -- and let a stream that waits for them go on -- before the reduce. */
 int vs_wgrad_reduce(const float* slabs, float* dw, int64_t elements, int splits, void* stream);
 int vs_wgrad_reduce_batched(const int64_t* table, int n_entries, int64_t total_blocks, void* stream);
+/* Deferred slab reduce (round 3).  mode 1: a slab reduce issued behind vs_conv_wgrad / vs_conv_pair_end on this host
+ * thread is not launched but waits (one slot) for the next vs_bn_bwd_finalize on the same stream, which issues ONE grid
+ * holding both kernels' blocks -- in a unit's backward (autograd of slowfast's BottleneckTransform, mdl_sf_base.py:21-34)
+ * they are neighbours on the stream and independent of each other; bitwise the two launches.  Flushed (launched alone) by
+ * a second deferred reduce, by a weight gradient handed the same workspace or dw, by vs_wgrad_reduce_flush() and by
+ * mode 0.  mode 2: suspended -- reduces are launched as usual and nothing is flushed (launches on a side lane, whose
+ * completion event must cover the reduce).  Thread-local state. */
+int vs_wgrad_reduce_defer(int mode);
+int vs_wgrad_reduce_flush(void);
 
 /* BatchNorm3d (mdl_sf_base.py:22-33 via slowfast BN modules; eps 1e-5, mom 0.1).
  * finalize: reduce conv-epilogue partials -> batch mean / biased var ->

@@ -638,3 +638,49 @@ def test_pair_launch_of_dgrad_and_wgrad_is_bitwise_the_separate_launches(dev):
     assert all(torch.equal(a, b) for a, b in zip(f0, f1))
     bad = [k for k in g0 if not torch.equal(g0[k], g1[k])]
     assert not bad, bad[:5]
+
+
+def test_deferred_slab_reduce_merged_with_the_next_finalize_is_bitwise_and_shorter(dev, monkeypatch):
+    """Round 3: the slab reduce behind a weight gradient waits for the next unit's BN-backward finalize and shares its
+    launch (vs_wgrad_reduce_defer, bn_bwd_finalize_wgrad_reduce_kernel).  Same bodies: every gradient of a SlowFast-R50
+    step bit for bit, with fewer launches; nothing is left pending after a backward pass."""
+    from vidsitu_amd import ops, synth_data
+    from vidsitu_amd.extended_config import get_cfg
+    from vidsitu_amd.mdl_selector import get_mdl_loss_eval
+    from vidsitu_amd.optim import ArenaAdam, ParamArena
+    from vidsitu_amd.train_step import TrainStep
+
+    cfg = get_cfg({"mdl.mdl_name": "sf_base_txenc", "mdl.sf_mdl_name": "slow_fast_nl_r50_8x8", "synth.num_verbs": 31,
+                   "tx_dec.encoder_layers": 2, "tx_dec.dropout": 0.0})
+    comm = synth_data.make_comm(cfg)
+    torch.manual_seed(0)
+    sel = get_mdl_loss_eval(cfg)
+    mdl = sel["mdl"](cfg=cfg, comm=comm).to(dev).train()
+    arena = ParamArena(mdl)
+    opt = ArenaAdam(arena, lr=1e-3)
+    batch = synth_data.synth_batch(cfg, comm, bs=2, n_ev=2, crop=96, device=dev, dtype=torch.bfloat16)
+    bufs = {k: v.clone() for k, v in mdl.named_buffers()}
+    lib = ops._lib.load()
+    out = {}
+    for merge in (False, True):
+        monkeypatch.setattr(ops, "REDUCE_MERGE", merge)
+        for deferred in (False, True):  # the autograd-driven backward and the segment-by-segment one
+            for k, v in mdl.named_buffers():
+                v.copy_(bufs[k])
+            ts = TrainStep(mdl, sel["loss"](cfg, comm), arena, opt, batch, world=1, use_dist=False, overlap=deferred)
+            ts.overlap = deferred
+            ts.segments = ts._build_segments()
+            arena.grad.fill_(float("nan"))
+            n0 = lib.vs_launch_count()
+            for fn, _ in ts.segments:
+                fn()
+            torch.cuda.synchronize()
+            out[(merge, deferred)] = (arena.grad.clone(), lib.vs_launch_count() - n0)
+    mdl.sf_mdl.defer_backward = False
+    for deferred in (False, True):
+        g0, n_sep = out[(False, deferred)]
+        g1, n_mrg = out[(True, deferred)]
+        assert torch.isfinite(g0).all()
+        assert torch.equal(g0, g1), f"deferred={deferred}: gradients differ with the merged launches"
+        assert n_mrg <= n_sep - 30, (n_sep, n_mrg)
+    assert torch.equal(out[(True, False)][0], out[(True, True)][0])

@@ -72,6 +72,8 @@ SIGNATURES = {
     "vs_wgrad_reduce_blocks": (_i64, [_i64]),
     "vs_wgrad_reduce": (_i, [_p, _p, _i64, _i, _p]),
     "vs_wgrad_reduce_batched": (_i, [_p, _i, _i64, _p]),
+    "vs_wgrad_reduce_defer": (_i, [_i]),
+    "vs_wgrad_reduce_flush": (_i, []),
     "vs_bn_finalize": (_i, [_p, _i, _d, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i, _p]),
     "vs_bn_partials_reduce": (_i, [_p, _i, _p, _i, _i, _p]),
     "vs_bn_apply": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p]),

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "glue_bodies.h"
 
 // ----------------------------------------------------------------------------
 // NCDHW (f32 | bf16) -> NDHWC bf16, channels zero-padded to Cpad (multiple of 8)
@@ -950,12 +951,10 @@ extern "C" int vs_bn_bwd_reduce(const void* dz, const void* z, const void* y, co
   return VS_OK;
 }
 
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* partial, int nparts,
-                                                              float* dgamma, float* dbeta, int C) {
-  __shared__ double sh_s[32][33];
-  __shared__ double sh_q[32][33];
+__device__ __forceinline__ void bn_bwd_finalize_body(const float* partial, int nparts, float* dgamma, float* dbeta,
+                                                     int C, int bid, double (*sh_s)[33], double (*sh_q)[33]) {
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  const int c = bid * 32 + cl;
   double s = 0.0, q = 0.0;
   if (c < C) {
     int p = sl;
@@ -991,11 +990,44 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* part
   }
 }
 
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* partial, int nparts,
+                                                              float* dgamma, float* dbeta, int C) {
+  __shared__ double sh_s[32][33];
+  __shared__ double sh_q[32][33];
+  bn_bwd_finalize_body(partial, nparts, dgamma, dbeta, C, blockIdx.x, sh_s, sh_q);
+}
+
+// The finalize and the slab reduce of the previous unit's weight gradient (pending on the stream: conv_wgrad.hip,
+// vs_wgrad_reduce_defer) as ONE grid: blocks [0, g1) finalize, the rest hold four 256-thread virtual blocks of the
+// reduce each.  Same bodies as the two stand-alone kernels: bitwise their results; one launch fewer on the chain.
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_wgrad_reduce_kernel(const float* partial, int nparts,
+                                                                           float* dgamma, float* dbeta, int C, int g1,
+                                                                           const float* slabs, float* dw, long long n,
+                                                                           int S) {
+  __shared__ __attribute__((aligned(16))) char lds[4 * 16 * 17 * 16];  // 4 x part[16][17] >= sh_s + sh_q (2 x 8 448 B)
+  if ((int)blockIdx.x < g1) {
+    double (*sh_s)[33] = (double (*)[33])lds;
+    double (*sh_q)[33] = (double (*)[33])(lds + 32 * 33 * 8);
+    bn_bwd_finalize_body(partial, nparts, dgamma, dbeta, C, blockIdx.x, sh_s, sh_q);
+  } else {
+    float4 (*part)[17] = (float4 (*)[17])(lds + (threadIdx.x >> 8) * 16 * 17 * 16);
+    wgrad_reduce_body(slabs, dw, n, S, part, (long long)(blockIdx.x - g1) * 4 + (threadIdx.x >> 8), threadIdx.x & 255);
+  }
+}
+
 extern "C" int vs_bn_bwd_finalize(const float* partial, int nparts, float* dgamma, float* dbeta,
                                   int C, void* stream) {
   VS_CHECK_ARG(partial && dgamma && dbeta && nparts > 0, "bad args");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0,
-                     (hipStream_t)stream, partial, nparts, dgamma, dbeta, C);
+  VsPendingReduce pr;
+  const int g1 = (C + 31) / 32;
+  if (vs_pending_reduce_take((hipStream_t)stream, &pr)) {
+    const long long rb = (pr.n / 4 + 15) / 16;  // 256-thread virtual blocks of the reduce
+    hipLaunchKernelGGL(bn_bwd_finalize_wgrad_reduce_kernel, dim3((unsigned)(g1 + (rb + 3) / 4)), dim3(1024), 0,
+                       (hipStream_t)stream, partial, nparts, dgamma, dbeta, C, g1, pr.slabs, pr.dw, pr.n, pr.S);
+  } else {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(g1), dim3(1024), 0, (hipStream_t)stream, partial, nparts, dgamma,
+                       dbeta, C);
+  }
   VS_CHECK_LAUNCH();
   return VS_OK;
 }

@@ -134,7 +134,7 @@ extern "C" int vs_conv_pair_end(void) {
         hipLaunchKernelGGL((conv_wgrad_ring_kernel<128, 128, 2, 2, 1, 2>), dim3(s.w_grid), dim3(256), s.w_smem, s.st, s.wp);
     }
   }
-  if (s.have_r) {
+  if (s.have_r && !pending_stash(s.slabs, s.dw, s.n, s.splits, s.st)) {
     const long long grid = (s.n / 4 + 15) / 16;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, s.st, s.slabs, s.dw, s.n, s.splits);
   }

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "glue_bodies.h"
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -491,49 +492,64 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradP p) {
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, float* dw,
                                                           long long n, int S) {
   __shared__ float4 part[16][17];
-  const long long n4 = n >> 2;
-  const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const long long i = (long long)blockIdx.x * 16 + col;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (i < n4) {
-    const int per = (S + 15) / 16;
-    const int s0 = sl * per, s1 = min(S, s0 + per);
-    // 8 slab rows in flight per thread (a one-load-at-a-time loop is a chain of memory
-    // latencies: 20 us for S = 1024); the sum order stays s0, s0+1, ...
-    int s = s0;
-    for (; s + 8 <= s1; s += 8) {
-      float4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(slabs + (long long)(s + u) * n + i * 4);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        acc.x += v[u].x;
-        acc.y += v[u].y;
-        acc.z += v[u].z;
-        acc.w += v[u].w;
-      }
-    }
-    for (; s < s1; ++s) {
-      const float4 v = *(const float4*)(slabs + (long long)s * n + i * 4);
-      acc.x += v.x;
-      acc.y += v.y;
-      acc.z += v.z;
-      acc.w += v.w;
-    }
+  wgrad_reduce_body(slabs, dw, n, S, part, blockIdx.x, threadIdx.x);
+}
+
+// ---- deferred slab reduce (round 3) ----------------------------------------------------------------------------
+// Between vs_wgrad_reduce_defer(1) and (0) a slab reduce issued behind a weight gradient is not launched: it waits, one
+// slot per host thread, for the next vs_bn_bwd_finalize on the same stream, which launches ONE grid holding both
+// (bn_pool.hip) -- the two ~5 us kernels are neighbours on the stream and independent of each other.  Whatever would
+// read the slabs' workspace or dw earlier flushes it: a second reduce, a weight gradient handed the same workspace,
+// vs_wgrad_reduce_flush() (the trunk calls it at the end of a backward segment), switching the mode off.
+namespace {
+struct PendingState {
+  int mode = 0;  // 0 off, 1 defer, 2 suspended (no stash, no flush: launches on a side lane)
+  bool have = false;
+  VsPendingReduce r{};
+};
+thread_local PendingState g_pending;
+
+static void pending_launch(const VsPendingReduce& r) {
+  const long long grid = (r.n / 4 + 15) / 16;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, r.st, r.slabs, r.dw, r.n, r.S);
+}
+}  // namespace
+
+static void pending_flush() {
+  if (g_pending.have) {
+    g_pending.have = false;
+    pending_launch(g_pending.r);
   }
-  part[sl][col] = acc;
-  __syncthreads();
-  if (sl == 0 && i < n4) {
-    float4 t = part[0][col];
-    for (int k = 1; k < 16; ++k) {
-      const float4 v = part[k][col];
-      t.x += v.x;
-      t.y += v.y;
-      t.z += v.z;
-      t.w += v.w;
-    }
-    *(float4*)(dw + i * 4) = t;
-  }
+}
+
+// true: the reduce was stashed (the caller must not launch it)
+static bool pending_stash(const float* slabs, float* dw, long long n, int S, hipStream_t st) {
+  if (g_pending.mode != 1) return false;
+  pending_flush();
+  g_pending.r = VsPendingReduce{slabs, dw, n, S, st};
+  g_pending.have = true;
+  return true;
+}
+
+bool vs_pending_reduce_take(hipStream_t st, VsPendingReduce* out) {
+  if (!g_pending.have || g_pending.r.st != st) return false;
+  *out = g_pending.r;
+  g_pending.have = false;
+  return true;
+}
+
+extern "C" int vs_wgrad_reduce_defer(int mode) {
+  VS_CHECK_ARG(mode >= 0 && mode <= 2, "mode 0 (off), 1 (defer), 2 (suspend)");
+  if (mode == 0) pending_flush();
+  g_pending.mode = mode;
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+extern "C" int vs_wgrad_reduce_flush(void) {
+  pending_flush();
+  VS_CHECK_LAUNCH();
+  return VS_OK;
 }
 
 // The same reduce for MANY layers in one launch (the slabs of every weight gradient of a backward segment are
@@ -763,6 +779,7 @@ static int wgrad_impl(const void* dy, const void* x, float* dw, const vs_conv_de
     vs_set_error("vs_conv_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
     return VS_ERR_WORKSPACE;
   }
+  if (g_pending.have && ((const void*)g_pending.r.slabs == workspace || g_pending.r.dw == dw)) pending_flush();
   WgradP p;
   p.dy = (const uint16_t*)dy;
   p.x = (const uint16_t*)x;
@@ -822,7 +839,8 @@ static int wgrad_impl(const void* dy, const void* x, float* dw, const vs_conv_de
   if (c.S > 1 && reduce_now) {
     const long long n = (long long)d->Cout * p.Kp;
     const long long grid = (n / 4 + 15) / 16;
-    if (!pair_defer_reduce((const float*)workspace, dw, n, c.S)) {
+    if (!pair_defer_reduce((const float*)workspace, dw, n, c.S) &&
+        !pending_stash((const float*)workspace, dw, n, c.S, st)) {
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, st,
                          (const float*)workspace, dw, n, c.S);
       VS_CHECK_LAUNCH();

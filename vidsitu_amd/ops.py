@@ -379,6 +379,20 @@ def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=N
 _ws_cache = {}
 
 
+# The slab reduce behind a weight gradient and the next unit's BN-backward finalize as ONE launch
+# (vs_wgrad_reduce_defer): VS_REDUCE_MERGE=0 switches it off (A/B; the results are bitwise the same).
+import os as _os_rm
+REDUCE_MERGE = _os_rm.environ.get("VS_REDUCE_MERGE", "1") != "0"
+
+
+def wgrad_reduce_defer(mode):
+    _lib.call("vs_wgrad_reduce_defer", int(mode))
+
+
+def wgrad_reduce_flush():
+    _lib.call("vs_wgrad_reduce_flush")
+
+
 def _workspace(nbytes, device):
     key = (device.index, torch.cuda.current_stream().cuda_stream)
     ws = _ws_cache.get(key)

@@ -162,6 +162,7 @@ class _WgradLanes:
     # gradient only goes to the lane when its convolution is at least this large (GFLOP of the unit's GEMM);
     # smaller ones run inline in front of the dgrad.  VS_WGRAD_LANE_MIN_GFLOP: sweep knob.
     min_gflop = float(os.environ.get("VS_WGRAD_LANE_MIN_GFLOP", "0"))
+    defer_active = False  # inside VideoTrunk._backward_segment with ops.REDUCE_MERGE (see there)
 
     @classmethod
     def run(cls, fn, *keep, gflop=None):
@@ -184,6 +185,9 @@ class _WgradLanes:
             cls._drain(lane, 0)
         lane[0] = main
         lane[1].wait_stream(main)
+        deferring = _WgradLanes.defer_active
+        if deferring:
+            ops.wgrad_reduce_defer(2)  # the lane's completion event must cover the slab reduce: launched as usual
         with torch.cuda.stream(lane[1]):
             tail = fn()
             ev = torch.cuda.Event()
@@ -191,6 +195,8 @@ class _WgradLanes:
             if callable(tail):
                 tail()
                 lane[3] = True  # work behind the last event: a full join waits for the stream, not the event
+        if deferring:
+            ops.wgrad_reduce_defer(1)
         lane[2].append((ev, keep))
 
     @staticmethod
@@ -811,6 +817,8 @@ class _Fork:
         return torch.cuda.stream(self.side)
 
     def join(self, keep=None):
+        if _WgradLanes.defer_active:
+            ops.wgrad_reduce_flush()  # a slab reduce still waiting on the side stream must be IN that stream before the join
         _WgradLanes.join_all()
         if self.side is None or not self.active:
             return
@@ -1148,10 +1156,20 @@ class VideoTrunk(nn.Module):
             if self._wgrad_batch is None:
                 self._wgrad_batch = ops.WgradBatch()
             _Unit.wgrad_batch = self._wgrad_batch
+        # Slab reduces of weight gradients issued on this thread's streams wait for the next unit's BN-backward finalize
+        # and share its launch (ops.REDUCE_MERGE, vs_wgrad_reduce_defer): ~70 launches fewer on the step's chain.
+        # Whatever is still pending at the end of the segment is launched there (the caller may all-reduce next).
+        merge = ops.REDUCE_MERGE and st["d"][0].is_cuda and not self.batch_wgrads
+        if merge:
+            ops.wgrad_reduce_defer(1)
+            _WgradLanes.defer_active = True
         try:
             self._backward_segment_body(st, seg)
         finally:
             _Unit.wgrad_batch = None
+            if merge:
+                _WgradLanes.defer_active = False
+                ops.wgrad_reduce_defer(0)  # flushes
         self._flush_wgrads(last=seg == self.BWD_SEGMENTS[-1])
 
     def _backward_segment_body(self, st, seg):
