@@ -429,6 +429,11 @@ def main():
     # VS_BENCH_FORCE_DIST=1: initialise RCCL even for one rank (exercises the launcher and the distributed
     # step on a single-GPU box)
     force_dist = os.environ.get("VS_BENCH_FORCE_DIST") == "1"
+    # TEST ONLY (tests/test_gpu_main_dist.py): every rank on cuda:0 and a gloo group, so that the N > 1 code path of
+    # this file -- launcher, barriers, bucketed overlapped all-reduce, max-over-ranks timing, rank 0's instrumented pass
+    # while the others wait -- runs on a one-GPU box.  The numbers of such a run mean nothing (the ranks share the chip).
+    share_gpu = os.environ.get("VS_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("VS_BENCH_DIST_BACKEND", "nccl")
     try:
         world, spawn = dist_launch.world_from_env(args.gpus)
     except ValueError as e:  # WORLD_SIZE from a launcher disagrees with --gpus: never a silent N' != N line
@@ -438,7 +443,8 @@ def main():
         # touched the GPU (importing torch does not) and never will: N fresh children, one per GPU, rank
         # environment + a free rendezvous port; rank 0's JSON line passes through; any failing rank fails
         # the job (the reference: `launch_job`, utils/trn_dist_utils.py:32-39).
-        sys.exit(dist_launch.launch_ranks(world, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+        sys.exit(dist_launch.launch_ranks(world, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                          check_devices=not share_gpu))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     global _JSON_FD
@@ -452,11 +458,15 @@ def main():
         if "MASTER_PORT" not in os.environ:
             sys.exit("bench.py: WORLD_SIZE is set but MASTER_PORT is not (launch through torch.distributed.run "
                      "or plain `python bench.py --gpus N`)")
+        if share_gpu:
+            local_rank = 0
         if torch.cuda.device_count() <= local_rank:
             sys.exit(f"bench.py: rank {rank} wants cuda:{local_rank} but {torch.cuda.device_count()} GPU(s) are visible")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
@@ -681,6 +691,7 @@ def main():
             else "clips/s (10s@32x224x224) SlowFast-R50 feature extractor fwd",
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world,
             "rccl_ranks": dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else None,
+            **({"dist_backend": backend + " (test only: ranks share one GPU)"} if (share_gpu or backend != "nccl") else {}),
             "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",

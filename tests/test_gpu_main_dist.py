@@ -85,3 +85,22 @@ def test_bench_gpus_2_on_a_one_gpu_box_fails_loudly(dev):
         pytest.skip("needs a box with fewer than 2 GPUs")
     rc, out, err = _run(["bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1"])
     assert rc != 0 and out.strip() == "" and "not launching" in err
+
+
+def test_bench_two_ranks_sharing_the_gpu_runs_the_whole_n_gt_1_path(dev):
+    """`python bench.py --gpus 2` end to end on a one-GPU box: the launcher starts two ranks, both on cuda:0 with a gloo
+    group (VS_BENCH_SHARE_GPU / VS_BENCH_DIST_BACKEND are test-only switches: RCCL refuses two ranks on one device).
+    Exercises what the driver's scaling run will execute on 2 / 4 / 8 GPUs: parameter broadcast, the five segment graphs
+    with a bf16 bucket all-reduce behind each, barriers on both sides of the timed region, max over ranks, rank 0's
+    instrumented pass while rank 1 waits, ONE JSON line.  The throughput of two ranks sharing a chip means nothing."""
+    rc, out, err = _run(["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"],
+                        {"VS_BENCH_SHARE_GPU": "1", "VS_BENCH_DIST_BACKEND": "gloo"}, timeout=1500)
+    assert rc == 0, out[-2000:] + err
+    lines = out.strip().splitlines()
+    assert len(lines) == 1, out
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and "gloo" in line["dist_backend"]
+    assert line["value"] > 0 and abs(line["value"] - 16 / (line["ms_per_step"] * 1e-3)) < 0.02 * line["value"]
+    ga = line["config"]["grad_allreduce"]
+    assert "4 bucket" in ga and "bf16" in ga and "overlapped" in ga, ga
+    assert line["cpu_baseline"] is None and line["roofline"] is not None

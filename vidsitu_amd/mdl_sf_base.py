@@ -118,6 +118,12 @@ def hip_cross_entropy(logits, labels):
     return _XentFn.apply(logits.float().contiguous(), labels)
 
 
+def _first_annotation(t):
+    """[B, E, n_ann, L] -> [B * E, L] of annotation 0 (the reference indexes `[:, :, [0], :]` and reshapes)."""
+    b, e, _, length = t.shape
+    return t[:, :, 0, :].reshape(b * e, length)
+
+
 def _num_events(inp):
     for key in ("frms_ev_raw_u8", "frms_ev_fast_u8", "frms_ev_fast_tensor"):
         if key in inp:
@@ -125,106 +131,101 @@ def _num_events(inp):
     raise KeyError("no frame tensor in the batch")
 
 
+_TRUNK_BY_NAME = {"SlowFast": SlowFast_FeatModel, "ResNet": ResNet_FeatModel}
+_PATHWAYS = {"multi": 2, "single": 1}
+
+
 class SFBase(nn.Module):
+    """Verb prediction from frames (`mdl_sf_base.py:116-216`): trunk -> trimmed head -> two-layer projection.
+    Surface the reference and its checkpoints address: `sf_mdl`, `head`, `proj_head`, `forward_encoder`,
+    `forward_decoder`, `get_feats`, and the `build_*` hooks its subclasses extend."""
+
     def __init__(self, cfg, comm):
         super().__init__()
-        self.full_cfg = cfg
-        self.sf_cfg = cfg.sf_mdl
-        self.cfg = cfg.mdl
-        self.comm = comm
+        self.full_cfg, self.sf_cfg, self.cfg, self.comm = cfg, cfg.sf_mdl, cfg.mdl, comm
         self.build_model()
 
     def build_model(self):
-        self.build_sf_model(self.sf_cfg)
-        self.build_head(self.sf_cfg)
-        self.build_projection_head(self.sf_cfg)
+        for hook in (self.build_sf_model, self.build_head, self.build_projection_head):
+            hook(self.sf_cfg)
 
     def build_sf_model(self, cfg):
-        mdl_name = cfg.MODEL.MODEL_NAME
-        if mdl_name == "SlowFast":
-            mdl = SlowFast_FeatModel(cfg)
-        elif mdl_name == "ResNet":
-            mdl = ResNet_FeatModel(cfg)
-        else:
-            raise NotImplementedError
-        self.sf_mdl = mdl
+        trunk_cls = _TRUNK_BY_NAME.get(cfg.MODEL.MODEL_NAME)
+        if trunk_cls is None:
+            raise NotImplementedError(f"MODEL.MODEL_NAME={cfg.MODEL.MODEL_NAME}")
+        self.sf_mdl = trunk_cls(cfg)
 
     def build_head(self, cfg):
-        dims = self.sf_mdl.dim_out
-        if self.comm.path_type == "multi":
-            assert dims == [cfg.RESNET.WIDTH_PER_GROUP * 32,
-                            cfg.RESNET.WIDTH_PER_GROUP * 32 // cfg.SLOWFAST.BETA_INV]
-            self.head = ResNetBasicHead_Trimmed(dim_in=dims, pool_size=[None, None])
-        elif self.comm.path_type == "single":
-            self.head = ResNetBasicHead_Trimmed(dim_in=dims, pool_size=[None])
+        widths = list(self.sf_mdl.dim_out)
+        n_path = _PATHWAYS.get(self.comm.path_type)
+        if n_path is None:
+            return  # (the reference builds no head for an unknown path type either)
+        if n_path == 2:  # slow: 32 x width, fast: that over beta_inv (2048 + 256 for R50)
+            full = 32 * cfg.RESNET.WIDTH_PER_GROUP
+            assert widths == [full, full // cfg.SLOWFAST.BETA_INV], widths
+        self.head = ResNetBasicHead_Trimmed(dim_in=widths, pool_size=[None] * n_path)
 
     def build_projection_head(self, cfg, out_dim=None):
-        if out_dim is None:
-            out_dim = len(self.comm.vb_id_vocab)
-        din = sum(self.head.dim_in)
-        self.proj_head = HipMLP(nn.Linear(din, din // 2), nn.ReLU(), nn.Linear(din // 2, out_dim))
+        feat = sum(self.head.dim_in)
+        n_out = len(self.comm.vb_id_vocab) if out_dim is None else out_dim
+        self.proj_head = HipMLP(nn.Linear(feat, feat // 2), nn.ReLU(), nn.Linear(feat // 2, n_out))
 
     def get_feats(self, inp):
+        """The trunk's input list, events folded into the batch axis: [slow, fast], [fast], or one uint8 tensor."""
         if "frms_ev_raw_u8" in inp:
             # decoded frames at their source size [B, E, T, H0, W0, 3]: the loader's
             # `img.resize((224, 224))` (dat_loader.py:188, PIL bicubic) runs on the GPU, bit-exact
-            crop = int(self.sf_cfg.DATA.TRAIN_CROP_SIZE)
-            return [combine_first_ax(ops.resize_bicubic_u8(inp["frms_ev_raw_u8"], crop, crop))]
+            side = int(self.sf_cfg.DATA.TRAIN_CROP_SIZE)
+            return [combine_first_ax(ops.resize_bicubic_u8(inp["frms_ev_raw_u8"], side, side))]
         if "frms_ev_fast_u8" in inp:
             # optional fast path beside the reference contract: the loader's uint8 RGB frames
             # [B, E, T, H, W, 3]; normalisation and the slow-pathway gather happen on the GPU
             return [combine_first_ax(inp["frms_ev_fast_u8"])]
-        if self.comm.path_type == "multi":
-            return [combine_first_ax(inp["frms_ev_slow_tensor"]),
-                    combine_first_ax(inp["frms_ev_fast_tensor"])]
-        elif self.comm.path_type == "single":
-            return [combine_first_ax(inp["frms_ev_fast_tensor"])]
-        raise NotImplementedError
+        keys = {"multi": ("frms_ev_slow_tensor", "frms_ev_fast_tensor"), "single": ("frms_ev_fast_tensor",)}
+        if self.comm.path_type not in keys:
+            raise NotImplementedError(f"path_type={self.comm.path_type}")
+        return [combine_first_ax(inp[k]) for k in keys[self.comm.path_type]]
 
     def forward_encoder(self, inp):
-        feats_used = self.get_feats(inp)
-        feat_out = self.sf_mdl.forward_features(feats_used)
-        assert len(feat_out) == self.sf_mdl.num_pathways
-        return feat_out
+        maps = self.sf_mdl.forward_features(self.get_feats(inp))
+        assert len(maps) == self.sf_mdl.num_pathways
+        return maps
 
     def forward_decoder(self, enc_out, inp):
-        head_out = self.head(enc_out)
-        head_out = head_out.permute((0, 2, 3, 4, 1))  # (B, C, T, H, W) -> (B, T, H, W, C)
-        proj_out = self.proj_head(head_out)
-        B = len(inp["vseg_idx"])
-        n_ev = _num_events(inp)
-        out = proj_out.view(B, n_ev, -1)
-        assert out.size(-1) == len(self.comm.vb_id_vocab)
-        return out
+        pooled = self.head(enc_out).permute((0, 2, 3, 4, 1))  # [N, C, 1, 1, 1] -> channels last
+        logits = self.proj_head(pooled).view(len(inp["vseg_idx"]), _num_events(inp), -1)
+        assert logits.size(-1) == len(self.comm.vb_id_vocab)
+        return logits
 
     def forward(self, inp: Dict):
-        feat_out = self.forward_encoder(inp)
-        mdl_out = self.forward_decoder(feat_out, inp)
-        return {"mdl_out": mdl_out}
+        return {"mdl_out": self.forward_decoder(self.forward_encoder(inp), inp)}
 
 
-class LossB(nn.Module):
+class _LossBase(nn.Module):
+    """`loss_fn = Cls(cfg, comm)`, `.loss_keys`, `loss_fn(out, inp) -> {"loss": 0-dim tensor}` (mdl_sf_base.py:219-243)."""
+
+    loss_keys = ["loss"]
+
     def __init__(self, cfg, comm):
         super().__init__()
-        self.cfg = cfg
-        self.comm = comm
-        self.loss_keys = ["loss"]
+        self.cfg, self.comm = cfg, comm
+        self.loss_keys = list(type(self).loss_keys)
+
+
+class LossB(_LossBase):
+    """Mean cross entropy of the per-event verb logits (`:219-231`)."""
 
     def forward(self, mdl_out, inp):
-        labels_c1 = combine_first_ax(inp["label_tensor"])
-        mdl_preds_c1 = combine_first_ax(mdl_out["mdl_out"])
-        return {"loss": hip_cross_entropy(mdl_preds_c1, labels_c1)}
+        flat = combine_first_ax
+        return {"loss": hip_cross_entropy(flat(mdl_out["mdl_out"]), flat(inp["label_tensor"]))}
 
 
-class LossLambda(nn.Module):
-    def __init__(self, cfg, comm):
-        super().__init__()
-        self.cfg = cfg
-        self.comm = comm
-        self.loss_keys = ["loss"]
+class LossLambda(_LossBase):
+    """The model computed its own loss (`:234-243`)."""
 
     def forward(self, mdl_out, inp):
-        assert "loss" in mdl_out
+        if "loss" not in mdl_out:
+            raise AssertionError("the model's output carries no 'loss'")
         return {"loss": mdl_out["loss"]}
 
 
@@ -335,18 +336,14 @@ class Simple_GPT2(nn.Module):
         return out_sents.view(B, num_ev, num_seq_eg, -1)
 
     def forward(self, inp):
-        src_toks1 = inp["seq_out_by_ev"][:, :, [0], :]
-        src_attn1 = inp["seq_out_lens_by_ev"][:, :, [0], :]
-        B, num_ev, num_seq_eg, seq_len = src_toks1.shape
-        assert num_seq_eg == 1
-        src_toks = src_toks1.reshape(B * num_ev, num_seq_eg * seq_len)
-        src_attn_mask = src_attn1.reshape(B * num_ev, num_seq_eg * seq_len).ne(0)
+        toks = _first_annotation(inp["seq_out_by_ev"])
+        keep = _first_annotation(inp["seq_out_lens_by_ev"]).ne(0)
         if self.training and torch.is_grad_enabled():
-            tick = torch.zeros(1, device=src_toks.device, requires_grad=True)
-            logits = _GPT2TrainFn.apply(self.gpt2_mdl, src_toks, src_attn_mask, tick)
+            tick = torch.zeros(1, device=toks.device, requires_grad=True)
+            logits = _GPT2TrainFn.apply(self.gpt2_mdl, toks, keep, tick)
         else:
-            logits = self.gpt2_mdl.forward_logits(src_toks, src_attn_mask)
-        return {"loss": gpt2_lm_loss(logits, src_toks, self.pad_index), "logits": logits}
+            logits = self.gpt2_mdl.forward_logits(toks, keep)
+        return {"loss": gpt2_lm_loss(logits, toks, self.pad_index), "logits": logits}
 
 
 class Simple_GPT2_New(Simple_GPT2):
@@ -364,61 +361,46 @@ class Simple_TxDec(nn.Module):
 
     def __init__(self, cfg, comm):
         super().__init__()
-        self.full_cfg = cfg
-        self.cfg = cfg.mdl
-        self.sf_cfg = cfg.sf_mdl
-        self.comm = comm
-        self.use_encoder = False
+        self.full_cfg, self.cfg, self.sf_cfg, self.comm = cfg, cfg.mdl, cfg.sf_mdl, comm
+        self.use_encoder = False  # read by seq_gen.EnsembleModel
         self.build_model()
 
     def build_model(self):
+        tok = self.comm.gpt2_hf_tok
         self.decoder = TxDecoder(self.full_cfg, self.comm)
-        self.pad_index = self.comm.gpt2_hf_tok.pad_token_id
-        self.bos_index = self.comm.gpt2_hf_tok.eos_token_id
+        self.pad_index, self.bos_index = tok.pad_token_id, tok.eos_token_id
         self.max_decoder_positions = lambda: 1024
 
     def forward_encoder(self, inp):
-        return None
+        return None  # text only: subclasses supply the video memory
 
     def prepare_prev_toks_inp(self, inp):
-        dst_toks1 = inp["seq_out_by_ev"][:, :, [0], :]
-        dst_attn1 = inp["seq_out_lens_by_ev"][:, :, [0], :]
-        vb_toks1 = inp["vb_out_by_ev"][:, :, [0], :]
-        B, num_ev, num_seq_eg, seq_len = dst_toks1.shape
-        assert num_seq_eg == 1
-        dst_toks = dst_toks1.reshape(B * num_ev, num_seq_eg * seq_len)
-        dst_attn_mask = dst_attn1.reshape(B * num_ev, num_seq_eg * seq_len)
-        dst_lens = dst_attn_mask.sum(dim=-1)
-        vb_toks = vb_toks1.reshape(B * num_ev, num_seq_eg * vb_toks1.size(-1))
-        return {"dst_toks": dst_toks, "dst_lens": dst_lens, "vb_only_tokens": vb_toks}
+        """Target tokens / lengths / verb tokens of every event's FIRST annotation, events folded into the batch axis."""
+        toks = _first_annotation(inp["seq_out_by_ev"])
+        lens = _first_annotation(inp["seq_out_lens_by_ev"]).sum(dim=-1)
+        return {"dst_toks": toks, "dst_lens": lens, "vb_only_tokens": _first_annotation(inp["vb_out_by_ev"])}
 
     def forward_decoder(self, prev_tokens, encoder_out, incremental_state=None, temperature=None):
-        if isinstance(encoder_out, list) and len(encoder_out) == 0:
-            encoder_out = None
-        return self.decoder(prev_tokens, encoder_out=encoder_out, incremental_state=incremental_state)
+        memory = None if (isinstance(encoder_out, list) and not encoder_out) else encoder_out
+        return self.decoder(prev_tokens, encoder_out=memory, incremental_state=incremental_state)
 
     def forward(self, inp):
-        inp_prep = self.prepare_prev_toks_inp(inp)
-        encoder_out = self.forward_encoder(inp)
-        prev_tokens = inp_prep["dst_toks"]
-        logits = self.forward_decoder(prev_tokens=prev_tokens, encoder_out=encoder_out)[0]
-        loss = gpt2_lm_loss(logits, prev_tokens, self.pad_index)
-        return {"loss": loss, "logits": logits}
+        toks = self.prepare_prev_toks_inp(inp)["dst_toks"]
+        logits = self.forward_decoder(prev_tokens=toks, encoder_out=self.forward_encoder(inp))[0]
+        return {"loss": gpt2_lm_loss(logits, toks, self.pad_index), "logits": logits}
 
     def forward_gen(self, inp, seq_gen):
-        inp_prep = self.prepare_prev_toks_inp(inp)
-        inp["src_tokens"] = inp_prep["dst_toks"][..., :1]
-        inp["src_lengths"] = inp_prep["dst_lens"]
-        inp_ids = inp_prep["dst_toks"][..., :1]
-        out_sents = seq_gen._generate(inp, prefix_tokens=inp_ids)
-        B, num_ev, num_seq_eg, seq_len = inp["seq_out_by_ev"][:, :, [0], :].shape
-        max_len = max(len(o[0]["tokens"]) for o in out_sents)
-        B1 = inp_ids.size(0)
-        out_sents_tensor = inp_ids.new_full((B1, max_len), self.pad_index)
-        for ix in range(B1):
-            xtoks = out_sents[ix][0]["tokens"]
-            out_sents_tensor[ix, : len(xtoks)] = xtoks
-        return out_sents_tensor.view(B, num_ev, num_seq_eg, -1)
+        """Beam search from each event's first token; hypotheses padded into [B, E, 1, longest]."""
+        prep = self.prepare_prev_toks_inp(inp)
+        prompt = prep["dst_toks"][..., :1]
+        inp["src_tokens"], inp["src_lengths"] = prompt, prep["dst_lens"]
+        hyps = seq_gen._generate(inp, prefix_tokens=prompt)
+        best = [h[0]["tokens"] for h in hyps]
+        out = prompt.new_full((prompt.size(0), max(len(t) for t in best)), self.pad_index)
+        for row, t in enumerate(best):
+            out[row, : len(t)] = t
+        b, n_ev = inp["seq_out_by_ev"].shape[:2]
+        return out.view(b, n_ev, 1, -1)
 
 
 class Reorderer:
