@@ -80,6 +80,9 @@ def main_fn(rank, cfg, steps, graph=True):
                 print(f"[{cfg.uid}] resumed {rpath} at iteration {num_it}")
         elif rank == 0:
             print(f"[{cfg.uid}] no existing model in {rpath}, starting from scratch")
+    elif cfg.mdl.load_sf_pretrained and cfg.task_type == "vb":  # Kinetics init of the trunk (utils/trn_utils.py:358-375)
+        checkpoint.load_sf_pretrained(cfg, mdl, log=(lambda m: print(f"[{cfg.uid}] {m}")) if rank == 0 else (lambda m: None))
+        arena.refresh()
     bs = max(cfg.train.bs // world, 1)
     n_ev = cfg.ds.vsitu.num_ev
     nb = 1 if cfg.overfit_batch else 2

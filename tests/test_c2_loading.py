@@ -118,3 +118,54 @@ def test_shape_mismatch_is_reported_not_loaded(tmp_path):
         pickle.dump({"weights": {}}, f)
     with pytest.raises(ValueError):
         c2.load_caffe2_checkpoint(str(tmp_path / "nope.pkl"), ours)
+
+
+def test_load_sf_pretrained_follows_the_config_keys(tmp_path):
+    """`checkpoint.load_sf_pretrained` = the `mdl.load_sf_pretrained` branch of the reference's Learner
+    (`utils/trn_utils.py:358-375`): path and type from `sf_mdl.TRAIN.*`, a Caffe2 pickle lands on `mdl.sf_mdl`,
+    the upstream head is tolerated, a stray tensor or a missing one raises, a missing file raises."""
+    from vidsitu_amd import checkpoint, synth_data
+    from vidsitu_amd.extended_config import get_cfg
+    from vidsitu_amd.mdl_selector import get_mdl_loss_eval
+
+    cfg = get_cfg({"mdl.sf_mdl_name": "slow_fast_nl_r50_8x8", "synth.num_verbs": 11})
+    assert cfg.sf_mdl.TRAIN.CHECKPOINT_TYPE == "caffe2" and cfg.sf_mdl.TRAIN.CHECKPOINT_FILE_PATH.endswith(".pkl")
+    comm = synth_data.make_comm(cfg)
+    mdl = get_mdl_loss_eval(cfg)["mdl"](cfg=cfg, comm=comm)
+    with pytest.raises(FileNotFoundError):
+        checkpoint.load_sf_pretrained(cfg, mdl, log=lambda m: None)
+    ref = slowfast_ref.VideoTrunk(cfg.sf_mdl)
+    path = tmp_path / "SLOWFAST_CU_8x8_R50.pkl"
+    want = _fake_c2_file(ref, path, 50)
+    cfg.sf_mdl.TRAIN.CHECKPOINT_FILE_PATH = str(path)
+    msgs = []
+    checkpoint.load_sf_pretrained(cfg, mdl, log=msgs.append)
+    assert msgs and "caffe2" in msgs[0]
+    sd = mdl.sf_mdl.state_dict()
+    for k, v in want.items():
+        assert torch.equal(sd[k], v), k
+    # a blob the trunk has no place for
+    with open(path, "rb") as f:
+        blobs = pickle.load(f)["blobs"]
+    blobs["res9_0_branch2a_w"] = np.zeros((4, 4, 1, 1, 1), np.float32)
+    bad = tmp_path / "stray.pkl"
+    with open(bad, "wb") as f:
+        pickle.dump({"blobs": blobs}, f, protocol=2)
+    cfg.sf_mdl.TRAIN.CHECKPOINT_FILE_PATH = str(bad)
+    with pytest.raises(ValueError, match="no place"):
+        checkpoint.load_sf_pretrained(cfg, mdl, log=lambda m: None)
+    # a trunk tensor the file lacks
+    del blobs["res9_0_branch2a_w"], blobs["res2_0_branch2a_w"]
+    with open(bad, "wb") as f:
+        pickle.dump({"blobs": blobs}, f, protocol=2)
+    with pytest.raises(ValueError, match="does not provide"):
+        checkpoint.load_sf_pretrained(cfg, mdl, log=lambda m: None)
+    # the slowfast torch format
+    tpath = tmp_path / "trunk.pyth"
+    torch.save({"model_state": {**{k: v for k, v in ref.state_dict().items()},
+                                "head.projection.weight": torch.zeros(400, 2304)}}, tpath)
+    cfg.sf_mdl.TRAIN.CHECKPOINT_FILE_PATH, cfg.sf_mdl.TRAIN.CHECKPOINT_TYPE = str(tpath), "pytorch"
+    checkpoint.load_sf_pretrained(cfg, mdl, log=lambda m: None)
+    for k, v in ref.state_dict().items():
+        if "num_batches_tracked" not in k:
+            assert torch.equal(mdl.sf_mdl.state_dict()[k], v), k

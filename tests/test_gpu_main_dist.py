@@ -104,3 +104,35 @@ def test_bench_two_ranks_sharing_the_gpu_runs_the_whole_n_gt_1_path(dev):
     ga = line["config"]["grad_allreduce"]
     assert "4 bucket" in ga and "bf16" in ga and "overlapped" in ga, ga
     assert line["cpu_baseline"] is None and line["roofline"] is not None
+
+
+def test_feat_extractor_cli_from_a_trained_checkpoint_and_from_a_caffe2_pickle(dev, tmp_path):
+    """`python -m vidsitu_amd.feat_extractor <weights> <name>` (reference `feat_extractor.py:119-176`): features of the
+    synthetic videos from (a) the checkpoint `main_dist.py` just wrote and (b) a model-zoo style Caffe2 pickle of the
+    trunk (`--is_cu=True`, names converted on load); [E, D] float32 files, readable by `read_frm_feats`."""
+    import numpy as np
+
+    common = ["--mdl.sf_mdl_name=slow_fast_mini", "--sf_mdl.DATA.TRAIN_CROP_SIZE=64", "--synth.num_verbs=31",
+              "--ds.vsitu.num_ev=2", f"--ds.vsitu.vsitu_frm_feats={tmp_path}/feats", "--train.bsv=2"]
+    rc, out, err = _run(["main_dist.py", "t_fx"] + MINI + [f"--misc.tmp_path={tmp_path}", "--steps=2"])
+    assert rc == 0, out[-2000:] + err
+    ck = tmp_path / "models" / "t_fx.pth"
+    rc, out, err = _run(["-m", "vidsitu_amd.feat_extractor", str(ck), "trained_mini", "--n_videos=3"] + common)
+    assert rc == 0 and "wrote 6 feature files" in out, out[-2000:] + err
+    files = sorted((tmp_path / "feats" / "trained_mini").glob("*_feats.npy"))
+    assert len(files) == 6
+    a = np.load(files[0])
+    assert a.dtype == np.float32 and a.ndim == 2 and a.shape[0] == 2 and np.isfinite(a).all() and np.abs(a).max() > 0
+    # (b) a Caffe2-style pickle written with the model zoo's blob names (tests/test_c2_loading.py's hand-written inverse)
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_c2_loading import _fake_c2_file
+    from oracle import slowfast_ref
+    from vidsitu_amd.extended_config import get_cfg
+
+    cfg = get_cfg({"mdl.sf_mdl_name": "slow_fast_mini"})
+    pk = tmp_path / "zoo.pkl"
+    _fake_c2_file(slowfast_ref.VideoTrunk(cfg.sf_mdl), pk, "mini")
+    rc, out, err = _run(["-m", "vidsitu_amd.feat_extractor", str(pk), "zoo_mini", "--is_cu=True", "--n_videos=2",
+                         "--splits=valid"] + common)
+    assert rc == 0 and "Using Caffe2 checkpoint" in out and "wrote 2 feature files" in out, out[-2000:] + err

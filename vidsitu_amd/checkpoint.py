@@ -95,3 +95,38 @@ def load_model_dict(path, mdl, optimizer=None, load_opt=False, strict=True, aren
             raise ValueError("load_opt needs an optimizer and a checkpoint that holds its state")
         optimizer.load_state_dict(ckpt["optimizer_state_dict"])
     return {k: ckpt.get(k) for k in ("num_it", "num_epoch", "best_met")}
+
+
+def load_sf_pretrained(cfg, mdl, log=print):
+    """`Learner.__init__`'s `elif self.cfg.mdl["load_sf_pretrained"]` branch for `task_type == "vb"`
+    (`utils/trn_utils.py:358-375`; the feature extractor does the same at `feat_extractor.py:154-161`): the trunk
+    `mdl.sf_mdl` starts from the Kinetics weights named by `cfg.sf_mdl.TRAIN.CHECKPOINT_FILE_PATH` -- a model-zoo Caffe2
+    pickle (`CHECKPOINT_TYPE: caffe2`, names converted by `c2_model_loading`) or a slowfast-format torch file
+    (`{"model_state": ...}`).  The upstream classification head (`head.projection.*`, which `forward_features` never
+    runs and `VideoTrunk` does not build) is the only thing a file may hold beyond the trunk: anything else unknown
+    raises, as upstream's assert does."""
+    from .c2_model_loading import load_caffe2_checkpoint
+
+    tr = cfg.sf_mdl.TRAIN
+    path = tr.CHECKPOINT_FILE_PATH
+    if not path or not os.path.exists(path):
+        raise FileNotFoundError(f"mdl.load_sf_pretrained: sf_mdl.TRAIN.CHECKPOINT_FILE_PATH = {path!r} does not exist")
+    trunk = mdl.sf_mdl
+    if tr.CHECKPOINT_TYPE == "caffe2":
+        report = load_caffe2_checkpoint(path, trunk)
+        stray = [k for k, ck in report["not_in_model"] if not ck.startswith("head.projection")]
+        missing = report["not_loaded"]
+    else:
+        with open(path, "rb") as f:
+            ckpt = torch.load(f, map_location="cpu", weights_only=True)
+        sd = _strip_module(ckpt.get("model_state", ckpt.get("model_state_dict", ckpt)))
+        sd = {k: v for k, v in sd.items() if not k.startswith("head.projection")}
+        res = trunk.load_state_dict(sd, strict=False)
+        stray, missing = list(res.unexpected_keys), [k for k in res.missing_keys if "num_batches_tracked" not in k]
+    if stray:
+        raise ValueError(f"{path}: tensors the trunk has no place for: {stray[:8]}{' ...' if len(stray) > 8 else ''}")
+    if missing:
+        raise ValueError(f"{path}: trunk parameters the file does not provide: {missing[:8]}{' ...' if len(missing) > 8 else ''}")
+    if hasattr(trunk, "refresh_weights") and next(trunk.parameters()).is_cuda:
+        trunk.refresh_weights()
+    log(f"loaded pretrained trunk weights from {path} ({tr.CHECKPOINT_TYPE})")

@@ -105,6 +105,9 @@ def sf_defaults():
                       "SINGLE_PATHWAY_ARCH": ["c2d", "i3d", "slow"],
                       "MULTI_PATHWAY_ARCH": ["slowfast"], "FC_INIT_STD": 0.01},
             "DETECTION": {"ENABLE": False},
+            # where `mdl.load_sf_pretrained` finds the Kinetics weights (utils/trn_utils.py:358-375); the model YAMLs
+            # name the model-zoo Caffe2 pickles as the reference's do
+            "TRAIN": {"CHECKPOINT_FILE_PATH": "", "CHECKPOINT_TYPE": "pytorch"},
         }
     )
 

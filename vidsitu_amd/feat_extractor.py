@@ -89,3 +89,54 @@ def read_frm_feats(feats_dir, vseg_name):
     """`VsituDS.get_frm_feats_all` (`dat_loader.py:503-511`): -> {"frm_feats": f32 [E, D]}."""
     arr = np.load(Path(feats_dir) / f"{vseg_name}_feats.npy")
     return {"frm_feats": torch.from_numpy(arr).float()}
+
+
+def main(mdl_resume_path: str, mdl_name_used: str, is_cu: bool = False, splits=("valid", "train"), n_videos=None,
+         **kwargs):
+    """`python -m vidsitu_amd.feat_extractor <weights> <name> [--is_cu=True] [--dotted.key=value ...]`
+    (`feat_extractor.py:119-176`): build the configured model, load a TRAINED checkpoint (the trainer's file format,
+    `module.` prefixes stripped) or -- `is_cu` -- the Kinetics model-zoo Caffe2 pickle into `mdl.sf_mdl`, and write
+    `<vsitu_frm_feats>/<name>/<vseg>_feats.npy` ([E, 2304] / [E, 2048] float32) for every video of every split.
+    The videos are the synthetic stand-in dataset (`SynthFrameDataset`; the 50 GB frame dataset is out of scope), so what this
+    entry point pins is the flow: weights -> eval trunk on the HIP kernels -> head -> files the TxEncoder rows read back."""
+    from . import checkpoint, synth_data
+    from .extended_config import get_cfg
+    from .mdl_selector import get_mdl_loss_eval
+
+    cfg = get_cfg(kwargs)
+    cfg.num_gpus, cfg.do_dist = 1, False
+    comm = synth_data.make_comm(cfg)
+    mdl = get_mdl_loss_eval(cfg)["mdl"](cfg=cfg, comm=comm)
+    if is_cu:
+        print("Using Caffe2 checkpoint")
+        cfg.sf_mdl.TRAIN.CHECKPOINT_FILE_PATH, cfg.sf_mdl.TRAIN.CHECKPOINT_TYPE = mdl_resume_path, "caffe2"
+        checkpoint.load_sf_pretrained(cfg, mdl)
+    else:
+        got = checkpoint.load_model_dict(mdl_resume_path, mdl, None, load_opt=False, strict=True)
+        if got is None:
+            raise FileNotFoundError(mdl_resume_path)
+    mdl = mdl.to(torch.device("cuda")).eval()
+    feat_ext, written = FeatExtract(cfg), []
+    n = int(n_videos) if n_videos is not None else int(cfg.synth.num_videos)
+    for si, split in enumerate(splits):
+        ds = SynthFrameDataset(cfg, comm, n, n_ev=cfg.ds.vsitu.num_ev, seed=cfg.synth.seed + 1000 * si,
+                               names=[f"{split}_v{i:05d}_seg_0-10" for i in range(n)])
+        feat_ext.set_mdl_dl(mdl, SimpleLoader(ds, max(1, int(cfg.train.bsv))), mdl_name=mdl_name_used, split_name=split)
+        written += feat_ext.forward_all()
+    print(f"wrote {len(written)} feature files under {feat_ext.out_tdir}")
+    return written
+
+
+if __name__ == "__main__":
+    import sys
+
+    if len(sys.argv) < 3:
+        sys.exit("usage: python -m vidsitu_amd.feat_extractor <weights> <name> [--is_cu=True] [--dotted.key=value ...]")
+    kw = {}
+    for a in sys.argv[3:]:
+        k, v = a[2:].split("=", 1)
+        kw[k] = v
+    is_cu = str(kw.pop("is_cu", "False")) in ("1", "True", "true")
+    if "splits" in kw:
+        kw["splits"] = tuple(kw["splits"].split(","))
+    main(sys.argv[1], sys.argv[2], is_cu=is_cu, **kw)
