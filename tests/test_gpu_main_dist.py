@@ -136,3 +136,18 @@ def test_feat_extractor_cli_from_a_trained_checkpoint_and_from_a_caffe2_pickle(d
     rc, out, err = _run(["-m", "vidsitu_amd.feat_extractor", str(pk), "zoo_mini", "--is_cu=True", "--n_videos=2",
                          "--splits=valid"] + common)
     assert rc == 0 and "Using Caffe2 checkpoint" in out and "wrote 2 feature files" in out, out[-2000:] + err
+
+
+def test_main_dist_vb_arg_row_trains_and_evaluates(dev, tmp_path):
+    """The SRL row of the same entry point (`--task_type=vb_arg`, features -> TxEncoder -> fairseq-style decoder,
+    `mdl_sf_base.py:793-832`): a few eager TrainStep iterations on the synthetic SRL batch, checkpoint, evaluation by beam
+    search (`EvalB_Gen`)."""
+    rc, out, err = _run(["main_dist.py", "t_srl", "--task_type=vb_arg", "--mdl.mdl_name=sfpret_txe_txd_vbarg",
+                         "--mdl.tx_dec_type=txdec", "--train.bs=2", "--ds.vsitu.num_ev=2", "--train.lr=1e-4",
+                         "--overfit_batch=True", "--gen.beam_size=2", "--gen.max_len_b=8", f"--misc.tmp_path={tmp_path}",
+                         "--steps=4"], timeout=1500)
+    assert rc == 0, out[-3000:] + err
+    assert "(eager" in out and "valid" in out, out
+    first, last = _losses(out)
+    assert last < first, out
+    assert (tmp_path / "models" / "t_srl.pth").exists()
