@@ -581,8 +581,12 @@ def main():
         torch.cuda.synchronize()
         launches_per_step = int(_vslib.load().vs_launch_count() - n0)
         # one stream, no lanes, no (dgrad, wgrad) pair launches: an event pair then brackets exactly one entry point's kernels
+        from vidsitu_amd import ops as _ops
         saved_modes = (_trunk.VideoTrunk.dual_stream, _trunk._WgradLanes.enabled, _trunk._Unit.pair_launch)
         _trunk.VideoTrunk.dual_stream, _trunk._WgradLanes.enabled, _trunk._Unit.pair_launch = False, False, False
+        # ... and a weight gradient's slab reduce stays behind ITS entry point (in the timed region it shares the next
+        # unit's BN-backward finalize launch: ops.REDUCE_MERGE), so the family it is charged to is the one it belongs to
+        saved_merge, _ops.REDUCE_MERGE = _ops.REDUCE_MERGE, False
         t0 = time.perf_counter()
         step()
         torch.cuda.synchronize()
@@ -601,6 +605,7 @@ def main():
         finally:
             probe.remove()
             _trunk.VideoTrunk.dual_stream, _trunk._WgradLanes.enabled, _trunk._Unit.pair_launch = saved_modes
+            _ops.REDUCE_MERGE = saved_merge
         agg = probe.summary()
         pmc = load_pmc_traffic(args.workload)
 
