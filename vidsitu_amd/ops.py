@@ -1032,6 +1032,12 @@ class TxStack:
     def run(self):
         n = len(self.rows)
         if self.table is None:
+            # the software grid barrier needs EVERY block resident at once (a plain launch, no cooperative check): one
+            # block per CU, so the device must have at least GRID CUs and the staging area must fit one CU's LDS
+            cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+            if cus < self.GRID or self.smem > 160 * 1024:
+                raise _lib.VsError(f"TxStack: {self.GRID} resident blocks of {self.smem} B LDS need {self.GRID} CUs "
+                                   f"with 160 KiB each; this device has {cus}")
             self.host = self._slot(n)
             self.host.copy_(torch.tensor(self.rows, dtype=torch.int64))
             self.table = torch.empty((n, 16), dtype=torch.int64, device=self.device)
