@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--grad-dtype", default="auto", choices=["auto", "fp32", "bf16"],
                     help="payload of the gradient all-reduce (auto: bf16 when WORLD_SIZE > 1, fp32 master "
                          "parameters / moments either way)")
+    ap.add_argument("--clips-per-gpu", type=int, default=8,
+                    help="PROBE ONLY: clips per GPU other than the BASELINE config's 8 (multiple of 4); the line is "
+                         "marked config.probe and is not the headline metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -423,7 +426,11 @@ def cpu_baseline(workload, n_vocab, budget_s=60.0):
 
 
 def main():
+    global CLIPS_PER_GPU
     args = parse()
+    if args.clips_per_gpu != 8:
+        assert args.clips_per_gpu % 4 == 0 and args.clips_per_gpu > 0, "--clips-per-gpu: a multiple of 4 (videos x 4 events)"
+        CLIPS_PER_GPU = args.clips_per_gpu
     from vidsitu_amd import dist_launch
 
     # VS_BENCH_FORCE_DIST=1: initialise RCCL even for one rank (exercises the launcher and the distributed
@@ -706,6 +713,8 @@ def main():
                                     "BASELINE configs[1]: SlowFast-R50 feature extractor only, eval, "
                                     "8 clips x 3x32x224x224 per GPU"),
                        "clips_per_gpu": CLIPS_PER_GPU, "hipgraph": used_graph,
+                       **({} if CLIPS_PER_GPU == 8 else
+                          {"probe": f"{CLIPS_PER_GPU} clips/GPU instead of the BASELINE config's 8: not the headline metric"}),
                        **({} if train else {"parity": eval_parity_note()}),
                        "grad_allreduce": (None if ts is None else
                                           (f"{len(ts.segments)} bucket(s), "

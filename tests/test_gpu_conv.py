@@ -600,7 +600,17 @@ HALO_CASES = [
     ("5x5_64_64", 2, 64, 4, 20, 20, 64, (1, 5, 5), (0, 2, 2)),
     ("3x1_64_136", 2, 64, 4, 20, 20, 136, (1, 3, 1), (0, 1, 0)),
     ("fast_t32_3x3", 2, 64, 32, 7, 7, 64, (1, 3, 3), (0, 1, 1)),
+    # 128-column tiles (never chosen at 8 clips per GPU; 16+ clips of slow s5 are): 224 / 128 rows, forward / dgrad
+    ("w128_3x3_224", 2, 64, 8, 28, 20, 512, (1, 3, 3), (0, 1, 1)),
+    ("w128_t3_224", 2, 64, 8, 28, 28, 512, (3, 1, 1), (1, 0, 0)),
+    ("w128_t3_128", 4, 64, 8, 9, 28, 512, (3, 1, 1), (1, 0, 0)),
+    ("w128_3x3_128", 4, 64, 8, 12, 20, 512, (1, 3, 3), (0, 1, 1)),
+    ("w128_dgrad_t3", 16, 128, 8, 9, 28, 128, (3, 1, 1), (1, 0, 0)),
+    ("w128_dgrad_3x3", 16, 128, 8, 12, 20, 128, (1, 3, 3), (0, 1, 1)),
+    ("s5b_3x3_512_n32", 32, 512, 8, 7, 7, 512, (1, 3, 3), (0, 1, 1)),
 ]
+_HALO_W128 = {"w128_3x3_224": (0, 224), "w128_t3_224": (0, 224), "w128_t3_128": (0, 128), "w128_3x3_128": (0, 128),
+              "w128_dgrad_t3": (1, 128), "w128_dgrad_3x3": (1, 128), "s5b_3x3_512_n32": (0, 224)}
 
 
 def _plan(ops, xs, ys, x_ld, y_ld, k, s, p, dgrad, flags=1 << 22):  # VS_CONV_FORCEHALO
@@ -629,6 +639,9 @@ def test_halo_image_kernel_fwd_and_dgrad(case, dev):
     assert _plan(ops, tuple(x.shape), ys, cin, cout, k, s, p, 0)[4] == 2, "forward did not take the halo kernel"
     # (the data gradient reduces over Cout in 64-channel chunks: 72 / 136 output channels stay on the other kernel)
     assert (_plan(ops, tuple(x.shape), ys, cin, cout, k, s, p, 1)[4] == 2) == (cout % 64 == 0), "dgrad kernel choice"
+    if name in _HALO_W128:  # the case exists for the 128-column variant: make sure that is what runs
+        dg, bm = _HALO_W128[name]
+        assert _plan(ops, tuple(x.shape), ys, cin, cout, k, s, p, dg)[:2] == [bm, 128], "not the 128-column tile"
     ref = F.conv3d(x, wgt, stride=s, padding=p)
     # forward: raw + BN-stat partials
     y, part = ops.conv_fwd(xa, wa, k, s, p, stats=True, halo="force")
@@ -657,7 +670,8 @@ def test_halo_image_kernel_fwd_and_dgrad(case, dev):
     dya = to_act(dy, dev)
     dx = ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, halo="force")
     assert_close(dx, dx_ref, TOL, name + " dgrad")
-    assert_close(dx, ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, halo=False).float(), 4e-3,
+    # two fp32 accumulation orders rounded to bf16: one bf16 ulp of the largest output is 2^-8 .. 2^-7 of it
+    assert_close(dx, ops.conv_dgrad(dya, wt, tuple(x.shape), k, s, p, halo=False).float(), 2.0 ** -7,
                  name + " dgrad vs implicit GEMM")
     rr = rb(torch.randn(x.shape, generator=g))
     rra = to_act(rr, dev)

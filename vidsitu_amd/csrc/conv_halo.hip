@@ -47,6 +47,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvP p, HaloGeo q) {
   constexpr int STAGING = 2 * ABYTES + NSB * BBYTES;
   constexpr int EPI = BM * BN * 4 + 256 * 16 * 4;  // fp32 tile (+ the BN-backward row-lane sums)
   constexpr int MAIN = STAGING > EPI ? STAGING : EPI;
+  constexpr int STAT = 2 * 8 * BN * 4;             // the epilogue's statistic rows [2][4 * 2][BN]
+  constexpr bool STAT_IN_MAIN = MAIN >= EPI + STAT;  // behind the fp32 tile, in the (by then idle) staging ring
   static_assert((D - 2) * LB + LA <= 63 && D >= 3, "vmcnt range");
 
   const int tid = threadIdx.x;
@@ -62,7 +64,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvP p, HaloGeo q) {
   unsigned* aoff_tab = (unsigned*)(smem + MAIN);          // [HALO_RA_MAX] byte offset of image row j
   int* orow = (int*)(smem + MAIN + HALO_RA_MAX * 4);      // [BM] output position of tile row r, or -1
   int* abase = orow + BM;                                 // [BM] image row of tile row r at tap (0, 0)
-  float* statbuf = (float*)(abase + BM);                  // [2][4 * 2][BN]
+  // [2][4 * 2][BN]; with 128-column tiles there is no room for it behind the tables (160 KiB of LDS)
+  float* statbuf = STAT_IN_MAIN ? (float*)(smem + EPI) : (float*)(abase + BM);
 
   // ---- tables (every row decoded once per block) ----
   const int ipg = q.D1 * q.D2, opg = q.O1 * q.O2p;
@@ -423,7 +426,9 @@ static size_t halo_smem_bytes(int mrw, int nrw, int depth) {
   const size_t bm = 32 * mrw, bn = 32 * nrw;
   const size_t staging = 2 * (size_t)HALO_RA_MAX * 128 + (size_t)(depth + 1) * bn * 128;
   const size_t epi = bm * bn * 4 + 256 * 16 * 4;
-  return (staging > epi ? staging : epi) + HALO_RA_MAX * 4 + 2 * bm * 4 + 2 * 8 * bn * 4;  // .. + statbuf [2][4 * WM][BN], WM = 2
+  const size_t stat = 2 * 8 * bn * 4;  // statbuf [2][4 * WM][BN], WM = 2: inside the main region when the ring leaves room
+  const size_t main_b = staging > epi ? staging : epi;
+  return main_b + HALO_RA_MAX * 4 + 2 * bm * 4 + (main_b >= epi + stat ? 0 : stat);
 }
 
 template <int MRW, int NRW, bool BNB, int D, int TAPS>
