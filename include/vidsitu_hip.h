@@ -124,6 +124,19 @@ size_t vs_conv_workspace_bytes(const vs_conv_desc* d, int dgrad);
  * 1 if the register-resident small-channel kernel runs}; out[4] == 2: the halo-image kernel (conv_halo.hip),
  * out[0..1] its tile, out[2] its weight-ring depth, out[3] its unrolled tap count.  Profiling / attribution only. */
 int vs_conv_plan(const vs_conv_desc* d, int dgrad, int* out);
+/* Evaluation: conv b (+ folded BN + ReLU) and conv c (1x1x1, + folded BN + residual + ReLU) of a fast-pathway
+ * bottleneck in ONE launch -- slowfast resnet_helper.BottleneckTransform.forward (b, b_bn, b_relu, c, c_bn) and
+ * ResBlock.forward's `x + f(x)` / relu for the blocks whose inner width is 8, 16 or 32 channels (SlowFast-R50 fast
+ * pathway res2 / res3 / res4, SURVEY.md 7 "Layout"): the inner tensor never leaves the CU.  d describes conv b (flags:
+ * VS_CONV_AFFINE | VS_CONV_RELU only; d->y_ld is ignored); w_c: bf16 [cout_c][Cout of b]; residual rows
+ * [positions][res_ld] or NULL; y rows [positions][y_ld].  vs_conv_fwd_bc_fusable: 1 if the pair is taken
+ * (conv b not pointwise; Cout_b in {8, 16}, taps * Cin_b <= 192, cout_c <= 64; or Cout_b = 32, 256 < taps * Cin_b <= 288,
+ * cout_c <= 128), else the caller runs two vs_conv_fwd. */
+int vs_conv_fwd_bc_fusable(const vs_conv_desc* d, int cout_c);
+int vs_conv_fwd_bc(const void* x, const void* w_b, const vs_conv_desc* d, const float* scale_b,
+                   const float* shift_b, const void* w_c, int cout_c, const float* scale_c,
+                   const float* shift_c, const void* residual, int res_ld, void* y, int y_ld, int relu_c,
+                   void* stream);
 
 /* Data gradient: dx[N,Ti,Hi,Wi,Cin] = conv_transpose(dy, w) (+ residual when
  * desc.flags has VS_CONV_RESIDUAL: the gradient arriving over the other branch

@@ -935,3 +935,71 @@ def test_dgrad_emits_the_sums_of_two_bn_units_fed_by_one_gradient(case, dev):
     want = (gm * xh2).double().sum((0, 2, 3, 4)).cpu()
     got = p2[:, 1].double().sum(0).cpu()
     assert float((got - want).abs().max()) / float(want.abs().max()) < 1e-5
+
+
+# name, N, Cin, T, H, W, Cb, k_b, s_b, p_b, Cc, residual   (conv b -> conv c in one launch, evaluation)
+BC_CASES = [
+    ("fast_s2", 2, 8, 32, 56, 56, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), 32, True),
+    ("fast_s3", 2, 16, 32, 28, 28, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1), 64, True),
+    ("fast_s3_first_stride2", 2, 16, 8, 56, 56, 16, (1, 3, 3), (1, 2, 2), (0, 1, 1), 64, True),
+    ("ragged_rows_no_res", 3, 8, 5, 13, 11, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), 24, False),
+    ("temporal_b_16_to_40", 1, 16, 9, 7, 9, 16, (3, 1, 1), (1, 1, 1), (1, 0, 0), 40, True),
+    ("wide_in_24", 1, 24, 4, 10, 10, 8, (1, 1, 3), (1, 1, 1), (0, 0, 1), 16, True),
+    ("fast_s4_32ch", 2, 32, 8, 14, 14, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1), 128, True),
+    ("fast_s4_first_stride2", 1, 32, 4, 28, 28, 32, (1, 3, 3), (1, 2, 2), (0, 1, 1), 128, True),
+    ("32ch_ragged_to_72", 3, 32, 3, 9, 7, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1), 72, False),
+]
+
+
+@pytest.mark.parametrize("case", BC_CASES, ids=[c[0] for c in BC_CASES])
+def test_fused_bc_eval(case, dev):
+    """vs_conv_fwd_bc (conv b + folded BN + ReLU -> conv c + folded BN + residual + ReLU, one launch) against the two
+    vs_conv_fwd launches it replaces (same bf16 inner tensor, fp32 residual add: at most one bf16 ulp apart) and
+    against torch fp32 on the bf16-rounded operands."""
+    from vidsitu_amd import ops
+
+    name, n, cin, t, h, w, cb, k, s, p, cc, with_res = case
+    g = torch.Generator().manual_seed(97)
+    x = rb(torch.randn(n, cin, t, h, w, generator=g))
+    wb = rb(torch.randn(cb, cin, *k, generator=g) / (cin * k[0] * k[1] * k[2]) ** 0.5)
+    wc = rb(torch.randn(cc, cb, 1, 1, 1, generator=g) / cb ** 0.5)
+    sb, hb = torch.rand(cb, generator=g) + 0.5, torch.randn(cb, generator=g) * 0.2
+    s_c, h_c = torch.rand(cc, generator=g) + 0.5, torch.randn(cc, generator=g) * 0.2
+    xa, wba, wca = to_act(x, dev), to_w(wb, dev), to_w(wc, dev)
+    sbd, hbd, scd, hcd = (v.to(dev) for v in (sb, hb, s_c, h_c))
+    assert ops.conv_fwd_bc_fusable(xa, wba, k, s, p, cc)
+    yb = F.conv3d(x, wb, stride=s, padding=p)
+    res = rb(torch.randn(n, cc, *yb.shape[2:], generator=g)) if with_res else None
+    inner = rb(torch.relu(yb * sb.view(1, -1, 1, 1, 1) + hb.view(1, -1, 1, 1, 1)))
+    ref = F.conv3d(inner, wc) * s_c.view(1, -1, 1, 1, 1) + h_c.view(1, -1, 1, 1, 1)
+    if with_res:
+        ref = ref + res
+    ref = torch.relu(ref)
+    ra = to_act(res, dev) if with_res else None
+    got = ops.conv_fwd_bc(xa, wba, k, s, p, sbd, hbd, wca, scd, hcd, residual=ra, relu=True)
+    assert_close(got, ref, TOL, name + " fused b->c vs torch")
+    b2, _ = ops.conv_fwd(xa, wba, k, s, p, scale=sbd, shift=hbd, relu=True)
+    two, _ = ops.conv_fwd(b2, wca, (1, 1, 1), (1, 1, 1), (0, 0, 0), scale=scd, shift=hcd, residual=ra, relu=True)
+    assert_close(got, two.float(), 2.0 ** -7, name + " fused b->c vs two launches")
+    # into a caller's buffer with a wider row pitch (the trunk writes block outputs into concatenation buffers)
+    big = ops.new_act(n, cc + 8, *yb.shape[2:], device=dev)
+    big.fill_(7.0)
+    view = big[:, :cc]
+    ops.conv_fwd_bc(xa, wba, k, s, p, sbd, hbd, wca, scd, hcd, residual=ra, relu=True, out=view)
+    assert torch.equal(view, got) and bool((big[:, cc:] == 7.0).all())
+
+
+def test_fused_bc_refuses_what_it_cannot_take(dev):
+    from vidsitu_amd import _lib, ops
+
+    x = to_act(torch.randn(1, 64, 4, 8, 8), dev)
+    w64 = to_w(torch.randn(64, 64, 1, 3, 3), dev)  # 64 inner channels, K = 576: the tile kernels' layer
+    assert not ops.conv_fwd_bc_fusable(x, w64, (1, 3, 3), (1, 1, 1), (0, 1, 1), 256)
+    w8 = to_w(torch.randn(8, 64, 1, 1, 1), dev)  # pointwise conv b
+    assert not ops.conv_fwd_bc_fusable(x, w8, (1, 1, 1), (1, 1, 1), (0, 0, 0), 32)
+    w16 = to_w(torch.randn(16, 64, 1, 3, 3), dev)  # 16 inner channels but K = 576 does not fit the registers
+    assert not ops.conv_fwd_bc_fusable(x, w16, (1, 3, 3), (1, 1, 1), (0, 1, 1), 64)
+    wc = to_w(torch.randn(256, 64, 1, 1, 1), dev)
+    one = torch.ones(256, device=dev)
+    with pytest.raises(_lib.VsError):
+        ops.conv_fwd_bc(x, w64, (1, 3, 3), (1, 1, 1), (0, 1, 1), one[:64], one[:64], wc, one, one)

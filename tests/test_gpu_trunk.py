@@ -684,3 +684,36 @@ def test_deferred_slab_reduce_merged_with_the_next_finalize_is_bitwise_and_short
         assert torch.equal(g0, g1), f"deferred={deferred}: gradients differ with the merged launches"
         assert n_mrg <= n_sep - 30, (n_sep, n_mrg)
     assert torch.equal(out[(True, False)][0], out[(True, True)][0])
+
+
+def test_eval_fused_bc_blocks_match_the_two_launch_blocks_and_save_thirteen_launches(dev):
+    """configs[1] (feature extractor, eval): conv b -> conv c of the fast pathway's res2 / res3 / res4 bottlenecks as one launch
+    (ResBlock.fuse_bc, vs_conv_fwd_bc) against the same forward with two launches per block -- 3 + 4 + 6 launches fewer
+    on SlowFast-R50, pooled features equal to a bf16 ulp of the block outputs."""
+    from vidsitu_amd import _lib, synth_data, trunk as T
+    from vidsitu_amd.extended_config import get_cfg
+    from vidsitu_amd.mdl_selector import get_mdl_loss_eval
+
+    cfg = get_cfg({"mdl.mdl_name": "sf_base"})
+    comm = synth_data.make_comm(cfg)
+    torch.manual_seed(0)
+    mdl = get_mdl_loss_eval(cfg)["mdl"](cfg=cfg, comm=comm).to(dev).eval()
+    batch = synth_data.synth_batch(cfg, comm, bs=1, n_ev=2, device=dev, dtype=torch.bfloat16)
+    lib = _lib.load()
+    got = {}
+    saved = T.ResBlock.fuse_bc
+    try:
+        for fuse in (False, True):
+            T.ResBlock.fuse_bc = fuse
+            with torch.no_grad():
+                mdl.head(mdl.forward_encoder(batch))  # warm-up: folds, weight casts
+                torch.cuda.synchronize()
+                n0 = lib.vs_launch_count()
+                f = mdl.head(mdl.forward_encoder(batch))
+            torch.cuda.synchronize()
+            got[fuse] = (f.float().clone(), lib.vs_launch_count() - n0)
+    finally:
+        T.ResBlock.fuse_bc = saved
+    assert got[False][1] - got[True][1] == 13, (got[False][1], got[True][1])
+    err = (got[True][0] - got[False][0]).abs().max().item() / got[False][0].abs().max().item()
+    assert err < 2e-3, err

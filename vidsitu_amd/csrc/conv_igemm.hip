@@ -694,28 +694,60 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(
 // buffer_load, each wave streams `tiles_per_wave` consecutive 16-row tiles, and the only
 // LDS use is a 512-byte per-wave transpose so that stores are whole channel vectors.
 // =============================================================================
-// TB = 16-row tiles a wave keeps in flight: the gathers of all TB tiles are issued before the first MFMA.  One
-// tile per round trip moved 256..1024 unique bytes per wave per memory latency (~1 TB/s over the chip for the
-// 8-channel layers of the fast pathway); see profiles/r02_direct_tb.txt for the sweep.
-// BNB (dgrad launches): the copy-out also emits the BN-backward sums of the unit this dx is the complete dz of --
-// the two variants of conv_tile_epilogue (no residual: mask recomputed from gamma / beta; residual: the unit's bit
-// mask) -- one partial row per block (fixed order: a lane's rows in order, then waves x lanes through LDS).
-template <int NT, int KS, int MODE, int TB, bool BNB = false>
-__global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p, int tiles_per_wave) {
-  __shared__ __attribute__((aligned(16))) uint16_t tbuf[4][TB * 16 * 16 * NT];
-  __shared__ float sstat[2][4][16 * NT];
-  __shared__ float bnred[BNB ? 4 * 64 * 16 : 1];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int lr = lane & 15, lq = lane >> 4;
-  const int K8 = p.K >> 3, C8 = p.Cg >> 3;
-  const __amdgpu_buffer_rsrc_t xsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+// Row decode of the register-resident kernels: output position m -> byte offset of its tap-0 input row and the
+// bitmask of taps that fall inside the input (MODE 0: pointwise, 1: forward / unit-stride dgrad, 2: strided dgrad).
+template <int MODE>
+__device__ __forceinline__ void direct_decode_row(const ConvP& p, int m, float rcpW, float rcpH, float rcpT,
+                                                  unsigned& roff, unsigned& vmask) {
+  int rw, t1, rh, t2, rt, n;
+  fast_divmod(m, p.Rw, rcpW, t1, rw);
+  fast_divmod(t1, p.Rh, rcpH, t2, rh);
+  fast_divmod(t2, p.Rt, rcpT, n, rt);
+  if (MODE == 0) {
+    const long long pos =
+        ((long long)(n * p.Gt + rt * p.mulT) * p.Gh + rh * p.mulH) * p.Gw + rw * p.mulW;
+    roff = (unsigned)(pos * p.g_ld * 2);
+    vmask = 1u;
+  } else {
+    const int ct = rt * p.mulT + p.offT, ch = rh * p.mulH + p.offH, cw = rw * p.mulW + p.offW;
+    long long pos0 = (long long)n * p.Gt * p.Gh * p.Gw;
+    if (MODE == 1) pos0 += ((long long)ct * p.Gh + ch) * p.Gw + cw;
+    else pos0 += ((long long)(ct >> p.shT) * p.Gh + (ch >> p.shH)) * p.Gw + (cw >> p.shW);
+    roff = (unsigned)(pos0 * p.g_ld * 2);
+    auto axis_mask = [&](int c, int kk, int shf, int G) {
+      unsigned mm = 0u;
+      for (int dd = 0; dd < kk; ++dd) {
+        int v = c + p.tmul * dd;
+        bool ok = true;
+        if (MODE == 2) {
+          ok = (v & ((1 << shf) - 1)) == 0;
+          v >>= shf;
+        }
+        ok = ok && ((unsigned)v < (unsigned)G);
+        mm |= (ok ? 1u : 0u) << dd;
+      }
+      return mm;
+    };
+    const unsigned mt = axis_mask(ct, p.kT, p.shT, p.Gt), mh = axis_mask(ch, p.kH, p.shH, p.Gh),
+                   mw = axis_mask(cw, p.kW, p.shW, p.Gw);
+    int tap = 0;
+    unsigned vm = 0u;
+    for (int dt = 0; dt < p.kT; ++dt)
+      for (int dh = 0; dh < p.kH; ++dh) {
+        const unsigned th = (mt >> dt) & (mh >> dh) & 1u;
+        vm |= (th ? mw : 0u) << tap;
+        tap += p.kW;
+      }
+    vmask = vm;
+  }
+}
 
-  // B fragments: B[k = ks*32 + 8*lq + j][n = nt*16 + lr], resident for the whole kernel
-  bf16x8 bfr[KS][NT];
-  int ktap[KS], kdel[KS];
+// The whole weight matrix of a register-resident kernel as MFMA B fragments, and per k-step the tap its 8-channel
+// group belongs to (ktap; 31 = none) with the byte offset of that group from a row's tap-0 address (kdel).
+template <int NT, int KS, int MODE>
+__device__ __forceinline__ void direct_load_weights(const ConvP& p, const __amdgpu_buffer_rsrc_t wsrc, int lq, int lr,
+                                                    bf16x8 (&bfr)[KS][NT], int (&ktap)[KS], int (&kdel)[KS]) {
+  const int K8 = p.K >> 3, C8 = p.Cg >> 3;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     const int k8 = ks * 4 + lq;
@@ -743,6 +775,30 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p, int tiles_per
       }
     }
   }
+}
+
+// TB = 16-row tiles a wave keeps in flight: the gathers of all TB tiles are issued before the first MFMA.  One
+// tile per round trip moved 256..1024 unique bytes per wave per memory latency (~1 TB/s over the chip for the
+// 8-channel layers of the fast pathway); see profiles/r02_direct_tb.txt for the sweep.
+// BNB (dgrad launches): the copy-out also emits the BN-backward sums of the unit this dx is the complete dz of --
+// the two variants of conv_tile_epilogue (no residual: mask recomputed from gamma / beta; residual: the unit's bit
+// mask) -- one partial row per block (fixed order: a lane's rows in order, then waves x lanes through LDS).
+template <int NT, int KS, int MODE, int TB, bool BNB = false>
+__global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p, int tiles_per_wave) {
+  __shared__ __attribute__((aligned(16))) uint16_t tbuf[4][TB * 16 * 16 * NT];
+  __shared__ float sstat[2][4][16 * NT];
+  __shared__ float bnred[BNB ? 4 * 64 * 16 : 1];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int lr = lane & 15, lq = lane >> 4;
+  const __amdgpu_buffer_rsrc_t xsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+
+  // B fragments: B[k = ks*32 + 8*lq + j][n = nt*16 + lr], resident for the whole kernel
+  bf16x8 bfr[KS][NT];
+  int ktap[KS], kdel[KS];
+  direct_load_weights<NT, KS, MODE>(p, wsrc, lq, lr, bfr, ktap, kdel);
   const float rcpW = 1.0f / (float)p.Rw, rcpH = 1.0f / (float)p.Rh, rcpT = 1.0f / (float)p.Rt;
   float ssum[NT], ssq[NT];
 #pragma unroll
@@ -788,49 +844,8 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p, int tiles_per
     unsigned roff_own = VS_OOB, vmask_own = 0u;
     {
       const int m = (tile0 + it) * 16 + lane;
-      if (lane < TB * 16 && m < p.M && it + (lane >> 4) < tiles_per_wave) {
-        int rw, t1, rh, t2, rt, n;
-        fast_divmod(m, p.Rw, rcpW, t1, rw);
-        fast_divmod(t1, p.Rh, rcpH, t2, rh);
-        fast_divmod(t2, p.Rt, rcpT, n, rt);
-        if (MODE == 0) {
-          const long long pos =
-              ((long long)(n * p.Gt + rt * p.mulT) * p.Gh + rh * p.mulH) * p.Gw + rw * p.mulW;
-          roff_own = (unsigned)(pos * p.g_ld * 2);
-          vmask_own = 1u;
-        } else {
-          const int ct = rt * p.mulT + p.offT, ch = rh * p.mulH + p.offH, cw = rw * p.mulW + p.offW;
-          long long pos0 = (long long)n * p.Gt * p.Gh * p.Gw;
-          if (MODE == 1) pos0 += ((long long)ct * p.Gh + ch) * p.Gw + cw;
-          else pos0 += ((long long)(ct >> p.shT) * p.Gh + (ch >> p.shH)) * p.Gw + (cw >> p.shW);
-          roff_own = (unsigned)(pos0 * p.g_ld * 2);
-          auto axis_mask = [&](int c, int kk, int shf, int G) {
-            unsigned mm = 0u;
-            for (int dd = 0; dd < kk; ++dd) {
-              int v = c + p.tmul * dd;
-              bool ok = true;
-              if (MODE == 2) {
-                ok = (v & ((1 << shf) - 1)) == 0;
-                v >>= shf;
-              }
-              ok = ok && ((unsigned)v < (unsigned)G);
-              mm |= (ok ? 1u : 0u) << dd;
-            }
-            return mm;
-          };
-          const unsigned mt = axis_mask(ct, p.kT, p.shT, p.Gt), mh = axis_mask(ch, p.kH, p.shH, p.Gh),
-                         mw = axis_mask(cw, p.kW, p.shW, p.Gw);
-          int tap = 0;
-          unsigned vm = 0u;
-          for (int dt = 0; dt < p.kT; ++dt)
-            for (int dh = 0; dh < p.kH; ++dh) {
-              const unsigned th = (mt >> dt) & (mh >> dh) & 1u;
-              vm |= (th ? mw : 0u) << tap;
-              tap += p.kW;
-            }
-          vmask_own = vm;
-        }
-      }
+      if (lane < TB * 16 && m < p.M && it + (lane >> 4) < tiles_per_wave)
+        direct_decode_row<MODE>(p, m, rcpW, rcpH, rcpT, roff_own, vmask_own);
     }
     unsigned roff[TB], vmask[TB];
 #pragma unroll
@@ -1016,6 +1031,214 @@ static int launch_direct(const ConvP& p, int mode, hipStream_t st) {
     case 4: return launch_direct_ks<NT, 4>(p, mode, st);
     case 5: return launch_direct_ks<NT, 5>(p, mode, st);
     default: return launch_direct_ks<NT, 6>(p, mode, st);
+  }
+}
+
+
+// =============================================================================
+// Evaluation only: conv b and conv c of a fast-pathway bottleneck in ONE launch (SURVEY.md 7 "Layout": the 8 / 16
+// channel inner tensor never leaves the CU).  Stage 1 is the register-resident kernel above for conv b (folded BN +
+// ReLU, bf16 like the stored tensor would be); the wave's transposed b tile in LDS IS the A operand of conv c: lane
+// (row lr, k-group lq) reads its 16 bytes = 8 inner channels of its row, one v_mfma_f32_16x16x32_bf16 per 16 output
+// channels of c against conv c's weights (<= 8 fragments, resident), then folded BN + residual + ReLU in fp32 (one
+// rounding, as conv_tile_epilogue does) through a per-wave fp32 LDS tile so that stores are whole channel vectors.
+// The residual rows of all TB tiles are fetched with the gathers, before the first MFMA.
+// =============================================================================
+struct BcP {
+  const uint16_t* w2;   // conv c weights [N2][K2 = conv b's Cout] bf16
+  unsigned w2_bytes;
+  int N2;               // conv c's output channels (<= 16 * NT2)
+  const float* scale2;  // folded BN of conv c
+  const float* shift2;
+  const uint16_t* res;  // block input / shortcut rows [M][res_ld], or null
+  int res_ld;
+  uint16_t* y2;         // block output rows [M][y2_ld]
+  int y2_ld;
+  int relu2;
+};
+
+template <int NT, int KS, int MODE, int TB, int NT2>
+__global__ __launch_bounds__(256) void conv_direct_bc_kernel(ConvP p, BcP q, int tiles_per_wave) {
+  constexpr int S2 = 16 * NT2 + 4;   // fp32 row pitch of the c tile (+4: the four row groups land in two bank halves)
+  constexpr int CPR2 = 2 * NT2;      // 8-channel chunks per output row
+  constexpr int CH2 = (16 * CPR2 + 63) / 64;  // chunks per lane and 16-row tile
+  __shared__ __attribute__((aligned(16))) uint16_t tbuf[4][TB * 16 * 16 * NT];
+  __shared__ __attribute__((aligned(16))) float tbuf2[4][16 * S2];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int lr = lane & 15, lq = lane >> 4;
+  const __amdgpu_buffer_rsrc_t xsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w2src =
+      __builtin_amdgcn_make_buffer_rsrc((void*)q.w2, 0, (int)q.w2_bytes, 0x00020000);
+
+  bf16x8 bfr[KS][NT];
+  int ktap[KS], kdel[KS];
+  direct_load_weights<NT, KS, MODE>(p, wsrc, lq, lr, bfr, ktap, kdel);
+  // conv c: B2[k = 8*lq + j][n = b*16 + lr], K2 = p.Ncols <= 16 * NT (one k-step of 32, zero beyond K2)
+  bf16x8 w2fr[NT2];
+  float sc2[NT2], sh2[NT2];
+#pragma unroll
+  for (int b = 0; b < NT2; ++b) {
+    const int n = b * 16 + lr;
+    const unsigned off = (lq * 8 < p.Ncols && n < q.N2) ? (unsigned)((n * p.Ncols + lq * 8) * 2) : VS_OOB;
+    w2fr[b] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w2src, off, 0, 0));
+    sc2[b] = n < q.N2 ? q.scale2[n] : 0.f;
+    sh2[b] = n < q.N2 ? q.shift2[n] : 0.f;
+  }
+  const float rcpW = 1.0f / (float)p.Rw, rcpH = 1.0f / (float)p.Rh, rcpT = 1.0f / (float)p.Rt;
+  float sc[NT], sh[NT];
+#pragma unroll
+  for (int b = 0; b < NT; ++b) {
+    const int col = b * 16 + lr;
+    sc[b] = 1.f;
+    sh[b] = 0.f;
+    if (col < p.Ncols) {
+      sc[b] = p.scale[col];
+      sh[b] = p.shift[col];
+    }
+  }
+  const bool relu = (p.flags & VS_CONV_RELU) != 0;
+  uint16_t* tb = tbuf[wave];
+  float* tb2 = tbuf2[wave];
+  const int tile0 = (blockIdx.x * 4 + wave) * tiles_per_wave;
+
+  for (int it = 0; it < tiles_per_wave; it += TB) {
+    if ((tile0 + it) * 16 >= p.M) break;
+    const int m0 = (tile0 + it) * 16;
+    unsigned roff_own = VS_OOB, vmask_own = 0u;
+    {
+      const int m = m0 + lane;
+      if (lane < TB * 16 && m < p.M && it + (lane >> 4) < tiles_per_wave)
+        direct_decode_row<MODE>(p, m, rcpW, rcpH, rcpT, roff_own, vmask_own);
+    }
+    unsigned roff[TB], vmask[TB];
+#pragma unroll
+    for (int u = 0; u < TB; ++u) {
+      roff[u] = (unsigned)__shfl((int)roff_own, u * 16 + lr, 64);
+      vmask[u] = (unsigned)__shfl((int)vmask_own, u * 16 + lr, 64);
+    }
+    bf16x8 af[TB][KS];
+#pragma unroll
+    for (int u = 0; u < TB; ++u)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const unsigned ok = (vmask[u] >> ktap[ks]) & 1u;
+        const unsigned off = ok ? roff[u] + (unsigned)kdel[ks] : VS_OOB;
+        af[u][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0));
+      }
+    // the residual chunks this lane adds in the copy-out of every tile of the batch
+    const int nrows = 16 * min(TB, tiles_per_wave - it);
+    uint4 resv[TB][CH2];
+#pragma unroll
+    for (int u = 0; u < TB; ++u)
+#pragma unroll
+      for (int j = 0; j < CH2; ++j) {
+        const int c = lane + j * 64;
+        const int row = c / CPR2, n = (c - row * CPR2) * 8;
+        const int mm = m0 + u * 16 + row;
+        resv[u][j] = make_uint4(0u, 0u, 0u, 0u);
+        if (q.res && c < 16 * CPR2 && u * 16 + row < nrows && mm < p.M && n < q.N2)
+          resv[u][j] = *(const uint4*)(q.res + (long long)mm * q.res_ld + n);
+      }
+#pragma unroll
+    for (int u = 0; u < TB; ++u) {
+      f32x4 acc[NT];
+#pragma unroll
+      for (int b = 0; b < NT; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+          acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][ks], bfr[ks][b], acc[b], 0, 0, 0);
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[b][r] * sc[b] + sh[b];
+          if (relu) v = fmaxf(v, 0.f);
+          tb[(u * 16 + lq * 4 + r) * (16 * NT) + b * 16 + lr] = f32_to_bf16(v);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's ds_writes have landed
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < TB; ++u) {
+      // conv c on the tile: A2[row lr][k = 8*lq + j] = the b tile's row, 16 bytes per lane (columns >= Ncols are zero:
+      // zero weight columns, unit scale, zero shift in stage 1)
+      uint4 a2w = make_uint4(0u, 0u, 0u, 0u);
+      if (lq * 8 < 16 * NT) a2w = *(const uint4*)(tb + (u * 16 + lr) * (16 * NT) + lq * 8);
+      const bf16x8 a2 = __builtin_bit_cast(bf16x8, a2w);
+#pragma unroll
+      for (int b = 0; b < NT2; ++b) {
+        f32x4 c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, w2fr[b], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tb2[(lq * 4 + r) * S2 + b * 16 + lr] = c2[r] * sc2[b] + sh2[b];
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < CH2; ++j) {
+        const int c = lane + j * 64;
+        const int row = c / CPR2, n = (c - row * CPR2) * 8;
+        const int mm = m0 + u * 16 + row;
+        if (c < 16 * CPR2 && u * 16 + row < nrows && mm < p.M && n < q.N2) {
+          const float4 lo = *(const float4*)(tb2 + row * S2 + n), hi = *(const float4*)(tb2 + row * S2 + n + 4);
+          float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          if (q.res) {
+            float g[8];
+            unpack8_bf16(resv[u][j], g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += g[e];
+          }
+          if (q.relu2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+          }
+          *(uint4*)(q.y2 + (long long)mm * q.y2_ld + n) = pack8_bf16(f);
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();  // reads done before the next tile overwrites tb2 (and the next batch tb)
+    }
+  }
+}
+
+template <int KS, int NT2>
+static int launch_direct_bc_ks(const ConvP& p, const BcP& q, hipStream_t st) {
+  const int grid = direct_blocks(p.M);
+  if (direct_tb(1, KS) == 4 && NT2 <= 2)
+    hipLaunchKernelGGL((conv_direct_bc_kernel<1, KS, 1, 4, NT2>), dim3(grid), dim3(256), 0, st, p, q, VS_DIRECT_TPW);
+  else
+    hipLaunchKernelGGL((conv_direct_bc_kernel<1, KS, 1, 2, NT2>), dim3(grid), dim3(256), 0, st, p, q, VS_DIRECT_TPW);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// 32 inner channels, 9 taps (fast res4: K = 288 = 9 k-steps, 72 weight registers per lane): two tiles in flight,
+// fewer tiles per wave than the 8 / 16-channel layers (a quarter of their rows)
+static int launch_direct_bc32(const ConvP& p, const BcP& q, hipStream_t st) {
+  static const int tpw = [] {
+    const char* e = getenv("VS_BC32_TPW");
+    const int v = e ? atoi(e) : 4;
+    return v < 2 ? 2 : (v & ~1);
+  }();
+  const int grid = (int)((p.M + 64ll * tpw - 1) / (64ll * tpw));
+  hipLaunchKernelGGL((conv_direct_bc_kernel<2, 9, 1, 2, 8>), dim3(grid), dim3(256), 0, st, p, q, tpw);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+template <int NT2>
+static int launch_direct_bc(const ConvP& p, const BcP& q, hipStream_t st) {
+  switch ((p.K + 31) / 32) {
+    case 1: return launch_direct_bc_ks<1, NT2>(p, q, st);
+    case 2: return launch_direct_bc_ks<2, NT2>(p, q, st);
+    case 3: return launch_direct_bc_ks<3, NT2>(p, q, st);
+    case 4: return launch_direct_bc_ks<4, NT2>(p, q, st);
+    case 5: return launch_direct_bc_ks<5, NT2>(p, q, st);
+    default: return launch_direct_bc_ks<6, NT2>(p, q, st);
   }
 }
 
@@ -1524,6 +1747,61 @@ extern "C" int vs_conv_fwd(const void* x, const void* w, void* y, const vs_conv_
   }
   return launch_conv(p, mode, (d->flags & VS_CONV_NAIVE) != 0, d->flags, workspace, ws_bytes,
                      (hipStream_t)stream);
+}
+
+// conv b -> conv c of a bottleneck in one launch (evaluation): which (descriptor of conv b, width of conv c) pairs
+// the register-resident kernel takes.  conv b: not pointwise, 8 / 16 output channels with K <= 192 or 32 output channels
+// with 256 < K <= 288 (3 x 3 on 32 channels), folded BN + ReLU and nothing else in its epilogue; conv c: 1x1x1 unit
+// stride on conv b's output, <= 64 (<= 128) output channels.
+extern "C" int vs_conv_fwd_bc_fusable(const vs_conv_desc* d, int cout_c) {
+  if (check_desc(d) != VS_OK) return 0;
+  const int taps = d->kT * d->kH * d->kW;
+  const long long M = (long long)d->N * d->To * d->Ho * d->Wo;
+  if (taps == 1 || taps > 31 || d->Cout % 8 != 0 || cout_c % 8 != 0 || cout_c < 8 || M < 64) return 0;
+  if ((d->flags & (VS_CONV_RESIDUAL | VS_CONV_STATS | VS_CONV_NAIVE)) || !(d->flags & VS_CONV_AFFINE)) return 0;
+  const int K = taps * d->Cin;
+  if (d->Cout == 32) return (K > 256 && K <= 288 && cout_c <= 128) ? 1 : 0;  // launch_direct_bc32
+  if (d->Cout > 16 || cout_c > 64) return 0;
+  const ConvPlan pl = plan_conv(M, d->Cout, K, taps, d->flags & ~0xf00);
+  return pl.direct ? 1 : 0;
+}
+
+extern "C" int vs_conv_fwd_bc(const void* x, const void* w_b, const vs_conv_desc* d, const float* scale_b,
+                              const float* shift_b, const void* w_c, int cout_c, const float* scale_c,
+                              const float* shift_c, const void* residual, int res_ld, void* y, int y_ld,
+                              int relu_c, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  VS_CHECK_ARG(x && w_b && w_c && y && scale_b && shift_b && scale_c && shift_c, "null tensor");
+  VS_CHECK_ARG(vs_conv_fwd_bc_fusable(d, cout_c), "not a fusable (conv b, conv c) pair: ask vs_conv_fwd_bc_fusable");
+  VS_CHECK_ARG(y_ld >= cout_c && y_ld % 8 == 0 && (!residual || (res_ld >= cout_c && res_ld % 8 == 0)), "row pitch");
+  ConvP p;
+  const int mode = fill_fwd_params(p, d);
+  VS_CHECK_ARG(mode == 1, "conv b must not be pointwise");
+  p.x = (const uint16_t*)x;
+  p.w = (const uint16_t*)w_b;
+  p.scale = scale_b;
+  p.shift = shift_b;
+  {
+    const long long xb = (long long)d->N * d->Ti * d->Hi * d->Wi * d->x_ld * 2;
+    const long long wb = (long long)d->Cout * p.K * 2;
+    VS_CHECK_ARG(xb < (1ll << 31) && wb < (1ll << 31), "tensor larger than 2 GiB");
+    p.x_bytes = (unsigned)xb;
+    p.w_bytes = (unsigned)wb;
+  }
+  BcP q;
+  q.w2 = (const uint16_t*)w_c;
+  q.w2_bytes = (unsigned)((long long)cout_c * d->Cout * 2);
+  q.N2 = cout_c;
+  q.scale2 = scale_c;
+  q.shift2 = shift_c;
+  q.res = (const uint16_t*)residual;
+  q.res_ld = res_ld;
+  q.y2 = (uint16_t*)y;
+  q.y2_ld = y_ld;
+  q.relu2 = relu_c;
+  if (d->Cout == 32) return launch_direct_bc32(p, q, (hipStream_t)stream);
+  return cout_c <= 32 ? launch_direct_bc<2>(p, q, (hipStream_t)stream) : launch_direct_bc<4>(p, q, (hipStream_t)stream);
 }
 
 // ConvP of a dgrad launch (everything but the tensor pointers); returns the kernel MODE or < 0.

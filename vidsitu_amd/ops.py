@@ -196,6 +196,38 @@ def conv_fwd(x, w, k, s, p, out=None, scale=None, shift=None, residual=None, rel
     return out, partials
 
 
+def _bc_desc(x, wb, k, s, p):
+    ys = conv_out_shape(x.shape, wb.shape[0], k, s, p)
+    return ys, make_desc(x.shape, act_ld(x), ys, wb.shape[0], k, s, p, VS_CONV_AFFINE | VS_CONV_RELU)
+
+
+def conv_fwd_bc_fusable(x, wb, k, s, p, cout_c):
+    """True if conv b (weights wb on input x) + a 1x1x1 conv c of cout_c channels run as one launch (eval)."""
+    _, d = _bc_desc(x, wb, k, s, p)
+    return bool(_lib.load().vs_conv_fwd_bc_fusable(C.byref(d), int(cout_c)))
+
+
+def conv_fwd_bc(x, wb, k, s, p, scale_b, shift_b, wc, scale_c, shift_c, residual=None, relu=True, out=None):
+    """relu?(conv1x1(relu(conv(x, wb) * scale_b + shift_b), wc) * scale_c + shift_c (+ residual)) in one launch
+    (evaluation; the fast pathway's 8 / 16-channel bottlenecks)."""
+    ys_b, d = _bc_desc(x, wb, k, s, p)
+    cout_c = wc.shape[0]
+    check_weight(wb, wb.shape[0], x.shape[1], k)
+    check_weight(wc, cout_c, wb.shape[0], (1, 1, 1))
+    ys = (ys_b[0], cout_c, *ys_b[2:])
+    if out is None:
+        out = new_act(*ys, device=x.device)
+    elif tuple(out.shape) != ys:
+        raise _lib.VsError(f"conv out shape {tuple(out.shape)} != {ys}")
+    if residual is not None and tuple(residual.shape) != ys:
+        raise _lib.VsError("residual shape mismatch")
+    _lib.call("vs_conv_fwd_bc", _ptr(x), _ptr(wb), C.byref(d), _ptr(scale_b), _ptr(shift_b), _ptr(wc),
+              C.c_int(cout_c), _ptr(scale_c), _ptr(shift_c), _ptr(residual),
+              C.c_int(act_ld(residual) if residual is not None else 0), _ptr(out), C.c_int(act_ld(out)),
+              C.c_int(1 if relu else 0), _stream())
+    return out
+
+
 def pack_stem_weight(w, out=None):
     """fp32 [Cout,3,kT,7,7] -> bf16 [ceil16(Cout)][kT][7][8][4] (zero padded) for the stem kernel."""
     cout, cin, kt, kh, kw = w.shape

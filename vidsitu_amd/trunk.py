@@ -502,6 +502,20 @@ class ResBlock(nn.Module):
     # The block's bf16 output carries the fp32 stream as the attribute `_vs_f32` for the next block of the stage.
     # Costs one element-wise pass per block (the c unit's residual + ReLU epilogue becomes that pass).  VS_RESIDUAL_FP32=1.
     residual_fp32 = os.environ.get("VS_RESIDUAL_FP32", "0") == "1"
+    # Eval only: conv b and conv c of the fast pathway's 8 / 16 / 32-channel bottlenecks (res2 - res4) as one launch
+    # (ops.conv_fwd_bc: the inner tensor stays in LDS).  VS_EVAL_FUSE_BC=0: two launches (A/B switch).
+    fuse_bc = os.environ.get("VS_EVAL_FUSE_BC", "1") != "0"
+
+    def _bc_fusable(self, a):
+        b2 = self.branch2
+        if (not ResBlock.fuse_bc or _Unit.split_weights or ResBlock.residual_fp32 or not a.is_cuda
+                or b2.b.bias is not None or b2.c.bias is not None):
+            return False
+        key = tuple(a.shape)
+        hit = self.__dict__.setdefault("_bc_ok", {}).get(key)
+        if hit is None:
+            hit = self._bc_ok[key] = ops.conv_fwd_bc_fusable(a, b2.b.w_bf16, b2.b.k, b2.b.s, b2.b.p, b2.c.cout)
+        return hit
 
     def fwd(self, x, out, train, saved):
         b2 = self.branch2
@@ -509,6 +523,10 @@ class ResBlock(nn.Module):
         if self.has_sc:
             sc = _Unit.fwd(self.branch1, self.branch1_bn, x, False, train=train, saved=saved)
         a = _Unit.fwd(b2.a, b2.a_bn, x, True, train=train, saved=saved)
+        if not train and self._bc_fusable(a):
+            (sb, hb), (s_c, h_c) = b2.b_bn.fold, b2.c_bn.fold
+            return ops.conv_fwd_bc(a, b2.b.w_bf16, b2.b.k, b2.b.s, b2.b.p, sb, hb, b2.c.w_bf16, s_c, h_c,
+                                   residual=sc, relu=True, out=out)
         b = _Unit.fwd(b2.b, b2.b_bn, a, True, train=train, saved=saved)
         if ResBlock.residual_fp32 and not train:
             branch = _Unit.fwd(b2.c, b2.c_bn, b, False, train=False)
