@@ -124,6 +124,21 @@ size_t vs_conv_workspace_bytes(const vs_conv_desc* d, int dgrad);
  * 1 if the register-resident small-channel kernel runs}; out[4] == 2: the halo-image kernel (conv_halo.hip),
  * out[0..1] its tile, out[2] its weight-ring depth, out[3] its unrolled tap count.  Profiling / attribution only. */
 int vs_conv_plan(const vs_conv_desc* d, int dgrad, int* out);
+/* Apply on load (training, the b -> c edge of a bottleneck: slowfast resnet_helper.BottleneckTransform.forward
+ * `x = self.b_relu(self.b_bn(x)); x = self.c(x)`): the 1x1x1 convolution takes the PRODUCER unit's raw convolution
+ * output x and that unit's batch-norm constants (vs_bn_finalize's scale / shift) and multiplies
+ * relu(x * in_scale[c] + in_shift[c]) rounded to bf16 -- bit for bit the tensor vs_bn_apply would have stored, formed
+ * on the operand fragments and never written.  vs_conv_fwd_aol: epilogue VS_CONV_STATS only; vs_conv_wgrad_aol: the
+ * weight gradient of the same convolution (dy, x as in vs_conv_wgrad).  The *_ok queries say for which descriptors
+ * the plan lands on a kernel with the transform (1x1x1, unit stride, Cin <= 512; forward: the persistent pointwise
+ * kernel's 128-column variant or the 128 x 128 two-stage-ring tile; weight gradient: the 128-row ring tiles); a caller
+ * materialises the activation with vs_bn_apply where they return 0. */
+int vs_conv_aol_ok(const vs_conv_desc* d);
+int vs_conv_fwd_aol(const void* x, const void* w, void* y, const vs_conv_desc* d, const float* in_scale,
+                    const float* in_shift, float* stats_partial, void* stream);
+int vs_conv_wgrad_aol_ok(const vs_conv_desc* d);
+int vs_conv_wgrad_aol(const void* dy, const void* x, float* dw, const vs_conv_desc* d, const float* in_scale,
+                      const float* in_shift, void* workspace, size_t ws_bytes, void* stream);
 /* Evaluation: conv b (+ folded BN + ReLU) and conv c (1x1x1, + folded BN + residual + ReLU) of a fast-pathway
  * bottleneck in ONE launch -- slowfast resnet_helper.BottleneckTransform.forward (b, b_bn, b_relu, c, c_bn) and
  * ResBlock.forward's `x + f(x)` / relu for the blocks whose inner width is 8, 16 or 32 channels (SlowFast-R50 fast

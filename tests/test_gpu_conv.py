@@ -1003,3 +1003,62 @@ def test_fused_bc_refuses_what_it_cannot_take(dev):
     one = torch.ones(256, device=dev)
     with pytest.raises(_lib.VsError):
         ops.conv_fwd_bc(x, w64, (1, 3, 3), (1, 1, 1), (0, 1, 1), one[:64], one[:64], wc, one, one)
+
+
+# name, clips, Cin (inner width of the bottleneck), T, H, W, Cout: the c units of the slow pathway at sizes whose plans
+# are the bench's (persistent pointwise kernel for K <= 128, the 128 x 128 ring tile above)
+AOL_CASES = [
+    ("slow_s2c_pw_k64", 1, 64, 8, 56, 56, 256),
+    ("slow_s3c_pw_k128", 2, 128, 8, 28, 28, 512),
+    ("slow_s4c_tile_k256", 4, 256, 8, 14, 14, 1024),
+    ("slow_s5c_tile_k512", 8, 512, 8, 7, 7, 2048),
+    ("ragged_rows_k128", 3, 128, 5, 13, 11, 384),
+    ("ragged_rows_tile_k256", 5, 256, 8, 14, 13, 1024),
+    ("slow_s3c_8clips_pair", 8, 128, 8, 28, 28, 512),
+]
+
+
+@pytest.mark.parametrize("case", AOL_CASES, ids=[c[0] for c in AOL_CASES])
+def test_apply_on_load_is_bitwise_the_materialised_activation(case, dev):
+    """vs_conv_fwd_aol / vs_conv_wgrad_aol (the consumer convolution forms relu(y * scale + shift) on its operand
+    fragments) against vs_bn_apply followed by vs_conv_fwd / vs_conv_wgrad: outputs, BN-statistic partials and the
+    weight gradient bit for bit, and the weight gradient inside a (dgrad, wgrad) pair launch too."""
+    from vidsitu_amd import ops
+
+    name, n, cin, t, h, w, cout = case
+    g = torch.Generator().manual_seed(131)
+    y = to_act(torch.randn(n, cin, t, h, w, generator=g) * 2.0, dev)
+    sc = (torch.rand(cin, generator=g) + 0.5).to(dev)
+    sh = (torch.randn(cin, generator=g) * 0.5).to(dev)
+    wgt = to_w(torch.randn(cout, cin, 1, 1, 1, generator=g) / cin ** 0.5, dev)
+    assert ops.conv_aol_ok(y, cout), "the plan of this shape has no apply-on-load kernel"
+    act = ops.bn_apply(y, sc, sh, None, True)
+    ref, pref = ops.conv_fwd(act, wgt, (1, 1, 1), (1, 1, 1), (0, 0, 0), stats=True)
+    got, pgot = ops.conv_fwd_aol(y, wgt, sc, sh, stats=True)
+    assert torch.equal(got, ref), f"{name}: forward differs"
+    assert torch.equal(pgot, pref), f"{name}: statistic partials differ"
+    dy = to_act(torch.randn(n, cout, t, h, w, generator=g), dev)
+    dw_ref = ops.conv_wgrad(dy, act, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    dw = ops.conv_wgrad_aol(dy, y, sc, sh)
+    assert torch.equal(dw, dw_ref), f"{name}: weight gradient differs"
+    # inside a pair launch (the trunk's backward): data gradient of the same unit + this weight gradient, one grid
+    wt = ops.weight_transpose(wgt)
+    dx_ref = ops.conv_dgrad(dy, wt, tuple(y.shape), (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    n0 = ops.conv_pair_count()
+    with ops.conv_pair():
+        dx = ops.conv_dgrad(dy, wt, tuple(y.shape), (1, 1, 1), (1, 1, 1), (0, 0, 0))
+        dw2 = ops.conv_wgrad_aol(dy, y, sc, sh)
+    assert torch.equal(dx, dx_ref) and torch.equal(dw2, dw_ref), f"{name}: pair launch differs"
+    if name == "slow_s3c_8clips_pair":  # both halves on the 128 x 128 ring kernels at the bench size
+        assert ops.conv_pair_count() == n0 + 1, f"{name}: the pair was not formed"
+
+
+def test_apply_on_load_refuses_what_it_cannot_take(dev):
+    from vidsitu_amd import _lib, ops
+
+    y = to_act(torch.randn(1, 32, 4, 14, 14), dev)  # 32 input channels to 128: a register-staged 64-row tile
+    assert not ops.conv_aol_ok(y, 128)
+    w = to_w(torch.randn(128, 32, 1, 1, 1), dev)
+    one = torch.ones(32, device=dev)
+    with pytest.raises(_lib.VsError):
+        ops.conv_fwd_aol(y, w, one, one)

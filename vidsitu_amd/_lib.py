@@ -58,6 +58,10 @@ SIGNATURES = {
     "vs_conv_stats_rows": (_i, [_dp]),
     "vs_conv_workspace_bytes": (_sz, [_dp, _i]),
     "vs_conv_plan": (_i, [_dp, _i, _p]),
+    "vs_conv_aol_ok": (_i, [_dp]),
+    "vs_conv_fwd_aol": (_i, [_p, _p, _p, _dp, _p, _p, _p, _p]),
+    "vs_conv_wgrad_aol_ok": (_i, [_dp]),
+    "vs_conv_wgrad_aol": (_i, [_p, _p, _p, _dp, _p, _p, _p, _sz, _p]),
     "vs_conv_fwd_bc_fusable": (_i, [_dp, _i]),
     "vs_conv_fwd_bc": (_i, [_p, _p, _dp, _p, _p, _p, _i, _p, _p, _p, _i, _p, _i, _i, _p]),
     "vs_conv_dgrad": (_i, [_p, _p, _p, _dp, _p, _p, _sz, _p]),

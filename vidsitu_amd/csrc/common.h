@@ -71,6 +71,32 @@ __device__ __forceinline__ uint4 pack8_bf16(const float* f) {
   return v;
 }
 
+// One operand fragment (8 bf16) through the BN + ReLU of its producer: the arithmetic of bn_apply_cols_kernel<false,
+// true> (fma, max, round to nearest even).  _k: the 8 elements are 8 consecutive channels (sc / sh point at their
+// constants); _n: one channel, 8 positions.
+__device__ __forceinline__ bf16x8 aol_frag_k(const bf16x8 v, const float* sc, const float* sh) {
+  float f[8];
+  unpack8_bf16(__builtin_bit_cast(uint4, v), f);
+  const float4 s0 = *(const float4*)sc, s1 = *(const float4*)(sc + 4);
+  const float4 h0 = *(const float4*)sh, h1 = *(const float4*)(sh + 4);
+  f[0] = fmaxf(__fmaf_rn(f[0], s0.x, h0.x), 0.f);
+  f[1] = fmaxf(__fmaf_rn(f[1], s0.y, h0.y), 0.f);
+  f[2] = fmaxf(__fmaf_rn(f[2], s0.z, h0.z), 0.f);
+  f[3] = fmaxf(__fmaf_rn(f[3], s0.w, h0.w), 0.f);
+  f[4] = fmaxf(__fmaf_rn(f[4], s1.x, h1.x), 0.f);
+  f[5] = fmaxf(__fmaf_rn(f[5], s1.y, h1.y), 0.f);
+  f[6] = fmaxf(__fmaf_rn(f[6], s1.z, h1.z), 0.f);
+  f[7] = fmaxf(__fmaf_rn(f[7], s1.w, h1.w), 0.f);
+  return __builtin_bit_cast(bf16x8, pack8_bf16(f));
+}
+__device__ __forceinline__ bf16x8 aol_frag_n(const bf16x8 v, const float sc, const float sh) {
+  float f[8];
+  unpack8_bf16(__builtin_bit_cast(uint4, v), f);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = fmaxf(__fmaf_rn(f[e], sc, sh), 0.f);
+  return __builtin_bit_cast(bf16x8, pack8_bf16(f));
+}
+
 // x = q * d + r for 0 <= x < 2^24, rcp = 1.0f / d (float quotient, two fix-ups): ~8 instructions where a runtime
 // 32-bit integer division is ~40 and a 64-bit one ~100+
 __device__ __forceinline__ void fast_divmod(int x, int d, float rcp, int& q, int& r) {

@@ -17,6 +17,8 @@
 // staged through LDS so stores are whole 16-byte channel vectors.
 #include "common.h"
 
+#include <mutex>
+
 #include "conv_tile.h"
 
 template <int BM, int BN, int NSTAGE = 2>
@@ -37,8 +39,10 @@ struct ConvSmem {
 // (`buffer_load_dwordx4 ... lds`, NS-1 tiles in flight, one raw barrier per k-step).
 // BNB: the dgrad variant that also emits the consumer BN's backward sums (VS_CONV_BNBWD); a template flag
 // so that the extra epilogue registers do not count against every other launch's occupancy.
+// AOL (MODE 0 ring launches only): apply on load, see ConvP::in_scale -- the constants of the input channels live in
+// LDS behind the statistic rows, every A fragment goes through aol_frag_k after its LDS read.
 template <int BM, int BN, int WM, int WN, int MODE, bool FAST, int DBG = 0, int NS = 0, bool BNB = false,
-          bool BNB2 = false>
+          bool BNB2 = false, bool AOL = false>
 __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, const int nblk) {
   // (blk / nblk: this block's index and the block count of THIS convolution's grid -- blockIdx.x / gridDim.x of the
   //  stand-alone launch, a sub-range of the grid in the dgrad + wgrad pair launch of conv_pair.hip)
@@ -50,6 +54,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, c
   constexpr int STAGE = ConvSmem<BM, BN>::STAGE;
   constexpr int MAIN = ConvSmem<BM, BN, (NS > 2 ? NS : 2)>::MAIN;
   static_assert(NS == 0 || (FAST && NS >= 2 && BN >= 32), "LDS-DMA ring needs the FAST gather");
+  static_assert(!AOL || (MODE == 0 && NS >= 2), "apply on load: pointwise ring launches");
   static_assert(WM * WN == 4, "4 waves");
   static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile");
 
@@ -348,6 +353,17 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, c
 
   // straight-line MFMA chains (no conditional exit: a branch here makes the compiler shuttle
   // every accumulator between AGPRs and VGPRs each k-step); a K tail multiplies staged zeros.
+  // AOL: [2][AOL_K] scale / shift of input channel k behind the statistic rows (MODE 0: no tables there); aol_k0 =
+  // first channel of the k-tile `compute` is about to multiply
+  constexpr int AOL_K = 512;
+  float* aol_tab = (float*)(smem + MAIN + 8 * WM * BN * 4);
+  int aol_k0 = 0;
+  if (AOL) {
+    for (int i = tid; i < AOL_K; i += 256) {
+      aol_tab[i] = i < p.K ? p.in_scale[i] : 0.f;
+      aol_tab[AOL_K + i] = i < p.K ? p.in_shift[i] : 0.f;
+    }  // (published by the ring loop's first barrier)
+  }
   auto compute = [&](int buf) __attribute__((always_inline)) {
     const char* A = smem + buf * STAGE;
     const char* B = A + BM * 128;
@@ -360,6 +376,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, c
         const int row = wm * TM + a * 16 + lr;
         if (DBG == 4) af[a] = __builtin_bit_cast(bf16x8, (u32x4){(unsigned)row, (unsigned)ch, 1u, 2u});
         else af[a] = *(const bf16x8*)(A + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+        if (AOL) {  // rows past M were zero-filled and have to stay zero (the statistic partials sum every tile row)
+          const bf16x8 t = aol_frag_k(af[a], aol_tab + aol_k0 + ch * 8, aol_tab + AOL_K + aol_k0 + ch * 8);
+          af[a] = (m0 + row < p.M) ? t : __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
+        }
       }
 #pragma unroll
       for (int b = 0; b < NR; ++b) {
@@ -480,7 +500,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, c
     // alternating) it costs 0..7 % on the long reductions and changes nothing in the step.  (An earlier A/B that showed
     // -8..-11 % was void: its on / off switch travelled in launch-flag bits 13 / 14, which the launcher also reads as
     // the diagnostic-variant selector of the 128 x 128 tile -- the two arms ran two different diagnostic kernels.)
-    const bool frags_first = nk >= p.ff_min && nk <= p.ff_max;
+    const bool frags_first = !AOL && nk >= p.ff_min && nk <= p.ff_max;
     int st_c = 0, st_l = D;  // stage computed / stage refilled this step
     for (int kt = 0; kt < nk; ++kt) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"i"((D - 1) * L) : "memory");  // my part of tile kt landed
@@ -528,6 +548,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, c
       } else {
         dma(kbeg + kt + D, st_l);
         __builtin_amdgcn_sched_barrier(0);
+        if (AOL) aol_k0 = (kbeg + kt) * 64;
         compute(st_c);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -606,6 +627,12 @@ template <int BM, int BN, int WM, int WN, int MODE, bool FAST, int DBG = 0, int 
           bool BNB2 = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   conv_igemm_body<BM, BN, WM, WN, MODE, FAST, DBG, NS, BNB, BNB2>(p, blockIdx.x, gridDim.x);
+}
+
+// Apply on load (ConvP::in_scale): the pointwise ring launch whose A fragments go through the producer's BN + ReLU.
+template <int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(256) void conv_igemm_aol_kernel(ConvP p) {
+  conv_igemm_body<BM, BN, WM, WN, 0, true, 0, NS, false, false, true>(p, blockIdx.x, gridDim.x);
 }
 
 // Sum of the split-K slabs (fixed order) + the whole fused epilogue.  Block = 64 rows x all
@@ -1520,6 +1547,11 @@ static void setup_stride_classes(ConvP& p, int bm, int mode, int flags) {
   }
 }
 
+// the tile-kernel launch apply on load is built for: pointwise, the 128 x 128 tile on the 2-stage ring, no split-K
+static bool aol_tile_ok(const ConvPlan& pl, int mode, int K) {
+  return mode == 0 && !pl.direct && pl.S == 1 && pl.tile.bm == 128 && pl.tile.bn == 128 && pl.ring == 2 && K <= 512;
+}
+
 static int launch_conv(ConvP& p, int mode, int naive, int flags, void* ws, size_t ws_bytes,
                        hipStream_t st) {
   // fragment-first ring order (off by default, see the ring loop): VS_RING_FRAGS_FIRST=1 switches it on everywhere,
@@ -1554,6 +1586,23 @@ static int launch_conv(ConvP& p, int mode, int naive, int flags, void* ws, size_
     }
   }
   const ConvPlan pl = plan_conv(p.M, p.Ncols, p.K, p.kT * p.kH * p.kW, flags);
+  if (p.in_scale) {  // apply on load: vs_conv_aol_ok told the caller which launches exist
+    if (!aol_tile_ok(pl, mode, p.K)) {
+      vs_set_error("conv: apply on load is not built for this plan (ask vs_conv_aol_ok)");
+      return VS_ERR_UNSUPPORTED;
+    }
+    p.tilesM = (p.M + 127) / 128;
+    p.tilesN = (p.Ncols + 127) / 128;
+    static std::once_flag attr;
+    std::call_once(attr, [] {
+      (void)hipFuncSetAttribute((const void*)conv_igemm_aol_kernel<128, 128, 2, 2, 2>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    const size_t smem = conv_smem_bytes(128, 128, 2, 2, 0, p.K) + 2 * 512 * sizeof(float);
+    hipLaunchKernelGGL((conv_igemm_aol_kernel<128, 128, 2, 2, 2>), dim3(p.tilesM * p.tilesN), dim3(256), smem, st, p);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+  }
   if (pl.direct)
     return p.Ncols <= 16 ? launch_direct<1>(p, mode, st) : launch_direct<2>(p, mode, st);
   const TileCfg c = pl.tile;
@@ -1628,6 +1677,7 @@ static int fill_fwd_params(ConvP& p, const vs_conv_desc* d) {
   p.bny_ld = 0;
   p.res_bits = nullptr;
   p.bny2 = nullptr; p.bn_mean2 = p.bn_invstd2 = nullptr; p.stats2 = nullptr; p.bny2_ld = 0;
+  p.in_scale = p.in_shift = nullptr;
   p.M = d->N * d->To * d->Ho * d->Wo;
   p.nclips = d->N;
   p.Ncols = d->Cout;
@@ -1749,6 +1799,50 @@ extern "C" int vs_conv_fwd(const void* x, const void* w, void* y, const vs_conv_
                      (hipStream_t)stream);
 }
 
+// Apply on load (train, the b -> c edge of a bottleneck): which forward convolutions can take their input as the
+// producer unit's RAW output plus that unit's BN scale / shift (vs_conv_fwd_aol), i.e. for which descriptors the plan
+// lands on a kernel with the fragment transform: 1x1x1, unit stride, Cin <= 512, on the persistent pointwise kernel
+// (128-column variant) or the 128 x 128 tile on the two-stage ring.
+extern "C" int vs_conv_aol_ok(const vs_conv_desc* d) {
+  if (check_desc(d) != VS_OK) return 0;
+  if (d->flags & (VS_CONV_NAIVE | VS_CONV_AFFINE | VS_CONV_RESIDUAL | VS_CONV_RELU)) return 0;
+  ConvP p;
+  const int mode = fill_fwd_params(p, d);
+  if (mode != 0 || !p.dense || p.K > 512 || p.K % 8) return 0;
+  PwGeo pg;
+  if (vs_pw_plan(p, mode, d->flags, &pg)) return vs_pw_aol_ok(pg, p) ? 1 : 0;
+  const ConvPlan pl = plan_conv(p.M, p.Ncols, p.K, 1, d->flags);
+  return aol_tile_ok(pl, mode, p.K) ? 1 : 0;
+}
+
+// y = conv1x1(relu(x * in_scale[c] + in_shift[c]), w) with x the producer's raw convolution output: the operand is
+// what vs_bn_apply(x, in_scale, in_shift, relu) would have written, bit for bit, never stored.  Epilogue: VS_CONV_STATS
+// only (the train-mode c unit).  Replaces `b_relu(b_bn(.))` -> `c(.)` of slowfast BottleneckTransform.forward.
+extern "C" int vs_conv_fwd_aol(const void* x, const void* w, void* y, const vs_conv_desc* d, const float* in_scale,
+                               const float* in_shift, float* stats_partial, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  VS_CHECK_ARG(x && w && y && in_scale && in_shift, "null tensor");
+  VS_CHECK_ARG(vs_conv_aol_ok(d), "apply on load is not built for this convolution: ask vs_conv_aol_ok");
+  VS_CHECK_ARG(!(d->flags & VS_CONV_STATS) || stats_partial, "STATS needs stats_partial");
+  ConvP p;
+  const int mode = fill_fwd_params(p, d);
+  p.x = (const uint16_t*)x;
+  p.w = (const uint16_t*)w;
+  p.y = (uint16_t*)y;
+  p.stats = stats_partial;
+  p.in_scale = in_scale;
+  p.in_shift = in_shift;
+  {
+    const long long xb = (long long)d->N * d->Ti * d->Hi * d->Wi * d->x_ld * 2;
+    const long long wb = (long long)d->Cout * p.K * 2;
+    VS_CHECK_ARG(xb < (1ll << 31) && wb < (1ll << 31), "tensor larger than 2 GiB");
+    p.x_bytes = (unsigned)xb;
+    p.w_bytes = (unsigned)wb;
+  }
+  return launch_conv(p, mode, 0, d->flags, nullptr, 0, (hipStream_t)stream);
+}
+
 // conv b -> conv c of a bottleneck in one launch (evaluation): which (descriptor of conv b, width of conv c) pairs
 // the register-resident kernel takes.  conv b: not pointwise, 8 / 16 output channels with K <= 192 or 32 output channels
 // with 256 < K <= 288 (3 x 3 on 32 channels), folded BN + ReLU and nothing else in its epilogue; conv c: 1x1x1 unit
@@ -1816,6 +1910,7 @@ static int fill_dgrad_params(ConvP& p, const vs_conv_desc* d) {
   p.bny_ld = 0;
   p.res_bits = nullptr;
   p.bny2 = nullptr; p.bn_mean2 = p.bn_invstd2 = nullptr; p.stats2 = nullptr; p.bny2_ld = 0;
+  p.in_scale = p.in_shift = nullptr;
   p.M = d->N * d->Ti * d->Hi * d->Wi;
   p.nclips = d->N;
   p.Ncols = d->Cin;

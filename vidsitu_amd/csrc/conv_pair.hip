@@ -66,24 +66,25 @@ static bool pair_defer_reduce(const float* slabs, float* dw, long long n, int sp
   return true;
 }
 
-template <int DMODE, bool BNB, int WMODE>
+// WAOL: the weight gradient's x operand goes through its producer's BN + ReLU on load (WgradP::in_scale; WMODE 0)
+template <int DMODE, bool BNB, int WMODE, bool WAOL = false>
 __global__ __launch_bounds__(256) void conv_pair_kernel(ConvP dp, WgradP wp, int gd) {
   if ((int)blockIdx.x < gd)
     conv_igemm_body<128, 128, 2, 2, DMODE, true, 0, 2, BNB, false>(dp, blockIdx.x, gd);
   else
-    conv_wgrad_ring_body<128, 128, 2, 2, WMODE, 2>(wp, blockIdx.x - gd, gridDim.x - gd);
+    conv_wgrad_ring_body<128, 128, 2, 2, WMODE, 2, WAOL>(wp, blockIdx.x - gd, gridDim.x - gd);
 }
 
-template <int DMODE, bool BNB, int WMODE>
+template <int DMODE, bool BNB, int WMODE, bool WAOL = false>
 static void pair_launch(const PairState& s) {
   static std::once_flag attr;  // the autograd thread and the main thread may both get here first
   std::call_once(attr, [] {
-    (void)hipFuncSetAttribute((const void*)conv_pair_kernel<DMODE, BNB, WMODE>,
+    (void)hipFuncSetAttribute((const void*)conv_pair_kernel<DMODE, BNB, WMODE, WAOL>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   const size_t smem = s.d_smem > s.w_smem ? s.d_smem : s.w_smem;
-  hipLaunchKernelGGL((conv_pair_kernel<DMODE, BNB, WMODE>), dim3(s.d_grid + s.w_grid), dim3(256), smem, s.st, s.dp,
-                     s.wp, s.d_grid);
+  hipLaunchKernelGGL((conv_pair_kernel<DMODE, BNB, WMODE, WAOL>), dim3(s.d_grid + s.w_grid), dim3(256), smem, s.st,
+                     s.dp, s.wp, s.d_grid);
 }
 
 template <int DMODE, bool BNB>
@@ -107,7 +108,13 @@ extern "C" int vs_conv_pair_begin(void) {
 extern "C" int vs_conv_pair_end(void) {
   PairState s = g_pair;
   g_pair = PairState();
-  if (s.have_d && s.have_w) {
+  if (s.have_d && s.have_w && s.wp.in_scale) {  // (recorded only for pointwise weight gradients: w_mode == 0)
+    switch (s.d_mode * 2 + (s.d_bnb ? 1 : 0)) {
+      case 0: pair_launch<0, false, 0, true>(s); break;  case 1: pair_launch<0, true, 0, true>(s); break;
+      case 2: pair_launch<1, false, 0, true>(s); break;  case 3: pair_launch<1, true, 0, true>(s); break;
+      case 4: pair_launch<2, false, 0, true>(s); break;  default: pair_launch<2, true, 0, true>(s); break;
+    }
+  } else if (s.have_d && s.have_w) {
 #define VS_PAIR(DM, B, WM_) pair_launch<DM, B, WM_>(s)
     const int key = s.d_mode * 4 + (s.d_bnb ? 2 : 0) + s.w_mode;
     switch (key) {
@@ -128,7 +135,15 @@ extern "C" int vs_conv_pair_end(void) {
       }
     }
     if (s.have_w) {
-      if (s.w_mode == 0)
+      if (s.wp.in_scale) {
+        static std::once_flag aattr;
+        std::call_once(aattr, [] {
+          (void)hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<128, 128, 2, 2, 0, 2, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        });
+        hipLaunchKernelGGL((conv_wgrad_ring_kernel<128, 128, 2, 2, 0, 2, true>), dim3(s.w_grid), dim3(256), s.w_smem,
+                           s.st, s.wp);
+      } else if (s.w_mode == 0)
         hipLaunchKernelGGL((conv_wgrad_ring_kernel<128, 128, 2, 2, 0, 2>), dim3(s.w_grid), dim3(256), s.w_smem, s.st, s.wp);
       else
         hipLaunchKernelGGL((conv_wgrad_ring_kernel<128, 128, 2, 2, 1, 2>), dim3(s.w_grid), dim3(256), s.w_smem, s.st, s.wp);

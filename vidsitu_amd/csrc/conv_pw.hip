@@ -36,7 +36,10 @@ __device__ __forceinline__ void pw_wait_vm(int n) {
   }
 }
 
-template <int BN, bool BNB, int EDBG = 0>
+// AOL: the activation operand is the producer's raw convolution output, BN + ReLU applied to every A fragment after
+// its LDS read (ConvP::in_scale / in_shift; the constants of the <= 512 input channels sit in the spare half of the
+// statistic rows' region).
+template <int BN, bool BNB, int EDBG = 0, bool AOL = false>
 __global__ __launch_bounds__(256) void conv_pw_kernel(ConvP p, PwGeo g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = PW_BM;
@@ -64,6 +67,13 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(ConvP p, PwGeo g) {
   char* ring = smem + b_bytes;
   char* epi = ring + g.nslot * PW_SLOT;
   float* statbuf = (float*)(epi + g.epi_bytes);
+  float* aol_tab = (float*)((char*)statbuf + 4096);  // [2][512]: scale, shift of input channel k (zero beyond K)
+  if (AOL) {
+    for (int i = tid; i < 512; i += 256) {
+      aol_tab[i] = i < p.K ? p.in_scale[i] : 0.f;
+      aol_tab[512 + i] = i < p.K ? p.in_shift[i] : 0.f;
+    }  // (published by the first chunk's barrier)
+  }
 
   typedef __attribute__((address_space(3))) char* lds_ptr_t;
   const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -134,6 +144,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(ConvP p, PwGeo g) {
   for (int d = 0; d < D; ++d) issue(d);
 
   f32x4 acc[MR][NR];
+  int m0c = 0;  // first row of the tile `compute` works on (AOL)
   auto compute = [&](int slot, int kch) __attribute__((always_inline)) {
     const char* A = ring + slot * PW_SLOT;
     const char* B = Bl + kch * BN * 128;
@@ -145,6 +156,10 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(ConvP p, PwGeo g) {
       for (int a = 0; a < MR; ++a) {
         const int row = wm * TM + a * 16 + lr;
         af[a] = *(const bf16x8*)(A + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+        if (AOL) {  // rows past M were zero-filled and have to stay zero (the statistic partials sum every tile row)
+          const bf16x8 t = aol_frag_k(af[a], aol_tab + kch * 64 + ch * 8, aol_tab + 512 + kch * 64 + ch * 8);
+          af[a] = (m0c + row < p.M) ? t : __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
+        }
       }
 #pragma unroll
       for (int b = 0; b < NR; ++b) {
@@ -164,6 +179,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(ConvP p, PwGeo g) {
   for (int ti = 0; ti < ntl; ++ti) {
     const int tm = gid + ti * g.ngroups;
     const int m0 = tm * BM;
+    m0c = m0;
 #pragma unroll
     for (int a = 0; a < MR; ++a)
 #pragma unroll
@@ -265,8 +281,30 @@ static int pw_launch_edbg(const ConvP& p, const PwGeo& g, hipStream_t st) {
   return VS_OK;
 }
 
+static int pw_launch_aol(const ConvP& p, const PwGeo& g, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)conv_pw_kernel<128, false, 0, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_pw_kernel<128, false, 0, true>), dim3(8 * g.nsl * g.gx), dim3(256), g.smem, st, p, g);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// apply on load is built for the 128-column variant without the BN-backward-sums epilogue (the c units' forward)
+bool vs_pw_aol_ok(const PwGeo& g, const ConvP& p) { return g.bn == 128 && !(p.flags & VS_CONV_BNBWD) && p.K <= 512; }
+
 int vs_pw_launch(const ConvP& p, const PwGeo& g, hipStream_t st) {
   const bool bnb = (p.flags & VS_CONV_BNBWD) != 0;
+  if (p.in_scale) {
+    if (!vs_pw_aol_ok(g, p)) {
+      vs_set_error("conv_pw: apply on load is not built for this variant");
+      return VS_ERR_UNSUPPORTED;
+    }
+    return pw_launch_aol(p, g, st);
+  }
   static const int edbg = pw_env("VS_PW_EDBG", 0);  // epilogue ablations (tools only): 1 no statistics, 2 no staging writes
   if (edbg && g.bn == 128 && !bnb) {
     if (edbg == 1) return pw_launch_edbg<1>(p, g, st);

@@ -59,6 +59,11 @@ struct ConvP {
   const float *bn_mean2, *bn_invstd2;
   float* stats2;
   int bny2_ld;
+  // Apply on load (train, the b -> c edge of a bottleneck): x is the PRODUCER unit's raw convolution output and the
+  // operand is relu(x * in_scale[c] + in_shift[c]) rounded to bf16 -- what vs_bn_apply would have written, bit for
+  // bit, formed on the A fragments after their LDS read.  NULL: x is used as it is.
+  const float* in_scale;
+  const float* in_shift;
 };
 #define VS_CONV_BNBWD (1 << 20)
 
@@ -474,4 +479,5 @@ struct PwGeo {
 };
 bool vs_pw_plan(const ConvP& p, int mode, int flags, PwGeo* out);
 int vs_pw_launch(const ConvP& p, const PwGeo& g, hipStream_t st);
+bool vs_pw_aol_ok(const PwGeo& g, const ConvP& p);
 

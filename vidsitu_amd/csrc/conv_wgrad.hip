@@ -16,6 +16,8 @@
 #include <stdlib.h>
 
 #include "common.h"
+
+#include <mutex>
 #include "glue_bodies.h"
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -34,6 +36,10 @@ struct WgradP {
   int xcd_order;  // 1: XCD-aware block order (default); 0: round-robin (VS_WGRAD_XCD=0, A/B)
   int dbg;        // VS_WGRAD_DBG ablations of the ring kernel (wrong results; tools only): 1 no MFMA, 2 no copies in
                   // the loop, 4 no vmcnt wait, 8 no barrier, 16 no fragment reads, 32 no table rebuild, 64 no epilogue
+  // Apply on load (pointwise ring launches): x is the producer unit's RAW convolution output and the operand is
+  // relu(x * in_scale[c] + in_shift[c]) rounded to bf16 (vs_bn_apply's bits), formed on the fragments.  NULL: off.
+  const float* in_scale;
+  const float* in_shift;
 };
 
 #define WG_OOB 0x80000000u
@@ -266,8 +272,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
 // double buffered and rebuilt one chunk ahead, so the pipeline never drains inside a block
 // (the register-staged kernel restarts it every 1024 positions).
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int MODE, int NS>
+template <int BM, int BN, int WM, int WN, int MODE, int NS, bool AOL = false>
 __device__ __forceinline__ void conv_wgrad_ring_body(const WgradP& p, const int blk, const int nblk) {
+  static_assert(!AOL || MODE == 0, "apply on load: pointwise launches");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MR = TM / 16, NR = TN / 16;
@@ -412,6 +419,14 @@ __device__ __forceinline__ void conv_wgrad_ring_body(const WgradP& p, const int 
 #pragma unroll
     for (int b = 0; b < NR; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // AOL: a lane's x fragment of n-tile b holds 8 positions of ONE input channel (the column it also stores)
+  float asc[NR], ash[NR];
+#pragma unroll
+  for (int b = 0; b < NR; ++b) {
+    const int col = n0 + wn * TN + b * 16 + li;
+    asc[b] = (AOL && col < p.Kp) ? p.in_scale[col] : 0.f;
+    ash[b] = (AOL && col < p.Kp) ? p.in_shift[col] : 0.f;
+  }
   auto compute = [&](int stage) __attribute__((always_inline)) {
     const char* A = smem + stage * STAGE;
     const char* B = A + IMG;
@@ -436,6 +451,7 @@ __device__ __forceinline__ void conv_wgrad_ring_body(const WgradP& p, const int 
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)ptr);
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ptr + 128));
         bfr[b] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        if (AOL) bfr[b] = aol_frag_n(bfr[b], asc[b], ash[b]);
       }
 #pragma unroll
       for (int a = 0; a < MR; ++a)
@@ -482,9 +498,9 @@ __device__ __forceinline__ void conv_wgrad_ring_body(const WgradP& p, const int 
     }
 }
 
-template <int BM, int BN, int WM, int WN, int MODE, int NS>
+template <int BM, int BN, int WM, int WN, int MODE, int NS, bool AOL = false>
 __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradP p) {
-  conv_wgrad_ring_body<BM, BN, WM, WN, MODE, NS>(p, blockIdx.x, gridDim.x);
+  conv_wgrad_ring_body<BM, BN, WM, WN, MODE, NS, AOL>(p, blockIdx.x, gridDim.x);
 }
 
 // dw[i] = sum_s slab[s][i], bitwise reproducible: block = 16 float4 columns x 16 slab slices,
@@ -747,6 +763,18 @@ static int wg_launch(const WgradP& p, int mode, int ring, hipStream_t st) {
     if constexpr (BM == 128 && BN == 128) {
       if (ring == 2 && pair_take_wgrad(p, grid, smem, mode, st)) return VS_OK;
     }
+    if (p.in_scale) {  // apply on load: wgrad_aol_ok admitted only (128-row tile, 2-stage ring, pointwise)
+      if constexpr (BM == 128) {
+        static std::once_flag aattr;
+        std::call_once(aattr, [] {
+          (void)hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<BM, BN, WM, WN, 0, 2, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        });
+        hipLaunchKernelGGL((conv_wgrad_ring_kernel<BM, BN, WM, WN, 0, 2, true>), dim3(grid), dim3(256), smem, st, p);
+        VS_CHECK_LAUNCH();
+        return VS_OK;
+      }
+    }
     if (ring == 2 && mode == 0)
       hipLaunchKernelGGL((conv_wgrad_ring_kernel<BM, BN, WM, WN, 0, 2>), dim3(grid), dim3(256), smem, st, p);
     else if (ring == 2)
@@ -767,8 +795,18 @@ static int wg_launch(const WgradP& p, int mode, int ring, hipStream_t st) {
   return VS_OK;
 }
 
+// the launch apply on load is built for: pointwise, unit stride, the 128-row tiles on the two-stage ring
+static bool wgrad_aol_plan_ok(const vs_conv_desc* d) {
+  const bool dense = (d->kT * d->kH * d->kW == 1) && d->sT == 1 && d->sH == 1 && d->sW == 1 &&
+                     d->pT == 0 && d->pH == 0 && d->pW == 0;
+  if (!dense || ((d->flags >> 16) & 7) || ((d->flags >> 8) & 0xf)) return false;
+  const WgCfg c = wg_pick(d);
+  return c.bm == 128 && (c.bn == 128 || c.bn == 64);
+}
+
 static int wgrad_impl(const void* dy, const void* x, float* dw, const vs_conv_desc* d, void* workspace,
-                      size_t ws_bytes, void* stream, bool reduce_now, int* splits_out) {
+                      size_t ws_bytes, void* stream, bool reduce_now, int* splits_out,
+                      const float* in_scale = nullptr, const float* in_shift = nullptr) {
   VS_CHECK_ARG(d && dy && x && dw, "null argument");
   VS_CHECK_ARG(d->Cin % 8 == 0 && d->Cout % 8 == 0, "Cin and Cout must be multiples of 8");
   VS_CHECK_ARG(d->x_ld % 8 == 0 && d->y_ld % 8 == 0, "row pitches must be multiples of 8");
@@ -780,9 +818,15 @@ static int wgrad_impl(const void* dy, const void* x, float* dw, const vs_conv_de
     return VS_ERR_WORKSPACE;
   }
   if (g_pending.have && ((const void*)g_pending.r.slabs == workspace || g_pending.r.dw == dw)) pending_flush();
+  if (in_scale && !wgrad_aol_plan_ok(d)) {
+    vs_set_error("vs_conv_wgrad_aol: apply on load is not built for this weight gradient (ask vs_conv_wgrad_aol_ok)");
+    return VS_ERR_UNSUPPORTED;
+  }
   WgradP p;
   p.dy = (const uint16_t*)dy;
   p.x = (const uint16_t*)x;
+  p.in_scale = in_scale;
+  p.in_shift = in_shift;
   p.out = c.S > 1 ? (float*)workspace : dw;
   p.P = d->N * d->To * d->Ho * d->Wo;
   p.Cout = d->Cout;
@@ -853,6 +897,16 @@ extern "C" int vs_conv_wgrad(const void* dy, const void* x, float* dw, const vs_
                              void* workspace,
                              size_t ws_bytes, void* stream) {
   return wgrad_impl(dy, x, dw, d, workspace, ws_bytes, stream, true, nullptr);
+}
+
+// dW of a 1x1x1 convolution whose input is relu(x * in_scale[c] + in_shift[c]) with x the producer unit's raw output
+// (see vs_conv_fwd_aol): the operand vs_bn_apply would have stored, formed on the fragments.  _ok: 1 where built.
+extern "C" int vs_conv_wgrad_aol_ok(const vs_conv_desc* d) { return (d && wgrad_aol_plan_ok(d)) ? 1 : 0; }
+
+extern "C" int vs_conv_wgrad_aol(const void* dy, const void* x, float* dw, const vs_conv_desc* d, const float* in_scale,
+                                 const float* in_shift, void* workspace, size_t ws_bytes, void* stream) {
+  VS_CHECK_ARG(in_scale && in_shift, "null constants");
+  return wgrad_impl(dy, x, dw, d, workspace, ws_bytes, stream, true, nullptr, in_scale, in_shift);
 }
 
 extern "C" int vs_conv_wgrad_partial(const void* dy, const void* x, float* dw, const vs_conv_desc* d, void* slabs,

@@ -196,6 +196,54 @@ def conv_fwd(x, w, k, s, p, out=None, scale=None, shift=None, residual=None, rel
     return out, partials
 
 
+_K1, _S1, _P0 = (1, 1, 1), (1, 1, 1), (0, 0, 0)
+
+
+def conv_aol_ok(x, cout, stats=True):
+    """True if a 1x1x1 convolution of x to cout channels can take x as its producer's RAW output (conv_fwd_aol) AND
+    its weight gradient can (conv_wgrad_aol): both or neither, the activation is then never stored."""
+    ys = conv_out_shape(x.shape, cout, _K1, _S1, _P0)
+    d = make_desc(x.shape, act_ld(x), ys, cout, _K1, _S1, _P0, VS_CONV_STATS if stats else 0)
+    lib = _lib.load()
+    return bool(lib.vs_conv_aol_ok(C.byref(d))) and bool(lib.vs_conv_wgrad_aol_ok(C.byref(d)))
+
+
+def conv_fwd_aol(x, w, in_scale, in_shift, out=None, stats=True):
+    """conv1x1(relu(x * in_scale + in_shift), w): x is the producer unit's raw convolution output, the operand is the
+    tensor bn_apply(x, in_scale, in_shift, relu=True) would have stored (same bits), formed on load.
+    Returns (y, partials|None)."""
+    cout = w.shape[0]
+    ys = conv_out_shape(x.shape, cout, _K1, _S1, _P0)
+    if out is None:
+        out = new_act(*ys, device=x.device)
+    elif tuple(out.shape) != ys:
+        raise _lib.VsError(f"conv out shape {tuple(out.shape)} != {ys}")
+    check_weight(w, cout, x.shape[1], _K1)
+    d = make_desc(x.shape, act_ld(x), ys, act_ld(out), _K1, _S1, _P0, VS_CONV_STATS if stats else 0)
+    partials = None
+    if stats:
+        rows = _lib.load().vs_conv_stats_rows(C.byref(d))
+        partials = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
+    _lib.call("vs_conv_fwd_aol", _ptr(x), _ptr(w), _ptr(out), C.byref(d), _ptr(in_scale), _ptr(in_shift),
+              _ptr(partials), _stream())
+    return out, partials
+
+
+def conv_wgrad_aol(dy, x, in_scale, in_shift, out=None):
+    """dW of the convolution of conv_fwd_aol (x: the producer's raw output)."""
+    cout, cin = dy.shape[1], x.shape[1]
+    if out is None:
+        out = torch.empty((cout, 1, 1, 1, cin), dtype=torch.float32, device=x.device).permute(0, 4, 1, 2, 3)
+    elif not out.permute(0, 2, 3, 4, 1).is_contiguous() or out.dtype != torch.float32:
+        raise _lib.VsError("conv_wgrad out must be fp32 with [Cout][taps][Cin] memory")
+    d = make_desc(x.shape, act_ld(x), dy.shape, act_ld(dy), _K1, _S1, _P0, 0)
+    need = _lib.load().vs_conv_wgrad_workspace_bytes(C.byref(d))
+    ws = _workspace(need, x.device) if need else None
+    _lib.call("vs_conv_wgrad_aol", _ptr(dy), _ptr(x), _ptr(out), C.byref(d), _ptr(in_scale), _ptr(in_shift),
+              _ptr(ws), C.c_size_t(ws.numel() if ws is not None else 0), _stream())
+    return out
+
+
 def _bc_desc(x, wb, k, s, p):
     ys = conv_out_shape(x.shape, wb.shape[0], k, s, p)
     return ys, make_desc(x.shape, act_ld(x), ys, wb.shape[0], k, s, p, VS_CONV_AFFINE | VS_CONV_RELU)
