@@ -717,3 +717,49 @@ def test_eval_fused_bc_blocks_match_the_two_launch_blocks_and_save_thirteen_laun
     assert got[False][1] - got[True][1] == 13, (got[False][1], got[True][1])
     err = (got[True][0] - got[False][0]).abs().max().item() / got[False][0].abs().max().item()
     assert err < 2e-3, err
+
+
+def test_apply_on_load_train_step_is_bitwise_and_launches_fewer_kernels(dev):
+    """`ResBlock.aol` (VS_TRAIN_AOL=1): the b unit of a slow-pathway bottleneck stops behind its finalize and the c unit's
+    forward and weight gradient form relu(y * scale + shift) on their operand fragments (vs_conv_fwd_aol /
+    vs_conv_wgrad_aol) -- features, running statistics and every gradient of a SlowFast-R50 train-mode pass at 224^2
+    bit for bit those of the pass that stores the activation, with one vs_bn_apply launch fewer per such block."""
+    from oracle.slowfast_ref import default_sf_cfg
+    from vidsitu_amd import _lib, trunk as T
+
+    torch.manual_seed(3)
+    cfg = default_sf_cfg("slowfast", 50, 64, 32)
+    mdl = T.VideoTrunk(cfg).to(dev).train()
+    g = torch.Generator().manual_seed(4)
+    fast = torch.randn(2, 3, 32, 224, 224, generator=g).to(dev)
+    xs = [fast[:, :, ::4].contiguous(), fast]
+    bufs = {k: v.clone() for k, v in mdl.named_buffers()}
+    lib = _lib.load()
+
+    def run(aol):
+        T.ResBlock.aol = aol
+        for k, v in mdl.named_buffers():
+            v.copy_(bufs[k])
+        for p in mdl.parameters():
+            p.grad = None
+        torch.cuda.synchronize()
+        n0 = lib.vs_launch_count()
+        feats = mdl.forward_features([x.clone() for x in xs])
+        gg = torch.Generator().manual_seed(5)
+        sum((f.float() * torch.randn(f.shape, generator=gg).to(dev)).sum() for f in feats).backward()
+        torch.cuda.synchronize()
+        return ([f.detach().clone() for f in feats], {k: p.grad.clone() for k, p in mdl.named_parameters()},
+                {k: v.clone() for k, v in mdl.named_buffers()}, lib.vs_launch_count() - n0)
+
+    saved = T.ResBlock.aol
+    try:
+        f0, g0, b0, n_off = run(False)
+        f1, g1, b1, n_on = run(True)
+    finally:
+        T.ResBlock.aol = saved
+    assert n_off - n_on >= 4, (n_off, n_on)  # at 2 clips the s2 / s3 blocks' plans have the transform
+    assert all(torch.equal(a, b) for a, b in zip(f0, f1))
+    bad = [k for k in g0 if not torch.equal(g0[k], g1[k])]
+    assert not bad, bad[:5]
+    bad = [k for k in b0 if not torch.equal(b0[k], b1[k])]
+    assert not bad, bad[:5]

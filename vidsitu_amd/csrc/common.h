@@ -72,29 +72,40 @@ __device__ __forceinline__ uint4 pack8_bf16(const float* f) {
 }
 
 // One operand fragment (8 bf16) through the BN + ReLU of its producer: the arithmetic of bn_apply_cols_kernel<false,
-// true> (fma, max, round to nearest even).  _k: the 8 elements are 8 consecutive channels (sc / sh point at their
-// constants); _n: one channel, 8 positions.
+// true> (fma, max, round to nearest even), same bits -- here as fma, ONE v_cvt_pk_bf16_f32 per pair and the ReLU on the
+// rounded pair as a packed signed-16-bit max with 0 (rounding keeps the sign, so max-then-round == round-then-max;
+// -0 becomes +0 either way).  _k: the 8 elements are 8 consecutive channels (sc / sh point at their constants);
+// _n: one channel, 8 positions.  (No v_pk_fma_f32: see profiles/r03_linear_fused_neighbor.txt.)
+typedef __attribute__((ext_vector_type(2))) float vs_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 vs_bf16x2;
+typedef __attribute__((ext_vector_type(2))) short vs_s16x2;
+__device__ __forceinline__ uint32_t aol_pair(float lo, float hi) {
+  const vs_bf16x2 h = __builtin_convertvector((vs_f32x2){lo, hi}, vs_bf16x2);
+  vs_s16x2 v = __builtin_bit_cast(vs_s16x2, h);
+  v = __builtin_elementwise_max(v, (vs_s16x2){0, 0});
+  return __builtin_bit_cast(uint32_t, v);
+}
 __device__ __forceinline__ bf16x8 aol_frag_k(const bf16x8 v, const float* sc, const float* sh) {
   float f[8];
   unpack8_bf16(__builtin_bit_cast(uint4, v), f);
   const float4 s0 = *(const float4*)sc, s1 = *(const float4*)(sc + 4);
   const float4 h0 = *(const float4*)sh, h1 = *(const float4*)(sh + 4);
-  f[0] = fmaxf(__fmaf_rn(f[0], s0.x, h0.x), 0.f);
-  f[1] = fmaxf(__fmaf_rn(f[1], s0.y, h0.y), 0.f);
-  f[2] = fmaxf(__fmaf_rn(f[2], s0.z, h0.z), 0.f);
-  f[3] = fmaxf(__fmaf_rn(f[3], s0.w, h0.w), 0.f);
-  f[4] = fmaxf(__fmaf_rn(f[4], s1.x, h1.x), 0.f);
-  f[5] = fmaxf(__fmaf_rn(f[5], s1.y, h1.y), 0.f);
-  f[6] = fmaxf(__fmaf_rn(f[6], s1.z, h1.z), 0.f);
-  f[7] = fmaxf(__fmaf_rn(f[7], s1.w, h1.w), 0.f);
-  return __builtin_bit_cast(bf16x8, pack8_bf16(f));
+  uint4 o;
+  o.x = aol_pair(__fmaf_rn(f[0], s0.x, h0.x), __fmaf_rn(f[1], s0.y, h0.y));
+  o.y = aol_pair(__fmaf_rn(f[2], s0.z, h0.z), __fmaf_rn(f[3], s0.w, h0.w));
+  o.z = aol_pair(__fmaf_rn(f[4], s1.x, h1.x), __fmaf_rn(f[5], s1.y, h1.y));
+  o.w = aol_pair(__fmaf_rn(f[6], s1.z, h1.z), __fmaf_rn(f[7], s1.w, h1.w));
+  return __builtin_bit_cast(bf16x8, o);
 }
 __device__ __forceinline__ bf16x8 aol_frag_n(const bf16x8 v, const float sc, const float sh) {
   float f[8];
   unpack8_bf16(__builtin_bit_cast(uint4, v), f);
-#pragma unroll
-  for (int e = 0; e < 8; ++e) f[e] = fmaxf(__fmaf_rn(f[e], sc, sh), 0.f);
-  return __builtin_bit_cast(bf16x8, pack8_bf16(f));
+  uint4 o;
+  o.x = aol_pair(__fmaf_rn(f[0], sc, sh), __fmaf_rn(f[1], sc, sh));
+  o.y = aol_pair(__fmaf_rn(f[2], sc, sh), __fmaf_rn(f[3], sc, sh));
+  o.z = aol_pair(__fmaf_rn(f[4], sc, sh), __fmaf_rn(f[5], sc, sh));
+  o.w = aol_pair(__fmaf_rn(f[6], sc, sh), __fmaf_rn(f[7], sc, sh));
+  return __builtin_bit_cast(bf16x8, o);
 }
 
 // x = q * d + r for 0 <= x < 2^24, rcp = 1.0f / d (float quotient, two fix-ups): ~8 instructions where a runtime

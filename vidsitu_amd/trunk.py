@@ -244,9 +244,14 @@ class _Unit:
     _zeros = {}
 
     @staticmethod
-    def fwd(conv, bn, x, relu, residual=None, out=None, train=False, saved=None, pool=False):
+    def fwd(conv, bn, x, relu, residual=None, out=None, train=False, saved=None, pool=False, no_apply=False,
+            x_affine=None):
         """pool (train mode, the stems): the unit's output goes through the [1,3,3] max-pool and nowhere else --
-        BN + ReLU + pool run as one pass, the record gets the argmax bytes (`pool_idx`) and no `z`."""
+        BN + ReLU + pool run as one pass, the record gets the argmax bytes (`pool_idx`) and no `z`.
+        Apply on load (train mode, `ResBlock.aol`): `no_apply` -- the unit stops behind its finalize and returns
+        (y, (scale, shift)); its consumer is called with `x` = that raw y and `x_affine` = the constants and forms
+        relu(y * scale + shift) on its operand fragments (ops.conv_fwd_aol / conv_wgrad_aol): the activation is never
+        stored."""
         if not train:
             scale, shift = bn.fold
             if conv.bias is not None:  # BN(conv + b) folded: the bias joins the shift
@@ -278,11 +283,13 @@ class _Unit:
         if conv.is_stem:
             y, partials = ops.stem_conv_fwd(x[0], conv.w_stem, conv.cout, conv.k[0], stats=True)
             x = x[0]  # the stem wgrad kernel reads the same C=4 packed input
+        elif x_affine is not None:
+            y, partials = ops.conv_fwd_aol(x, conv.w_bf16, x_affine[0], x_affine[1], stats=True)
         else:
             y, partials = ops.conv_fwd(x, conv.w_bf16, conv.k, conv.s, conv.p, stats=True)
         # the apply pass finalizes for itself where the partial-row count allows it (ops.bn_apply_fin: no finalize
         # launch on the chain); the pooled stems and debug traces keep the separate launches
-        fin_fused = (not pool and _Unit.trace is None and y.is_cuda
+        fin_fused = (not pool and not no_apply and _Unit.trace is None and y.is_cuda
                      and ops.bn_fin_fusable(partials.shape[0], y.shape[1]))
         if not fin_fused:
             scale, shift, mean, invstd = ops.bn_finalize(
@@ -293,6 +300,11 @@ class _Unit:
             # only the running mean sees it: mean(conv + b) = mean(conv) + b
             with torch.no_grad():
                 bn.running_mean.add_(conv.bias.detach() * bn.momentum)
+        if no_apply:  # the consumer applies scale / shift / ReLU on load; backward recomputes the mask from y
+            assert relu and residual is None and not pool
+            saved.append(dict(conv=conv, bn=bn, x=x, y=y, z=None, zbits=None, mean=mean, invstd=invstd,
+                              relu=True, has_res=False, aol=True, x_affine=x_affine))
+            return y, (scale, shift)
         # a unit with a residual input cannot recompute its ReLU mask from y alone: keep it as bits
         if pool and not ops.bn_apply_maxpool_ok(y):
             pool, out = False, None  # the caller pools z itself (`out` was meant for the pooled tensor)
@@ -313,7 +325,7 @@ class _Unit:
         if _Unit.trace is not None:
             _Unit.trace.append((conv, y.float().cpu(), z.float().cpu(), mean.cpu(), invstd.cpu()))
         saved.append(dict(conv=conv, bn=bn, x=x, y=y, z=z, zbits=zbits, mean=mean, invstd=invstd,
-                          relu=relu, has_res=residual is not None))
+                          relu=relu, has_res=residual is not None, x_affine=x_affine))
         return z
 
     @staticmethod
@@ -357,15 +369,17 @@ class _Unit:
         pair_ctx = ops.conv_pair() if pair else contextlib.nullcontext()
         pair_ctx.__enter__()
         try:
-            dx = _Unit._bwd_convs(conv, dy, x, need_dx, producer, dx_residual, dx_residual_bits, inplace, pair)
+            dx = _Unit._bwd_convs(conv, dy, x, need_dx, producer, dx_residual, dx_residual_bits, inplace, pair,
+                                  rec.get("x_affine"))
         finally:
             pair_ctx.__exit__(None, None, None)
         _WgradLanes.join_unit()  # wgrad || dgrad of this unit (and, with a lag, of the next units)
         return dx, dres
 
     @staticmethod
-    def _bwd_convs(conv, dy, x, need_dx, producer, dx_residual, dx_residual_bits, inplace, pair):
-        """The unit's weight gradient (side lane, or inline when `pair`) and data gradient."""
+    def _bwd_convs(conv, dy, x, need_dx, producer, dx_residual, dx_residual_bits, inplace, pair, x_affine=None):
+        """The unit's weight gradient (side lane, or inline when `pair`) and data gradient.  x_affine: x is the
+        producer's raw output, the weight gradient applies its BN + ReLU on load."""
         if conv.is_stem:
             _WgradLanes.run(lambda: _set_grad(conv.weight, ops.stem_conv_wgrad(dy, x, conv.k[0])) and None, dy, x)
         elif conv.cin_pad == conv.cin:
@@ -377,7 +391,10 @@ class _Unit:
             gf = 2e-9 * dy.numel() * conv.cin * conv.k[0] * conv.k[1] * conv.k[2]  # the unit's GEMM, GFLOP
             if pair:
                 gf = -1.0  # inline
-            if batch is not None:
+            if x_affine is not None:
+                _WgradLanes.run(lambda: (ops.conv_wgrad_aol(dy, x, x_affine[0], x_affine[1], out=conv.weight.grad),
+                                         None)[1], dy, x, gflop=gf)
+            elif batch is not None:
                 _WgradLanes.run(lambda: (ops.conv_wgrad(dy, x, conv.k, conv.s, conv.p, out=conv.weight.grad,
                                                         batch=batch), None)[1], dy, x, gflop=gf)
             elif _Unit.split_wgrad_reduce:
@@ -396,7 +413,7 @@ class _Unit:
             # the producer's complete dz is this dx when its output feeds this convolution and -- with
             # dx_residual -- the branch whose gradient arrives as that residual, and nothing else
             fuse = (_Unit.fuse_bn_sums and producer is not None and "conv" in producer and producer["relu"]
-                    and producer["z"] is x)
+                    and (producer["y"] is x if producer.get("aol") else producer["z"] is x))
             if fuse and dx_residual is None:
                 fuse = not producer["has_res"] and producer.get("zbits") is None
             elif fuse:
@@ -506,6 +523,24 @@ class ResBlock(nn.Module):
     # (ops.conv_fwd_bc: the inner tensor stays in LDS).  VS_EVAL_FUSE_BC=0: two launches (A/B switch).
     fuse_bc = os.environ.get("VS_EVAL_FUSE_BC", "1") != "0"
 
+    # Train: the b -> c edge without the stored activation (apply on load, `_Unit.fwd(no_apply / x_affine)`) where the
+    # c unit's forward and weight-gradient plans have the fragment transform (slow pathway).  VS_TRAIN_AOL=0 / 1.
+    aol = os.environ.get("VS_TRAIN_AOL", "0") == "1"
+
+    def _aol_ok(self, a, saved):
+        b2 = self.branch2
+        if (not ResBlock.aol or saved is None or not a.is_cuda or _Unit.trace is not None or _Unit.wgrad_batch is not None
+                or _Unit.split_wgrad_reduce or b2.b.bias is not None or b2.c.bias is not None
+                or b2.c.cin_pad != b2.c.cin):
+            return False
+        key = ("aol",) + tuple(a.shape)
+        hit = self.__dict__.setdefault("_bc_ok", {}).get(key)
+        if hit is None:
+            yb_shape = ops.conv_out_shape(a.shape, b2.b.cout, b2.b.k, b2.b.s, b2.b.p)
+            probe = ops.new_act(*yb_shape, device=a.device)  # (shape / pitch carrier for the plan query)
+            hit = self._bc_ok[key] = ops.conv_aol_ok(probe, b2.c.cout)
+        return hit
+
     def _bc_fusable(self, a):
         b2 = self.branch2
         if (not ResBlock.fuse_bc or _Unit.split_weights or ResBlock.residual_fp32 or not a.is_cuda
@@ -523,6 +558,12 @@ class ResBlock(nn.Module):
         if self.has_sc:
             sc = _Unit.fwd(self.branch1, self.branch1_bn, x, False, train=train, saved=saved)
         a = _Unit.fwd(b2.a, b2.a_bn, x, True, train=train, saved=saved)
+        if train and self._aol_ok(a, saved):
+            yb, aff = _Unit.fwd(b2.b, b2.b_bn, a, True, train=True, saved=saved, no_apply=True)
+            z = _Unit.fwd(b2.c, b2.c_bn, yb, True, residual=sc, out=out, train=True, saved=saved, x_affine=aff)
+            if self.has_sc and saved is not None and len(saved) >= 4:
+                saved[-1]["sc_rec"] = saved[-4]
+            return z
         if not train and self._bc_fusable(a):
             (sb, hb), (s_c, h_c) = b2.b_bn.fold, b2.c_bn.fold
             return ops.conv_fwd_bc(a, b2.b.w_bf16, b2.b.k, b2.b.s, b2.b.p, sb, hb, b2.c.w_bf16, s_c, h_c,
