@@ -871,23 +871,8 @@ def linear_bwd(dy, x, w, need_dx=True, has_bias=True, dw_out=None, db_out=None, 
                 db = db_out if db_out is not None else torch.empty(n, dtype=torch.float32, device=x.device)
             if dx_res is not None and (dx_res.dtype != torch.float32 or not dx_res.is_contiguous()):
                 dx_res = _f32c(dx_res)
-            _dbg = _os.environ.get("VS_LBF_DBG", "")
-            if "x" in _dbg:
-                x = x.clone()
-            if "y" in _dbg:
-                dy = dy.clone()
-            dw_real = None
-            if "w" in _dbg and dw_out is not None:
-                dw_real, dw = dw, torch.empty_like(dw)
-            if "p" in _dbg:
-                torch.cuda.synchronize()
             _lib.call("vs_linear_bwd_fused_res", _ptr(dy), _ptr(relu_y), _ptr(x), _ptr(wt), _ptr(dx_res), _ptr(dx),
                       _ptr(dw), _ptr(db), m, n, k, _stream())
-            if "s" in _dbg:
-                torch.cuda.synchronize()
-            if dw_real is not None:
-                dw_real.copy_(dw)
-                dw = dw_real
             return dx, dw, db
     if relu_y is not None:
         dy = relu_bwd(dy, relu_y)
