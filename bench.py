@@ -488,7 +488,8 @@ def main():
     train = args.workload == "sf_txenc_train"
     overrides = {"mdl.mdl_name": "sf_base_txenc" if train else "sf_base"}
     if train:
-        overrides.update({"tx_dec.encoder_layers": 6})  # dropout stays at the reference's 0.1
+        # dropout stays at the reference's 0.1.  VS_BENCH_ENC_LAYERS: probe only (cost of the 8-token section per layer)
+        overrides.update({"tx_dec.encoder_layers": int(os.environ.get("VS_BENCH_ENC_LAYERS", "6"))})
     cfg = get_cfg(overrides)
     comm = synth_data.make_comm(cfg)
     torch.manual_seed(0)
@@ -715,6 +716,8 @@ def main():
                        "clips_per_gpu": CLIPS_PER_GPU, "hipgraph": used_graph,
                        **({} if CLIPS_PER_GPU == 8 else
                           {"probe": f"{CLIPS_PER_GPU} clips/GPU instead of the BASELINE config's 8: not the headline metric"}),
+                       **({"probe_enc_layers": os.environ["VS_BENCH_ENC_LAYERS"]}
+                          if train and os.environ.get("VS_BENCH_ENC_LAYERS", "6") != "6" else {}),
                        **({} if train else {"parity": eval_parity_note()}),
                        "grad_allreduce": (None if ts is None else
                                           (f"{len(ts.segments)} bucket(s), "
