@@ -418,6 +418,22 @@ int64_t vs_conv_pair_count(void);
  * a barrier wait exceeds its iteration cap (the blocks then leave instead of hanging the GPU).
  * `smem_bytes`: dynamic LDS = 32 bytes x the widest inner dimension of a LIN / LINBWD stage (>= 8320). */
 int vs_txenc_stack_run(const void* stages, int nstages, void* barriers, int grid, int smem_bytes, void* stream);
+/* LayerNorm in the prologue of the linear that consumes it (<= 8 rows, D <= 1024): utils/transformer_code.py
+ * ResidualBlock.forward's `self.layernorm(x[0] + self.dropout(self.layer(*x)))` followed by the next block's first
+ * nn.Linear (FeedForward.linear1 / the fused q|k|v projection) as ONE launch, and in the backward the LayerNorm's
+ * backward followed by the backward of the linear whose output gradient it produces (FeedForward.linear2 /
+ * MultiHead.wo).  Same bodies as vs_add_layernorm_fwd / _bwd and vs_linear_fwd / vs_linear_bwd_fused: same bits.
+ *   fwd: y_ln [M][K] = LayerNorm(x + r * rmask) (stored with mean / rstd [M]); y [M][N] = act(y_ln . w^T + b)
+ *   bwd: dx_ln [M][D], dgamma / dbeta [D] of the LayerNorm for the output gradient dy; dr = dx_ln * rmask is the
+ *        output gradient of the linear x_lin [M][K] -> [M][D] (wt: its [D][K]... weight image as vs_linear_bwd_fused
+ *        takes it): dx_lin [M][K], dw [D][K], db [D] (or NULL). */
+int vs_ln_linear_fwd(const float* x, const float* r, const float* rmask, const float* gamma, const float* beta,
+                     float eps, float* y_ln, float* mean, float* rstd, const float* w, const float* b, float* y,
+                     int M, int N, int K, int relu, void* stream);
+int vs_ln_bwd_linear_bwd(const float* dy, const float* x_ln, const float* r, const float* rmask, const float* gamma,
+                         const float* mean, const float* rstd, float* dx_ln, float* dgamma, float* dbeta,
+                         const float* x_lin, const float* wt, float* dx_lin, float* dw, float* db, int M, int D,
+                         int K, void* stream);
 
 /* softmax(Q_h K_h^T / scale) V_h for short sequences (L <= 16), per head.
  * q,k,v,o: [B, L, H*dh] fp32.  utils/transformer_code.py:33-48,60-68 --

@@ -412,3 +412,85 @@ def test_txstack_stage_kinds_are_bitwise_the_stand_alone_ops(dev):
     refs = (dx_ref, dw_ref, dxl, drl, dg_ref, db_ref, dxl + drl, dq_ref)
     for name, got, ref in zip(("dx", "dw", "ln dx", "ln dr", "dgamma", "dbeta", "add", "dqkv"), run(bwd), refs):
         assert torch.equal(got, ref), name
+
+
+@pytest.mark.parametrize("layers,b,l,drop,d", [(2, 2, 4, 0.1, 512), (6, 2, 4, 0.1, 512), (3, 1, 5, 0.0, 1024),
+                                               (2, 1, 8, 0.1, 256)])
+def test_layernorm_in_the_prologue_of_its_consumer_is_bitwise_the_separate_launches(layers, b, l, drop, d, dev,
+                                                                                      monkeypatch):
+    """`_Lazy` (round 3): a LayerNorm's forward runs in the prologue of the linear that consumes it (vs_ln_linear_fwd) and
+    its backward in front of the backward of the linear whose output gradient it produces (vs_ln_bwd_linear_bwd) --
+    every layer output, the input gradient and every parameter gradient bit for bit those of the separate launches,
+    and the fused launches actually happen: 2 per layer forward (the last LayerNorm has no consumer in the encoder),
+    2 per layer backward."""
+    from vidsitu_amd import transformer_code as T
+    from vidsitu_amd.optim import ParamArena
+
+    torch.manual_seed(3)
+    mdl = T.Transformer(d_model=d, n_vocab_src=0, vocab_trg=0, d_hidden=2 * d, n_layers=layers, n_heads=8,
+                        drop_ratio=drop, pe=False).to(dev).train()
+    arena = ParamArena(mdl)
+    x0 = torch.randn(b, l, d, device=dev)
+    dy = torch.randn(b, l, d, device=dev)
+    monkeypatch.setenv("VS_TXENC_STACK", "0")
+
+    def run(fuse):
+        monkeypatch.setattr(T._Lazy, "enabled", fuse)
+        T._Lazy.fused[:] = [0, 0]
+        arena.grad.fill_(float("nan"))
+        for off, nxt, p in zip(arena.offsets, arena.offsets[1:], arena.params):
+            arena.grad[off + p.numel():nxt].zero_()
+        torch.manual_seed(11)
+        T._masks.__init__()
+        x = x0.clone().requires_grad_()
+        outs = mdl.encoder(x)
+        outs[-1].backward(dy)
+        torch.cuda.synchronize()
+        assert T._Lazy.fwd is None and T._Lazy.bwd is None
+        return [o.detach().clone() for o in outs[1:]], x.grad.clone(), arena.grad.clone(), list(T._Lazy.fused)
+
+    o0, dx0, g0, n0 = run(False)
+    o1, dx1, g1, n1 = run(True)
+    assert n0 == [0, 0] and n1 == [2 * layers - 1, 2 * layers], (n0, n1)
+    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    for i, (a, c) in enumerate(zip(o0, o1)):
+        assert torch.equal(a, c), f"layer {i} output: max diff {float((a - c).abs().max()):.3e}"
+    bad = [f"{k} ({float((g0[off:off + p.numel()] - g1[off:off + p.numel()]).abs().max()):.1e})"
+           for (k, p), off in zip(mdl.named_parameters(), arena.offsets)
+           if not torch.equal(g0[off:off + p.numel()], g1[off:off + p.numel()])]
+    assert not bad, f"parameter gradients differ: {bad}"
+    assert torch.equal(dx0, dx1), f"dx: max diff {float((dx0 - dx1).abs().max()):.3e}"
+
+
+def test_parked_layernorm_is_flushed_for_any_other_reader(dev, monkeypatch):
+    """Without a parameter arena (no in-place gradients, three separate q / k / v linears) the backward never parks and
+    the forward's parked LayerNorm is taken by the first of the three projections; an encoder used without gradients
+    does not park at all: same results as the separate launches."""
+    from vidsitu_amd import transformer_code as T
+
+    d, layers, b, l = 256, 2, 1, 6
+    torch.manual_seed(5)
+    mdl = T.Transformer(d_model=d, n_vocab_src=0, vocab_trg=0, d_hidden=512, n_layers=layers, n_heads=8,
+                        drop_ratio=0.0, pe=False).to(dev).train()
+    x0, dy = torch.randn(b, l, d, device=dev), torch.randn(b, l, d, device=dev)
+    monkeypatch.setenv("VS_TXENC_STACK", "0")
+
+    def run(fuse):
+        monkeypatch.setattr(T._Lazy, "enabled", fuse)
+        T._Lazy.fused[:] = [0, 0]
+        for p in mdl.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_()
+        out = mdl.encoder(x)[-1]
+        out.backward(dy)
+        with torch.no_grad():
+            out_ng = mdl.encoder(x0)[-1]
+        torch.cuda.synchronize()
+        return out.detach().clone(), out_ng.clone(), x.grad.clone(), [p.grad.clone() for p in mdl.parameters()], \
+            list(T._Lazy.fused)
+
+    o0, e0, dx0, g0, n0 = run(False)
+    o1, e1, dx1, g1, n1 = run(True)
+    assert n0 == [0, 0] and n1[0] == 2 * layers - 1 and n1[1] == 0, (n0, n1)
+    assert torch.equal(o0, o1) and torch.equal(e0, e1) and torch.equal(dx0, dx1)
+    assert all(torch.equal(a, c) for a, c in zip(g0, g1))

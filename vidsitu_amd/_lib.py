@@ -110,6 +110,8 @@ SIGNATURES = {
     "vs_linear_bwd_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "vs_linear_bwd_fused": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "vs_txenc_stack_run": (_i, [_p, _i, _p, _i, _i, _p]),
+    "vs_ln_linear_fwd": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "vs_ln_bwd_linear_bwd": (_i, [_p] * 15 + [_i, _i, _i, _p]),
     "vs_conv_pair_begin": (_i, []),
     "vs_conv_pair_end": (_i, []),
     "vs_conv_pair_count": (_i64, []),

@@ -11,6 +11,8 @@
 // 64-row slab, activations are staged in LDS, reductions are wave shuffles.
 #include "common.h"
 
+#include <mutex>
+
 // ----------------------------------------------------------------------------
 // y[M,N] = act(x[M,K] @ W[N,K]^T + b).   One wave per output column; lanes split
 // K in float4 units; x chunk [MT][256] staged in LDS and shared by the 4 waves.
@@ -109,7 +111,10 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
 // which at M = 8 (TxEncoder tokens of one rank) left each launch at ~10 us for 4 MB of weights.
 // (xmask: the rows of x are multiplied by (xmask > 0) while they are staged -- the ReLU backward of the layer whose
 //  output gradient x is, fused into the data-gradient product; bid: the block's index within this product)
-template <int MT, int KC>  // KC = number of 256-wide K chunks held in registers (K <= 256 * KC)
+// PRE (K <= 1024 only): the rows of x are already in LDS, row-major with pitch K at the start of the dynamic area -- put
+// there by the prologue of a fused kernel (LayerNorm in front of its consumer, below); the staging loads are skipped,
+// everything else -- chunk order, FMA chains, the cross-lane sums -- is the same code, hence the same bits.
+template <int MT, int KC, bool PRE = false>  // KC = number of 256-wide K chunks held in registers (K <= 256 * KC)
 __device__ __forceinline__ void linear_fullx_body(const float* __restrict__ x, const float* __restrict__ xmask,
                                                   const float* __restrict__ w, const float* __restrict__ b,
                                                   const float* res, float* y, int M, int N, int K, int act,
@@ -132,6 +137,7 @@ __device__ __forceinline__ void linear_fullx_body(const float* __restrict__ x, c
   // included: 22.6 us against 9.)  The weights of every chunk are requested up front; the sums run over the
   // chunks in order, i.e. in the same order as with x staged whole.
   constexpr int NCH = (KC + 3) / 4;
+  static_assert(!PRE || NCH == 1, "pre-staged x: one chunk");
   const int CW4 = NCH == 1 ? K4 : 256;  // row pitch of the staged chunk, in float4s
   float acc[MT];
 #pragma unroll
@@ -139,22 +145,24 @@ __device__ __forceinline__ void linear_fullx_body(const float* __restrict__ x, c
 #pragma unroll
   for (int h = 0; h < NCH; ++h) {
     const int k4 = h * 256 + threadIdx.x;
-    float4 t[MT];
+    if constexpr (!PRE) {
+      float4 t[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const bool ok = m < M && k4 < K4;
-      float4 v = *(const float4*)(x + (ok ? (long long)m * K + k4 * 4 : 0));
-      if (xmask) {
-        const float4 mk = *(const float4*)(xmask + (ok ? (long long)m * K + k4 * 4 : 0));
-        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
-        v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+      for (int m = 0; m < MT; ++m) {
+        const bool ok = m < M && k4 < K4;
+        float4 v = *(const float4*)(x + (ok ? (long long)m * K + k4 * 4 : 0));
+        if (xmask) {
+          const float4 mk = *(const float4*)(xmask + (ok ? (long long)m * K + k4 * 4 : 0));
+          v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+          v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+        }
+        t[m] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      t[m] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (h) __syncthreads();  // the previous chunk has been consumed
-    if (k4 < K4) {
+      if (h) __syncthreads();  // the previous chunk has been consumed
+      if (k4 < K4) {
 #pragma unroll
-      for (int m = 0; m < MT; ++m) xs4[m * CW4 + threadIdx.x] = t[m];
+        for (int m = 0; m < MT; ++m) xs4[m * CW4 + threadIdx.x] = t[m];
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -1554,6 +1562,119 @@ extern "C" int vs_txenc_stack_run(const void* stages, int nstages, void* barrier
   }
   hipLaunchKernelGGL(txenc_stack_kernel, dim3(grid), dim3(256), (size_t)smem_bytes, st, (const TxStage*)stages,
                      nstages, (unsigned*)barriers, mode);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// ----------------------------------------------------------------------------
+// LayerNorm in the prologue of the linear that consumes it (round 3).  On the encoder's 8 token rows every launch is
+// ~11 us of the step's critical path (profiles/r03_encoder_section.txt) and a LayerNorm over 8 x 512 values is a
+// microsecond of work: every block of the consuming linear recomputes it into the LDS area the linear stages its input
+// in -- the stand-alone kernels' bodies (same arithmetic, same order: same bits) -- and block 0 stores what the rest of
+// the step needs (the normalised rows and their statistics; the input gradient of the residual path).
+//   forward : y_ln = LayerNorm(x + r * rmask); y = act(y_ln . w^T + b)
+//   backward: (dx_ln, dr) = LayerNorm backward of dy; then both gradients of the linear whose output gradient dr is
+// ----------------------------------------------------------------------------
+template <int KC>
+__global__ __launch_bounds__(256) void ln_linear_fwd_kernel(const float* x, const float* r, const float* rmask,
+                                                            const float* gamma, const float* beta, float eps,
+                                                            float* y_ln, float* mean, float* rstd,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            float* y, int M, int N, int K, int act) {
+  extern __shared__ float4 xs4[];
+  const bool first = blockIdx.x == 0;
+  for (int row = threadIdx.x >> 6; row < M; row += 4)
+    add_layernorm_fwd_vec_body(x, r, rmask, gamma, beta, (float*)xs4, first ? mean : nullptr, first ? rstd : nullptr,
+                               M, K, eps, 0, row);
+  if (first) {
+    __syncthreads();
+    const int n4 = M * (K >> 2);
+    for (int i = threadIdx.x; i < n4; i += 256) ((float4*)y_ln)[i] = xs4[i];
+  }
+  linear_fullx_body<8, KC, true>(nullptr, nullptr, w, b, nullptr, y, M, N, K, act, blockIdx.x);
+}
+
+extern "C" int vs_ln_linear_fwd(const float* x, const float* r, const float* rmask, const float* gamma,
+                                const float* beta, float eps, float* y_ln, float* mean, float* rstd, const float* w,
+                                const float* b, float* y, int M, int N, int K, int relu, void* stream) {
+  VS_CHECK_ARG(x && gamma && beta && y_ln && mean && rstd && w && y && M > 0 && N > 0, "bad args");
+  const uintptr_t al = (uintptr_t)x | (uintptr_t)r | (uintptr_t)rmask | (uintptr_t)gamma | (uintptr_t)beta |
+                       (uintptr_t)y_ln | (uintptr_t)w;
+  if (M > 8 || (K & 3) || K > 1024 || (al & 15)) {
+    vs_set_error("vs_ln_linear_fwd: M <= 8, K %% 4 == 0, K <= 1024, 16-byte aligned pointers "
+                 "(use vs_add_layernorm_fwd + vs_linear_fwd)");
+    return VS_ERR_UNSUPPORTED;
+  }
+  static std::once_flag attr;
+  std::call_once(attr, [] {
+    (void)hipFuncSetAttribute((const void*)ln_linear_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+  });
+  size_t smem = (size_t)8 * K * 4;
+  if (smem < (size_t)4 * 8 * 65 * 4) smem = (size_t)4 * 8 * 65 * 4;
+  hipLaunchKernelGGL((ln_linear_fwd_kernel<4>), dim3((N + 3) / 4), dim3(256), smem, (hipStream_t)stream, x, r, rmask,
+                     gamma, beta, eps, y_ln, mean, rstd, w, b, y, M, N, K, relu ? 1 : 0);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// blocks [0, g1): dx of the linear; [g1, g1 + g2): its dW / db; [g1 + g2, ..): dgamma / dbeta of the LayerNorm
+template <int KC, bool VEC>
+__global__ __launch_bounds__(256) void ln_bwd_linear_bwd_kernel(
+    const float* dy, const float* x_ln, const float* r, const float* rmask, const float* gamma, const float* mean,
+    const float* rstd, float* dx_ln, float* dgamma, float* dbeta, const float* __restrict__ x_lin,
+    const float* __restrict__ wt, float* dx_lin, float* dw, float* db, int M, int D, int K, int g1, int g2,
+    int stage_floats) {
+  extern __shared__ float4 xs4[];
+  const int bid = blockIdx.x;
+  if (bid >= g1 + g2) {
+    tx_ln_bwd_param_body(dy, nullptr, x_ln, r, rmask, mean, rstd, dgamma, dbeta, M, D, bid - g1 - g2);
+    return;
+  }
+  float* A = (float*)xs4 + stage_floats;  // LayerNorm input gradient rows [M][D] (behind the linear's staging area)
+  float* B = A + 8 * D;                   // the same under the residual-dropout mask = the linear's output gradient
+  for (int row = threadIdx.x >> 6; row < M; row += 4)
+    add_layernorm_bwd_dx_vec_body<4>(dy, x_ln, r, rmask, gamma, mean, rstd, A, rmask ? B : nullptr, M, D, row, nullptr);
+  __syncthreads();
+  if (bid == 0) {
+    const int n4 = M * (D >> 2);
+    for (int i = threadIdx.x; i < n4; i += 256) ((float4*)dx_ln)[i] = ((const float4*)A)[i];
+  }
+  const float* dyl = rmask ? B : A;
+  if (bid < g1)
+    linear_fullx_body<8, KC>(dyl, nullptr, wt, nullptr, nullptr, dx_lin, M, K, D, 0, bid);
+  else
+    linear_bwd_weight_body<VEC>(dyl, nullptr, x_lin, dw, db, M, D, K, bid - g1, g2);
+}
+
+extern "C" int vs_ln_bwd_linear_bwd(const float* dy, const float* x_ln, const float* r, const float* rmask,
+                                    const float* gamma, const float* mean, const float* rstd, float* dx_ln,
+                                    float* dgamma, float* dbeta, const float* x_lin, const float* wt, float* dx_lin,
+                                    float* dw, float* db, int M, int D, int K, void* stream) {
+  VS_CHECK_ARG(dy && x_ln && gamma && mean && rstd && dx_ln && dgamma && dbeta && x_lin && wt && dx_lin && dw,
+               "null tensor");
+  const uintptr_t al = (uintptr_t)dy | (uintptr_t)x_ln | (uintptr_t)r | (uintptr_t)rmask | (uintptr_t)gamma |
+                       (uintptr_t)dx_ln | (uintptr_t)wt | (uintptr_t)x_lin | (uintptr_t)dw;
+  if (M > 8 || (D & 3) || D > 1024 || (K & 3) || (al & 15)) {
+    vs_set_error("vs_ln_bwd_linear_bwd: M <= 8, D %% 4 == 0, D <= 1024, K %% 4 == 0, 16-byte aligned pointers "
+                 "(use vs_add_layernorm_bwd + vs_linear_bwd_fused)");
+    return VS_ERR_UNSUPPORTED;
+  }
+  static std::once_flag attr;
+  std::call_once(attr, [] {
+    (void)hipFuncSetAttribute((const void*)ln_bwd_linear_bwd_kernel<4, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  size_t stage = (size_t)8 * D * 4;  // linear_fullx_body's staging of the dr rows (inner dimension D <= 1024)
+  if (stage < (size_t)4 * 8 * 65 * 4) stage = (size_t)4 * 8 * 65 * 4;
+  const size_t smem = stage + (size_t)2 * 8 * D * 4;
+  const int g1 = (K + 3) / 4;
+  long long g2 = ((long long)D * ((K + 3) / 4) + 255) / 256;
+  if (g2 > 4096) g2 = 4096;
+  const int g3 = (D + 255) / 256;
+  hipLaunchKernelGGL((ln_bwd_linear_bwd_kernel<4, true>), dim3((unsigned)(g1 + g2 + g3)), dim3(256), smem,
+                     (hipStream_t)stream, dy, x_ln, r, rmask, gamma, mean, rstd, dx_ln, dgamma, dbeta, x_lin, wt, dx_lin,
+                     dw, db, M, D, K, g1, (int)g2, (int)(stage / 4));
   VS_CHECK_LAUNCH();
   return VS_OK;
 }

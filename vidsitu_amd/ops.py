@@ -1141,6 +1141,34 @@ def add_layernorm_bwd(dy, x, r, gamma, mean, rstd, rmask=None, dg_out=None, db_o
     return dx, (dr if dr is not None else dx), dg, db
 
 
+def ln_linear_ok(rows, d):
+    """The shapes vs_ln_linear_fwd / vs_ln_bwd_linear_bwd take (the encoder's token rows)."""
+    return rows <= 8 and d % 4 == 0 and d <= 1024
+
+
+def ln_linear_fwd(x, r, gamma, beta, eps, rmask, y_ln, mean, rstd, w, b, relu):
+    """y_ln = LayerNorm(x + r * rmask) (written with mean / rstd into the given tensors) and act(y_ln @ w^T + b) as one
+    launch; bitwise add_layernorm_fwd + linear_fwd."""
+    rows, d = x.shape
+    n = w.shape[0]
+    y = torch.empty((rows, n), dtype=torch.float32, device=x.device)
+    _lib.call("vs_ln_linear_fwd", _ptr(x), _ptr(r), _ptr(rmask), _ptr(gamma), _ptr(beta), float(eps), _ptr(y_ln),
+              _ptr(mean), _ptr(rstd), _ptr(w), _ptr(b), _ptr(y), rows, n, d, int(relu), _stream())
+    return y
+
+
+def ln_bwd_linear_bwd(dy, x_ln, r, gamma, mean, rstd, rmask, dx_ln, dgamma, dbeta, x_lin, wt, dw, db):
+    """LayerNorm backward (dx_ln, dgamma, dbeta written into the given tensors) + both gradients of the linear whose
+    output gradient is dx_ln * rmask, as one launch; bitwise add_layernorm_bwd + linear_bwd.  Returns dx_lin."""
+    rows, d = x_ln.shape
+    k = x_lin.shape[1]
+    dx_lin = torch.empty((rows, k), dtype=torch.float32, device=dy.device)
+    _lib.call("vs_ln_bwd_linear_bwd", _ptr(dy), _ptr(x_ln), _ptr(r), _ptr(rmask), _ptr(gamma), _ptr(mean),
+              _ptr(rstd), _ptr(dx_ln), _ptr(dgamma), _ptr(dbeta), _ptr(x_lin), _ptr(wt), _ptr(dx_lin), _ptr(dw),
+              _ptr(db), rows, d, k, _stream())
+    return dx_lin
+
+
 def softmax_xent(logits, labels, want_grad=True):
     logits = _f32c(logits)
     labels = labels.contiguous()

@@ -17,6 +17,60 @@ from torch import nn
 from . import ops
 
 
+class _Lazy:
+    """LayerNorm launches parked for the linear that consumes them (`Encoder.forward` and its backward only).
+
+    On the encoder's 8 token rows every launch is ~11 us of the step's critical path and a LayerNorm is a microsecond of
+    work: `AddLayerNormFn.forward` allocates its outputs and parks the launch; the next `LinearFn` / `FusedQKVAttnFn`
+    whose input IS that output runs LayerNorm + linear as one kernel (`ops.ln_linear_fwd`: every block recomputes the
+    8 rows in its prologue, block 0 stores them).  Backward: `AddLayerNormFn.backward` parks, the backward of the linear
+    that receives its `dr` runs both (`ops.ln_bwd_linear_bwd`).  Anything else that could read a parked output flushes
+    it first (the stand-alone launch into the same tensors): same bits either way.
+    OFF by default (VS_LN_LINEAR_FUSE=1 switches it on): measured SLOWER -- train step 12.47-12.63 vs 12.11-12.17 ms;
+    per launch (tools/ln_linear_time.py, dependent chains in a hipGraph) LN ; linear = 9.3 us against 10.9 us fused
+    (forward) and 9.5 against 16.3 us (backward of the 2048-wide feed-forward): inside one kernel the LayerNorm's
+    dependent loads run IN FRONT of the weight stream instead of beside the previous kernel's tail, and the weight-
+    gradient blocks read the LayerNorm's result through flat loads from LDS.  profiles/r03_encoder_section.txt."""
+
+    enabled = os.environ.get("VS_LN_LINEAR_FUSE", "0") == "1"
+    active = False
+    fwd = None
+    bwd = None
+    fused = [0, 0]  # forward / backward launches that took a parked LayerNorm (tests)
+
+    @staticmethod
+    def flush_fwd():
+        p, _Lazy.fwd = _Lazy.fwd, None
+        if p is not None:
+            rows, d = p["x"].shape
+            ops._lib.call("vs_add_layernorm_fwd", ops._ptr(p["x"]), ops._ptr(p["r"]), ops._ptr(p["rmask"]),
+                          ops._ptr(p["gamma"]), ops._ptr(p["beta"]), ops._ptr(p["y"]), ops._ptr(p["mean"]),
+                          ops._ptr(p["rstd"]), rows, d, float(p["eps"]), ops._stream())
+
+    @staticmethod
+    def take_fwd(x2, w, b):
+        """The parked LayerNorm whose output x2 is, if the fused kernel takes this linear; else flush and None."""
+        p = _Lazy.fwd
+        if p is None:
+            return None
+        if (p["y"].data_ptr() == x2.data_ptr() and x2.is_contiguous() and w.dtype == torch.float32
+                and w.is_contiguous() and w.data_ptr() % 16 == 0 and (b is None or b.dtype == torch.float32)):
+            _Lazy.fwd = None
+            return p
+        _Lazy.flush_fwd()
+        return None
+
+    @staticmethod
+    def flush_bwd():
+        p, _Lazy.bwd = _Lazy.bwd, None
+        if p is not None:
+            rows, d = p["x"].shape
+            ops._lib.call("vs_add_layernorm_bwd", ops._ptr(p["dy"]), ops._ptr(p["x"]), ops._ptr(p["r"]),
+                          ops._ptr(p["rmask"]), ops._ptr(p["gamma"]), ops._ptr(p["mean"]), ops._ptr(p["rstd"]),
+                          ops._ptr(p["dx"]), ops._ptr(p["dr"]) if p["rmask"] is not None else None, ops._ptr(p["dg"]),
+                          ops._ptr(p["db"]), rows, d, ops._stream())
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(x @ W^T + b) on vs_linear_*  (x: [..., K] fp32)."""
 
@@ -25,7 +79,13 @@ class LinearFn(torch.autograd.Function):
         ctx.route = route  # see ResidualBlock: the residual path's gradient joins this layer's dx in the kernel
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
-        y = ops.linear_fwd(x2, w, b, relu)
+        pend = _Lazy.take_fwd(x2, w, b)
+        if pend is not None:  # LayerNorm + this linear as one launch
+            y = ops.ln_linear_fwd(pend["x"], pend["r"], pend["gamma"], pend["beta"], pend["eps"], pend["rmask"],
+                                  pend["y"], pend["mean"], pend["rstd"], w, b, relu)
+            _Lazy.fused[0] += 1
+        else:
+            y = ops.linear_fwd(x2, w, b, relu)
         ctx.save_for_backward(x2, w, y if relu else None)
         ctx.has_bias, ctx.relu, ctx.shp = b is not None, relu, shp
         # parameters that live in a ParamArena take their gradient in place (overwrite
@@ -48,6 +108,18 @@ class LinearFn(torch.autograd.Function):
 
             if Conv3dP._pending_arenas:  # an asynchronous refresh may still be in flight
                 Conv3dP.join_pending_refresh()
+        pend = _Lazy.bwd
+        if pend is not None:
+            if (pend["dr"].data_ptr() == dy2.data_ptr() and direct and wt is not None and not ctx.relu
+                    and ctx.needs_input_grad[0] and wt.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0
+                    and x2.shape[1] % 4 == 0 and (ctx.route is None or "dx" not in ctx.route)):
+                _Lazy.bwd = None  # the LayerNorm's backward + both gradients of this linear as one launch
+                dx = ops.ln_bwd_linear_bwd(pend["dy"], pend["x"], pend["r"], pend["gamma"], pend["mean"], pend["rstd"],
+                                           pend["rmask"], pend["dx"], pend["dg"], pend["db"], x2, wt,
+                                           ctx.w_param.grad, ctx.b_param.grad if ctx.has_bias else None)
+                _Lazy.fused[1] += 1
+                return dx.reshape(ctx.shp), None, None, None, None
+            _Lazy.flush_bwd()
         dx, dw, db = ops.linear_bwd(
             dy2.contiguous(), x2, w, need_dx=ctx.needs_input_grad[0], has_bias=ctx.has_bias,
             dw_out=ctx.w_param.grad if direct else None,
@@ -65,6 +137,7 @@ class AttnSmallFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, n_heads, scale, drop_mask):
+        _Lazy.flush_fwd()
         o, probs = ops.attn_small_fwd(q, k, v, n_heads, scale, drop_mask)
         ctx.save_for_backward(q, k, v, probs, drop_mask)
         ctx.n_heads, ctx.scale = n_heads, scale
@@ -72,6 +145,7 @@ class AttnSmallFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, do):
+        _Lazy.flush_bwd()
         q, k, v, probs, drop_mask = ctx.saved_tensors
         dq, dk, dv = ops.attn_small_bwd(q.contiguous(), k.contiguous(), v.contiguous(), probs, do,
                                         ctx.n_heads, ctx.scale, drop_mask)
@@ -90,7 +164,13 @@ class FusedQKVAttnFn(torch.autograd.Function):
         ctx.route = route
         b, l, d = x.shape
         x2 = x.reshape(b * l, d)
-        qkv = ops.linear_fwd(x2, fused["w"], None, False)
+        pend = _Lazy.take_fwd(x2, fused["w"], None)
+        if pend is not None:  # the previous block's LayerNorm + the q | k | v projection as one launch
+            qkv = ops.ln_linear_fwd(pend["x"], pend["r"], pend["gamma"], pend["beta"], pend["eps"], pend["rmask"],
+                                    pend["y"], pend["mean"], pend["rstd"], fused["w"], None, False)
+            _Lazy.fused[0] += 1
+        else:
+            qkv = ops.linear_fwd(x2, fused["w"], None, False)
         o, probs = ops.attn_small_fwd_fused(qkv, b, l, n_heads, scale, drop_mask)
         ctx.save_for_backward(x2, qkv, probs, drop_mask)
         ctx.fused, ctx.n_heads, ctx.scale, ctx.bl = fused, n_heads, scale, (b, l)
@@ -98,6 +178,7 @@ class FusedQKVAttnFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, do):
+        _Lazy.flush_bwd()
         x2, qkv, probs, drop_mask = ctx.saved_tensors
         b, l = ctx.bl
         f = ctx.fused
@@ -124,7 +205,20 @@ class AddLayerNormFn(torch.autograd.Function):
         ctx.route = route
         shp = x.shape
         x2, r2 = x.reshape(-1, shp[-1]).contiguous(), r.reshape(-1, shp[-1]).contiguous()
-        y, mean, rstd = ops.add_layernorm_fwd(x2, r2, gamma, beta, eps, rmask)
+        rows, d = x2.shape
+        ctx.lazy_ok = (_Lazy.enabled and x2.is_cuda and ops.ln_linear_ok(rows, d) and x2.dtype == torch.float32
+                       and r2.dtype == torch.float32 and gamma.dtype == torch.float32
+                       and all(t.data_ptr() % 16 == 0 for t in (x2, r2, gamma, beta))
+                       and (rmask is None or rmask.data_ptr() % 16 == 0))
+        if ctx.lazy_ok and _Lazy.active:
+            _Lazy.flush_fwd()  # (an earlier parked one that no linear took)
+            y = torch.empty_like(x2)
+            mean = torch.empty(rows, dtype=torch.float32, device=x2.device)
+            rstd = torch.empty(rows, dtype=torch.float32, device=x2.device)
+            _Lazy.fwd = dict(x=x2, r=r2, gamma=gamma, beta=beta, eps=eps, rmask=rmask, y=y, mean=mean, rstd=rstd)
+        else:
+            _Lazy.flush_fwd()
+            y, mean, rstd = ops.add_layernorm_fwd(x2, r2, gamma, beta, eps, rmask)
         ctx.save_for_backward(x2, r2, gamma, mean, rstd, rmask)
         ctx.shp = shp
         # arena parameters take their gradient in place (overwrite), like LinearFn
@@ -136,6 +230,20 @@ class AddLayerNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         x2, r2, gamma, mean, rstd, rmask = ctx.saved_tensors
         direct = ctx.params is not None and ctx.params[0].grad is not None and ctx.params[1].grad is not None
+        _Lazy.flush_bwd()
+        dy2 = dy.reshape(x2.shape)
+        if (ctx.lazy_ok and direct and ctx.route is not None and dy2.is_contiguous() and dy2.dtype == torch.float32
+                and dy2.data_ptr() % 16 == 0):
+            # parked: the backward of the linear that receives dr (the wrapped layer's last op) runs both.  Only with
+            # in-place parameter gradients and the routed dx -- nothing autograd does before that launch may read
+            # a tensor it fills.
+            dx = torch.empty_like(x2)
+            dr = torch.empty_like(x2) if rmask is not None else dx
+            _Lazy.bwd = dict(dy=dy2, x=x2, r=r2, gamma=gamma, mean=mean, rstd=rstd, rmask=rmask, dx=dx, dr=dr,
+                             dg=ctx.params[0].grad, db=ctx.params[1].grad)
+            torch.autograd.Variable._execution_engine.queue_callback(_Lazy.flush_bwd)
+            ctx.route["dx"] = dx
+            return None, dr.reshape(ctx.shp), None, None, None, None, None
         dx, dr, dg, db = ops.add_layernorm_bwd(
             dy.reshape(x2.shape), x2, r2, gamma, mean, rstd, rmask,
             dg_out=ctx.params[0].grad if direct else None, db_out=ctx.params[1].grad if direct else None)
@@ -416,11 +524,17 @@ class Encoder(nn.Module):
         encoding = [x]
         if EncoderStackFn.eligible(self, x, mask):
             return encoding + list(EncoderStackFn.apply(x, self))
-        for layer in self.layers:
-            x = layer(x)
-            if mask is not None:
-                x = x * mask
-            encoding.append(x)
+        prev = _Lazy.active
+        _Lazy.active = _Lazy.enabled and mask is None and torch.is_grad_enabled()
+        try:
+            for layer in self.layers:
+                x = layer(x)
+                if mask is not None:
+                    x = x * mask
+                encoding.append(x)
+        finally:
+            _Lazy.active = prev
+            _Lazy.flush_fwd()  # the last LayerNorm has no linear of this encoder behind it
         return encoding
 
 
