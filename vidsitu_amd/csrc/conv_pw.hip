@@ -37,8 +37,7 @@ __device__ __forceinline__ void pw_wait_vm(int n) {
 }
 
 // AOL: the activation operand is the producer's raw convolution output, BN + ReLU applied to every A fragment after
-// its LDS read (ConvP::in_scale / in_shift; the constants of the <= 512 input channels sit in the spare half of the
-// statistic rows' region).
+// its LDS read (ConvP::in_scale / in_shift; the constants of the <= 128 input channels sit behind the statistic rows).
 template <int BN, bool BNB, int EDBG = 0, bool AOL = false>
 __global__ __launch_bounds__(256) void conv_pw_kernel(ConvP p, PwGeo g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -67,11 +66,11 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(ConvP p, PwGeo g) {
   char* ring = smem + b_bytes;
   char* epi = ring + g.nslot * PW_SLOT;
   float* statbuf = (float*)(epi + g.epi_bytes);
-  float* aol_tab = (float*)((char*)statbuf + 4096);  // [2][512]: scale, shift of input channel k (zero beyond K)
+  float* aol_tab = (float*)((char*)statbuf + 4096);  // [2][128]: scale, shift of input channel k (zero beyond K)
   if (AOL) {
-    for (int i = tid; i < 512; i += 256) {
-      aol_tab[i] = i < p.K ? p.in_scale[i] : 0.f;
-      aol_tab[512 + i] = i < p.K ? p.in_shift[i] : 0.f;
+    if (tid < 128) {
+      aol_tab[tid] = tid < p.K ? p.in_scale[tid] : 0.f;
+      aol_tab[128 + tid] = tid < p.K ? p.in_shift[tid] : 0.f;
     }  // (published by the first chunk's barrier)
   }
 
@@ -157,7 +156,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(ConvP p, PwGeo g) {
         const int row = wm * TM + a * 16 + lr;
         af[a] = *(const bf16x8*)(A + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
         if (AOL) {  // rows past M were zero-filled and have to stay zero (the statistic partials sum every tile row)
-          const bf16x8 t = aol_frag_k(af[a], aol_tab + kch * 64 + ch * 8, aol_tab + 512 + kch * 64 + ch * 8);
+          const bf16x8 t = aol_frag_k(af[a], aol_tab + kch * 64 + ch * 8, aol_tab + 128 + kch * 64 + ch * 8);
           af[a] = (m0c + row < p.M) ? t : __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
         }
       }
@@ -226,8 +225,10 @@ bool vs_pw_plan(const ConvP& p, int mode, int flags, PwGeo* out) {
   g.bn = (p.Ncols >= 128 && g.nk <= 2) ? 128 : 64;
   if (f_bn == 64 || (f_bn == 128 && p.Ncols >= 128 && g.nk <= 4)) g.bn = f_bn;
   const bool has_res = (p.flags & VS_CONV_RESIDUAL) != 0, bnb = (p.flags & VS_CONV_BNBWD) != 0;
-  g.epi_bytes = has_res ? PW_BM * g.bn * 4 : (bnb ? PW_BM * g.bn * 2 + 16384 : PW_BM * g.bn * 2);
-  const int fixed = g.nk * g.bn * 128 + g.epi_bytes + 2 * 8 * 128 * 4;  // + statbuf [2][4 * WM][BN]
+  // (bf16 staging tile: row pitch bn + 8 elements, see conv_tile_epilogue)
+  g.epi_bytes = has_res ? PW_BM * g.bn * 4 : (bnb ? PW_BM * (g.bn + 8) * 2 + 16384 : PW_BM * (g.bn + 8) * 2);
+  // + statbuf [2][4 * WM][BN] = 4 KB for both variants (WM * BN = 128) + 1 KB: apply-on-load constants [2][128]
+  const int fixed = g.nk * g.bn * 128 + g.epi_bytes + 4096 + 1024;
   // Measured (profiles/r02_pw_ab.txt): a block's epilogue is ~1 us of serial VALU / LDS work per tile and only a
   // second resident block hides it -- one block per CU loses to the tile kernel at every shape, a deeper ring
   // buys nothing (3 slots = 5 = 8 at equal occupancy).  After the tile kernel's prologue lost its integer
@@ -294,7 +295,7 @@ static int pw_launch_aol(const ConvP& p, const PwGeo& g, hipStream_t st) {
 }
 
 // apply on load is built for the 128-column variant without the BN-backward-sums epilogue (the c units' forward)
-bool vs_pw_aol_ok(const PwGeo& g, const ConvP& p) { return g.bn == 128 && !(p.flags & VS_CONV_BNBWD) && p.K <= 512; }
+bool vs_pw_aol_ok(const PwGeo& g, const ConvP& p) { return g.bn == 128 && !(p.flags & VS_CONV_BNBWD) && p.K <= 128; }
 
 int vs_pw_launch(const ConvP& p, const PwGeo& g, hipStream_t st) {
   const bool bnb = (p.flags & VS_CONV_BNBWD) != 0;

@@ -139,6 +139,12 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
   if (!has_res) {
     // (2a) no residual: affine + ReLU in registers, bf16 straight into an LDS tile, then
     //      whole 16-byte channel vectors are copied out (no unpack / repack pass).
+    // Row pitch BN + 8 elements (+16 bytes): a wave's ds_write_b16 covers 16 columns x the four lane quarters' rows
+    // q * 4 + r; with a 2 * BN-byte pitch (a multiple of 256 B) the four quarters hit the same 8 banks (4-way conflict:
+    // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.24-0.33 on the pointwise launches, where the epilogue is most of
+    // the LDS traffic); +16 bytes per row moves each quarter by 16 banks.  The 16-byte reads of the copy-out take a
+    // whole row per 16 lanes either way.
+    constexpr int EP = BN + 8;
     uint16_t* Eh = (uint16_t*)smem;
     const bool relu = (p.flags & VS_CONV_RELU) != 0;
     if (!(p.flags & (VS_CONV_AFFINE | VS_CONV_RELU))) {
@@ -152,7 +158,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             if (EDBG & 2) asm volatile("" ::"v"(acc[a][b][r]));
-            else Eh[(wm * TM + a * 16 + lq * 4 + r) * BN + col] = f32_to_bf16(acc[a][b][r]);
+            else Eh[(wm * TM + a * 16 + lq * 4 + r) * EP + col] = f32_to_bf16(acc[a][b][r]);
           }
       }
     } else {
@@ -171,7 +177,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
           const int row = wm * TM + a * 16 + lq * 4 + r;
           float v = acc[a][b][r] * sc + sh;
           if (relu) v = fmaxf(v, 0.f);
-          Eh[row * BN + col] = f32_to_bf16(v);
+          Eh[row * EP + col] = f32_to_bf16(v);
         }
     }
     }
@@ -207,7 +213,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
 #pragma unroll
       for (int i = 0; i < IT; ++i) {
         const int row = rl + i * RL;
-        const uint4 v = *(const uint4*)(Eh + row * BN + c8 * 8);
+        const uint4 v = *(const uint4*)(Eh + row * EP + c8 * 8);
         if (mm[i] >= 0) {
           *(uint4*)(p.y + (long long)mm[i] * p.y_ld + n) = v;
           float g[8], yv[8];
@@ -221,7 +227,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
           }
         }
       }
-      float* red = (float*)(smem + BM * BN * 2);  // behind the bf16 tile
+      float* red = (float*)(smem + BM * EP * 2);  // behind the bf16 tile
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         red[tid * 16 + e] = sg[e];
@@ -252,7 +258,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
       const bool in = idx < BM * CPR;
       const int m = in ? rowm(row) : -1;
       cm[u] = (m >= 0 && n0 + c8 * 8 < p.Ncols) ? m : -1;
-      cv[u] = *(const uint4*)(Eh + (in ? row : 0) * BN + c8 * 8);
+      cv[u] = *(const uint4*)(Eh + (in ? row : 0) * EP + c8 * 8);
     }
 #pragma unroll
     for (int u = 0; u < CO; ++u) {
