@@ -66,6 +66,8 @@ def parse():
                          "marked config.probe and is not the headline metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-feat-fwd", action="store_true",
+                    help="train workload: skip the feature-extractor forward leg (`feat_fwd` object of the line)")
     return ap.parse_args()
 
 
@@ -227,22 +229,69 @@ def load_pmc_traffic(workload="sf_txenc_train"):
 
 
 def eval_parity_note():
-    """The eval path's distance to the fp32 reference at the logits, as measured by tests/test_gpu_parity_full.py on one
-    224^2 SlowFast-R50 clip against the fp32 oracle (round 3, profiles/r03_parity.txt), with the eval mode this process
-    runs in.  north_star asks for 1e-3: the default bf16 path sits at 3.0e-3, ALL of it the rounding of the fp32 master
-    weights to bf16 (against the oracle with the same bf16-representable weights: 4.4e-4); split bf16 weights
-    (VS_EVAL_SPLIT_WEIGHTS=1, every convolution twice) meet it at about half the clips/s; an fp32 residual stream
-    (VS_RESIDUAL_FP32=1) changes nothing."""
+    """The eval path's distance to the fp32 reference at the logits, as LAST MEASURED by
+    tests/test_gpu_parity_full.py (one 224^2 SlowFast-R50 clip against the fp32 oracle), read from
+    profiles/parity_eval.json (the file that test writes, committed with the commit it was measured at), for the eval
+    mode this process runs in.  north_star asks for 1e-3: the default bf16 path sits at ~3e-3, all of it the rounding of
+    the fp32 master weights to bf16; split bf16 weights (VS_EVAL_SPLIT_WEIGHTS=1, every convolution twice) meet it.
+    None when the file is absent: the line then carries no parity figures rather than remembered ones."""
     from vidsitu_amd.trunk import ResBlock, _Unit
 
     mode = "split_bf16_weights" if _Unit.split_weights else ("fp32_residual_stream" if ResBlock.residual_fp32
                                                              else "bf16")
-    table = {"bf16": 3.02e-3, "fp32_residual_stream": 3.03e-3, "split_bf16_weights": 7.6e-4}
-    return {"eval_mode": mode, "logits_rel_err_vs_fp32_oracle": table[mode], "north_star": 1e-3,
-            "same_bf16_weights_both_sides": 4.4e-4,
-            "clips_per_s_measured": {"bf16": 3345, "fp32_residual_stream": 2413, "split_bf16_weights": 1666},
-            "source": "tests/test_gpu_parity_full.py (one 224^2 clip, 1564-verb head), profiles/r03_parity.txt; "
-                      "not re-measured in this run"}
+    try:
+        with open(os.path.join(ROOT, "profiles", "parity_eval.json")) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    return {"eval_mode": mode, "logits_rel_err_vs_fp32_oracle": rec["logits_rel_err_vs_fp32_oracle"].get(mode),
+            "north_star": rec.get("north_star", 1e-3),
+            "same_bf16_weights_both_sides": rec.get("same_bf16_weights_both_sides"),
+            "measured_at_commit": rec.get("commit"), "source": rec.get("source", "") + "; not re-measured in this run"}
+
+
+def feat_fwd_leg(dev, rank, replays=20):
+    """BASELINE configs[1] (SlowFast-R50 feature extractor only, eval, 8 x 3x32x224x224 bf16): one hipGraph of the
+    forward to the [8, 2304] features, `replays` replays between two synchronisations.  Same model construction, batch
+    and step as `--workload feat_fwd`."""
+    from vidsitu_amd import synth_data
+    from vidsitu_amd.extended_config import get_cfg
+    from vidsitu_amd.mdl_selector import get_mdl_loss_eval
+
+    cfg = get_cfg({"mdl.mdl_name": "sf_base"})
+    comm = synth_data.make_comm(cfg)
+    torch.manual_seed(0)
+    mdl = get_mdl_loss_eval(cfg)["mdl"](cfg=cfg, comm=comm).to(dev)
+    mdl.eval()
+    batch = synth_data.synth_batch(cfg, comm, bs=2, n_ev=4, seed=1234 + rank, device=dev, dtype=torch.bfloat16)
+
+    def step():
+        with torch.no_grad():
+            return mdl.head(mdl.forward_encoder(batch))
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(replays):
+        g.replay()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    cps = 8 * replays / dt
+    return {"workload": "BASELINE configs[1]: SlowFast-R50 feature extractor only, eval, 8 clips x 3x32x224x224",
+            "clips_per_s": round(cps, 1), "ms_per_step": round(dt / replays * 1e3, 3), "replays": replays,
+            "hipgraph": True, "dtype": "bf16",
+            "frac_of_bf16_mfma_peak": round(cps * GFLOP_PER_CLIP_FWD / 1e3 / PEAK_BF16_TFLOPS, 4),
+            "parity": eval_parity_note()}
 
 
 def bench_srl_gen(args, rank, world, dev):
@@ -694,6 +743,13 @@ def main():
                               "tiny_launches_per_step": sum(v[0] for k, v in bn if v[4] is None) // reps}
         roof["families"] = [fam(k, v) for k, v in fams[:16]]
 
+    # BASELINE configs[1] beside configs[2]: the feature extractor's eval forward (the `feat_fwd` workload) timed by the
+    # same process AFTER the timed region, rank 0 only, 20 hipGraph replays -- so that the forward rate is a
+    # driver-measured number too.  Not part of `value`.
+    fwd = None
+    if rank == 0 and train and args.graph and not args.no_feat_fwd:
+        fwd = feat_fwd_leg(dev, rank)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # a reported baseline of the N = 1 line only
         cpu = cpu_baseline(args.workload, len(comm.vb_id_vocab))
@@ -718,7 +774,9 @@ def main():
                           {"probe": f"{CLIPS_PER_GPU} clips/GPU instead of the BASELINE config's 8: not the headline metric"}),
                        **({"probe_enc_layers": os.environ["VS_BENCH_ENC_LAYERS"]}
                           if train and os.environ.get("VS_BENCH_ENC_LAYERS", "6") != "6" else {}),
-                       **({} if train else {"parity": eval_parity_note()}),
+                       # the arithmetic of the line: bf16 operands (fp32 accumulation / statistics / optimizer); the
+                       # logits' distance to the fp32 reference in that arithmetic, as last measured by the parity test
+                       "parity": eval_parity_note(),
                        "grad_allreduce": (None if ts is None else
                                           (f"{len(ts.segments)} bucket(s), "
                                            f"{'bf16' if ts.grad_bf16 else 'fp32'} payload, "
@@ -728,6 +786,7 @@ def main():
                        "frac_of_bf16_mfma_peak": round(value * flop_per_clip / 1e3 / world /
                                                        PEAK_BF16_TFLOPS, 4)},
             "roofline": roof, "cpu_baseline": cpu,
+            **({"feat_fwd": fwd} if fwd is not None else {}),
         }
         emit(line)
     if dist.is_available() and dist.is_initialized():

@@ -53,11 +53,14 @@ def _load_batch(static, new):
 
 def main_fn(rank, cfg, steps, graph=True):
     world = cfg.num_gpus
+    # the device index is the rank's place on ITS node (LOCAL_RANK, set by dist_launch.rank_env and by
+    # torch.distributed.run); RANK only equals it on one node
+    local = int(os.environ.get("LOCAL_RANK", rank)) if os.environ.get("WORLD_SIZE") not in (None, "") else rank
     if cfg.do_dist:
-        torch.cuda.set_device(rank)
+        torch.cuda.set_device(local)
         dist.init_process_group(backend=cfg.DIST_BACKEND, rank=rank, world_size=world,
-                                device_id=torch.device("cuda", rank))
-    dev = torch.device("cuda", rank)
+                                device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     comm = synth_data.make_comm(cfg)
     sel = get_mdl_loss_eval(cfg)
@@ -103,23 +106,30 @@ def main_fn(rank, cfg, steps, graph=True):
         losses = []
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
-        t0 = time.time()
+        # the rate printed below is that of the steps AFTER the eager warm-up step and the capture (it == 0 and the
+        # capture at it == 1 take seconds; a 10-step run would otherwise report mostly those)
+        t0, timed_from = time.time(), 0
         with torch.cuda.stream(side):
             for it in range(steps):
                 _load_batch(static, batches[it % len(batches)])
                 if graph and it == 1:
                     ts.capture()  # raises on failure: never a silent eager loop under the graph's name
                     _load_batch(static, batches[it % len(batches)])  # (capture does not execute the step)
+                if it == (1 if graph else min(1, steps - 1)) and steps > 1:
+                    torch.cuda.synchronize()
+                    t0, timed_from = time.time(), it
                 ts.run()
                 losses.append(ts.loss.clone())
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        t_run = time.time() - t0
         if rank == 0:
             ls = [round(float(x), 4) for x in losses]
             mode = "hipGraph replay" if ts.graphs is not None else "eager"
             print(f"[{cfg.uid}] {steps} steps ({mode}, {len(ts.segments)} segment(s), "
                   f"{'bf16' if ts.grad_bf16 else 'fp32'} gradient payload, world {world}), "
-                  f"{bs * n_ev * world * steps / (time.time() - t0):.1f} clips/s, loss {ls[0]} -> {ls[-1]}")
+                  f"{bs * n_ev * world * (steps - timed_from) / t_run:.1f} clips/s over the last {steps - timed_from} "
+                  f"step(s), loss {ls[0]} -> {ls[-1]}")
             checkpoint.save_model_dict(model_file, mdl, opt, num_it=num_it + steps, cfg=None)
             print(f"[{cfg.uid}] saved {model_file}")
     loss_d, acc_d = eval_fn(mdl, loss_fn, batches, "valid", rank)

@@ -53,6 +53,47 @@ def test_bn_eval_fold(dev):
     assert_close(shift, beta - rm * sref, 1e-5, "shift")
 
 
+@pytest.mark.parametrize("c,n,t,hw", [(8, 8, 32, 56), (32, 8, 32, 28)], ids=["c8_802816pos", "c32_200704pos"])
+@pytest.mark.parametrize("mask", ["bits", "from_y"])
+def test_bn_backward_sums_vs_fp64_on_equal_operands_at_full_size(c, n, t, hw, mask, dev):
+    """dgamma = sum g * xhat and dbeta = sum g over up to 802 816 positions per channel (the fast pathway's first
+    blocks at 8 clips) against fp64 sums of the SAME bf16 operands and the same ReLU mask: the tight companion of the
+    layer-local parity bounds, which at these sizes are dominated by the operands' roundings.  The kernels' partial
+    sums are fp32 in a fixed order and the finalize is fp64: the result has to sit within a few 1e-7 of the exact sum
+    of absolute terms."""
+    from vidsitu_amd import ops
+
+    g = torch.Generator().manual_seed(c + hw)
+    y = rb(torch.randn(n, c, t, hw, hw, generator=g) * 1.5 + 0.3)
+    dz = rb(torch.randn(n, c, t, hw, hw, generator=g))
+    gamma = torch.rand(c, generator=g) + 0.5
+    beta = torch.randn(c, generator=g) * 0.2
+    mean = y.mean(dim=(0, 2, 3, 4))
+    invstd = 1.0 / torch.sqrt(y.var(dim=(0, 2, 3, 4), unbiased=False) + 1e-5)
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    yd, dzd = to_act(y, dev), to_act(dz, dev)
+    z, bits = ops.bn_apply(yd, scale.to(dev), shift.to(dev), None, True, want_bits=True)
+    if mask == "bits":
+        _, _, dgamma, dbeta = ops.bn_bwd(dzd, None, yd, mean.to(dev), invstd.to(dev), gamma.to(dev), True,
+                                         want_dres=False, zbits=bits)
+        m = ((bits.view(-1, c // 8, 1) >> torch.arange(8, device=dev, dtype=torch.uint8)) & 1).view(-1, c).bool()
+    else:
+        _, _, dgamma, dbeta = ops.bn_bwd(dzd, None, yd, mean.to(dev), invstd.to(dev), gamma.to(dev), True,
+                                         want_dres=False, beta=beta.to(dev))
+        # the kernel's own mask rule, in its own fp32 arithmetic
+        yf = yd.permute(0, 2, 3, 4, 1).reshape(-1, c).float()
+        m = ((yf - mean.to(dev)) * invstd.to(dev) * gamma.to(dev) + beta.to(dev)) > 0
+    y64 = yd.permute(0, 2, 3, 4, 1).reshape(-1, c).double()
+    g64 = dzd.permute(0, 2, 3, 4, 1).reshape(-1, c).double() * m
+    xh = (y64 - mean.to(dev).double()) * invstd.to(dev).double()
+    ref_b, ref_g = g64.sum(0), (g64 * xh).sum(0)
+    sc_b, sc_g = g64.abs().sum(0), (g64 * xh).abs().sum(0)
+    eb = float(((dbeta.double() - ref_b).abs() / sc_b).max())
+    eg = float(((dgamma.double() - ref_g).abs() / sc_g).max())
+    print(f"c{c} rows {y64.shape[0]} mask={mask}: |dbeta - fp64| / sum|g| {eb:.2e}, |dgamma - fp64| / sum|g xhat| {eg:.2e}")
+    assert eb <= 2e-6 and eg <= 2e-6, (eb, eg)
+
+
 @pytest.mark.parametrize("c,hw,relu,res", [(8, 20, True, False), (32, 12, True, True),
                                            (256, 6, False, False), (2048, 3, True, True)])
 def test_bn_backward_matches_autograd(c, hw, relu, res, dev):

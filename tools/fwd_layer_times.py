@@ -1,7 +1,8 @@
 """Per-layer time of every distinct conv GEMM of SlowFast-R50 at the bench shape (8 clips), each launch
 alone on the GPU replayed from a hipGraph: forward (eval epilogue: folded BN + ReLU), dgrad, wgrad.
 Prints us, TFLOP/s, algorithmic GB/s and the fraction of the binding roof (max of flops / 2.5 PF and
-bytes / 8 TB/s).  usage: python tools/fwd_layer_times.py [fwd|dgrad|wgrad ...]"""
+bytes / 8 TB/s).  usage: python tools/fwd_layer_times.py [fwd|dgrad|wgrad ...] [--clips=N] [--only=s4.,s5.]
+(--clips: the same layers at another batch, e.g. 32 = each kernel's steady state; --only: name substrings)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,6 +13,8 @@ dev = torch.device("cuda:0")
 kinds = [a for a in sys.argv[1:] if not a.startswith("--")] or ["fwd"]
 HALO = "force" if "--halo" in sys.argv else (False if "--nohalo" in sys.argv else True)
 REPS = 20
+NCLIPS = int(next((a.split("=")[1] for a in sys.argv if a.startswith("--clips=")), 8))
+ONLY = next((a.split("=")[1].split(",") for a in sys.argv if a.startswith("--only=")), None)
 
 
 def graph_time(fn):
@@ -33,13 +36,15 @@ def graph_time(fn):
 
 
 agg = {}
-for name, M, N, K, k, s, xin in rows():
+for name, M, N, K, k, s, xin in rows(n=NCLIPS):
     key = (M, N, K, k, s)
     a = agg.setdefault(key, [0, name, xin]); a[0] += 1
 tot = {kd: [0.0, 0.0] for kd in kinds}
 print(f"{'layer':14s} {'x':>2s} {'M':>7s} {'N':>5s} {'K':>5s} " + " ".join(f"{kd + ' us':>9s} {'TF/s':>6s} {'GB/s':>6s} {'roof':>5s}" for kd in kinds))
 for (M, N, K, k, s), (cnt, name, xin) in sorted(agg.items(), key=lambda kv: -2.0 * kv[0][0] * kv[0][1] * kv[0][2] * kv[1][0]):
     if "stem" in name:
+        continue
+    if ONLY and not any(o in name for o in ONLY):
         continue
     if "--small" in sys.argv and not (N <= 32 and K <= 192):  # the register-resident small-channel kernel's layers
         continue
@@ -48,7 +53,7 @@ for (M, N, K, k, s), (cnt, name, xin) in sorted(agg.items(), key=lambda kv: -2.0
     # reconstruct the input shape: rows() gives M of the output; invert the strides
     # (all strided layers here: spatial stride 2 with pad k//2, temporal stride 4 for the fuse convs)
     p = (k[0] // 2, k[1] // 2, k[2] // 2)
-    n = 8
+    n = NCLIPS
     pos_in = xin // cin
     # find (t, h, w) of the input from the known stage geometry
     cands = [(t, hw, hw) for t in (8, 32) for hw in (56, 28, 14, 7) if n * t * hw * hw == pos_in]

@@ -1,0 +1,360 @@
+// Probe: the main loop planned for the MFMA-side convolutions, as a plain bf16 GEMM  C[M][N] = A[M][K] * B[N][K]^T.
+//
+// 512 threads = 8 waves as 2 (M) x 4 (N), block tile 256 x 256 x 64, wave tile 128 x 64 (acc 8 x 4 fragments),
+// v_mfma_f32_16x16x32_bf16.  LDS = 2 stages x 64 KiB, each stage cut into four 16-KiB sub-buffers
+//   At / Ab : the top / bottom 64 rows of every wave row's 128       (128 rows x 128 B)
+//   Bl / Br : the left / right 32 columns of every wave column's 64  (128 rows x 128 B)
+// A k-tile is four phases of 16 MFMAs per wave: At x Bl, At x Br, Ab x Br, Ab x Bl.  Every phase
+//   s_waitcnt vmcnt(12); s_barrier; issue ONE sub-buffer (2 LDS-DMA per wave) 7 phases ahead of its first read;
+//   read the operand fragments the NEXT phase changes (4 or 8 ds_read_b128) ; 16 MFMAs on fragments already in
+//   registers; s_waitcnt lgkmcnt(0)
+// so 7 of the 8 sub-buffers (112 KiB) are in flight or waiting, each read exactly once, and a sub-buffer is refilled
+// in the phase after its only read.  Read order r = 0, 1, 2, ...: At(0), Bl(0), Br(0), Ab(0), At(1), ...; sub-buffer
+// r is read in phase r - 2 and issued in phase r - 9.
+// build: hipcc -O3 --offload-arch=gfx950 gemm_deep.hip -o gemm_deep
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <cmath>
+#include <vector>
+#include <type_traits>
+#include <cstring>
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+#define OOB 0x80000000u
+
+struct P {
+  const uint16_t* A;
+  const uint16_t* B;
+  uint16_t* C;
+  int M, N, K;
+  unsigned a_bytes, b_bytes;
+  int tilesN;
+  int prio;
+};
+
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  unsigned u = __builtin_bit_cast(unsigned, f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+template <int VAR>
+__global__ __launch_bounds__(512) void gemm_deep(P p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  int swz;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tn = swz % p.tilesN, tm = swz / p.tilesN;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int nk = (p.K + 63) >> 6;
+
+  // ---- copy side.  VAR 0 / 2: every wave issues 2 of a sub-buffer's 16 LDS-DMA instructions (rows sr = (i * 8 + wv) * 8 +
+  // (lane >> 3)); VAR 3 / 4: the waves of ONE half (wv >> 2; a SIMD hosts one wave of each half) issue 4 each (rows
+  // sr = (i * 4 + (wv & 3)) * 8 + (lane >> 3)) -- half 0 the sub-buffers At and Br, half 1 Bl and Ab, so every phase has
+  // one loading wave and one purely multiplying wave per SIMD.  VAR 0 / 4: issued in a burst when the phase opens;
+  // VAR 2 / 3: spread between the phase's MFMAs.
+  constexpr bool HALVES = VAR == 3 || VAR == 4;
+  constexpr bool SPREAD = VAR == 2 || VAR == 3;
+  constexpr int NI = HALVES ? 4 : 2;
+  const int hf = wv >> 2;
+  unsigned src[HALVES ? 2 : 4][NI];  // byte offsets at k = 0; [kind or kind >> 1][i]
+  {
+    const int kc = lane & 7, r8 = lane >> 3;
+#pragma unroll
+    for (int kind = 0; kind < 4; ++kind) {
+      if (HALVES && (kind & 1) != hf) continue;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int sr = (HALVES ? (i * 4 + (wv & 3)) : (i * 8 + wv)) * 8 + r8;
+        const unsigned unit = (unsigned)((kc ^ ((sr >> 1) & 7)) << 4);
+        const bool isA = kind == 0 || kind == 3;
+        const int h = (kind == 0 || kind == 1) ? 0 : 1;
+        unsigned o;
+        if (isA) {
+          const int arow = m0 + (sr >> 6) * 128 + h * 64 + (sr & 63);
+          o = arow < p.M ? (unsigned)((long long)arow * p.K * 2) + unit : OOB;
+        } else {
+          const int brow = n0 + (sr >> 5) * 64 + h * 32 + (sr & 31);
+          o = brow < p.N ? (unsigned)((long long)brow * p.K * 2) + unit : OOB;
+        }
+        src[HALVES ? (kind >> 1) : kind][i] = o;
+      }
+    }
+  }
+  typedef __attribute__((address_space(3))) char* lds_ptr_t;
+  const unsigned lds0 = (unsigned)(unsigned long)(lds_ptr_t)smem + (unsigned)(HALVES ? (wv & 3) : wv) * 1024u;
+  auto rsrc_words = [](const void* base, unsigned bytes) __attribute__((always_inline)) {
+    const unsigned long a = (unsigned long)base;
+    return (i32x4){(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+  };
+  const i32x4 adesc = rsrc_words(p.A, p.a_bytes), bdesc = rsrc_words(p.B, p.b_bytes);
+  auto dma16 = [](const i32x4& desc, unsigned lds_addr, unsigned voff) __attribute__((always_inline)) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(desc)
+                 : "memory");
+  };
+  // sub-buffer of read index r: kind = r & 3 (0 At, 1 Bl, 2 Br, 3 Ab), tile = r >> 2, stage = tile & 1
+  constexpr unsigned SUB_AT = 0, SUB_AB = 16384, SUB_BL = 32768, SUB_BR = 49152;
+  // instruction i of this wave's share of sub-buffer (kind, tile); no-op for the half that does not load `kind`
+  auto issue1 = [&](int kind, int tile, int i) __attribute__((always_inline)) {
+    if (HALVES && (kind & 1) != hf) return;
+    const unsigned st = (unsigned)(tile & 1) * 65536u;
+    const unsigned kadd = tile < nk ? (unsigned)tile * 128u : OOB;  // past the last tile: zeros nobody reads
+    const bool isA = kind == 0 || kind == 3;
+    const unsigned sub = kind == 0 ? SUB_AT : kind == 1 ? SUB_BL : kind == 2 ? SUB_BR : SUB_AB;
+    const unsigned s0 = src[HALVES ? (kind >> 1) : kind][i];
+    const unsigned off = (s0 | kadd) >= OOB ? OOB : s0 + kadd;
+    dma16(isA ? adesc : bdesc, lds0 + st + sub + (unsigned)i * (HALVES ? 4096u : 8192u), off);
+  };
+  auto issue = [&](int kind, int tile) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) issue1(kind, tile, i);
+  };
+
+  // ---- compute side
+  const int wm = wv >> 2, wn = wv & 3;
+  const int lr = lane & 15, lq = lane >> 4;
+  const unsigned lpart = (unsigned)(lr * 128 + ((lq ^ (lr >> 1)) << 4));  // ks = 0; ks = 1: ^ 64
+  const char* aBase[2] = {smem + wm * 8192 + lpart, smem + wm * 8192 + (lpart ^ 64u)};  // + stage + sub + a * 2048
+  const char* bBase[2] = {smem + wn * 4096 + lpart, smem + wn * 4096 + (lpart ^ 64u)};  // + stage + sub + b * 2048
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 A0[4][2], A1[4][2], B0[2][2], B1[2][2];
+
+  auto readA = [&](bf16x8 (&dst)[4][2], unsigned off) __attribute__((always_inline)) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        dst[a][ks] = *(const bf16x8*)(aBase[ks] + off + a * 2048);
+  };
+  auto readB = [&](bf16x8 (&dst)[2][2], unsigned off) __attribute__((always_inline)) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        dst[b][ks] = *(const bf16x8*)(bBase[ks] + off + b * 2048);
+  };
+  // the phase's 16 MFMAs; SPREAD: this wave's copies of sub-buffer (kind, tile) go between them
+  auto mma = [&](const bf16x8 (&Af)[4][2], const bf16x8 (&Bf)[2][2], const int a0, const int b0, int kind, int tile)
+      __attribute__((always_inline)) {
+#pragma unroll
+    for (int idx = 0; idx < 16; ++idx) {
+      const int ks = idx >> 3, a = (idx >> 1) & 3, b = idx & 1;
+      acc[a0 + a][b0 + b] =
+          __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af[a][ks], Bf[b][ks], acc[a0 + a][b0 + b], 0, 0, 0);
+      if (SPREAD) {
+        constexpr int STEP = 16 / NI;  // after MFMA STEP / 2 - 1, then every STEP
+        if ((idx % STEP) == STEP / 2 - 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue1(kind, tile, idx / STEP);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  };
+  auto phase_open = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto phase_close = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // prologue: r = 0 .. 6
+  issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0); issue(0, 1); issue(1, 1); issue(2, 1);
+  // phase -2: issue r = 7 (Ab 1), read At(0)
+  phase_open();
+  issue(3, 1);
+  readA(A0, 0 + SUB_AT);
+  phase_close();
+  // phase -1: issue r = 8 (At 2), read Bl(0)
+  phase_open();
+  issue(0, 2);
+  readB(B0, 0 + SUB_BL);
+  phase_close();
+
+  // one k-tile; PAR = tile parity (stage and B register-set roles)
+  auto tile_body = [&](auto par, int t) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par)::value;
+    constexpr unsigned ST = PAR * 65536u, STN = (PAR ^ 1) * 65536u;
+    bf16x8(&BL)[2][2] = PAR ? B1 : B0;
+    bf16x8(&BR)[2][2] = PAR ? B0 : B1;
+    // P1: issue Bl(t+2), read Br(t), At x Bl
+    phase_open();
+    if (!SPREAD) issue(1, t + 2);
+    readB(BR, ST + SUB_BR);
+    if (p.prio) __builtin_amdgcn_s_setprio(1);
+    mma(A0, BL, 0, 0, 1, t + 2);
+    if (p.prio) __builtin_amdgcn_s_setprio(0);
+    phase_close();
+    // P2: issue Br(t+2), read Ab(t), At x Br
+    phase_open();
+    if (!SPREAD) issue(2, t + 2);
+    readA(A1, ST + SUB_AB);
+    if (p.prio) __builtin_amdgcn_s_setprio(1);
+    mma(A0, BR, 0, 2, 2, t + 2);
+    if (p.prio) __builtin_amdgcn_s_setprio(0);
+    phase_close();
+    // P3: issue Ab(t+2), read At(t+1), Ab x Br
+    phase_open();
+    if (!SPREAD) issue(3, t + 2);
+    readA(A0, STN + SUB_AT);
+    if (p.prio) __builtin_amdgcn_s_setprio(1);
+    mma(A1, BR, 4, 2, 3, t + 2);
+    if (p.prio) __builtin_amdgcn_s_setprio(0);
+    phase_close();
+    // P4: issue At(t+3), read Bl(t+1) into the set Br(t) leaves, Ab x Bl
+    phase_open();
+    if (!SPREAD) issue(0, t + 3);
+    readB(BR, STN + SUB_BL);
+    if (p.prio) __builtin_amdgcn_s_setprio(1);
+    mma(A1, BL, 4, 0, 0, t + 3);
+    if (p.prio) __builtin_amdgcn_s_setprio(0);
+    phase_close();
+  };
+  int t = 0;
+  for (; t + 1 < nk; t += 2) {
+    tile_body(std::integral_constant<int, 0>{}, t);
+    tile_body(std::integral_constant<int, 1>{}, t + 1);
+  }
+  if (t < nk) tile_body(std::integral_constant<int, 0>{}, t);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // epilogue: bf16 tile through LDS (row pitch 256 + 8 elements), 16-byte stores
+  constexpr int EP = 256 + 8;
+  uint16_t* E = (uint16_t*)smem;
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int half = a >> 2, aa = a & 3, hb = b >> 1, bb = b & 1;
+      const int row0 = wm * 128 + half * 64 + aa * 16 + lq * 4;
+      const int col = wn * 64 + hb * 32 + bb * 16 + lr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) E[(row0 + r) * EP + col] = f2bf(acc[a][b][r]);
+    }
+  __syncthreads();
+  for (int idx = tid; idx < 256 * 32; idx += 512) {
+    const int row = idx >> 5, c8 = idx & 31;
+    if (m0 + row < p.M && n0 + c8 * 8 < p.N)
+      *(uint4*)(p.C + (long long)(m0 + row) * p.N + n0 + c8 * 8) = *(const uint4*)(E + row * EP + c8 * 8);
+  }
+}
+
+static uint16_t h_f2bf(float f) {
+  unsigned u;
+  memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static float h_bf2f(uint16_t h) {
+  unsigned u = (unsigned)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+template <int VAR>
+static float run(const P& p, int grid, int reps) {
+  hipFuncSetAttribute((const void*)gemm_deep<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  const size_t smem = 256 * (256 + 8) * 2 > 131072 ? 256 * (256 + 8) * 2 : 131072;
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm_deep<VAR>, dim3(grid), dim3(512), smem, 0, p);
+  hipDeviceSynchronize();
+  float best = 1e30f;
+  for (int r = 0; r < 3; ++r) {
+    hipEventRecord(e0);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(gemm_deep<VAR>, dim3(grid), dim3(512), smem, 0, p);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (ms / reps < best) best = ms / reps;
+  }
+  return best;
+}
+
+int main(int argc, char** argv) {
+  struct Shape { int M, N, K; const char* what; };
+  const Shape shapes[] = {
+      {4096, 4096, 4096, "4096^3 (guide's template shape)"},
+      {8192, 8192, 8192, "8192^3"},
+      {50176, 256, 3072, "s4.a at 32 clips"},
+      {12544, 256, 3072, "s4.a at 8 clips (49 tiles)"},
+      {50176, 256, 2304, "s4.b at 32 clips (as a dense GEMM)"},
+      {50176, 256, 1920, "s4.b0.a at 8 clips"},
+      {12544, 1024, 768, "s4.a dgrad at 8 clips"},
+      {50176, 512, 1152, "K = 1152"},
+      {12544, 1024, 640, "s4 shortcut at 8 clips"},
+  };
+  for (const Shape& s : shapes) {
+    const size_t na = (size_t)s.M * s.K, nb = (size_t)s.N * s.K, nc = (size_t)s.M * s.N;
+    std::vector<uint16_t> ha(na), hb(nb), hc(nc);
+    unsigned seed = 12345u;
+    auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return ((seed >> 8) & 0xffff) / 32768.0f - 1.0f; };
+    for (auto& v : ha) v = h_f2bf(rnd());
+    for (auto& v : hb) v = h_f2bf(rnd() * 0.05f);
+    uint16_t *dA, *dB, *dC;
+    hipMalloc(&dA, na * 2); hipMalloc(&dB, nb * 2); hipMalloc(&dC, nc * 2);
+    hipMemcpy(dA, ha.data(), na * 2, hipMemcpyHostToDevice);
+    hipMemcpy(dB, hb.data(), nb * 2, hipMemcpyHostToDevice);
+    hipMemset(dC, 0, nc * 2);
+    P p;
+    p.A = dA; p.B = dB; p.C = dC; p.M = s.M; p.N = s.N; p.K = s.K;
+    p.a_bytes = (unsigned)(na * 2); p.b_bytes = (unsigned)(nb * 2);
+    p.tilesN = (s.N + 255) / 256;
+    const int grid = ((s.M + 255) / 256) * p.tilesN;
+    const double fl = 2.0 * s.M * s.N * s.K;
+    const int reps = fl > 5e11 ? 5 : 20;
+    for (int prio = 0; prio < 2; ++prio) {
+      p.prio = prio;
+      const float t0 = run<0>(p, grid, reps), t2 = run<2>(p, grid, reps), t3 = run<3>(p, grid, reps), t4 = run<4>(p, grid, reps);
+      printf("%-36s M%6d N%5d K%5d blocks %5d prio %d: burst %7.1f us %5.0f TF/s | spread %7.1f us %5.0f | halves spread %7.1f us %5.0f | halves burst %7.1f us %5.0f\n",
+             s.what, s.M, s.N, s.K, grid, prio, t0 * 1e3, fl / t0 / 1e9, t2 * 1e3, fl / t2 / 1e9, t3 * 1e3, fl / t3 / 1e9,
+             t4 * 1e3, fl / t4 / 1e9);
+    }
+    // check sampled outputs against a host dot product (the full-epilogue variant ran last? no: rerun it)
+    p.prio = 0;
+    run<3>(p, grid, 1);
+    hipMemcpy(hc.data(), dC, nc * 2, hipMemcpyDeviceToHost);
+    double maxerr = 0.0;
+    int bad = 0;
+    for (int i = 0; i < 4000; ++i) {
+      seed = seed * 1664525u + 1013904223u;
+      const int m = (int)((seed >> 4) % (unsigned)s.M);
+      seed = seed * 1664525u + 1013904223u;
+      const int n = (int)((seed >> 4) % (unsigned)s.N);
+      double ref = 0.0;
+      for (int k = 0; k < s.K; ++k) ref += (double)h_bf2f(ha[(size_t)m * s.K + k]) * h_bf2f(hb[(size_t)n * s.K + k]);
+      const double got = h_bf2f(hc[(size_t)m * s.N + n]);
+      const double err = fabs(got - ref);
+      if (err > maxerr) maxerr = err;
+      if (err > 0.02 + 0.01 * fabs(ref)) ++bad;
+    }
+    printf("   check: 4000 samples, max abs err %.4f, bad %d\n", maxerr, bad);
+    hipFree(dA); hipFree(dB); hipFree(dC);
+  }
+  return 0;
+}

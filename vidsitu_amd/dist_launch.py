@@ -28,11 +28,32 @@ def free_port():
 
 
 def visible_gpus():
-    """Number of visible GPUs WITHOUT initialising one (`device_count` does not create a context on this
-    image; `torch.cuda.is_available()` would)."""
-    import torch
+    """Number of GPUs this process could use, WITHOUT touching the HIP / HSA runtime (the launcher parent must stay
+    GPU-free: it forks the ranks): the KFD topology nodes that carry SIMDs (CPU nodes have `simd_count 0`), cut down by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when one is set.  Where the topology is not exposed (a sandbox without
+    that sysfs tree) the count falls back to `torch.cuda.device_count()` -- hipGetDeviceCount: it loads the runtime but
+    creates no context and opens no queue on this image."""
+    import glob
 
-    return int(torch.cuda.device_count())
+    files = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not files:
+        import torch
+
+        return int(torch.cuda.device_count())
+    n = 0
+    for f in files:
+        try:
+            with open(f) as fh:
+                props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+        except OSError:
+            continue  # a node this user may not read is not a usable GPU
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
 
 
 def rank_env(rank, world, port, base=None):

@@ -238,7 +238,7 @@ def conv_wgrad_aol(dy, x, in_scale, in_shift, out=None):
         raise _lib.VsError("conv_wgrad out must be fp32 with [Cout][taps][Cin] memory")
     d = make_desc(x.shape, act_ld(x), dy.shape, act_ld(dy), _K1, _S1, _P0, 0)
     need = _lib.load().vs_conv_wgrad_workspace_bytes(C.byref(d))
-    ws = _workspace(need, x.device) if need else None
+    ws = _workspace(need, x.device, "wgrad") if need else None
     _lib.call("vs_conv_wgrad_aol", _ptr(dy), _ptr(x), _ptr(out), C.byref(d), _ptr(in_scale), _ptr(in_shift),
               _ptr(ws), C.c_size_t(ws.numel() if ws is not None else 0), _stream())
     return out
@@ -473,8 +473,13 @@ def wgrad_reduce_flush():
     _lib.call("vs_wgrad_reduce_flush")
 
 
-def _workspace(nbytes, device):
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+def _workspace(nbytes, device, kind="scratch"):
+    """Per-(device, stream) scratch.  kind = "wgrad": the weight-gradient slabs live in a buffer of their own -- a slab
+    reduce may stay un-launched until the next BN-backward finalize on its stream (REDUCE_MERGE), and nothing else that
+    takes a workspace (a split-K dgrad of the same unit, the stems' slabs, gemm_nt's partials) may write over slabs
+    that are still waiting; only another weight gradient gets the same buffer, and vs_conv_wgrad flushes the pending
+    reduce when it is handed the buffer it reads."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream, kind)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -540,7 +545,7 @@ def conv_wgrad_split(dy, x, k, s, p, out, ring=0):
         raise _lib.VsError("conv_wgrad out must be fp32 with [Cout][taps][Cin] memory")
     d = make_desc(x.shape, act_ld(x), dy.shape, act_ld(dy), k, s, p, (ring & 7) << 16)
     need = int(_lib.load().vs_conv_wgrad_workspace_bytes(C.byref(d)))
-    ws = _workspace(need, x.device) if need else None
+    ws = _workspace(need, x.device, "wgrad") if need else None
     splits = C.c_int(0)
     _lib.call("vs_conv_wgrad_partial", _ptr(dy), _ptr(x), _ptr(out), C.byref(d), _ptr(ws), C.c_size_t(need),
               C.byref(splits), _stream())
@@ -565,7 +570,7 @@ def conv_wgrad(dy, x, k, s, p, out=None, ring=0, batch=None, tile=None, slots=0)
     flags = ((ring & 7) << 16) | (((tile + 1) << 8) if tile is not None else 0) | (((slots // 8) & 0xff) << 24)
     d = make_desc(x.shape, act_ld(x), dy.shape, act_ld(dy), k, s, p, flags)
     need = _lib.load().vs_conv_wgrad_workspace_bytes(C.byref(d))
-    ws = _workspace(need, x.device) if need else None
+    ws = _workspace(need, x.device, "wgrad") if need else None
     _lib.call("vs_conv_wgrad", _ptr(dy), _ptr(x), _ptr(out), C.byref(d), _ptr(ws),
               C.c_size_t(ws.numel() if ws is not None else 0), _stream())
     return out

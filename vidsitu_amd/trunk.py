@@ -289,7 +289,9 @@ class _Unit:
             y, partials = ops.conv_fwd(x, conv.w_bf16, conv.k, conv.s, conv.p, stats=True)
         # the apply pass finalizes for itself where the partial-row count allows it (ops.bn_apply_fin: no finalize
         # launch on the chain); the pooled stems and debug traces keep the separate launches
-        fin_fused = (not pool and not no_apply and _Unit.trace is None and y.is_cuda
+        # (a conv with a bias keeps the separate finalize: its running-mean correction below must come AFTER the
+        #  finalize's momentum update -- applied before the in-kernel update it would be scaled by 1 - momentum)
+        fin_fused = (not pool and not no_apply and _Unit.trace is None and y.is_cuda and conv.bias is None
                      and ops.bn_fin_fusable(partials.shape[0], y.shape[1]))
         if not fin_fused:
             scale, shift, mean, invstd = ops.bn_finalize(
