@@ -59,6 +59,9 @@ typedef enum vs_status {
                                   of both vs_conv_dgrad_bnstats_rows and the launch (the tile kernel's variant only) */
 #define VS_CONV_FORCEPW (1 << 24) /* run it on that kernel whenever the shape is eligible, also where the plan would
                                      not (one block per CU; A/B, tests) */
+#define VS_CONV_NODEEP (1 << 27) /* keep a >= 192-column deep-reduction conv on the 128 x 128 tile kernel instead of the
+                                    256 x 256 deep-pipeline kernel (conv_deep.hip; A/B, tests) */
+#define VS_CONV_FORCEDEEP (1 << 28) /* run it on the deep-pipeline kernel whenever the shape is eligible (A/B, tests) */
 
 /* Geometry of one Conv3d (bias-free, groups 1, dilation 1).
  * Replaces nn.Conv3d reached from vidsitu_code/mdl_sf_base.py:22-33 (s1..s5,

@@ -735,6 +735,106 @@ def test_halo_image_kernel_fwd_and_dgrad(case, dev):
     assert float((psb.double().sum(0).cpu() - want).abs().max()) / float(want.abs().max()) < 1e-5
 
 
+# name, N, Cin, T, H, W, Cout, k, s, p: shapes for the deep-pipeline kernel (>= 192 columns both directions)
+DEEP_CASES = [
+    ("s4a_t3_1024_256", 2, 1024, 8, 14, 14, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ("s4b_3x3_256", 2, 256, 4, 14, 14, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("pw_dense_1024_512", 2, 1024, 4, 14, 14, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("pw_strided_640_1024", 2, 640, 4, 14, 14, 1024, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
+    ("3x3_strided_256_256", 2, 256, 4, 14, 14, 256, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ("ragged_72_264", 3, 72, 3, 13, 11, 264, (1, 3, 3), (1, 1, 1), (0, 1, 1)),   # K = 648 (tail), N = 256 + 8, M = 1287
+    ("nk1_64_256", 2, 64, 2, 14, 14, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),      # one k-tile: prologue only
+    ("nk2_128_256", 2, 128, 2, 14, 14, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("nk3_192_200", 2, 192, 2, 14, 14, 200, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("t5_64_320", 2, 64, 8, 9, 9, 320, (5, 1, 1), (1, 1, 1), (2, 0, 0)),
+    ("dg_wide_256_1024", 2, 1024, 4, 14, 14, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)),  # its dgrad: N = 1024, K = 768
+]
+
+
+@pytest.mark.parametrize("case", DEEP_CASES, ids=[c[0] for c in DEEP_CASES])
+def test_deep_pipeline_kernel_fwd_and_dgrad(case, dev):
+    """conv_deep.hip (256 x 256 x 64 tile, 8 waves, sub-buffer ring 7 phases deep): forward with every epilogue
+    (BN-stat partials, affine + ReLU, residual into a wider buffer) and the unit-stride data gradient (plain,
+    + residual, + masked residual, + the producer's BN-backward sums in both mask forms) against torch and against
+    the 128 x 128 tile kernel (VS_CONV_NODEEP) -- pointwise dense / strided, temporal and spatial taps, 1 .. 48
+    k-tiles, row / column / reduction tails."""
+    from vidsitu_amd import ops
+
+    name, n, cin, t, h, w, cout, k, s, p = case
+    g = torch.Generator().manual_seed(83)
+    x = rb(torch.randn(n, cin, t, h, w, generator=g))
+    wgt = rb(torch.randn(cout, cin, *k, generator=g) / (cin * k[0] * k[1] * k[2]) ** 0.5)
+    xa, wa = to_act(x, dev), to_w(wgt, dev)
+    ref = F.conv3d(x, wgt, stride=s, padding=p)
+    ys = tuple(ref.shape)
+    FORCE, NO = 1 << 28, 1 << 27  # VS_CONV_FORCEDEEP / VS_CONV_NODEEP (+ NOHALO | NOPW: the comparison kernel is the tile kernel)
+    assert _plan(ops, tuple(x.shape), ys, cin, cout, k, s, p, 0, FORCE | (1 << 21) | (1 << 23))[4] == 4, "forward did not take the deep kernel"
+    kw = dict(halo=False, pw=False)
+    y, part = ops.conv_fwd(xa, wa, k, s, p, stats=True, deep="force", **kw)
+    assert_close(y, ref, TOL, name + " fwd")
+    y0, part0 = ops.conv_fwd(xa, wa, k, s, p, stats=True, deep=False, **kw)
+    assert_close(y, y0.float(), 4e-3, name + " fwd vs 128 x 128 tile")
+    tot, tot0 = part.double().sum(0).cpu(), part0.double().sum(0).cpu()
+    assert part.shape[0] == (ops.act_rows(y) + 255) // 256
+    assert torch.allclose(tot, tot0, rtol=2e-3, atol=2e-3 * float(tot0.abs().max()))
+    assert torch.allclose(tot[0], ref.double().sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=2e-2)
+    assert torch.allclose(tot[1], (ref.double() ** 2).sum(dim=(0, 2, 3, 4)), rtol=2e-3, atol=2e-2)
+    # run to run: bit for bit
+    y2, part2 = ops.conv_fwd(xa, wa, k, s, p, stats=True, deep="force", **kw)
+    assert torch.equal(y2.view(torch.int16), y.view(torch.int16)) and torch.equal(part2, part)
+    # folded BN + residual + ReLU into a wider (concat) buffer
+    sc = (torch.rand(cout, generator=g) + 0.5).to(dev)
+    sh = torch.randn(cout, generator=g).to(dev)
+    r = rb(torch.randn(ref.shape, generator=g))
+    buf = ops.new_act(ys[0], cout + 16, *ys[2:], dev, zero=True)
+    out = ops.channel_slice(buf, 8, cout)
+    ops.conv_fwd(xa, wa, k, s, p, out=out, scale=sc, shift=sh, residual=to_act(r, dev), relu=True, deep="force", **kw)
+    want = (ref * sc.cpu().view(1, -1, 1, 1, 1) + sh.cpu().view(1, -1, 1, 1, 1) + r).relu()
+    assert_close(out, want, TOL, name + " fwd epilogue")
+    assert float(buf[:, :8].abs().max()) == 0.0 and float(buf[:, 8 + cout:].abs().max()) == 0.0
+    if s != (1, 1, 1) or cin < 192:
+        return  # the data gradient of a strided conv is the transposed gather (tile kernel); < 192 columns: not deep
+    xg = x.clone().requires_grad_()
+    yy = F.conv3d(xg, wgt, stride=s, padding=p)
+    dy = rb(torch.randn(yy.shape, generator=g))
+    (dx_ref,) = torch.autograd.grad(yy, xg, dy)
+    wt = ops.weight_transpose(wa)
+    dya = to_act(dy, dev)
+    xs = tuple(x.shape)
+    assert _plan(ops, xs, ys, cin, cout, k, s, p, 1, FORCE | (1 << 21) | (1 << 23))[4] == 4, "dgrad did not take the deep kernel"
+    dx = ops.conv_dgrad(dya, wt, xs, k, s, p, deep="force", **kw)
+    assert_close(dx, dx_ref, TOL, name + " dgrad")
+    assert_close(dx, ops.conv_dgrad(dya, wt, xs, k, s, p, deep=False, **kw).float(), 2.0 ** -7, name + " dgrad vs tile")
+    rr = rb(torch.randn(x.shape, generator=g))
+    rra = to_act(rr, dev)
+    dxr = ops.conv_dgrad(dya, wt, xs, k, s, p, residual=rra, deep="force", **kw)
+    assert_close(dxr, dx_ref + rr, TOL, name + " dgrad + residual")
+    rows = ops.act_rows(rra)
+    bits = torch.randint(0, 256, (rows, cin // 8), generator=g, dtype=torch.uint8).to(dev)
+    keep = _unpack_bits(bits, xs)
+    dxm = ops.conv_dgrad(dya, wt, xs, k, s, p, residual=rra, residual_bits=bits, deep="force", **kw)
+    assert_close(dxm, dx_ref + torch.where(keep.cpu(), rr, torch.zeros(())), TOL, name + " dgrad + masked residual")
+    bn_y = to_act(rb(torch.randn(x.shape, generator=g)), dev)
+    mean = (torch.randn(cin, generator=g) * 0.2).to(dev)
+    invstd = (torch.rand(cin, generator=g) + 0.5).to(dev)
+    gamma, beta = torch.randn(cin, generator=g).to(dev), (torch.randn(cin, generator=g) * 0.3).to(dev)
+    dxs, psum = ops.conv_dgrad(dya, wt, xs, k, s, p, bn_stats=(bn_y, mean, invstd, gamma, beta), deep="force", **kw)
+    assert psum is not None and psum.shape[0] == (rows + 255) // 256
+    assert torch.equal(dxs.view(torch.int16), dx.view(torch.int16))
+    v = lambda a: a.view(1, -1, 1, 1, 1)
+    xh = (bn_y.float() - v(mean)) * v(invstd)
+    gm = torch.where(xh * v(gamma) + v(beta) > 0, dx.float(), torch.zeros((), device=dev))
+    want = torch.stack([gm.double().sum((0, 2, 3, 4)), (gm * xh).double().sum((0, 2, 3, 4))]).cpu()
+    got = psum.double().sum(0).cpu()
+    assert float((got - want).abs().max()) / float(want.abs().max()) < 2e-3
+    dxb, psb = ops.conv_dgrad(dya, wt, xs, k, s, p, residual=rra, bn_stats=(bn_y, mean, invstd, None, None, bits),
+                              deep="force", **kw)
+    assert psb is not None and torch.equal(dxb.view(torch.int16), dxr.view(torch.int16))
+    gm = torch.where(keep, dxr.float(), torch.zeros((), device=dev))
+    want = torch.stack([gm.double().sum((0, 2, 3, 4)), (gm * xh).double().sum((0, 2, 3, 4))]).cpu()
+    assert float((psb.double().sum(0).cpu() - want).abs().max()) / float(want.abs().max()) < 1e-5
+
+
 def test_batched_wgrad_slab_reduce_is_bitwise_the_per_layer_reduce(dev):
     """ops.WgradBatch: the position-split partials of several layers stay in per-layer slabs and ONE launch
     (vs_wgrad_reduce_batched) sums them -- bit for bit what vs_conv_wgrad's own reduce writes; the device table

@@ -12,6 +12,7 @@ from tools.layer_table import rows
 dev = torch.device("cuda:0")
 kinds = [a for a in sys.argv[1:] if not a.startswith("--")] or ["fwd"]
 HALO = "force" if "--halo" in sys.argv else (False if "--nohalo" in sys.argv else True)
+DEEP = "force" if "--deep" in sys.argv else (False if "--nodeep" in sys.argv else True)  # conv_deep.hip: forced / off / plan
 REPS = 20
 NCLIPS = int(next((a.split("=")[1] for a in sys.argv if a.startswith("--clips=")), 8))
 ONLY = next((a.split("=")[1].split(",") for a in sys.argv if a.startswith("--only=")), None)
@@ -70,12 +71,12 @@ for (M, N, K, k, s), (cnt, name, xin) in sorted(agg.items(), key=lambda kv: -2.0
     for kd in kinds:
         if kd == "fwd":
             out = ops.new_act(*ys, device=dev)
-            fn = lambda: ops.conv_fwd(x, wt, k, s, p, out=out, scale=sc, shift=sh, relu=True, halo=HALO)
+            fn = lambda: ops.conv_fwd(x, wt, k, s, p, out=out, scale=sc, shift=sh, relu=True, halo=HALO, deep=DEEP)
         elif kd == "dgrad":
             dy = ops.new_act(*ys, device=dev); dy.normal_()
             wtt = ops.weight_transpose(wt)
             dx = ops.new_act(*x.shape, device=dev)
-            fn = lambda: ops.conv_dgrad(dy, wtt, tuple(x.shape), k, s, p, out=dx, halo=HALO)
+            fn = lambda: ops.conv_dgrad(dy, wtt, tuple(x.shape), k, s, p, out=dx, halo=HALO, deep=DEEP)
         else:
             dy = ops.new_act(*ys, device=dev); dy.normal_()
             dw = torch.empty((N, *k, cin), dtype=torch.float32, device=dev).permute(0, 4, 1, 2, 3)

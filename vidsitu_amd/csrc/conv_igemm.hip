@@ -1584,6 +1584,12 @@ static int launch_conv(ConvP& p, int mode, int naive, int flags, void* ws, size_
       p.tilesN = pg.nsl;
       return vs_pw_launch(p, pg, st);
     }
+    DeepGeo dg;
+    if (vs_deep_plan(p, mode, flags, &dg)) {  // wide, deep reductions that fill the chip with 256 x 256 tiles
+      p.tilesM = dg.tilesM;
+      p.tilesN = dg.tilesN;
+      return vs_deep_launch(p, mode, dg, st);
+    }
   }
   const ConvPlan pl = plan_conv(p.M, p.Ncols, p.K, p.kT * p.kH * p.kW, flags);
   if (p.in_scale) {  // apply on load: vs_conv_aol_ok told the caller which launches exist
@@ -1711,6 +1717,8 @@ extern "C" int vs_conv_stats_rows(const vs_conv_desc* d) {
     PwGeo pg;
     p.flags |= d->flags & VS_CONV_RESIDUAL;
     if (vs_pw_plan(p, mode, d->flags, &pg)) return pg.tilesM;
+    DeepGeo dg;
+    if (!(d->flags & VS_CONV_NAIVE) && vs_deep_plan(p, mode, d->flags, &dg)) return dg.tilesM;
   }
   const long long M = (long long)d->N * d->To * d->Ho * d->Wo;
   const ConvPlan pl = plan_conv(M, d->Cout, d->kT * d->kH * d->kW * d->Cin, d->kT * d->kH * d->kW,
@@ -1741,6 +1749,15 @@ extern "C" int vs_conv_plan(const vs_conv_desc* d, int dgrad, int* out) {
       out[2] = pg.nslot;  // activation ring slots
       out[3] = 1;
       out[4] = 3;  // persistent pointwise kernel
+      return VS_OK;
+    }
+    DeepGeo dg;
+    if (mode >= 0 && !(d->flags & VS_CONV_NAIVE) && vs_deep_plan(p, mode, d->flags, &dg)) {
+      out[0] = 256;
+      out[1] = 256;
+      out[2] = 8;  // sub-buffers of the ring (7 in flight)
+      out[3] = 1;
+      out[4] = 4;  // deep-pipeline kernel
       return VS_OK;
     }
   }
@@ -2009,6 +2026,8 @@ extern "C" int vs_conv_dgrad_bnstats_rows(const vs_conv_desc* d) {
     PwGeo pg;
     p.flags |= VS_CONV_BNBWD;
     if (vs_pw_plan(p, mode, pf, &pg)) return pg.tilesM;
+    DeepGeo dg;
+    if (vs_deep_plan(p, mode, pf, &dg)) return dg.tilesM;
   }
   const ConvPlan pl = plan_conv(p.M, p.Ncols, p.K, p.kT * p.kH * p.kW, d->flags);
   if (pl.direct) {

@@ -487,3 +487,11 @@ bool vs_pw_plan(const ConvP& p, int mode, int flags, PwGeo* out);
 int vs_pw_launch(const ConvP& p, const PwGeo& g, hipStream_t st);
 bool vs_pw_aol_ok(const PwGeo& g, const ConvP& p);
 
+// ---- deep-pipeline kernel (conv_deep.hip): 256 x 256 x 64 tile, 8 waves, sub-buffer ring 7 phases deep ----
+struct DeepGeo {
+  int tilesM, tilesN;  // 256 x 256 tiles (tilesM = rows of the batch-statistic / BN-backward partials)
+  int smem;            // dynamic LDS of the launch
+};
+bool vs_deep_plan(const ConvP& p, int mode, int flags, DeepGeo* out);
+int vs_deep_launch(const ConvP& p, int mode, const DeepGeo& g, hipStream_t st);
+

@@ -145,7 +145,7 @@ def tile_flag(kind, M, ncols, K, k, s, force=None):
 
 
 def conv_fwd(x, w, k, s, p, out=None, scale=None, shift=None, residual=None, relu=False,
-             stats=False, naive=False, tile=None, dbg=0, splitk=False, ring=0, halo=True, pw=True):
+             stats=False, naive=False, tile=None, dbg=0, splitk=False, ring=0, halo=True, pw=True, deep=True):
     """y = conv3d(x, w) [*scale+shift] [+residual] [relu]; optional BN-stat partials.
     Returns (y, partials|None)."""
     cout = w.shape[0]
@@ -182,6 +182,10 @@ def conv_fwd(x, w, k, s, p, out=None, scale=None, shift=None, residual=None, rel
         flags |= 1 << 23  # VS_CONV_NOPW
     elif pw == "force":
         flags |= 1 << 24  # VS_CONV_FORCEPW
+    if not deep:
+        flags |= 1 << 27  # VS_CONV_NODEEP
+    elif deep == "force":
+        flags |= 1 << 28  # VS_CONV_FORCEDEEP
     d = make_desc(x.shape, act_ld(x), ys, act_ld(out), k, s, p, flags,
                   act_ld(residual) if residual is not None else 0)
     partials = None
@@ -378,7 +382,7 @@ def transpose_f32_batched(src, dst, table, total, tiled=True):
 
 def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=None, ring=0,
                noclass=False, bn_stats=None, residual_bits=None, inplace=False, halo=True, pw=True,
-               direct_bnb=False, bn_stats2=None):
+               direct_bnb=False, bn_stats2=None, deep=True):
     """dx[xs] = conv_transpose(dy, w) (+ residual).  wt from weight_transpose.
     bn_stats = (y, mean, invstd, gamma, beta[, relu_bits]) of the BatchNorm + ReLU unit whose output this
     convolution consumed and whose complete dz this dx is: returns (dx, partial) with partial [rows, 2, Cin]
@@ -410,6 +414,10 @@ def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=N
         flags |= 1 << 24  # VS_CONV_FORCEPW
     if direct_bnb:
         flags |= 1 << 25  # VS_CONV_DIRECTBNB
+    if not deep:
+        flags |= 1 << 27  # VS_CONV_NODEEP
+    elif deep == "force":
+        flags |= 1 << 28  # VS_CONV_FORCEDEEP
     two = bn_stats2 is not None and bn_stats is not None and residual is not None and tuple(s) == (1, 1, 1)
     if two:
         flags |= 1 << 26  # VS_CONV_BNB2
