@@ -74,3 +74,29 @@ for k, (t, c) in sorted(by_next.items(), key=lambda kv: -kv[1][0])[:14]:
 print("idle by (kernel that ended last -> kernel that starts):")
 for k, (t, c) in sorted(by_pair.items(), key=lambda kv: -kv[1][0])[:14]:
     print(f"  {t / 1e3:7.1f} us {c:4d} x {t / c / 1e3:5.1f}  {k}")
+
+# how many kernels run at once (time at depth 0 / 1 / 2 / 3+), over the last step, and which kernels run ALONE
+ev2 = []
+for a, b, n in s:
+    ev2.append((a, 1, n)); ev2.append((b, -1, n))
+ev2.sort(key=lambda x: (x[0], x[1]))
+hist = collections.Counter(); alone = collections.defaultdict(int); live = {}
+last = ev2[0][0]; depth = 0
+for t, d, n in ev2:
+    dt = t - last
+    if dt > 0:
+        hist[min(depth, 3)] += dt
+        if depth == 1:
+            alone[next(iter(live.values())).split("(")[0][:60]] += dt
+    if d > 0:
+        live[(t, n)] = n
+    else:
+        for k in list(live):
+            if k[1] == n:
+                del live[k]; break
+    depth += d; last = t
+span = (max(x[1] for x in s) - s[0][0])
+print("time by number of kernels running (last step): " + ", ".join(f"{k}{'+' if k == 3 else ''}: {v / 1e3:.0f} us ({100.0 * v / span:.0f} %)" for k, v in sorted(hist.items())))
+print("kernels that run ALONE on the chip (no other kernel resident), by time:")
+for k, t in sorted(alone.items(), key=lambda kv: -kv[1])[:16]:
+    print(f"  {t / 1e3:8.1f} us  {k}")

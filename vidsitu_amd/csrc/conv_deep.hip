@@ -76,7 +76,14 @@ __global__ __launch_bounds__(512) void conv_deep_kernel(ConvP p) {
         continue;
       }
       int tap, c8, dw, dh, dt, t2;
-      fast_divmod(k8, C8, rcpC8, tap, c8);
+      if (p.korder) {  // chunk-major: k-tile kt = chunk kt / taps of tap kt % taps (ConvP::korder)
+        const int ntaps = p.kT * p.kH * p.kW;
+        int chunk;
+        fast_divmod(k8 >> 3, ntaps, 1.0f / (float)ntaps, chunk, tap);
+        c8 = chunk * 8 + (k8 & 7);
+      } else {
+        fast_divmod(k8, C8, rcpC8, tap, c8);
+      }
       fast_divmod(tap, p.kW, rcpkW, t2, dw);
       fast_divmod(t2, p.kH, rcpkH, dt, dh);
       const long long dpos = (((long long)dt * p.Gh + dh) * p.Gw + dw) * p.tmul;
@@ -482,14 +489,19 @@ bool vs_deep_plan(const ConvP& p, int mode, int flags, DeepGeo* out) {
   const int tilesM = (p.M + 255) / 256, tilesN = (p.Ncols + 255) / 256;
   const int nk = (p.K + 63) / 64;
   if (deep_mode() != 2 && !(flags & VS_CONV_FORCEDEEP)) {
-    // Where it pays (per-layer A/B at 8 and 32 clips, isolated launches: profiles/r04_deep_layers_*.txt): the chip
-    // has to be full of 256 x 256 tiles (one block per CU, 150 KiB of LDS each), the column tiles have to be mostly
-    // useful, and the reduction deep enough to amortise the longer prologue / two-pass epilogue.
+    // Where it pays (per-layer A/B at 8 and 32 clips, isolated launches: profiles/r04_deep_layers.txt).  A block costs
+    // ~13 us of prologue + two-pass epilogue and ~1.15 us per k-tile; with one block per CU (150 KiB of LDS) whole
+    // rounds of 256 tiles count, and columns beyond Ncols are wasted work.  Useful fraction of the launch:
+    //   fill x column efficiency x nk * 1.15 / (13 + nk * 1.15);
+    // measured: >= 0.49 wins 1.14-1.30x (s4.a / s4.b / s5.b0.a at 32 clips, s4.b0.a at 8), 0.39 wins 1.15x or ties
+    // (s4.a dgrad at 8 clips, s4.b0.a dgrad at 32), <= 0.36 ties or loses (s4 shortcut 0.95-1.01x, s4.b0.a dgrad at 8
+    // clips 0.85x); fewer than 160 tiles (s5 at 8 clips, s4.a / s4.b forward at 8 clips) lose 0.4-0.7x.
     const long long tiles = (long long)tilesM * tilesN;
     const double col_eff = (double)p.Ncols / (256.0 * tilesN);
     const long long rounds = (tiles + 255) / 256;
     const double fill = (double)tiles / (256.0 * rounds);
-    if (tiles < 160 || col_eff < 0.8 || fill < 0.7 || nk < 8) return false;
+    const double loop = nk * 1.15 / (13.0 + nk * 1.15);
+    if (tiles < 160 || fill * col_eff * loop < 0.38) return false;
   }
   out->tilesM = tilesM;
   out->tilesN = tilesN;

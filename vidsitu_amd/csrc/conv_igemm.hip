@@ -137,7 +137,14 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, c
         continue;
       }
       int tap, c8;
-      fast_divmod(k8, C8, rcpC8, tap, c8);  // k8 < 2^24: float-reciprocal splits (three integer divisions per entry before)
+      if (p.korder && !cls) {  // chunk-major: k-tile kt = chunk kt / taps of tap kt % taps (Cg % 64 == 0)
+        const int ntaps = p.kT * p.kH * p.kW;
+        int kt = k8 >> 3, chunk;
+        fast_divmod(kt, ntaps, 1.0f / (float)ntaps, chunk, tap);
+        c8 = chunk * 8 + (k8 & 7);
+      } else {
+        fast_divmod(k8, C8, rcpC8, tap, c8);  // k8 < 2^24: float-reciprocal splits (three integer divisions per entry before)
+      }
       int dw, dh, dt;
       if (cls) {  // enumerate only the taps of this class
         int iw, t2, ih, it;
@@ -1561,6 +1568,12 @@ static int launch_conv(ConvP& p, int mode, int naive, int flags, void* ws, size_
   static const int ff_max = [] { const char* e = getenv("VS_RING_FF_MAX"); return e ? atoi(e) : 1 << 30; }();
   p.ff_min = ff_min >= 0 ? ff_min : (frags_first == 1 ? 0 : 1 << 30);
   p.ff_max = ff_max;
+  {
+    // chunk-major reduction (ConvP::korder) where a tap spans at least VS_CONV_KORDER_MIN k-tiles (default 2; 0 = never)
+    static const int kmin = [] { const char* e = getenv("VS_CONV_KORDER_MIN"); return e ? atoi(e) : 2; }();
+    const int taps = p.kT * p.kH * p.kW;
+    p.korder = (kmin > 0 && mode != 0 && taps > 1 && taps <= 31 && p.Cg % 64 == 0 && p.Cg / 64 >= kmin) ? 1 : 0;
+  }
   p.splitK = 1;
   p.slab = nullptr;
   if (naive) {

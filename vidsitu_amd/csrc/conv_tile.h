@@ -53,6 +53,11 @@ struct ConvP {
   int dense;  // pointwise, unit stride: row m is position m of the gathered tensor (no row decode)
   int nclips;  // M / (Rt * Rh * Rw)
   int ff_min, ff_max;  // ring loop: fragment reads before the copy issue for ff_min <= k-steps <= ff_max
+  // Order of the reduction (gathering launches with > 1 tap and Cg % 64 == 0): 0 = tap-major (k = tap * Cg + c, the
+  // weights' own order), 1 = chunk-major (k-tile kt = 64-channel chunk kt / taps of tap kt % taps).  The taps of a
+  // position re-read (nearly) the same activation rows: tap-major puts Cg / 64 k-tiles -- on the wide layers more
+  // than an XCD's 4 MiB of L2 worth of streaming -- between two reads of a row, chunk-major one or two.
+  int korder;
   // VS_CONV_BNBWD with RESIDUAL, second unit: a ResBlock's shortcut unit receives the same masked gradient as its c
   // unit (one sum(g), two sum(g * xhat)): stats2[tm][0][c] = sum g, [1][c] = sum g * (bny2 - mean2) * invstd2
   const uint16_t* bny2;

@@ -1859,33 +1859,54 @@ __global__ void adam_dev_kernel(float* p, const void* gv, float* m, float* v, ui
   const float a = lr / bc1;
   const float* g = (const float*)gv;
   const uint16_t* gh = (const uint16_t*)gv;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-       i += (long long)gridDim.x * blockDim.x) {
-    float gg[4];
+  // Two float4 groups per thread and iteration, all eight loads issued before the first use: with one group (four
+  // loads, then ~40 dependent VALU instructions incl. a divide and a square root per element, then the stores) the
+  // kernel moved its 1.1 GB at 2.4 TB/s.  Same arithmetic per element, same results bit for bit.
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += 2 * stride) {
+    const long long i1 = i0 + stride;
+    const bool two = i1 < n4;
+    const long long j1 = two ? i1 : i0;
+    float gg[2][4];
     if (G16) {
-      const uint2 g2 = ((const uint2*)gv)[i];
-      gg[0] = __uint_as_float(g2.x << 16) * grad_scale;
-      gg[1] = __uint_as_float(g2.x & 0xffff0000u) * grad_scale;
-      gg[2] = __uint_as_float(g2.y << 16) * grad_scale;
-      gg[3] = __uint_as_float(g2.y & 0xffff0000u) * grad_scale;
+      const uint2 ga = ((const uint2*)gv)[i0], gb = ((const uint2*)gv)[j1];
+      gg[0][0] = __uint_as_float(ga.x << 16) * grad_scale;
+      gg[0][1] = __uint_as_float(ga.x & 0xffff0000u) * grad_scale;
+      gg[0][2] = __uint_as_float(ga.y << 16) * grad_scale;
+      gg[0][3] = __uint_as_float(ga.y & 0xffff0000u) * grad_scale;
+      gg[1][0] = __uint_as_float(gb.x << 16) * grad_scale;
+      gg[1][1] = __uint_as_float(gb.x & 0xffff0000u) * grad_scale;
+      gg[1][2] = __uint_as_float(gb.y << 16) * grad_scale;
+      gg[1][3] = __uint_as_float(gb.y & 0xffff0000u) * grad_scale;
     } else {
-      const float4 g4 = ((const float4*)gv)[i];
-      gg[0] = g4.x * grad_scale; gg[1] = g4.y * grad_scale; gg[2] = g4.z * grad_scale; gg[3] = g4.w * grad_scale;
+      const float4 ga = ((const float4*)gv)[i0], gb = ((const float4*)gv)[j1];
+      gg[0][0] = ga.x * grad_scale; gg[0][1] = ga.y * grad_scale; gg[0][2] = ga.z * grad_scale; gg[0][3] = ga.w * grad_scale;
+      gg[1][0] = gb.x * grad_scale; gg[1][1] = gb.y * grad_scale; gg[1][2] = gb.z * grad_scale; gg[1][3] = gb.w * grad_scale;
     }
-    float4 m4 = ((float4*)m)[i], v4 = ((float4*)v)[i], p4 = ((float4*)p)[i];
-    float mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
-    float pp[4] = {p4.x, p4.y, p4.z, p4.w};
+    const float4 ma = ((float4*)m)[i0], va = ((float4*)v)[i0], pa = ((float4*)p)[i0];
+    const float4 mb = ((float4*)m)[j1], vb = ((float4*)v)[j1], pq = ((float4*)p)[j1];
+    float mm[2][4] = {{ma.x, ma.y, ma.z, ma.w}, {mb.x, mb.y, mb.z, mb.w}};
+    float vv[2][4] = {{va.x, va.y, va.z, va.w}, {vb.x, vb.y, vb.z, vb.w}};
+    float pp[2][4] = {{pa.x, pa.y, pa.z, pa.w}, {pq.x, pq.y, pq.z, pq.w}};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      mm[e] = b1 * mm[e] + (1.f - b1) * gg[e];
-      vv[e] = b2 * vv[e] + (1.f - b2) * gg[e] * gg[e];
-      const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
-      pp[e] -= a * (mm[e] / denom);
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        mm[u][e] = b1 * mm[u][e] + (1.f - b1) * gg[u][e];
+        vv[u][e] = b2 * vv[u][e] + (1.f - b2) * gg[u][e] * gg[u][e];
+        const float denom = sqrtf(vv[u][e]) / bc2_sqrt + eps;
+        pp[u][e] -= a * (mm[u][e] / denom);
+      }
+    ((float4*)m)[i0] = make_float4(mm[0][0], mm[0][1], mm[0][2], mm[0][3]);
+    ((float4*)v)[i0] = make_float4(vv[0][0], vv[0][1], vv[0][2], vv[0][3]);
+    ((float4*)p)[i0] = make_float4(pp[0][0], pp[0][1], pp[0][2], pp[0][3]);
+    if (pb) ((uint2*)pb)[i0] = make_uint2(pack2_bf16(pp[0][0], pp[0][1]), pack2_bf16(pp[0][2], pp[0][3]));
+    if (two) {
+      ((float4*)m)[i1] = make_float4(mm[1][0], mm[1][1], mm[1][2], mm[1][3]);
+      ((float4*)v)[i1] = make_float4(vv[1][0], vv[1][1], vv[1][2], vv[1][3]);
+      ((float4*)p)[i1] = make_float4(pp[1][0], pp[1][1], pp[1][2], pp[1][3]);
+      if (pb) ((uint2*)pb)[i1] = make_uint2(pack2_bf16(pp[1][0], pp[1][1]), pack2_bf16(pp[1][2], pp[1][3]));
     }
-    ((float4*)m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
-    ((float4*)v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
-    ((float4*)p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
-    if (pb) ((uint2*)pb)[i] = make_uint2(pack2_bf16(pp[0], pp[1]), pack2_bf16(pp[2], pp[3]));
   }
   // scalar tail (n not a multiple of 4, or unaligned buffers: then n4 == 0 and this is everything)
   for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
