@@ -155,6 +155,50 @@ def test_conv_wgrad_matches_autograd(case, dev):
     assert_close(dw, dw_ref, 5e-3, case[0])  # fp32 output, only operand rounding differs
 
 
+# name, N, Cin, T, H, W, Cout, k, s, p: weight gradients for the deep-pipeline kernel (128 x 256 output tiles)
+WGD_CASES = [
+    ("s4a_t3_1024_256", 2, 1024, 8, 14, 14, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ("s4b_3x3_256", 2, 256, 8, 14, 14, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("pw_1024_512", 2, 1024, 4, 14, 14, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ("pw_strided_640_1024", 2, 640, 4, 14, 14, 1024, (1, 1, 1), (1, 2, 2), (0, 0, 0)),
+    ("3x3_strided_256_256", 2, 256, 4, 14, 14, 256, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ("ragged_72_136", 3, 72, 3, 13, 11, 136, (1, 3, 3), (1, 1, 1), (0, 1, 1)),   # Cout 128 + 8, K' 648 = 2 x 256 + 136, P = 1287
+    ("short_64_128", 1, 64, 2, 9, 9, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1)),        # 162 positions: 6 units (< the 6-slot ring + 1)
+    ("one_unit_64_128", 1, 64, 1, 5, 6, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0)),     # 30 positions: a single, partial unit
+    ("long_128_128", 4, 128, 16, 14, 14, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0)),    # 12 544 positions: table chunks rebuilt in flight
+    ("t5_64_320", 2, 64, 8, 9, 9, 320, (5, 1, 1), (1, 1, 1), (2, 0, 0)),
+]
+
+
+@pytest.mark.parametrize("case", WGD_CASES, ids=[c[0] for c in WGD_CASES])
+def test_deep_pipeline_wgrad_matches_autograd_and_the_ring_kernel(case, dev):
+    """conv_wgrad_deep_kernel (128 x 256 tile, units of 32 positions, six-slot ring, five units in flight): against
+    autograd on the same bf16 operands, against fp64 at the kernel's own accuracy, against the ring kernel, and run to
+    run bit for bit -- pointwise dense / strided, temporal and spatial taps, ragged Cout / K' / position counts,
+    position ranges shorter than the ring and longer than a table chunk."""
+    from vidsitu_amd import ops
+
+    name, n, cin, t, h, w, cout, k, s, p = case
+    g = torch.Generator().manual_seed(91)
+    x = rb(torch.randn(n, cin, t, h, w, generator=g))
+    wgt = torch.zeros(cout, cin, *k, requires_grad=True)
+    y = F.conv3d(x, wgt, stride=s, padding=p)
+    dy = rb(torch.randn(y.shape, generator=g))
+    (dw_ref,) = torch.autograd.grad(y, wgt, dy)
+    xa, dya = to_act(x, dev), to_act(dy, dev)
+    dw = ops.conv_wgrad(dya, xa, k, s, p, deep="force")
+    assert tuple(dw.shape) == tuple(dw_ref.shape)
+    assert_close(dw, dw_ref, 5e-3, name)
+    # fp64 on the same operands: only the kernel's own arithmetic is left
+    w64 = torch.zeros(cout, cin, *k, dtype=torch.float64, device=dev, requires_grad=True)
+    ref64 = torch.autograd.grad(F.conv3d(x.to(dev).double(), w64, stride=s, padding=p), w64, dy.to(dev).double())[0]
+    err = float((dw.double() - ref64).norm() / ref64.norm())
+    assert err <= 5e-6, err
+    dw0 = ops.conv_wgrad(dya, xa, k, s, p, deep=False)
+    assert_close(dw, dw0.float(), 1e-5, name + " vs ring kernel")
+    assert torch.equal(ops.conv_wgrad(dya, xa, k, s, p, deep="force"), dw)
+
+
 def test_direct_kernel_epilogue_and_residual(dev):
     """The register-resident small-channel kernel: affine + ReLU, residual add (dgrad fan-out),
     forced tiled kernel gives the same answer."""

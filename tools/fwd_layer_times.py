@@ -80,7 +80,7 @@ for (M, N, K, k, s), (cnt, name, xin) in sorted(agg.items(), key=lambda kv: -2.0
         else:
             dy = ops.new_act(*ys, device=dev); dy.normal_()
             dw = torch.empty((N, *k, cin), dtype=torch.float32, device=dev).permute(0, 4, 1, 2, 3)
-            fn = lambda: ops.conv_wgrad(dy, x, k, s, p, out=dw)
+            fn = lambda: ops.conv_wgrad(dy, x, k, s, p, out=dw, deep=DEEP)
         us = graph_time(fn)
         roof = max(fl / 2.5e15, by / 8e12) * 1e6 / us
         tot[kd][0] += us * cnt

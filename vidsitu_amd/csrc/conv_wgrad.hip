@@ -18,6 +18,7 @@
 #include "common.h"
 
 #include <mutex>
+#include <type_traits>
 #include "glue_bodies.h"
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -503,6 +504,259 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradP p) {
   conv_wgrad_ring_body<BM, BN, WM, WN, MODE, NS, AOL>(p, blockIdx.x, gridDim.x);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Deep-pipeline variant (round 4).  The ring kernel above keeps ONE 64-position step in flight behind
+// `vmcnt(0)` + barrier: its copy stream and its MFMAs do not overlap inside a block (ablation,
+// profiles/r02_wgrad_ablation.txt: copies alone 17 us, MFMAs alone 13.5 us, both 32.6 us on s4.b).  Here:
+//   * 512 threads = 8 waves as 2 (Cout) x 4 (taps * Cin), output tile 128 x 256, wave tile 64 x 64
+//     (16 v_mfma_f32_16x16x32_bf16 per 32 positions; 96 FLOP per staged byte instead of 64);
+//   * the reduction is cut into UNITS of 32 positions = [dY 32 x 128 ch | x 32 x 128 ch | x 32 x 128 ch]
+//     (24 KiB, whole 256-byte rows), six unit slots in LDS; one phase per unit: counted vmcnt, ONE raw
+//     barrier, the copies of the unit six ahead (into the slot whose fragments were read two phases ago),
+//     the transposing fragment reads (ds_read_b64_tr_b16) of the NEXT unit, 16 MFMAs on fragments already in
+//     registers -- five units (120 KiB) in flight;
+//   * the waves of one half (wv >> 2; one wave of each half per SIMD) issue a whole unit's 24 copies, the halves
+//     alternating by unit: every phase has a loading and a purely multiplying wave per SIMD (conv_deep.hip);
+//   * the position table (byte offset + tap mask per position) covers 512 positions, double buffered, rebuilt
+//     every 16 phases one chunk ahead; the fp32 tile leaves through LDS as 16-byte stores.
+// Same slab layout / reduce as the other kernels; a different (fixed) summation order over the positions.
+// ---------------------------------------------------------------------------------------------
+#define WGD_UNIT (3 * 8192)
+#define WGD_NU 6
+#define WGD_TAB 512
+#define WGD_EP 260
+
+template <int MODE>
+__global__ __launch_bounds__(512) void conv_wgrad_deep_kernel(WgradP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int hf = wv >> 2, wq = wv & 3;
+  int bid = blockIdx.x;
+  if (p.xcd_order) {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+  }
+  const int ntile = p.tilesM * p.tilesN;
+  const int s = bid / ntile;
+  bid -= s * ntile;
+  const int tn = bid % p.tilesN, tm = bid / p.tilesN;
+  const int m0 = tm * 128, n0 = tn * 256;
+  const int pbeg = s * p.rows_per_split;
+  const int pend = min(p.P, pbeg + p.rows_per_split);
+  const int nu = (pend - pbeg + 31) >> 5;
+  int2* rowtab = (int2*)(smem + WGD_NU * WGD_UNIT);  // [2][WGD_TAB] (byte offset, tap mask)
+
+  // ---- copy side: instruction j (0, 1) of wave wq covers rows (j * 4 + wq) * 4 + rg of an image, lane -> 16-byte chunk cc
+  const int rg = lane >> 4, cc = lane & 15;
+  const int lc = cc ^ ((rg << 1) | ((wq >> 1) << 3));  // logical chunk fetched into physical chunk cc (row swizzle)
+  const bool mcol_ok = (m0 + lc * 8) < p.Cout;
+  const unsigned dycol = (unsigned)((m0 + lc * 8) * 2);
+  bool ncol_ok[2];
+  int tap[2];
+  unsigned xtap[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ncol = n0 + i * 128 + lc * 8;
+    ncol_ok[i] = ncol < p.Kp;
+    tap[i] = 0;
+    xtap[i] = (unsigned)(ncol * 2);
+    if (MODE == 1 && ncol_ok[i]) {
+      tap[i] = ncol / p.Cin;
+      const int c0 = ncol - tap[i] * p.Cin;
+      const int dw = tap[i] % p.kW, t2 = tap[i] / p.kW;
+      const int dh = t2 % p.kH, dt = t2 / p.kH;
+      xtap[i] = (unsigned)(((((long long)dt * p.Hi + dh) * p.Wi + dw) * p.x_ld + c0) * 2);
+    }
+  }
+  const unsigned dy_pitch = (unsigned)(p.dy_ld * 2), x_pitch = (unsigned)(p.x_ld * 2);
+  typedef __attribute__((address_space(3))) char* lds_ptr_t;
+  const unsigned lds0 = (unsigned)(unsigned long)(lds_ptr_t)smem + (unsigned)wq * 1024u;
+  auto rsrc_words = [](const void* base, unsigned bytes) __attribute__((always_inline)) {
+    const unsigned long a = (unsigned long)base;
+    return (i32x4){(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+  };
+  const i32x4 xdesc = rsrc_words(p.x, p.x_bytes), dydesc = rsrc_words(p.dy, p.dy_bytes);
+  auto dma16 = [](const i32x4& desc, unsigned lds_addr, unsigned voff) __attribute__((always_inline)) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :
+                 : "s"(lds_addr), "v"(voff), "s"(desc)
+                 : "memory");
+  };
+  const bool small_p = p.P < (1 << 24);
+  const float rcpWo = 1.0f / (float)p.Wo, rcpHo = 1.0f / (float)p.Ho, rcpTo = 1.0f / (float)p.To;
+  auto build_tab = [&](int chunk) __attribute__((always_inline)) {  // 512 positions, one per thread
+    int2* tab = rowtab + (chunk & 1) * WGD_TAB;
+    const int pp = pbeg + chunk * WGD_TAB + tid;
+    int2 e = make_int2(0, 0);
+    if (pp < pend) {
+      int wo, t1, ho, t2, to, n;
+      if (small_p) {
+        fast_divmod(pp, p.Wo, rcpWo, t1, wo);
+        fast_divmod(t1, p.Ho, rcpHo, t2, ho);
+        fast_divmod(t2, p.To, rcpTo, n, to);
+      } else {
+        wo = pp % p.Wo; t1 = pp / p.Wo;
+        ho = t1 % p.Ho; t2 = t1 / p.Ho;
+        to = t2 % p.To; n = t2 / p.To;
+      }
+      const int ti0 = to * p.sT - p.pT, hi0 = ho * p.sH - p.pH, wi0 = wo * p.sW - p.pW;
+      const long long pos0 = (((long long)n * p.Ti + ti0) * p.Hi + hi0) * p.Wi + wi0;
+      e.x = (int)(unsigned)(pos0 * p.x_ld * 2);  // exact modulo 2^32 whenever the tap is valid
+      unsigned mt = 0u, mh = 0u, mw = 0u;
+      for (int a = 0; a < p.kT; ++a) mt |= ((unsigned)(ti0 + a) < (unsigned)p.Ti ? 1u : 0u) << a;
+      for (int a = 0; a < p.kH; ++a) mh |= ((unsigned)(hi0 + a) < (unsigned)p.Hi ? 1u : 0u) << a;
+      for (int a = 0; a < p.kW; ++a) mw |= ((unsigned)(wi0 + a) < (unsigned)p.Wi ? 1u : 0u) << a;
+      unsigned mk = 0u;
+      int tp = 0;
+      for (int a = 0; a < p.kT; ++a)
+        for (int b = 0; b < p.kH; ++b) {
+          const unsigned th = (mt >> a) & (mh >> b) & 1u;
+          mk |= (th ? mw : 0u) << tp;
+          tp += p.kW;
+        }
+      e.y = (int)mk;
+    }
+    tab[tid] = e;
+  };
+  // the 6 copies of this wave's share of unit u (only the half u & 1 issues): dY, x image 0, x image 1
+  auto dma_unit = [&](int u, int slot) __attribute__((always_inline)) {
+    if ((u & 1) != hf) return;
+    const unsigned U = lds0 + (unsigned)(slot * WGD_UNIT);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int rel = u * 32 + j * 16 + wq * 4 + rg;  // position relative to pbeg
+      const int pp = pbeg + rel;
+      const bool pok = pp < pend;
+      dma16(dydesc, U + j * 4096, (mcol_ok && pok) ? (unsigned)pp * dy_pitch + dycol : WG_OOB);
+      int2 e = make_int2(0, 0);
+      if (MODE == 1) e = rowtab[((rel >> 9) & 1) * WGD_TAB + (rel & (WGD_TAB - 1))];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        unsigned ok = (unsigned)ncol_ok[i] & (unsigned)pok;
+        unsigned off;
+        if (MODE == 0) {
+          off = (unsigned)pp * x_pitch + xtap[i];
+        } else {
+          ok &= ((unsigned)e.y >> tap[i]) & 1u;
+          off = (unsigned)e.x + xtap[i];
+        }
+        dma16(xdesc, U + (1 + i) * 8192 + j * 4096, ok ? off : WG_OOB);
+      }
+    }
+  };
+
+  // ---- compute side
+  const int wm = wv >> 2, wn = wv & 3;
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, pp4 = li & 3;
+  const int frow = 8 * g + q;  // this lane supplies unit rows frow and frow + 4
+  const int fswz = ((frow & 3) << 2) | (((frow >> 3) & 1) << 4);
+  unsigned aoff[4], boff[4];  // byte offsets of the lane's fragment sources inside a unit
+#pragma unroll
+  for (int a = 0; a < 4; ++a) aoff[a] = (unsigned)(frow * 256 + (((((wm * 64 + a * 16) >> 2) + pp4) ^ fswz) << 3));
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+    boff[b] = (unsigned)((1 + (wn >> 1)) * 8192 + frow * 256 + ((((((wn & 1) * 64 + b * 16) >> 2) + pp4) ^ fswz) << 3));
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 FA0[4], FB0[4], FA1[4], FB1[4];
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  auto read_frags = [&](int slot, bf16x8 (&fa)[4], bf16x8 (&fb)[4]) __attribute__((always_inline)) {
+    const char* U = smem + slot * WGD_UNIT;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const lds_s16x4* ptr = (const lds_s16x4*)(U + aoff[a]);
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)ptr);
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ptr + 128));
+      fa[a] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const lds_s16x4* ptr = (const lds_s16x4*)(U + boff[b]);
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)ptr);
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ptr + 128));
+      fb[b] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+  };
+  auto mma = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4]) __attribute__((always_inline)) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // before the fragment reads of unit u (issued 5 phases ago by half u & 1): that half's two younger units stay in flight
+  auto open_phase = [&](int u) __attribute__((always_inline)) {
+    if (hf == (u & 1)) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto close_phase = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  if (MODE == 1) {
+    build_tab(0);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < 5; ++u) dma_unit(u, u);
+  open_phase(0);  // phase -1: unit 0 landed; issue unit 5; fragments of unit 0
+  dma_unit(5, 5);
+  read_frags(0, FA0, FB0);
+  close_phase();
+  int slot = 0;  // slot of unit ph
+  // phase ph: multiply unit ph (fragments in registers), read unit ph + 1, issue unit ph + 6 into unit ph's slot
+  auto phase = [&](auto par, int ph) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par)::value;
+    open_phase(ph + 1);
+    if (MODE == 1 && (ph & 15) == 0 && pbeg + ((ph >> 4) + 1) * WGD_TAB < pend) build_tab((ph >> 4) + 1);
+    dma_unit(ph + 6, slot);
+    const int nslot = slot + 1 == WGD_NU ? 0 : slot + 1;
+    if (PAR == 0) {
+      read_frags(nslot, FA1, FB1);
+      mma(FA0, FB0);
+    } else {
+      read_frags(nslot, FA0, FB0);
+      mma(FA1, FB1);
+    }
+    close_phase();
+    slot = nslot;
+  };
+  int ph = 0;
+  for (; ph + 1 < nu; ph += 2) {
+    phase(std::integral_constant<int, 0>{}, ph);
+    phase(std::integral_constant<int, 1>{}, ph + 1);
+  }
+  if (ph < nu) phase(std::integral_constant<int, 0>{}, ph);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // run-ahead copies (zeros nobody reads) before LDS is reused
+  __syncthreads();
+
+  // fp32 tile through LDS: D[m][n]: row = g * 4 + reg (cout), col = li (k' column)
+  float* E = (float*)smem;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int col = wn * 64 + b * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) E[(wm * 64 + a * 16 + g * 4 + r) * WGD_EP + col] = acc[a][b][r];
+    }
+  __syncthreads();
+  float* dst = p.out + (long long)s * p.Cout * p.Kp;
+  for (int idx = tid; idx < 128 * 64; idx += 512) {
+    const int row = idx >> 6, c4 = idx & 63;
+    if (m0 + row < p.Cout && n0 + c4 * 4 < p.Kp)
+      *(float4*)(dst + (long long)(m0 + row) * p.Kp + n0 + c4 * 4) = *(const float4*)(E + row * WGD_EP + c4 * 4);
+  }
+}
+
 // dw[i] = sum_s slab[s][i], bitwise reproducible: block = 16 float4 columns x 16 slab slices,
 // each slice summed in order, the 16 slice sums combined in order through LDS.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, float* dw,
@@ -650,12 +904,54 @@ extern "C" int vs_wgrad_reduce(const float* slabs, float* dw, int64_t n, int spl
 // ------------------------------ host side ------------------------------------
 struct WgCfg {
   int bm, bn, S, rows_per_split, tilesM, tilesN;
+  int deep;  // conv_wgrad_deep_kernel (128 x 256 tile, 512 threads)
 };
+
+#define VS_WGRAD_NODEEP (1 << 12)    /* vs_conv_desc.flags of a weight gradient: keep it off the deep-pipeline kernel (A/B, tests) */
+#define VS_WGRAD_FORCEDEEP (1 << 13) /* ... on it whenever the shape is eligible */
+
+// Deep-pipeline plan: 128 x 256 output tiles, one block per CU (152 KiB of LDS), the positions split so that the grid
+// is one residency round.  Where it pays (profiles/r04_wgrad_deep.txt): >= 128 output channels and >= 192 columns
+// mostly filling their tiles, enough tiles x splits for >= half the chip, >= 16 units of 32 positions per block.
+static bool wg_deep_plan(const vs_conv_desc* d, WgCfg* c) {
+  static const int mode = [] { const char* e = getenv("VS_WGRAD_DEEP"); return e ? atoi(e) : 1; }();
+  const bool force = mode == 2 || (d->flags & VS_WGRAD_FORCEDEEP);
+  if (mode == 0 || (d->flags & VS_WGRAD_NODEEP)) return false;
+  if (((d->flags >> 8) & 0xf) || ((d->flags >> 16) & 7) || ((d->flags >> 24) & 0xff)) return false;  // forced tile / ring / slots
+  const int taps = d->kT * d->kH * d->kW;
+  const int Kp = taps * d->Cin;
+  const long long P = (long long)d->N * d->To * d->Ho * d->Wo;
+  if (taps > 31 || Kp % 8 != 0 || d->Cout % 8 != 0) return false;
+  const int tilesM = (d->Cout + 127) / 128, tilesN = (Kp + 255) / 256;
+  const long long tiles = (long long)tilesM * tilesN;
+  const double row_eff = (double)d->Cout / (128.0 * tilesM), col_eff = (double)Kp / (256.0 * tilesN);
+  long long S = 256 / tiles;
+  const long long maxS = P / 512;  // >= 16 units per block
+  if (S > maxS) S = maxS;
+  const long long slab_cap = (64ll << 20) / ((long long)d->Cout * Kp * 4);
+  if (S > slab_cap) S = slab_cap;
+  if (S < 1) S = 1;
+  long long rps = (P + S - 1) / S;
+  rps = (rps + 31) / 32 * 32;
+  S = (P + rps - 1) / rps;
+  if (!force && (row_eff < 0.9 || col_eff < 0.75 || tiles * S < 128 || tiles > 256 || rps < 512)) return false;
+  if (tiles * S > 65535) return false;
+  c->bm = 128;
+  c->bn = 256;
+  c->tilesM = tilesM;
+  c->tilesN = tilesN;
+  c->S = (int)S;
+  c->rows_per_split = (int)rps;
+  c->deep = 1;
+  return true;
+}
 
 static const int kWgTiles[8][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {32, 128}, {32, 64}, {16, 128}, {16, 64}};
 
 static WgCfg wg_pick(const vs_conv_desc* d) {
   WgCfg c;
+  c.deep = 0;
+  if (wg_deep_plan(d, &c)) return c;
   const int Kp = d->kT * d->kH * d->kW * d->Cin;
   const long long P = (long long)d->N * d->To * d->Ho * d->Wo;
   c.bm = d->Cout >= 128 ? 128 : (d->Cout >= 64 ? 64 : (d->Cout >= 32 ? 32 : 16));
@@ -715,6 +1011,20 @@ static WgCfg wg_pick(const vs_conv_desc* d) {
   if (S > slab_cap) S = slab_cap;
   if (S > 1024) S = 1024;
   if (S < 1) S = 1;
+  // One position split per XCD (or a whole number of them).  The blocks of a split read the SAME dY / x rows, one
+  // block per output tile; with the XCD-contiguous block order (xcd_order) and S a multiple of 8 every XCD works on
+  // whole splits, so a row is fetched once per XCD from beyond its L2 and the other tiles' reads hit.  Unaligned
+  // (e.g. 48 tiles x 7 splits) the blocks of one XCD straddle splits, most staged bytes miss L2, and the kernel is
+  // bound by the ~27 GB/s a CU takes in from beyond L2 (tools/probes/lds_dma_rate.hip): s4.a staged 300 MB at
+  // 256 x 27 GB/s = 43 us, measured 44.6.  THAT WAS THE HYPOTHESIS; measured (profiles/r04_wgrad_xcd_align.txt) the
+  // aligned plan is 4 % slower over the layers (s4.b 37 -> 45 us with 8 instead of 10 splits, s4.a unchanged with the
+  // XCD order alone) and 0.5 % slower in the step: the ring kernel is not bound by L2 misses.  Opt-in: VS_WGRAD_ALIGN8=1.
+  static const int align8 = [] { const char* e = getenv("VS_WGRAD_ALIGN8"); return e ? atoi(e) : 0; }();
+  if (align8 && !forced_slots && tiles <= 64 && S >= 5) {
+    long long S8 = ((S + 3) / 8) * 8;
+    if (S8 < 8) S8 = 8;
+    if (S8 <= maxS && S8 <= slab_cap) S = S8;
+  }
   long long rps = (P + S - 1) / S;
   rps = (rps + 63) / 64 * 64;
   S = (P + rps - 1) / rps;
@@ -854,7 +1164,8 @@ static int wgrad_impl(const void* dy, const void* x, float* dw, const vs_conv_de
     // measured per layer (batch 8): a win up to ~16 output tiles (s3.b 43.5 -> 35.4 us, s4.c 22.1 -> 19.7,
     // s3.c 24.7 -> 21.2, s2.c 29.7 -> 26.4), a loss from 36 tiles on (s4.b 36.7 -> 38.9, s5.b 48.9 -> 52.9), where
     // one split's tiles no longer fit an XCD's share of the grid anyway
-    p.xcd_order = xo && c.tilesM * c.tilesN <= 32;
+    // (round 4: with S a multiple of 8 -- wg_pick, VS_WGRAD_ALIGN8 -- the XCD runs are whole splits for any tile count)
+    p.xcd_order = xo && (c.tilesM * c.tilesN <= 32 || xo == 2 || (c.S % 8 == 0 && c.tilesM * c.tilesN <= 64));
     static const int dbg = [] { const char* e = getenv("VS_WGRAD_DBG"); return e ? atoi(e) : 0; }();
     p.dbg = dbg;
   }
@@ -870,7 +1181,23 @@ static int wgrad_impl(const void* dy, const void* x, float* dw, const vs_conv_de
   int ring = fring == 1 ? 0 : (fring >= 2 ? (fring > 3 ? 3 : fring) : (c.bm == 128 ? 2 : 0));
   if (d->kT * d->kH * d->kW > 31) ring = 0;  // the tap bitmask of the ring's position table
   int rc;
-  if (c.bm == 128 && c.bn == 128) rc = wg_launch<128, 128, 2, 2>(p, mode, ring, st);
+  if (c.deep) {
+    static std::once_flag dattr;
+    std::call_once(dattr, [] {
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_deep_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_deep_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (in_scale) {
+      vs_set_error("vs_conv_wgrad_aol: not built for the deep-pipeline plan");
+      return VS_ERR_UNSUPPORTED;
+    }
+    const size_t smem = (size_t)WGD_NU * WGD_UNIT + 2 * WGD_TAB * sizeof(int2);
+    const int grid = p.tilesM * p.tilesN * p.S;
+    if (mode == 0) hipLaunchKernelGGL((conv_wgrad_deep_kernel<0>), dim3(grid), dim3(512), smem, st, p);
+    else hipLaunchKernelGGL((conv_wgrad_deep_kernel<1>), dim3(grid), dim3(512), smem, st, p);
+    VS_CHECK_LAUNCH();
+    rc = VS_OK;
+  } else if (c.bm == 128 && c.bn == 128) rc = wg_launch<128, 128, 2, 2>(p, mode, ring, st);
   else if (c.bm == 128) rc = wg_launch<128, 64, 2, 2>(p, mode, ring, st);
   else if (c.bm == 64 && c.bn == 128) rc = wg_launch<64, 128, 2, 2>(p, mode, ring, st);
   else if (c.bm == 64) rc = wg_launch<64, 64, 2, 2>(p, mode, ring, st);

@@ -563,7 +563,7 @@ def conv_wgrad_split(dy, x, k, s, p, out, ring=0):
     return lambda: _lib.call("vs_wgrad_reduce", _ptr(ws), _ptr(out), n, S, _stream())
 
 
-def conv_wgrad(dy, x, k, s, p, out=None, ring=0, batch=None, tile=None, slots=0):
+def conv_wgrad(dy, x, k, s, p, out=None, ring=0, batch=None, tile=None, slots=0, deep=True):
     """dw fp32, logical [Cout,Cin,kT,kH,kW], memory [Cout][taps][Cin].
     ring: 0 heuristic, 1 register-staged pipeline, 2 / 3 LDS-DMA ring stages (VS_CONV_RING).
     batch: a WgradBatch -- the split partials stay in the batch's slabs until `batch.flush()`."""
@@ -576,6 +576,10 @@ def conv_wgrad(dy, x, k, s, p, out=None, ring=0, batch=None, tile=None, slots=0)
         return batch.wgrad(dy, x, k, s, p, out, ring)
     # tile: index into WG_TILES, slots: block slots to fill (multiple of 8) -- tuning knobs, 0 / None = the plan
     flags = ((ring & 7) << 16) | (((tile + 1) << 8) if tile is not None else 0) | (((slots // 8) & 0xff) << 24)
+    if not deep:
+        flags |= 1 << 12  # VS_WGRAD_NODEEP: not the deep-pipeline kernel (A/B, tests)
+    elif deep == "force":
+        flags |= 1 << 13  # VS_WGRAD_FORCEDEEP
     d = make_desc(x.shape, act_ld(x), dy.shape, act_ld(dy), k, s, p, flags)
     need = _lib.load().vs_conv_wgrad_workspace_bytes(C.byref(d))
     ws = _workspace(need, x.device, "wgrad") if need else None
