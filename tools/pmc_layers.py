@@ -9,7 +9,7 @@ from vidsitu_amd import ops
 dev = torch.device("cuda:0")
 plan_path = sys.argv[1]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-# name, Cin, T, H, W, Cout, k, s, p   (8 clips)
+# name, Cin, T, H, W, Cout, k, s, p   (8 clips unless the name ends in "@N")
 SHAPES = [
     ("s4.a 1024->256 [3,1,1]", 1024, 8, 14, 14, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
     ("s4.b 256->256 [1,3,3]", 256, 8, 14, 14, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
@@ -20,10 +20,16 @@ SHAPES = [
     ("s3.c 128->512 [1,1,1]", 128, 8, 28, 28, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     ("s2.b 64->64 [1,3,3]", 64, 8, 56, 56, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ("s2.c 64->256 [1,1,1]", 64, 8, 56, 56, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    # round 4: the launches the deep-pipeline kernels take (conv_deep.hip / conv_wgrad_deep_kernel)
+    ("s4.b0.a 640->256 [3,1,1]", 640, 8, 28, 28, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ("s4.a 1024->256 [3,1,1] @32", 1024, 8, 14, 14, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ("s4.b 256->256 [1,3,3] @32", 256, 8, 14, 14, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("s5.a 2048->512 [3,1,1] @32", 2048, 8, 7, 7, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
 ]
 plan = []
 for name, cin, t, h, w, cout, k, s, p in SHAPES:
-    x = ops.new_act(8, cin, t, h, w, dev); x.normal_()
+    nclips = int(name.split("@")[1]) if "@" in name else 8
+    x = ops.new_act(nclips, cin, t, h, w, dev); x.normal_()
     wt = (torch.randn(cout, *k, cin, device=dev) / (cin * k[0] * k[1] * k[2]) ** 0.5).to(ops.BF16).permute(0, 4, 1, 2, 3)
     ys = ops.conv_out_shape(x.shape, cout, k, s, p)
     dy = ops.new_act(*ys, device=dev); dy.normal_()

@@ -12,7 +12,7 @@ import collections, csv, glob, json, sys
 out_dir, build = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "")
 plan = json.load(open(f"{out_dir}/plan.json"))
 KEEP = ("conv_igemm_kernel", "conv_wgrad_ring_kernel", "conv_wgrad_kernel", "conv_direct_kernel", "conv_halo_kernel",
-        "conv_pw_kernel")
+        "conv_pw_kernel", "conv_deep_kernel", "conv_wgrad_deep_kernel")
 
 
 def rows_of(sub):

@@ -47,7 +47,9 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
 // (wave tile 64 x 64).  The waves of half hf = wv >> 2 (a SIMD hosts one wave of each half) issue the copies of
 // sub-buffers At / Br (half 0) and Bl / Ab (half 1), in a burst when the phase opens: every phase has one loading and
 // one purely multiplying wave per SIMD ("halves burst", the fastest of the four issue orders tried -- v2 of this probe).
-template <int AF>
+// STAG (AF = 4 only): every wave copies 2 of a sub-buffer's 16 pieces; waves 0-3 issue theirs when the phase opens, waves 4-7
+// after their MFMAs (the two waves of a SIMD run half a phase apart).
+template <int AF, bool STAG = false>
 __global__ __launch_bounds__(512) void gemm_deep(P p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = 64 * AF;
@@ -86,8 +88,23 @@ __global__ __launch_bounds__(512) void gemm_deep(P p) {
       srcB[i] = brow < p.N ? (unsigned)((long long)brow * p.K * 2) + unit : OOB;
     }
   }
+  unsigned sA[2][2], sB[2][2];  // STAG: [half of the tile][i], rows sr = (i * 8 + wv) * 8 + (lane >> 3)
+  if (STAG) {
+    const int kc = lane & 7, r8 = lane >> 3;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int sr = (i * 8 + wv) * 8 + r8;
+        const unsigned unit = (unsigned)((kc ^ ((sr >> 1) & 7)) << 4);
+        const int arow = m0 + (sr >> 6) * 128 + h * 64 + (sr & 63);
+        sA[h][i] = arow < p.M ? (unsigned)((long long)arow * p.K * 2) + unit : OOB;
+        const int brow = n0 + (sr >> 5) * 64 + h * 32 + (sr & 31);
+        sB[h][i] = brow < p.N ? (unsigned)((long long)brow * p.K * 2) + unit : OOB;
+      }
+  }
   typedef __attribute__((address_space(3))) char* lds_ptr_t;
-  const unsigned lds0 = (unsigned)(unsigned long)(lds_ptr_t)smem + (unsigned)wq * 1024u;
+  const unsigned lds0 = (unsigned)(unsigned long)(lds_ptr_t)smem + (unsigned)(STAG ? wv : wq) * 1024u;
   auto rsrc_words = [](const void* base, unsigned bytes) __attribute__((always_inline)) {
     const unsigned long a = (unsigned long)base;
     return (i32x4){(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
@@ -102,6 +119,19 @@ __global__ __launch_bounds__(512) void gemm_deep(P p) {
   // sub-buffer of read index r: kind = r & 3 (0 At, 1 Bl, 2 Br, 3 Ab), tile = r >> 2, stage = tile & 1; kinds 0 / 2 are
   // half 0's, kinds 1 / 3 half 1's
   auto issue = [&](int kind, int tile) __attribute__((always_inline)) {
+    if (STAG) {
+      const unsigned st = (unsigned)(tile & 1) * STAGE;
+      const unsigned kadd = tile < nk ? (unsigned)tile * 128u : OOB;
+      const bool isA = kind == 0 || kind == 3;
+      const int h = (kind == 0 || kind == 1) ? 0 : 1;
+      const unsigned sub = kind == 0 ? SUB_AT : kind == 1 ? SUB_BL : kind == 2 ? SUB_BR : SUB_AB;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const unsigned s0 = isA ? sA[h][i] : sB[h][i];
+        dma16(isA ? adesc : bdesc, lds0 + st + sub + (unsigned)i * 8192u, (s0 | kadd) >= OOB ? OOB : s0 + kadd);
+      }
+      return;
+    }
     if ((kind & 1) != hf) return;
     const unsigned st = (unsigned)(tile & 1) * STAGE;
     const unsigned kadd = tile < nk ? (unsigned)tile * 128u : OOB;  // past the last tile: zeros nobody reads
@@ -123,7 +153,8 @@ __global__ __launch_bounds__(512) void gemm_deep(P p) {
     constexpr int kr = decltype(kr_)::value;
     constexpr int nA = (kr == 2) ? 2 : (kr == 3) ? 1 : (kr == 0) ? 1 : 2;  // A sub-buffers among the 3 younger ones of this half
     constexpr int N = nA * AF + (3 - nA) * 4;
-    if (hf == (kr & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+    if (STAG) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // six younger sub-buffers x 2 pieces per wave
+    else if (hf == (kr & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
   };
 
   // ---- compute side
@@ -203,27 +234,31 @@ __global__ __launch_bounds__(512) void gemm_deep(P p) {
     bf16x8(&BR)[2][2] = PAR ? B0 : B1;
     // P1: issue Bl(t+2), read Br(t), At x Bl
     phase_open(K2{});
-    issue(1, t + 2);
+    if (!STAG || hf == 0) issue(1, t + 2);
     readB(BR, ST + SUB_BR);
     mma(A0, BL, 0, 0);
+    if (STAG && hf == 1) { __builtin_amdgcn_sched_barrier(0); issue(1, t + 2); }
     phase_close();
     // P2: issue Br(t+2), read Ab(t), At x Br
     phase_open(K3{});
-    issue(2, t + 2);
+    if (!STAG || hf == 0) issue(2, t + 2);
     readA(A1, ST + SUB_AB);
     mma(A0, BR, 0, 2);
+    if (STAG && hf == 1) { __builtin_amdgcn_sched_barrier(0); issue(2, t + 2); }
     phase_close();
     // P3: issue Ab(t+2), read At(t+1), Ab x Br
     phase_open(K0{});
-    issue(3, t + 2);
+    if (!STAG || hf == 0) issue(3, t + 2);
     readA(A0, STN + SUB_AT);
     mma(A1, BR, AF, 2);
+    if (STAG && hf == 1) { __builtin_amdgcn_sched_barrier(0); issue(3, t + 2); }
     phase_close();
     // P4: issue At(t+3), read Bl(t+1) into the set Br(t) leaves, Ab x Bl
     phase_open(K1{});
-    issue(0, t + 3);
+    if (!STAG || hf == 0) issue(0, t + 3);
     readB(BR, STN + SUB_BL);
     mma(A1, BL, AF, 0);
+    if (STAG && hf == 1) { __builtin_amdgcn_sched_barrier(0); issue(0, t + 3); }
     phase_close();
   };
   int t = 0;
@@ -270,20 +305,20 @@ static float h_bf2f(uint16_t h) {
   return f;
 }
 
-template <int AF>
+template <int AF, bool STAG = false>
 static float run(const P& p, int grid, int reps) {
-  hipFuncSetAttribute((const void*)gemm_deep<AF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute((const void*)gemm_deep<AF, STAG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   const size_t ring = 2 * (2 * AF * 4096 + 32768), epi = (size_t)64 * AF * (256 + 8) * 2;
   const size_t smem = ring > epi ? ring : epi;
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm_deep<AF>, dim3(grid), dim3(512), smem, 0, p);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_deep<AF, STAG>), dim3(grid), dim3(512), smem, 0, p);
   hipDeviceSynchronize();
   float best = 1e30f;
   for (int r = 0; r < 3; ++r) {
     hipEventRecord(e0);
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(gemm_deep<AF>, dim3(grid), dim3(512), smem, 0, p);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((gemm_deep<AF, STAG>), dim3(grid), dim3(512), smem, 0, p);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -330,14 +365,14 @@ int main(int argc, char** argv) {
     const int reps = fl > 5e11 ? 5 : 20;
     const int g4 = ((s.M + 255) / 256) * p.tilesN, g2 = ((s.M + 127) / 128) * p.tilesN;
     p.prio = 0;
-    const float t4 = run<4>(p, g4, reps), t2 = run<2>(p, g2, reps);
+    const float t4 = run<4>(p, g4, reps), t2 = run<2>(p, g2, reps), ts = run<4, true>(p, g4, reps);
     p.prio = 99;
-    const float l4 = run<4>(p, g4, reps), l2 = run<2>(p, g2, reps);
-    printf("%-40s M%6d N%5d K%5d | 256x256: %4d blocks %7.1f us %5.0f TF/s (loop only %7.1f) | 128x256: %4d blocks %7.1f us %5.0f TF/s (loop only %7.1f)\n",
-           s.what, s.M, s.N, s.K, g4, t4 * 1e3, fl / t4 / 1e9, l4 * 1e3, g2, t2 * 1e3, fl / t2 / 1e9, l2 * 1e3);
+    const float l4 = run<4>(p, g4, reps), l2 = run<2>(p, g2, reps), ls = run<4, true>(p, g4, reps);
+    printf("%-40s M%6d N%5d K%5d | 256x256: %4d blocks %7.1f us %5.0f TF/s (loop only %7.1f) | staggered all-wave issue %7.1f us %5.0f TF/s (loop only %7.1f) | 128x256: %4d blocks %7.1f us %5.0f TF/s (loop only %7.1f)\n",
+           s.what, s.M, s.N, s.K, g4, t4 * 1e3, fl / t4 / 1e9, l4 * 1e3, ts * 1e3, fl / ts / 1e9, ls * 1e3, g2, t2 * 1e3, fl / t2 / 1e9, l2 * 1e3);
     // check sampled outputs against a host dot product (the full-epilogue variant ran last? no: rerun it)
     p.prio = 0;
-    run<2>(p, g2, 1);
+    run<4, true>(p, g4, 1);
     hipMemcpy(hc.data(), dC, nc * 2, hipMemcpyDeviceToHost);
     double maxerr = 0.0;
     int bad = 0;

@@ -100,3 +100,14 @@ print("time by number of kernels running (last step): " + ", ".join(f"{k}{'+' if
 print("kernels that run ALONE on the chip (no other kernel resident), by time:")
 for k, t in sorted(alone.items(), key=lambda kv: -kv[1])[:16]:
     print(f"  {t / 1e3:8.1f} us  {k}")
+
+# torch-native kernels inside the replayed step (fills, copies, elementwise glue): are the PMC pass's FillFunctor /
+# transposes part of the steady-state step?
+nat = collections.defaultdict(lambda: [0, 0])
+for a, b, n in s:
+    if "at::native" in n or "transpose" in n or "cast_f32" in n:
+        k = n.replace("void ", "")[:110]
+        nat[k][0] += b - a; nat[k][1] += 1
+print("torch-native / layout kernels in the last burst (time, launches):")
+for k, (t, c) in sorted(nat.items(), key=lambda kv: -kv[1][0])[:12]:
+    print(f"  {t / 1e3:8.1f} us {c:4d} x  {k}")

@@ -402,7 +402,14 @@ bool vs_halo_plan(const ConvP& p, int mode, int dgrad, int flags, HaloGeo* out) 
         const double fill = blocks / (256.0 * rounds);                    // one block per CU, whole rounds
         // fill bytes per tile-FLOP: image once per chunk + a weight tile per tap
         const double inten = (double)(G * g.O1 * g.O2) * bn * taps / ((double)g.RA + (double)taps * bn);  // FLOP / byte
-        const double conflicts = (!temporal && !pad && (W % 16) != 0) ? 0.85 : 1.0;
+        // lines that are not a multiple of 16 rows: the fragment reads conflict (measured SQ_LDS_BANK_CONFLICT /
+        // SQ_LDS_IDX_ACTIVE 0.32 on s4.b, 0.49 on s5.b; simulated over row pitches 1024 + 0..128 B per 8 rows and
+        // 6 swizzle families, no layout of 128-byte rows gets below 1.8x the conflict-free cycles: the hardware
+        // serves a ds_read_b128 in lane groups that MIX two k-units, and an odd tap shift or a line wrap puts two of
+        // a group's rows on one slot -- tools/probes/halo_lds_sim.py).  VS_HALO_CONFLICT_WEIGHT: A/B of the planner's
+        // price for it (lower = prefer the padded lines).
+        static const double cw = [] { const char* e = getenv("VS_HALO_CONFLICT_WEIGHT"); return e ? atof(e) : 0.85; }();
+        const double conflicts = (!temporal && !pad && (W % 16) != 0) ? cw : 1.0;
         const double score = eff * fill * conflicts * (inten > 96.0 ? 1.0 : 0.6 + 0.4 * inten / 96.0) * (1.0 + 1e-4 * inten);
         if (score > best_score) { best_score = score; best = g; }
       }

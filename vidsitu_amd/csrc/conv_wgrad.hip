@@ -526,7 +526,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradP p) {
 #define WGD_TAB 512
 #define WGD_EP 260
 
-template <int MODE>
+// STAG: every wave copies 3 of a unit's 24 pieces (rows wv * 4 .. + 3 of the three images) instead of the waves of one half
+// copying 6 each: waves 0-3 issue theirs when the phase opens (copies, then MFMAs), waves 4-7 after their MFMAs (MFMAs,
+// then copies) -- the two waves of a SIMD run half a phase apart and the CU's address path sees one half at a time.
+template <int MODE, bool STAG>
 __global__ __launch_bounds__(512) void conv_wgrad_deep_kernel(WgradP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -549,7 +552,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_deep_kernel(WgradP p) {
 
   // ---- copy side: instruction j (0, 1) of wave wq covers rows (j * 4 + wq) * 4 + rg of an image, lane -> 16-byte chunk cc
   const int rg = lane >> 4, cc = lane & 15;
-  const int lc = cc ^ ((rg << 1) | ((wq >> 1) << 3));  // logical chunk fetched into physical chunk cc (row swizzle)
+  // logical chunk fetched into physical chunk cc (row swizzle: (row & 3) << 1 | ((row >> 3) & 1) << 3)
+  const int lc = cc ^ ((rg << 1) | (((STAG ? wv : wq) >> 1 & 1) << 3));
   const bool mcol_ok = (m0 + lc * 8) < p.Cout;
   const unsigned dycol = (unsigned)((m0 + lc * 8) * 2);
   bool ncol_ok[2];
@@ -571,7 +575,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_deep_kernel(WgradP p) {
   }
   const unsigned dy_pitch = (unsigned)(p.dy_ld * 2), x_pitch = (unsigned)(p.x_ld * 2);
   typedef __attribute__((address_space(3))) char* lds_ptr_t;
-  const unsigned lds0 = (unsigned)(unsigned long)(lds_ptr_t)smem + (unsigned)wq * 1024u;
+  const unsigned lds0 = (unsigned)(unsigned long)(lds_ptr_t)smem + (unsigned)(STAG ? wv : wq) * 1024u;
   auto rsrc_words = [](const void* base, unsigned bytes) __attribute__((always_inline)) {
     const unsigned long a = (unsigned long)base;
     return (i32x4){(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
@@ -621,11 +625,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_deep_kernel(WgradP p) {
   };
   // the 6 copies of this wave's share of unit u (only the half u & 1 issues): dY, x image 0, x image 1
   auto dma_unit = [&](int u, int slot) __attribute__((always_inline)) {
-    if ((u & 1) != hf) return;
+    if (!STAG && (u & 1) != hf) return;
     const unsigned U = lds0 + (unsigned)(slot * WGD_UNIT);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int rel = u * 32 + j * 16 + wq * 4 + rg;  // position relative to pbeg
+    for (int j = 0; j < (STAG ? 1 : 2); ++j) {
+      const int rel = u * 32 + (STAG ? wv * 4 : j * 16 + wq * 4) + rg;  // position relative to pbeg
       const int pp = pbeg + rel;
       const bool pok = pp < pend;
       dma16(dydesc, U + j * 4096, (mcol_ok && pok) ? (unsigned)pp * dy_pitch + dycol : WG_OOB);
@@ -691,7 +695,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_deep_kernel(WgradP p) {
   };
   // before the fragment reads of unit u (issued 5 phases ago by half u & 1): that half's two younger units stay in flight
   auto open_phase = [&](int u) __attribute__((always_inline)) {
-    if (hf == (u & 1)) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    if (STAG || hf == (u & 1)) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // (STAG: 4 younger units x 3 pieces)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -717,7 +721,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_deep_kernel(WgradP p) {
     constexpr int PAR = decltype(par)::value;
     open_phase(ph + 1);
     if (MODE == 1 && (ph & 15) == 0 && pbeg + ((ph >> 4) + 1) * WGD_TAB < pend) build_tab((ph >> 4) + 1);
-    dma_unit(ph + 6, slot);
+    if (!STAG || hf == 0) dma_unit(ph + 6, slot);
     const int nslot = slot + 1 == WGD_NU ? 0 : slot + 1;
     if (PAR == 0) {
       read_frags(nslot, FA1, FB1);
@@ -725,6 +729,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_deep_kernel(WgradP p) {
     } else {
       read_frags(nslot, FA0, FB0);
       mma(FA1, FB1);
+    }
+    if (STAG && hf == 1) {
+      __builtin_amdgcn_sched_barrier(0);
+      dma_unit(ph + 6, slot);
     }
     close_phase();
     slot = nslot;
@@ -931,10 +939,20 @@ static bool wg_deep_plan(const vs_conv_desc* d, WgCfg* c) {
   const long long slab_cap = (64ll << 20) / ((long long)d->Cout * Kp * 4);
   if (S > slab_cap) S = slab_cap;
   if (S < 1) S = 1;
+  // VS_WGRAD_DEEP_ALIGN=1 (experiment): whole splits per XCD -- S rounded down to a multiple of 8 where a split's tiles
+  // fit one XCD's 32 CUs; with the XCD-contiguous block order every dY / x row is then fetched once per XCD
+  static const int align = [] { const char* e = getenv("VS_WGRAD_DEEP_ALIGN"); return e ? atoi(e) : 0; }();
+  if (align && tiles <= 32 && S >= 8) S = (S / 8) * 8;
   long long rps = (P + S - 1) / S;
   rps = (rps + 31) / 32 * 32;
   S = (P + rps - 1) / rps;
   if (!force && (row_eff < 0.9 || col_eff < 0.75 || tiles * S < 128 || tiles > 256 || rps < 512)) return false;
+  // Fewer than ~40 000 positions (every slow-pathway s4 / s5 layer at 8 clips per GPU): alone the kernel is 1.03-1.38x
+  // the ring kernel's speed there, but the STEP is 0.4 % slower with it (12.18-12.29 vs 12.13-12.23 ms, alternating,
+  // with and without pair launches: profiles/r04_wgrad_deep.txt) -- one 152-KiB block per CU shares no CU with the data
+  // gradient that runs beside it, where the ring kernel's 64-80 KiB blocks do.  From 32 clips on the step gains 2.5 %.
+  static const long long min_p = [] { const char* e = getenv("VS_WGRAD_DEEP_MINP"); return e ? atoll(e) : 40000ll; }();
+  if (!force && P < min_p) return false;
   if (tiles * S > 65535) return false;
   c->bm = 128;
   c->bn = 256;
@@ -1184,17 +1202,22 @@ static int wgrad_impl(const void* dy, const void* x, float* dw, const vs_conv_de
   if (c.deep) {
     static std::once_flag dattr;
     std::call_once(dattr, [] {
-      (void)hipFuncSetAttribute((const void*)conv_wgrad_deep_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)conv_wgrad_deep_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_deep_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_deep_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_deep_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_deep_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
+    static const int stag = [] { const char* e = getenv("VS_WGRAD_DEEP_STAG"); return e ? atoi(e) : 1; }();  // +2.7 % at 32 clips, neutral at 8
     if (in_scale) {
       vs_set_error("vs_conv_wgrad_aol: not built for the deep-pipeline plan");
       return VS_ERR_UNSUPPORTED;
     }
     const size_t smem = (size_t)WGD_NU * WGD_UNIT + 2 * WGD_TAB * sizeof(int2);
     const int grid = p.tilesM * p.tilesN * p.S;
-    if (mode == 0) hipLaunchKernelGGL((conv_wgrad_deep_kernel<0>), dim3(grid), dim3(512), smem, st, p);
-    else hipLaunchKernelGGL((conv_wgrad_deep_kernel<1>), dim3(grid), dim3(512), smem, st, p);
+    if (stag && mode == 0) hipLaunchKernelGGL((conv_wgrad_deep_kernel<0, true>), dim3(grid), dim3(512), smem, st, p);
+    else if (stag) hipLaunchKernelGGL((conv_wgrad_deep_kernel<1, true>), dim3(grid), dim3(512), smem, st, p);
+    else if (mode == 0) hipLaunchKernelGGL((conv_wgrad_deep_kernel<0, false>), dim3(grid), dim3(512), smem, st, p);
+    else hipLaunchKernelGGL((conv_wgrad_deep_kernel<1, false>), dim3(grid), dim3(512), smem, st, p);
     VS_CHECK_LAUNCH();
     rc = VS_OK;
   } else if (c.bm == 128 && c.bn == 128) rc = wg_launch<128, 128, 2, 2>(p, mode, ring, st);
