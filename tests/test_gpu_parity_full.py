@@ -316,8 +316,9 @@ def test_every_resblock_fwd_bwd_matches_oracle_on_the_oracles_own_tensors(arch, 
     # 1.5e-1 these two tensors get here only says "nothing gross", everything else gets 4e-2.
     # Round 4: the reduction order of the wide multi-tap convolutions became chunk-major (ConvP::korder) -- another
     # draw of the same process: at the 64-pixel crop one BN-bias gradient of slow s4 (256 positions per channel, half of
-    # them behind the mask) moved from 1.9e-2 to 4.9e-2 while the table's median and the 1e-2 / 2e-2 fractions below
-    # stayed put (VS_CONV_KORDER_MIN=0 reproduces the old table).  BN parameter gradients of the small-crop runs get
+    # them behind the mask) moved from < 1.4e-2 to 4.9e-2 (its block's dx 2.3e-2) while the table's median and the
+    # 1e-2 / 2e-2 fractions below stayed put (VS_CONV_KORDER_MIN=0 reproduces the old table: worst tensor 2.2e-2; both
+    # tables in profiles/r04_parity_blocks_korder.txt; the kernels themselves are tested against torch in both orders).  BN parameter gradients of the small-crop runs get
     # 7e-2 (still far below the O(1) a wrong formula gives); everything else keeps 4e-2.
     def limit(block, tensor):
         if hw >= 224 and block.endswith("_res0") and tensor in ("branch1.weight", "branch2.a.weight"):
