@@ -273,17 +273,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
 // double buffered and rebuilt one chunk ahead, so the pipeline never drains inside a block
 // (the register-staged kernel restarts it every 1024 positions).
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int MODE, int NS, bool AOL = false>
+// ROWS (round 4): positions per ring stage.  64 = the round-1..3 ring; 32 = half stages -- the SAME 64 KiB hold four of
+// them instead of two, i.e. three 32-position steps in flight behind `vmcnt(8)` instead of one 64-position step behind
+// `vmcnt(0)`, at 2 blocks per CU as before (whole 256-byte rows either way: halving the K depth of THIS kernel's stage
+// halves the row count, not the row length).  One barrier per 16 MFMAs per wave instead of per 32.
+template <int BM, int BN, int WM, int WN, int MODE, int NS, bool AOL = false, int ROWS = 64>
 __device__ __forceinline__ void conv_wgrad_ring_body(const WgradP& p, const int blk, const int nblk) {
   static_assert(!AOL || MODE == 0, "apply on load: pointwise launches");
+  static_assert(ROWS == 64 || ROWS == 32, "stage depth");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MR = TM / 16, NR = TN / 16;
   constexpr int CM = BM / 8, CN = BN / 8;  // 16-byte chunks that carry data (of 16 per row)
-  constexpr int IMG = 64 * 256;
+  constexpr int IMG = ROWS * 256;
   constexpr int STAGE = 2 * IMG;
   constexpr int D = NS - 1;
-  constexpr int L = 8;  // DMA instructions per thread per step: 4 row groups x 2 images
+  constexpr int RG = ROWS / 16;  // row groups (of 16 positions: 4 rows per wave instruction x 4 waves) per image
+  constexpr int L = 2 * RG;      // DMA instructions per thread per step: RG row groups x 2 images
+  constexpr int SPC = WG_ROWTAB / ROWS;  // steps per table chunk
   static_assert(WM * WN == 4, "4 waves");
   static_assert((D - 1) * L <= 63, "vmcnt range");
 
@@ -304,7 +311,7 @@ __device__ __forceinline__ void conv_wgrad_ring_body(const WgradP& p, const int 
   const int m0 = tm * BM, n0 = tn * BN;
   const int pbeg = s * p.rows_per_split;
   const int pend = min(p.P, pbeg + p.rows_per_split);
-  const int nsteps = (pend - pbeg + 63) >> 6;
+  const int nsteps = (pend - pbeg + ROWS - 1) / ROWS;
   int2* rowtab = (int2*)(smem + NS * STAGE);  // [2][WG_ROWTAB] (byte offset, tap mask)
 
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -387,16 +394,16 @@ __device__ __forceinline__ void conv_wgrad_ring_body(const WgradP& p, const int 
   auto dma = [&](int st, int stage) __attribute__((always_inline)) {
     const unsigned A = lds0 + (unsigned)(stage * STAGE);
     const unsigned B = A + IMG;
-    const int rel0 = st * 64 + 4 * wv + rg;  // position of row group 0, relative to pbeg
+    const int rel0 = st * ROWS + 4 * wv + rg;  // position of row group 0, relative to pbeg
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RG; ++i) {
       const int rel = rel0 + 16 * i;
       const int pp = pbeg + rel;
       const unsigned ok = (unsigned)mcol_ok & (unsigned)(pp < pend);
       dma16(dydesc, A + i * 4096, ok ? (unsigned)pp * dy_pitch + dycol : WG_OOB);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RG; ++i) {
       const int rel = rel0 + 16 * i;
       const int pp = pbeg + rel;
       unsigned ok = (unsigned)ncol_ok & (unsigned)(pp < pend);
@@ -432,7 +439,7 @@ __device__ __forceinline__ void conv_wgrad_ring_body(const WgradP& p, const int 
     const char* A = smem + stage * STAGE;
     const char* B = A + IMG;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < ROWS / 32; ++ks) {
       const int row = ks * 32 + 8 * g + q;  // this lane supplies row `row` (and row+4)
       const int swz = ((row & 3) << 2) | (((row >> 3) & 1) << 4);
       bf16x8 af[MR], bfr[NR];
@@ -473,8 +480,8 @@ __device__ __forceinline__ void conv_wgrad_ring_body(const WgradP& p, const int 
     if (!(p.dbg & 4)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"((D - 1) * L) : "memory");
     if (!(p.dbg & 8)) __builtin_amdgcn_s_barrier();  // tile st landed everywhere; stage st_l and the old table are free
     __builtin_amdgcn_sched_barrier(0);
-    if (MODE == 1 && (st & 15) == 0 && pbeg + ((st >> 4) + 1) * WG_ROWTAB < pend && !(p.dbg & 32))
-      build_tab((st >> 4) + 1);  // next chunk's table, first read >= 13 steps from now
+    if (MODE == 1 && (st % SPC) == 0 && pbeg + (st / SPC + 1) * WG_ROWTAB < pend && !(p.dbg & 32))
+      build_tab(st / SPC + 1);  // next chunk's table, first read >= 13 steps from now
     if (!(p.dbg & 2)) dma(st + D, st_l);
     __builtin_amdgcn_sched_barrier(0);
     if (!(p.dbg & 1)) compute(st_c);
@@ -499,9 +506,9 @@ __device__ __forceinline__ void conv_wgrad_ring_body(const WgradP& p, const int 
     }
 }
 
-template <int BM, int BN, int WM, int WN, int MODE, int NS, bool AOL = false>
+template <int BM, int BN, int WM, int WN, int MODE, int NS, bool AOL = false, int ROWS = 64>
 __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradP p) {
-  conv_wgrad_ring_body<BM, BN, WM, WN, MODE, NS, AOL>(p, blockIdx.x, gridDim.x);
+  conv_wgrad_ring_body<BM, BN, WM, WN, MODE, NS, AOL, ROWS>(p, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1085,6 +1092,23 @@ static int wg_launch(const WgradP& p, int mode, int ring, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
+  if (ring == 5) {  // half-stage ring: four stages of 32 positions in the two-stage ring's 64 KiB (VS_WGRAD_HALF)
+    static bool hattr = false;
+    if (!hattr) {
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<BM, BN, WM, WN, 0, 4, false, 32>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<BM, BN, WM, WN, 1, 4, false, 32>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hattr = true;
+    }
+    const size_t smem = (size_t)4 * 2 * 32 * 256 + (mode ? 2 * WG_ROWTAB * sizeof(int2) : 0);
+    if (mode == 0)
+      hipLaunchKernelGGL((conv_wgrad_ring_kernel<BM, BN, WM, WN, 0, 4, false, 32>), dim3(grid), dim3(256), smem, st, p);
+    else
+      hipLaunchKernelGGL((conv_wgrad_ring_kernel<BM, BN, WM, WN, 1, 4, false, 32>), dim3(grid), dim3(256), smem, st, p);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+  }
   if (ring >= 2) {
     const size_t tab = mode ? 2 * WG_ROWTAB * sizeof(int2) : 0;
     const size_t smem = (size_t)ring * 2 * 64 * 256 + tab;
@@ -1198,6 +1222,10 @@ static int wgrad_impl(const void* dy, const void* x, float* dw, const vs_conv_de
   // loses a little on the skinny ones
   int ring = fring == 1 ? 0 : (fring >= 2 ? (fring > 3 ? 3 : fring) : (c.bm == 128 ? 2 : 0));
   if (d->kT * d->kH * d->kW > 31) ring = 0;  // the tap bitmask of the ring's position table
+  {
+    static const int half = [] { const char* e = getenv("VS_WGRAD_HALF"); return e ? atoi(e) : 0; }();
+    if (half && ring == 2 && !in_scale) ring = 5;
+  }
   int rc;
   if (c.deep) {
     static std::once_flag dattr;
