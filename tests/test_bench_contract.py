@@ -1,5 +1,5 @@
 """The bench line's schema (the driver parses it): checked on the committed lines of the current round's build
-(`profiles/r03_bench_train_v3.json`, `profiles/r03_bench_feat_fwd_v3.json`, produced by `python bench.py` on an MI355X)
+(`profiles/r04_bench_train_v1.json`, `profiles/r04_bench_feat_fwd_v1.json`, produced by `python bench.py` on an MI355X)
 and on bench.py's argument surface -- no GPU needed."""
 import json
 import os
@@ -14,7 +14,7 @@ def _line(name):
 
 
 def test_train_line_has_the_contract_fields():
-    d = _line("r03_bench_train_v3.json")
+    d = _line("r04_bench_train_v1.json")
     for k in ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better",
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -39,10 +39,30 @@ def test_train_line_has_the_contract_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1
+    # round 4: BASELINE configs[1] measured by the same (driver-run) process, and the arithmetic's parity on the train line
+    f = d["feat_fwd"]
+    for k in ("workload", "clips_per_s", "ms_per_step", "replays", "frac_of_bf16_mfma_peak", "parity"):
+        assert k in f, k
+    assert "configs[1]" in f["workload"] and f["clips_per_s"] > 0
+    assert abs(f["clips_per_s"] - 8 / (f["ms_per_step"] * 1e-3)) < 0.02 * f["clips_per_s"]
+    par = d["config"]["parity"]
+    assert par["north_star"] == 1e-3 and 0 < par["logits_rel_err_vs_fp32_oracle"] < 1e-2
+    assert "measured_at_commit" in par and "not re-measured in this run" in par["source"]
+
+
+def test_parity_numbers_come_from_the_file_the_parity_test_writes():
+    """bench.py quotes no remembered numbers: `config.parity` is read from profiles/parity_eval.json (written by
+    tests/test_gpu_parity_full.py, committed with the commit it was measured at) and is None without it."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "parity_eval.json" in src and "3345" not in src and "3.02e-3" not in src
+    with open(os.path.join(ROOT, "profiles", "parity_eval.json")) as fh:
+        rec = json.load(fh)
+    assert set(rec["logits_rel_err_vs_fp32_oracle"]) == {"bf16", "fp32_residual_stream", "split_bf16_weights"}
+    assert rec["logits_rel_err_vs_fp32_oracle"]["split_bf16_weights"] < rec["north_star"] < rec["logits_rel_err_vs_fp32_oracle"]["bf16"]
 
 
 def test_forward_line_and_cli_surface():
-    d = _line("r03_bench_feat_fwd_v3.json")
+    d = _line("r04_bench_feat_fwd_v1.json")
     assert d["unit"] == "clips/s" and d["value"] > 0 and "feature extractor" in d["metric"]
     assert "parity" in d["config"]  # the measured logit distance to the fp32 oracle, per eval mode
     src = open(os.path.join(ROOT, "bench.py")).read()

@@ -35,6 +35,7 @@ struct P {
   unsigned a_bytes, b_bytes;
   int tilesN;
   int prio;
+  unsigned long long* dbg;
 };
 
 __device__ __forceinline__ uint16_t f2bf(float f) {
@@ -49,7 +50,10 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
 // one purely multiplying wave per SIMD ("halves burst", the fastest of the four issue orders tried -- v2 of this probe).
 // STAG (AF = 4 only): every wave copies 2 of a sub-buffer's 16 pieces; waves 0-3 issue theirs when the phase opens, waves 4-7
 // after their MFMAs (the two waves of a SIMD run half a phase apart).
-template <int AF, bool STAG = false>
+// STAMP (diagnostic build; +3 s_memtime per phase): per wave, summed over the main loop, the cycles of a phase's three
+// segments -- [vmcnt wait + barrier] [copy issue] [fragment reads + 16 MFMAs + lgkmcnt(0)] -- separately for the phases in
+// which the wave is the loading one and those in which it only multiplies; written to p.dbg[block][wave][8].
+template <int AF, bool STAG = false, bool STAMP = false>
 __global__ __launch_bounds__(512) void gemm_deep(P p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = 64 * AF;
@@ -198,15 +202,37 @@ __global__ __launch_bounds__(512) void gemm_deep(P p) {
               __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af[a][ks], Bf[b][ks], acc[a0 + a][b0 + b], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   };
+  unsigned long long tsum[2][3] = {{0, 0, 0}, {0, 0, 0}}, tcnt[2] = {0, 0}, tprev = 0, tbar = 0;
+  int trole = 0;
   auto phase_open = [&](auto kr_) __attribute__((always_inline)) {
+    if (STAMP) tprev = __builtin_readcyclecounter();
     wait_for(kr_);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    if (STAMP) {
+      tbar = __builtin_readcyclecounter();
+      // the sub-buffer issued in this phase is of kind kr + 3 (mod 4): its half is the loading one
+      trole = ((decltype(kr_)::value + 3) & 1) == hf ? 1 : 0;
+      tsum[trole][0] += tbar - tprev;
+    }
+  };
+  auto issued = [&]() __attribute__((always_inline)) {  // call right after the phase's issue()
+    if (STAMP) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t = __builtin_readcyclecounter();
+      tsum[trole][1] += t - tbar;
+      tbar = t;
+      __builtin_amdgcn_sched_barrier(0);
+    }
   };
   auto phase_close = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    if (STAMP) {
+      tsum[trole][2] += __builtin_readcyclecounter() - tbar;
+      tcnt[trole] += 1;
+    }
   };
   using K0 = std::integral_constant<int, 0>;
   using K1 = std::integral_constant<int, 1>;
@@ -235,6 +261,7 @@ __global__ __launch_bounds__(512) void gemm_deep(P p) {
     // P1: issue Bl(t+2), read Br(t), At x Bl
     phase_open(K2{});
     if (!STAG || hf == 0) issue(1, t + 2);
+    issued();
     readB(BR, ST + SUB_BR);
     mma(A0, BL, 0, 0);
     if (STAG && hf == 1) { __builtin_amdgcn_sched_barrier(0); issue(1, t + 2); }
@@ -242,6 +269,7 @@ __global__ __launch_bounds__(512) void gemm_deep(P p) {
     // P2: issue Br(t+2), read Ab(t), At x Br
     phase_open(K3{});
     if (!STAG || hf == 0) issue(2, t + 2);
+    issued();
     readA(A1, ST + SUB_AB);
     mma(A0, BR, 0, 2);
     if (STAG && hf == 1) { __builtin_amdgcn_sched_barrier(0); issue(2, t + 2); }
@@ -249,6 +277,7 @@ __global__ __launch_bounds__(512) void gemm_deep(P p) {
     // P3: issue Ab(t+2), read At(t+1), Ab x Br
     phase_open(K0{});
     if (!STAG || hf == 0) issue(3, t + 2);
+    issued();
     readA(A0, STN + SUB_AT);
     mma(A1, BR, AF, 2);
     if (STAG && hf == 1) { __builtin_amdgcn_sched_barrier(0); issue(3, t + 2); }
@@ -256,6 +285,7 @@ __global__ __launch_bounds__(512) void gemm_deep(P p) {
     // P4: issue At(t+3), read Bl(t+1) into the set Br(t) leaves, Ab x Bl
     phase_open(K1{});
     if (!STAG || hf == 0) issue(0, t + 3);
+    issued();
     readB(BR, STN + SUB_BL);
     mma(A1, BL, AF, 0);
     if (STAG && hf == 1) { __builtin_amdgcn_sched_barrier(0); issue(0, t + 3); }
@@ -269,6 +299,11 @@ __global__ __launch_bounds__(512) void gemm_deep(P p) {
   if (t < nk) tile_body(std::integral_constant<int, 0>{}, t);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (STAMP && lane == 0) {
+    unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 8 + wv) * 8;
+    d[0] = tsum[0][0]; d[1] = tsum[0][1]; d[2] = tsum[0][2]; d[3] = tcnt[0];
+    d[4] = tsum[1][0]; d[5] = tsum[1][1]; d[6] = tsum[1][2]; d[7] = tcnt[1];
+  }
   if (p.prio == 99) return;  // (ablation from the host: main loop only; wrong results)
 
   // epilogue: bf16 tile through LDS (row pitch 256 + 8 elements), 16-byte stores
@@ -361,6 +396,7 @@ int main(int argc, char** argv) {
     p.A = dA; p.B = dB; p.C = dC; p.M = s.M; p.N = s.N; p.K = s.K;
     p.a_bytes = (unsigned)(na * 2); p.b_bytes = (unsigned)(nb * 2);
     p.tilesN = (s.N + 255) / 256;
+    p.dbg = nullptr;
     const double fl = 2.0 * s.M * s.N * s.K;
     const int reps = fl > 5e11 ? 5 : 20;
     const int g4 = ((s.M + 255) / 256) * p.tilesN, g2 = ((s.M + 127) / 128) * p.tilesN;
@@ -370,6 +406,34 @@ int main(int argc, char** argv) {
     const float l4 = run<4>(p, g4, reps), l2 = run<2>(p, g2, reps), ls = run<4, true>(p, g4, reps);
     printf("%-40s M%6d N%5d K%5d | 256x256: %4d blocks %7.1f us %5.0f TF/s (loop only %7.1f) | staggered all-wave issue %7.1f us %5.0f TF/s (loop only %7.1f) | 128x256: %4d blocks %7.1f us %5.0f TF/s (loop only %7.1f)\n",
            s.what, s.M, s.N, s.K, g4, t4 * 1e3, fl / t4 / 1e9, l4 * 1e3, ts * 1e3, fl / ts / 1e9, ls * 1e3, g2, t2 * 1e3, fl / t2 / 1e9, l2 * 1e3);
+    if (s.M == 4096 || (s.M == 50176 && s.K == 3072)) {  // cycle budget of a phase (diagnostic build)
+      unsigned long long* dbg;
+      hipMalloc(&dbg, (size_t)g4 * 8 * 8 * 8);
+      hipMemset(dbg, 0, (size_t)g4 * 8 * 8 * 8);
+      p.dbg = dbg;
+      p.prio = 0;
+      hipFuncSetAttribute((const void*)gemm_deep<4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      const size_t smem = 256 * (256 + 8) * 2;
+      for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_deep<4, false, true>), dim3(g4), dim3(512), smem, 0, p);
+      hipDeviceSynchronize();
+      std::vector<unsigned long long> h((size_t)g4 * 64);
+      hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+      for (int half = 0; half < 2; ++half) {
+        double a[2][3] = {{0, 0, 0}, {0, 0, 0}}, c[2] = {0, 0};
+        for (int b = 0; b < g4; ++b)
+          for (int w = half * 4; w < half * 4 + 4; ++w) {
+            const unsigned long long* d = &h[((size_t)b * 8 + w) * 8];
+            for (int r = 0; r < 2; ++r) {
+              for (int k = 0; k < 3; ++k) a[r][k] += (double)d[r * 4 + k];
+              c[r] += (double)d[r * 4 + 3];
+            }
+          }
+        printf("   stamps, waves %d-%d: multiplying phases: wait+barrier %6.0f, (no copies) %4.0f, reads+MFMA+lgkm %6.0f | loading phases: wait+barrier %6.0f, copy issue %6.0f, reads+MFMA+lgkm %6.0f   [cycles per phase, mean over %0.f phases]\n",
+               half * 4, half * 4 + 3, a[0][0] / c[0], a[0][1] / c[0], a[0][2] / c[0], a[1][0] / c[1], a[1][1] / c[1], a[1][2] / c[1], c[0] + c[1]);
+      }
+      hipFree(dbg);
+      p.dbg = nullptr;
+    }
     // check sampled outputs against a host dot product (the full-epilogue variant ran last? no: rerun it)
     p.prio = 0;
     run<4, true>(p, g4, 1);
