@@ -1007,10 +1007,21 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvP p, int tiles_per
   }
 }
 
-#define VS_DIRECT_TPW 8  // 16-row tiles per wave -> 512 rows per block
+// 16-row tiles per wave (x 4 waves x 16 rows = rows per block): 8 (512 rows).  VS_DIRECT_TPW_BLOCKS=N (experiment, round 4):
+// fewer tiles per wave where 8 leave fewer than N blocks -- measured neutral at N = 512 over the small-channel layers
+// (0.316 vs 0.317 ms forward, 200 704-row layers with 784 instead of 392 blocks), 10 % slower at 1024, and 0.4 % slower
+// in the step (more BN partial rows): off by default (profiles/r04_direct_tpw.txt).
+static int direct_tpw(long long M) {
+  static const long long want = [] { const char* e = getenv("VS_DIRECT_TPW_BLOCKS"); return e ? atoll(e) : 0ll; }();
+  int tpw = 8;
+  while (want > 0 && tpw > 2 && (M + 64 * tpw - 1) / (64 * tpw) < want) tpw >>= 1;
+  return tpw;
+}
+#define VS_DIRECT_TPW direct_tpw(p.M)
 
 static int direct_blocks(long long M) {
-  return (int)((M + 16 * 4 * VS_DIRECT_TPW - 1) / (16 * 4 * VS_DIRECT_TPW));
+  const int tpw = direct_tpw(M);
+  return (int)((M + 16 * 4 * tpw - 1) / (16 * 4 * tpw));
 }
 
 template <int NT, int KS, int TB>
