@@ -125,7 +125,9 @@ size_t vs_conv_workspace_bytes(const vs_conv_desc* d, int dgrad);
 /* The launch plan the library picks for this descriptor (dgrad = 1: for vs_conv_dgrad):
  * out[5] = {tile rows, tile cols, LDS-DMA ring stages (0 = register-staged), split-K factor,
  * 1 if the register-resident small-channel kernel runs}; out[4] == 2: the halo-image kernel (conv_halo.hip),
- * out[0..1] its tile, out[2] its weight-ring depth, out[3] its unrolled tap count.  Profiling / attribution only. */
+ * out[0..1] its tile, out[2] its weight-ring depth, out[3] its unrolled tap count; out[4] == 3: the persistent
+ * pointwise kernel (conv_pw.hip); out[4] == 4: the deep-pipeline kernel (conv_deep.hip: 256 x 256 tile, out[2] = 8
+ * LDS sub-buffers).  Profiling / attribution only. */
 int vs_conv_plan(const vs_conv_desc* d, int dgrad, int* out);
 /* Apply on load (training, the b -> c edge of a bottleneck: slowfast resnet_helper.BottleneckTransform.forward
  * `x = self.b_relu(self.b_bn(x)); x = self.c(x)`): the 1x1x1 convolution takes the PRODUCER unit's raw convolution
@@ -232,7 +234,12 @@ int vs_weight_transpose_tiled(const void* src, void* dst, const int64_t* table, 
                               int n, int64_t total_tiles, int elem_bytes, void* stream);
 
 /* Weight gradient: dw[Cout][taps][Cin] fp32 = sum_p dy[p][co] * x[p@tap][ci].
- * workspace: vs_conv_wgrad_workspace_bytes(desc) bytes of fp32 split-K slabs. */
+ * workspace: vs_conv_wgrad_workspace_bytes(desc) bytes of fp32 split-K slabs.
+ * desc.flags of a weight gradient: bits 8..11 forced tile, 16..18 VS_CONV_RING, 24..31 block slots / 8 (tuning knobs),
+ * VS_WGRAD_NODEEP / VS_WGRAD_FORCEDEEP: keep it off / put it on the deep-pipeline kernel (128 x 256 output tile,
+ * 32-position units, six-slot LDS ring; the plan takes it from 40 000 positions on). */
+#define VS_WGRAD_NODEEP (1 << 12)
+#define VS_WGRAD_FORCEDEEP (1 << 13)
 size_t vs_conv_wgrad_workspace_bytes(const vs_conv_desc* d);
 int vs_conv_wgrad(const void* dy, const void* x, float* dw, const vs_conv_desc* d,
                   void* workspace, size_t ws_bytes, void* stream);

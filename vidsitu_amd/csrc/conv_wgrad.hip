@@ -922,8 +922,7 @@ struct WgCfg {
   int deep;  // conv_wgrad_deep_kernel (128 x 256 tile, 512 threads)
 };
 
-#define VS_WGRAD_NODEEP (1 << 12)    /* vs_conv_desc.flags of a weight gradient: keep it off the deep-pipeline kernel (A/B, tests) */
-#define VS_WGRAD_FORCEDEEP (1 << 13) /* ... on it whenever the shape is eligible */
+// (VS_WGRAD_NODEEP / VS_WGRAD_FORCEDEEP: include/vidsitu_hip.h)
 
 // Deep-pipeline plan: 128 x 256 output tiles, one block per CU (152 KiB of LDS), the positions split so that the grid
 // is one residency round.  Where it pays (profiles/r04_wgrad_deep.txt): >= 128 output channels and >= 192 columns
