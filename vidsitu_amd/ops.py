@@ -465,6 +465,8 @@ def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=N
 
 
 _ws_cache = {}
+import os as _os_wi
+_WHATIF_WGRAD = (int(_os_wi.environ.get("VS_WHATIF", "0")) & 4) != 0  # tools only (see conv_wgrad)
 
 
 # The slab reduce behind a weight gradient and the next unit's BN-backward finalize as ONE launch
@@ -574,6 +576,8 @@ def conv_wgrad(dy, x, k, s, p, out=None, ring=0, batch=None, tile=None, slots=0,
         raise _lib.VsError("conv_wgrad out must be fp32 with [Cout][taps][Cin] memory")
     if batch is not None:
         return batch.wgrad(dy, x, k, s, p, out, ring)
+    if _WHATIF_WGRAD:  # timing experiment only (tools): what the step costs WITHOUT its weight gradients (garbage dW)
+        return out
     # tile: index into WG_TILES, slots: block slots to fill (multiple of 8) -- tuning knobs, 0 / None = the plan
     flags = ((ring & 7) << 16) | (((tile + 1) << 8) if tile is not None else 0) | (((slots // 8) & 0xff) << 24)
     if not deep:
