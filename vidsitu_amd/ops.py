@@ -670,6 +670,10 @@ def bn_apply(y, scale, shift, residual=None, relu=True, out=None, want_bits=Fals
     mask as bits, uint8 [rows, C/8], for the backward passes (vs_bn_apply_mask)."""
     if out is None:
         out = new_act(*y.shape, device=y.device)
+    if _WHATIF & 8:  # timing experiment only (tools): the step without its BN apply / backward passes (garbage tensors)
+        if want_bits:
+            return out, (torch.empty((act_rows(y), y.shape[1] // 8), dtype=torch.uint8, device=y.device) if relu else None)
+        return out
     if want_bits and relu:
         bits = torch.empty((act_rows(y), y.shape[1] // 8), dtype=torch.uint8, device=y.device)
         _lib.call("vs_bn_apply_mask", _ptr(y), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out),
@@ -743,7 +747,7 @@ def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres, dy_out=None, dgamma=N
         if nblk <= 0:
             raise _lib.VsError("bn_bwd: unsupported channel count")
         partial = torch.empty((nblk, 2, c), dtype=torch.float32, device=dev)
-        _lib.call("vs_bn_bwd_reduce", _ptr(dz), _ptr(zz), _ptr(y), _ptr(mean), _ptr(invstd),
+        if not (_WHATIF & 8): _lib.call("vs_bn_bwd_reduce", _ptr(dz), _ptr(zz), _ptr(y), _ptr(mean), _ptr(invstd),
                   _ptr(gamma), _ptr(beta), _ptr(partial), rows, c, act_ld(dz), z_ld, act_ld(y),
                   mode, _stream())
     if dgamma is None:
@@ -760,7 +764,7 @@ def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres, dy_out=None, dgamma=N
         return dy, dres, dgamma, dbeta
     if not (_WHATIF & 2):
         _lib.call("vs_bn_bwd_finalize", _ptr(partial), nblk, _ptr(dgamma), _ptr(dbeta), c, _stream())
-    _lib.call("vs_bn_bwd_apply", _ptr(dz), _ptr(zz), _ptr(y), _ptr(mean), _ptr(invstd),
+    if not (_WHATIF & 8): _lib.call("vs_bn_bwd_apply", _ptr(dz), _ptr(zz), _ptr(y), _ptr(mean), _ptr(invstd),
               _ptr(gamma), _ptr(beta), _ptr(dgamma), _ptr(dbeta), _ptr(dy), _ptr(dres), rows, c,
               act_ld(dz), z_ld, act_ld(y), act_ld(dy), act_ld(dres) if want_dres else 0,
               mode, _stream())
