@@ -62,6 +62,10 @@ typedef enum vs_status {
 #define VS_CONV_NODEEP (1 << 27) /* keep a >= 192-column deep-reduction conv on the 128 x 128 tile kernel instead of the
                                     256 x 256 deep-pipeline kernel (conv_deep.hip; A/B, tests) */
 #define VS_CONV_FORCEDEEP (1 << 28) /* run it on the deep-pipeline kernel whenever the shape is eligible (A/B, tests) */
+#define VS_CONV_SPLITK_IL (1 << 29) /* in-launch split-K on the 128 x 128 tile (S blocks per tile, the last arriver sums the
+                                       partial accumulators in split order and runs the fused epilogue) wherever the shape is
+                                       eligible; without the flag the plan picks it for under-tiled deep reductions */
+#define VS_CONV_NOSPLITK_IL (1 << 30) /* never (A/B, tests) */
 
 /* Geometry of one Conv3d (bias-free, groups 1, dilation 1).
  * Replaces nn.Conv3d reached from vidsitu_code/mdl_sf_base.py:22-33 (s1..s5,
@@ -119,15 +123,19 @@ int vs_conv_fwd(const void* x, const void* w, void* y, const vs_conv_desc* d, co
                 const float* shift, const void* residual, float* stats_partial,
                 void* workspace, size_t ws_bytes, void* stream);
 int vs_conv_stats_rows(const vs_conv_desc* d);
-/* fp32 split-K slabs (few-tile, deep-K layers); 0 when the plan for this shape has no split.
- * dgrad = 1 sizes the workspace of vs_conv_dgrad for the same descriptor. */
+/* Split-K workspace (few-tile, deep-K layers); 0 when the plan for this shape has no split.
+ * dgrad = 1 sizes the workspace of vs_conv_dgrad for the same descriptor.
+ * The buffer's head holds one arrival counter per tile for the in-launch split plan: it has to be ZERO before the first
+ * launch that uses the buffer and belongs to the library from then on (every launch leaves the counters at zero);
+ * launches that may run concurrently (different streams) need different buffers. */
 size_t vs_conv_workspace_bytes(const vs_conv_desc* d, int dgrad);
 /* The launch plan the library picks for this descriptor (dgrad = 1: for vs_conv_dgrad):
  * out[5] = {tile rows, tile cols, LDS-DMA ring stages (0 = register-staged), split-K factor,
  * 1 if the register-resident small-channel kernel runs}; out[4] == 2: the halo-image kernel (conv_halo.hip),
  * out[0..1] its tile, out[2] its weight-ring depth, out[3] its unrolled tap count; out[4] == 3: the persistent
  * pointwise kernel (conv_pw.hip); out[4] == 4: the deep-pipeline kernel (conv_deep.hip: 256 x 256 tile, out[2] = 8
- * LDS sub-buffers).  Profiling / attribution only. */
+ * LDS sub-buffers); out[4] == 5: the tile kernel with out[3] blocks per tile and the in-launch split-K sum.
+ * Profiling / attribution only. */
 int vs_conv_plan(const vs_conv_desc* d, int dgrad, int* out);
 /* Apply on load (training, the b -> c edge of a bottleneck: slowfast resnet_helper.BottleneckTransform.forward
  * `x = self.b_relu(self.b_bn(x)); x = self.c(x)`): the 1x1x1 convolution takes the PRODUCER unit's raw convolution

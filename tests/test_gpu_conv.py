@@ -779,6 +779,101 @@ def test_halo_image_kernel_fwd_and_dgrad(case, dev):
     assert float((psb.double().sum(0).cpu() - want).abs().max()) / float(want.abs().max()) < 1e-5
 
 
+# name, N, Cin, T, H, W, Cout, k, s, p: few-tile, deep-K shapes for the in-launch split-K plan of the 128 x 128 tile
+SPLITK_IL_CASES = [
+    ("s5a_t3_1024_512", 2, 1024, 4, 7, 7, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0)),      # 4 x 4 tiles, 48 k-steps
+    ("s5b_3x3_512", 2, 512, 4, 7, 7, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1)),           # 72 k-steps
+    ("pw_2048_512", 2, 2048, 2, 7, 7, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0)),          # pointwise dense, 32 k-steps
+    ("3x3_strided_256_256", 2, 256, 4, 14, 14, 256, (1, 3, 3), (1, 2, 2), (0, 1, 1)),  # its dgrad: stride classes
+    ("ragged_136_264", 3, 136, 3, 13, 11, 264, (1, 3, 3), (1, 1, 1), (0, 1, 1)),      # K = 1224 (tail), N = 256 + 8, M = 1287
+    ("short_k_512_128", 2, 512, 2, 7, 7, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0)),       # 8 k-steps: S = 2
+]
+
+
+@pytest.mark.parametrize("case", SPLITK_IL_CASES, ids=[c[0] for c in SPLITK_IL_CASES])
+def test_in_launch_splitk_fwd_and_dgrad(case, dev):
+    """In-launch split-K of the 128 x 128 tile kernel (S blocks per tile store their partial accumulators, the tile's
+    last arriver sums them in split order and runs the fused epilogue): forward with every epilogue and the data
+    gradient (plain, + residual, + masked residual, + BN-backward sums; strided: stride classes) against torch and
+    against the unsplit launch; 30 repeats bit for bit (the sum must not depend on which block arrives last); the
+    arrival counters are back at zero after every launch."""
+    from vidsitu_amd import ops
+
+    name, n, cin, t, h, w, cout, k, s, p = case
+    g = torch.Generator().manual_seed(89)
+    x = rb(torch.randn(n, cin, t, h, w, generator=g))
+    wgt = rb(torch.randn(cout, cin, *k, generator=g) / (cin * k[0] * k[1] * k[2]) ** 0.5)
+    xa, wa = to_act(x, dev), to_w(wgt, dev)
+    ref = F.conv3d(x, wgt, stride=s, padding=p)
+    ys = tuple(ref.shape)
+    IL = 1 << 29  # VS_CONV_SPLITK_IL (+ NOHALO | NOPW | NODEEP: the tile kernel)
+    other = (1 << 21) | (1 << 23) | (1 << 27)
+    pl = _plan(ops, tuple(x.shape), ys, cin, cout, k, s, p, 0, IL | other)
+    assert pl[4] == 5 and pl[3] >= 2 and pl[0] == 128 and pl[1] == 128, f"forward did not take the in-launch split: {list(pl)}"
+    kw = dict(halo=False, pw=False, deep=False)
+    y, part = ops.conv_fwd(xa, wa, k, s, p, stats=True, splitk_il=True, **kw)
+    assert_close(y, ref, TOL, name + " fwd")
+    y0, part0 = ops.conv_fwd(xa, wa, k, s, p, stats=True, splitk_il=False, tile=0, ring=2, **kw)
+    assert_close(y, y0.float(), 4e-3, name + " fwd vs unsplit")
+    assert part.shape == part0.shape
+    tot, tot0 = part.double().sum(0).cpu(), part0.double().sum(0).cpu()
+    assert torch.allclose(tot, tot0, rtol=2e-3, atol=2e-3 * float(tot0.abs().max()))
+    for _ in range(30):  # run to run: bit for bit, whoever arrives last
+        y2, part2 = ops.conv_fwd(xa, wa, k, s, p, stats=True, splitk_il=True, **kw)
+        assert torch.equal(y2.view(torch.int16), y.view(torch.int16)) and torch.equal(part2, part)
+    ws = ops._workspace(1, dev, "splitk")
+    assert int(ws[:4096].view(torch.int32).abs().max()) == 0, "arrival counters not cleared"
+    sc = (torch.rand(cout, generator=g) + 0.5).to(dev)
+    sh = torch.randn(cout, generator=g).to(dev)
+    r = rb(torch.randn(ref.shape, generator=g))
+    buf = ops.new_act(ys[0], cout + 16, *ys[2:], dev, zero=True)
+    out = ops.channel_slice(buf, 8, cout)
+    ops.conv_fwd(xa, wa, k, s, p, out=out, scale=sc, shift=sh, residual=to_act(r, dev), relu=True, splitk_il=True, **kw)
+    want = (ref * sc.cpu().view(1, -1, 1, 1, 1) + sh.cpu().view(1, -1, 1, 1, 1) + r).relu()
+    assert_close(out, want, TOL, name + " fwd epilogue")
+    assert float(buf[:, :8].abs().max()) == 0.0 and float(buf[:, 8 + cout:].abs().max()) == 0.0
+    if cout * k[0] * k[1] * k[2] < 512:
+        return  # the data gradient's reduction is shorter than 8 k-steps: nothing to split
+    xg = x.clone().requires_grad_()
+    yy = F.conv3d(xg, wgt, stride=s, padding=p)
+    dy = rb(torch.randn(yy.shape, generator=g))
+    (dx_ref,) = torch.autograd.grad(yy, xg, dy)
+    wt = ops.weight_transpose(wa)
+    dya = to_act(dy, dev)
+    xs = tuple(x.shape)
+    pld = _plan(ops, xs, ys, cin, cout, k, s, p, 1, IL | other)
+    assert pld[4] == 5 and pld[3] >= 2, f"dgrad did not take the in-launch split: {list(pld)}"
+    dx = ops.conv_dgrad(dya, wt, xs, k, s, p, splitk_il=True, **kw)
+    assert_close(dx, dx_ref, TOL, name + " dgrad")
+    assert_close(dx, ops.conv_dgrad(dya, wt, xs, k, s, p, splitk_il=False, **kw).float(), 2.0 ** -7, name + " dgrad vs unsplit")
+    for _ in range(10):
+        assert torch.equal(ops.conv_dgrad(dya, wt, xs, k, s, p, splitk_il=True, **kw).view(torch.int16), dx.view(torch.int16))
+    rr = rb(torch.randn(x.shape, generator=g))
+    rra = to_act(rr, dev)
+    dxr = ops.conv_dgrad(dya, wt, xs, k, s, p, residual=rra, splitk_il=True, **kw)
+    assert_close(dxr, dx_ref + rr, TOL, name + " dgrad + residual")
+    rows = ops.act_rows(rra)
+    bits = torch.randint(0, 256, (rows, cin // 8), generator=g, dtype=torch.uint8).to(dev)
+    keep = _unpack_bits(bits, xs)
+    dxm = ops.conv_dgrad(dya, wt, xs, k, s, p, residual=rra, residual_bits=bits, splitk_il=True, **kw)
+    assert_close(dxm, dx_ref + torch.where(keep.cpu(), rr, torch.zeros(())), TOL, name + " dgrad + masked residual")
+    bn_y = to_act(rb(torch.randn(x.shape, generator=g)), dev)
+    mean = (torch.randn(cin, generator=g) * 0.2).to(dev)
+    invstd = (torch.rand(cin, generator=g) + 0.5).to(dev)
+    gamma, beta = torch.randn(cin, generator=g).to(dev), (torch.randn(cin, generator=g) * 0.3).to(dev)
+    dxs, psum = ops.conv_dgrad(dya, wt, xs, k, s, p, bn_stats=(bn_y, mean, invstd, gamma, beta), splitk_il=True, **kw)
+    assert psum is not None, "the in-launch split keeps the fused BN-backward sums"
+    assert torch.equal(dxs.view(torch.int16), dx.view(torch.int16))
+    v = lambda a: a.view(1, -1, 1, 1, 1)
+    xh = (bn_y.float() - v(mean)) * v(invstd)
+    gm = torch.where(xh * v(gamma) + v(beta) > 0, dx.float(), torch.zeros((), device=dev))
+    want = torch.stack([gm.double().sum((0, 2, 3, 4)), (gm * xh).double().sum((0, 2, 3, 4))]).cpu()
+    got = psum.double().sum(0).cpu()
+    assert float((got - want).abs().max()) / float(want.abs().max()) < 2e-3
+    ws = ops._workspace(1, dev, "splitk")
+    assert int(ws[:4096].view(torch.int32).abs().max()) == 0, "arrival counters not cleared"
+
+
 # name, N, Cin, T, H, W, Cout, k, s, p: shapes for the deep-pipeline kernel (>= 192 columns both directions)
 DEEP_CASES = [
     ("s4a_t3_1024_256", 2, 1024, 8, 14, 14, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0)),

@@ -502,62 +502,18 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, c
     };
 #pragma unroll
     for (int d = 0; d < D; ++d) dma(kbeg + d, d);
-    // Optional order of the ring loop: the first fragment reads of a k-step issued before the copies of tile kt + D.
-    // OFF by default.  Measured cleanly (profiles/r02_ring_frags_first.txt, VS_RING_FF_MIN / VS_RING_FF_MAX, same box,
-    // alternating) it costs 0..7 % on the long reductions and changes nothing in the step.  (An earlier A/B that showed
-    // -8..-11 % was void: its on / off switch travelled in launch-flag bits 13 / 14, which the launcher also reads as
-    // the diagnostic-variant selector of the 128 x 128 tile -- the two arms ran two different diagnostic kernels.)
-    const bool frags_first = !AOL && nk >= p.ff_min && nk <= p.ff_max;
     int st_c = 0, st_l = D;  // stage computed / stage refilled this step
     for (int kt = 0; kt < nk; ++kt) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"i"((D - 1) * L) : "memory");  // my part of tile kt landed
       __builtin_amdgcn_s_barrier();  // everyone's did; stage st_l (tile kt-1) is no longer read
       __builtin_amdgcn_sched_barrier(0);
-      if (frags_first) {
-        // the first fragment reads of this tile are issued BEFORE the copies of tile kt + D: the ~30 instructions
-        // of copy address arithmetic and issue run under the LDS latency instead of in front of it
-        const char* A = smem + st_c * STAGE;
-        const char* B = A + BM * 128;
-        bf16x8 af0[MR], bf0[NR], af1[MR], bf1[NR];
-#pragma unroll
-        for (int a = 0; a < MR; ++a) {
-          const int row = wm * TM + a * 16 + lr;
-          af0[a] = *(const bf16x8*)(A + row * 128 + ((lq ^ ((row >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int b = 0; b < NR; ++b) {
-          const int row = wn * TN + b * 16 + lr;
-          bf0[b] = *(const bf16x8*)(B + row * 128 + ((lq ^ ((row >> 1) & 7)) << 4));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        dma(kbeg + kt + D, st_l);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int a = 0; a < MR; ++a) {
-          const int row = wm * TM + a * 16 + lr;
-          af1[a] = *(const bf16x8*)(A + row * 128 + (((4 + lq) ^ ((row >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int b = 0; b < NR; ++b) {
-          const int row = wn * TN + b * 16 + lr;
-          bf1[b] = *(const bf16x8*)(B + row * 128 + (((4 + lq) ^ ((row >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int a = 0; a < MR; ++a)
-#pragma unroll
-          for (int b = 0; b < NR; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0[a], bf0[b], acc[a][b], 0, 0, 0);
-#pragma unroll
-        for (int a = 0; a < MR; ++a)
-#pragma unroll
-          for (int b = 0; b < NR; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1[a], bf1[b], acc[a][b], 0, 0, 0);
-      } else {
-        dma(kbeg + kt + D, st_l);
-        __builtin_amdgcn_sched_barrier(0);
-        if (AOL) aol_k0 = (kbeg + kt) * 64;
-        compute(st_c);
-      }
+      // (one straight-line body: a second, "fragment reads first" order of this step lived here behind a run-time
+      //  switch until round 4 -- measured useless in round 2 (profiles/r02_ring_frags_first.txt), and its mere presence
+      //  made hipcc move all 64 accumulator registers at the top of every k-step)
+      dma(kbeg + kt + D, st_l);
+      __builtin_amdgcn_sched_barrier(0);
+      if (AOL) aol_k0 = (kbeg + kt) * 64;
+      compute(st_c);
       __builtin_amdgcn_sched_barrier(0);
       st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
       st_l = (st_l + 1 == NS) ? 0 : st_l + 1;
@@ -600,7 +556,61 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, c
   __syncthreads();
   }
 
-  if (p.splitK > 1) {
+  bool in_launch = false;
+  if constexpr (NS >= 2 && !AOL) {
+    if (p.splitK > 1 && p.sk_cnt != nullptr) {
+      // In-launch split-K: the S blocks of a tile (neighbours in the block order, same XCD run) each store their fp32
+      // partial accumulators -- in register order, one 4-KiB row of float4 per (a, b) fragment, nothing staged -- and
+      // take a ticket from the tile's arrival counter.  The block that draws ticket S - 1 sums the partials of splits
+      // 0 .. S - 1 IN THAT ORDER (its own included, re-read: the sum does not depend on who arrived last, so the result
+      // is bitwise the same from run to run), clears the counter for the next launch and runs the fused epilogue.
+      // sk_cnt has to be zero before the first launch (vs_conv_workspace_bytes).
+      in_launch = true;
+      // Partials and ticket without a cache-wide fence: an agent-scope release / acquire fence on gfx950 is
+      // buffer_wbl2 + buffer_inv over the XCD's whole L2 (~100 us per launch, measured: every split launch took
+      // 100-135 us whatever its size).  Instead every partial word is an agent-scope relaxed atomic store / load
+      // (global_store / global_load with sc1: written through to, and read from, the point the XCDs share); the
+      // workgroup barrier's vmcnt(0) retires the stores before the ticket is drawn.
+      constexpr int Q = MR * NR;
+      float* part = p.slab + ((long long)tile_id * p.splitK) * (Q * 1024);  // [split][fragment][component][256 threads]
+      float* mine = part + (long long)ksplit * (Q * 1024) + tid;
+#pragma unroll
+      for (int a = 0; a < MR; ++a)
+#pragma unroll
+        for (int b = 0; b < NR; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            __hip_atomic_store(mine + ((a * NR + b) * 4 + r) * 256, acc[a][b][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();  // (s_waitcnt vmcnt(0) + barrier: every wave's partial words are written through)
+      int* flag = (int*)smem;
+      if (tid == 0) flag[0] = atomicAdd(p.sk_cnt + tile_id, 1);
+      __syncthreads();
+      const int ticket = flag[0];
+      if (ticket != p.splitK - 1) return;
+      if (tid == 0) p.sk_cnt[tile_id] = 0;
+      auto load_part = [&](int s, int q) __attribute__((always_inline)) {
+        const float* ps = part + (long long)s * (Q * 1024) + q * 1024 + tid;
+        f32x4 t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = __hip_atomic_load(ps + r * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return t;
+      };
+      // (whole-vector assignments and adds: with per-component updates of acc here, hipcc treated three of the four
+      //  lanes of every accumulator as undefined in the MAIN LOOP -- three quarters of every ring launch's outputs garbage)
+#pragma unroll
+      for (int a = 0; a < MR; ++a)
+#pragma unroll
+        for (int b = 0; b < NR; ++b) acc[a][b] = load_part(0, a * NR + b);
+      for (int s = 1; s < p.splitK; ++s) {
+#pragma unroll
+        for (int a = 0; a < MR; ++a)
+#pragma unroll
+          for (int b = 0; b < NR; ++b) acc[a][b] = acc[a][b] + load_part(s, a * NR + b);
+      }
+      __syncthreads();  // flag word: the epilogue reuses the tile memory
+    }
+  }
+  if (p.splitK > 1 && !in_launch) {
     // split-K: raw fp32 partial tile -> slab[ksplit]; BN statistics, affine, residual, ReLU and
     // the bf16 store happen in conv_splitk_epilogue_kernel after the fixed-order slab sum
     float* E = (float*)smem;
@@ -1377,7 +1387,7 @@ static bool pair_take_dgrad(const ConvP&, int, size_t, int, bool, hipStream_t) {
 template <int BM, int BN, int WM, int WN, int MODE, int NS, bool BNB = false, bool BNB2 = false>
 static int launch_one(const ConvP& p, int grid, size_t smem, hipStream_t st) {
   if constexpr (BM == 128 && BN == 128 && WM == 2 && WN == 2 && NS == 2 && !BNB2) {
-    if (pair_take_dgrad(p, grid, smem, MODE, BNB, st)) return VS_OK;
+    if (p.sk_cnt == nullptr && pair_take_dgrad(p, grid, smem, MODE, BNB, st)) return VS_OK;
   }
   static bool attr_done = false;  // dynamic LDS above 64 KiB needs an explicit opt-in, once per kernel
   if (!attr_done) {
@@ -1486,7 +1496,18 @@ struct ConvPlan {
   int S;        // split-K factor (1 = none)
   bool direct;  // register-resident small-channel kernel
   int ring;     // 0 = register-staged pipeline, 2..4 = LDS-DMA ring stages
+  bool in_launch;  // S > 1: partial accumulators summed by the last block of each tile inside the launch (no second kernel)
 };
+
+// VS_CONV_SPLITK_IL: 0 = only where the descriptor asks for it (VS_CONV_SPLITK_IL in flags; default), 1 = where the plan
+// below would pick it, 2 = wherever the shape is eligible.  OFF by default: measured at 8 clips per GPU
+// (profiles/r04_splitk_in_launch.txt) it loses on every layer of the step -- a 128 x 128 fp32 partial is 64 KiB written
+// through and read back per block, the operand traffic of four k-steps, and the layers it would fill the chip for are
+// already on the halo-image / deep kernels.
+static int splitk_il_mode() {
+  static const int m = [] { const char* e = getenv("VS_CONV_SPLITK_IL"); return e ? atoi(e) : 0; }();
+  return m;
+}
 
 // Few-tile, deep-K layers (slow s4 / s5 at batch 8: 100-400 tiles for 256 CUs) leave each CU
 // with at most one block, which is bound by bytes-in-flight / latency; splitting K puts 2-4
@@ -1495,6 +1516,7 @@ static ConvPlan plan_conv(long long M, int Ncols, int K, int taps, int flags) {
   ConvPlan pl;
   pl.S = 1;
   pl.direct = false;
+  pl.in_launch = false;
   const int fring = (flags >> 16) & 7;  // VS_CONV_RING: 1 = register-staged, 2..4 = ring stages
   pl.ring = fring >= 2 ? (fring > 4 ? 4 : fring) : 0;
   const int forced = (flags >> 8) & 0xf;
@@ -1515,6 +1537,26 @@ static ConvPlan plan_conv(long long M, int Ncols, int K, int taps, int flags) {
   const long long t128 = ((M + 127) / 128) * ((Ncols + 127) / 128);
   // measured on MI355X at batch 8: the slab write + re-read costs more than the extra occupancy
   // buys (s4.a 46 -> 58 us), so the split plan is opt-in (VS_CONV_SPLITK) until batches grow
+  // In-launch split-K (the 128 x 128 tile on the 2-stage ring): under-tiled deep reductions get S blocks per tile, 2 per
+  // CU; the tile's last arriver sums the S partial accumulators in split order and runs the ordinary epilogue.
+  {
+    const int il = (flags & VS_CONV_NOSPLITK_IL) ? 0 : ((flags & VS_CONV_SPLITK_IL) ? 2 : splitk_il_mode());
+    static const int il_tiles = [] { const char* e = getenv("VS_CONV_SPLITK_IL_TILES"); return e ? atoi(e) : 224; }();
+    static const int il_nk = [] { const char* e = getenv("VS_CONV_SPLITK_IL_NK"); return e ? atoi(e) : 32; }();
+    const bool shape_ok = Ncols >= 128 && Ncols % 8 == 0 && taps <= 31 && nk >= 8 && fring == 0 && forced == 0;
+    if (il && shape_ok && !(flags & VS_CONV_SPLITK) && (il == 2 || (t128 <= il_tiles && nk >= il_nk))) {
+      long long S = (512 + t128 / 2) / t128;  // ~2 blocks per CU
+      if (S > nk / 4) S = nk / 4;             // >= 4 k-steps per block
+      if (S > 8) S = 8;
+      if (S >= 2) {
+        pl.tile = kTileTable[0];
+        pl.ring = 2;
+        pl.S = (int)S;
+        pl.in_launch = true;
+        return pl;
+      }
+    }
+  }
   if ((flags & VS_CONV_SPLITK) && Ncols >= 128 && Ncols % 8 == 0 && taps <= 31 && t128 < 384 && nk >= 16) {
     pl.tile = kTileTable[0];
     pl.ring = fring >= 2 ? pl.ring : 0;
@@ -1527,8 +1569,18 @@ static ConvPlan plan_conv(long long M, int Ncols, int K, int taps, int flags) {
   return pl;
 }
 
+// in-launch plan: [counters: one int per tile, 4 KiB aligned][tile][S][128 x 128 fp32]; tile count with room for the
+// class-interleaved numbering of strided data gradients (setup_stride_classes: at most 16 partly filled tiles more)
+static size_t il_counter_bytes(long long M, int Ncols) {
+  const size_t tiles = (size_t)((M + 127) / 128 + 16) * (size_t)((Ncols + 127) / 128);
+  return (tiles * sizeof(int) + 4095) & ~(size_t)4095;
+}
 static size_t plan_ws_bytes(const ConvPlan& pl, long long M, int Ncols) {
-  return pl.S > 1 ? (size_t)pl.S * M * Ncols * sizeof(float) : 0;
+  if (pl.S > 1 && pl.in_launch) {
+    const size_t tiles = (size_t)((M + 127) / 128 + 16) * (size_t)((Ncols + 127) / 128);
+    return il_counter_bytes(M, Ncols) + tiles * (size_t)pl.S * 128 * 128 * sizeof(float);
+  }
+  return pl.S > 1 ? il_counter_bytes(M, Ncols) + (size_t)pl.S * M * Ncols * sizeof(float) : 0;  // (same head: one buffer)
 }
 
 // Stride classes of the transposed gather (MODE 2): tiles are laid out class by class; sets
@@ -1572,13 +1624,6 @@ static bool aol_tile_ok(const ConvPlan& pl, int mode, int K) {
 
 static int launch_conv(ConvP& p, int mode, int naive, int flags, void* ws, size_t ws_bytes,
                        hipStream_t st) {
-  // fragment-first ring order (off by default, see the ring loop): VS_RING_FRAGS_FIRST=1 switches it on everywhere,
-  // VS_RING_FF_MIN / VS_RING_FF_MAX bound the k-step counts it is used for
-  static const int frags_first = [] { const char* e = getenv("VS_RING_FRAGS_FIRST"); return e ? atoi(e) : 0; }();
-  static const int ff_min = [] { const char* e = getenv("VS_RING_FF_MIN"); return e ? atoi(e) : -1; }();
-  static const int ff_max = [] { const char* e = getenv("VS_RING_FF_MAX"); return e ? atoi(e) : 1 << 30; }();
-  p.ff_min = ff_min >= 0 ? ff_min : (frags_first == 1 ? 0 : 1 << 30);
-  p.ff_max = ff_max;
   {
     // chunk-major reduction (ConvP::korder) where a tap spans at least VS_CONV_KORDER_MIN k-tiles (default 2; 0 = never)
     static const int kmin = [] { const char* e = getenv("VS_CONV_KORDER_MIN"); return e ? atoi(e) : 2; }();
@@ -1587,6 +1632,7 @@ static int launch_conv(ConvP& p, int mode, int naive, int flags, void* ws, size_
   }
   p.splitK = 1;
   p.slab = nullptr;
+  p.sk_cnt = nullptr;
   if (naive) {
     const long long total = (long long)p.M * p.Ncols;
     hipLaunchKernelGGL(conv_naive_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
@@ -1639,6 +1685,20 @@ static int launch_conv(ConvP& p, int mode, int naive, int flags, void* ws, size_
   p.tilesM = (p.M + c.bm - 1) / c.bm;
   p.tilesN = (p.Ncols + c.bn - 1) / c.bn;
   setup_stride_classes(p, c.bm, mode, flags);
+  if (pl.S > 1 && pl.in_launch) {
+    if (ws == nullptr || ws_bytes < plan_ws_bytes(pl, p.M, p.Ncols)) {
+      vs_set_error("conv: in-launch split-K workspace too small (%zu < %zu)", ws_bytes, plan_ws_bytes(pl, p.M, p.Ncols));
+      return VS_ERR_WORKSPACE;
+    }
+    if ((size_t)p.tilesM * p.tilesN * sizeof(int) > il_counter_bytes(p.M, p.Ncols)) {
+      vs_set_error("conv: in-launch split-K: %d x %d tiles exceed the counter block", p.tilesM, p.tilesN);
+      return VS_ERR_WORKSPACE;
+    }
+    p.splitK = pl.S;
+    p.sk_cnt = (int*)ws;
+    p.slab = (float*)((char*)ws + il_counter_bytes(p.M, p.Ncols));
+    return launch_cfg<128, 128, 2, 2>(p, mode, 2, st);
+  }
   if (pl.S > 1) {
     if (p.res_bits) {
       vs_set_error("conv: the split-K plan has no masked-residual epilogue");
@@ -1650,13 +1710,13 @@ static int launch_conv(ConvP& p, int mode, int naive, int flags, void* ws, size_
       return VS_ERR_WORKSPACE;
     }
     p.splitK = pl.S;
-    p.slab = (float*)ws;
+    p.slab = (float*)((char*)ws + il_counter_bytes(p.M, p.Ncols));  // (the head of the buffer holds the in-launch plan's counters)
     const int user_flags = p.flags;
     p.flags &= ~(VS_CONV_STATS | VS_CONV_AFFINE | VS_CONV_RESIDUAL | VS_CONV_RELU);
     const int rc = launch_cfg<128, 128, 2, 2>(p, mode, pl.ring, st);
     if (rc) return rc;
     hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((p.M + 63) / 64), dim3(256), 0, st,
-                       (const float*)ws, pl.S, p.y, p.scale, p.shift, p.res, p.stats, p.M, p.Ncols,
+                       (const float*)p.slab, pl.S, p.y, p.scale, p.shift, p.res, p.stats, p.M, p.Ncols,
                        p.y_ld, p.res_ld, user_flags);
     VS_CHECK_LAUNCH();
     return VS_OK;
@@ -1748,7 +1808,7 @@ extern "C" int vs_conv_stats_rows(const vs_conv_desc* d) {
   const ConvPlan pl = plan_conv(M, d->Cout, d->kT * d->kH * d->kW * d->Cin, d->kT * d->kH * d->kW,
                                 d->flags);
   if (pl.direct) return direct_blocks(M);
-  if (pl.S > 1) return (int)((M + 63) / 64);
+  if (pl.S > 1 && !pl.in_launch) return (int)((M + 63) / 64);
   return (int)((M + pl.tile.bm - 1) / pl.tile.bm);
 }
 
@@ -1797,7 +1857,7 @@ extern "C" int vs_conv_plan(const vs_conv_desc* d, int dgrad, int* out) {
   out[1] = pl.tile.bn;
   out[2] = (taps <= 31 && pl.tile.bn >= 32 && !pl.direct) ? pl.ring : 0;
   out[3] = pl.S;
-  out[4] = pl.direct ? 1 : 0;
+  out[4] = pl.direct ? 1 : (pl.S > 1 && pl.in_launch ? 5 : 0);  // 5: the tile kernel with the in-launch split-K sum
   return VS_OK;
 }
 
@@ -2062,7 +2122,7 @@ extern "C" int vs_conv_dgrad_bnstats_rows(const vs_conv_desc* d) {
     static const int on = [] { const char* e = getenv("VS_DIRECT_BNB"); return e ? atoi(e) : 0; }();
     return (on || (d->flags & VS_CONV_DIRECTBNB)) ? direct_blocks(p.M) : 0;
   }
-  if (pl.S > 1 || !bnb_tile(pl.tile.bm, pl.tile.bn) || p.kT * p.kH * p.kW > 31) return 0;
+  if ((pl.S > 1 && !pl.in_launch) || !bnb_tile(pl.tile.bm, pl.tile.bn) || p.kT * p.kH * p.kW > 31) return 0;
   p.tilesM = (p.M + pl.tile.bm - 1) / pl.tile.bm;
   setup_stride_classes(p, pl.tile.bm, mode, d->flags);
   return p.tilesM;

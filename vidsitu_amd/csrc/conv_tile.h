@@ -24,6 +24,9 @@ struct ConvP {
   unsigned x_bytes, w_bytes;  // extents for the buffer resources (FAST path)
   int splitK;                 // > 1: blocks (tile, s) write fp32 partial tiles to `slab`
   float* slab;                // [splitK][M][Ncols]
+  // In-launch split-K (ring launches): slab = [tile][splitK][fragment][256 threads] float4 partial accumulators and
+  // sk_cnt one arrival counter per tile (zero between launches: the last arriver clears it).  NULL: the slab plan.
+  int* sk_cnt;
   // MODE 2 (dgrad of a strided conv), stride classes: rows whose coordinate (r + pad) has the same
   // residues mod (sT, sH, sW) use the same subset of taps (dd == residue mod s); tiles never mix
   // classes, so a tile walks only ITS taps -- 9/4 instead of 9 for a 3x3 stride-(1,2,2) conv,
@@ -52,7 +55,6 @@ struct ConvP {
   const uint8_t* res_bits;
   int dense;  // pointwise, unit stride: row m is position m of the gathered tensor (no row decode)
   int nclips;  // M / (Rt * Rh * Rw)
-  int ff_min, ff_max;  // ring loop: fragment reads before the copy issue for ff_min <= k-steps <= ff_max
   // Order of the reduction (gathering launches with > 1 tap and Cg % 64 == 0): 0 = tap-major (k = tap * Cg + c, the
   // weights' own order), 1 = chunk-major (k-tile kt = 64-channel chunk kt / taps of tap kt % taps).  The taps of a
   // position re-read (nearly) the same activation rows: tap-major puts Cg / 64 k-tiles -- on the wide layers more

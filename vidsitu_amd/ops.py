@@ -145,7 +145,8 @@ def tile_flag(kind, M, ncols, K, k, s, force=None):
 
 
 def conv_fwd(x, w, k, s, p, out=None, scale=None, shift=None, residual=None, relu=False,
-             stats=False, naive=False, tile=None, dbg=0, splitk=False, ring=0, halo=True, pw=True, deep=True):
+             stats=False, naive=False, tile=None, dbg=0, splitk=False, ring=0, halo=True, pw=True, deep=True,
+             splitk_il=None):
     """y = conv3d(x, w) [*scale+shift] [+residual] [relu]; optional BN-stat partials.
     Returns (y, partials|None)."""
     cout = w.shape[0]
@@ -186,6 +187,8 @@ def conv_fwd(x, w, k, s, p, out=None, scale=None, shift=None, residual=None, rel
         flags |= 1 << 27  # VS_CONV_NODEEP
     elif deep == "force":
         flags |= 1 << 28  # VS_CONV_FORCEDEEP
+    if splitk_il is not None:  # in-launch split-K: "force" / True = wherever eligible, False = never, None = the plan
+        flags |= (1 << 29) if splitk_il else (1 << 30)  # VS_CONV_SPLITK_IL / VS_CONV_NOSPLITK_IL
     d = make_desc(x.shape, act_ld(x), ys, act_ld(out), k, s, p, flags,
                   act_ld(residual) if residual is not None else 0)
     partials = None
@@ -193,7 +196,7 @@ def conv_fwd(x, w, k, s, p, out=None, scale=None, shift=None, residual=None, rel
         rows = _lib.load().vs_conv_stats_rows(C.byref(d))
         partials = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
     need = _lib.load().vs_conv_workspace_bytes(C.byref(d), 0)
-    ws = _workspace(need, x.device) if need else None
+    ws = _workspace(need, x.device, "splitk") if need else None
     _lib.call("vs_conv_fwd", _ptr(x), _ptr(w), _ptr(out), C.byref(d), _ptr(scale), _ptr(shift),
               _ptr(residual), _ptr(partials), _ptr(ws),
               C.c_size_t(ws.numel() if ws is not None else 0), _stream())
@@ -382,7 +385,7 @@ def transpose_f32_batched(src, dst, table, total, tiled=True):
 
 def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=None, ring=0,
                noclass=False, bn_stats=None, residual_bits=None, inplace=False, halo=True, pw=True,
-               direct_bnb=False, bn_stats2=None, deep=True):
+               direct_bnb=False, bn_stats2=None, deep=True, splitk_il=None):
     """dx[xs] = conv_transpose(dy, w) (+ residual).  wt from weight_transpose.
     bn_stats = (y, mean, invstd, gamma, beta[, relu_bits]) of the BatchNorm + ReLU unit whose output this
     convolution consumed and whose complete dz this dx is: returns (dx, partial) with partial [rows, 2, Cin]
@@ -418,6 +421,8 @@ def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=N
         flags |= 1 << 27  # VS_CONV_NODEEP
     elif deep == "force":
         flags |= 1 << 28  # VS_CONV_FORCEDEEP
+    if splitk_il is not None:
+        flags |= (1 << 29) if splitk_il else (1 << 30)  # VS_CONV_SPLITK_IL / VS_CONV_NOSPLITK_IL
     two = bn_stats2 is not None and bn_stats is not None and residual is not None and tuple(s) == (1, 1, 1)
     if two:
         flags |= 1 << 26  # VS_CONV_BNB2
@@ -428,7 +433,7 @@ def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=N
                 or residual_bits.dtype != torch.uint8:
             raise _lib.VsError("residual_bits must be uint8 [rows, Cin / 8] beside a residual")
     need = _lib.load().vs_conv_workspace_bytes(C.byref(d), 1)
-    ws = _workspace(need, dy.device) if need else None
+    ws = _workspace(need, dy.device, "splitk") if need else None
     want_sums = bn_stats is not None
     ep = _lib.DgradEpilogue()
     ep.residual = residual.data_ptr() if residual is not None else None
@@ -492,7 +497,10 @@ def _workspace(nbytes, device, kind="scratch"):
     key = (device.index, torch.cuda.current_stream().cuda_stream, kind)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        # "splitk" (vs_conv_fwd / vs_conv_dgrad): the head of the buffer holds the arrival counters of the in-launch
+        # split-K plan -- zero before the first launch, left at zero by every launch, written by nobody else
+        alloc = torch.zeros if kind == "splitk" else torch.empty
+        ws = alloc(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = ws
     return ws
 
