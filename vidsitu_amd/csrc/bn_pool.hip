@@ -1021,7 +1021,7 @@ extern "C" int vs_bn_bwd_finalize(const float* partial, int nparts, float* dgamm
   VsPendingReduce pr;
   const int g1 = (C + 31) / 32;
   if (vs_pending_reduce_take((hipStream_t)stream, &pr)) {
-    const long long rb = (pr.n / 4 + 15) / 16;  // 256-thread virtual blocks of the reduce
+    const long long rb = wgrad_reduce_vblocks(pr.n, pr.S);  // 256-thread virtual blocks of the reduce
     hipLaunchKernelGGL(bn_bwd_finalize_wgrad_reduce_kernel, dim3((unsigned)(g1 + (rb + 3) / 4)), dim3(1024), 0,
                        (hipStream_t)stream, partial, nparts, dgamma, dbeta, C, g1, pr.slabs, pr.dw, pr.n, pr.S);
   } else {

@@ -150,7 +150,7 @@ extern "C" int vs_conv_pair_end(void) {
     }
   }
   if (s.have_r && !pending_stash(s.slabs, s.dw, s.n, s.splits, s.st)) {
-    const long long grid = (s.n / 4 + 15) / 16;
+    const long long grid = wgrad_reduce_vblocks(s.n, s.splits);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, s.st, s.slabs, s.dw, s.n, s.splits);
   }
   hipError_t e = hipGetLastError();

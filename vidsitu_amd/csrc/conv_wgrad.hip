@@ -795,7 +795,7 @@ struct PendingState {
 thread_local PendingState g_pending;
 
 static void pending_launch(const VsPendingReduce& r) {
-  const long long grid = (r.n / 4 + 15) / 16;
+  const long long grid = wgrad_reduce_vblocks(r.n, r.S);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, r.st, r.slabs, r.dw, r.n, r.S);
 }
 }  // namespace
@@ -910,8 +910,8 @@ extern "C" int64_t vs_wgrad_reduce_blocks(int64_t n) { return (n / 4 + 15) / 16;
 
 extern "C" int vs_wgrad_reduce(const float* slabs, float* dw, int64_t n, int splits, void* stream) {
   VS_CHECK_ARG(slabs && dw && n > 0 && splits > 1, "bad args");
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, (hipStream_t)stream, slabs,
-                     dw, (long long)n, splits);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)wgrad_reduce_vblocks(n, splits)), dim3(256), 0, (hipStream_t)stream,
+                     slabs, dw, (long long)n, splits);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }
@@ -1259,7 +1259,7 @@ static int wgrad_impl(const void* dy, const void* x, float* dw, const vs_conv_de
   if (splits_out) *splits_out = c.S;
   if (c.S > 1 && reduce_now) {
     const long long n = (long long)d->Cout * p.Kp;
-    const long long grid = (n / 4 + 15) / 16;
+    const long long grid = wgrad_reduce_vblocks(n, c.S);
     if (!pair_defer_reduce((const float*)workspace, dw, n, c.S) &&
         !pending_stash((const float*)workspace, dw, n, c.S, st)) {
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, st,
