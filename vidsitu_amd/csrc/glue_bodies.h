@@ -5,44 +5,64 @@
 #pragma once
 #include "common.h"
 
-// Virtual 256-thread blocks of the reduce below (every launch site sizes its grid with this).
+// The reduce below has two thread mappings with the SAME arithmetic; this picks one (host and device agree through it).
+// Column form: one thread per float4 column walks all S slabs -- whole 4-KiB rows per wave, no LDS.  It needs columns
+// to spread over the chip, so: every split of <= 16 (each convolution layer of the slow pathway) and splits up to 64
+// whose dW has >= 32 768 float4 columns (slow s4's c layers: S = 22, 23 MB of slabs).
+__host__ __device__ __forceinline__ bool wgrad_reduce_cols(long long n, int S) {
+  return S <= 16 || (S <= 64 && (n >> 2) >= 32768);
+}
+// Virtual 256-thread blocks of the reduce (every launch site sizes its grid with this).
 static inline long long wgrad_reduce_vblocks(long long n, int S) {
   const long long n4 = n >> 2;
-  return S <= 16 ? (n4 + 255) / 256 : (n4 + 15) / 16;
+  return wgrad_reduce_cols(n, S) ? (n4 + 255) / 256 : (n4 + 15) / 16;
 }
 
-// dw[i] = sum_s slab[s][i], bitwise reproducible: a (virtual) 256-thread block = 16 float4 columns x 16 slab slices,
-// each slice summed in order, the 16 slice sums combined in order through LDS.  t: thread within the virtual block.
-// S <= 16 (every convolution layer's position split; only the stems split deeper): one slab per slice, so the sum is
-// ((0 + s0) + (0 + s1)) + ... -- formed by ONE thread per float4 column, 256 columns per virtual block, all S loads in
-// flight, no LDS: the same additions in the same order (bit for bit the slice form, signs of zero included), at 16
-// times the bytes per block.  (Round 4: the slice form left 256 - 16 S threads of a block idle and fetched 256 bytes
-// per slab per block: 99 launches per step at 1.5 TB/s.)
+// dw[i] = sum_s slab[s][i], bitwise reproducible.  The sum is defined by the slice form: 16 slices of per = ceil(S / 16)
+// consecutive slabs, each slice summed in order starting from +0.0, the 16 slice sums added in order.
+//   slice form  (few columns, many slabs: the fast pathway's S = 79 .. 349 over 1 .. 12 K floats): a (virtual) 256-thread
+//               block = 16 float4 columns x 16 slices, combined through LDS; a slice's loads go out 16 at a time, the
+//               tail predicated (round 4: the tail was a loop of up to 7 dependent load -> add round trips);
+//   column form (wgrad_reduce_cols): one thread forms the 16 slice sums of its column one after the other and adds
+//               them -- the same additions in the same order, signs of zero included (the batched slice-form kernel of
+//               conv_wgrad.hip is the tests' bitwise reference), 16 loads in flight, no LDS, no barrier.
+// Round 4, measured: the slice form at S <= 22 left most of a block idle and moved 256 bytes per slab per block --
+// 99 launches per step at 1.5 TB/s, the largest in-situ kernel time of the train step.
+// t: thread within the virtual block.
 __device__ __forceinline__ void wgrad_reduce_body(const float* slabs, float* dw, long long n, int S, float4 (*part)[17],
                                                   long long vb, int t) {
   const long long n4 = n >> 2;
-  if (S <= 16) {
+  const int per = (S + 15) / 16;
+  if (wgrad_reduce_cols(n, S)) {
     const long long i = vb * 256 + t;
     if (i >= n4) return;
     const float* src = slabs + i * 4;
-    float4 v[16];
+    float4 tt = make_float4(0.f, 0.f, 0.f, 0.f), acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool have = false;  // tt holds the sum of the finished slices
+    int left = per;     // slabs the current slice still takes
+    for (int s0 = 0; s0 < S; s0 += 16) {
+      float4 v[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u)
-      if (u < S) v[u] = *(const float4*)(src + (long long)u * n);
-    float4 tt = make_float4(0.f + v[0].x, 0.f + v[0].y, 0.f + v[0].z, 0.f + v[0].w);
+      for (int u = 0; u < 16; ++u)
+        if (s0 + u < S) v[u] = *(const float4*)(src + (long long)(s0 + u) * n);
 #pragma unroll
-    for (int u = 1; u < 16; ++u)
-      if (u < S) {
-        tt.x += 0.f + v[u].x;
-        tt.y += 0.f + v[u].y;
-        tt.z += 0.f + v[u].z;
-        tt.w += 0.f + v[u].w;
-      }
-    if (S < 16) {  // the slice form adds the empty slices' +0.0 (turns a -0.0 sum into +0.0)
-      tt.x += 0.f;
-      tt.y += 0.f;
-      tt.z += 0.f;
-      tt.w += 0.f;
+      for (int u = 0; u < 16; ++u)
+        if (s0 + u < S) {
+          if (left == 0) {  // the previous slice is complete
+            if (have) { tt.x += acc.x; tt.y += acc.y; tt.z += acc.z; tt.w += acc.w; }
+            else tt = acc;
+            have = true;
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            left = per;
+          }
+          acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+          --left;
+        }
+    }
+    if (have) { tt.x += acc.x; tt.y += acc.y; tt.z += acc.z; tt.w += acc.w; }
+    else tt = acc;
+    if ((S + per - 1) / per < 16) {  // the slice form adds the empty slices' +0.0 (turns a -0.0 sum into +0.0)
+      tt.x += 0.f; tt.y += 0.f; tt.z += 0.f; tt.w += 0.f;
     }
     *(float4*)(dw + i * 4) = tt;
     return;
@@ -51,29 +71,23 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* slabs, float* dw,
   const long long i = vb * 16 + col;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < n4) {
-    const int per = (S + 15) / 16;
     const int s0 = sl * per, s1 = min(S, s0 + per);
-    // 8 slab rows in flight per thread (a one-load-at-a-time loop is a chain of memory
-    // latencies: 20 us for S = 1024); the sum order stays s0, s0+1, ...
-    int s = s0;
-    for (; s + 8 <= s1; s += 8) {
-      float4 v[8];
+    const float* src = slabs + i * 4;
+    for (int s = s0; s < s1; s += 16) {
+      float4 v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(slabs + (long long)(s + u) * n + i * 4);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        acc.x += v[u].x;
-        acc.y += v[u].y;
-        acc.z += v[u].z;
-        acc.w += v[u].w;
+      for (int u = 0; u < 16; ++u) {  // branch-free: a clamped address, the value dropped below
+        const int su = min(s + u, s1 - 1);
+        v[u] = *(const float4*)(src + (long long)su * n);
       }
-    }
-    for (; s < s1; ++s) {
-      const float4 v = *(const float4*)(slabs + (long long)s * n + i * 4);
-      acc.x += v.x;
-      acc.y += v.y;
-      acc.z += v.z;
-      acc.w += v.w;
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (s + u < s1) {
+          acc.x += v[u].x;
+          acc.y += v[u].y;
+          acc.z += v[u].z;
+          acc.w += v[u].w;
+        }
     }
   }
   part[sl][col] = acc;
