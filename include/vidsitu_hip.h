@@ -299,18 +299,6 @@ int vs_bn_apply(const void* y, const float* scale, const float* shift, const voi
 int vs_bn_apply_mask(const void* y, const float* scale, const float* shift, const void* residual,
                      void* out, uint8_t* relu_bits, int64_t rows, int C, int y_ld, int res_ld,
                      int out_ld, void* stream);
-/* vs_bn_finalize + vs_bn_apply / vs_bn_apply_mask as ONE launch (round 3): the apply kernel is tiled over (column
- * group of <= 64 channels) x (row slab) and every block reduces the partial rows of its own column group in its
- * prologue -- same slices, same fp64 order, same closing arithmetic as vs_bn_finalize, so bitwise its scale / shift;
- * the blocks of row slab 0 store mean / invstd (for the backward) and update the running statistics.  For at most
- * 256 partial rows and C/8 a power of two (vs_bn_fin_fusable; layers with thousands of rows run
- * vs_bn_partials_reduce first and pass its 32 rows).  relu_bits may be NULL.  Replaces the train-mode forward of
- * slowfast's BatchNorm3d (+ residual add + ReLU) inside BottleneckTransform / ResBlock (mdl_sf_base.py:21-34). */
-int vs_bn_fin_fusable(int nparts, int C);
-int vs_bn_apply_fin(const float* partials, int nparts, double count, const float* gamma, const float* beta,
-                    float* running_mean, float* running_var, float momentum, float eps, float* mean,
-                    float* invstd, const void* y, const void* residual, void* out, uint8_t* relu_bits,
-                    int64_t rows, int C, int y_ld, int res_ld, int out_ld, int relu, void* stream);
 /* Backward of z = relu?(bn(y) (+res)):  g = dz * [z>0];
  *   pass 1 (reduce): partial[blk][2][C] = (sum g, sum g*xhat), xhat=(y-mean)*invstd
  *   pass 2 (apply):  dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M); dres = g. */
@@ -327,13 +315,6 @@ int vs_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* m
                     const float* dgamma, const float* dbeta, void* dy, void* dres, int64_t rows,
                     int C, int dz_ld, int z_ld, int y_ld, int dy_ld, int dres_ld, int relu,
                     void* stream);
-/* vs_bn_bwd_finalize + vs_bn_bwd_apply as ONE launch (see vs_bn_apply_fin): dgamma / dbeta come out of the kernel's
- * prologue (bitwise vs_bn_bwd_finalize) and are stored by the blocks of row slab 0.  `partial` = the rows of
- * vs_bn_bwd_reduce or of a dgrad epilogue (vs_conv_dgrad_bnstats / vs_conv_dgrad_ex); vs_bn_fin_fusable(nparts, C). */
-int vs_bn_bwd_apply_fin(const float* partial, int nparts, const void* dz, const void* z, const void* y,
-                        const float* mean, const float* invstd, const float* gamma, const float* beta,
-                        float* dgamma, float* dbeta, void* dy, void* dres, int64_t rows, int C, int dz_ld,
-                        int z_ld, int y_ld, int dy_ld, int dres_ld, int relu, void* stream);
 
 /* fp32 residual stream of a stage (eval mode, optional): out32 = relu?(residual + branch), out16 = bf16(out32),
  * rows of C channels.  `branch` = the bottleneck's last unit with its BatchNorm folded (bf16, no residual, no
@@ -417,41 +398,6 @@ int vs_linear_bwd_fused_res(const float* dy, const float* relu_y, const float* x
 int vs_conv_pair_begin(void);
 int vs_conv_pair_end(void);
 int64_t vs_conv_pair_count(void);
-
-/* A chain of few-row stages behind ONE launch (utils/transformer_code.py:215-250: the EncoderLayer stack on the
- * 8 event tokens of a rank; forward = 7 stages per layer, backward = 7).  `stages`: device array of
- *   struct { int64 op, M, N, K, ia, ib; const void* p[10]; }           (128 bytes per stage)
- * op 1 LIN      y = act(x . w^T + b) (+ res): p = x, w, b, res, y; ia = act (vs_gemm_nt_f32_res codes); M <= 8
- *    2 LINBWD   vs_linear_bwd_fused: p = dy, relu_y, x, wt, dx (null: no dx), dw, db; ia = weight-gradient blocks
- *    3 ATTN_FWD vs_attn_small_fwd on a fused [rows, 3 D] q|k|v buffer: p = qkv, o, probs, drop_mask;
- *               M = B, N = H, K = dh, ia = L, ib = float bits of 1 / scale
- *    4 ATTN_BWD vs_attn_small_bwd: p = qkv, dout, probs, drop_mask, dqkv (same fields)
- *    5 LN_FWD   vs_add_layernorm_fwd: p = x, r, rmask, gamma, beta, y, mean, rstd; M rows, N = D, ib = eps bits
- *    6 LN_BWD   vs_add_layernorm_bwd with the output gradient given as dy (+ dy2): p = dy, dy2, x, r, rmask,
- *               gamma, mean, rstd, dx, dr; ia / ib = dgamma / dbeta pointers; M <= 16 rows
- *    7 ADD      y = a + b: p = a, b, y; N = number of float4s
- * Every stage runs the body of the stand-alone kernel over virtual blocks (bitwise the launches it replaces);
- * between stages the persistent grid (`grid` blocks of 256 threads, <= one per CU so that all are resident)
- * meets at a barrier.  `barriers`: nstages * 129 + 16 uint32 words; word [nstages] is an error flag the kernel sets if
- * a barrier wait exceeds its iteration cap (the blocks then leave instead of hanging the GPU).
- * `smem_bytes`: dynamic LDS = 32 bytes x the widest inner dimension of a LIN / LINBWD stage (>= 8320). */
-int vs_txenc_stack_run(const void* stages, int nstages, void* barriers, int grid, int smem_bytes, void* stream);
-/* LayerNorm in the prologue of the linear that consumes it (<= 8 rows, D <= 1024): utils/transformer_code.py
- * ResidualBlock.forward's `self.layernorm(x[0] + self.dropout(self.layer(*x)))` followed by the next block's first
- * nn.Linear (FeedForward.linear1 / the fused q|k|v projection) as ONE launch, and in the backward the LayerNorm's
- * backward followed by the backward of the linear whose output gradient it produces (FeedForward.linear2 /
- * MultiHead.wo).  Same bodies as vs_add_layernorm_fwd / _bwd and vs_linear_fwd / vs_linear_bwd_fused: same bits.
- *   fwd: y_ln [M][K] = LayerNorm(x + r * rmask) (stored with mean / rstd [M]); y [M][N] = act(y_ln . w^T + b)
- *   bwd: dx_ln [M][D], dgamma / dbeta [D] of the LayerNorm for the output gradient dy; dr = dx_ln * rmask is the
- *        output gradient of the linear x_lin [M][K] -> [M][D] (wt: its [D][K]... weight image as vs_linear_bwd_fused
- *        takes it): dx_lin [M][K], dw [D][K], db [D] (or NULL). */
-int vs_ln_linear_fwd(const float* x, const float* r, const float* rmask, const float* gamma, const float* beta,
-                     float eps, float* y_ln, float* mean, float* rstd, const float* w, const float* b, float* y,
-                     int M, int N, int K, int relu, void* stream);
-int vs_ln_bwd_linear_bwd(const float* dy, const float* x_ln, const float* r, const float* rmask, const float* gamma,
-                         const float* mean, const float* rstd, float* dx_ln, float* dgamma, float* dbeta,
-                         const float* x_lin, const float* wt, float* dx_lin, float* dw, float* db, int M, int D,
-                         int K, void* stream);
 
 /* softmax(Q_h K_h^T / scale) V_h for short sequences (L <= 16), per head.
  * q,k,v,o: [B, L, H*dh] fp32.  utils/transformer_code.py:33-48,60-68 --

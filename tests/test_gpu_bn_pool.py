@@ -233,129 +233,3 @@ def test_stem_bn_relu_maxpool_in_one_pass_is_bitwise_the_three_launches(c, n, t,
     dy_ref, _, dg_ref, db_ref = ops.bn_bwd(dz, None, y, mean, invstd, gamma, True, False, beta=beta)
     dy, _, dg, db = ops.bn_bwd(None, None, y, mean, invstd, gamma, True, False, beta=beta, pool_src=(dp, i_ref))
     assert torch.equal(dy, dy_ref) and torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
-
-
-class _BN:
-    """The attributes ops.bn_apply_fin reads of a trunk.BN3dP."""
-
-    def __init__(self, gamma, beta, rm, rv, momentum=0.1, eps=1e-5):
-        self.weight, self.bias, self.running_mean, self.running_var = gamma, beta, rm, rv
-        self.momentum, self.eps = momentum, eps
-
-
-@pytest.mark.parametrize("c,rows,nparts,relu,res,bits", [
-    (8, 5000, 40, True, False, False),       # one thread column, 256 row lanes
-    (32, 3136, 196, True, False, False),
-    (64, 12544, 196, True, True, True),      # exactly one 64-channel column group
-    (256, 12544, 98, True, False, False),
-    (512, 3136, 49, False, False, False),    # shortcut unit: no ReLU
-    (2048, 3136, 25, True, True, True),      # 32 column groups
-    (256, 50176, 1568, True, True, True),    # thousands of rows: level-1 reduce to 32, then the fused pass
-    (128, 777, 256, True, False, False),     # the last fusable row count, ragged rows
-])
-def test_apply_that_finalizes_for_itself_is_bitwise_the_two_launches(c, rows, nparts, relu, res, bits, dev, monkeypatch):
-    """vs_bn_apply_fin (round 3: the apply pass reduces the partial rows of its column group in its prologue) against
-    vs_bn_finalize (+ vs_bn_partials_reduce) + vs_bn_apply / vs_bn_apply_mask: output, ReLU bits, saved mean / invstd
-    and the updated running statistics bit for bit."""
-    from vidsitu_amd import ops
-
-    monkeypatch.setattr(ops, "BN_FIN_FUSE", True)  # opt-in path (measured slower in the step: profiles/r03_bn_fin_fuse.txt)
-    g = torch.Generator().manual_seed(c + rows + nparts)
-    y = ops.new_act(1, c, 1, 1, rows, dev)
-    y.copy_((torch.randn(1, c, 1, 1, rows, generator=g) * 1.7 + 0.4).to(dev))
-    r = None
-    if res:
-        r = ops.new_act(1, c, 1, 1, rows, dev)
-        r.copy_(torch.randn(1, c, 1, 1, rows, generator=g).to(dev))
-    # partial rows whose totals are the tensor's true sums (any split works for the comparison; uneven magnitudes
-    # make the summation order matter)
-    yf = y.float().permute(0, 2, 3, 4, 1).reshape(rows, c)
-    cut = torch.linspace(0, rows, nparts + 1).long().tolist()
-    partials = torch.stack([torch.stack([yf[a:b].sum(0), (yf[a:b] ** 2).sum(0)]) for a, b in zip(cut, cut[1:])])
-    partials = partials.contiguous()
-    gamma = (torch.rand(c, generator=g) + 0.5).to(dev)
-    beta = (torch.randn(c, generator=g) * 0.2).to(dev)
-    rm0, rv0 = (torch.randn(c, generator=g) * 0.1).to(dev), (torch.rand(c, generator=g) + 0.5).to(dev)
-
-    rm_a, rv_a = rm0.clone(), rv0.clone()
-    scale, shift, mean_a, invstd_a = ops.bn_finalize(partials, rows, gamma, beta, rm_a, rv_a, 0.1, 1e-5, train=True)
-    if bits:
-        z_a, bits_a = ops.bn_apply(y, scale, shift, r, relu, want_bits=True)
-    else:
-        z_a, bits_a = ops.bn_apply(y, scale, shift, r, relu), None
-
-    assert ops.bn_fin_fusable(nparts, c)
-    bn = _BN(gamma, beta, rm0.clone(), rv0.clone())
-    z_b, bits_b, mean_b, invstd_b = ops.bn_apply_fin(partials, rows, bn, y, r, relu, want_bits=bits)
-    torch.cuda.synchronize()
-    assert torch.equal(mean_a, mean_b) and torch.equal(invstd_a, invstd_b)
-    assert torch.equal(rm_a, bn.running_mean) and torch.equal(rv_a, bn.running_var)
-    assert torch.equal(z_a.view(torch.int16), z_b.view(torch.int16))
-    if bits:
-        assert torch.equal(bits_a, bits_b)
-    # and the statistics are the tensor's
-    assert_close(mean_b, yf.mean(0), 1e-5, "mean")
-
-
-def test_fin_fusable_row_counts(monkeypatch):
-    from vidsitu_amd import ops
-
-    assert not ops.bn_fin_fusable(64, 64) or ops.BN_FIN_FUSE  # off unless VS_BN_FIN_FUSE=1
-    monkeypatch.setattr(ops, "BN_FIN_FUSE", True)
-    assert ops.bn_fin_fusable(1, 64) and ops.bn_fin_fusable(256, 64) and ops.bn_fin_fusable(3136, 64)
-    assert not ops.bn_fin_fusable(257, 64) and not ops.bn_fin_fusable(512, 64)  # the separate finalize launch stays
-    assert not ops.bn_fin_fusable(100, 24)  # C/8 not a power of two
-
-
-@pytest.mark.parametrize("c,rows,mode,dres", [
-    (8, 6000, "recompute", False), (64, 12544, "bits", False), (256, 3136, "z", True),
-    (512, 3136, "none", False), (2048, 1000, "bits", False), (32, 50176, "recompute", False),
-])
-def test_backward_apply_that_finalizes_for_itself_is_bitwise_the_two_launches(c, rows, mode, dres, dev, monkeypatch):
-    """vs_bn_bwd_apply_fin against vs_bn_bwd_finalize + vs_bn_bwd_apply on the same partial rows (those of
-    vs_bn_bwd_reduce): dy, dres, dgamma, dbeta bit for bit, every ReLU-mask source."""
-    from vidsitu_amd import ops
-
-    g = torch.Generator().manual_seed(c * 3 + rows)
-    def act(scale=1.0, shift=0.0):
-        a = ops.new_act(1, c, 1, 1, rows, dev)
-        a.copy_((torch.randn(1, c, 1, 1, rows, generator=g) * scale + shift).to(dev))
-        return a
-    y, dz = act(1.5, 0.3), act()
-    yf = y.float().permute(0, 2, 3, 4, 1).reshape(rows, c)
-    mean = yf.mean(0).contiguous()
-    invstd = (1.0 / torch.sqrt(yf.var(0, unbiased=False) + 1e-5)).contiguous()
-    gamma = (torch.rand(c, generator=g) + 0.5).to(dev)
-    beta = (torch.randn(c, generator=g) * 0.2).to(dev)
-    relu = mode != "none"
-    z = zbits = None
-    if mode in ("z", "bits"):
-        res = act()
-        z, zbits = ops.bn_apply(y, gamma * invstd, beta - mean * gamma * invstd, res, True, want_bits=True)
-        if mode == "z":
-            zbits = None
-        else:
-            z = None
-
-    def run(fuse):
-        monkeypatch.setattr(ops, "BN_FIN_FUSE", fuse)
-        dgam, dbet = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
-        dy, dr, _, _ = ops.bn_bwd(dz, z, y, mean, invstd, gamma, relu, dres, dgamma=dgam, dbeta=dbet,
-                                  beta=beta if mode == "recompute" else None, zbits=zbits)
-        torch.cuda.synchronize()
-        return dy, dr, dgam, dbet
-
-    nblk = ops._lib.load().vs_bn_bwd_reduce_rows(rows, c)
-    a, b = run(False), run(True)
-    if nblk <= 256:  # else both runs took the separate launches: still equal, nothing fused to compare
-        n0 = ops._lib.load().vs_launch_count()
-        run(True)
-        n_f = ops._lib.load().vs_launch_count() - n0
-        n0 = ops._lib.load().vs_launch_count()
-        run(False)
-        assert ops._lib.load().vs_launch_count() - n0 == n_f + 1, "the fused run should be one launch shorter"
-    assert torch.equal(a[0].view(torch.int16), b[0].view(torch.int16))
-    if dres:
-        assert torch.equal(a[1].view(torch.int16), b[1].view(torch.int16))
-    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
-    assert float(a[2].abs().max()) > 0

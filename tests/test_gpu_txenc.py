@@ -263,52 +263,6 @@ def test_adam_with_fused_bf16_cast_and_arena_refresh(dev):
     assert torch.equal(bf.view(torch.int16), ref_bf.view(torch.int16)) and int(tb) == 3
 
 
-@pytest.mark.parametrize("layers,b,l,drop", [(2, 2, 4, 0.1), (6, 2, 4, 0.1), (3, 1, 5, 0.0), (2, 1, 8, 0.1)])
-def test_encoder_stack_in_one_launch_is_bitwise_the_per_op_path(layers, b, l, drop, dev, monkeypatch):
-    """`EncoderStackFn` (all layers' forward behind one `vs_txenc_stack_run` launch, the backward behind another) runs
-    the bodies of the per-op kernels over virtual blocks: output, every layer output, input gradient and every
-    parameter gradient are bit for bit those of the per-op autograd path, with the same dropout masks."""
-    from vidsitu_amd import transformer_code as T
-    from vidsitu_amd.optim import ParamArena
-
-    d = 1024
-    torch.manual_seed(3)
-    mdl = T.Transformer(d_model=d, n_vocab_src=0, vocab_trg=0, d_hidden=d, n_layers=layers, n_heads=8,
-                        drop_ratio=drop, pe=False).to(dev).train()
-    arena = ParamArena(mdl)
-    x0 = torch.randn(b, l, d, device=dev)
-    dy = torch.randn(b, l, d, device=dev)
-
-    def run(stack):
-        monkeypatch.setenv("VS_TXENC_STACK", "1" if stack else "0")
-        used = []
-        orig = T.EncoderStackFn.forward
-        monkeypatch.setattr(T.EncoderStackFn, "forward", staticmethod(lambda ctx, x, enc: (used.append(1), orig(ctx, x, enc))[1]))
-        arena.grad.fill_(float("nan"))
-        for off, nxt, p in zip(arena.offsets, arena.offsets[1:], arena.params):
-            arena.grad[off + p.numel():nxt].zero_()
-        torch.manual_seed(11)
-        T._masks.__init__()  # same mask plan state on both sides
-        x = x0.clone().requires_grad_()
-        outs = mdl.encoder(x)
-        outs[-1].backward(dy)
-        torch.cuda.synchronize()
-        monkeypatch.setattr(T.EncoderStackFn, "forward", orig)
-        assert bool(used) == stack
-        return [o.detach().clone() for o in outs[1:]], x.grad.clone(), arena.grad.clone()
-
-    o0, dx0, g0 = run(False)
-    o1, dx1, g1 = run(True)
-    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
-    for i, (a, c) in enumerate(zip(o0, o1)):
-        assert torch.equal(a, c), f"layer {i} output: max diff {float((a - c).abs().max()):.3e}"
-    bad = [f"{k} ({float((g0[off:off + p.numel()] - g1[off:off + p.numel()]).abs().max()):.1e})"
-           for (k, p), off in zip(mdl.named_parameters(), arena.offsets)
-           if not torch.equal(g0[off:off + p.numel()], g1[off:off + p.numel()])]
-    assert not bad, f"parameter gradients differ: {bad}"
-    assert torch.equal(dx0, dx1), f"dx: max diff {float((dx0 - dx1).abs().max()):.3e}"
-
-
 @pytest.mark.parametrize("arena_on", [True, False], ids=["arena", "loose"])
 def test_residual_gradient_joins_in_the_linear_epilogue_bitwise(arena_on, dev, monkeypatch):
     """`ResidualBlock.route_grads`: the LayerNorm's dx reaches the wrapped layer's first op through a side channel and
@@ -325,7 +279,6 @@ def test_residual_gradient_joins_in_the_linear_epilogue_bitwise(arena_on, dev, m
     if arena_on:
         ParamArena(mdl)
     x0, dy = torch.randn(b, l, d, device=dev), torch.randn(b, l, d, device=dev)
-    monkeypatch.setenv("VS_TXENC_STACK", "0")
 
     def run(route):
         monkeypatch.setattr(T.ResidualBlock, "route_grads", route)
@@ -354,143 +307,3 @@ def test_residual_gradient_joins_in_the_linear_epilogue_bitwise(arena_on, dev, m
     assert not bad, bad
 
 
-def test_txstack_stage_kinds_are_bitwise_the_stand_alone_ops(dev):
-    """Every stage kind of `vs_txenc_stack_run` against the entry point whose body it runs, bit for bit -- alone and
-    chained (a stage reading what the stage before it wrote on other CUs / XCDs: the grid barrier's fences)."""
-    from vidsitu_amd import ops
-
-    torch.manual_seed(0)
-    rows, d, n3 = 8, 1024, 3072
-    f = dict(device=dev, dtype=torch.float32)
-    a, b2, x, r = (torch.randn(rows, d, **f) for _ in range(4))
-    rmask = F.dropout(torch.ones(rows, d, **f), 0.1, True)
-    gamma, beta = torch.randn(d, **f), torch.randn(d, **f)
-    w3 = torch.randn(n3, d, **f) * 0.02
-    wt3 = w3.t().contiguous()
-    bias = torch.randn(n3, **f)
-
-    def run(build):
-        st = ops.TxStack(dev)
-        outs = build(st)
-        st.run()
-        torch.cuda.synchronize()
-        assert not st.failed(), "a grid barrier gave up"
-        return outs
-
-    # forward kinds: linear (+bias, ReLU), add + LayerNorm, attention on a fused q|k|v buffer
-    y_ref = ops.linear_fwd(x, w3, bias, True)
-    ln_ref, mean, rstd = ops.add_layernorm_fwd(x, r, gamma, beta, 1e-5, rmask)
-    o_ref, p_ref = ops.attn_small_fwd_fused(y_ref, 2, 4, 8, 32.0, None)
-
-    def fwd(st):
-        y, ln = torch.empty(rows, n3, **f), torch.empty(rows, d, **f)
-        mu, rs = torch.empty(rows, **f), torch.empty(rows, **f)
-        o, p = torch.empty(rows, d, **f), torch.empty(2, 8, 4, 4, **f)
-        st.linear(x, w3, bias, y, act=1)
-        st.add_layernorm(x, r, rmask, gamma, beta, ln, mu, rs, 1e-5)
-        st.attn_fwd(y, o, p, None, 2, 4, 8, 32.0)  # reads the first stage's output
-        return y, ln, mu, rs, o, p
-    for name, got, ref in zip(("linear", "layernorm", "mean", "rstd", "attention", "probs"), run(fwd),
-                              (y_ref, ln_ref, mean, rstd, o_ref.reshape(rows, d), p_ref)):
-        assert torch.equal(got, ref), name
-
-    # backward kinds, chained: linear_bwd (inner dimension 3072) -> add + LayerNorm backward with two addends -> add
-    dyq = torch.randn(rows, n3, **f)
-    dx_ref, dw_ref, _ = ops.linear_bwd(dyq, x, w3, need_dx=True, has_bias=False, wt=wt3)
-    dxl, drl, dg_ref, db_ref = ops.add_layernorm_bwd(a + dx_ref, x, r, gamma, mean, rstd, rmask)
-    dq_ref = ops.attn_small_bwd_fused(y_ref, p_ref, a.reshape(2, 4, d), 2, 4, 8, 32.0, None)
-
-    def bwd(st):
-        dx, dw = torch.empty(rows, d, **f), torch.empty(n3, d, **f)
-        dx2, dr2, dg, db = torch.empty(rows, d, **f), torch.empty(rows, d, **f), torch.empty(d, **f), torch.empty(d, **f)
-        s, dq = torch.empty(rows, d, **f), torch.empty(rows, n3, **f)
-        st.linear_bwd(dyq, None, x, wt3, dx, dw, None)
-        st.add_layernorm_bwd(a, dx, x, r, rmask, gamma, mean, rstd, dx2, dr2, dg, db)
-        st.add(dx2, dr2, s)
-        st.attn_bwd(y_ref, a, p_ref, None, dq, 2, 4, 8, 32.0)
-        return dx, dw, dx2, dr2, dg, db, s, dq
-    refs = (dx_ref, dw_ref, dxl, drl, dg_ref, db_ref, dxl + drl, dq_ref)
-    for name, got, ref in zip(("dx", "dw", "ln dx", "ln dr", "dgamma", "dbeta", "add", "dqkv"), run(bwd), refs):
-        assert torch.equal(got, ref), name
-
-
-@pytest.mark.parametrize("layers,b,l,drop,d", [(2, 2, 4, 0.1, 512), (6, 2, 4, 0.1, 512), (3, 1, 5, 0.0, 1024),
-                                               (2, 1, 8, 0.1, 256)])
-def test_layernorm_in_the_prologue_of_its_consumer_is_bitwise_the_separate_launches(layers, b, l, drop, d, dev,
-                                                                                      monkeypatch):
-    """`_Lazy` (round 3): a LayerNorm's forward runs in the prologue of the linear that consumes it (vs_ln_linear_fwd) and
-    its backward in front of the backward of the linear whose output gradient it produces (vs_ln_bwd_linear_bwd) --
-    every layer output, the input gradient and every parameter gradient bit for bit those of the separate launches,
-    and the fused launches actually happen: 2 per layer forward (the last LayerNorm has no consumer in the encoder),
-    2 per layer backward."""
-    from vidsitu_amd import transformer_code as T
-    from vidsitu_amd.optim import ParamArena
-
-    torch.manual_seed(3)
-    mdl = T.Transformer(d_model=d, n_vocab_src=0, vocab_trg=0, d_hidden=2 * d, n_layers=layers, n_heads=8,
-                        drop_ratio=drop, pe=False).to(dev).train()
-    arena = ParamArena(mdl)
-    x0 = torch.randn(b, l, d, device=dev)
-    dy = torch.randn(b, l, d, device=dev)
-    monkeypatch.setenv("VS_TXENC_STACK", "0")
-
-    def run(fuse):
-        monkeypatch.setattr(T._Lazy, "enabled", fuse)
-        T._Lazy.fused[:] = [0, 0]
-        arena.grad.fill_(float("nan"))
-        for off, nxt, p in zip(arena.offsets, arena.offsets[1:], arena.params):
-            arena.grad[off + p.numel():nxt].zero_()
-        torch.manual_seed(11)
-        T._masks.__init__()
-        x = x0.clone().requires_grad_()
-        outs = mdl.encoder(x)
-        outs[-1].backward(dy)
-        torch.cuda.synchronize()
-        assert T._Lazy.fwd is None and T._Lazy.bwd is None
-        return [o.detach().clone() for o in outs[1:]], x.grad.clone(), arena.grad.clone(), list(T._Lazy.fused)
-
-    o0, dx0, g0, n0 = run(False)
-    o1, dx1, g1, n1 = run(True)
-    assert n0 == [0, 0] and n1 == [2 * layers - 1, 2 * layers], (n0, n1)
-    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
-    for i, (a, c) in enumerate(zip(o0, o1)):
-        assert torch.equal(a, c), f"layer {i} output: max diff {float((a - c).abs().max()):.3e}"
-    bad = [f"{k} ({float((g0[off:off + p.numel()] - g1[off:off + p.numel()]).abs().max()):.1e})"
-           for (k, p), off in zip(mdl.named_parameters(), arena.offsets)
-           if not torch.equal(g0[off:off + p.numel()], g1[off:off + p.numel()])]
-    assert not bad, f"parameter gradients differ: {bad}"
-    assert torch.equal(dx0, dx1), f"dx: max diff {float((dx0 - dx1).abs().max()):.3e}"
-
-
-def test_parked_layernorm_is_flushed_for_any_other_reader(dev, monkeypatch):
-    """Without a parameter arena (no in-place gradients, three separate q / k / v linears) the backward never parks and
-    the forward's parked LayerNorm is taken by the first of the three projections; an encoder used without gradients
-    does not park at all: same results as the separate launches."""
-    from vidsitu_amd import transformer_code as T
-
-    d, layers, b, l = 256, 2, 1, 6
-    torch.manual_seed(5)
-    mdl = T.Transformer(d_model=d, n_vocab_src=0, vocab_trg=0, d_hidden=512, n_layers=layers, n_heads=8,
-                        drop_ratio=0.0, pe=False).to(dev).train()
-    x0, dy = torch.randn(b, l, d, device=dev), torch.randn(b, l, d, device=dev)
-    monkeypatch.setenv("VS_TXENC_STACK", "0")
-
-    def run(fuse):
-        monkeypatch.setattr(T._Lazy, "enabled", fuse)
-        T._Lazy.fused[:] = [0, 0]
-        for p in mdl.parameters():
-            p.grad = None
-        x = x0.clone().requires_grad_()
-        out = mdl.encoder(x)[-1]
-        out.backward(dy)
-        with torch.no_grad():
-            out_ng = mdl.encoder(x0)[-1]
-        torch.cuda.synchronize()
-        return out.detach().clone(), out_ng.clone(), x.grad.clone(), [p.grad.clone() for p in mdl.parameters()], \
-            list(T._Lazy.fused)
-
-    o0, e0, dx0, g0, n0 = run(False)
-    o1, e1, dx1, g1, n1 = run(True)
-    assert n0 == [0, 0] and n1[0] == 2 * layers - 1 and n1[1] == 0, (n0, n1)
-    assert torch.equal(o0, o1) and torch.equal(e0, e1) and torch.equal(dx0, dx1)
-    assert all(torch.equal(a, c) for a, c in zip(g0, g1))

@@ -84,9 +84,6 @@ SIGNATURES = {
     "vs_bn_partials_reduce": (_i, [_p, _i, _p, _i, _i, _p]),
     "vs_bn_apply": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p]),
     "vs_bn_apply_mask": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _p]),
-    "vs_bn_fin_fusable": (_i, [_i, _i]),
-    "vs_bn_apply_fin": (_i, [_p, _i, _d, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p]),
-    "vs_bn_bwd_apply_fin": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _p]),
     "vs_bn_bwd_reduce": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p]),
     "vs_bn_bwd_reduce_rows": (_i, [_i64, _i]),
     "vs_bn_bwd_finalize": (_i, [_p, _i, _p, _p, _i, _p]),
@@ -109,9 +106,6 @@ SIGNATURES = {
     "vs_linear_bwd_data": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "vs_linear_bwd_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "vs_linear_bwd_fused": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
-    "vs_txenc_stack_run": (_i, [_p, _i, _p, _i, _i, _p]),
-    "vs_ln_linear_fwd": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "vs_ln_bwd_linear_bwd": (_i, [_p] * 15 + [_i, _i, _i, _p]),
     "vs_conv_pair_begin": (_i, []),
     "vs_conv_pair_end": (_i, []),
     "vs_conv_pair_count": (_i64, []),

@@ -469,226 +469,6 @@ extern "C" int vs_bn_apply_mask(const void* y, const float* scale, const float* 
 }
 
 // ----------------------------------------------------------------------------
-// Apply kernels that FINALIZE FOR THEMSELVES (round 3).  A train-mode unit used to be conv(+partials) -> finalize ->
-// apply and, backward, reduce -> finalize -> apply: the two finalize launches are 4-6 us kernels on a dependency
-// chain of ~1000 launches (110 + 110 per SlowFast-R50 step).  Here the apply kernel is tiled over (column group of
-// <= 64 channels) x (row slab) and every block reduces the partial rows of ITS column group in its prologue -- the
-// same 32 slices, the same fp64 order and the same closing arithmetic as the finalize kernels, so bitwise their
-// result; the blocks of row slab 0 store the per-channel outputs (mean / invstd / running statistics, or dgamma /
-// dbeta).  The redundancy is (row slabs) x (partial table) of L2-resident fp32 reads: the host plan caps it at twice
-// the tensor bytes the pass moves, and the fused form is only taken for <= BNF_MAXPARTS partial rows (layers with
-// thousands of rows run vs_bn_partials_reduce first: 32 rows).
-// ----------------------------------------------------------------------------
-#define BNF_MAXPARTS 256
-
-// (ts, tq) of channel c0 + t for the threads t < G (G = ncol * 8 <= 64 channels per block); LDS: 32 * G doubles.
-__device__ __forceinline__ void bnf_reduce_partials(const float* partials, int nparts, int C, int c0, int ncol,
-                                                    int col, int lane_r, double* sh, double& ts, double& tq) {
-  const int G = ncol * 8;
-  double s[8], q[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.0;
-  if (lane_r < 32) {
-    const float* base = partials + c0 + col * 8;
-    for (int p = lane_r; p < nparts; p += 128) {  // 4 rows x 4 float4 in flight; summation order = the finalize kernel's
-      float4 a[4][2], b[4][2];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int pp = p + 32 * u;
-        const long long off = (long long)(pp < nparts ? pp : p) * 2 * C;
-        a[u][0] = *(const float4*)(base + off);
-        a[u][1] = *(const float4*)(base + off + 4);
-        b[u][0] = *(const float4*)(base + off + C);
-        b[u][1] = *(const float4*)(base + off + C + 4);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (p + 32 * u < nparts) {
-          s[0] += (double)a[u][0].x; s[1] += (double)a[u][0].y; s[2] += (double)a[u][0].z; s[3] += (double)a[u][0].w;
-          s[4] += (double)a[u][1].x; s[5] += (double)a[u][1].y; s[6] += (double)a[u][1].z; s[7] += (double)a[u][1].w;
-          q[0] += (double)b[u][0].x; q[1] += (double)b[u][0].y; q[2] += (double)b[u][0].z; q[3] += (double)b[u][0].w;
-          q[4] += (double)b[u][1].x; q[5] += (double)b[u][1].y; q[6] += (double)b[u][1].z; q[7] += (double)b[u][1].w;
-        }
-      }
-    }
-  }
-  const int t = threadIdx.x;
-  ts = 0.0;
-  tq = 0.0;
-  if (lane_r < 32) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) sh[lane_r * G + col * 8 + e] = s[e];
-  }
-  __syncthreads();
-  if (t < G) {
-    for (int i = 0; i < 32; ++i) ts += sh[i * G + t];
-  }
-  __syncthreads();
-  if (lane_r < 32) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) sh[lane_r * G + col * 8 + e] = q[e];
-  }
-  __syncthreads();
-  if (t < G) {
-    for (int i = 0; i < 32; ++i) tq += sh[i * G + t];
-  }
-}
-
-struct BnfPlan {
-  int ncol, colgroups, slabs, nbatch;
-};
-
-// tensors: block-output-sized bf16 tensors the pass reads + writes (2 for y -> out, 3 with a residual, ...)
-static BnfPlan bnf_plan(long long rows, int C, int nparts, int tensors) {
-  BnfPlan pl;
-  const int cpr = C / 8;
-  pl.ncol = cpr < 8 ? cpr : 8;
-  pl.colgroups = cpr / pl.ncol;
-  const long long unit = (long long)(256 / pl.ncol) * BNA_BATCH;  // rows of one batch of a block
-  const long long max_slabs = (rows + unit - 1) / unit;
-  static const int env_target = getenv("VS_BNF_TARGET") ? atoi(getenv("VS_BNF_TARGET")) : 0;
-  const int target = env_target > 0 ? env_target : 1024;
-  long long slabs = (target + pl.colgroups - 1) / pl.colgroups;
-  const double table = (double)nparts * 2.0 * C * 4.0, tensor = (double)rows * C * 2.0 * tensors;
-  long long cap = (long long)(2.0 * tensor / (table > 1.0 ? table : 1.0));
-  if (cap < 1) cap = 1;
-  if (slabs > cap) slabs = cap;
-  if (slabs > max_slabs) slabs = max_slabs;
-  if (slabs < 1) slabs = 1;
-  const long long per = (rows + slabs - 1) / slabs;
-  pl.nbatch = (int)((per + unit - 1) / unit);
-  pl.slabs = (int)((rows + unit * pl.nbatch - 1) / (unit * pl.nbatch));
-  return pl;
-}
-
-template <bool RES, bool RELU>
-__global__ __launch_bounds__(256) void bn_apply_fin_kernel(
-    const float* partials, int nparts, double count, const float* gamma, const float* beta, float* running_mean,
-    float* running_var, float momentum, float eps, float* mean_out, float* invstd_out, const uint16_t* y,
-    const uint16_t* res, uint16_t* out, uint8_t* bits, long long rows, int C, int y_ld, int res_ld, int out_ld,
-    int ncol, int nbatch) {
-  __shared__ double sh[32 * 64];
-  __shared__ float aff[2][64];
-  const int cpr = C >> 3;
-  const int rl = 256 / ncol;
-  const int col = threadIdx.x % ncol, lane_r = threadIdx.x / ncol;
-  const int c0 = blockIdx.x * ncol * 8;
-  const int G = ncol * 8, t = threadIdx.x;
-  // per-channel parameters requested in front of the partial sums' loads
-  float ga_c = 0.f, be_c = 0.f, rm_c = 0.f, rv_c = 0.f;
-  if (t < G) {
-    ga_c = gamma[c0 + t];
-    be_c = beta[c0 + t];
-    if (running_mean && blockIdx.y == 0) {
-      rm_c = running_mean[c0 + t];
-      rv_c = running_var[c0 + t];
-    }
-  }
-  // the first batch of rows is requested BEFORE the prologue: its HBM latency runs beside the partial sums'
-  const int cb = blockIdx.x * ncol + col;
-  const int c = cb * 8;
-  const long long r0 = (long long)blockIdx.y * rl * BNA_BATCH * nbatch;
-  uint4 vy[BNA_BATCH], vr[BNA_BATCH];
-  long long row[BNA_BATCH];
-#pragma unroll
-  for (int u = 0; u < BNA_BATCH; ++u) {
-    row[u] = r0 + (long long)u * rl + lane_r;
-    const long long rr = row[u] < rows ? row[u] : 0;
-    vy[u] = *(const uint4*)(y + rr * y_ld + c);
-    if (RES) vr[u] = *(const uint4*)(res + rr * res_ld + c);
-  }
-  double ts, tq;
-  bnf_reduce_partials(partials, nparts, C, c0, ncol, col, lane_r, sh, ts, tq);
-  if (t < G) {
-    float scv, sfv, mean_f, invstd;
-    double var;
-    bn_affine_from_sums(ts, tq, count, ga_c, be_c, eps, scv, sfv, mean_f, invstd, var);
-    aff[0][t] = scv;
-    aff[1][t] = sfv;
-    if (blockIdx.y == 0) {
-      if (mean_out) mean_out[c0 + t] = mean_f;
-      if (invstd_out) invstd_out[c0 + t] = invstd;
-      if (running_mean) {
-        float rm_n, rv_n;
-        bn_running_update(rm_c, rv_c, mean_f, var, count, momentum, rm_n, rv_n);
-        running_mean[c0 + t] = rm_n;
-        running_var[c0 + t] = rv_n;
-      }
-    }
-  }
-  __syncthreads();
-  float sc[8], shf[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    sc[e] = aff[0][col * 8 + e];
-    shf[e] = aff[1][col * 8 + e];
-  }
-  for (int b = 0; b < nbatch; ++b) {
-    if (b > 0) {
-#pragma unroll
-      for (int u = 0; u < BNA_BATCH; ++u) {
-        row[u] = r0 + (long long)(b * BNA_BATCH + u) * rl + lane_r;
-        const long long rr = row[u] < rows ? row[u] : 0;
-        vy[u] = *(const uint4*)(y + rr * y_ld + c);
-        if (RES) vr[u] = *(const uint4*)(res + rr * res_ld + c);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < BNA_BATCH; ++u) {
-      float v[8], r[8];
-      unpack8_bf16(vy[u], v);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = __fmaf_rn(v[e], sc[e], shf[e]);
-      if (RES) {
-        unpack8_bf16(vr[u], r);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += r[e];
-      }
-      unsigned mbits = 0u;
-      if (RELU) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          mbits |= (v[e] > 0.f ? 1u : 0u) << e;
-          v[e] = fmaxf(v[e], 0.f);
-        }
-      }
-      if (row[u] < rows) {
-        *(uint4*)(out + row[u] * out_ld + c) = pack8_bf16(v);
-        if (RELU && bits) bits[row[u] * cpr + cb] = (uint8_t)mbits;
-      }
-    }
-  }
-}
-
-extern "C" int vs_bn_fin_fusable(int nparts, int C) {
-  return nparts > 0 && nparts <= BNF_MAXPARTS && cpr_pow2(C);
-}
-
-extern "C" int vs_bn_apply_fin(const float* partials, int nparts, double count, const float* gamma, const float* beta,
-                               float* running_mean, float* running_var, float momentum, float eps, float* mean,
-                               float* invstd, const void* y, const void* residual, void* out, uint8_t* relu_bits,
-                               int64_t rows, int C, int y_ld, int res_ld, int out_ld, int relu, void* stream) {
-  VS_CHECK_ARG(partials && gamma && beta && y && out && count > 0, "null tensor");
-  VS_CHECK_ARG(vs_bn_fin_fusable(nparts, C), "1..256 partial rows, C/8 a power of two (else vs_bn_finalize + vs_bn_apply)");
-  VS_CHECK_ARG(y_ld % 8 == 0 && out_ld % 8 == 0 && (!residual || res_ld % 8 == 0), "pitches must be multiples of 8");
-  VS_CHECK_ARG(!relu_bits || relu, "the bit mask belongs to a ReLU unit");
-  VS_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running statistics come as a pair");
-  const BnfPlan pl = bnf_plan(rows, C, nparts, residual ? 3 : 2);
-  const dim3 grid(pl.colgroups, pl.slabs), block(256);
-  hipStream_t st = (hipStream_t)stream;
-#define BNF_ARGS partials, nparts, count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, \
-                 (const uint16_t*)y, (const uint16_t*)residual, (uint16_t*)out, relu_bits, (long long)rows, C, y_ld, \
-                 res_ld, out_ld, pl.ncol, pl.nbatch
-  if (residual && relu) hipLaunchKernelGGL((bn_apply_fin_kernel<true, true>), grid, block, 0, st, BNF_ARGS);
-  else if (residual) hipLaunchKernelGGL((bn_apply_fin_kernel<true, false>), grid, block, 0, st, BNF_ARGS);
-  else if (relu) hipLaunchKernelGGL((bn_apply_fin_kernel<false, true>), grid, block, 0, st, BNF_ARGS);
-  else hipLaunchKernelGGL((bn_apply_fin_kernel<false, false>), grid, block, 0, st, BNF_ARGS);
-#undef BNF_ARGS
-  VS_CHECK_LAUNCH();
-  return VS_OK;
-}
-
-// ----------------------------------------------------------------------------
 // The stems: BN + ReLU + max-pool [1,3,3] / [1,2,2] / pad [0,1,1] as ONE forward pass over the conv output (the
 // normalised full-resolution tensor is never written: its only reader was the pool) and, in the backward passes,
 // the pool's gradient gathered on the fly from the pooled gradient and the argmax bytes instead of read from a
@@ -1192,129 +972,6 @@ extern "C" int vs_bn_bwd_apply(const void* dz, const void* z, const void* y, con
   else if (z) hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, grid, block, 0, st, BNB_ARGS);
   else hipLaunchKernelGGL(bn_bwd_apply_kernel<2>, grid, block, 0, st, BNB_ARGS);
 #undef BNB_ARGS
-  VS_CHECK_LAUNCH();
-  return VS_OK;
-}
-
-// The backward apply that finalizes for itself (see bn_apply_fin_kernel): dgamma / dbeta of the block's column group
-// from the partial rows (vs_bn_bwd_reduce's, or the ones a dgrad epilogue emitted) in the prologue -- bitwise
-// vs_bn_bwd_finalize -- and the blocks of row slab 0 store them.
-template <int MASK, bool DRES>
-__global__ __launch_bounds__(256) void bn_bwd_apply_fin_kernel(
-    const float* partial, int nparts, const uint16_t* dz, const uint16_t* z, const uint16_t* y, const float* mean,
-    const float* invstd, const float* gamma, const float* beta, float* dgamma, float* dbeta, uint16_t* dy,
-    uint16_t* dres, long long rows, int C, int dz_ld, int z_ld, int y_ld, int dy_ld, int dres_ld, int ncol,
-    int nbatch) {
-  __shared__ double sh[32 * 64];
-  __shared__ float dgb[2][64];
-  const int cpr = C >> 3;
-  const int rl = 256 / ncol;
-  const int col = threadIdx.x % ncol, lane_r = threadIdx.x / ncol;
-  const int c0 = blockIdx.x * ncol * 8;
-  const int G = ncol * 8, t = threadIdx.x;
-  const int cb = blockIdx.x * ncol + col;
-  const int c = cb * 8;
-  const float invM = 1.0f / (float)rows;
-  float mu[8], is[8], ga[8], be[8], b1[8], b2[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {  // in flight beside the partial rows
-    mu[e] = mean[c + e];
-    is[e] = invstd[c + e];
-    ga[e] = gamma[c + e];
-    be[e] = (MASK == 2) ? beta[c + e] : 0.f;
-  }
-  const long long r0 = (long long)blockIdx.y * rl * BNA_BATCH * nbatch;
-  uint4 vg[BNA_BATCH], vy[BNA_BATCH], vz[BNA_BATCH];
-  long long row[BNA_BATCH];
-#pragma unroll
-  for (int u = 0; u < BNA_BATCH; ++u) {  // batch 0, requested before the prologue
-    row[u] = r0 + (long long)u * rl + lane_r;
-    const long long rr = row[u] < rows ? row[u] : 0;
-    vg[u] = *(const uint4*)(dz + rr * dz_ld + c);
-    vy[u] = *(const uint4*)(y + rr * y_ld + c);
-    if (MASK == 1) vz[u] = *(const uint4*)(z + rr * z_ld + c);
-    if (MASK == 3) vz[u].x = ((const uint8_t*)z)[rr * cpr + cb];
-  }
-  double ts, tq;
-  bnf_reduce_partials(partial, nparts, C, c0, ncol, col, lane_r, sh, ts, tq);
-  if (t < G) {
-    const float db = (float)ts, dg = (float)tq;
-    dgb[0][t] = db;
-    dgb[1][t] = dg;
-    if (blockIdx.y == 0) {
-      dbeta[c0 + t] = db;
-      dgamma[c0 + t] = dg;
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    b1[e] = dgb[0][col * 8 + e] * invM;
-    b2[e] = dgb[1][col * 8 + e] * invM;
-  }
-  for (int b = 0; b < nbatch; ++b) {
-    if (b > 0) {
-#pragma unroll
-      for (int u = 0; u < BNA_BATCH; ++u) {
-        row[u] = r0 + (long long)(b * BNA_BATCH + u) * rl + lane_r;
-        const long long rr = row[u] < rows ? row[u] : 0;
-        vg[u] = *(const uint4*)(dz + rr * dz_ld + c);
-        vy[u] = *(const uint4*)(y + rr * y_ld + c);
-        if (MASK == 1) vz[u] = *(const uint4*)(z + rr * z_ld + c);
-        if (MASK == 3) vz[u].x = ((const uint8_t*)z)[rr * cpr + cb];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < BNA_BATCH; ++u) {
-      float g[8], yv[8], o[8];
-      unpack8_bf16(vg[u], g);
-      unpack8_bf16(vy[u], yv);
-      if (MASK == 1) {
-        float zv[8];
-        unpack8_bf16(vz[u], zv);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] = zv[e] > 0.f ? g[e] : 0.f;
-      }
-      if (MASK == 3) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] = ((vz[u].x >> e) & 1u) ? g[e] : 0.f;
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        o[e] = bn_bwd_elem<MASK == 2>(g[e], yv[e], mu[e], is[e], ga[e], be[e], b1[e], b2[e]);
-      if (row[u] < rows) {
-        *(uint4*)(dy + row[u] * dy_ld + c) = pack8_bf16(o);
-        if (DRES) *(uint4*)(dres + row[u] * dres_ld + c) = pack8_bf16(g);
-      }
-    }
-  }
-}
-
-extern "C" int vs_bn_bwd_apply_fin(const float* partial, int nparts, const void* dz, const void* z, const void* y,
-                                   const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                   float* dgamma, float* dbeta, void* dy, void* dres, int64_t rows, int C, int dz_ld,
-                                   int z_ld, int y_ld, int dy_ld, int dres_ld, int relu, void* stream) {
-  VS_CHECK_ARG(partial && dz && y && mean && invstd && gamma && dgamma && dbeta && dy, "null tensor");
-  VS_CHECK_ARG(!relu || z || beta, "relu needs z, or beta to recompute the mask");
-  VS_CHECK_ARG(vs_bn_fin_fusable(nparts, C),
-               "1..256 partial rows, C/8 a power of two (else vs_bn_bwd_finalize + vs_bn_bwd_apply)");
-  const int mask = !relu ? 0 : (relu == 2 ? 3 : (z ? 1 : 2));
-  const BnfPlan pl = bnf_plan(rows, C, nparts, 3 + (dres ? 1 : 0) + (mask == 1 ? 1 : 0));
-  const dim3 grid(pl.colgroups, pl.slabs), block(256);
-  hipStream_t st = (hipStream_t)stream;
-#define BNBF_L(M, D)                                                                                              \
-  hipLaunchKernelGGL((bn_bwd_apply_fin_kernel<M, D>), grid, block, 0, st, partial, nparts, (const uint16_t*)dz,   \
-                     (const uint16_t*)z, (const uint16_t*)y, mean, invstd, gamma, beta, dgamma, dbeta,            \
-                     (uint16_t*)dy, (uint16_t*)dres, (long long)rows, C, dz_ld, z_ld, y_ld, dy_ld, dres_ld,        \
-                     pl.ncol, pl.nbatch)
-  if (dres) {
-    if (mask == 0) BNBF_L(0, true); else if (mask == 1) BNBF_L(1, true);
-    else if (mask == 2) BNBF_L(2, true); else BNBF_L(3, true);
-  } else {
-    if (mask == 0) BNBF_L(0, false); else if (mask == 1) BNBF_L(1, false);
-    else if (mask == 2) BNBF_L(2, false); else BNBF_L(3, false);
-  }
-#undef BNBF_L
   VS_CHECK_LAUNCH();
   return VS_OK;
 }

@@ -1347,339 +1347,6 @@ extern "C" int vs_add_layernorm_bwd(const float* dy, const float* x, const float
 }
 
 // ----------------------------------------------------------------------------
-// One launch for a chain of few-row stages: the TxEncoder's 6 layers on the 8 tokens of a rank run 42
-// forward and ~50 backward launches of ~6 us each, every one depending on the one before -- 1.1 ms of a
-// 12.5 ms step with the chip idle.  Here one persistent grid (one 256-thread block per CU) walks a table
-// of stages; a stage is the body of the stand-alone kernel (same arithmetic, same order: bitwise the
-// launches it replaces) run over "virtual blocks" strided by the grid, and between two stages the grid
-// meets at a barrier (one counter per stage, agent-scope release / acquire fences around it: the L2s of the
-// eight XCDs are not coherent with each other -- MI355X_MICROARCH, memory model).  The spin has an iteration
-// cap: a block that waits too long sets the error word and leaves, so a bug here cannot hang the GPU.
-// ----------------------------------------------------------------------------
-struct TxStage {
-  long long op, M, N, K, ia, ib;  // ia / ib: op-specific integers (or float bit patterns)
-  const void* p[10];
-};
-enum { TX_LIN = 1, TX_LINBWD = 2, TX_ATTN_FWD = 3, TX_ATTN_BWD = 4, TX_LN_FWD = 5, TX_LN_BWD = 6, TX_ADD = 7 };
-
-// mode (VS_TX_BAR; default 3): bit 0 = the agent-scope fences by the first wave of a block only (every wave first waits
-// for its own stores to be acknowledged, the block meets, then one release covers them all; after the wait one
-// acquire invalidates the CU's L1 and the XCD's L2 for everybody) instead of by every wave; bit 1 = two-level
-// counters (the blocks of an XCD -- blockIdx % 8 -- meet on their own word, the last of each adds to the grid's
-// word: 32 + 8 contended atomics per word instead of 256); bit 2 = NO fences (timing experiments only, results
-// undefined).  Per barrier: 37 us (0), 14 us (1), 9.4 us (3), 2.9 us (6) -- profiles/r02_txenc_stack.txt.
-__device__ __forceinline__ bool tx_grid_barrier(unsigned* ctr, unsigned* xcd_ctr, unsigned nblocks, unsigned* err,
-                                                int mode) {
-  __shared__ int tx_timed_out;
-  const bool fence = !(mode & 4), first_wave_only = (mode & 1) != 0;
-  if (fence) {
-    if (first_wave_only) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached L2
-    else __threadfence();
-  }
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    if (fence && first_wave_only) __threadfence();  // release: the block's stores leave the XCD's L2
-    if (threadIdx.x == 0) {
-      tx_timed_out = 0;
-      if (mode & 2) {
-        const unsigned x = blockIdx.x & 7u;
-        const unsigned per = (nblocks + 7u - x) / 8u;  // blocks with this blockIdx % 8
-        const unsigned old =
-            __hip_atomic_fetch_add(xcd_ctr + x * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1 == per) __hip_atomic_fetch_add(ctr, per, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      unsigned spins = 0;
-      while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nblocks) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1u << 20)) {
-          tx_timed_out = 1;
-          __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-      }
-    }
-    if (fence && first_wave_only) __threadfence();  // acquire (the L1 is the CU's, the L2 the XCD's: one wave's does)
-  }
-  __syncthreads();
-  if (fence && !first_wave_only) __threadfence();
-  return tx_timed_out == 0;
-}
-
-// dgamma / dbeta of a LayerNorm over <= 16 rows, one thread per column: the 16-wave kernel above gives every row
-// its own wave there and adds the per-wave terms in wave order -- i.e. sum over rows, in order, of
-// round(round(dy * (v - mean)) * rstd): the same sum, term by term, without contraction.
-__device__ __forceinline__ void tx_ln_bwd_param_body(const float* dy, const float* dy2, const float* x,
-                                                     const float* r, const float* rmask, const float* mean,
-                                                     const float* rstd, float* dgamma, float* dbeta, int rows,
-                                                     int D, int vb) {
-  const int d = vb * 256 + threadIdx.x;
-  if (d >= D) return;
-  float vv[16], gg[16];
-#pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const bool ok = u < rows;
-    const long long i = (long long)(ok ? u : 0) * D + d;
-    float v = x[i];
-    if (r) v += rmask ? r[i] * rmask[i] : r[i];
-    float g = dy[i];
-    if (dy2) g += dy2[i];
-    vv[u] = v;
-    gg[u] = ok ? g : 0.f;
-  }
-  float a = 0.f, b = 0.f;
-#pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    if (u < rows) {
-      a = __fadd_rn(a, __fmul_rn(__fmul_rn(gg[u], vv[u] - mean[u]), rstd[u]));
-      b = __fadd_rn(b, gg[u]);
-    }
-  }
-  dgamma[d] = a;
-  dbeta[d] = b;
-}
-
-template <int MT>
-__device__ __forceinline__ void tx_fullx(const float* x, const float* xmask, const float* w, const float* b,
-                                         const float* res, float* y, int M, int N, int K, int act, int vb) {
-  if (K <= 1024) linear_fullx_body<MT, 4>(x, xmask, w, b, res, y, M, N, K, act, vb);
-  else if (K <= 2048) linear_fullx_body<MT, 8>(x, xmask, w, b, res, y, M, N, K, act, vb);
-  else linear_fullx_body<MT, 16>(x, xmask, w, b, res, y, M, N, K, act, vb);
-}
-
-__global__ __launch_bounds__(256) void txenc_stack_kernel(const TxStage* __restrict__ stages, int nstages,
-                                                          unsigned* bars, int mode) {
-  extern __shared__ __attribute__((aligned(16))) char tx_smem[];
-  const int G = gridDim.x;
-  for (int s = 0; s < nstages; ++s) {
-    const TxStage& st = stages[s];
-    const int op = (int)st.op, M = (int)st.M, N = (int)st.N, K = (int)st.K;
-    if (op == TX_LIN) {  // y[M,N] = act(x[M,K] . w[N,K]^T + b) (+ res)
-      const int nvb = (N + 3) / 4;
-      for (int vb = blockIdx.x; vb < nvb; vb += G) {
-        tx_fullx<8>((const float*)st.p[0], nullptr, (const float*)st.p[1], (const float*)st.p[2],
-                    (const float*)st.p[3], (float*)st.p[4], M, N, K, (int)st.ia, vb);
-        __syncthreads();
-      }
-    } else if (op == TX_LINBWD) {  // dx = (dy * (relu_y > 0)) . W on wt ; dW = dy_eff^T x ; db
-      const float* dy = (const float*)st.p[0];
-      const float* relu_y = (const float*)st.p[1];
-      const int g1 = st.p[4] ? (K + 3) / 4 : 0;
-      const int g2 = (int)st.ia;
-      for (int vb = blockIdx.x; vb < g1 + g2; vb += G) {
-        if (vb < g1)
-          tx_fullx<8>(dy, relu_y, (const float*)st.p[3], nullptr, nullptr, (float*)st.p[4], M, K, N, 0, vb);
-        else
-          linear_bwd_weight_body<true>(dy, relu_y, (const float*)st.p[2], (float*)st.p[5], (float*)st.p[6], M, N, K,
-                                       vb - g1, g2);
-        __syncthreads();
-      }
-    } else if (op == TX_ATTN_FWD) {  // M = B, N = H, K = dh, ia = L, ib = float bits of 1 / scale
-      const int L = (int)st.ia, D = N * K;
-      const float* qkv = (const float*)st.p[0];
-      for (int vb = blockIdx.x; vb < M * N; vb += G) {
-        attn_small_fwd_body(qkv, qkv + D, qkv + 2 * D, (float*)st.p[1], (float*)st.p[2], (const float*)st.p[3], L, N,
-                            K, __int_as_float((int)st.ib), 3 * D, vb, tx_smem);
-        __syncthreads();
-      }
-    } else if (op == TX_ATTN_BWD) {
-      const int L = (int)st.ia, D = N * K;
-      const float* qkv = (const float*)st.p[0];
-      float* dqkv = (float*)st.p[4];
-      for (int vb = blockIdx.x; vb < M * N; vb += G) {
-        attn_small_bwd_body(qkv, qkv + D, qkv + 2 * D, (const float*)st.p[2], (const float*)st.p[1], dqkv, dqkv + D,
-                            dqkv + 2 * D, (const float*)st.p[3], L, N, K, __int_as_float((int)st.ib), 3 * D, vb,
-                            tx_smem);
-        __syncthreads();
-      }
-    } else if (op == TX_LN_FWD) {  // M rows, N = D, ib = float bits of eps
-      const int nvb = (M + 3) / 4;
-      for (int vb = blockIdx.x; vb < nvb; vb += G)
-        add_layernorm_fwd_vec_body((const float*)st.p[0], (const float*)st.p[1], (const float*)st.p[2],
-                                   (const float*)st.p[3], (const float*)st.p[4], (float*)st.p[5], (float*)st.p[6],
-                                   (float*)st.p[7], M, N, __int_as_float((int)st.ib), 0, vb * 4 + (threadIdx.x >> 6));
-    } else if (op == TX_LN_BWD) {  // p: dy, dy2, x, r, rmask, gamma, mean, rstd, dx, dr ; dgamma / dbeta behind dx
-      const int g1 = (M + 3) / 4, g2 = (N + 255) / 256;
-      float* dgamma = (float*)(size_t)st.ia;
-      float* dbeta = (float*)(size_t)st.ib;
-      for (int vb = blockIdx.x; vb < g1 + g2; vb += G) {
-        if (vb < g1) {
-          const int row = vb * 4 + (threadIdx.x >> 6);
-          if (N <= 1024)
-            add_layernorm_bwd_dx_vec_body<4>((const float*)st.p[0], (const float*)st.p[2], (const float*)st.p[3],
-                                             (const float*)st.p[4], (const float*)st.p[5], (const float*)st.p[6],
-                                             (const float*)st.p[7], (float*)st.p[8], (float*)st.p[9], M, N, row,
-                                             (const float*)st.p[1]);
-          else
-            add_layernorm_bwd_dx_vec_body<LN_MAXE / 4>(
-                (const float*)st.p[0], (const float*)st.p[2], (const float*)st.p[3], (const float*)st.p[4],
-                (const float*)st.p[5], (const float*)st.p[6], (const float*)st.p[7], (float*)st.p[8],
-                (float*)st.p[9], M, N, row, (const float*)st.p[1]);
-        } else {
-          tx_ln_bwd_param_body((const float*)st.p[0], (const float*)st.p[1], (const float*)st.p[2],
-                               (const float*)st.p[3], (const float*)st.p[4], (const float*)st.p[6],
-                               (const float*)st.p[7], dgamma, dbeta, M, N, vb - g1);
-        }
-      }
-    } else if (op == TX_ADD) {  // y = a + b, N float4s
-      const float4* a = (const float4*)st.p[0];
-      const float4* b = (const float4*)st.p[1];
-      float4* y = (float4*)st.p[2];
-      for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long long)G * 256) {
-        const float4 u = a[i], v = b[i];
-        y[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
-      }
-    }
-    if (s + 1 < nstages &&
-        !tx_grid_barrier(bars + s, bars + nstages + 16 + s * 128, (unsigned)G, bars + nstages, mode))
-      return;
-  }
-}
-
-// stages: TxStage[nstages] in device memory; barriers: nstages * 129 + 16 words, zeroed here (word [nstages] = error
-// flag, then 8 x 16 words per stage for the two-level counters);
-// smem_bytes: the largest dynamic LDS any stage needs (8 rows x the widest inner dimension x 4 bytes).
-extern "C" int vs_txenc_stack_run(const void* stages, int nstages, void* barriers, int grid, int smem_bytes,
-                                  void* stream) {
-  VS_CHECK_ARG(stages && barriers && nstages > 0 && grid > 0 && grid <= 1024, "bad args");
-  VS_CHECK_ARG(smem_bytes >= 4 * 8 * 65 * 4 && smem_bytes <= 159 * 1024, "dynamic LDS size");
-  static bool attr = false;
-  if (!attr) {
-    // (the kernel also has a few bytes of static LDS: the cap is dynamic + static <= 160 KB)
-    if (hipFuncSetAttribute((const void*)txenc_stack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            159 * 1024) != hipSuccess) {
-      vs_set_error("vs_txenc_stack_run: hipFuncSetAttribute failed");
-      return VS_ERR_LAUNCH;
-    }
-    attr = true;
-  }
-  hipStream_t st = (hipStream_t)stream;
-  static const int mode = getenv("VS_TX_BAR") ? atoi(getenv("VS_TX_BAR")) : 3;
-  if (hipMemsetAsync(barriers, 0, (size_t)(nstages + 16 + nstages * 128) * 4, st) != hipSuccess) {
-    vs_set_error("vs_txenc_stack_run: memset failed");
-    return VS_ERR_LAUNCH;
-  }
-  hipLaunchKernelGGL(txenc_stack_kernel, dim3(grid), dim3(256), (size_t)smem_bytes, st, (const TxStage*)stages,
-                     nstages, (unsigned*)barriers, mode);
-  VS_CHECK_LAUNCH();
-  return VS_OK;
-}
-
-// ----------------------------------------------------------------------------
-// LayerNorm in the prologue of the linear that consumes it (round 3).  On the encoder's 8 token rows every launch is
-// ~11 us of the step's critical path (profiles/r03_encoder_section.txt) and a LayerNorm over 8 x 512 values is a
-// microsecond of work: every block of the consuming linear recomputes it into the LDS area the linear stages its input
-// in -- the stand-alone kernels' bodies (same arithmetic, same order: same bits) -- and block 0 stores what the rest of
-// the step needs (the normalised rows and their statistics; the input gradient of the residual path).
-//   forward : y_ln = LayerNorm(x + r * rmask); y = act(y_ln . w^T + b)
-//   backward: (dx_ln, dr) = LayerNorm backward of dy; then both gradients of the linear whose output gradient dr is
-// ----------------------------------------------------------------------------
-template <int KC>
-__global__ __launch_bounds__(256) void ln_linear_fwd_kernel(const float* x, const float* r, const float* rmask,
-                                                            const float* gamma, const float* beta, float eps,
-                                                            float* y_ln, float* mean, float* rstd,
-                                                            const float* __restrict__ w, const float* __restrict__ b,
-                                                            float* y, int M, int N, int K, int act) {
-  extern __shared__ float4 xs4[];
-  const bool first = blockIdx.x == 0;
-  for (int row = threadIdx.x >> 6; row < M; row += 4)
-    add_layernorm_fwd_vec_body(x, r, rmask, gamma, beta, (float*)xs4, first ? mean : nullptr, first ? rstd : nullptr,
-                               M, K, eps, 0, row);
-  if (first) {
-    __syncthreads();
-    const int n4 = M * (K >> 2);
-    for (int i = threadIdx.x; i < n4; i += 256) ((float4*)y_ln)[i] = xs4[i];
-  }
-  linear_fullx_body<8, KC, true>(nullptr, nullptr, w, b, nullptr, y, M, N, K, act, blockIdx.x);
-}
-
-extern "C" int vs_ln_linear_fwd(const float* x, const float* r, const float* rmask, const float* gamma,
-                                const float* beta, float eps, float* y_ln, float* mean, float* rstd, const float* w,
-                                const float* b, float* y, int M, int N, int K, int relu, void* stream) {
-  VS_CHECK_ARG(x && gamma && beta && y_ln && mean && rstd && w && y && M > 0 && N > 0, "bad args");
-  const uintptr_t al = (uintptr_t)x | (uintptr_t)r | (uintptr_t)rmask | (uintptr_t)gamma | (uintptr_t)beta |
-                       (uintptr_t)y_ln | (uintptr_t)w;
-  if (M > 8 || (K & 3) || K > 1024 || (al & 15)) {
-    vs_set_error("vs_ln_linear_fwd: M <= 8, K %% 4 == 0, K <= 1024, 16-byte aligned pointers "
-                 "(use vs_add_layernorm_fwd + vs_linear_fwd)");
-    return VS_ERR_UNSUPPORTED;
-  }
-  static std::once_flag attr;
-  std::call_once(attr, [] {
-    (void)hipFuncSetAttribute((const void*)ln_linear_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-  });
-  size_t smem = (size_t)8 * K * 4;
-  if (smem < (size_t)4 * 8 * 65 * 4) smem = (size_t)4 * 8 * 65 * 4;
-  hipLaunchKernelGGL((ln_linear_fwd_kernel<4>), dim3((N + 3) / 4), dim3(256), smem, (hipStream_t)stream, x, r, rmask,
-                     gamma, beta, eps, y_ln, mean, rstd, w, b, y, M, N, K, relu ? 1 : 0);
-  VS_CHECK_LAUNCH();
-  return VS_OK;
-}
-
-// blocks [0, g1): dx of the linear; [g1, g1 + g2): its dW / db; [g1 + g2, ..): dgamma / dbeta of the LayerNorm
-template <int KC, bool VEC>
-__global__ __launch_bounds__(256) void ln_bwd_linear_bwd_kernel(
-    const float* dy, const float* x_ln, const float* r, const float* rmask, const float* gamma, const float* mean,
-    const float* rstd, float* dx_ln, float* dgamma, float* dbeta, const float* __restrict__ x_lin,
-    const float* __restrict__ wt, float* dx_lin, float* dw, float* db, int M, int D, int K, int g1, int g2,
-    int stage_floats) {
-  extern __shared__ float4 xs4[];
-  const int bid = blockIdx.x;
-  if (bid >= g1 + g2) {
-    tx_ln_bwd_param_body(dy, nullptr, x_ln, r, rmask, mean, rstd, dgamma, dbeta, M, D, bid - g1 - g2);
-    return;
-  }
-  float* A = (float*)xs4 + stage_floats;  // LayerNorm input gradient rows [M][D] (behind the linear's staging area)
-  float* B = A + 8 * D;                   // the same under the residual-dropout mask = the linear's output gradient
-  for (int row = threadIdx.x >> 6; row < M; row += 4)
-    add_layernorm_bwd_dx_vec_body<4>(dy, x_ln, r, rmask, gamma, mean, rstd, A, rmask ? B : nullptr, M, D, row, nullptr);
-  __syncthreads();
-  if (bid == 0) {
-    const int n4 = M * (D >> 2);
-    for (int i = threadIdx.x; i < n4; i += 256) ((float4*)dx_ln)[i] = ((const float4*)A)[i];
-  }
-  const float* dyl = rmask ? B : A;
-  if (bid < g1)
-    linear_fullx_body<8, KC>(dyl, nullptr, wt, nullptr, nullptr, dx_lin, M, K, D, 0, bid);
-  else
-    linear_bwd_weight_body<VEC>(dyl, nullptr, x_lin, dw, db, M, D, K, bid - g1, g2);
-}
-
-extern "C" int vs_ln_bwd_linear_bwd(const float* dy, const float* x_ln, const float* r, const float* rmask,
-                                    const float* gamma, const float* mean, const float* rstd, float* dx_ln,
-                                    float* dgamma, float* dbeta, const float* x_lin, const float* wt, float* dx_lin,
-                                    float* dw, float* db, int M, int D, int K, void* stream) {
-  VS_CHECK_ARG(dy && x_ln && gamma && mean && rstd && dx_ln && dgamma && dbeta && x_lin && wt && dx_lin && dw,
-               "null tensor");
-  const uintptr_t al = (uintptr_t)dy | (uintptr_t)x_ln | (uintptr_t)r | (uintptr_t)rmask | (uintptr_t)gamma |
-                       (uintptr_t)dx_ln | (uintptr_t)wt | (uintptr_t)x_lin | (uintptr_t)dw;
-  if (M > 8 || (D & 3) || D > 1024 || (K & 3) || (al & 15)) {
-    vs_set_error("vs_ln_bwd_linear_bwd: M <= 8, D %% 4 == 0, D <= 1024, K %% 4 == 0, 16-byte aligned pointers "
-                 "(use vs_add_layernorm_bwd + vs_linear_bwd_fused)");
-    return VS_ERR_UNSUPPORTED;
-  }
-  static std::once_flag attr;
-  std::call_once(attr, [] {
-    (void)hipFuncSetAttribute((const void*)ln_bwd_linear_bwd_kernel<4, true>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  });
-  size_t stage = (size_t)8 * D * 4;  // linear_fullx_body's staging of the dr rows (inner dimension D <= 1024)
-  if (stage < (size_t)4 * 8 * 65 * 4) stage = (size_t)4 * 8 * 65 * 4;
-  const size_t smem = stage + (size_t)2 * 8 * D * 4;
-  const int g1 = (K + 3) / 4;
-  long long g2 = ((long long)D * ((K + 3) / 4) + 255) / 256;
-  if (g2 > 4096) g2 = 4096;
-  const int g3 = (D + 255) / 256;
-  hipLaunchKernelGGL((ln_bwd_linear_bwd_kernel<4, true>), dim3((unsigned)(g1 + g2 + g3)), dim3(256), smem,
-                     (hipStream_t)stream, dy, x_ln, r, rmask, gamma, mean, rstd, dx_ln, dgamma, dbeta, x_lin, wt, dx_lin,
-                     dw, db, M, D, K, g1, (int)g2, (int)(stage / 4));
-  VS_CHECK_LAUNCH();
-  return VS_OK;
-}
-
-// ----------------------------------------------------------------------------
 // mean cross-entropy + dlogits.  One block; waves take rows round-robin and the
 // per-wave loss sums are combined in a fixed order (bitwise reproducible).
 // ----------------------------------------------------------------------------

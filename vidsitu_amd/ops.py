@@ -628,51 +628,6 @@ def bn_finalize(partials, count, gamma, beta, running_mean, running_var, momentu
     return scale, shift, mean, invstd
 
 
-# Apply kernels that finalize for themselves (vs_bn_apply_fin / vs_bn_bwd_apply_fin): no finalize launch on the
-# step's dependency chain; results bitwise the separate launches (tests/test_gpu_bn_pool.py).  Built in round 3 on
-# the round-2 review's item 2 and MEASURED SLOWER: 12.62 vs 12.46 ms per train step (three alternating pairs, one box,
-# profiles/r03_bn_fin_fuse.txt).  Per layer (tools/bn_fin_time.py, dependent chains in a hipGraph): a finalize launch
-# costs ~4 us on the chain, and the fused pass pays about that in every block's prologue (100 KB of partial rows per
-# 64-channel column group from L2, two load rounds, an LDS tree) while its body, tiled over column groups, streams
-# worse than the column-owner kernel on the large tensors (s3.c 36.8 -> 49.3 us, s4.c 21.4 -> 25.6); only the
-# smallest layers gain (s5.b 6.8 -> 5.4 us).  OFF by default; VS_BN_FIN_FUSE=1 switches it on.
-BN_FIN_FUSE = _os.environ.get("VS_BN_FIN_FUSE", "0") == "1"
-_BN_FIN_MAXPARTS = 256
-
-
-def bn_fin_fusable(nparts, c):
-    """Whether `bn_apply_fin` takes these partial rows: directly (<= 256 rows) or behind the level-1 reduce that
-    `bn_finalize` would run as well (> _BN_TWO_LEVEL rows -> 32).  In between the separate finalize launch stays
-    (its one-level fp64 sum over up to 512 rows is what the results are pinned to)."""
-    cpr = c // 8
-    return (BN_FIN_FUSE and c % 8 == 0 and cpr > 0 and cpr & (cpr - 1) == 0
-            and (nparts <= _BN_FIN_MAXPARTS or nparts > _BN_TWO_LEVEL))
-
-
-def bn_apply_fin(partials, count, bn, y, residual=None, relu=True, out=None, want_bits=False):
-    """bn_finalize(train) + bn_apply as one launch: -> (out, bits | None, mean, invstd); running statistics of `bn`
-    updated in place.  Bitwise the two launches."""
-    c = bn.weight.numel()
-    dev = y.device
-    nparts = partials.shape[0]
-    if nparts > _BN_TWO_LEVEL:
-        lvl1 = torch.empty((32, 2, c), dtype=torch.float32, device=dev)
-        _lib.call("vs_bn_partials_reduce", _ptr(partials), nparts, _ptr(lvl1), c, 32, _stream())
-        partials, nparts = lvl1, 32
-    mean = torch.empty(c, dtype=torch.float32, device=dev)
-    invstd = torch.empty(c, dtype=torch.float32, device=dev)
-    if out is None:
-        out = new_act(*y.shape, device=dev)
-    bits = None
-    if want_bits and relu:
-        bits = torch.empty((act_rows(y), c // 8), dtype=torch.uint8, device=dev)
-    _lib.call("vs_bn_apply_fin", _ptr(partials), nparts, float(count), _ptr(bn.weight), _ptr(bn.bias),
-              _ptr(bn.running_mean), _ptr(bn.running_var), float(bn.momentum), float(bn.eps), _ptr(mean),
-              _ptr(invstd), _ptr(y), _ptr(residual), _ptr(out), _ptr(bits), act_rows(y), c, act_ld(y),
-              act_ld(residual) if residual is not None else 0, act_ld(out), int(relu), _stream())
-    return out, bits, mean, invstd
-
-
 def bn_apply(y, scale, shift, residual=None, relu=True, out=None, want_bits=False):
     """out = relu?(y * scale + shift (+ residual)).  want_bits (with relu): also returns the ReLU
     mask as bits, uint8 [rows, C/8], for the backward passes (vs_bn_apply_mask)."""
@@ -764,12 +719,6 @@ def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres, dy_out=None, dgamma=N
         dbeta = torch.empty(c, dtype=torch.float32, device=dev)
     dy = new_act(*y.shape, device=dev) if dy_out is None else dy_out
     dres = new_act(*y.shape, device=dev) if want_dres else None
-    if BN_FIN_FUSE and nblk <= _BN_FIN_MAXPARTS and _lib.load().vs_bn_fin_fusable(nblk, c):
-        # the apply pass sums the partial rows itself (bitwise vs_bn_bwd_finalize): one launch fewer on the chain
-        _lib.call("vs_bn_bwd_apply_fin", _ptr(partial), nblk, _ptr(dz), _ptr(zz), _ptr(y), _ptr(mean), _ptr(invstd),
-                  _ptr(gamma), _ptr(beta), _ptr(dgamma), _ptr(dbeta), _ptr(dy), _ptr(dres), rows, c,
-                  act_ld(dz), z_ld, act_ld(y), act_ld(dy), act_ld(dres) if want_dres else 0, mode, _stream())
-        return dy, dres, dgamma, dbeta
     if not (_WHATIF & 2):
         _lib.call("vs_bn_bwd_finalize", _ptr(partial), nblk, _ptr(dgamma), _ptr(dbeta), c, _stream())
     if not (_WHATIF & 8): _lib.call("vs_bn_bwd_apply", _ptr(dz), _ptr(zz), _ptr(y), _ptr(mean), _ptr(invstd),
@@ -1029,125 +978,6 @@ def conv_pair_count():
     return int(_lib.load().vs_conv_pair_count())
 
 
-class TxStack:
-    """Stage list of `vs_txenc_stack_run` (include/vidsitu_hip.h): a chain of few-row kernels behind one launch.
-    Build with the methods below (each = the stand-alone op of the same name, same arguments, M <= 8 rows), then
-    `run()`.  The table travels host (pinned) -> device with an asynchronous copy on the current stream, which a
-    hipGraph capture records as a memcpy node; the object keeps every tensor it points to alive."""
-
-    GRID = 256  # one 256-thread block per CU: every block resident, the barrier cannot starve
-
-    def __init__(self, device):
-        self.device, self.rows, self.keep, self.smem = device, [], [], 4 * 8 * 65 * 4
-        self.table = self.host = self.bars = None
-
-    @staticmethod
-    def _fbits(v):
-        import struct
-
-        return struct.unpack("<i", struct.pack("<f", float(v)))[0]
-
-    def _add(self, op, m, n, k, ia, ib, tensors):
-        ptrs = [0 if t is None else int(t.data_ptr()) for t in tensors]
-        self.keep.extend(t for t in tensors if t is not None)
-        self.rows.append([op, m, n, k, ia, ib] + ptrs + [0] * (10 - len(ptrs)))
-
-    def linear(self, x, w, b, y, act=0, res=None):
-        m, k = x.shape
-        n = w.shape[0]
-        if m > 8 or k % 4 or k > 4096:
-            raise _lib.VsError("TxStack.linear: M <= 8, K % 4 == 0, K <= 4096")
-        self.smem = max(self.smem, 32 * min(k, 1024))
-        self._add(1, m, n, k, int(act), 0, [x, w, b, res, y])
-
-    def linear_bwd(self, dy, relu_y, x, wt, dx, dw, db):
-        m, n = dy.shape
-        k = x.shape[1]
-        if m > 8 or n % 4 or n > 4096 or k % 4:
-            raise _lib.VsError("TxStack.linear_bwd: M <= 8, N % 4 == 0, N <= 4096, K % 4 == 0")
-        self.smem = max(self.smem, 32 * min(n, 1024))
-        g2 = min(4096, (n * (k // 4) + 255) // 256)
-        self._add(2, m, n, k, g2, 0, [dy, relu_y, x, wt, dx, dw, db])
-
-    def attn_fwd(self, qkv, o, probs, drop_mask, b, l, heads, scale):
-        import numpy as np
-
-        dh = qkv.shape[1] // 3 // heads
-        self.smem = max(self.smem, (3 * l * dh + l * l) * 4)
-        self._add(3, b, heads, dh, l, self._fbits(np.float32(1.0) / np.float32(scale)), [qkv, o, probs, drop_mask])
-
-    def attn_bwd(self, qkv, dout, probs, drop_mask, dqkv, b, l, heads, scale):
-        import numpy as np
-
-        dh = qkv.shape[1] // 3 // heads
-        self.smem = max(self.smem, (4 * l * dh + 3 * l * l) * 4)
-        self._add(4, b, heads, dh, l, self._fbits(np.float32(1.0) / np.float32(scale)),
-                  [qkv, dout, probs, drop_mask, dqkv])
-
-    def add_layernorm(self, x, r, rmask, gamma, beta, y, mean, rstd, eps):
-        rows, d = x.shape
-        if d % 4 or d > 2048:
-            raise _lib.VsError("TxStack.add_layernorm: D % 4 == 0, D <= 2048")
-        self._add(5, rows, d, 0, 0, self._fbits(eps), [x, r, rmask, gamma, beta, y, mean, rstd])
-
-    def add_layernorm_bwd(self, dy, dy2, x, r, rmask, gamma, mean, rstd, dx, dr, dgamma, dbeta):
-        rows, d = x.shape
-        if rows > 16 or d % 4 or d > 2048:
-            raise _lib.VsError("TxStack.add_layernorm_bwd: rows <= 16, D % 4 == 0, D <= 2048")
-        self.keep.extend((dgamma, dbeta))
-        self._add(6, rows, d, 0, int(dgamma.data_ptr()), int(dbeta.data_ptr()),
-                  [dy, dy2, x, r, rmask, gamma, mean, rstd, dx, dr])
-
-    def add(self, a, b, y):
-        if a.numel() % 4:
-            raise _lib.VsError("TxStack.add: numel % 4 == 0")
-        self._add(7, 0, a.numel() // 4, 0, 0, 0, [a, b, y])
-
-    # pinned staging slots for the tables, allocated once (a pinned allocation is not allowed while a stream
-    # captures): eager runs cycle through them, a slot handed out during a capture is never reused
-    SLOT_STAGES, NSLOTS = 128, 96
-    _pin = {"buf": None, "next": 0, "frozen": set()}
-
-    @classmethod
-    def _slot(cls, n):
-        if n > cls.SLOT_STAGES:
-            raise _lib.VsError(f"TxStack: at most {cls.SLOT_STAGES} stages per launch")
-        st = cls._pin
-        capturing = torch.cuda.is_current_stream_capturing()
-        if st["buf"] is None:
-            if capturing:
-                raise _lib.VsError("TxStack: run once eagerly before capturing (pinned staging buffer)")
-            st["buf"] = torch.empty((cls.NSLOTS, cls.SLOT_STAGES, 16), dtype=torch.int64).pin_memory()
-        for _ in range(cls.NSLOTS):
-            i = st["next"]
-            st["next"] = (i + 1) % cls.NSLOTS
-            if i not in st["frozen"]:
-                if capturing:
-                    st["frozen"].add(i)
-                return st["buf"][i, :n]
-        raise _lib.VsError("TxStack: every pinned staging slot belongs to a captured graph")
-
-    def run(self):
-        n = len(self.rows)
-        if self.table is None:
-            # the software grid barrier needs EVERY block resident at once (a plain launch, no cooperative check): one
-            # block per CU, so the device must have at least GRID CUs and the staging area must fit one CU's LDS
-            cus = torch.cuda.get_device_properties(self.device).multi_processor_count
-            if cus < self.GRID or self.smem > 160 * 1024:
-                raise _lib.VsError(f"TxStack: {self.GRID} resident blocks of {self.smem} B LDS need {self.GRID} CUs "
-                                   f"with 160 KiB each; this device has {cus}")
-            self.host = self._slot(n)
-            self.host.copy_(torch.tensor(self.rows, dtype=torch.int64))
-            self.table = torch.empty((n, 16), dtype=torch.int64, device=self.device)
-            self.bars = torch.empty(n * 129 + 16, dtype=torch.int32, device=self.device)
-        self.table.copy_(self.host, non_blocking=True)
-        _lib.call("vs_txenc_stack_run", _ptr(self.table), n, _ptr(self.bars), self.GRID, int(self.smem), _stream())
-
-    def failed(self):
-        """True if a barrier of a past run gave up (synchronises)."""
-        return bool(int(self.bars[len(self.rows)].item()) != 0)
-
-
 def add_layernorm_fwd(x, r, gamma, beta, eps=1e-5, rmask=None):
     x = _f32c(x)
     r = _f32c(r) if r is not None else None
@@ -1172,34 +1002,6 @@ def add_layernorm_bwd(dy, x, r, gamma, mean, rstd, rmask=None, dg_out=None, db_o
     _lib.call("vs_add_layernorm_bwd", _ptr(dy), _ptr(x), _ptr(r), _ptr(rmask), _ptr(gamma),
               _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dr), _ptr(dg), _ptr(db), rows, d, _stream())
     return dx, (dr if dr is not None else dx), dg, db
-
-
-def ln_linear_ok(rows, d):
-    """The shapes vs_ln_linear_fwd / vs_ln_bwd_linear_bwd take (the encoder's token rows)."""
-    return rows <= 8 and d % 4 == 0 and d <= 1024
-
-
-def ln_linear_fwd(x, r, gamma, beta, eps, rmask, y_ln, mean, rstd, w, b, relu):
-    """y_ln = LayerNorm(x + r * rmask) (written with mean / rstd into the given tensors) and act(y_ln @ w^T + b) as one
-    launch; bitwise add_layernorm_fwd + linear_fwd."""
-    rows, d = x.shape
-    n = w.shape[0]
-    y = torch.empty((rows, n), dtype=torch.float32, device=x.device)
-    _lib.call("vs_ln_linear_fwd", _ptr(x), _ptr(r), _ptr(rmask), _ptr(gamma), _ptr(beta), float(eps), _ptr(y_ln),
-              _ptr(mean), _ptr(rstd), _ptr(w), _ptr(b), _ptr(y), rows, n, d, int(relu), _stream())
-    return y
-
-
-def ln_bwd_linear_bwd(dy, x_ln, r, gamma, mean, rstd, rmask, dx_ln, dgamma, dbeta, x_lin, wt, dw, db):
-    """LayerNorm backward (dx_ln, dgamma, dbeta written into the given tensors) + both gradients of the linear whose
-    output gradient is dx_ln * rmask, as one launch; bitwise add_layernorm_bwd + linear_bwd.  Returns dx_lin."""
-    rows, d = x_ln.shape
-    k = x_lin.shape[1]
-    dx_lin = torch.empty((rows, k), dtype=torch.float32, device=dy.device)
-    _lib.call("vs_ln_bwd_linear_bwd", _ptr(dy), _ptr(x_ln), _ptr(r), _ptr(rmask), _ptr(gamma), _ptr(mean),
-              _ptr(rstd), _ptr(dx_ln), _ptr(dgamma), _ptr(dbeta), _ptr(x_lin), _ptr(wt), _ptr(dx_lin), _ptr(dw),
-              _ptr(db), rows, d, k, _stream())
-    return dx_lin
 
 
 def softmax_xent(logits, labels, want_grad=True):

@@ -287,16 +287,9 @@ class _Unit:
             y, partials = ops.conv_fwd_aol(x, conv.w_bf16, x_affine[0], x_affine[1], stats=True)
         else:
             y, partials = ops.conv_fwd(x, conv.w_bf16, conv.k, conv.s, conv.p, stats=True)
-        # the apply pass finalizes for itself where the partial-row count allows it (ops.bn_apply_fin: no finalize
-        # launch on the chain); the pooled stems and debug traces keep the separate launches
-        # (a conv with a bias keeps the separate finalize: its running-mean correction below must come AFTER the
-        #  finalize's momentum update -- applied before the in-kernel update it would be scaled by 1 - momentum)
-        fin_fused = (not pool and not no_apply and _Unit.trace is None and y.is_cuda and conv.bias is None
-                     and ops.bn_fin_fusable(partials.shape[0], y.shape[1]))
-        if not fin_fused:
-            scale, shift, mean, invstd = ops.bn_finalize(
-                partials, ops.act_rows(y), bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                bn.momentum, bn.eps, train=True)
+        scale, shift, mean, invstd = ops.bn_finalize(
+            partials, ops.act_rows(y), bn.weight, bn.bias, bn.running_mean, bn.running_var,
+            bn.momentum, bn.eps, train=True)
         if conv.bias is not None:
             # train-mode BN removes a per-channel constant exactly, so the conv ran without its bias;
             # only the running mean sees it: mean(conv + b) = mean(conv) + b
@@ -317,10 +310,7 @@ class _Unit:
             return pooled
         want_bits = relu and residual is not None and y.shape[1] % 8 == 0 and \
             ((y.shape[1] // 8) & (y.shape[1] // 8 - 1)) == 0
-        if fin_fused:
-            z, zbits, mean, invstd = ops.bn_apply_fin(partials, ops.act_rows(y), bn, y, residual, relu, out=out,
-                                                      want_bits=want_bits)
-        elif want_bits:
+        if want_bits:
             z, zbits = ops.bn_apply(y, scale, shift, residual, relu, out=out, want_bits=True)
         else:
             z, zbits = ops.bn_apply(y, scale, shift, residual, relu, out=out), None
