@@ -130,7 +130,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, c
   if (MODE != 0) {
     const int C8 = p.Cg >> 3;
     const float rcpC8 = 1.0f / (float)C8, rcpkW = 1.0f / (float)p.kW, rcpkH = 1.0f / (float)p.kH;
-    const int K8pad = (((Keff + 63) >> 6) + (NS > 0 ? NS - 1 : 0)) << 3;  // + the ring's run-ahead
+    const int K8pad = (((Keff + 63) >> 6) + (NS > 0 ? NS : 0)) << 3;  // + the ring's run-ahead + the entry read one k-step early
     for (int k8 = tid; k8 < K8pad; k8 += 256) {
       if (k8 >= K8) {  // K tail: tap 31 is never valid (FAST requires <= 31 taps)
         ktab[k8] = FAST ? make_int2(31, 0) : make_int2(0, 0);
@@ -478,11 +478,13 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, c
                    : "s"(lds_addr), "v"(voff), "s"(desc)
                    : "memory");
     };
-    auto dma = [&](int kt, int stage) __attribute__((always_inline)) {
+    // (e: the k-table entry of (kt, this thread's unit) for the gathering modes -- handed in, so that the ring loop can read
+    //  the NEXT k-step's entry behind this step's copies instead of in front of them: one LDS round trip per k-step off
+    //  the copy-issue path)
+    auto dma_e = [&](int kt, int stage, int2 e) __attribute__((always_inline)) {
       const int k8 = kt * 8 + kce;
       const bool kval = k8 < K8;
-      int2 e = make_int2(0, k8 * 16);
-      if (MODE != 0) e = ktab[k8];
+      if (MODE == 0) e = make_int2(0, k8 * 16);
       const unsigned kbit = (MODE == 0) ? (unsigned)kval : 1u;
       const unsigned wk = (MODE == 0) ? (unsigned)k8 : ((unsigned)e.x >> 5);
       const unsigned A = lds0 + (unsigned)(stage * STAGE);
@@ -500,8 +502,15 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, c
         dma16(wdesc, B + j * 4096, off);
       }
     };
+    auto dma = [&](int kt, int stage) __attribute__((always_inline)) {
+      int2 e = make_int2(0, 0);
+      if (MODE != 0) e = ktab[kt * 8 + kce];
+      dma_e(kt, stage, e);
+    };
 #pragma unroll
     for (int d = 0; d < D; ++d) dma(kbeg + d, d);
+    int2 e_next = make_int2(0, 0);
+    if (MODE != 0) e_next = ktab[(kbeg + D) * 8 + kce];
     int st_c = 0, st_l = D;  // stage computed / stage refilled this step
     for (int kt = 0; kt < nk; ++kt) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"i"((D - 1) * L) : "memory");  // my part of tile kt landed
@@ -510,7 +519,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, c
       // (one straight-line body: a second, "fragment reads first" order of this step lived here behind a run-time
       //  switch until round 4 -- measured useless in round 2 (profiles/r02_ring_frags_first.txt), and its mere presence
       //  made hipcc move all 64 accumulator registers at the top of every k-step)
-      dma(kbeg + kt + D, st_l);
+      dma_e(kbeg + kt + D, st_l, e_next);
+      if (MODE != 0) e_next = ktab[(kbeg + kt + D + 1) * 8 + kce];  // (the table is padded one k-step past the ring's run-ahead)
       __builtin_amdgcn_sched_barrier(0);
       if (AOL) aol_k0 = (kbeg + kt) * 64;
       compute(st_c);
@@ -1428,7 +1438,7 @@ static int launch_mode(const ConvP& p, int mode, int grid, size_t smem, hipStrea
 static size_t conv_smem_bytes(int bm, int bn, int wm, int ns, int mode, int K) {
   const size_t stage = (size_t)(bm + bn) * 128, epi = (size_t)bm * bn * 4;
   const size_t ring = (size_t)(ns > 2 ? ns : 2) * stage;
-  const size_t tab = mode ? (size_t)(((K + 63) >> 6) + (ns > 0 ? ns - 1 : 0)) * 64 : 0;
+  const size_t tab = mode ? (size_t)(((K + 63) >> 6) + (ns > 0 ? ns : 0)) * 64 : 0;
   const size_t rowpos = mode == 2 ? (size_t)bm * 4 : 0;
   return (ring > epi ? ring : epi) + (size_t)8 * wm * bn * 4 + rowpos + tab;
 }

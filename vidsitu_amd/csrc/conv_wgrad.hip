@@ -395,6 +395,17 @@ __device__ __forceinline__ void conv_wgrad_ring_body(const WgradP& p, const int 
     const unsigned A = lds0 + (unsigned)(stage * STAGE);
     const unsigned B = A + IMG;
     const int rel0 = st * ROWS + 4 * wv + rg;  // position of row group 0, relative to pbeg
+    // the row-table entries of all RG row groups are read BEFORE the first copy is issued: the copies are asm
+    // statements with a memory clobber, so a table read placed between two of them stays there -- four dependent
+    // ds_read -> wait -> copy round trips per k-step (round 4, read off the loop's ISA)
+    int2 ent[RG];
+    if (MODE == 1) {
+#pragma unroll
+      for (int i = 0; i < RG; ++i) {
+        const int rel = rel0 + 16 * i;
+        ent[i] = rowtab[((rel >> 10) & 1) * WG_ROWTAB + (rel & (WG_ROWTAB - 1))];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < RG; ++i) {
       const int rel = rel0 + 16 * i;
@@ -411,9 +422,8 @@ __device__ __forceinline__ void conv_wgrad_ring_body(const WgradP& p, const int 
       if (MODE == 0) {
         off = (unsigned)pp * x_pitch + xtap;
       } else {
-        const int2 e = rowtab[((rel >> 10) & 1) * WG_ROWTAB + (rel & (WG_ROWTAB - 1))];
-        ok &= ((unsigned)e.y >> tap) & 1u;
-        off = (unsigned)e.x + xtap;
+        ok &= ((unsigned)ent[i].y >> tap) & 1u;
+        off = (unsigned)ent[i].x + xtap;
       }
       dma16(xdesc, B + i * 4096, ok ? off : WG_OOB);
     }
@@ -639,9 +649,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_deep_kernel(WgradP p) {
       const int rel = u * 32 + (STAG ? wv * 4 : j * 16 + wq * 4) + rg;  // position relative to pbeg
       const int pp = pbeg + rel;
       const bool pok = pp < pend;
-      dma16(dydesc, U + j * 4096, (mcol_ok && pok) ? (unsigned)pp * dy_pitch + dycol : WG_OOB);
-      int2 e = make_int2(0, 0);
+      int2 e = make_int2(0, 0);  // (read before the first copy: the copies are asm statements with a memory clobber)
       if (MODE == 1) e = rowtab[((rel >> 9) & 1) * WGD_TAB + (rel & (WGD_TAB - 1))];
+      dma16(dydesc, U + j * 4096, (mcol_ok && pok) ? (unsigned)pp * dy_pitch + dycol : WG_OOB);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         unsigned ok = (unsigned)ncol_ok[i] & (unsigned)pok;
