@@ -963,11 +963,14 @@ static bool wg_deep_plan(const vs_conv_desc* d, WgCfg* c) {
   rps = (rps + 31) / 32 * 32;
   S = (P + rps - 1) / rps;
   if (!force && (row_eff < 0.9 || col_eff < 0.75 || tiles * S < 128 || tiles > 256 || rps < 512)) return false;
-  // Fewer than ~40 000 positions (every slow-pathway s4 / s5 layer at 8 clips per GPU): alone the kernel is 1.03-1.38x
-  // the ring kernel's speed there, but the STEP is 0.4 % slower with it (12.18-12.29 vs 12.13-12.23 ms, alternating,
-  // with and without pair launches: profiles/r04_wgrad_deep.txt) -- one 152-KiB block per CU shares no CU with the data
-  // gradient that runs beside it, where the ring kernel's 64-80 KiB blocks do.  From 32 clips on the step gains 2.5 %.
-  static const long long min_p = [] { const char* e = getenv("VS_WGRAD_DEEP_MINP"); return e ? atoll(e) : 40000ll; }();
+  // Position floor.  Mid-round 4 the slow-pathway s4 / s5 layers at 8 clips per GPU (12 544 / 3 136 positions) LOST with
+  // this kernel in the step (-0.4 %, floor 40 000: profiles/r04_wgrad_deep.txt) although it was 1.03-1.38x the ring
+  // kernel alone -- one 152-KiB block per CU shares no CU with the data gradient beside it.  After the round's later
+  // fixes (row-table entries read before the copy statements, the column-form slab reduce, the ring loop of the paired
+  // data gradient without accumulator moves) the same A/B reads +0.5-0.7 % with them on the deep kernel (floor 10 000:
+  // 668.3-669.9 vs 662.1-666.5 clips/s; floor 3 000: another +0.2 %; 0 = 3 000; VS_WGRAD_DEEP=2 everywhere: -2.7 %;
+  // profiles/r04_wgrad_deep_floor.txt).  From 32 clips on the step gains 2.5 %.
+  static const long long min_p = [] { const char* e = getenv("VS_WGRAD_DEEP_MINP"); return e ? atoll(e) : 3000ll; }();
   if (!force && P < min_p) return false;
   if (tiles * S > 65535) return false;
   c->bm = 128;
