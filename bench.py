@@ -139,7 +139,7 @@ class EntryProbe:
                 flops = 2.0 * mo * d.Cout * d.Cin * taps
                 byts = 2.0 * (mi * d.Cin + mo * d.Cout + d.Cout * d.Cin * taps)
                 if name == "vs_conv_wgrad":
-                    return "conv_wgrad (conv_wgrad_ring_kernel | conv_wgrad_kernel, + wgrad_reduce_kernel)", "mfma", flops, byts
+                    return "conv_wgrad (conv_wgrad_ring_kernel | conv_wgrad_deep_kernel | conv_wgrad_kernel, + wgrad_reduce_kernel)", "mfma", flops, byts
                 if name == "vs_conv_fwd" and (d.flags & 2):
                     byts += 2.0 * mo * d.Cout
                 if name == "vs_conv_dgrad_bnstats":  # + the producer's saved conv output, read by the epilogue

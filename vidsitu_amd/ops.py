@@ -211,8 +211,9 @@ def conv_aol_ok(x, cout, stats=True):
     its weight gradient can (conv_wgrad_aol): both or neither, the activation is then never stored."""
     ys = conv_out_shape(x.shape, cout, _K1, _S1, _P0)
     d = make_desc(x.shape, act_ld(x), ys, cout, _K1, _S1, _P0, VS_CONV_STATS if stats else 0)
+    dw = make_desc(x.shape, act_ld(x), ys, cout, _K1, _S1, _P0, VS_WGRAD_NODEEP)  # (the transform lives in the ring kernel)
     lib = _lib.load()
-    return bool(lib.vs_conv_aol_ok(C.byref(d))) and bool(lib.vs_conv_wgrad_aol_ok(C.byref(d)))
+    return bool(lib.vs_conv_aol_ok(C.byref(d))) and bool(lib.vs_conv_wgrad_aol_ok(C.byref(dw)))
 
 
 def conv_fwd_aol(x, w, in_scale, in_shift, out=None, stats=True):
@@ -243,7 +244,7 @@ def conv_wgrad_aol(dy, x, in_scale, in_shift, out=None):
         out = torch.empty((cout, 1, 1, 1, cin), dtype=torch.float32, device=x.device).permute(0, 4, 1, 2, 3)
     elif not out.permute(0, 2, 3, 4, 1).is_contiguous() or out.dtype != torch.float32:
         raise _lib.VsError("conv_wgrad out must be fp32 with [Cout][taps][Cin] memory")
-    d = make_desc(x.shape, act_ld(x), dy.shape, act_ld(dy), _K1, _S1, _P0, 0)
+    d = make_desc(x.shape, act_ld(x), dy.shape, act_ld(dy), _K1, _S1, _P0, VS_WGRAD_NODEEP)  # ring kernel: it has the transform
     need = _lib.load().vs_conv_wgrad_workspace_bytes(C.byref(d))
     ws = _workspace(need, x.device, "wgrad") if need else None
     _lib.call("vs_conv_wgrad_aol", _ptr(dy), _ptr(x), _ptr(out), C.byref(d), _ptr(in_scale), _ptr(in_shift),
@@ -470,6 +471,7 @@ def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=N
 
 
 _ws_cache = {}
+VS_WGRAD_NODEEP = 1 << 12  # include/vidsitu_hip.h: keep a weight gradient off the deep-pipeline kernel
 import os as _os_wi
 _WHATIF_WGRAD = (int(_os_wi.environ.get("VS_WHATIF", "0")) & 4) != 0  # tools only (see conv_wgrad)
 
