@@ -789,6 +789,10 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_wgrad_reduce_kernel(cons
     double (*sh_s)[33] = (double (*)[33])lds;
     double (*sh_q)[33] = (double (*)[33])(lds + 32 * 33 * 8);
     bn_bwd_finalize_body(partial, nparts, dgamma, dbeta, C, blockIdx.x, sh_s, sh_q);
+  } else if (wgrad_reduce_cols(n, S)) {
+    // column form: ONE 256-column virtual block per block (the other 12 waves leave at once) -- four of them packed
+    // into a 1024-thread block put a 590 K-element, 14-slab reduce on 144 CUs, and a CU takes in ~30 GB/s from beyond L2
+    if (threadIdx.x < 256) wgrad_reduce_body(slabs, dw, n, S, nullptr, (long long)(blockIdx.x - g1), threadIdx.x);
   } else {
     float4 (*part)[17] = (float4 (*)[17])(lds + (threadIdx.x >> 8) * 16 * 17 * 16);
     wgrad_reduce_body(slabs, dw, n, S, part, (long long)(blockIdx.x - g1) * 4 + (threadIdx.x >> 8), threadIdx.x & 255);
@@ -802,7 +806,8 @@ extern "C" int vs_bn_bwd_finalize(const float* partial, int nparts, float* dgamm
   const int g1 = (C + 31) / 32;
   if (vs_pending_reduce_take((hipStream_t)stream, &pr)) {
     const long long rb = wgrad_reduce_vblocks(pr.n, pr.S);  // 256-thread virtual blocks of the reduce
-    hipLaunchKernelGGL(bn_bwd_finalize_wgrad_reduce_kernel, dim3((unsigned)(g1 + (rb + 3) / 4)), dim3(1024), 0,
+    const long long rblocks = wgrad_reduce_cols(pr.n, pr.S) ? rb : (rb + 3) / 4;
+    hipLaunchKernelGGL(bn_bwd_finalize_wgrad_reduce_kernel, dim3((unsigned)(g1 + rblocks)), dim3(1024), 0,
                        (hipStream_t)stream, partial, nparts, dgamma, dbeta, C, g1, pr.slabs, pr.dw, pr.n, pr.S);
   } else {
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(g1), dim3(1024), 0, (hipStream_t)stream, partial, nparts, dgamma,
