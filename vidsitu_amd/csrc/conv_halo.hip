@@ -244,21 +244,40 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvP p, HaloGeo q) {
 
   bf16x8 fa0[MRW], fb0[NRW], fa1[MRW], fb1[NRW];
   if constexpr (TAPS > 0) {
-    // every A-fragment byte offset (ks = 0) inside an image buffer, per tap
-    unsigned aaddr[TAPS][MRW];
+    // every A-fragment byte offset (ks = 0) inside an image buffer, per tap -- two 16-bit offsets per register
+    // (an image buffer is HALO_RA_MAX x 128 B = 44 KiB): 9 x 7 full words were 63 VGPRs of a 256-VGPR wave and the
+    // 224-row tiles spilled 6-7 registers (a private segment = ~3 us more per launch, tools/probes/scratch_dispatch.hip)
+    static_assert(HALO_RA_MAX * 128 <= 65536, "16-bit fragment offsets");
+    constexpr int MP = (MRW + 1) / 2;
+    unsigned aaddr[TAPS][MP];
 #pragma unroll
     for (int tp = 0; tp < TAPS; ++tp) {
       const int toff = tap_offset();
       next_tap();
 #pragma unroll
-      for (int a = 0; a < MRW; ++a) {
-        const unsigned R = (unsigned)(arow[a] + toff);
-        aaddr[tp][a] = (R << 7) + ((lq ^ ((R >> 1) & 7u)) << 4);
+      for (int a2 = 0; a2 < MP; ++a2) {
+        unsigned pk = 0u;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int a = a2 * 2 + h;
+          if (a < MRW) {
+            const unsigned R = (unsigned)(arow[a] + toff);
+            pk |= ((R << 7) + ((lq ^ ((R >> 1) & 7u)) << 4)) << (16 * h);
+          }
+        }
+        aaddr[tp][a2] = pk;
       }
     }
     auto loadA = [&](const char* A, const unsigned* aa, unsigned x, bf16x8* af) __attribute__((always_inline)) {
 #pragma unroll
-      for (int a = 0; a < MRW; ++a) af[a] = *(const bf16x8*)(A + (aa[a] ^ x));
+      for (int a = 0; a < MRW; ++a) {
+        // (unpacked by an asm statement: written in C the compiler hoists all 63 unpacked offsets out of the tap loop
+        //  again -- 69-72 spilled registers instead of 6-7)
+        unsigned off;
+        if (a & 1) asm volatile("v_lshrrev_b32 %0, 16, %1" : "=v"(off) : "v"(aa[a >> 1]));
+        else asm volatile("v_and_b32 %0, 0xffff, %1" : "=v"(off) : "v"(aa[a >> 1]));
+        af[a] = *(const bf16x8*)(A + (off ^ x));
+      }
     };
     auto loadB = [&](const char* B, unsigned x, bf16x8* bfr) __attribute__((always_inline)) {
 #pragma unroll
