@@ -1006,6 +1006,41 @@ def test_batched_wgrad_slab_reduce_is_bitwise_the_per_layer_reduce(dev):
     assert n_pending >= 2, "expected several split layers in the batch"
 
 
+@pytest.mark.parametrize("S,n", [(2, 4096), (3, 40), (16, 40000), (17, 140000), (22, 262144), (64, 131072), (65, 131072),
+                                 (14, 589824), (349, 1024), (1024, 2048)])
+def test_slab_reduce_forms_are_bitwise_equal(S, n, dev):
+    """vs_wgrad_reduce picks a thread mapping by (S, n) -- one thread per float4 column for S <= 16 and for S <= 64 on
+    >= 32 768 columns, 16 slices per column through LDS otherwise -- and promises the slice form's additions in the
+    slice form's order.  The batched kernel (vs_wgrad_reduce_batched) always runs the slice form: bit for bit, signs of
+    zero and special values included; and against an fp64 sum."""
+    from vidsitu_amd import ops
+    import ctypes as C
+
+    lib = ops._lib.load()
+    g = torch.Generator().manual_seed(1000 + S)
+    slabs = (torch.randn(S, n, generator=g) * 3.0)
+    slabs[:, : min(n, 64)] = 0.0
+    slabs[0, : min(n, 32)] = -0.0          # a column of -0.0 + 0.0 ...: the sign of the sum depends on the form's extra + 0.0
+    if n > 200:
+        slabs[:, 100:104] = -0.0            # all slabs -0.0
+        slabs[S // 2, 150] = float("inf")
+        slabs[S - 1, 160] = 1e30
+        slabs[0, 160] = -1e30
+    slabs = slabs.to(dev)
+    a = torch.full((n,), float("nan"), device=dev)
+    b = torch.full((n,), float("nan"), device=dev)
+    ops._lib.call("vs_wgrad_reduce", ops._ptr(slabs), ops._ptr(a), n, S, ops._stream())
+    blocks = int(lib.vs_wgrad_reduce_blocks(n))
+    table = torch.tensor([[slabs.data_ptr(), b.data_ptr(), n, S, 0]], dtype=torch.int64, device=dev)
+    ops._lib.call("vs_wgrad_reduce_batched", ops._ptr(table), 1, blocks, ops._stream())
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32)), f"S={S} n={n}: the two forms differ in bits"
+    ref = slabs.double().sum(0)
+    fin = torch.isfinite(ref)
+    err = (a.double() - ref)[fin].abs().max() / slabs.double().abs().sum(0)[fin].max().clamp_min(1.0)
+    assert float(err) < 1e-6
+
+
 # name, N, Cin, T, H, W, Cout, stride   (1x1x1, no padding): shapes the persistent pointwise kernel takes
 PW_CASES = [
     ("s2c_64_256", 2, 64, 8, 56, 56, 256, (1, 1, 1)),
