@@ -341,6 +341,22 @@ static inline int ew_grid(long long total) {
   return (int)g;
 }
 
+// 16-byte load of a tensor an APPLY pass reads for the last time in a while (the raw convolution output y, the incoming
+// gradient dz): a non-temporal load, so that the stream does not push the pass's OUTPUT -- which the next kernel reads --
+// out of L2 / Infinity Cache.  (-DVS_BN_NT=0 restores plain loads: A/B.)  The REDUCE passes keep plain loads: the apply
+// pass behind them reads the same tensors again.
+#ifndef VS_BN_NT
+#define VS_BN_NT 1
+#endif
+__device__ __forceinline__ uint4 ld_stream16(const uint16_t* p) {
+#if VS_BN_NT
+  const u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+#else
+  return *(const uint4*)p;
+#endif
+}
+
 // Column-owner form (C/8 a power of two): a thread keeps the scale / shift of ITS 8 channels in
 // registers and walks rows in batches of 4 with every load of a batch in flight before the first
 // use; no per-element 64-bit division, no per-element parameter reloads.
@@ -391,7 +407,7 @@ __global__ __launch_bounds__(256) void bn_apply_cols_kernel(const uint16_t* y, c
       for (int u = 0; u < BNA_BATCH; ++u) {
         row[u] = r0 + (long long)(b * BNA_BATCH + u) * rl + lane_r;
         const long long rr = row[u] < rows ? row[u] : 0;
-        vy[u] = *(const uint4*)(y + rr * y_ld + c);
+        vy[u] = ld_stream16(y + rr * y_ld + c);
         if (RES) vr[u] = *(const uint4*)(res + rr * res_ld + c);
       }
 #pragma unroll
@@ -907,8 +923,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cols_kernel(
       for (int u = 0; u < BNA_BATCH; ++u) {
         row[u] = r0 + (long long)(b * BNA_BATCH + u) * rl + lane_r;
         const long long rr = row[u] < rows ? row[u] : 0;
-        vg[u] = POOL ? pool_grad8(ps, (int)rr, c, C) : *(const uint4*)(dz + rr * dz_ld + c);
-        vy[u] = *(const uint4*)(y + rr * y_ld + c);
+        vg[u] = POOL ? pool_grad8(ps, (int)rr, c, C) : ld_stream16(dz + rr * dz_ld + c);
+        vy[u] = ld_stream16(y + rr * y_ld + c);
         if (MASK == 1) vz[u] = *(const uint4*)(z + rr * z_ld + c);
         if (MASK == 3) vz[u].x = ((const uint8_t*)z)[rr * cpr + cb];
       }
