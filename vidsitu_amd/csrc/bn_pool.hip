@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void bn_apply_cols_kernel(const uint16_t* y, c
         row[u] = r0 + (long long)(b * BNA_BATCH + u) * rl + lane_r;
         const long long rr = row[u] < rows ? row[u] : 0;
         vy[u] = ld_stream16(y + rr * y_ld + c);
-        if (RES) vr[u] = *(const uint4*)(res + rr * res_ld + c);
+        if (RES) vr[u] = ld_stream16(res + rr * res_ld + c);  // (the block's input: its last reader of the forward pass)
       }
 #pragma unroll
       for (int u = 0; u < BNA_BATCH; ++u) {
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void bn_apply_cols_kernel(const uint16_t* y, c
           *(uint4*)(out + row[u] * out_ld + c) = pack8_bf16(v);
           // ReLU mask as one bit per element: the backward passes read it instead of the 16x
           // larger output tensor
-          if (RELU && bits) bits[row[u] * cpr + cb] = (uint8_t)mbits;
+          if (RELU && bits) __builtin_nontemporal_store((uint8_t)mbits, bits + row[u] * cpr + cb);  // (read in the backward pass)
         }
       }
     }
@@ -925,8 +925,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cols_kernel(
         const long long rr = row[u] < rows ? row[u] : 0;
         vg[u] = POOL ? pool_grad8(ps, (int)rr, c, C) : ld_stream16(dz + rr * dz_ld + c);
         vy[u] = ld_stream16(y + rr * y_ld + c);
-        if (MASK == 1) vz[u] = *(const uint4*)(z + rr * z_ld + c);
-        if (MASK == 3) vz[u].x = ((const uint8_t*)z)[rr * cpr + cb];
+        if (MASK == 1) vz[u] = ld_stream16(z + rr * z_ld + c);
+        if (MASK == 3) vz[u].x = __builtin_nontemporal_load((const uint8_t*)z + rr * cpr + cb);
       }
 #pragma unroll
       for (int u = 0; u < BNA_BATCH; ++u) {

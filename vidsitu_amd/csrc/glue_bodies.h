@@ -5,6 +5,14 @@
 #pragma once
 #include "common.h"
 
+// A slab row is read exactly once (by this reduce) after the weight-gradient kernel wrote it: non-temporal loads keep
+// the 20-30 MB of a wide layer's slabs from evicting what the kernels behind the reduce read (profiles/r04_nontemporal.txt).
+__device__ __forceinline__ float4 ld_slab4(const float* p) {
+  typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+  const f32x4_t v = __builtin_nontemporal_load((const f32x4_t*)p);
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // The reduce below has two thread mappings with the SAME arithmetic; this picks one (host and device agree through it).
 // Column form: one thread per float4 column walks all S slabs -- whole 4-KiB rows per wave, no LDS.  It needs columns
 // to spread over the chip, so: every split of <= 16 (each convolution layer of the slow pathway) and splits up to 64
@@ -44,7 +52,7 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* slabs, float* dw,
       float4 v[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u)
-        if (s0 + u < S) v[u] = *(const float4*)(src + (long long)(s0 + u) * n);
+        if (s0 + u < S) v[u] = ld_slab4(src + (long long)(s0 + u) * n);
 #pragma unroll
       for (int u = 0; u < 16; ++u)
         if (s0 + u < S) {
@@ -78,7 +86,7 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* slabs, float* dw,
 #pragma unroll
       for (int u = 0; u < 16; ++u) {  // branch-free: a clamped address, the value dropped below
         const int su = min(s + u, s1 - 1);
-        v[u] = *(const float4*)(src + (long long)su * n);
+        v[u] = ld_slab4(src + (long long)su * n);
       }
 #pragma unroll
       for (int u = 0; u < 16; ++u)
