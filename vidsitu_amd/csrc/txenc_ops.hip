@@ -1529,6 +1529,19 @@ __global__ void adam_dev_kernel(float* p, const void* gv, float* m, float* v, ui
   // Two float4 groups per thread and iteration, all eight loads issued before the first use: with one group (four
   // loads, then ~40 dependent VALU instructions incl. a divide and a square root per element, then the stores) the
   // kernel moved its 1.1 GB at 2.4 TB/s.  Same arithmetic per element, same results bit for bit.
+  // The gradient is read for the last time and the moments are touched by nobody until the next step's update: non-
+  // temporal loads / stores keep this 2.3 GB stream from flushing the parameters (and their bf16 image) it writes --
+  // which the next step's first kernels read -- out of the Infinity Cache (profiles/r04_nontemporal.txt).
+  typedef __attribute__((ext_vector_type(4))) float nt_f4;
+  typedef __attribute__((ext_vector_type(2))) unsigned nt_u2;
+  auto ldnt = [](const float* q, long long i) __attribute__((always_inline)) {
+    const nt_f4 t = __builtin_nontemporal_load((const nt_f4*)q + i);
+    return make_float4(t[0], t[1], t[2], t[3]);
+  };
+  auto stnt = [](float* q, long long i, float a0, float a1, float a2, float a3) __attribute__((always_inline)) {
+    const nt_f4 t = {a0, a1, a2, a3};
+    __builtin_nontemporal_store(t, (nt_f4*)q + i);
+  };
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += 2 * stride) {
     const long long i1 = i0 + stride;
@@ -1536,7 +1549,8 @@ __global__ void adam_dev_kernel(float* p, const void* gv, float* m, float* v, ui
     const long long j1 = two ? i1 : i0;
     float gg[2][4];
     if (G16) {
-      const uint2 ga = ((const uint2*)gv)[i0], gb = ((const uint2*)gv)[j1];
+      const nt_u2 ga_ = __builtin_nontemporal_load((const nt_u2*)gv + i0), gb_ = __builtin_nontemporal_load((const nt_u2*)gv + j1);
+      const uint2 ga = make_uint2(ga_[0], ga_[1]), gb = make_uint2(gb_[0], gb_[1]);
       gg[0][0] = __uint_as_float(ga.x << 16) * grad_scale;
       gg[0][1] = __uint_as_float(ga.x & 0xffff0000u) * grad_scale;
       gg[0][2] = __uint_as_float(ga.y << 16) * grad_scale;
@@ -1546,12 +1560,12 @@ __global__ void adam_dev_kernel(float* p, const void* gv, float* m, float* v, ui
       gg[1][2] = __uint_as_float(gb.y << 16) * grad_scale;
       gg[1][3] = __uint_as_float(gb.y & 0xffff0000u) * grad_scale;
     } else {
-      const float4 ga = ((const float4*)gv)[i0], gb = ((const float4*)gv)[j1];
+      const float4 ga = ldnt((const float*)gv, i0), gb = ldnt((const float*)gv, j1);
       gg[0][0] = ga.x * grad_scale; gg[0][1] = ga.y * grad_scale; gg[0][2] = ga.z * grad_scale; gg[0][3] = ga.w * grad_scale;
       gg[1][0] = gb.x * grad_scale; gg[1][1] = gb.y * grad_scale; gg[1][2] = gb.z * grad_scale; gg[1][3] = gb.w * grad_scale;
     }
-    const float4 ma = ((float4*)m)[i0], va = ((float4*)v)[i0], pa = ((float4*)p)[i0];
-    const float4 mb = ((float4*)m)[j1], vb = ((float4*)v)[j1], pq = ((float4*)p)[j1];
+    const float4 ma = ldnt(m, i0), va = ldnt(v, i0), pa = ((float4*)p)[i0];
+    const float4 mb = ldnt(m, j1), vb = ldnt(v, j1), pq = ((float4*)p)[j1];
     float mm[2][4] = {{ma.x, ma.y, ma.z, ma.w}, {mb.x, mb.y, mb.z, mb.w}};
     float vv[2][4] = {{va.x, va.y, va.z, va.w}, {vb.x, vb.y, vb.z, vb.w}};
     float pp[2][4] = {{pa.x, pa.y, pa.z, pa.w}, {pq.x, pq.y, pq.z, pq.w}};
@@ -1564,13 +1578,13 @@ __global__ void adam_dev_kernel(float* p, const void* gv, float* m, float* v, ui
         const float denom = sqrtf(vv[u][e]) / bc2_sqrt + eps;
         pp[u][e] -= a * (mm[u][e] / denom);
       }
-    ((float4*)m)[i0] = make_float4(mm[0][0], mm[0][1], mm[0][2], mm[0][3]);
-    ((float4*)v)[i0] = make_float4(vv[0][0], vv[0][1], vv[0][2], vv[0][3]);
+    stnt(m, i0, mm[0][0], mm[0][1], mm[0][2], mm[0][3]);
+    stnt(v, i0, vv[0][0], vv[0][1], vv[0][2], vv[0][3]);
     ((float4*)p)[i0] = make_float4(pp[0][0], pp[0][1], pp[0][2], pp[0][3]);
     if (pb) ((uint2*)pb)[i0] = make_uint2(pack2_bf16(pp[0][0], pp[0][1]), pack2_bf16(pp[0][2], pp[0][3]));
     if (two) {
-      ((float4*)m)[i1] = make_float4(mm[1][0], mm[1][1], mm[1][2], mm[1][3]);
-      ((float4*)v)[i1] = make_float4(vv[1][0], vv[1][1], vv[1][2], vv[1][3]);
+      stnt(m, i1, mm[1][0], mm[1][1], mm[1][2], mm[1][3]);
+      stnt(v, i1, vv[1][0], vv[1][1], vv[1][2], vv[1][3]);
       ((float4*)p)[i1] = make_float4(pp[1][0], pp[1][1], pp[1][2], pp[1][3]);
       if (pb) ((uint2*)pb)[i1] = make_uint2(pack2_bf16(pp[1][0], pp[1][1]), pack2_bf16(pp[1][2], pp[1][3]));
     }
