@@ -128,7 +128,12 @@ __device__ __forceinline__ void linear_fullx_body(const float* __restrict__ x, c
   for (int u = 0; u < KC; ++u) {
     const int k4 = u * 64 + lane;
     const bool ok = n < N && k4 < K4;  // branch-free (see linear_rows16_kernel)
-    const float4 v = *(const float4*)(w + (ok ? (long long)n * K + k4 * 4 : 0));
+    // (a weight row is read once per launch and the matrix once per pass: a non-temporal load -- the encoder's 600 MB of
+    //  weight traffic per step otherwise flushes the trunk's last activations out of the Infinity Cache right before
+    //  the backward pass wants them)
+    typedef __attribute__((ext_vector_type(4))) float nt_f4;
+    const nt_f4 vt = __builtin_nontemporal_load((const nt_f4*)(w + (ok ? (long long)n * K + k4 * 4 : 0)));
+    const float4 v = make_float4(vt[0], vt[1], vt[2], vt[3]);
     wv[u] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   // x goes through LDS 1024 columns (one float4 column per thread) at a time: thread t owns column c * 256 + t of
@@ -692,8 +697,10 @@ __device__ __forceinline__ void linear_bwd_weight_body(const float* __restrict__
       }
     }
     float* dst = dw + (long long)n * K + k;
-    if (VEC) {
-      *(float4*)dst = acc;
+    if (VEC) {  // (read next by the optimizer at the end of the step: a non-temporal store)
+      typedef __attribute__((ext_vector_type(4))) float nt_f4;
+      const nt_f4 t = {acc.x, acc.y, acc.z, acc.w};
+      __builtin_nontemporal_store(t, (nt_f4*)dst);
     } else {
       dst[0] = acc.x;
       if (k + 1 < K) dst[1] = acc.y;
