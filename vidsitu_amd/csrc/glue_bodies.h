@@ -13,6 +13,13 @@ __device__ __forceinline__ float4 ld_slab4(const float* p) {
   return make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// dW is read next by the optimizer at the end of the step: a non-temporal store.
+__device__ __forceinline__ void st_dw4(float* p, float4 v) {
+  typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+  const f32x4_t t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, (f32x4_t*)p);
+}
+
 // The reduce below has two thread mappings with the SAME arithmetic; this picks one (host and device agree through it).
 // Column form: one thread per float4 column walks all S slabs -- whole 4-KiB rows per wave, no LDS.  It needs columns
 // to spread over the chip, so: every split of <= 16 (each convolution layer of the slow pathway) and splits up to 64
@@ -72,7 +79,7 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* slabs, float* dw,
     if ((S + per - 1) / per < 16) {  // the slice form adds the empty slices' +0.0 (turns a -0.0 sum into +0.0)
       tt.x += 0.f; tt.y += 0.f; tt.z += 0.f; tt.w += 0.f;
     }
-    *(float4*)(dw + i * 4) = tt;
+    st_dw4(dw + i * 4, tt);
     return;
   }
   const int col = t & 15, sl = t >> 4;
@@ -109,7 +116,7 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* slabs, float* dw,
       tt.z += v.z;
       tt.w += v.w;
     }
-    *(float4*)(dw + i * 4) = tt;
+    st_dw4(dw + i * 4, tt);
   }
 }
 
