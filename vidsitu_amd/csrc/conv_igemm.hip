@@ -2265,13 +2265,15 @@ __global__ __launch_bounds__(256) void weight_transpose_tiled_kernel(const T* __
 #pragma unroll
   for (int r = 0; r < TS; r += RY) {
     const int co = oc * TS + ty + r, ci = ic * TS + tx;
-    if (co < Cout && ci < Cin) tile[ty + r][tx] = src[off + ((long long)co * taps + tap) * Cin + ci];
+    if (co < Cout && ci < Cin) tile[ty + r][tx] = __builtin_nontemporal_load(src + off + ((long long)co * taps + tap) * Cin + ci);
   }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < TS; r += RY) {
     const int ci = ic * TS + ty + r, co = oc * TS + tx;
-    if (ci < Cin && co < Cout) dst[off + ((long long)ci * taps + tap) * Cout + co] = tile[tx][ty + r];
+    // (both sides non-temporal: 1.1 GB per step of layout traffic beside the forward pass, read again only by the data
+    //  gradients of the backward pass)
+    if (ci < Cin && co < Cout) __builtin_nontemporal_store(tile[tx][ty + r], dst + off + ((long long)ci * taps + tap) * Cout + co);
   }
 }
 

@@ -110,6 +110,13 @@ __device__ __forceinline__ void tile_sync() {
   }
 }
 
+// 16-byte non-temporal load: the residual operand of an epilogue (the other branch's gradient / the block's input) is
+// read here for the last time in the pass.
+__device__ __forceinline__ uint4 ld_res16(const uint16_t* q) {
+  const u32x4 v = __builtin_nontemporal_load((const u32x4*)q);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
 template <int BM, int BN, int WM, int WN, bool BNB, bool RAWSYNC = false, bool TWO = false, int EDBG = 0, typename RowMap>
 __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16],
                                                    char* smem, float* statbuf, int tm, int n0, RowMap rowm) {
@@ -327,7 +334,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
         const long long mc = mm[i] >= 0 ? mm[i] : 0;
         yv4[i] = *(const uint4*)(p.bny + mc * p.bny_ld + nn);
         yw4[i] = two ? *(const uint4*)(p.bny2 + mc * p.bny2_ld + nn) : make_uint4(0u, 0u, 0u, 0u);
-        rv4[i] = *(const uint4*)(p.res + mc * p.res_ld + nn);
+        rv4[i] = ld_res16(p.res + mc * p.res_ld + nn);
         bits[i] = p.bn_bits[mc * bpr + (nn >> 3)];
         rbits[i] = p.res_bits ? (unsigned)p.res_bits[mc * bpr + (nn >> 3)] : 0xffu;
       }
@@ -413,7 +420,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
       cm[u] = (m >= 0 && n < p.Ncols) ? m : -1;
       const long long mc = cm[u] >= 0 ? cm[u] : 0;
       const int nc = cm[u] >= 0 ? n : 0;
-      rv[u] = *(const uint4*)(p.res + mc * p.res_ld + nc);
+      rv[u] = ld_res16(p.res + mc * p.res_ld + nc);
       rb[u] = p.res_bits ? (unsigned)p.res_bits[mc * (p.Ncols >> 3) + (nc >> 3)] : 0xffu;
     }
 #pragma unroll
