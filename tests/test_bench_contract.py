@@ -1,5 +1,5 @@
 """The bench line's schema (the driver parses it): checked on the committed lines of the current round's build
-(`profiles/r04_bench_train_v6.json`, `profiles/r04_bench_feat_fwd_v6.json`, produced by `python bench.py` on an MI355X)
+(`profiles/r04_bench_train_v7.json`, `profiles/r04_bench_feat_fwd_v7.json`, produced by `python bench.py` on an MI355X)
 and on bench.py's argument surface -- no GPU needed."""
 import json
 import os
@@ -14,7 +14,7 @@ def _line(name):
 
 
 def test_train_line_has_the_contract_fields():
-    d = _line("r04_bench_train_v6.json")
+    d = _line("r04_bench_train_v7.json")
     for k in ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better",
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -62,7 +62,7 @@ def test_parity_numbers_come_from_the_file_the_parity_test_writes():
 
 
 def test_forward_line_and_cli_surface():
-    d = _line("r04_bench_feat_fwd_v6.json")
+    d = _line("r04_bench_feat_fwd_v7.json")
     assert d["unit"] == "clips/s" and d["value"] > 0 and "feature extractor" in d["metric"]
     assert "parity" in d["config"]  # the measured logit distance to the fp32 oracle, per eval mode
     src = open(os.path.join(ROOT, "bench.py")).read()
