@@ -164,7 +164,24 @@ def test_slowfast_r50_one_clip_224_eval_logits_fp32_residual_stream(dev, monkeyp
         head = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=root, capture_output=True, text=True).stdout.strip()
     except OSError:
         head = ""
-    rec = {"logits_rel_err_vs_fp32_oracle": {"bf16": e16, "fp32_residual_stream": e32, "split_bf16_weights": e_sw},
+    # ... and at no cost per forward: bf16 weights with the rounding's per-channel constants folded into the BN shifts,
+    # calibrated on TWO OTHER clips (seed 999) -- `SFBase.calibrate_weight_rounding`, tools/bias_correction_probe.py
+    monkeypatch.setattr(_Unit, "split_weights", False)
+    cal = synth_data.synth_batch(cfg, comm, bs=1, n_ev=2, seed=999)
+    ncal = mdl.calibrate_weight_rounding({k: v.to(dev) for k, v in cal.items()})
+    assert ncal == 108  # every convolution of SlowFast-R50 but the two stems
+    with torch.no_grad():
+        lo_bc = mdl(gb)["mdl_out"].float().cpu().view(1, -1)
+        lo_bc2 = mdl(gb)["mdl_out"].float().cpu().view(1, -1)
+    assert torch.equal(lo_bc, lo_bc2)
+    e_bc = rel(lo_bc, lr)
+    print(f"  bf16 weights + shift correction of their rounding (2 calibration clips): logits relative error {e_bc:.3e} "
+          f"(rel_l2 {rel_l2(lo_bc, lr):.3e})")
+    mdl.sf_mdl.reset_weight_rounding()
+    with torch.no_grad():
+        assert torch.equal(mdl(gb)["mdl_out"].float().cpu().view(1, -1), lo16), "reset must restore the plain folds"
+    rec = {"logits_rel_err_vs_fp32_oracle": {"bf16": e16, "fp32_residual_stream": e32, "split_bf16_weights": e_sw,
+                                             "bf16_calibrated_shift": e_bc},
            "same_bf16_weights_both_sides": rel(lo16, lr_w16), "bf16_weight_rounding_alone": rel(lr_w16, lr),
            "north_star": 1e-3, "commit": head or os.environ.get("VS_BUILD_TAG", ""),
            "source": "tests/test_gpu_parity_full.py::test_slowfast_r50_one_clip_224_eval_logits_fp32_residual_stream "
@@ -173,6 +190,8 @@ def test_slowfast_r50_one_clip_224_eval_logits_fp32_residual_stream(dev, monkeyp
     with open(os.path.join(root, "gpurun_out", "parity_eval.json"), "w") as f:
         json.dump(rec, f, indent=1)
     assert e_sw < 1e-3, "north_star: logits within 1e-3 of the reference"
+    assert e_bc < 1e-3, "north_star: logits within 1e-3 of the reference (calibrated shifts, the mode bench.py times)"
+    assert _check_top5(lo_bc, lr, e_bc * scale) >= 0
     assert _check_top5(lo_sw, lr, e_sw * scale) >= 0
 
 

@@ -579,8 +579,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, c
       // Partials and ticket without a cache-wide fence: an agent-scope release / acquire fence on gfx950 is
       // buffer_wbl2 + buffer_inv over the XCD's whole L2 (~100 us per launch, measured: every split launch took
       // 100-135 us whatever its size).  Instead every partial word is an agent-scope relaxed atomic store / load
-      // (global_store / global_load with sc1: written through to, and read from, the point the XCDs share); the
-      // workgroup barrier's vmcnt(0) retires the stores before the ticket is drawn.
+      // (global_store / global_load with sc1: written through to, and read from, the point the XCDs share); an explicit
+      // s_waitcnt vmcnt(0) in every wave retires the stores before the barrier behind which the ticket is drawn.
       constexpr int Q = MR * NR;
       float* part = p.slab + ((long long)tile_id * p.splitK) * (Q * 1024);  // [split][fragment][component][256 threads]
       float* mine = part + (long long)ksplit * (Q * 1024) + tid;
@@ -591,7 +591,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, c
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             __hip_atomic_store(mine + ((a * NR + b) * 4 + r) * 256, acc[a][b][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();  // (s_waitcnt vmcnt(0) + barrier: every wave's partial words are written through)
+      // Retire this wave's partial stores BEFORE the barrier: a workgroup-scope barrier on gfx950 does not wait for
+      // vmcnt outside tgsplit mode (the ISA of this kernel showed `s_waitcnt vmcnt(63)` in front of s_barrier), so
+      // without the explicit wait the ticket could be drawn -- and the last arriver start summing -- while partial
+      // words were still in flight.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
       int* flag = (int*)smem;
       if (tid == 0) flag[0] = atomicAdd(p.sk_cnt + tile_id, 1);
       __syncthreads();
@@ -1922,6 +1927,12 @@ extern "C" int vs_conv_aol_ok(const vs_conv_desc* d) {
   if (mode != 0 || !p.dense || p.K > 512 || p.K % 8) return 0;
   PwGeo pg;
   if (vs_pw_plan(p, mode, d->flags, &pg)) return vs_pw_aol_ok(pg, p) ? 1 : 0;
+  // The apply-on-load launch never runs on the deep-pipeline kernel, but vs_conv_stats_rows (which sees no in_scale)
+  // would size the statistic rows for it (256-row tiles) while the 128-row tile kernel writes twice as many rows:
+  // a descriptor the deep plan accepts is refused here -- callers pass VS_CONV_NODEEP so that the rows query and the
+  // launch agree.
+  DeepGeo dg;
+  if (vs_deep_plan(p, mode, d->flags, &dg)) return 0;
   const ConvPlan pl = plan_conv(p.M, p.Ncols, p.K, 1, d->flags);
   return aol_tile_ok(pl, mode, p.K) ? 1 : 0;
 }

@@ -191,6 +191,12 @@ class SFBase(nn.Module):
         assert len(maps) == self.sf_mdl.num_pathways
         return maps
 
+    def calibrate_weight_rounding(self, inp):
+        """Eval only: measure, on the calibration batch `inp` (the same dict contract as forward; clips other than the
+        ones evaluated), the per-channel constants the bf16 rounding of the trunk's convolution weights adds, and fold
+        their correction into the BN shifts (`VideoTrunk.calibrate_weight_rounding`).  Free at run time."""
+        return self.sf_mdl.calibrate_weight_rounding(self.get_feats(inp))
+
     def forward_decoder(self, enc_out, inp):
         pooled = self.head(enc_out).permute((0, 2, 3, 4, 1))  # [N, C, 1, 1, 1] -> channels last
         logits = self.proj_head(pooled).view(len(inp["vseg_idx"]), _num_events(inp), -1)

@@ -204,13 +204,14 @@ def conv_fwd(x, w, k, s, p, out=None, scale=None, shift=None, residual=None, rel
 
 
 _K1, _S1, _P0 = (1, 1, 1), (1, 1, 1), (0, 0, 0)
+VS_CONV_NODEEP = 1 << 27  # include/vidsitu_hip.h
 
 
 def conv_aol_ok(x, cout, stats=True):
     """True if a 1x1x1 convolution of x to cout channels can take x as its producer's RAW output (conv_fwd_aol) AND
     its weight gradient can (conv_wgrad_aol): both or neither, the activation is then never stored."""
     ys = conv_out_shape(x.shape, cout, _K1, _S1, _P0)
-    d = make_desc(x.shape, act_ld(x), ys, cout, _K1, _S1, _P0, VS_CONV_STATS if stats else 0)
+    d = make_desc(x.shape, act_ld(x), ys, cout, _K1, _S1, _P0, (VS_CONV_STATS if stats else 0) | VS_CONV_NODEEP)
     dw = make_desc(x.shape, act_ld(x), ys, cout, _K1, _S1, _P0, VS_WGRAD_NODEEP)  # (the transform lives in the ring kernel)
     lib = _lib.load()
     return bool(lib.vs_conv_aol_ok(C.byref(d))) and bool(lib.vs_conv_wgrad_aol_ok(C.byref(dw)))
@@ -227,7 +228,9 @@ def conv_fwd_aol(x, w, in_scale, in_shift, out=None, stats=True):
     elif tuple(out.shape) != ys:
         raise _lib.VsError(f"conv out shape {tuple(out.shape)} != {ys}")
     check_weight(w, cout, x.shape[1], _K1)
-    d = make_desc(x.shape, act_ld(x), ys, act_ld(out), _K1, _S1, _P0, VS_CONV_STATS if stats else 0)
+    # VS_CONV_NODEEP: the transform lives in the pointwise / 128 x 128 ring kernels; without the flag the rows query
+    # below would answer for the deep-pipeline kernel's 256-row tiles
+    d = make_desc(x.shape, act_ld(x), ys, act_ld(out), _K1, _S1, _P0, (VS_CONV_STATS if stats else 0) | VS_CONV_NODEEP)
     partials = None
     if stats:
         rows = _lib.load().vs_conv_stats_rows(C.byref(d))

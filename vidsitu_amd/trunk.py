@@ -130,6 +130,9 @@ class BN3dP(nn.Module):
         self.register_buffer("running_var", torch.ones(c))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
         self.fold = None  # eval-mode (scale, shift), cached by the trunk
+        # eval only: per-channel mean of conv(x, bf16(W) - W) of the convolution in front of this BN, measured by
+        # VideoTrunk.calibrate_weight_rounding; the fold subtracts scale * wround_bias from the shift.  None: no correction.
+        self.wround_bias = None
 
 
 def _set_grad(param, g):
@@ -243,6 +246,27 @@ class _Unit:
     split_weights = os.environ.get("VS_EVAL_SPLIT_WEIGHTS", "0") == "1"
     _zeros = {}
 
+    # VideoTrunk.calibrate_weight_rounding: a dict while the calibration pass runs (conv -> measured input means)
+    calib = None
+
+    @staticmethod
+    def _calibrate(conv, bn, x):
+        """Calibration pass (eval): the rounding of this convolution's fp32 weights to bf16 adds conv(x, dW),
+        dW = bf16(W) - W, to its output.  The trimmed head averages the feature map over positions, so what reaches the
+        logits is the position MEAN of that error -- per output channel sum_{taps, ci} dW[co, ci, tap] * mean(x[ci])
+        (borders ignored) -- and a per-channel constant is something the folded BatchNorm shift can absorb: the fold
+        subtracts scale * wround_bias.  x is the input this launch is about to read (its producers already corrected),
+        so the means are those of the corrected path.  Host-side bookkeeping on [Cout, Cin] tensors; the activation
+        means come from vs_colsum_bf16."""
+        with torch.no_grad():
+            mu = ops.colsum_bf16(x) / float(ops.act_rows(x))  # [Cin]
+            w = conv.weight.detach()
+            dw = (conv.w_bf16[:, : conv.cin].float() - w).sum(dim=(2, 3, 4))  # [Cout, Cin]
+            bn.wround_bias = (dw * mu.view(1, -1)).sum(dim=1)
+            sc, sh = bn.fold_raw
+            bn.fold = (sc, sh - sc * bn.wround_bias)
+            _Unit.calib[conv] = mu
+
     @staticmethod
     def fwd(conv, bn, x, relu, residual=None, out=None, train=False, saved=None, pool=False, no_apply=False,
             x_affine=None):
@@ -253,6 +277,8 @@ class _Unit:
         relu(y * scale + shift) on its operand fragments (ops.conv_fwd_aol / conv_wgrad_aol): the activation is never
         stored."""
         if not train:
+            if _Unit.calib is not None and not conv.is_stem and conv.cin_pad == conv.cin:
+                _Unit._calibrate(conv, bn, x)
             scale, shift = bn.fold
             if conv.bias is not None:  # BN(conv + b) folded: the bias joins the shift
                 shift = shift + conv.bias.detach() * scale
@@ -1004,8 +1030,43 @@ class VideoTrunk(nn.Module):
             for b in self._bns():
                 sc, sh, _, _ = ops.bn_finalize(None, 0, b.weight, b.bias, b.running_mean,
                                                b.running_var, b.momentum, b.eps, train=False)
-                b.fold = (sc, sh)
+                b.fold_raw = (sc, sh)
+                b.fold = (sc, sh) if b.wround_bias is None else (sc, sh - sc * b.wround_bias)
             self._folds_version = key
+
+    def calibrate_weight_rounding(self, x):
+        """Eval-mode bias correction for the bf16 rounding of the convolution weights (north_star: "logits within 1e-3
+        of reference" on the arithmetic that is timed).  x: calibration clips, a list like forward_features' input --
+        NOT the clips that are evaluated.  One eval forward pass in which every convolution (the two Cin = 3 stems
+        excepted: normalised frames have no channel mean to speak of) measures its input's channel means and stores
+        the per-channel constant its weight rounding adds (`BN3dP.wround_bias`); from then on the folded BN shift of
+        every eval forward carries the correction -- no launch, byte or FLOP more per forward.  Measured on one
+        224^2 SlowFast-R50 clip (tools/bias_correction_probe.py, CPU oracle: the weight-rounding error of the logits
+        3.9e-3 -> 5.7e-4 with 2 calibration clips, 6 clips the same; tests/test_gpu_parity_full.py for the HIP path).
+        The correction belongs to the weights it was measured with: an optimizer step or a state_dict load drops it
+        (`reset_weight_rounding`); training never uses it (batch statistics remove a per-channel constant exactly)."""
+        if self.training:
+            raise ops._lib.VsError("calibrate_weight_rounding is an eval-mode pass (call .eval() first)")
+        self.reset_weight_rounding()
+        fb, sw = ResBlock.fuse_bc, _Unit.split_weights
+        ResBlock.fuse_bc, _Unit.split_weights = False, False  # every convolution as a launch of its own: its input exists
+        _Unit.calib = {}
+        try:
+            with torch.no_grad():
+                self.forward_features(x)
+        finally:
+            n = len(_Unit.calib)
+            _Unit.calib = None
+            ResBlock.fuse_bc, _Unit.split_weights = fb, sw
+        self._wround_key = self._version_key()
+        self._folds_version = None  # re-fold (the corrected folds of the pass are what a re-fold produces)
+        return n
+
+    def reset_weight_rounding(self):
+        for b in self._bns():
+            b.wround_bias = None
+        self._wround_key = None
+        self._folds_version = None
 
     # ---- forward ------------------------------------------------------------------
     def forward_features(self, x):
@@ -1015,6 +1076,8 @@ class VideoTrunk(nn.Module):
             raise ops._lib.VsError("VideoTrunk runs on the HIP kernels only (GPU tensors required)")
         if self._weights_version != self._version_key():
             self.refresh_weights()
+            if getattr(self, "_wround_key", None) is not None and self._wround_key != self._weights_version:
+                self.reset_weight_rounding()  # measured with other weights
         if self.training and torch.is_grad_enabled():
             tick = torch.zeros(1, device=x[0].device, requires_grad=True)
             return list(_TrunkFn.apply(self, tick, *x))
