@@ -285,6 +285,16 @@ int vs_bn_finalize(const float* partials, int nparts, double count, const float*
                    const float* beta, float* running_mean, float* running_var, float momentum,
                    float eps, float* scale, float* shift, float* mean, float* invstd, int C,
                    void* stream);
+/* The same (training mode) for ANY number of partial rows in one launch: (C / 32) x G blocks sum row groups, the last
+ * arriver of a channel group adds the group sums in group order and closes the channels.  workspace:
+ * vs_bn_finalize_workspace_bytes() bytes, zero before its first use (left zero), one per stream that may run such
+ * launches concurrently.  Bitwise stable from run to run; for <= 256 rows bitwise vs_bn_finalize.  VS_BN_FIN2=0 (or a
+ * NULL workspace): vs_bn_partials_reduce + vs_bn_finalize as before. */
+size_t vs_bn_finalize_workspace_bytes(void);
+int vs_bn_finalize_ws(const float* partials, int nparts, double count, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                      float* shift, float* mean, float* invstd, int C, void* workspace, size_t ws_bytes,
+                      void* stream);
 /* Level-1 reduction of the conv-epilogue partials when there are thousands of rows:
  * out[G][2][C] (then passed to vs_bn_finalize with nparts = G). */
 int vs_bn_partials_reduce(const float* partials, int nparts, float* out, int C, int G,
@@ -310,6 +320,10 @@ int vs_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* 
 int vs_bn_bwd_reduce_rows(int64_t rows, int C);
 int vs_bn_bwd_finalize(const float* partial, int nparts, float* dgamma, float* dbeta, int C,
                        void* stream);
+/* The same with a workspace (vs_bn_finalize_workspace_bytes(), as for vs_bn_finalize_ws): the rows are summed by
+ * (C / 32) x G blocks in one launch instead of C / 32 blocks walking all of them. */
+int vs_bn_bwd_finalize_ws(const float* partial, int nparts, float* dgamma, float* dbeta, int C, void* workspace,
+                          size_t ws_bytes, void* stream);
 int vs_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* mean,
                     const float* invstd, const float* gamma, const float* beta,
                     const float* dgamma, const float* dbeta, void* dy, void* dres, int64_t rows,

@@ -233,3 +233,61 @@ def test_stem_bn_relu_maxpool_in_one_pass_is_bitwise_the_three_launches(c, n, t,
     dy_ref, _, dg_ref, db_ref = ops.bn_bwd(dz, None, y, mean, invstd, gamma, True, False, beta=beta)
     dy, _, dg, db = ops.bn_bwd(None, None, y, mean, invstd, gamma, True, False, beta=beta, pool_src=(dp, i_ref))
     assert torch.equal(dy, dy_ref) and torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
+
+
+@pytest.mark.parametrize("nparts,c", [(25, 2048), (98, 1024), (256, 64), (257, 64), (784, 128), (1568, 8), (3136, 256),
+                                      (3136, 72), (9000, 16)])
+def test_one_launch_finalize_forward_and_backward(nparts, c, dev, monkeypatch):
+    """vs_bn_finalize_ws / vs_bn_bwd_finalize_ws: any number of partial rows in one launch (groups of 256 rows summed by
+    their own blocks, the last-arriving block of a channel group adds the group sums in order).  Against fp64 sums of the
+    same rows (the oracle of a sum), against the round-4 launches (vs_bn_partials_reduce + vs_bn_finalize /
+    vs_bn_bwd_finalize: another order, or -- up to 256 rows -- the same order: bit for bit), run to run bit for bit
+    with the arrival counters back at zero."""
+    from vidsitu_amd import ops
+
+    g = torch.Generator().manual_seed(nparts + c)
+    count = float(nparts * 64)
+    s1 = torch.randn(nparts, c, generator=g) * 8 + 3.0
+    s2 = (s1 ** 2) / 64 + torch.rand(nparts, c, generator=g) * 50 + 10
+    part = torch.stack([s1, s2], dim=1).contiguous().to(dev)  # [nparts, 2, C]
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).to(dev), (torch.randn(c, generator=g) * 0.2).to(dev)
+    rm0, rv0 = (torch.randn(c, generator=g) * 0.1).to(dev), (torch.rand(c, generator=g) + 0.5).to(dev)
+
+    def fwd(new):
+        monkeypatch.setattr(ops, "BN_FIN2", new)
+        rm, rv = rm0.clone(), rv0.clone()
+        out = ops.bn_finalize(part, count, gamma, beta, rm, rv, 0.1, 1e-5, train=True)
+        return list(out) + [rm, rv]
+
+    new, old = fwd(True), fwd(False)
+    ts, tq = part[:, 0].double().sum(0), part[:, 1].double().sum(0)
+    mu = ts / count
+    var = (tq / count - mu * mu).clamp_min(0)
+    assert float((new[2].double() - mu).abs().max()) <= 1e-6 * float(mu.abs().max())
+    assert float((new[3].double() * torch.sqrt(var + 1e-5) - 1).abs().max()) <= 1e-6
+    for a, b in zip(new, old):
+        if nparts <= 256:
+            assert torch.equal(a, b), "up to 256 rows the one-launch finalize keeps vs_bn_finalize's order"
+        else:
+            assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+    for _ in range(10):
+        for a, b in zip(fwd(True), new):
+            assert torch.equal(a, b)
+
+    def bwd(new):
+        monkeypatch.setattr(ops, "BN_FIN2", new)
+        dg, db = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        ops._bn_bwd_finalize(part, nparts, dg, db, c)
+        return dg, db
+
+    (dg, db), (dg0, db0) = bwd(True), bwd(False)
+    assert float((db.double() - ts).abs().max()) <= 1e-6 * float(ts.abs().max())
+    assert float((dg.double() - tq).abs().max()) <= 1e-6 * float(tq.abs().max())
+    if nparts <= 256:
+        assert torch.equal(dg, dg0) and torch.equal(db, db0)
+    for _ in range(10):
+        a, b = bwd(True)
+        assert torch.equal(a, dg) and torch.equal(b, db)
+    torch.cuda.synchronize()
+    ws = ops._workspace(0, dev, "fin")
+    assert int(ws[:4096].view(torch.int32).abs().sum()) == 0, "arrival counters not back at zero"

@@ -81,6 +81,9 @@ SIGNATURES = {
     "vs_wgrad_reduce_defer": (_i, [_i]),
     "vs_wgrad_reduce_flush": (_i, []),
     "vs_bn_finalize": (_i, [_p, _i, _d, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i, _p]),
+    "vs_bn_finalize_workspace_bytes": (_sz, []),
+    "vs_bn_finalize_ws": (_i, [_p, _i, _d, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i, _p, _sz, _p]),
+    "vs_bn_bwd_finalize_ws": (_i, [_p, _i, _p, _p, _i, _p, _sz, _p]),
     "vs_bn_partials_reduce": (_i, [_p, _i, _p, _i, _i, _p]),
     "vs_bn_apply": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p]),
     "vs_bn_apply_mask": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _p]),

@@ -156,6 +156,15 @@ extern "C" int vs_frames_u8_pack(const uint8_t* frames, const int* t_index, void
 // BN finalize: partial[nparts][2][C] -> mean / biased var -> scale, shift
 // block = 32 channels x 32 slices; fp64 cross-partial accumulation.
 // ----------------------------------------------------------------------------
+// agent-scope relaxed 8-byte stores / loads (`global_store_dwordx2 ... sc1` / `global_load_dwordx2 ... sc1`): cross-block
+// hand-off inside one launch without a cache-wide fence (MI355X_MICROARCH.md, "hand-offs measured with sc1 loads")
+__device__ __forceinline__ void st_part64(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_part64(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // The arithmetic from (sum, sum of squares) to the affine form, shared by the finalize kernel and by the apply
 // kernels that finalize for themselves (below).  Every multiply-add is spelled out: left to the compiler's
 // contraction the same source rounds differently in different kernels, and the two paths are meant to be bitwise.
@@ -278,6 +287,179 @@ __global__ __launch_bounds__(1024) void bn_partials_reduce_kernel(const float* p
   }
 }
 
+// ----------------------------------------------------------------------------
+// Two-level finalize in ONE launch (round 5).  Layers whose producer wrote hundreds to thousands of partial rows (s2 / s3
+// and the whole fast pathway: 392 .. 3136 rows) took a level-1 reduce launch + the finalize launch in the forward pass
+// (53 + 110 launches per SlowFast-R50 step) and, in the backward pass, one finalize launch whose 32 slices walked up to
+// 98 rows each, 8 loads at a time (9.8 us per launch in the replayed step).  Here grid = (C / 32) x G: block (bx, g)
+// sums rows [g * rpg, (g + 1) * rpg) of its 32 channels -- thread (slice, channel) takes rows slice + 32 u, all of a
+// batch of 8 in flight -- and, with G > 1, stores its sums (agent-scope stores), draws a ticket from the channel
+// group's counter, and the block that draws the last ticket adds the G group sums IN GROUP ORDER and closes the
+// channels.  A ticket costs every block one store drain + one atomic round trip (~1.5 us): cheap in a kernel whose
+// blocks do nothing else -- unlike at the end of every convolution tile (profiles/r05_fin_inlaunch.txt).  The sums
+// are bitwise stable (fixed order whoever arrives last); counters are zero between launches.
+// ----------------------------------------------------------------------------
+struct Fin2P {
+  const float* part;
+  int nparts, C, G, rpg;  // rows, channels, groups (<= 32), rows per group (multiple of 32)
+  double* lvl1;           // [G][2][C]
+  int* cnt;               // [ceil(C / 32)] arrival counters
+  int kind;               // 1: BN forward, 2: BN backward
+  double count;
+  float momentum, eps;
+  const float *gamma, *beta;
+  float *rmean, *rvar, *scale, *shift, *mean, *invstd;
+  float *dgamma, *dbeta;
+};
+
+#define VS_FIN2_CNT_BYTES 4096
+#define VS_FIN2_LVL1_BYTES (32 * 2 * 4096 * 8)
+
+extern "C" size_t vs_bn_finalize_workspace_bytes(void) { return VS_FIN2_CNT_BYTES + VS_FIN2_LVL1_BYTES; }
+
+__device__ __forceinline__ void fin2_close(const Fin2P& f, int c, double ts, double tq, float ga_c, float be_c, float rm_c,
+                                           float rv_c) {
+  if (f.kind == 1) {
+    float sc, sf, mean_f, invstd;
+    double var;
+    bn_affine_from_sums(ts, tq, f.count, ga_c, be_c, f.eps, sc, sf, mean_f, invstd, var);
+    if (f.mean) f.mean[c] = mean_f;
+    if (f.invstd) f.invstd[c] = invstd;
+    if (f.rmean) {
+      float rm_n, rv_n;
+      bn_running_update(rm_c, rv_c, mean_f, var, f.count, f.momentum, rm_n, rv_n);
+      f.rmean[c] = rm_n;
+      f.rvar[c] = rv_n;
+    }
+    f.scale[c] = sc;
+    f.shift[c] = sf;
+  } else {
+    f.dbeta[c] = (float)ts;
+    f.dgamma[c] = (float)tq;
+  }
+}
+
+// one 1024-thread block: channel group bx, row group g.  lds: sh_s / sh_q [32][33] doubles + one int.
+__device__ __forceinline__ void fin2_body(const Fin2P& f, int bx, int g, double (*sh_s)[33], double (*sh_q)[33],
+                                          int* sh_t) {
+  const int tid = threadIdx.x;
+  const int cl = tid & 31, sl = tid >> 5;
+  const int c = bx * 32 + cl;
+  const int C = f.C;
+  const int cc = c < C ? c : C - 1;
+  // the closing block's per-channel parameters, requested up front (their latency runs beside the rows')
+  float ga_c = 0.f, be_c = 0.f, rm_c = 0.f, rv_c = 0.f;
+  if (f.kind == 1) {
+    ga_c = f.gamma[cc];
+    be_c = f.beta[cc];
+    rm_c = (f.rmean ? f.rmean : f.gamma)[cc];
+    rv_c = (f.rvar ? f.rvar : f.gamma)[cc];
+  }
+  const int r0 = g * f.rpg, r1 = min(f.nparts, r0 + f.rpg);
+  double s = 0.0, q = 0.0;
+  if (c < C) {
+    const float* base = f.part + c;
+    for (int p = r0 + sl; p < r1; p += 256) {  // 8 rows (16 loads) in flight; rows past r1 re-read row r1 - 1, dropped
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int pr = min(p + 32 * u, r1 - 1);
+        a[u] = base[(long long)pr * 2 * C];
+        b[u] = base[(long long)pr * 2 * C + C];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (p + 32 * u < r1) {
+          s += (double)a[u];
+          q += (double)b[u];
+        }
+    }
+  }
+  sh_s[sl][cl] = s;
+  sh_q[sl][cl] = q;
+  __syncthreads();
+  double ts = 0.0, tq = 0.0;
+  if (sl == 0 && c < C) {
+    for (int i = 0; i < 32; ++i) {
+      ts += sh_s[i][cl];
+      tq += sh_q[i][cl];
+    }
+    if (f.G == 1) {
+      fin2_close(f, c, ts, tq, ga_c, be_c, rm_c, rv_c);
+    } else {
+      st_part64(f.lvl1 + ((long long)g * 2) * C + c, ts);
+      st_part64(f.lvl1 + ((long long)g * 2 + 1) * C + c, tq);
+    }
+  }
+  if (f.G == 1) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the group sums are written through before the ticket
+  __syncthreads();
+  if (tid == 0) {
+    const int t = atomicAdd(f.cnt + bx, 1);
+    if (t == f.G - 1) __hip_atomic_store(f.cnt + bx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *sh_t = t;
+  }
+  __syncthreads();
+  if (*sh_t != f.G - 1) return;
+  double ls = 0.0, lq = 0.0;
+  if (sl < f.G && c < C) {
+    ls = ld_part64(f.lvl1 + ((long long)sl * 2) * C + c);
+    lq = ld_part64(f.lvl1 + ((long long)sl * 2 + 1) * C + c);
+  }
+  __syncthreads();  // (sh_s / sh_q were read above by slice 0)
+  sh_s[sl][cl] = ls;
+  sh_q[sl][cl] = lq;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    ts = 0.0;
+    tq = 0.0;
+    for (int i = 0; i < f.G; ++i) {
+      ts += sh_s[i][cl];
+      tq += sh_q[i][cl];
+    }
+    fin2_close(f, c, ts, tq, ga_c, be_c, rm_c, rv_c);
+  }
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize2_kernel(Fin2P f, int g1) {
+  __shared__ double sh_s[32][33];
+  __shared__ double sh_q[32][33];
+  __shared__ int sh_t;
+  fin2_body(f, blockIdx.x % g1, blockIdx.x / g1, sh_s, sh_q, &sh_t);
+}
+
+// + the pending slab reduce of the previous unit's weight gradient (see bn_bwd_finalize_wgrad_reduce_kernel below)
+__global__ __launch_bounds__(1024) void bn_finalize2_wgrad_reduce_kernel(Fin2P f, int g1, int nfin, const float* slabs,
+                                                                        float* dw, long long n, int S) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * 32 * 33 * 8 + 16];
+  if ((int)blockIdx.x < nfin) {
+    double (*sh_s)[33] = (double (*)[33])lds;
+    double (*sh_q)[33] = (double (*)[33])(lds + 32 * 33 * 8);
+    fin2_body(f, blockIdx.x % g1, blockIdx.x / g1, sh_s, sh_q, (int*)(lds + 2 * 32 * 33 * 8));
+  } else if (wgrad_reduce_cols(n, S)) {
+    if (threadIdx.x < 256) wgrad_reduce_body(slabs, dw, n, S, nullptr, (long long)(blockIdx.x - nfin), threadIdx.x);
+  } else {
+    float4 (*part)[17] = (float4 (*)[17])(lds + (threadIdx.x >> 8) * 16 * 17 * 16);
+    wgrad_reduce_body(slabs, dw, n, S, part, (long long)(blockIdx.x - nfin) * 4 + (threadIdx.x >> 8), threadIdx.x & 255);
+  }
+}
+
+// groups of the plan: one up to 256 rows (every slice-thread's rows in ONE batch of 8), else groups of 256 rows, at most 32
+static bool fin2_plan(Fin2P& f, int nparts, int C, void* ws, size_t ws_bytes) {
+  static const int on = [] { const char* e = getenv("VS_BN_FIN2"); return e ? atoi(e) : 1; }();
+  if (!on || ws == nullptr || ws_bytes < vs_bn_finalize_workspace_bytes() || C > 4096) return false;
+  int rpg = 256;
+  while ((nparts + rpg - 1) / rpg > 32) rpg += 256;
+  f.nparts = nparts;
+  f.C = C;
+  f.rpg = rpg;
+  f.G = (nparts + rpg - 1) / rpg;
+  if (f.G < 1) f.G = 1;
+  f.cnt = (int*)ws;
+  f.lvl1 = (double*)((char*)ws + VS_FIN2_CNT_BYTES);
+  return true;
+}
+
 extern "C" int vs_bn_partials_reduce(const float* partials, int nparts, float* out, int C, int G,
                                      void* stream) {
   VS_CHECK_ARG(partials && out && nparts > 0 && C > 0 && G > 0, "bad args");
@@ -297,6 +479,46 @@ extern "C" int vs_bn_finalize(const float* partials, int nparts, double count, c
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream,
                      partials, nparts, count, gamma, beta, running_mean, running_var, momentum, eps,
                      scale, shift, mean, invstd, C);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// vs_bn_finalize (train mode) with a workspace: any number of partial rows in ONE launch (two levels inside it).
+extern "C" int vs_bn_finalize_ws(const float* partials, int nparts, double count, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                                 float* shift, float* mean, float* invstd, int C, void* workspace, size_t ws_bytes,
+                                 void* stream) {
+  VS_CHECK_ARG(gamma && beta && scale && shift && C > 0, "bad args");
+  VS_CHECK_ARG(partials && nparts > 0 && count > 0, "train mode needs partials and count");
+  Fin2P f;
+  if (!fin2_plan(f, nparts, C, workspace, ws_bytes)) {
+    // the two-launch form (VS_BN_FIN2=0, or no workspace)
+    if (nparts > 512 && workspace && ws_bytes >= (size_t)32 * 2 * C * sizeof(float) + VS_FIN2_CNT_BYTES) {
+      float* lvl1 = (float*)((char*)workspace + VS_FIN2_CNT_BYTES);
+      int rc = vs_bn_partials_reduce(partials, nparts, lvl1, C, 32, stream);
+      if (rc) return rc;
+      return vs_bn_finalize(lvl1, 32, count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean,
+                            invstd, C, stream);
+    }
+    return vs_bn_finalize(partials, nparts, count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift,
+                          mean, invstd, C, stream);
+  }
+  f.part = partials;
+  f.kind = 1;
+  f.count = count;
+  f.momentum = momentum;
+  f.eps = eps;
+  f.gamma = gamma;
+  f.beta = beta;
+  f.rmean = running_mean;
+  f.rvar = running_var;
+  f.scale = scale;
+  f.shift = shift;
+  f.mean = mean;
+  f.invstd = invstd;
+  f.dgamma = f.dbeta = nullptr;
+  const int g1 = (C + 31) / 32;
+  hipLaunchKernelGGL(bn_finalize2_kernel, dim3(g1 * f.G), dim3(1024), 0, (hipStream_t)stream, f, g1);
   VS_CHECK_LAUNCH();
   return VS_OK;
 }
@@ -828,6 +1050,36 @@ extern "C" int vs_bn_bwd_finalize(const float* partial, int nparts, float* dgamm
   } else {
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(g1), dim3(1024), 0, (hipStream_t)stream, partial, nparts, dgamma,
                        dbeta, C);
+  }
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
+// vs_bn_bwd_finalize with a workspace: the rows summed by (C / 32) x G blocks in one launch (bn_finalize2_kernel), the
+// pending slab reduce riding in the same grid as before.
+extern "C" int vs_bn_bwd_finalize_ws(const float* partial, int nparts, float* dgamma, float* dbeta, int C, void* workspace,
+                                     size_t ws_bytes, void* stream) {
+  VS_CHECK_ARG(partial && dgamma && dbeta && nparts > 0, "bad args");
+  Fin2P f;
+  if (!fin2_plan(f, nparts, C, workspace, ws_bytes)) return vs_bn_bwd_finalize(partial, nparts, dgamma, dbeta, C, stream);
+  f.part = partial;
+  f.kind = 2;
+  f.count = 1.0;
+  f.momentum = f.eps = 0.f;
+  f.gamma = f.beta = nullptr;
+  f.rmean = f.rvar = f.scale = f.shift = f.mean = f.invstd = nullptr;
+  f.dgamma = dgamma;
+  f.dbeta = dbeta;
+  const int g1 = (C + 31) / 32;
+  const int nfin = g1 * f.G;
+  VsPendingReduce pr;
+  if (vs_pending_reduce_take((hipStream_t)stream, &pr)) {
+    const long long rb = wgrad_reduce_vblocks(pr.n, pr.S);
+    const long long rblocks = wgrad_reduce_cols(pr.n, pr.S) ? rb : (rb + 3) / 4;
+    hipLaunchKernelGGL(bn_finalize2_wgrad_reduce_kernel, dim3((unsigned)(nfin + rblocks)), dim3(1024), 0,
+                       (hipStream_t)stream, f, g1, nfin, pr.slabs, pr.dw, pr.n, pr.S);
+  } else {
+    hipLaunchKernelGGL(bn_finalize2_kernel, dim3(nfin), dim3(1024), 0, (hipStream_t)stream, f, g1);
   }
   VS_CHECK_LAUNCH();
   return VS_OK;

@@ -504,7 +504,8 @@ def _workspace(nbytes, device, kind="scratch"):
     if ws is None or ws.numel() < nbytes:
         # "splitk" (vs_conv_fwd / vs_conv_dgrad): the head of the buffer holds the arrival counters of the in-launch
         # split-K plan -- zero before the first launch, left at zero by every launch, written by nobody else
-        alloc = torch.zeros if kind == "splitk" else torch.empty
+        # "fin" (bn_finalize / bn_bwd): arrival counters of the one-launch finalize -- zero before the first launch, left zero
+        alloc = torch.zeros if kind in ("splitk", "fin") else torch.empty
         ws = alloc(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = ws
     return ws
@@ -611,6 +612,17 @@ def conv_wgrad(dy, x, k, s, p, out=None, ring=0, batch=None, tile=None, slots=0,
 import os as _os
 _WHATIF = int(_os.environ.get("VS_WHATIF", "0"))  # tools only: skip launches to measure what they cost on the step
 _BN_TWO_LEVEL = int(_os.environ.get("VS_BN_TWO_LEVEL", "512"))  # partial rows above which a level-1 reduce runs first
+# the BN finalizes (forward and backward) as ONE launch each whatever the number of partial rows (vs_bn_finalize_ws /
+# vs_bn_bwd_finalize_ws); VS_BN_FIN2=0: the round-4 launches (A/B)
+BN_FIN2 = _os.environ.get("VS_BN_FIN2", "1") != "0"
+_fin_ws = [0]
+
+
+def _fin_ws_bytes():
+    if not _fin_ws[0]:
+        _fin_ws[0] = int(_lib.load().vs_bn_finalize_workspace_bytes())
+    return _fin_ws[0]
+
 
 
 def bn_finalize(partials, count, gamma, beta, running_mean, running_var, momentum, eps, train):
@@ -623,6 +635,12 @@ def bn_finalize(partials, count, gamma, beta, running_mean, running_var, momentu
     nparts = partials.shape[0] if train else 0
     if train and _WHATIF & 1:  # timing experiment only (garbage statistics)
         return scale.zero_().add_(1.0), shift.zero_(), mean.zero_(), invstd.zero_().add_(1.0)
+    if train and BN_FIN2:  # any number of rows in ONE launch (two levels inside it: vs_bn_finalize_ws)
+        ws = _workspace(_fin_ws_bytes(), dev, "fin")
+        _lib.call("vs_bn_finalize_ws", _ptr(partials), nparts, float(count), _ptr(gamma), _ptr(beta),
+                  _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), _ptr(scale), _ptr(shift),
+                  _ptr(mean), _ptr(invstd), c, _ptr(ws), C.c_size_t(ws.numel()), _stream())
+        return scale, shift, mean, invstd
     if train and nparts > _BN_TWO_LEVEL:  # two-level reduction keeps the finalize launch short
         lvl1 = torch.empty((32, 2, c), dtype=torch.float32, device=dev)
         _lib.call("vs_bn_partials_reduce", _ptr(partials), nparts, _ptr(lvl1), c, 32, _stream())
@@ -673,6 +691,15 @@ def bn_apply_maxpool_ok(y):
     return c % 8 == 0 and cpr & (cpr - 1) == 0 and n * t * h * w < (1 << 24)
 
 
+def _bn_bwd_finalize(partial, nblk, dgamma, dbeta, c):
+    if BN_FIN2:
+        ws = _workspace(_fin_ws_bytes(), partial.device, "fin")
+        _lib.call("vs_bn_bwd_finalize_ws", _ptr(partial), nblk, _ptr(dgamma), _ptr(dbeta), c, _ptr(ws),
+                  C.c_size_t(ws.numel()), _stream())
+    else:
+        _lib.call("vs_bn_bwd_finalize", _ptr(partial), nblk, _ptr(dgamma), _ptr(dbeta), c, _stream())
+
+
 def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres, dy_out=None, dgamma=None, dbeta=None,
            beta=None, zbits=None, partial=None, pool_src=None):
     """Returns (dy, dres|None, dgamma, dbeta); dgamma / dbeta may be given (param.grad views).
@@ -695,7 +722,7 @@ def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres, dy_out=None, dgamma=N
                   _ptr(beta), _ptr(partial), n, t, h, w, c, act_ld(dp), act_ld(y), _stream())
         dgamma = torch.empty(c, dtype=torch.float32, device=dev) if dgamma is None else dgamma
         dbeta = torch.empty(c, dtype=torch.float32, device=dev) if dbeta is None else dbeta
-        _lib.call("vs_bn_bwd_finalize", _ptr(partial), nblk, _ptr(dgamma), _ptr(dbeta), c, _stream())
+        _bn_bwd_finalize(partial, nblk, dgamma, dbeta, c)
         dy = new_act(*y.shape, device=dev) if dy_out is None else dy_out
         _lib.call("vs_bn_bwd_apply_pool", _ptr(dp), _ptr(pidx), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma),
                   _ptr(beta), _ptr(dgamma), _ptr(dbeta), _ptr(dy), n, t, h, w, c, act_ld(dp), act_ld(y), act_ld(dy),
@@ -725,7 +752,7 @@ def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres, dy_out=None, dgamma=N
     dy = new_act(*y.shape, device=dev) if dy_out is None else dy_out
     dres = new_act(*y.shape, device=dev) if want_dres else None
     if not (_WHATIF & 2):
-        _lib.call("vs_bn_bwd_finalize", _ptr(partial), nblk, _ptr(dgamma), _ptr(dbeta), c, _stream())
+        _bn_bwd_finalize(partial, nblk, dgamma, dbeta, c)
     if not (_WHATIF & 8): _lib.call("vs_bn_bwd_apply", _ptr(dz), _ptr(zz), _ptr(y), _ptr(mean), _ptr(invstd),
               _ptr(gamma), _ptr(beta), _ptr(dgamma), _ptr(dbeta), _ptr(dy), _ptr(dres), rows, c,
               act_ld(dz), z_ld, act_ld(y), act_ld(dy), act_ld(dres) if want_dres else 0,
