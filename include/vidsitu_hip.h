@@ -309,6 +309,13 @@ int vs_bn_apply(const void* y, const float* scale, const float* shift, const voi
 int vs_bn_apply_mask(const void* y, const float* scale, const float* shift, const void* residual,
                      void* out, uint8_t* relu_bits, int64_t rows, int C, int y_ld, int res_ld,
                      int out_ld, void* stream);
+/* out = relu(y * scale + shift + bf16(y2 * scale2 + shift2)), relu_bits (may be NULL) as in vs_bn_apply_mask: the last
+ * unit of a ResBlock whose shortcut unit hands over its raw convolution output y2 and BN constants -- bitwise
+ * vs_bn_apply(y2, scale2, shift2, relu = 0) followed by vs_bn_apply_mask(y, ..., residual = that), one pass less over a
+ * block-output-sized tensor.  C / 8 a power of two. */
+int vs_bn_apply2(const void* y, const float* scale, const float* shift, const void* y2, const float* scale2,
+                 const float* shift2, void* out, uint8_t* relu_bits, int64_t rows, int C, int y_ld, int y2_ld,
+                 int out_ld, void* stream);
 /* Backward of z = relu?(bn(y) (+res)):  g = dz * [z>0];
  *   pass 1 (reduce): partial[blk][2][C] = (sum g, sum g*xhat), xhat=(y-mean)*invstd
  *   pass 2 (apply):  dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M); dres = g. */

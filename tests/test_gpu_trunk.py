@@ -763,3 +763,47 @@ def test_apply_on_load_train_step_is_bitwise_and_launches_fewer_kernels(dev):
     assert not bad, bad[:5]
     bad = [k for k in b0 if not torch.equal(b0[k], b1[k])]
     assert not bad, bad[:5]
+
+
+def test_shortcut_apply_inside_the_last_apply_pass_is_bitwise_and_saves_eight_launches(dev):
+    """`ResBlock.fuse_sc_apply` (round 5): the shortcut unit's BN is applied inside the c unit's apply pass
+    (vs_bn_apply2) -- features, running statistics and every gradient of a SlowFast-R50 train-mode pass bit for bit
+    those of the pass with the shortcut's own apply launch, eight launches (the res0 blocks of four stages x two
+    pathways) fewer."""
+    from oracle.slowfast_ref import default_sf_cfg
+    from vidsitu_amd import ops, trunk as T
+
+    torch.manual_seed(3)
+    cfg = default_sf_cfg("slowfast", 50, 64, 32)
+    mdl = T.VideoTrunk(cfg).to(dev).train()
+    g = torch.Generator().manual_seed(4)
+    fast = torch.randn(2, 3, 32, 96, 96, generator=g).to(dev)
+    xs = [fast[:, :, ::4].contiguous(), fast]
+    bufs = {k: v.clone() for k, v in mdl.named_buffers()}
+    lib = ops._lib.load()
+
+    def run(fuse):
+        T.ResBlock.fuse_sc_apply = fuse
+        for k, v in mdl.named_buffers():
+            v.copy_(bufs[k])
+        for p in mdl.parameters():
+            p.grad = None
+        n0 = lib.vs_launch_count()
+        feats = mdl.forward_features([x.clone() for x in xs])
+        n_fwd = lib.vs_launch_count() - n0
+        gg = torch.Generator().manual_seed(5)
+        sum((f.float() * torch.randn(f.shape, generator=gg).to(dev)).sum() for f in feats).backward()
+        torch.cuda.synchronize()
+        return ([f.detach().clone() for f in feats], {k: p.grad.clone() for k, p in mdl.named_parameters()},
+                {k: v.clone() for k, v in mdl.named_buffers()}, n_fwd)
+
+    try:
+        run(True)  # (the first pass also builds the bf16 weight images)
+        f0, g0, b0, n0 = run(False)
+        f1, g1, b1, n1 = run(True)
+    finally:
+        T.ResBlock.fuse_sc_apply = True
+    assert n0 - n1 == 8, (n0, n1)
+    assert all(torch.equal(a, b) for a, b in zip(f0, f1))
+    assert not [k for k in g0 if not torch.equal(g0[k], g1[k])]
+    assert not [k for k in b0 if not torch.equal(b0[k], b1[k])]

@@ -87,6 +87,7 @@ SIGNATURES = {
     "vs_bn_partials_reduce": (_i, [_p, _i, _p, _i, _i, _p]),
     "vs_bn_apply": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p]),
     "vs_bn_apply_mask": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _p]),
+    "vs_bn_apply2": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _p]),
     "vs_bn_bwd_reduce": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _p]),
     "vs_bn_bwd_reduce_rows": (_i, [_i64, _i]),
     "vs_bn_bwd_finalize": (_i, [_p, _i, _p, _p, _i, _p]),

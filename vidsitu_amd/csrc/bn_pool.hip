@@ -604,12 +604,17 @@ static bool cpr_pow2(int C) {
   return C % 8 == 0 && cpr > 0 && (cpr & (cpr - 1)) == 0;
 }
 
-template <bool RES, bool RELU>
+// RES_AFF (with RES): `res` is the RAW convolution output of a second unit (a ResBlock's shortcut) and the residual is
+// bf16(res * scale2 + shift2) -- the tensor that unit's own apply pass would have stored, formed here instead (same
+// fma, same rounding: bitwise the two-pass result; the shortcut's normalised output is neither written nor re-read).
+template <bool RES, bool RELU, bool RES_AFF = false>
 __global__ __launch_bounds__(256) void bn_apply_cols_kernel(const uint16_t* y, const float* scale,
                                                             const float* shift, const uint16_t* res,
                                                             uint16_t* out, uint8_t* bits,
                                                             long long rows, int C, int y_ld,
-                                                            int res_ld, int out_ld, int nbatch) {
+                                                            int res_ld, int out_ld, int nbatch,
+                                                            const float* scale2 = nullptr,
+                                                            const float* shift2 = nullptr) {
   const int cpr = C >> 3;
   const int ncol = cpr < 256 ? cpr : 256;
   const int rl = 256 / ncol;
@@ -622,6 +627,13 @@ __global__ __launch_bounds__(256) void bn_apply_cols_kernel(const uint16_t* y, c
     *(float4*)(sc + 4) = *(const float4*)(scale + c + 4);
     *(float4*)(sh) = *(const float4*)(shift + c);
     *(float4*)(sh + 4) = *(const float4*)(shift + c + 4);
+    float sc2[8], sh2[8];
+    if (RES_AFF) {
+      *(float4*)(sc2) = *(const float4*)(scale2 + c);
+      *(float4*)(sc2 + 4) = *(const float4*)(scale2 + c + 4);
+      *(float4*)(sh2) = *(const float4*)(shift2 + c);
+      *(float4*)(sh2 + 4) = *(const float4*)(shift2 + c + 4);
+    }
     for (int b = 0; b < nbatch; ++b) {
       uint4 vy[BNA_BATCH], vr[BNA_BATCH];
       long long row[BNA_BATCH];
@@ -640,6 +652,10 @@ __global__ __launch_bounds__(256) void bn_apply_cols_kernel(const uint16_t* y, c
         for (int e = 0; e < 8; ++e) v[e] = __fmaf_rn(v[e], sc[e], sh[e]);
         if (RES) {
           unpack8_bf16(vr[u], r);
+          if (RES_AFF) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = bf16_to_f32(f32_to_bf16(__fmaf_rn(r[e], sc2[e], sh2[e])));
+          }
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += r[e];
         }
@@ -704,6 +720,25 @@ extern "C" int vs_bn_apply_mask(const void* y, const float* scale, const float* 
   VS_CHECK_ARG(relu_bits, "null mask");
   return bn_apply_impl(y, scale, shift, residual, out, relu_bits, rows, C, y_ld, res_ld, out_ld, 1,
                        stream);
+}
+
+// out = relu(y * scale + shift + bf16(y2 * scale2 + shift2)) (+ the ReLU bit mask): the c unit's apply pass of a
+// ResBlock whose shortcut unit hands over its RAW convolution output y2 and BN constants instead of a normalised tensor
+// (slowfast ResBlock.forward: `x = self.branch1_bn(self.branch1(x)) + self.branch2(x); x = self.relu(x)`).
+extern "C" int vs_bn_apply2(const void* y, const float* scale, const float* shift, const void* y2, const float* scale2,
+                            const float* shift2, void* out, uint8_t* relu_bits, int64_t rows, int C, int y_ld, int y2_ld,
+                            int out_ld, void* stream) {
+  VS_CHECK_ARG(y && scale && shift && y2 && scale2 && shift2 && out, "null tensor");
+  VS_CHECK_ARG(C % 8 == 0 && y_ld % 8 == 0 && out_ld % 8 == 0 && y2_ld % 8 == 0, "channels / pitches must be multiples of 8");
+  VS_CHECK_ARG(cpr_pow2(C), "C/8 must be a power of two");
+  const int nb = bn_rows_batches(rows, C, 2048);
+  const int cpr = C / 8, ncol = cpr < 256 ? cpr : 256;
+  const long long rpb = (long long)(256 / ncol) * BNA_BATCH * nb;
+  hipLaunchKernelGGL((bn_apply_cols_kernel<true, true, true>), dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0,
+                     (hipStream_t)stream, (const uint16_t*)y, scale, shift, (const uint16_t*)y2, (uint16_t*)out,
+                     relu_bits, (long long)rows, C, y_ld, y2_ld, out_ld, nb, scale2, shift2);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
 }
 
 // ----------------------------------------------------------------------------

@@ -672,6 +672,24 @@ def bn_apply(y, scale, shift, residual=None, relu=True, out=None, want_bits=Fals
     return (out, None) if want_bits else out
 
 
+def bn_apply2(y, scale, shift, y2, scale2, shift2, out=None, want_bits=False):
+    """out = relu(y * scale + shift + bf16(y2 * scale2 + shift2)): the c unit's apply pass with the shortcut unit's BN
+    applied on the fly (vs_bn_apply2) -- bitwise bn_apply(y2, ...) then bn_apply(y, ..., residual); -> (out, bits | None)."""
+    if out is None:
+        out = new_act(*y.shape, device=y.device)
+    bits = torch.empty((act_rows(y), y.shape[1] // 8), dtype=torch.uint8, device=y.device) if want_bits else None
+    if _WHATIF & 8:
+        return out, bits
+    _lib.call("vs_bn_apply2", _ptr(y), _ptr(scale), _ptr(shift), _ptr(y2), _ptr(scale2), _ptr(shift2), _ptr(out),
+              _ptr(bits), act_rows(y), y.shape[1], act_ld(y), act_ld(y2), act_ld(out), _stream())
+    return out, bits
+
+
+def bn_apply2_ok(c):
+    cpr = c // 8
+    return c % 8 == 0 and cpr & (cpr - 1) == 0
+
+
 def bn_apply_maxpool(y, scale, shift, out=None, want_idx=True):
     """maxpool_hw(relu(y * scale + shift)) in one pass (the stems): -> (pooled, idx | None).  Bitwise bn_apply +
     maxpool_hw; the full-resolution normalised tensor is not written."""

@@ -269,13 +269,17 @@ class _Unit:
 
     @staticmethod
     def fwd(conv, bn, x, relu, residual=None, out=None, train=False, saved=None, pool=False, no_apply=False,
-            x_affine=None):
+            x_affine=None, defer_apply=False, residual_affine=None):
         """pool (train mode, the stems): the unit's output goes through the [1,3,3] max-pool and nowhere else --
         BN + ReLU + pool run as one pass, the record gets the argmax bytes (`pool_idx`) and no `z`.
         Apply on load (train mode, `ResBlock.aol`): `no_apply` -- the unit stops behind its finalize and returns
         (y, (scale, shift)); its consumer is called with `x` = that raw y and `x_affine` = the constants and forms
         relu(y * scale + shift) on its operand fragments (ops.conv_fwd_aol / conv_wgrad_aol): the activation is never
-        stored."""
+        stored.
+        Shortcut apply in the block's last pass (train mode, `ResBlock.fuse_sc_apply`): the shortcut unit is called with
+        `defer_apply` -- it stops behind its finalize and returns (y, (scale, shift)) -- and the c unit with
+        `residual_affine` = that pair: its apply pass forms the shortcut's normalised output on the fly (ops.bn_apply2,
+        bitwise the two passes)."""
         if not train:
             if _Unit.calib is not None and not conv.is_stem and conv.cin_pad == conv.cin:
                 _Unit._calibrate(conv, bn, x)
@@ -321,6 +325,11 @@ class _Unit:
             # only the running mean sees it: mean(conv + b) = mean(conv) + b
             with torch.no_grad():
                 bn.running_mean.add_(conv.bias.detach() * bn.momentum)
+        if defer_apply:  # a ReLU-less unit whose output is formed by its only reader (the block's last apply pass)
+            assert not relu and residual is None and not pool and x_affine is None
+            saved.append(dict(conv=conv, bn=bn, x=x, y=y, z=None, zbits=None, mean=mean, invstd=invstd,
+                              relu=False, has_res=False, x_affine=None))
+            return y, (scale, shift)
         if no_apply:  # the consumer applies scale / shift / ReLU on load; backward recomputes the mask from y
             assert relu and residual is None and not pool
             saved.append(dict(conv=conv, bn=bn, x=x, y=y, z=None, zbits=None, mean=mean, invstd=invstd,
@@ -334,6 +343,13 @@ class _Unit:
             saved.append(dict(conv=conv, bn=bn, x=x, y=y, z=None, zbits=None, mean=mean, invstd=invstd,
                               relu=True, has_res=False, pool_idx=pidx))
             return pooled
+        if residual_affine is not None:
+            y2, (sc2, sh2) = residual_affine
+            assert relu and residual is None
+            z, zbits = ops.bn_apply2(y, scale, shift, y2, sc2, sh2, out=out, want_bits=True)
+            saved.append(dict(conv=conv, bn=bn, x=x, y=y, z=z, zbits=zbits, mean=mean, invstd=invstd,
+                              relu=True, has_res=True, x_affine=x_affine))
+            return z
         want_bits = relu and residual is not None and y.shape[1] % 8 == 0 and \
             ((y.shape[1] // 8) & (y.shape[1] // 8 - 1)) == 0
         if want_bits:
@@ -573,9 +589,22 @@ class ResBlock(nn.Module):
     def fwd(self, x, out, train, saved):
         b2 = self.branch2
         sc = x
+        sc_aff = None
         if self.has_sc:
-            sc = _Unit.fwd(self.branch1, self.branch1_bn, x, False, train=train, saved=saved)
+            if (train and ResBlock.fuse_sc_apply and _Unit.trace is None and x.is_cuda
+                    and ops.bn_apply2_ok(self.branch1.cout)):
+                # the shortcut's BN is applied inside the block's last apply pass: its normalised output -- a block-
+                # output-sized tensor -- is neither written nor re-read (same bits as the two passes)
+                sc_aff = _Unit.fwd(self.branch1, self.branch1_bn, x, False, train=True, saved=saved, defer_apply=True)
+            else:
+                sc = _Unit.fwd(self.branch1, self.branch1_bn, x, False, train=train, saved=saved)
         a = _Unit.fwd(b2.a, b2.a_bn, x, True, train=train, saved=saved)
+        if sc_aff is not None:
+            b = _Unit.fwd(b2.b, b2.b_bn, a, True, train=True, saved=saved)
+            z = _Unit.fwd(b2.c, b2.c_bn, b, True, out=out, train=True, saved=saved, residual_affine=sc_aff)
+            if saved is not None and len(saved) >= 4:
+                saved[-1]["sc_rec"] = saved[-4]
+            return z
         if train and self._aol_ok(a, saved):
             yb, aff = _Unit.fwd(b2.b, b2.b_bn, a, True, train=True, saved=saved, no_apply=True)
             z = _Unit.fwd(b2.c, b2.c_bn, yb, True, residual=sc, out=out, train=True, saved=saved, x_affine=aff)
@@ -630,6 +659,9 @@ class ResBlock(nn.Module):
         else:
             dx, _ = _Unit.bwd(ra, da, dx_residual=g, producer=saved[-1] if (chain and saved) else None)
         return dx
+
+    # Train: the shortcut unit's BN apply inside the c unit's apply pass (ops.bn_apply2).  VS_FUSE_SC_APPLY=0: two passes.
+    fuse_sc_apply = os.environ.get("VS_FUSE_SC_APPLY", "1") != "0"
 
     # A/B switch (VS_ACC_SHORTCUT=0: the round-1 data flow of the shortcut's gradient)
     accumulate_shortcut = os.environ.get("VS_ACC_SHORTCUT", "1") != "0"
