@@ -336,6 +336,14 @@ int vs_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* m
                     const float* dgamma, const float* dbeta, void* dy, void* dres, int64_t rows,
                     int C, int dz_ld, int z_ld, int y_ld, int dy_ld, int dres_ld, int relu,
                     void* stream);
+/* The backward apply of TWO units fed by the same masked gradient (a ResBlock's last unit and its shortcut unit:
+ * g = dz where the block's ReLU bit is set) in one pass: bitwise two vs_bn_bwd_apply(relu = 2) launches, dz and the bits
+ * read once.  C / 8 a power of two. */
+int vs_bn_bwd_apply2(const void* dz, const uint8_t* relu_bits, const void* y_a, const float* mean_a,
+                     const float* invstd_a, const float* gamma_a, const float* dgamma_a, const float* dbeta_a,
+                     void* dy_a, const void* y_b, const float* mean_b, const float* invstd_b,
+                     const float* gamma_b, const float* dgamma_b, const float* dbeta_b, void* dy_b, int64_t rows,
+                     int C, int dz_ld, int ya_ld, int dya_ld, int yb_ld, int dyb_ld, void* stream);
 
 /* fp32 residual stream of a stage (eval mode, optional): out32 = relu?(residual + branch), out16 = bf16(out32),
  * rows of C channels.  `branch` = the bottleneck's last unit with its BatchNorm folded (bf16, no residual, no

@@ -782,8 +782,8 @@ def test_shortcut_apply_inside_the_last_apply_pass_is_bitwise_and_saves_eight_la
     bufs = {k: v.clone() for k, v in mdl.named_buffers()}
     lib = ops._lib.load()
 
-    def run(fuse):
-        T.ResBlock.fuse_sc_apply = fuse
+    def run(fuse, fuse_bwd=False):
+        T.ResBlock.fuse_sc_apply, T.ResBlock.fuse_sc_bwd = fuse, fuse_bwd
         for k, v in mdl.named_buffers():
             v.copy_(bufs[k])
         for p in mdl.parameters():
@@ -801,9 +801,21 @@ def test_shortcut_apply_inside_the_last_apply_pass_is_bitwise_and_saves_eight_la
         run(True)  # (the first pass also builds the bf16 weight images)
         f0, g0, b0, n0 = run(False)
         f1, g1, b1, n1 = run(True)
+        # ... and the backward counterpart (`ResBlock.fuse_sc_bwd`, vs_bn_bwd_apply2): the c unit's and the shortcut
+        # unit's BN-backward apply as one pass over the block's output gradient
+        nb0 = lib.vs_launch_count()
+        f2, g2, b2, _ = run(True, True)
+        nb2 = lib.vs_launch_count() - nb0
+        nb0 = lib.vs_launch_count()
+        run(True, False)
+        nb1 = lib.vs_launch_count() - nb0
     finally:
-        T.ResBlock.fuse_sc_apply = True
+        T.ResBlock.fuse_sc_apply, T.ResBlock.fuse_sc_bwd = True, True
     assert n0 - n1 == 8, (n0, n1)
-    assert all(torch.equal(a, b) for a, b in zip(f0, f1))
+    # (one apply launch fewer per res0 block; the shortcut's finalize no longer carries conv a's pending slab reduce,
+    #  which then takes a launch of its own: never more launches, 0.29 GB per step fewer)
+    assert nb2 <= nb1, (nb1, nb2)
+    assert all(torch.equal(a, b) for a, b in zip(f0, f1)) and all(torch.equal(a, b) for a, b in zip(f0, f2))
     assert not [k for k in g0 if not torch.equal(g0[k], g1[k])]
+    assert not [k for k in g0 if not torch.equal(g0[k], g2[k])]
     assert not [k for k in b0 if not torch.equal(b0[k], b1[k])]

@@ -95,6 +95,7 @@ SIGNATURES = {
         _i,
         [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _p],
     ),
+    "vs_bn_bwd_apply2": (_i, [_p] * 16 + [_i64, _i, _i, _i, _i, _i, _i, _p]),
     "vs_residual_add_f32": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _p]),
     "vs_maxpool_hw3s2_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "vs_maxpool_hw3s2_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -1244,6 +1244,88 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cols_kernel(
   }
 }
 
+// Two units fed by the SAME masked gradient (a ResBlock's c unit and its shortcut unit: g = dz under the block's ReLU
+// bits) in one pass: dz and the bits are read once, both dy written.  Per element the arithmetic of
+// bn_bwd_apply_cols_kernel<3> (bn_bwd_elem): bitwise the two passes.
+struct BnbUnit {
+  const uint16_t* y;
+  const float *mean, *invstd, *gamma, *dgamma, *dbeta;
+  uint16_t* dy;
+  int y_ld, dy_ld;
+};
+__global__ __launch_bounds__(256) void bn_bwd_apply2_cols_kernel(const uint16_t* dz, const uint8_t* bits, BnbUnit A, BnbUnit B,
+                                                                 long long rows, int C, int dz_ld, int nbatch) {
+  const int cpr = C >> 3;
+  const int ncol = cpr < 256 ? cpr : 256;
+  const int rl = 256 / ncol;
+  const int col = threadIdx.x % ncol, lane_r = threadIdx.x / ncol;
+  const long long r0 = (long long)blockIdx.x * rl * BNA_BATCH * nbatch;
+  const float invM = 1.0f / (float)rows;
+  for (int cb = col; cb < cpr; cb += ncol) {
+    const int c = cb * 8;
+    float muA[8], isA[8], gaA[8], b1A[8], b2A[8], muB[8], isB[8], gaB[8], b1B[8], b2B[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      muA[e] = A.mean[c + e]; isA[e] = A.invstd[c + e]; gaA[e] = A.gamma[c + e];
+      b1A[e] = A.dbeta[c + e] * invM; b2A[e] = A.dgamma[c + e] * invM;
+      muB[e] = B.mean[c + e]; isB[e] = B.invstd[c + e]; gaB[e] = B.gamma[c + e];
+      b1B[e] = B.dbeta[c + e] * invM; b2B[e] = B.dgamma[c + e] * invM;
+    }
+    for (int b = 0; b < nbatch; ++b) {
+      uint4 vg[BNA_BATCH], vA[BNA_BATCH], vB[BNA_BATCH];
+      unsigned vm[BNA_BATCH];
+      long long row[BNA_BATCH];
+#pragma unroll
+      for (int u = 0; u < BNA_BATCH; ++u) {
+        row[u] = r0 + (long long)(b * BNA_BATCH + u) * rl + lane_r;
+        const long long rr = row[u] < rows ? row[u] : 0;
+        vg[u] = ld_stream16(dz + rr * dz_ld + c);
+        vA[u] = ld_stream16(A.y + rr * A.y_ld + c);
+        vB[u] = ld_stream16(B.y + rr * B.y_ld + c);
+        vm[u] = __builtin_nontemporal_load(bits + rr * cpr + cb);
+      }
+#pragma unroll
+      for (int u = 0; u < BNA_BATCH; ++u) {
+        float g[8], ya[8], yb[8], oa[8], ob[8];
+        unpack8_bf16(vg[u], g);
+        unpack8_bf16(vA[u], ya);
+        unpack8_bf16(vB[u], yb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = ((vm[u] >> e) & 1u) ? g[e] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          oa[e] = bn_bwd_elem<false>(g[e], ya[e], muA[e], isA[e], gaA[e], 0.f, b1A[e], b2A[e]);
+          ob[e] = bn_bwd_elem<false>(g[e], yb[e], muB[e], isB[e], gaB[e], 0.f, b1B[e], b2B[e]);
+        }
+        if (row[u] < rows) {
+          *(uint4*)(A.dy + row[u] * A.dy_ld + c) = pack8_bf16(oa);
+          *(uint4*)(B.dy + row[u] * B.dy_ld + c) = pack8_bf16(ob);
+        }
+      }
+    }
+  }
+}
+
+extern "C" int vs_bn_bwd_apply2(const void* dz, const uint8_t* relu_bits, const void* y_a, const float* mean_a,
+                                const float* invstd_a, const float* gamma_a, const float* dgamma_a, const float* dbeta_a,
+                                void* dy_a, const void* y_b, const float* mean_b, const float* invstd_b,
+                                const float* gamma_b, const float* dgamma_b, const float* dbeta_b, void* dy_b, int64_t rows,
+                                int C, int dz_ld, int ya_ld, int dya_ld, int yb_ld, int dyb_ld, void* stream) {
+  VS_CHECK_ARG(dz && relu_bits && y_a && y_b && dy_a && dy_b, "null tensor");
+  VS_CHECK_ARG(mean_a && invstd_a && gamma_a && dgamma_a && dbeta_a && mean_b && invstd_b && gamma_b && dgamma_b && dbeta_b,
+               "null statistics");
+  VS_CHECK_ARG(C % 8 == 0 && cpr_pow2(C), "C/8 must be a power of two");
+  BnbUnit A{(const uint16_t*)y_a, mean_a, invstd_a, gamma_a, dgamma_a, dbeta_a, (uint16_t*)dy_a, ya_ld, dya_ld};
+  BnbUnit B{(const uint16_t*)y_b, mean_b, invstd_b, gamma_b, dgamma_b, dbeta_b, (uint16_t*)dy_b, yb_ld, dyb_ld};
+  const int nb = bn_rows_batches(rows, C, 2048);
+  const int cpr = C / 8, ncol = cpr < 256 ? cpr : 256;
+  const long long rpb = (long long)(256 / ncol) * BNA_BATCH * nb;
+  hipLaunchKernelGGL(bn_bwd_apply2_cols_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0,
+                     (hipStream_t)stream, (const uint16_t*)dz, relu_bits, A, B, (long long)rows, C, dz_ld, nb);
+  VS_CHECK_LAUNCH();
+  return VS_OK;
+}
+
 extern "C" int vs_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* mean,
                                const float* invstd, const float* gamma, const float* beta,
                                const float* dgamma, const float* dbeta, void* dy, void* dres,

@@ -778,6 +778,36 @@ def bn_bwd(dz, z, y, mean, invstd, gamma, relu, want_dres, dy_out=None, dgamma=N
     return dy, dres, dgamma, dbeta
 
 
+def bn_bwd_sums(dz, y, mean, invstd, zbits, dgamma, dbeta, partial=None):
+    """The reduce + finalize half of bn_bwd for a unit whose gradient is dz under a ReLU bit mask: dgamma / dbeta are
+    written; `partial`: the sums a data gradient already emitted (no reduce pass)."""
+    rows, c = act_rows(y), y.shape[1]
+    if partial is None:
+        nblk = _lib.load().vs_bn_bwd_reduce_rows(rows, c)
+        if nblk <= 0:
+            raise _lib.VsError("bn_bwd: unsupported channel count")
+        partial = torch.empty((nblk, 2, c), dtype=torch.float32, device=y.device)
+        if not (_WHATIF & 8):
+            _lib.call("vs_bn_bwd_reduce", _ptr(dz), _ptr(zbits), _ptr(y), _ptr(mean), _ptr(invstd), None, None,
+                      _ptr(partial), rows, c, act_ld(dz), c // 8, act_ld(y), 2, _stream())
+    if not (_WHATIF & 2):
+        _bn_bwd_finalize(partial, partial.shape[0], dgamma, dbeta, c)
+
+
+def bn_bwd_apply2(dz, zbits, a, b):
+    """Backward apply of two units fed by the same masked gradient (vs_bn_bwd_apply2); a / b = (y, mean, invstd, gamma,
+    dgamma, dbeta) -> (dy_a, dy_b).  Bitwise two bn_bwd apply passes."""
+    ya, yb = a[0], b[0]
+    rows, c = act_rows(ya), ya.shape[1]
+    dya, dyb = new_act(*ya.shape, device=ya.device), new_act(*yb.shape, device=yb.device)
+    if _WHATIF & 8:
+        return dya, dyb
+    _lib.call("vs_bn_bwd_apply2", _ptr(dz), _ptr(zbits), _ptr(ya), *[_ptr(t) for t in a[1:]], _ptr(dya),
+              _ptr(yb), *[_ptr(t) for t in b[1:]], _ptr(dyb), rows, c, act_ld(dz), act_ld(ya), act_ld(dya),
+              act_ld(yb), act_ld(dyb), _stream())
+    return dya, dyb
+
+
 def residual_add_f32(branch, residual, relu=True, out16=None):
     """fp32 residual stream (eval): -> (out16 bf16 activation, out32 fp32 [rows, C]).  `residual`: a bf16 activation
     (the shortcut unit's output) or the fp32 [rows, C] stream of the previous block."""

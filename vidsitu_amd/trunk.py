@@ -364,7 +364,7 @@ class _Unit:
 
     @staticmethod
     def bwd(rec, dz, need_dx=True, want_dres=False, dx_residual=None, masked=False, producer=None,
-            dz_bits=None, dx_residual_bits=None, inplace=False):
+            dz_bits=None, dx_residual_bits=None, inplace=False, dy_ready=None):
         """Returns (dx|None, dres|None).  `masked`: dz already carries the ReLU mask.
         `producer`: the record of the unit whose output is this unit's only input (the a -> b and b -> c
         links of a bottleneck): this unit's dgrad then also emits the producer's BN-backward sums
@@ -372,8 +372,24 @@ class _Unit:
         `dz_bits`: dz is an UNMASKED gradient and these the ReLU bits to apply to it (the shortcut unit of a
         ResBlock reads the block's output gradient through the block's own mask instead of a masked copy).
         `dx_residual_bits`: the same for the gradient added in the dgrad epilogue.
-        `inplace`: the dgrad accumulates into dx_residual."""
+        `inplace`: the dgrad accumulates into dx_residual.
+        `dy_ready`: the unit's BN backward already ran (`ResBlock.bwd`: the c and shortcut units in one pass) and this
+        is its dy -- only the convolution's gradients are left."""
         conv, bn = rec["conv"], rec["bn"]
+        if dy_ready is not None:
+            assert not want_dres
+            x = rec["x"]
+            pair = (_Unit.pair_launch and need_dx and not conv.is_stem and conv.cin_pad == conv.cin and dy_ready.is_cuda
+                    and _Unit.wgrad_batch is None and not _Unit.split_wgrad_reduce)
+            pair_ctx = ops.conv_pair() if pair else contextlib.nullcontext()
+            pair_ctx.__enter__()
+            try:
+                dx = _Unit._bwd_convs(conv, dy_ready, x, need_dx, producer, dx_residual, dx_residual_bits, inplace, pair,
+                                      rec.get("x_affine"))
+            finally:
+                pair_ctx.__exit__(None, None, None)
+            _WgradLanes.join_unit()
+            return dx, None
         relu = rec["relu"] and not masked
         if bn.weight.grad is None:
             bn.weight.grad = torch.zeros_like(bn.weight)
@@ -636,7 +652,26 @@ class ResBlock(nn.Module):
         # kept as bits (`zbits`, written by the forward apply) its two readers take (dout, bits) and the c unit's
         # backward apply does not write a masked copy (`dres`: one block-output-sized tensor per block).
         cbits = rc.get("zbits")  # None for channel counts whose mask is not kept as bits
-        db, g = _Unit.bwd(rc, dout, want_dres=cbits is None, producer=rb)
+        dy_sc = None
+        if (self.has_sc and cbits is not None and ResBlock.fuse_sc_bwd and dout.is_cuda and saved
+                and rc["conv"].bias is None and saved[-1]["conv"].bias is None and ops.bn_apply2_ok(rc["y"].shape[1])):
+            # the c unit and the shortcut unit receive the same masked gradient: both finalizes first, then ONE backward
+            # apply pass that reads dout and the bits once and writes both dy (bitwise the two passes)
+            rsc = saved[-1]
+            units = []
+            for r in (rc, rsc):
+                bn = r["bn"]
+                if bn.weight.grad is None:
+                    bn.weight.grad = torch.zeros_like(bn.weight)
+                if bn.bias.grad is None:
+                    bn.bias.grad = torch.zeros_like(bn.bias)
+                ops.bn_bwd_sums(dout, r["y"], r["mean"], r["invstd"], cbits, bn.weight.grad, bn.bias.grad,
+                                partial=r.pop("bwd_partial", None))
+                units.append((r["y"], r["mean"], r["invstd"], bn.weight, bn.weight.grad, bn.bias.grad))
+            dy_c, dy_sc = ops.bn_bwd_apply2(dout, cbits, units[0], units[1])
+            db, g = _Unit.bwd(rc, dout, producer=rb, dy_ready=dy_c)
+        else:
+            db, g = _Unit.bwd(rc, dout, want_dres=cbits is None, producer=rb)
         da, _ = _Unit.bwd(rb, db, producer=ra)
         if self.has_sc:
             rsc = saved.pop()
@@ -646,11 +681,11 @@ class ResBlock(nn.Module):
                 # a block-input-sized tensor that is 3/4 zeros and re-reading it as a residual
                 dxa, _ = _Unit.bwd(ra, da)
                 if cbits is not None:
-                    dx, _ = _Unit.bwd(rsc, dout, dz_bits=cbits, dx_residual=dxa, inplace=True)
+                    dx, _ = _Unit.bwd(rsc, dout, dz_bits=cbits, dx_residual=dxa, inplace=True, dy_ready=dy_sc)
                 else:
                     dx, _ = _Unit.bwd(rsc, g, masked=True, dx_residual=dxa, inplace=True)
             else:
-                dx1, _ = (_Unit.bwd(rsc, dout, dz_bits=cbits) if cbits is not None
+                dx1, _ = (_Unit.bwd(rsc, dout, dz_bits=cbits, dy_ready=dy_sc) if cbits is not None
                           else _Unit.bwd(rsc, g, masked=True))
                 dx, _ = _Unit.bwd(ra, da, dx_residual=dx1)
         elif cbits is not None:
@@ -660,6 +695,9 @@ class ResBlock(nn.Module):
             dx, _ = _Unit.bwd(ra, da, dx_residual=g, producer=saved[-1] if (chain and saved) else None)
         return dx
 
+    # Train, backward: the c unit's and the shortcut unit's BN-backward apply as one pass (ops.bn_bwd_apply2): the block's
+    # output gradient and its ReLU bits are read once.  VS_FUSE_SC_BWD=0: two passes.
+    fuse_sc_bwd = os.environ.get("VS_FUSE_SC_BWD", "1") != "0"
     # Train: the shortcut unit's BN apply inside the c unit's apply pass (ops.bn_apply2).  VS_FUSE_SC_APPLY=0: two passes.
     fuse_sc_apply = os.environ.get("VS_FUSE_SC_APPLY", "1") != "0"
 
