@@ -838,6 +838,9 @@ def main():
                                     "BASELINE configs[1]: SlowFast-R50 feature extractor only, eval, "
                                     "8 clips x 3x32x224x224 per GPU"),
                        "clips_per_gpu": CLIPS_PER_GPU, "hipgraph": used_graph,
+                       **({"whatif": f"VS_WHATIF={os.environ['VS_WHATIF']}: kernel launches skipped, GARBAGE numerics -- a "
+                                     "timing experiment, not a measurement of the workload"}
+                          if os.environ.get("VS_WHATIF", "0") not in ("", "0") else {}),
                        **({} if CLIPS_PER_GPU == 8 else
                           {"probe": f"{CLIPS_PER_GPU} clips/GPU instead of the BASELINE config's 8: not the headline metric"}),
                        **({"probe_enc_layers": os.environ["VS_BENCH_ENC_LAYERS"]}

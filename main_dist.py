@@ -157,8 +157,11 @@ def main_dist(uid, **kwargs):
         if kwargs.get("num_gpus") is not None and world != want:
             sys.exit(f"main_dist.py: --num_gpus={want} but the launcher set WORLD_SIZE={world}")
         want = world
-    if want > n:
-        sys.exit(f"main_dist.py: {want} ranks requested but {n} GPU(s) visible")
+    # ranks that must find a GPU on THIS node: under an external launcher that is LOCAL_WORLD_SIZE (torch.distributed.run
+    # sets it; a multi-node job has WORLD_SIZE > the node's GPUs), else the whole job
+    local_want = int(os.environ.get("LOCAL_WORLD_SIZE", want)) if in_rank else want
+    if local_want > n:
+        sys.exit(f"main_dist.py: {local_want} ranks on this node but {n} GPU(s) visible")
     cfg.num_gpus = want
     cfg.do_dist = want > 1 or os.environ.get("VS_FORCE_DIST") == "1"
     cfg.freeze()

@@ -337,17 +337,19 @@ def test_every_resblock_fwd_bwd_matches_oracle_on_the_oracles_own_tensors(arch, 
     # draw of the same process: at the 64-pixel crop one BN-bias gradient of slow s4 (256 positions per channel, half of
     # them behind the mask) moved from < 1.4e-2 to 4.9e-2 (its block's dx 2.3e-2) while the table's median and the
     # 1e-2 / 2e-2 fractions below stayed put (VS_CONV_KORDER_MIN=0 reproduces the old table: worst tensor 2.2e-2; both
-    # tables in profiles/r04_parity_blocks_korder.txt; the kernels themselves are tested against torch in both orders).  BN parameter gradients of the small-crop runs get
-    # 7e-2 (still far below the O(1) a wrong formula gives); everything else keeps 4e-2.
+    # tables in profiles/r04_parity_blocks_korder.txt; the kernels themselves are tested against torch in both orders).  That one tensor gets
+    # 7e-2 at the small crops (still far below the O(1) a wrong formula gives); everything else keeps 4e-2.
     def limit(block, tensor):
         if hw >= 224 and block.endswith("_res0") and tensor in ("branch1.weight", "branch2.a.weight"):
             return 1.5e-1
-        if hw < 224 and ("_bn." in tensor or tensor.startswith("branch1_bn")):
+        # (the relaxed bound is for the ONE tensor that moved -- slow s4 res2's b_bn bias at the 64-pixel crop,
+        #  4.87e-2 in profiles/r04_parity_blocks_korder.txt -- not for every BN tensor of every block)
+        if hw < 224 and block == "s4.pathway0_res2" and tensor == "branch2.b_bn.bias":
             return 7e-2
         return 4e-2
     gross = [(n, [(k, e) for k, e in bad if not e < limit(n, k)]) for _, n, _, _, _, bad in worst]
     gross = [(n, b) for n, b in gross if b]
-    assert not gross, f"tensors beyond their bound (4e-2; BN parameters at small crops 7e-2): {gross[:3]}"
+    assert not gross, f"tensors beyond their bound (4e-2; slow s4 res2's b_bn bias at small crops 7e-2): {gross[:3]}"
     errs = sorted(r[0] for r in worst)
     assert errs[len(errs) // 2] < 1e-2, f"median block's worst tensor {errs[len(errs) // 2]:.3e}"
     tight = sum(1 for e in errs if e < 1e-2)

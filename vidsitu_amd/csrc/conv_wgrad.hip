@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
 template <int BM, int BN, int WM, int WN, int MODE, int NS, bool AOL = false, int ROWS = 64>
 __device__ __forceinline__ void conv_wgrad_ring_body(const WgradP& p, const int blk, const int nblk) {
   static_assert(!AOL || MODE == 0, "apply on load: pointwise launches");
-  static_assert(ROWS == 64 || ROWS == 32, "stage depth");
+  static_assert(ROWS == 64, "stage depth (the half-depth variant of round 4 was measured slower and removed)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MR = TM / 16, NR = TN / 16;
@@ -955,10 +955,6 @@ static bool wg_deep_plan(const vs_conv_desc* d, WgCfg* c) {
   const long long slab_cap = (64ll << 20) / ((long long)d->Cout * Kp * 4);
   if (S > slab_cap) S = slab_cap;
   if (S < 1) S = 1;
-  // VS_WGRAD_DEEP_ALIGN=1 (experiment): whole splits per XCD -- S rounded down to a multiple of 8 where a split's tiles
-  // fit one XCD's 32 CUs; with the XCD-contiguous block order every dY / x row is then fetched once per XCD
-  static const int align = [] { const char* e = getenv("VS_WGRAD_DEEP_ALIGN"); return e ? atoi(e) : 0; }();
-  if (align && tiles <= 32 && S >= 8) S = (S / 8) * 8;
   long long rps = (P + S - 1) / S;
   rps = (rps + 31) / 32 * 32;
   S = (P + rps - 1) / rps;
@@ -1048,20 +1044,10 @@ static WgCfg wg_pick(const vs_conv_desc* d) {
   if (S > slab_cap) S = slab_cap;
   if (S > 1024) S = 1024;
   if (S < 1) S = 1;
-  // One position split per XCD (or a whole number of them).  The blocks of a split read the SAME dY / x rows, one
-  // block per output tile; with the XCD-contiguous block order (xcd_order) and S a multiple of 8 every XCD works on
-  // whole splits, so a row is fetched once per XCD from beyond its L2 and the other tiles' reads hit.  Unaligned
-  // (e.g. 48 tiles x 7 splits) the blocks of one XCD straddle splits, most staged bytes miss L2, and the kernel is
-  // bound by the ~27 GB/s a CU takes in from beyond L2 (tools/probes/lds_dma_rate.hip): s4.a staged 300 MB at
-  // 256 x 27 GB/s = 43 us, measured 44.6.  THAT WAS THE HYPOTHESIS; measured (profiles/r04_wgrad_xcd_align.txt) the
-  // aligned plan is 4 % slower over the layers (s4.b 37 -> 45 us with 8 instead of 10 splits, s4.a unchanged with the
-  // XCD order alone) and 0.5 % slower in the step: the ring kernel is not bound by L2 misses.  Opt-in: VS_WGRAD_ALIGN8=1.
-  static const int align8 = [] { const char* e = getenv("VS_WGRAD_ALIGN8"); return e ? atoi(e) : 0; }();
-  if (align8 && !forced_slots && tiles <= 64 && S >= 5) {
-    long long S8 = ((S + 3) / 8) * 8;
-    if (S8 < 8) S8 = 8;
-    if (S8 <= maxS && S8 <= slab_cap) S = S8;
-  }
+  // (Rounds 3-4 measured two variants that are gone from the tree: splits rounded to whole multiples of 8, one per XCD
+  //  -- VS_WGRAD_ALIGN8, 4 % slower over the layers: the ring kernel is not bound by L2 misses,
+  //  profiles/r04_wgrad_xcd_align.txt -- and half-depth ring stages, 4 x 32 positions -- VS_WGRAD_HALF, -3.4 %,
+  //  profiles/r04_wgrad_half_stages.txt.)
   long long rps = (P + S - 1) / S;
   rps = (rps + 63) / 64 * 64;
   S = (P + rps - 1) / rps;
@@ -1103,23 +1089,6 @@ static int wg_launch(const WgradP& p, int mode, int ring, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<BM, BN, WM, WN, 1, 3>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
-  }
-  if (ring == 5) {  // half-stage ring: four stages of 32 positions in the two-stage ring's 64 KiB (VS_WGRAD_HALF)
-    static bool hattr = false;
-    if (!hattr) {
-      (void)hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<BM, BN, WM, WN, 0, 4, false, 32>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<BM, BN, WM, WN, 1, 4, false, 32>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hattr = true;
-    }
-    const size_t smem = (size_t)4 * 2 * 32 * 256 + (mode ? 2 * WG_ROWTAB * sizeof(int2) : 0);
-    if (mode == 0)
-      hipLaunchKernelGGL((conv_wgrad_ring_kernel<BM, BN, WM, WN, 0, 4, false, 32>), dim3(grid), dim3(256), smem, st, p);
-    else
-      hipLaunchKernelGGL((conv_wgrad_ring_kernel<BM, BN, WM, WN, 1, 4, false, 32>), dim3(grid), dim3(256), smem, st, p);
-    VS_CHECK_LAUNCH();
-    return VS_OK;
   }
   if (ring >= 2) {
     const size_t tab = mode ? 2 * WG_ROWTAB * sizeof(int2) : 0;
@@ -1218,7 +1187,6 @@ static int wgrad_impl(const void* dy, const void* x, float* dw, const vs_conv_de
     // measured per layer (batch 8): a win up to ~16 output tiles (s3.b 43.5 -> 35.4 us, s4.c 22.1 -> 19.7,
     // s3.c 24.7 -> 21.2, s2.c 29.7 -> 26.4), a loss from 36 tiles on (s4.b 36.7 -> 38.9, s5.b 48.9 -> 52.9), where
     // one split's tiles no longer fit an XCD's share of the grid anyway
-    // (round 4: with S a multiple of 8 -- wg_pick, VS_WGRAD_ALIGN8 -- the XCD runs are whole splits for any tile count)
     p.xcd_order = xo && (c.tilesM * c.tilesN <= 32 || xo == 2 || (c.S % 8 == 0 && c.tilesM * c.tilesN <= 64));
     static const int dbg = [] { const char* e = getenv("VS_WGRAD_DBG"); return e ? atoi(e) : 0; }();
     p.dbg = dbg;
@@ -1234,10 +1202,6 @@ static int wgrad_impl(const void* dy, const void* x, float* dw, const vs_conv_de
   // loses a little on the skinny ones
   int ring = fring == 1 ? 0 : (fring >= 2 ? (fring > 3 ? 3 : fring) : (c.bm == 128 ? 2 : 0));
   if (d->kT * d->kH * d->kW > 31) ring = 0;  // the tap bitmask of the ring's position table
-  {
-    static const int half = [] { const char* e = getenv("VS_WGRAD_HALF"); return e ? atoi(e) : 0; }();
-    if (half && ring == 2 && !in_scale) ring = 5;
-  }
   int rc;
   if (c.deep) {
     static std::once_flag dattr;

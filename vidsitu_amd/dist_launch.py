@@ -49,11 +49,33 @@ def visible_gpus():
             continue  # a node this user may not read is not a usable GPU
         if int(props.get("simd_count", "0")) > 0:
             n += 1
+    # The topology lists every GPU of the HOST; a container / cgroup may map only some of them.  What this process can
+    # open is a render node: the sysfs count is an upper bound, cut down to the /dev/dri/renderD* nodes that exist
+    # here AND are openable by this user (where /dev/dri is absent altogether the bound stays as it is).
+    nodes = glob.glob("/dev/dri/renderD*")
+    if nodes:
+        n = min(n, sum(1 for d in nodes if os.access(d, os.R_OK | os.W_OK)))
     for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:
-            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+            n = min(n, _count_visible_tokens(v, n))
     return n
+
+
+def _count_visible_tokens(value, n_devices):
+    """Devices a *_VISIBLE_DEVICES value selects out of n_devices: integer tokens must be in range and distinct (the
+    runtime stops at the first invalid one); anything else (a GPU-<uuid> token) is taken at face value."""
+    seen = []
+    for t in value.split(","):
+        t = t.strip()
+        if t == "":
+            break
+        if t.lstrip("-").isdigit():
+            i = int(t)
+            if i < 0 or i >= n_devices or i in seen:
+                break
+        seen.append(t)
+    return len(seen)
 
 
 def rank_env(rank, world, port, base=None):

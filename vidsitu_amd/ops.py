@@ -476,6 +476,11 @@ def conv_dgrad(dy, wt, xs, k, s, p, out=None, residual=None, naive=False, tile=N
 _ws_cache = {}
 VS_WGRAD_NODEEP = 1 << 12  # include/vidsitu_hip.h: keep a weight gradient off the deep-pipeline kernel
 import os as _os_wi
+# VS_WHATIF (tools/whatif.sh: whole kernel families skipped to time what they cost -- GARBAGE numerics) is refused unless
+# the tools-only guard VS_WHATIF_OK=1 stands beside it: a leaked variable must not train silently on garbage.
+if int(_os_wi.environ.get("VS_WHATIF", "0")) != 0 and _os_wi.environ.get("VS_WHATIF_OK") != "1":
+    raise RuntimeError("VS_WHATIF skips kernel launches (garbage numerics, timing experiments only): set VS_WHATIF_OK=1 "
+                       "beside it, or unset it")
 _WHATIF_WGRAD = (int(_os_wi.environ.get("VS_WHATIF", "0")) & 4) != 0  # tools only (see conv_wgrad)
 
 
