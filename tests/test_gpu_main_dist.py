@@ -119,6 +119,7 @@ def test_feat_extractor_cli_from_a_trained_checkpoint_and_from_a_caffe2_pickle(d
     ck = tmp_path / "models" / "t_fx.pth"
     rc, out, err = _run(["-m", "vidsitu_amd.feat_extractor", str(ck), "trained_mini", "--n_videos=3"] + common)
     assert rc == 0 and "wrote 6 feature files" in out, out[-2000:] + err
+    assert "weight-rounding correction calibrated on 2 clip(s)" in out  # (round 5: on by default, --calibrate=0 switches it off)
     files = sorted((tmp_path / "feats" / "trained_mini").glob("*_feats.npy"))
     assert len(files) == 6
     a = np.load(files[0])
@@ -134,8 +135,9 @@ def test_feat_extractor_cli_from_a_trained_checkpoint_and_from_a_caffe2_pickle(d
     pk = tmp_path / "zoo.pkl"
     _fake_c2_file(slowfast_ref.VideoTrunk(cfg.sf_mdl), pk, "mini")
     rc, out, err = _run(["-m", "vidsitu_amd.feat_extractor", str(pk), "zoo_mini", "--is_cu=True", "--n_videos=2",
-                         "--splits=valid"] + common)
+                         "--splits=valid", "--calibrate=0"] + common)
     assert rc == 0 and "Using Caffe2 checkpoint" in out and "wrote 2 feature files" in out, out[-2000:] + err
+    assert "weight-rounding correction" not in out
 
 
 def test_main_dist_vb_arg_row_trains_and_evaluates(dev, tmp_path):

@@ -92,13 +92,17 @@ def read_frm_feats(feats_dir, vseg_name):
 
 
 def main(mdl_resume_path: str, mdl_name_used: str, is_cu: bool = False, splits=("valid", "train"), n_videos=None,
-         **kwargs):
+         calibrate: int = 2, **kwargs):
     """`python -m vidsitu_amd.feat_extractor <weights> <name> [--is_cu=True] [--dotted.key=value ...]`
     (`feat_extractor.py:119-176`): build the configured model, load a TRAINED checkpoint (the trainer's file format,
     `module.` prefixes stripped) or -- `is_cu` -- the Kinetics model-zoo Caffe2 pickle into `mdl.sf_mdl`, and write
     `<vsitu_frm_feats>/<name>/<vseg>_feats.npy` ([E, 2304] / [E, 2048] float32) for every video of every split.
     The videos are the synthetic stand-in dataset (`SynthFrameDataset`; the 50 GB frame dataset is out of scope), so what this
-    entry point pins is the flow: weights -> eval trunk on the HIP kernels -> head -> files the TxEncoder rows read back."""
+    entry point pins is the flow: weights -> eval trunk on the HIP kernels -> head -> files the TxEncoder rows read back.
+    `--calibrate=N` (default 2; 0 = off): before the first split the model measures, on N videos' clips that are NOT
+    dumped (their own seed), the per-channel constants the bf16 rounding of its convolution weights adds and folds their
+    correction into the BN shifts (`SFBase.calibrate_weight_rounding`): features within 1e-3 of the fp32 reference's instead
+    of 3e-3 (tests/test_gpu_parity_full.py), at no cost per forward."""
     from . import checkpoint, synth_data
     from .extended_config import get_cfg
     from .mdl_selector import get_mdl_loss_eval
@@ -116,6 +120,11 @@ def main(mdl_resume_path: str, mdl_name_used: str, is_cu: bool = False, splits=(
         if got is None:
             raise FileNotFoundError(mdl_resume_path)
     mdl = mdl.to(torch.device("cuda")).eval()
+    if int(calibrate) > 0 and hasattr(mdl, "calibrate_weight_rounding"):
+        cal = synth_data.synth_batch(cfg, comm, bs=int(calibrate), n_ev=1, seed=cfg.synth.seed + 999_983,
+                                     device=torch.device("cuda"), dtype=torch.bfloat16)
+        n_cal = mdl.calibrate_weight_rounding(cal)
+        print(f"weight-rounding correction calibrated on {int(calibrate)} clip(s): {n_cal} convolutions")
     feat_ext, written = FeatExtract(cfg), []
     n = int(n_videos) if n_videos is not None else int(cfg.synth.num_videos)
     for si, split in enumerate(splits):
@@ -137,6 +146,8 @@ if __name__ == "__main__":
         k, v = a[2:].split("=", 1)
         kw[k] = v
     is_cu = str(kw.pop("is_cu", "False")) in ("1", "True", "true")
+    if "calibrate" in kw:
+        kw["calibrate"] = int(kw["calibrate"])
     if "splits" in kw:
         kw["splits"] = tuple(kw["splits"].split(","))
     main(sys.argv[1], sys.argv[2], is_cu=is_cu, **kw)
