@@ -1,5 +1,5 @@
 """The bench line's schema (the driver parses it): checked on the committed lines of the current round's build
-(`profiles/r04_bench_train_v7.json`, `profiles/r04_bench_feat_fwd_v7.json`, produced by `python bench.py` on an MI355X)
+(`profiles/r05_bench_train_v1.json`, `profiles/r05_bench_feat_fwd_v1.json`, produced by `python bench.py` on an MI355X)
 and on bench.py's argument surface -- no GPU needed."""
 import json
 import os
@@ -14,7 +14,7 @@ def _line(name):
 
 
 def test_train_line_has_the_contract_fields():
-    d = _line("r04_bench_train_v7.json")
+    d = _line("r05_bench_train_v1.json")
     for k in ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better",
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -45,6 +45,14 @@ def test_train_line_has_the_contract_fields():
         assert k in f, k
     assert "configs[1]" in f["workload"] and f["clips_per_s"] > 0
     assert abs(f["clips_per_s"] - 8 / (f["ms_per_step"] * 1e-3)) < 0.02 * f["clips_per_s"]
+    # round 5: the eval leg runs with calibrated BN shifts (north_star's 1e-3 on the arithmetic that is timed), and the
+    # reference's own batch [B = 8, E = 5] is in the driver's record
+    assert f["parity"]["eval_mode"] == "bf16_calibrated_shift" and f["parity"]["logits_rel_err_vs_fp32_oracle"] < 1e-3
+    c40 = d["canonical_b8x5"]
+    for k in ("workload", "clips_per_s", "ms_per_step", "replays", "frac_of_bf16_mfma_peak"):
+        assert k in c40, k
+    assert abs(c40["clips_per_s"] - 40 / (c40["ms_per_step"] * 1e-3)) < 0.02 * c40["clips_per_s"]
+    assert r["total_launches_per_step"] <= 920 and r["bn_all"]["tiny_launches_per_step"] <= 240
     par = d["config"]["parity"]
     assert par["north_star"] == 1e-3 and 0 < par["logits_rel_err_vs_fp32_oracle"] < 1e-2
     assert "measured_at_commit" in par and "not re-measured in this run" in par["source"]
@@ -67,7 +75,7 @@ def test_parity_numbers_come_from_the_file_the_parity_test_writes():
 
 
 def test_forward_line_and_cli_surface():
-    d = _line("r04_bench_feat_fwd_v7.json")
+    d = _line("r05_bench_feat_fwd_v1.json")
     assert d["unit"] == "clips/s" and d["value"] > 0 and "feature extractor" in d["metric"]
     assert "parity" in d["config"]  # the measured logit distance to the fp32 oracle, per eval mode
     src = open(os.path.join(ROOT, "bench.py")).read()
