@@ -101,3 +101,24 @@ def test_bench_gpus_flag_fails_loudly_without_the_devices():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
                        text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_visible_device_tokens_are_counted_like_the_runtime_does():
+    """`*_VISIBLE_DEVICES` is more than a comma count -- out-of-range, repeated or empty tokens end the list
+    (the runtime stops there); UUID tokens are taken at face value."""
+    f = dist_launch._count_visible_tokens
+    assert f("0,1,2", 8) == 3
+    assert f("0,1,9", 8) == 2          # 9 does not exist: the runtime stops at it
+    assert f("3,3", 8) == 1            # a repeated index ends the list
+    assert f("", 8) == 0 and f("0,,1", 8) == 1
+    assert f("-1", 8) == 0
+    assert f("GPU-abcdef,GPU-123456", 8) == 2
+    assert f("1, 2", 4) == 2
+
+
+def test_visible_gpus_is_bounded_by_what_the_environment_selects(monkeypatch):
+    n = dist_launch.visible_gpus()
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert dist_launch.visible_gpus() == 0
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2,3,4,5,6,7,8,9")
+    assert dist_launch.visible_gpus() <= n
