@@ -71,9 +71,9 @@ def _count_visible_tokens(value, n_devices):
         if t == "":
             break
         if t.lstrip("-").isdigit():
-            i = int(t)
-            if i < 0 or i >= n_devices or i in seen:
+            if int(t) < 0 or int(t) >= n_devices or str(int(t)) in seen:
                 break
+            t = str(int(t))
         seen.append(t)
     return len(seen)
 
