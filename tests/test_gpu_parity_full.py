@@ -356,3 +356,44 @@ def test_every_resblock_fwd_bwd_matches_oracle_on_the_oracles_own_tensors(arch, 
     assert tight >= 0.5 * len(errs), f"only {tight} of {len(errs)} blocks entirely within 1e-2"
     near = sum(1 for e in errs if e < 2e-2)
     assert near >= 0.9 * len(errs) - 1e-9, f"only {near} of {len(errs)} blocks entirely within 2e-2"
+
+
+def test_configs2_bench_batch_train_mode_forward_and_loss_vs_the_fp32_oracle(dev):
+    """BASELINE configs[2] at its full size, TRAINING mode (the arithmetic the headline line times): the bench's 8-clip batch
+    (2 videos x 4 events, 3 x 32 x 224 x 224) through SlowFast-R50 + the verb head with batch-statistic BatchNorm, HIP vs
+    the fp32 oracle on the CPU -- logits, loss, and the running statistics the pass leaves behind.  Batch statistics remove a
+    per-channel constant exactly, so the bf16 rounding of the weights (all of the eval path's 2.8e-3) does not reach these
+    logits the way it reaches the eval ones; what is left is the activations' rounding through 110 renormalised layers.
+    Measured (round 5): logits 1.1e-2 of max |logit| (rel_l2 1.0e-2), loss 8.9243 vs 8.9383 (0.16 %), running_var 2.0e-3,
+    running_mean 3.9e-4 of sqrt(var); the bounds are ~2x that (running statistics: 10x -- they are sums, not chains)."""
+    import torch.nn.functional as F
+    from vidsitu_amd import synth_data
+
+    cfg, comm, ref, mdl = _sfbase_pair("slow_fast_nl_r50_8x8", 1564, dev)
+    with torch.no_grad():  # (ZERO_INIT_FINAL_BN would leave the residual branches switched off: every layer should count)
+        for n, m in ref.named_modules():
+            if n.endswith("branch2.c_bn"):
+                m.weight.fill_(0.5)
+    mdl.load_state_dict(ref.state_dict(), strict=True)
+    batch = synth_data.synth_batch(cfg, comm, bs=2, n_ev=4, seed=1234)
+    assert tuple(batch["frms_ev_fast_tensor"].shape) == (2, 4, 3, 32, 224, 224)
+    labels = batch["label_tensor"].flatten()
+    ref.train()
+    mdl.train()
+    with torch.no_grad():
+        lr = ref([batch["frms_ev_slow_tensor"].flatten(0, 1), batch["frms_ev_fast_tensor"].flatten(0, 1)])
+        gb = {k: v.to(dev) for k, v in batch.items()}
+        lo = mdl(gb)["mdl_out"].float().cpu().view(8, -1)
+    scale = float(lr.abs().max())
+    err = float((lo - lr).abs().max()) / scale
+    loss_r, loss_o = float(F.cross_entropy(lr, labels)), float(F.cross_entropy(lo, labels))
+    print(f"train-mode forward, 8 clips 224^2: logits relative error {err:.3e} (rel_l2 {rel_l2(lo, lr):.3e}), "
+          f"loss {loss_o:.5f} vs {loss_r:.5f}")
+    sd_o, sd_r = mdl.state_dict(), ref.state_dict()
+    rv = max(rel_l2(sd_o[k].float().cpu(), sd_r[k]) for k in sd_r if "running_var" in k)
+    rm = max(float((sd_o[k].float().cpu() - sd_r[k]).norm() / sd_r[k.replace("running_mean", "running_var")].sqrt().norm())
+             for k in sd_r if "running_mean" in k)
+    print(f"running statistics after the pass: running_var worst rel_l2 {rv:.3e}, running_mean worst error / sqrt(var) {rm:.3e}")
+    assert err < 2e-2 and abs(loss_o - loss_r) < 1e-2 * abs(loss_r)
+    assert rv < 2e-2 and rm < 2e-2
+    _check_top5(lo, lr, err * scale)
