@@ -819,3 +819,50 @@ def test_shortcut_apply_inside_the_last_apply_pass_is_bitwise_and_saves_eight_la
     assert not [k for k in g0 if not torch.equal(g0[k], g1[k])]
     assert not [k for k in g0 if not torch.equal(g0[k], g2[k])]
     assert not [k for k in b0 if not torch.equal(b0[k], b1[k])]
+
+
+@pytest.mark.parametrize("sf_name,crop", [("slow_fast_mini", 64), ("i3d_tiny", 64), ("i3d_r50_nl_8x8", 64)])
+def test_weight_rounding_calibration_on_every_trunk_family(sf_name, crop, dev):
+    """`SFBase.calibrate_weight_rounding` on the two-pathway, single-pathway and non-local trunks: the eval logits move
+    TOWARDS the fp32 oracle's (calibration on other clips), the correction survives repeated forwards bit for bit, is
+    dropped by `reset_weight_rounding` and by a weight update, and never touches the training path."""
+    from oracle.slowfast_ref import SFBaseRef, randomize_bn
+    from vidsitu_amd import synth_data
+    from vidsitu_amd.extended_config import get_cfg
+    from vidsitu_amd.mdl_selector import get_mdl_loss_eval
+
+    cfg = get_cfg({"mdl.sf_mdl_name": sf_name, "synth.num_verbs": 64})
+    comm = synth_data.make_comm(cfg)
+    torch.manual_seed(0)
+    mdl = get_mdl_loss_eval(cfg)["mdl"](cfg=cfg, comm=comm)
+    ref = SFBaseRef(cfg.sf_mdl, 64)
+    randomize_bn(ref, 1)
+    mdl.load_state_dict(ref.state_dict(), strict=True)
+    mdl, ref = mdl.to(dev).eval(), ref.eval()
+    batch = synth_data.synth_batch(cfg, comm, bs=1, n_ev=2, crop=crop, seed=11)
+    cal = synth_data.synth_batch(cfg, comm, bs=1, n_ev=2, crop=crop, seed=12)
+    gb = {k: v.to(dev) for k, v in batch.items()}
+    with torch.no_grad():
+        inp = [batch["frms_ev_fast_tensor"].flatten(0, 1)]
+        if "frms_ev_slow_tensor" in batch:
+            inp = [batch["frms_ev_slow_tensor"].flatten(0, 1)] + inp
+        want = ref(inp).view(1, 2, -1)
+        plain = mdl(gb)["mdl_out"].float().cpu()
+        n = mdl.calibrate_weight_rounding({k: v.to(dev) for k, v in cal.items()})
+        assert n >= 8
+        got = mdl(gb)["mdl_out"].float().cpu()
+        again = mdl(gb)["mdl_out"].float().cpu()
+    scale = float(want.abs().max())
+    e0, e1 = float((plain - want).abs().max()) / scale, float((got - want).abs().max()) / scale
+    print(f"{sf_name}: eval logits vs the fp32 oracle {e0:.3e} -> {e1:.3e} with calibrated shifts ({n} convolutions)")
+    assert torch.equal(got, again)
+    assert e1 < max(0.9 * e0, 1.5e-3), (e0, e1)  # small nets at 64^2 have little weight-rounding error to remove
+    mdl.sf_mdl.reset_weight_rounding()
+    with torch.no_grad():
+        assert torch.equal(mdl(gb)["mdl_out"].float().cpu(), plain)
+        mdl.calibrate_weight_rounding({k: v.to(dev) for k, v in cal.items()})
+        with torch.no_grad():
+            next(iter(mdl.sf_mdl.parameters())).mul_(1.0)  # any in-place weight update bumps the version counters
+        out = mdl(gb)["mdl_out"].float().cpu()
+    assert all(b.wround_bias is None for b in mdl.sf_mdl._bns()), "a weight update must drop the correction"
+    assert torch.equal(out, plain)

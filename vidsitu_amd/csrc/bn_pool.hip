@@ -431,11 +431,13 @@ __global__ __launch_bounds__(1024) void bn_finalize2_kernel(Fin2P f, int g1) {
 // + the pending slab reduce of the previous unit's weight gradient (see bn_bwd_finalize_wgrad_reduce_kernel below)
 __global__ __launch_bounds__(1024) void bn_finalize2_wgrad_reduce_kernel(Fin2P f, int g1, int nfin, const float* slabs,
                                                                         float* dw, long long n, int S) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * 32 * 33 * 8 + 16];
+  // the larger of: sh_s + sh_q (2 x 8 448 B) + the ticket word | four part[16][17] float4 tiles of the slice-form reduce
+  __shared__ __attribute__((aligned(16))) char lds[4 * 16 * 17 * 16 + 16];
+  static_assert(2 * 32 * 33 * 8 <= 4 * 16 * 17 * 16, "finalize rows fit under the reduce's tiles");
   if ((int)blockIdx.x < nfin) {
     double (*sh_s)[33] = (double (*)[33])lds;
     double (*sh_q)[33] = (double (*)[33])(lds + 32 * 33 * 8);
-    fin2_body(f, blockIdx.x % g1, blockIdx.x / g1, sh_s, sh_q, (int*)(lds + 2 * 32 * 33 * 8));
+    fin2_body(f, blockIdx.x % g1, blockIdx.x / g1, sh_s, sh_q, (int*)(lds + 4 * 16 * 17 * 16));
   } else if (wgrad_reduce_cols(n, S)) {
     if (threadIdx.x < 256) wgrad_reduce_body(slabs, dw, n, S, nullptr, (long long)(blockIdx.x - nfin), threadIdx.x);
   } else {
