@@ -15,6 +15,10 @@ Workloads (BASELINE.json `configs`):
 timings of every C-ABI entry point, taken in a separate instrumented pass on the launch stream
 (algorithmic FLOPs or bytes of each launch / its measured duration); `cpu_baseline` times the fp32 torch oracle restatement
 (kind "port": the reference's own CPU path cannot run) on a bounded sample.
+Beside the headline value the N = 1 train line carries two more measured legs (rank 0, outside the timed region):
+`feat_fwd` = configs[1] (eval forward, BN shifts calibrated for the bf16 weight rounding on two other clips: the
+arithmetic whose logits sit within 1e-3 of the fp32 oracle, `config.parity`) and `canonical_b8x5` = the reference's own
+batch, 8 videos x 5 events = 40 clips per step.
 """
 import argparse
 import json
