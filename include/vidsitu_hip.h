@@ -251,6 +251,22 @@ int vs_weight_transpose_tiled(const void* src, void* dst, const int64_t* table, 
 size_t vs_conv_wgrad_workspace_bytes(const vs_conv_desc* d);
 int vs_conv_wgrad(const void* dy, const void* x, float* dw, const vs_conv_desc* d,
                   void* workspace, size_t ws_bytes, void* stream);
+/* Grouped weight gradients (round 5): the Conv3d bwd-filter of up to 8 convolutions -- a ResBlock's a, b, c and shortcut
+ * (slowfast resnet_helper.ResBlock, reached from mdl_sf_base.py:22-33) -- as ONE launch of deep-pipeline blocks (128 x 256
+ * output tiles) whose problems share the chip, + one grouped slab reduce where a problem is still split over positions.
+ * Together the problems need far fewer position splits than each alone.  Every item: taps <= 31, Cin and Cout multiples
+ * of 8, >= 512 positions, no forced-plan flags (vs_conv_wgrad_group_ok).  dw: fp32 [Cout][taps][Cin], overwritten.
+ * workspace: vs_conv_wgrad_group_workspace_bytes bytes (slabs), private to the stream until the launch retires.
+ * Bitwise reproducible (fixed summation order per problem for a given group). */
+typedef struct vs_wgrad_item {
+  const void* dy;
+  const void* x;
+  float* dw;
+  vs_conv_desc d;
+} vs_wgrad_item;
+int vs_conv_wgrad_group_ok(const vs_wgrad_item* items, int n);
+size_t vs_conv_wgrad_group_workspace_bytes(const vs_wgrad_item* items, int n);
+int vs_conv_wgrad_group(const vs_wgrad_item* items, int n, void* workspace, size_t ws_bytes, void* stream);
 /* The same weight gradient without its slab reduce: the position-split partials stay in `slabs`
  * ([*splits][Cout][taps*Cin] fp32, vs_conv_wgrad_workspace_bytes(desc) bytes, owned by the caller until the
  * reduce) and *splits says how many there are; *splits == 1 means dw was written directly and slabs is

@@ -1370,3 +1370,41 @@ def test_apply_on_load_refuses_what_it_cannot_take(dev):
     one = torch.ones(32, device=dev)
     with pytest.raises(_lib.VsError):
         ops.conv_fwd_aol(y, w, one, one)
+
+
+def test_grouped_weight_gradients_vs_torch(dev):
+    """vs_conv_wgrad_group: four convolutions of a slow-pathway ResBlock (1x1x1 stride-2 shortcut, [3,1,1], [1,3,3]
+    stride 2, 1x1x1) as one launch -- each dW against torch's fp32 weight gradient of the same bf16 operands, and against
+    the per-layer launch."""
+    from vidsitu_amd import ops
+
+    g = torch.Generator().manual_seed(21)
+    specs = [(128, 256, (1, 1, 1), (1, 2, 2), 4, 14), (128, 128, (3, 1, 1), (1, 1, 1), 4, 14),
+             (128, 128, (1, 3, 3), (1, 2, 2), 4, 14), (128, 256, (1, 1, 1), (1, 1, 1), 4, 7)]
+    items, refs, seps = [], [], []
+    for cin, cout, k, s, t, hw in specs:
+        p = (k[0] // 2, k[1] // 2, k[2] // 2)
+        x = rb(torch.randn(3, cin, t, hw, hw, generator=g))
+        w = torch.zeros(cout, cin, *k, requires_grad=True)
+        y = F.conv3d(x, w, stride=s, padding=p)
+        dy = rb(torch.randn(y.shape, generator=g))
+        y.backward(dy)
+        refs.append(w.grad)
+        xa, dya = to_act(x, dev), to_act(dy, dev)
+        dw = torch.empty((cout, *k, cin), dtype=torch.float32, device=dev).permute(0, 4, 1, 2, 3)
+        items.append((dya, xa, k, s, p, dw))
+        seps.append(ops.conv_wgrad(dya, xa, k, s, p).clone())
+    assert ops.conv_wgrad_group_ok(items)
+    ops.conv_wgrad_group(items)
+    torch.cuda.synchronize()
+    for (dya, xa, k, s, p, dw), ref, sep in zip(items, refs, seps):
+        assert_close(dw, ref, 2e-3, f"grouped dW {tuple(ref.shape)}")
+        assert float((dw - sep).abs().max() / sep.abs().max()) < 1e-5
+    again = [it[5].clone() for it in items]
+    for it in items:
+        it[5].zero_()
+    ops.conv_wgrad_group(items)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, it[5]) for a, it in zip(again, items))
+    # outside the envelope: nine items, or a convolution with fewer than 512 positions
+    assert not ops.conv_wgrad_group_ok(items * 3)

@@ -617,6 +617,7 @@ def test_pair_launch_of_dgrad_and_wgrad_is_bitwise_the_separate_launches(dev):
 
     def run(pair):
         T._Unit.pair_launch = pair
+        T.ResBlock.group_wgrads = False  # (round 5: grouped blocks launch their weight gradients together, not in pairs)
         for k, v in mdl.named_buffers():
             v.copy_(bufs[k])
         for p in mdl.parameters():
@@ -634,6 +635,7 @@ def test_pair_launch_of_dgrad_and_wgrad_is_bitwise_the_separate_launches(dev):
         f1, g1, n_on = run(True)
     finally:
         T._Unit.pair_launch = True
+        T.ResBlock.group_wgrads = True
     assert n_off == 0 and n_on >= 1, (n_off, n_on)
     assert all(torch.equal(a, b) for a, b in zip(f0, f1))
     bad = [k for k in g0 if not torch.equal(g0[k], g1[k])]
@@ -866,3 +868,51 @@ def test_weight_rounding_calibration_on_every_trunk_family(sf_name, crop, dev):
         out = mdl(gb)["mdl_out"].float().cpu()
     assert all(b.wround_bias is None for b in mdl.sf_mdl._bns()), "a weight update must drop the correction"
     assert torch.equal(out, plain)
+
+
+def test_grouped_weight_gradients_of_a_resblock(dev):
+    """`ResBlock.group_wgrads` (round 5, vs_conv_wgrad_group): the weight gradients of a wide, few-position block as ONE
+    launch of deep-pipeline blocks.  A SlowFast-R50 train-mode pass at 112^2: features bit for bit, every parameter
+    gradient within fp32 summation-order distance of the per-unit launches (another position split = another order),
+    grouped launches actually issued (fewer launches in the backward pass), and the grouped pass bit for bit from run to run."""
+    from oracle.slowfast_ref import default_sf_cfg
+    from vidsitu_amd import ops, trunk as T
+
+    torch.manual_seed(3)
+    cfg = default_sf_cfg("slowfast", 50, 64, 32)
+    mdl = T.VideoTrunk(cfg).to(dev).train()
+    g = torch.Generator().manual_seed(4)
+    fast = torch.randn(2, 3, 32, 112, 112, generator=g).to(dev)
+    xs = [fast[:, :, ::4].contiguous(), fast]
+    bufs = {k: v.clone() for k, v in mdl.named_buffers()}
+    lib = ops._lib.load()
+
+    def run(group):
+        T.ResBlock.group_wgrads = group
+        for k, v in mdl.named_buffers():
+            v.copy_(bufs[k])
+        for p in mdl.parameters():
+            p.grad = None
+        feats = mdl.forward_features([x.clone() for x in xs])
+        gg = torch.Generator().manual_seed(5)
+        loss = sum((f.float() * torch.randn(f.shape, generator=gg).to(dev)).sum() for f in feats)
+        n0 = lib.vs_launch_count()
+        loss.backward()
+        torch.cuda.synchronize()
+        return ([f.detach().clone() for f in feats], {k: p.grad.clone() for k, p in mdl.named_parameters()},
+                lib.vs_launch_count() - n0)
+
+    try:
+        run(True)
+        f0, g0, n_sep = run(False)
+        f1, g1, n_grp = run(True)
+        f2, g2, _ = run(True)
+    finally:
+        T.ResBlock.group_wgrads = True
+    assert n_grp <= n_sep - 20, (n_sep, n_grp)
+    assert all(torch.equal(a, b) for a, b in zip(f0, f1))
+    assert not [k for k in g1 if not torch.equal(g1[k], g2[k])], "the grouped pass must be bitwise reproducible"
+    worst = max((float((g1[k] - g0[k]).abs().max() / g0[k].abs().max().clamp_min(1e-30)), k) for k in g0)
+    print(f"grouped vs per-unit weight gradients: worst max-normalised difference {worst[0]:.2e} ({worst[1]}); "
+          f"backward launches {n_sep} -> {n_grp}")
+    assert worst[0] < 2e-5, worst

@@ -40,6 +40,12 @@ class DgradEpilogue(C.Structure):
                 ("mean2", C.c_void_p), ("invstd2", C.c_void_p), ("stats_partial2", C.c_void_p)]
 
 
+class WgradItem(C.Structure):
+    """vs_wgrad_item (include/vidsitu_hip.h)."""
+
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("d", ConvDesc)]
+
+
 _p, _i, _i64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
 _dp = C.POINTER(ConvDesc)
 
@@ -74,6 +80,9 @@ SIGNATURES = {
     "vs_weight_transpose_tiled": (_i, [_p, _p, _p, _p, _i, _i64, _i, _p]),
     "vs_conv_wgrad_workspace_bytes": (_sz, [_dp]),
     "vs_conv_wgrad": (_i, [_p, _p, _p, _dp, _p, _sz, _p]),
+    "vs_conv_wgrad_group_ok": (_i, [C.POINTER(WgradItem), _i]),
+    "vs_conv_wgrad_group_workspace_bytes": (_sz, [C.POINTER(WgradItem), _i]),
+    "vs_conv_wgrad_group": (_i, [C.POINTER(WgradItem), _i, _p, _sz, _p]),
     "vs_conv_wgrad_partial": (_i, [_p, _p, _p, _dp, _p, _sz, C.POINTER(C.c_int), _p]),
     "vs_wgrad_reduce_blocks": (_i64, [_i64]),
     "vs_wgrad_reduce": (_i, [_p, _p, _i64, _i, _p]),

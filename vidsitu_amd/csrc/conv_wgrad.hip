@@ -546,16 +546,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradP p) {
 // STAG: every wave copies 3 of a unit's 24 pieces (rows wv * 4 .. + 3 of the three images) instead of the waves of one half
 // copying 6 each: waves 0-3 issue theirs when the phase opens (copies, then MFMAs), waves 4-7 after their MFMAs (MFMAs,
 // then copies) -- the two waves of a SIMD run half a phase apart and the CU's address path sees one half at a time.
+// (blk / nblk: this block's index and the block count of THIS problem's grid -- blockIdx.x / gridDim.x of the stand-alone
+//  launch, a sub-range of the grid in the grouped launch below)
 template <int MODE, bool STAG>
-__global__ __launch_bounds__(512) void conv_wgrad_deep_kernel(WgradP p) {
+__device__ __forceinline__ void conv_wgrad_deep_body(const WgradP& p, const int blk, const int nblk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int hf = wv >> 2, wq = wv & 3;
-  int bid = blockIdx.x;
+  int bid = blk;
   if (p.xcd_order) {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    const int nwg = nblk, q = nwg >> 3, r = nwg & 7, xcd = blk & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blk >> 3);
   }
   const int ntile = p.tilesM * p.tilesN;
   const int s = bid / ntile;
@@ -780,6 +782,60 @@ __global__ __launch_bounds__(512) void conv_wgrad_deep_kernel(WgradP p) {
     if (m0 + row < p.Cout && n0 + c4 * 4 < p.Kp)
       *(float4*)(dst + (long long)(m0 + row) * p.Kp + n0 + c4 * 4) = *(const float4*)(E + row * WGD_EP + c4 * 4);
   }
+}
+
+template <int MODE, bool STAG>
+__global__ __launch_bounds__(512) void conv_wgrad_deep_kernel(WgradP p) {
+  conv_wgrad_deep_body<MODE, STAG>(p, blockIdx.x, gridDim.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grouped launch (round 5): the weight gradients of several convolutions -- a ResBlock's a, b, c and
+// shortcut -- as ONE grid of deep-pipeline blocks.  The problems' block ranges lie one after the other (first[j] ..
+// first[j + 1]); a block finds its problem by a scan of at most WGG_MAX entries and runs the deep body on that problem's
+// WgradP with its index inside the range.  Together the problems fill the chip with far fewer position splits than
+// each alone (a slow s4 block: 50 output tiles -> 5 splits instead of 10 / 14 / 24; slow s5: 200 tiles, no split at
+// all), so fewer fp32 slabs are written and re-read, and one launch (+ one grouped slab reduce) replaces three or four
+// (+ their reduces).  Same body, same summation order per problem for a given split count.
+// ---------------------------------------------------------------------------------------------
+#define WGG_MAX 8
+struct WgGroupP {
+  int n;
+  int first[WGG_MAX + 1];  // block range of problem j: [first[j], first[j + 1])
+  int mode[WGG_MAX];       // 0 pointwise, 1 gather
+  WgradP p[WGG_MAX];
+};
+
+__global__ __launch_bounds__(512) void conv_wgrad_deep_group_kernel(WgGroupP g) {
+  const int b = blockIdx.x;
+  int j = 0;
+#pragma unroll
+  for (int i = 1; i < WGG_MAX; ++i)
+    if (i < g.n && b >= g.first[i]) j = i;
+  j = __builtin_amdgcn_readfirstlane(j);
+  const int lo = g.first[j], hi = g.first[j + 1];
+  if (g.mode[j] == 0) conv_wgrad_deep_body<0, true>(g.p[j], b - lo, hi - lo);
+  else conv_wgrad_deep_body<1, true>(g.p[j], b - lo, hi - lo);
+}
+
+// the slab reduces of a grouped launch as one grid: entry e owns the virtual 256-thread blocks [first[e], first[e + 1])
+struct WgReduceGroupP {
+  int n;
+  long long first[WGG_MAX + 1];
+  const float* slabs[WGG_MAX];
+  float* dw[WGG_MAX];
+  long long len[WGG_MAX];
+  int S[WGG_MAX];
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(WgReduceGroupP g) {
+  __shared__ float4 part[16][17];
+  const long long b = blockIdx.x;
+  int e = 0;
+#pragma unroll
+  for (int i = 1; i < WGG_MAX; ++i)
+    if (i < g.n && b >= g.first[i]) e = i;
+  wgrad_reduce_body(g.slabs[e], g.dw[e], g.len[e], g.S[e], part, b - g.first[e], threadIdx.x);
 }
 
 // dw[i] = sum_s slab[s][i], bitwise reproducible: block = 16 float4 columns x 16 slab slices,
@@ -1137,30 +1193,13 @@ static bool wgrad_aol_plan_ok(const vs_conv_desc* d) {
   return c.bm == 128 && (c.bn == 128 || c.bn == 64);
 }
 
-static int wgrad_impl(const void* dy, const void* x, float* dw, const vs_conv_desc* d, void* workspace,
-                      size_t ws_bytes, void* stream, bool reduce_now, int* splits_out,
-                      const float* in_scale = nullptr, const float* in_shift = nullptr) {
-  VS_CHECK_ARG(d && dy && x && dw, "null argument");
-  VS_CHECK_ARG(d->Cin % 8 == 0 && d->Cout % 8 == 0, "Cin and Cout must be multiples of 8");
-  VS_CHECK_ARG(d->x_ld % 8 == 0 && d->y_ld % 8 == 0, "row pitches must be multiples of 8");
-  VS_CHECK_ARG((long long)d->N * d->Ti * d->Hi * d->Wi < (1ll << 31), "too many positions");
-  const WgCfg c = wg_pick(d);
-  const size_t need = vs_conv_wgrad_workspace_bytes(d);
-  if (need > 0 && (workspace == nullptr || ws_bytes < need)) {
-    vs_set_error("vs_conv_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
-    return VS_ERR_WORKSPACE;
-  }
-  if (g_pending.have && ((const void*)g_pending.r.slabs == workspace || g_pending.r.dw == dw)) pending_flush();
-  if (in_scale && !wgrad_aol_plan_ok(d)) {
-    vs_set_error("vs_conv_wgrad_aol: apply on load is not built for this weight gradient (ask vs_conv_wgrad_aol_ok)");
-    return VS_ERR_UNSUPPORTED;
-  }
-  WgradP p;
+// WgradP of one weight gradient from its descriptor and plan (tensor pointers, extents, tile counts, split)
+static int wg_fill_params(WgradP& p, const void* dy, const void* x, float* out, const vs_conv_desc* d, const WgCfg& c) {
   p.dy = (const uint16_t*)dy;
   p.x = (const uint16_t*)x;
-  p.in_scale = in_scale;
-  p.in_shift = in_shift;
-  p.out = c.S > 1 ? (float*)workspace : dw;
+  p.in_scale = nullptr;
+  p.in_shift = nullptr;
+  p.out = out;
   p.P = d->N * d->To * d->Ho * d->Wo;
   p.Cout = d->Cout;
   p.Cin = d->Cin;
@@ -1182,6 +1221,164 @@ static int wgrad_impl(const void* dy, const void* x, float* dw, const vs_conv_de
   p.tilesM = c.tilesM;
   p.tilesN = c.tilesN;
   p.S = c.S;
+  p.rows_per_split = c.rows_per_split;
+  p.xcd_order = 0;
+  p.dbg = 0;
+  return VS_OK;
+}
+
+// ---- grouped launch: plan, workspace, entry point (kernel: conv_wgrad_deep_group_kernel) ----
+static bool wgg_item_ok(const vs_conv_desc* d) {
+  const int taps = d->kT * d->kH * d->kW;
+  const long long Kp = (long long)taps * d->Cin;
+  if (taps > 31 || Kp % 8 != 0 || d->Cout % 8 != 0 || d->x_ld % 8 != 0 || d->y_ld % 8 != 0) return false;
+  if (((d->flags >> 8) & 0xf) || ((d->flags >> 16) & 7) || ((d->flags >> 24) & 0xff)) return false;  // forced plans
+  const long long P = (long long)d->N * d->To * d->Ho * d->Wo;
+  return P >= 512 && (long long)d->N * d->Ti * d->Hi * d->Wi < (1ll << 31);
+}
+
+// Splits of a group: every block should carry about the same number of 32-position units and the grid should be
+// one residency round of the chip (one 152-KiB block per CU).  VS_WGG_BLOCKS: target blocks (default 256).
+static bool wgg_plan(const vs_wgrad_item* it, int n, WgCfg* cfg, size_t* slab_off, size_t* slab_total) {
+  if (n < 1 || n > WGG_MAX) return false;
+  static const long long target = [] { const char* e = getenv("VS_WGG_BLOCKS"); return e ? atoll(e) : 256ll; }();
+  long long W = 0;
+  for (int j = 0; j < n; ++j) {
+    const vs_conv_desc* d = &it[j].d;
+    if (!wgg_item_ok(d)) return false;
+    const int Kp = d->kT * d->kH * d->kW * d->Cin;
+    cfg[j].bm = 128;
+    cfg[j].bn = 256;
+    cfg[j].deep = 1;
+    cfg[j].tilesM = (d->Cout + 127) / 128;
+    cfg[j].tilesN = (Kp + 255) / 256;
+    const long long P = (long long)d->N * d->To * d->Ho * d->Wo;
+    W += (long long)cfg[j].tilesM * cfg[j].tilesN * ((P + 31) / 32);
+  }
+  long long ustar = (W + target - 1) / target;
+  if (ustar < 16) ustar = 16;
+  size_t off = 0;
+  long long blocks = 0;
+  for (int j = 0; j < n; ++j) {
+    const vs_conv_desc* d = &it[j].d;
+    const int Kp = d->kT * d->kH * d->kW * d->Cin;
+    const long long P = (long long)d->N * d->To * d->Ho * d->Wo;
+    const long long units = (P + 31) / 32;
+    long long S = (units + ustar / 2) / ustar;
+    const long long maxS = P / 512;
+    if (S > maxS) S = maxS;
+    const long long slab_cap = (64ll << 20) / ((long long)d->Cout * Kp * 4);
+    if (S > slab_cap) S = slab_cap;
+    if (S < 1) S = 1;
+    long long rps = (P + S - 1) / S;
+    rps = (rps + 31) / 32 * 32;
+    S = (P + rps - 1) / rps;
+    cfg[j].S = (int)S;
+    cfg[j].rows_per_split = (int)rps;
+    slab_off[j] = off;
+    if (S > 1) off += (size_t)S * d->Cout * Kp * sizeof(float);
+    blocks += (long long)cfg[j].tilesM * cfg[j].tilesN * S;
+  }
+  *slab_total = off;
+  return blocks <= 65535;
+}
+
+extern "C" int vs_conv_wgrad_group_ok(const vs_wgrad_item* items, int n) {
+  if (items == nullptr) return 0;
+  WgCfg cfg[WGG_MAX];
+  size_t off[WGG_MAX], tot;
+  return wgg_plan(items, n, cfg, off, &tot) ? 1 : 0;
+}
+
+extern "C" size_t vs_conv_wgrad_group_workspace_bytes(const vs_wgrad_item* items, int n) {
+  if (items == nullptr) return 0;
+  WgCfg cfg[WGG_MAX];
+  size_t off[WGG_MAX], tot = 0;
+  if (!wgg_plan(items, n, cfg, off, &tot)) return 0;
+  return tot;
+}
+
+extern "C" int vs_conv_wgrad_group(const vs_wgrad_item* items, int n, void* workspace, size_t ws_bytes, void* stream) {
+  VS_CHECK_ARG(items != nullptr && n >= 1 && n <= WGG_MAX, "1 .. 8 items");
+  WgCfg cfg[WGG_MAX];
+  size_t off[WGG_MAX], tot = 0;
+  if (!wgg_plan(items, n, cfg, off, &tot)) {
+    vs_set_error("vs_conv_wgrad_group: an item is outside the deep-pipeline kernel's envelope (ask vs_conv_wgrad_group_ok)");
+    return VS_ERR_UNSUPPORTED;
+  }
+  if (tot > 0 && (workspace == nullptr || ws_bytes < tot)) {
+    vs_set_error("vs_conv_wgrad_group: workspace too small (%zu < %zu)", ws_bytes, tot);
+    return VS_ERR_WORKSPACE;
+  }
+  if (g_pending.have) pending_flush();  // (a deferred reduce of an earlier launch may read this workspace / write these dw)
+  WgGroupP g;
+  WgReduceGroupP r;
+  g.n = n;
+  r.n = 0;
+  r.first[0] = 0;
+  int first = 0;
+  for (int j = 0; j < n; ++j) {
+    const vs_wgrad_item& t = items[j];
+    VS_CHECK_ARG(t.dy && t.x && t.dw, "null tensor");
+    const vs_conv_desc* d = &t.d;
+    float* out = cfg[j].S > 1 ? (float*)((char*)workspace + off[j]) : t.dw;
+    const int rc = wg_fill_params(g.p[j], t.dy, t.x, out, d, cfg[j]);
+    if (rc) return rc;
+    const bool dense = (d->kT * d->kH * d->kW == 1) && d->sT == 1 && d->sH == 1 && d->sW == 1 && d->pT == 0 &&
+                       d->pH == 0 && d->pW == 0;
+    g.mode[j] = dense ? 0 : 1;
+    g.first[j] = first;
+    first += cfg[j].tilesM * cfg[j].tilesN * cfg[j].S;
+    if (cfg[j].S > 1) {
+      const int e = r.n++;
+      r.slabs[e] = out;
+      r.dw[e] = t.dw;
+      r.len[e] = (long long)d->Cout * g.p[j].Kp;
+      r.S[e] = cfg[j].S;
+      r.first[e + 1] = r.first[e] + wgrad_reduce_vblocks(r.len[e], r.S[e]);
+    }
+  }
+  g.first[n] = first;
+  for (int j = n; j < WGG_MAX; ++j) g.first[j + 1] = first;
+  static std::once_flag gattr;
+  std::call_once(gattr, [] {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_deep_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  const size_t smem = (size_t)WGD_NU * WGD_UNIT + 2 * WGD_TAB * sizeof(int2);
+  hipLaunchKernelGGL(conv_wgrad_deep_group_kernel, dim3(first), dim3(512), smem, (hipStream_t)stream, g);
+  VS_CHECK_LAUNCH();
+  if (r.n > 0) {
+    hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3((unsigned)r.first[r.n]), dim3(256), 0, (hipStream_t)stream, r);
+    VS_CHECK_LAUNCH();
+  }
+  return VS_OK;
+}
+
+static int wgrad_impl(const void* dy, const void* x, float* dw, const vs_conv_desc* d, void* workspace,
+                      size_t ws_bytes, void* stream, bool reduce_now, int* splits_out,
+                      const float* in_scale = nullptr, const float* in_shift = nullptr) {
+  VS_CHECK_ARG(d && dy && x && dw, "null argument");
+  VS_CHECK_ARG(d->Cin % 8 == 0 && d->Cout % 8 == 0, "Cin and Cout must be multiples of 8");
+  VS_CHECK_ARG(d->x_ld % 8 == 0 && d->y_ld % 8 == 0, "row pitches must be multiples of 8");
+  VS_CHECK_ARG((long long)d->N * d->Ti * d->Hi * d->Wi < (1ll << 31), "too many positions");
+  const WgCfg c = wg_pick(d);
+  const size_t need = vs_conv_wgrad_workspace_bytes(d);
+  if (need > 0 && (workspace == nullptr || ws_bytes < need)) {
+    vs_set_error("vs_conv_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
+    return VS_ERR_WORKSPACE;
+  }
+  if (g_pending.have && ((const void*)g_pending.r.slabs == workspace || g_pending.r.dw == dw)) pending_flush();
+  if (in_scale && !wgrad_aol_plan_ok(d)) {
+    vs_set_error("vs_conv_wgrad_aol: apply on load is not built for this weight gradient (ask vs_conv_wgrad_aol_ok)");
+    return VS_ERR_UNSUPPORTED;
+  }
+  WgradP p;
+  {
+    const int rc = wg_fill_params(p, dy, x, c.S > 1 ? (float*)workspace : dw, d, c);
+    if (rc) return rc;
+  }
+  p.in_scale = in_scale;
+  p.in_shift = in_shift;
   {
     static const int xo = [] { const char* e = getenv("VS_WGRAD_XCD"); return e ? atoi(e) : 1; }();
     // measured per layer (batch 8): a win up to ~16 output tiles (s3.b 43.5 -> 35.4 us, s4.c 22.1 -> 19.7,

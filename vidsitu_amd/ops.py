@@ -584,6 +584,36 @@ def conv_wgrad_split(dy, x, k, s, p, out, ring=0):
     return lambda: _lib.call("vs_wgrad_reduce", _ptr(ws), _ptr(out), n, S, _stream())
 
 
+def _wgrad_items(items):
+    arr = (_lib.WgradItem * len(items))()
+    for i, (dy, x, k, s, p, out) in enumerate(items):
+        if not out.permute(0, 2, 3, 4, 1).is_contiguous() or out.dtype != torch.float32:
+            raise _lib.VsError("conv_wgrad out must be fp32 with [Cout][taps][Cin] memory")
+        arr[i].dy, arr[i].x, arr[i].dw = dy.data_ptr(), x.data_ptr(), out.data_ptr()
+        arr[i].d = make_desc(x.shape, act_ld(x), dy.shape, act_ld(dy), k, s, p, 0)
+        _ptr(dy), _ptr(x), _ptr(out)
+    return arr
+
+
+def conv_wgrad_group_ok(items):
+    """items: [(dy, x, k, s, p, dw_out)] -- can these weight gradients run as one grouped launch?"""
+    if not 1 <= len(items) <= 8:
+        return False
+    return bool(_lib.load().vs_conv_wgrad_group_ok(_wgrad_items(items), len(items)))
+
+
+def conv_wgrad_group(items):
+    """The weight gradients of several convolutions as ONE deep-pipeline launch (+ one grouped slab reduce):
+    vs_conv_wgrad_group.  items: [(dy, x, k, s, p, dw_out)], dw_out fp32 [Cout][taps][Cin], overwritten."""
+    if _WHATIF_WGRAD:
+        return
+    arr = _wgrad_items(items)
+    need = int(_lib.load().vs_conv_wgrad_group_workspace_bytes(arr, len(items)))
+    ws = _workspace(need, items[0][0].device, "wgrad") if need else None
+    _lib.call("vs_conv_wgrad_group", arr, len(items), _ptr(ws), C.c_size_t(ws.numel() if ws is not None else 0),
+              _stream())
+
+
 def conv_wgrad(dy, x, k, s, p, out=None, ring=0, batch=None, tile=None, slots=0, deep=True):
     """dw fp32, logical [Cout,Cin,kT,kH,kW], memory [Cout][taps][Cin].
     ring: 0 heuristic, 1 register-staged pipeline, 2 / 3 LDS-DMA ring stages (VS_CONV_RING).

@@ -364,7 +364,7 @@ class _Unit:
 
     @staticmethod
     def bwd(rec, dz, need_dx=True, want_dres=False, dx_residual=None, masked=False, producer=None,
-            dz_bits=None, dx_residual_bits=None, inplace=False, dy_ready=None):
+            dz_bits=None, dx_residual_bits=None, inplace=False, dy_ready=None, wgrad_sink=None):
         """Returns (dx|None, dres|None).  `masked`: dz already carries the ReLU mask.
         `producer`: the record of the unit whose output is this unit's only input (the a -> b and b -> c
         links of a bottleneck): this unit's dgrad then also emits the producer's BN-backward sums
@@ -374,18 +374,20 @@ class _Unit:
         `dx_residual_bits`: the same for the gradient added in the dgrad epilogue.
         `inplace`: the dgrad accumulates into dx_residual.
         `dy_ready`: the unit's BN backward already ran (`ResBlock.bwd`: the c and shortcut units in one pass) and this
-        is its dy -- only the convolution's gradients are left."""
+        is its dy -- only the convolution's gradients are left.
+        `wgrad_sink`: a list -- the unit's weight gradient is not launched here but appended as (dy, x, conv) for the
+        block's grouped launch (`ResBlock.bwd`, ops.conv_wgrad_group)."""
         conv, bn = rec["conv"], rec["bn"]
         if dy_ready is not None:
             assert not want_dres
             x = rec["x"]
             pair = (_Unit.pair_launch and need_dx and not conv.is_stem and conv.cin_pad == conv.cin and dy_ready.is_cuda
-                    and _Unit.wgrad_batch is None and not _Unit.split_wgrad_reduce)
+                    and _Unit.wgrad_batch is None and not _Unit.split_wgrad_reduce and wgrad_sink is None)
             pair_ctx = ops.conv_pair() if pair else contextlib.nullcontext()
             pair_ctx.__enter__()
             try:
                 dx = _Unit._bwd_convs(conv, dy_ready, x, need_dx, producer, dx_residual, dx_residual_bits, inplace, pair,
-                                      rec.get("x_affine"))
+                                      rec.get("x_affine"), wgrad_sink)
             finally:
                 pair_ctx.__exit__(None, None, None)
             _WgradLanes.join_unit()
@@ -415,22 +417,27 @@ class _Unit:
         # one launch for the unit's two gradients where both kernels allow it (`pair_launch`): the weight gradient is
         # then issued inline (recorded, like the data gradient below) instead of on the lane
         pair = (_Unit.pair_launch and need_dx and not conv.is_stem and conv.cin_pad == conv.cin and dy.is_cuda
-                and _Unit.wgrad_batch is None and not _Unit.split_wgrad_reduce)
+                and _Unit.wgrad_batch is None and not _Unit.split_wgrad_reduce and wgrad_sink is None)
         pair_ctx = ops.conv_pair() if pair else contextlib.nullcontext()
         pair_ctx.__enter__()
         try:
             dx = _Unit._bwd_convs(conv, dy, x, need_dx, producer, dx_residual, dx_residual_bits, inplace, pair,
-                                  rec.get("x_affine"))
+                                  rec.get("x_affine"), wgrad_sink)
         finally:
             pair_ctx.__exit__(None, None, None)
         _WgradLanes.join_unit()  # wgrad || dgrad of this unit (and, with a lag, of the next units)
         return dx, dres
 
     @staticmethod
-    def _bwd_convs(conv, dy, x, need_dx, producer, dx_residual, dx_residual_bits, inplace, pair, x_affine=None):
+    def _bwd_convs(conv, dy, x, need_dx, producer, dx_residual, dx_residual_bits, inplace, pair, x_affine=None,
+                   wgrad_sink=None):
         """The unit's weight gradient (side lane, or inline when `pair`) and data gradient.  x_affine: x is the
-        producer's raw output, the weight gradient applies its BN + ReLU on load."""
-        if conv.is_stem:
+        producer's raw output, the weight gradient applies its BN + ReLU on load.  wgrad_sink: see `bwd`."""
+        if wgrad_sink is not None:
+            if conv.weight.grad is None:
+                conv.weight.grad = torch.empty_like(conv.weight)
+            wgrad_sink.append((dy, x, conv))
+        elif conv.is_stem:
             _WgradLanes.run(lambda: _set_grad(conv.weight, ops.stem_conv_wgrad(dy, x, conv.k[0])) and None, dy, x)
         elif conv.cin_pad == conv.cin:
             if conv.weight.grad is None:
@@ -648,6 +655,51 @@ class ResBlock(nn.Module):
         on top of `saved` after this block's own is then that block's c unit (`_Unit.bwd` checks the tensor
         identity), whose BN-backward sums come out of this block's conv-a dgrad."""
         rc, rb, ra = saved.pop(), saved.pop(), saved.pop()
+        # The block's weight gradients as ONE grouped launch behind its last data gradient (ops.conv_wgrad_group) where
+        # that wins: wide, few-position blocks (slow res3 - res5 at 8 clips per GPU: 60-140 us per block instead of
+        # 85-170 as three or four launches + their slab reduces; tools/wgrad_group_time.py)
+        sink = [] if self._wgrad_grouped(rc, rb, ra, saved[-1] if (self.has_sc and saved) else None, dout) else None
+        try:
+            return self._bwd_units(saved, dout, chain, rc, rb, ra, sink)
+        finally:
+            if sink:
+                ops.conv_wgrad_group([(dy, x, c.k, c.s, c.p, c.weight.grad) for dy, x, c in sink])
+
+    # Train: a block's weight gradients as one launch.  VS_WGRAD_GROUP=0: per-unit launches; VS_WGRAD_GROUP_MAXP: the
+    # position count up to which a block is grouped (at 32 clips per GPU the separate launches fill the chip themselves).
+    group_wgrads = os.environ.get("VS_WGRAD_GROUP", "1") != "0"
+    group_max_positions = int(os.environ.get("VS_WGRAD_GROUP_MAXP", "60000"))
+
+    def _wgrad_grouped(self, rc, rb, ra, rsc, dout):
+        if (not ResBlock.group_wgrads or not dout.is_cuda or _Unit.wgrad_batch is not None or _Unit.split_wgrad_reduce
+                or ResBlock.aol):
+            return False
+        recs = [r for r in (rc, rb, ra, rsc) if r is not None]
+        key = ("wgg",) + tuple(tuple(r["y"].shape) for r in recs)
+        hit = self.__dict__.setdefault("_bc_ok", {}).get(key)
+        if hit is None:
+            hit = True
+            items = []
+            for r in recs:
+                c, y, x = r["conv"], r["y"], r["x"]
+                kp = c.cin * c.k[0] * c.k[1] * c.k[2]
+                if (c.is_stem or c.cin_pad != c.cin or c.bias is not None or r.get("x_affine") is not None or c.cout < 128
+                        or kp < 128 or not isinstance(x, torch.Tensor)
+                        or not getattr(c.weight, "_vs_direct_grad", True)):
+                    hit = False
+                    break
+                items.append((y, x, c.k, c.s, c.p, torch.empty(0)))
+            if hit:
+                hit = min(ops.act_rows(r["y"]) for r in recs) <= ResBlock.group_max_positions
+            if hit:
+                # (the plan query needs descriptors only: the raw conv output stands in for its gradient, same shape / pitch)
+                probe = [(y, x, k, s_, p, torch.empty((y.shape[1], *k, x.shape[1]), dtype=torch.float32,
+                                                      device=y.device).permute(0, 4, 1, 2, 3)) for y, x, k, s_, p, _ in items]
+                hit = ops.conv_wgrad_group_ok(probe)
+            self._bc_ok[key] = hit
+        return hit
+
+    def _bwd_units(self, saved, dout, chain, rc, rb, ra, sink):
         # The gradient over the identity / shortcut branch is dout under the block's ReLU mask.  With the mask
         # kept as bits (`zbits`, written by the forward apply) its two readers take (dout, bits) and the c unit's
         # backward apply does not write a masked copy (`dres`: one block-output-sized tensor per block).
@@ -669,30 +721,30 @@ class ResBlock(nn.Module):
                                 partial=r.pop("bwd_partial", None))
                 units.append((r["y"], r["mean"], r["invstd"], bn.weight, bn.weight.grad, bn.bias.grad))
             dy_c, dy_sc = ops.bn_bwd_apply2(dout, cbits, units[0], units[1])
-            db, g = _Unit.bwd(rc, dout, producer=rb, dy_ready=dy_c)
+            db, g = _Unit.bwd(rc, dout, producer=rb, dy_ready=dy_c, wgrad_sink=sink)
         else:
-            db, g = _Unit.bwd(rc, dout, want_dres=cbits is None, producer=rb)
-        da, _ = _Unit.bwd(rb, db, producer=ra)
+            db, g = _Unit.bwd(rc, dout, want_dres=cbits is None, producer=rb, wgrad_sink=sink)
+        da, _ = _Unit.bwd(rb, db, producer=ra, wgrad_sink=sink)
         if self.has_sc:
             rsc = saved.pop()
             if ResBlock.accumulate_shortcut:
                 # conv a's (unit-stride) data gradient first; the shortcut's dgrad then accumulates into it in
                 # place -- a strided shortcut touches only the positions its stride reaches, instead of writing
                 # a block-input-sized tensor that is 3/4 zeros and re-reading it as a residual
-                dxa, _ = _Unit.bwd(ra, da)
+                dxa, _ = _Unit.bwd(ra, da, wgrad_sink=sink)
                 if cbits is not None:
-                    dx, _ = _Unit.bwd(rsc, dout, dz_bits=cbits, dx_residual=dxa, inplace=True, dy_ready=dy_sc)
+                    dx, _ = _Unit.bwd(rsc, dout, dz_bits=cbits, dx_residual=dxa, inplace=True, dy_ready=dy_sc, wgrad_sink=sink)
                 else:
-                    dx, _ = _Unit.bwd(rsc, g, masked=True, dx_residual=dxa, inplace=True)
+                    dx, _ = _Unit.bwd(rsc, g, masked=True, dx_residual=dxa, inplace=True, wgrad_sink=sink)
             else:
-                dx1, _ = (_Unit.bwd(rsc, dout, dz_bits=cbits, dy_ready=dy_sc) if cbits is not None
-                          else _Unit.bwd(rsc, g, masked=True))
-                dx, _ = _Unit.bwd(ra, da, dx_residual=dx1)
+                dx1, _ = (_Unit.bwd(rsc, dout, dz_bits=cbits, dy_ready=dy_sc, wgrad_sink=sink) if cbits is not None
+                          else _Unit.bwd(rsc, g, masked=True, wgrad_sink=sink))
+                dx, _ = _Unit.bwd(ra, da, dx_residual=dx1, wgrad_sink=sink)
         elif cbits is not None:
             dx, _ = _Unit.bwd(ra, da, dx_residual=dout, dx_residual_bits=cbits,
-                              producer=saved[-1] if (chain and saved) else None)
+                              producer=saved[-1] if (chain and saved) else None, wgrad_sink=sink)
         else:
-            dx, _ = _Unit.bwd(ra, da, dx_residual=g, producer=saved[-1] if (chain and saved) else None)
+            dx, _ = _Unit.bwd(ra, da, dx_residual=g, producer=saved[-1] if (chain and saved) else None, wgrad_sink=sink)
         return dx
 
     # Train, backward: the c unit's and the shortcut unit's BN-backward apply as one pass (ops.bn_bwd_apply2): the block's
