@@ -754,11 +754,13 @@ def test_apply_on_load_train_step_is_bitwise_and_launches_fewer_kernels(dev):
                 {k: v.clone() for k, v in mdl.named_buffers()}, lib.vs_launch_count() - n0)
 
     saved = T.ResBlock.aol
+    T.ResBlock.group_wgrads = False  # (apply-on-load blocks keep per-unit weight gradients: compare like with like)
     try:
         f0, g0, b0, n_off = run(False)
         f1, g1, b1, n_on = run(True)
     finally:
         T.ResBlock.aol = saved
+        T.ResBlock.group_wgrads = True
     assert n_off - n_on >= 4, (n_off, n_on)  # at 2 clips the s2 / s3 blocks' plans have the transform
     assert all(torch.equal(a, b) for a, b in zip(f0, f1))
     bad = [k for k in g0 if not torch.equal(g0[k], g1[k])]

@@ -52,6 +52,29 @@ BLOCKS = [
     ("s2.res1 (a,b,c)", [unit(256, 64, (1, 1, 1), (1, 1, 1), 8, 56), unit(64, 64, (1, 3, 3), (1, 1, 1), 8, 56),
                          unit(64, 256, (1, 1, 1), (1, 1, 1), 8, 56)]),
 ]
+if "--fast" in sys.argv:  # fast-pathway blocks (T = 32, 1/8 of the channels)
+    BLOCKS = [
+        ("fast s5.res1", [unit(256, 64, (3, 1, 1), (1, 1, 1), 32, 7), unit(64, 64, (1, 3, 3), (1, 1, 1), 32, 7),
+                          unit(64, 256, (1, 1, 1), (1, 1, 1), 32, 7)]),
+        ("fast s4.res1", [unit(128, 32, (3, 1, 1), (1, 1, 1), 32, 14), unit(32, 32, (1, 3, 3), (1, 1, 1), 32, 14),
+                          unit(32, 128, (1, 1, 1), (1, 1, 1), 32, 14)]),
+        ("fast s3.res1", [unit(64, 16, (3, 1, 1), (1, 1, 1), 32, 28), unit(16, 16, (1, 3, 3), (1, 1, 1), 32, 28),
+                          unit(16, 64, (1, 1, 1), (1, 1, 1), 32, 28)]),
+        ("fast s5.res0", [unit(128, 256, (1, 1, 1), (1, 2, 2), 32, 14), unit(128, 64, (3, 1, 1), (1, 1, 1), 32, 14),
+                          unit(64, 64, (1, 3, 3), (1, 2, 2), 32, 14), unit(64, 256, (1, 1, 1), (1, 1, 1), 32, 7)]),
+    ]
+
+
+def rep(units, n):  # the same block n times (independent tensors)
+    out = []
+    for _ in range(n):
+        out += [unit(x.shape[1], dy.shape[1], k, s_, x.shape[2], x.shape[3]) for dy, x, k, s_, p, dw in units]
+    return out
+
+
+if "--span" in sys.argv:  # two consecutive blocks of a stage as one group (<= 8 items)
+    BLOCKS = [("2 x s3.res1", rep(BLOCKS[0][1], 2)), ("2 x s4.res1", rep(BLOCKS[2][1], 2)), ("2 x s5.res1", rep(BLOCKS[4][1], 2)),
+              ("s4.res0 + s4.res1", BLOCKS[1][1] + rep(BLOCKS[2][1], 1)), ("s5.res0 + s5.res1", BLOCKS[3][1] + rep(BLOCKS[4][1], 1))]
 print(f"{N} clips.  block: separate launches (sum of {'{'}kernel + reduce{'}'} chains) | grouped launch | worst rel. diff of dW")
 tot = [0.0, 0.0]
 for name, units in BLOCKS:

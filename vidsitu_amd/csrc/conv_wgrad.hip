@@ -1237,12 +1237,21 @@ static bool wgg_item_ok(const vs_conv_desc* d) {
   return P >= 512 && (long long)d->N * d->Ti * d->Hi * d->Wi < (1ll << 31);
 }
 
-// Splits of a group: every block should carry about the same number of 32-position units and the grid should be
-// one residency round of the chip (one 152-KiB block per CU).  VS_WGG_BLOCKS: target blocks (default 256).
-static bool wgg_plan(const vs_wgrad_item* it, int n, WgCfg* cfg, size_t* slab_off, size_t* slab_total) {
+// Splits of a group.  Every candidate "units per block" u gives each problem S_j = round(units_j / u) splits; the grid is
+// laid out longest blocks first (the block ranges of the problems in descending block length) and the candidate's cost is
+// the makespan of that list on the chip's block slots (greedy: a block goes to the slot that frees first) plus what its
+// slabs cost the reduce behind it.  Block cost = WGG_C0 units of prologue + epilogue + its 32-position units (one unit =
+// ~0.64 us on the deep body); slabs at ~3 TB/s.  Measured (tools/wgrad_group_time.py): one residency round with a 4x
+// longer problem in it (slow s5's first block: conv a runs on 4x the positions) loses to two rounds of balanced blocks,
+// and 256 nominal blocks that round to 270 lose 12 % to 224 -- hence a simulated makespan instead of a block-count target.
+// VS_WGG_SLOTS: block slots (default 256 = one 152-KiB block per CU).
+#define WGG_C0 14
+static bool wgg_plan(const vs_wgrad_item* it, int n, WgCfg* cfg, size_t* slab_off, size_t* slab_total, int* order) {
   if (n < 1 || n > WGG_MAX) return false;
-  static const long long target = [] { const char* e = getenv("VS_WGG_BLOCKS"); return e ? atoll(e) : 256ll; }();
-  long long W = 0;
+  static const int slots = [] { const char* e = getenv("VS_WGG_SLOTS"); const int v = e ? atoi(e) : 256; return v < 1 ? 1 : (v > 1024 ? 1024 : v); }();
+  long long units[WGG_MAX], P[WGG_MAX], maxS[WGG_MAX], dwn[WGG_MAX];
+  int tiles[WGG_MAX];
+  long long W = 0, umax = 0;
   for (int j = 0; j < n; ++j) {
     const vs_conv_desc* d = &it[j].d;
     if (!wgg_item_ok(d)) return false;
@@ -1252,33 +1261,92 @@ static bool wgg_plan(const vs_wgrad_item* it, int n, WgCfg* cfg, size_t* slab_of
     cfg[j].deep = 1;
     cfg[j].tilesM = (d->Cout + 127) / 128;
     cfg[j].tilesN = (Kp + 255) / 256;
-    const long long P = (long long)d->N * d->To * d->Ho * d->Wo;
-    W += (long long)cfg[j].tilesM * cfg[j].tilesN * ((P + 31) / 32);
+    tiles[j] = cfg[j].tilesM * cfg[j].tilesN;
+    P[j] = (long long)d->N * d->To * d->Ho * d->Wo;
+    units[j] = (P[j] + 31) / 32;
+    dwn[j] = (long long)d->Cout * Kp;
+    maxS[j] = P[j] / 512;
+    const long long slab_cap = (64ll << 20) / (dwn[j] * 4);
+    if (maxS[j] > slab_cap) maxS[j] = slab_cap;
+    if (maxS[j] < 1) maxS[j] = 1;
+    W += (long long)tiles[j] * units[j];
+    if (units[j] > umax) umax = units[j];
   }
-  long long ustar = (W + target - 1) / target;
-  if (ustar < 16) ustar = 16;
+  auto splits = [&](long long u, long long* S, long long* rps) {
+    for (int j = 0; j < n; ++j) {
+      long long s = (units[j] + u / 2) / u;
+      if (s > maxS[j]) s = maxS[j];
+      if (s < 1) s = 1;
+      long long r = (P[j] + s - 1) / s;
+      r = (r + 31) / 32 * 32;
+      S[j] = (P[j] + r - 1) / r;
+      rps[j] = r;
+    }
+  };
+  auto cost = [&](const long long* S, const long long* rps) {
+    // longest blocks first
+    int ord[WGG_MAX];
+    for (int j = 0; j < n; ++j) ord[j] = j;
+    for (int a = 0; a < n; ++a)
+      for (int b = a + 1; b < n; ++b)
+        if (rps[ord[b]] > rps[ord[a]]) { const int t = ord[a]; ord[a] = ord[b]; ord[b] = t; }
+    long long slot[1024];
+    for (int i = 0; i < slots; ++i) slot[i] = 0;
+    long long span = 0;
+    int nxt = 0;  // blocks of equal length arrive in runs: the slots are used round-robin from the earliest-free one
+    for (int a = 0; a < n; ++a) {
+      const int j = ord[a];
+      const long long len = WGG_C0 + (rps[j] + 31) / 32;
+      const long long nb = (long long)tiles[j] * S[j];
+      for (long long b = 0; b < nb; ++b) {
+        // earliest-free slot: with runs of equal blocks the slots fill in index order, so a linear probe from `nxt`
+        // finds it in O(1) amortised; a full scan every `slots` blocks keeps it exact enough for a cost model
+        int best = nxt;
+        if ((b % slots) == 0) {
+          for (int i = 0; i < slots; ++i)
+            if (slot[i] < slot[best]) best = i;
+        }
+        slot[best] += len;
+        if (slot[best] > span) span = slot[best];
+        nxt = (best + 1) % slots;
+      }
+    }
+    double slab = 0.0;
+    for (int j = 0; j < n; ++j)
+      if (S[j] > 1) slab += 2.0 * (double)S[j] * (double)dwn[j] * 4.0;  // written, then read by the reduce
+    return (double)span + slab / 3.0e12 / 0.64e-6;
+  };
+  long long bestS[WGG_MAX], bestR[WGG_MAX], S[WGG_MAX], R[WGG_MAX];
+  double best = -1.0;
+  static const int plan_mode = [] { const char* e = getenv("VS_WGG_PLAN"); return e ? atoi(e) : 1; }();
+  long long u = W / (3ll * slots);
+  if (u < 16) u = 16;
+  if (plan_mode == 0) {  // (A/B: the first planner -- one candidate, ~slots blocks nominal, problems in caller order)
+    u = (W + slots - 1) / slots;
+    if (u < 16) u = 16;
+    umax = u;
+  }
+  for (; u <= umax + 1; u += (u + 15) / 16) {
+    splits(u, S, R);
+    const double c = cost(S, R);
+    if (best < 0.0 || c < best) {
+      best = c;
+      for (int j = 0; j < n; ++j) { bestS[j] = S[j]; bestR[j] = R[j]; }
+    }
+  }
   size_t off = 0;
   long long blocks = 0;
   for (int j = 0; j < n; ++j) {
-    const vs_conv_desc* d = &it[j].d;
-    const int Kp = d->kT * d->kH * d->kW * d->Cin;
-    const long long P = (long long)d->N * d->To * d->Ho * d->Wo;
-    const long long units = (P + 31) / 32;
-    long long S = (units + ustar / 2) / ustar;
-    const long long maxS = P / 512;
-    if (S > maxS) S = maxS;
-    const long long slab_cap = (64ll << 20) / ((long long)d->Cout * Kp * 4);
-    if (S > slab_cap) S = slab_cap;
-    if (S < 1) S = 1;
-    long long rps = (P + S - 1) / S;
-    rps = (rps + 31) / 32 * 32;
-    S = (P + rps - 1) / rps;
-    cfg[j].S = (int)S;
-    cfg[j].rows_per_split = (int)rps;
+    cfg[j].S = (int)bestS[j];
+    cfg[j].rows_per_split = (int)bestR[j];
     slab_off[j] = off;
-    if (S > 1) off += (size_t)S * d->Cout * Kp * sizeof(float);
-    blocks += (long long)cfg[j].tilesM * cfg[j].tilesN * S;
+    if (bestS[j] > 1) off += (size_t)bestS[j] * dwn[j] * sizeof(float);
+    blocks += (long long)tiles[j] * bestS[j];
+    order[j] = j;
   }
+  for (int a = 0; a < n && plan_mode != 0; ++a)
+    for (int b = a + 1; b < n; ++b)
+      if (bestR[order[b]] > bestR[order[a]]) { const int t = order[a]; order[a] = order[b]; order[b] = t; }
   *slab_total = off;
   return blocks <= 65535;
 }
@@ -1287,14 +1355,16 @@ extern "C" int vs_conv_wgrad_group_ok(const vs_wgrad_item* items, int n) {
   if (items == nullptr) return 0;
   WgCfg cfg[WGG_MAX];
   size_t off[WGG_MAX], tot;
-  return wgg_plan(items, n, cfg, off, &tot) ? 1 : 0;
+  int order[WGG_MAX];
+  return wgg_plan(items, n, cfg, off, &tot, order) ? 1 : 0;
 }
 
 extern "C" size_t vs_conv_wgrad_group_workspace_bytes(const vs_wgrad_item* items, int n) {
   if (items == nullptr) return 0;
   WgCfg cfg[WGG_MAX];
   size_t off[WGG_MAX], tot = 0;
-  if (!wgg_plan(items, n, cfg, off, &tot)) return 0;
+  int order[WGG_MAX];
+  if (!wgg_plan(items, n, cfg, off, &tot, order)) return 0;
   return tot;
 }
 
@@ -1302,7 +1372,8 @@ extern "C" int vs_conv_wgrad_group(const vs_wgrad_item* items, int n, void* work
   VS_CHECK_ARG(items != nullptr && n >= 1 && n <= WGG_MAX, "1 .. 8 items");
   WgCfg cfg[WGG_MAX];
   size_t off[WGG_MAX], tot = 0;
-  if (!wgg_plan(items, n, cfg, off, &tot)) {
+  int order[WGG_MAX];
+  if (!wgg_plan(items, n, cfg, off, &tot, order)) {
     vs_set_error("vs_conv_wgrad_group: an item is outside the deep-pipeline kernel's envelope (ask vs_conv_wgrad_group_ok)");
     return VS_ERR_UNSUPPORTED;
   }
@@ -1317,23 +1388,24 @@ extern "C" int vs_conv_wgrad_group(const vs_wgrad_item* items, int n, void* work
   r.n = 0;
   r.first[0] = 0;
   int first = 0;
-  for (int j = 0; j < n; ++j) {
+  for (int a = 0; a < n; ++a) {  // grid position a = problem order[a]: longest blocks first
+    const int j = order[a];
     const vs_wgrad_item& t = items[j];
     VS_CHECK_ARG(t.dy && t.x && t.dw, "null tensor");
     const vs_conv_desc* d = &t.d;
     float* out = cfg[j].S > 1 ? (float*)((char*)workspace + off[j]) : t.dw;
-    const int rc = wg_fill_params(g.p[j], t.dy, t.x, out, d, cfg[j]);
+    const int rc = wg_fill_params(g.p[a], t.dy, t.x, out, d, cfg[j]);
     if (rc) return rc;
     const bool dense = (d->kT * d->kH * d->kW == 1) && d->sT == 1 && d->sH == 1 && d->sW == 1 && d->pT == 0 &&
                        d->pH == 0 && d->pW == 0;
-    g.mode[j] = dense ? 0 : 1;
-    g.first[j] = first;
+    g.mode[a] = dense ? 0 : 1;
+    g.first[a] = first;
     first += cfg[j].tilesM * cfg[j].tilesN * cfg[j].S;
     if (cfg[j].S > 1) {
       const int e = r.n++;
       r.slabs[e] = out;
       r.dw[e] = t.dw;
-      r.len[e] = (long long)d->Cout * g.p[j].Kp;
+      r.len[e] = (long long)d->Cout * g.p[a].Kp;
       r.S[e] = cfg[j].S;
       r.first[e + 1] = r.first[e] + wgrad_reduce_vblocks(r.len[e], r.S[e]);
     }

@@ -668,7 +668,8 @@ class ResBlock(nn.Module):
     # Train: a block's weight gradients as one launch.  VS_WGRAD_GROUP=0: per-unit launches; VS_WGRAD_GROUP_MAXP: the
     # position count up to which a block is grouped (at 32 clips per GPU the separate launches fill the chip themselves).
     group_wgrads = os.environ.get("VS_WGRAD_GROUP", "1") != "0"
-    group_max_positions = int(os.environ.get("VS_WGRAD_GROUP_MAXP", "60000"))
+    group_max_positions = int(os.environ.get("VS_WGRAD_GROUP_MAXP", "1000000000"))
+    group_min_channels = int(os.environ.get("VS_WGRAD_GROUP_MINC", "128"))  # narrower blocks: neutral (64, 32) or slower (16, 8) in the step
 
     def _wgrad_grouped(self, rc, rb, ra, rsc, dout):
         if (not ResBlock.group_wgrads or not dout.is_cuda or _Unit.wgrad_batch is not None or _Unit.split_wgrad_reduce
@@ -682,9 +683,8 @@ class ResBlock(nn.Module):
             items = []
             for r in recs:
                 c, y, x = r["conv"], r["y"], r["x"]
-                kp = c.cin * c.k[0] * c.k[1] * c.k[2]
-                if (c.is_stem or c.cin_pad != c.cin or c.bias is not None or r.get("x_affine") is not None or c.cout < 128
-                        or kp < 128 or not isinstance(x, torch.Tensor)
+                if (c.is_stem or c.cin_pad != c.cin or c.bias is not None or r.get("x_affine") is not None
+                        or c.cout < ResBlock.group_min_channels or not isinstance(x, torch.Tensor)
                         or not getattr(c.weight, "_vs_direct_grad", True)):
                     hit = False
                     break
