@@ -251,7 +251,7 @@ int vs_weight_transpose_tiled(const void* src, void* dst, const int64_t* table, 
 size_t vs_conv_wgrad_workspace_bytes(const vs_conv_desc* d);
 int vs_conv_wgrad(const void* dy, const void* x, float* dw, const vs_conv_desc* d,
                   void* workspace, size_t ws_bytes, void* stream);
-/* Grouped weight gradients (round 5): the Conv3d bwd-filter of up to 8 convolutions -- a ResBlock's a, b, c and shortcut
+/* Grouped weight gradients (round 5): the Conv3d bwd-filter of up to 20 convolutions -- a ResBlock's a, b, c and shortcut, or those of two or three consecutive blocks
  * (slowfast resnet_helper.ResBlock, reached from mdl_sf_base.py:22-33) -- as ONE launch of deep-pipeline blocks (128 x 256
  * output tiles) whose problems share the chip, + one grouped slab reduce where a problem is still split over positions.
  * Together the problems need far fewer position splits than each alone.  Every item: taps <= 31, Cin and Cout multiples

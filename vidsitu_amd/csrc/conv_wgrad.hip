@@ -798,7 +798,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_deep_kernel(WgradP p) {
 // all), so fewer fp32 slabs are written and re-read, and one launch (+ one grouped slab reduce) replaces three or four
 // (+ their reduces).  Same body, same summation order per problem for a given split count.
 // ---------------------------------------------------------------------------------------------
-#define WGG_MAX 8
+#define WGG_MAX 20
 struct WgGroupP {
   int n;
   int first[WGG_MAX + 1];  // block range of problem j: [first[j], first[j + 1])
@@ -1369,7 +1369,7 @@ extern "C" size_t vs_conv_wgrad_group_workspace_bytes(const vs_wgrad_item* items
 }
 
 extern "C" int vs_conv_wgrad_group(const vs_wgrad_item* items, int n, void* workspace, size_t ws_bytes, void* stream) {
-  VS_CHECK_ARG(items != nullptr && n >= 1 && n <= WGG_MAX, "1 .. 8 items");
+  VS_CHECK_ARG(items != nullptr && n >= 1 && n <= WGG_MAX, "1 .. 20 items");
   WgCfg cfg[WGG_MAX];
   size_t off[WGG_MAX], tot = 0;
   int order[WGG_MAX];

@@ -584,6 +584,9 @@ def conv_wgrad_split(dy, x, k, s, p, out, ring=0):
     return lambda: _lib.call("vs_wgrad_reduce", _ptr(ws), _ptr(out), n, S, _stream())
 
 
+WGRAD_GROUP_MAX = 20  # vs_conv_wgrad_group: items per launch
+
+
 def _wgrad_items(items):
     arr = (_lib.WgradItem * len(items))()
     for i, (dy, x, k, s, p, out) in enumerate(items):
@@ -597,7 +600,7 @@ def _wgrad_items(items):
 
 def conv_wgrad_group_ok(items):
     """items: [(dy, x, k, s, p, dw_out)] -- can these weight gradients run as one grouped launch?"""
-    if not 1 <= len(items) <= 8:
+    if not 1 <= len(items) <= WGRAD_GROUP_MAX:
         return False
     return bool(_lib.load().vs_conv_wgrad_group_ok(_wgrad_items(items), len(items)))
 

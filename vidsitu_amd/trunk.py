@@ -650,10 +650,13 @@ class ResBlock(nn.Module):
             saved[-1]["sc_rec"] = saved[-4]  # the next block's conv-a dgrad also emits the shortcut unit's BN sums
         return z
 
-    def bwd(self, saved, dout, chain=False):
+    def bwd(self, saved, dout, chain=False, carry=None):
         """chain: this block's input is the previous block's output and nothing else reads it -- the record
         on top of `saved` after this block's own is then that block's c unit (`_Unit.bwd` checks the tensor
-        identity), whose BN-backward sums come out of this block's conv-a dgrad."""
+        identity), whose BN-backward sums come out of this block's conv-a dgrad.
+        carry: the stage's pending grouped weight gradients (`VideoTrunk._backward_stage`): a groupable block adds its
+        items and the launch goes out every `ResBlock.group_span` blocks (two blocks' weight gradients share one grid
+        better than each fills its own: tools/wgrad_group_time.py --span)."""
         rc, rb, ra = saved.pop(), saved.pop(), saved.pop()
         # The block's weight gradients as ONE grouped launch behind its last data gradient (ops.conv_wgrad_group) where
         # that wins: wide, few-position blocks (slow res3 - res5 at 8 clips per GPU: 60-140 us per block instead of
@@ -663,7 +666,24 @@ class ResBlock(nn.Module):
             return self._bwd_units(saved, dout, chain, rc, rb, ra, sink)
         finally:
             if sink:
-                ops.conv_wgrad_group([(dy, x, c.k, c.s, c.p, c.weight.grad) for dy, x, c in sink])
+                items = [(dy, x, c.k, c.s, c.p, c.weight.grad) for dy, x, c in sink]
+                if carry is None:
+                    ops.conv_wgrad_group(items)
+                else:
+                    carry["items"] += items
+                    carry["blocks"] += 1
+                    if carry["blocks"] >= ResBlock.group_span or len(carry["items"]) + 4 > ops.WGRAD_GROUP_MAX:
+                        ResBlock.flush_wgrads(carry)
+
+    @staticmethod
+    def flush_wgrads(carry):
+        if carry and carry["items"]:
+            ops.conv_wgrad_group(carry["items"])
+        if carry:
+            carry["items"], carry["blocks"] = [], 0
+
+    # blocks whose weight gradients share one grouped launch (VS_WGRAD_GROUP_SPAN)
+    group_span = int(os.environ.get("VS_WGRAD_GROUP_SPAN", "3"))  # A/B in the step: 1 -> 2 -> 3 blocks +0.2 % each, 4 the same, 6 -0.3 %
 
     # Train: a block's weight gradients as one launch.  VS_WGRAD_GROUP=0: per-unit launches; VS_WGRAD_GROUP_MAXP: the
     # position count up to which a block is grouped (at 32 clips per GPU the separate launches fill the chip themselves).
@@ -1442,10 +1462,16 @@ class VideoTrunk(nn.Module):
             with par.on(p):
                 g = d[p]
                 blks = stage.blocks(p)
+                carry = {"items": [], "blocks": 0}  # grouped weight gradients waiting for their launch (this stream's)
                 for i in reversed(range(len(blks))):
                     # chain: the block's input is the previous block's output and has no other consumer
                     # (a stage's first block shares its input with the lateral connection / the shortcut)
-                    g = blks[i].bwd(saved, g, chain=i > 0) if isinstance(blks[i], ResBlock) else blks[i].bwd(saved, g)
+                    if isinstance(blks[i], ResBlock):
+                        g = blks[i].bwd(saved, g, chain=i > 0, carry=carry)
+                    else:
+                        ResBlock.flush_wgrads(carry)
+                        g = blks[i].bwd(saved, g)
+                ResBlock.flush_wgrads(carry)
                 d[p] = g
         par.join(keep=d_in)
         st["d"] = d
