@@ -801,7 +801,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_deep_kernel(WgradP p) {
 #define WGG_MAX 20
 struct WgGroupP {
   int n;
-  int first[WGG_MAX + 1];  // block range of problem j: [first[j], first[j + 1])
+  int first[WGG_MAX + 1];  // block range of problem j starts at first[j] (a multiple of 8 with the XCD order) ...
+  int count[WGG_MAX];      // ... and holds count[j] blocks (the rest of the range up to first[j + 1] exits at once)
   int mode[WGG_MAX];       // 0 pointwise, 1 gather
   WgradP p[WGG_MAX];
 };
@@ -813,9 +814,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_deep_group_kernel(WgGroupP g) 
   for (int i = 1; i < WGG_MAX; ++i)
     if (i < g.n && b >= g.first[i]) j = i;
   j = __builtin_amdgcn_readfirstlane(j);
-  const int lo = g.first[j], hi = g.first[j + 1];
-  if (g.mode[j] == 0) conv_wgrad_deep_body<0, true>(g.p[j], b - lo, hi - lo);
-  else conv_wgrad_deep_body<1, true>(g.p[j], b - lo, hi - lo);
+  const int lo = g.first[j], cnt = g.count[j];
+  if (b - lo >= cnt) return;
+  if (g.mode[j] == 0) conv_wgrad_deep_body<0, true>(g.p[j], b - lo, cnt);
+  else conv_wgrad_deep_body<1, true>(g.p[j], b - lo, cnt);
 }
 
 // the slab reduces of a grouped launch as one grid: entry e owns the virtual 256-thread blocks [first[e], first[e + 1])
@@ -1399,8 +1401,12 @@ extern "C" int vs_conv_wgrad_group(const vs_wgrad_item* items, int n, void* work
     const bool dense = (d->kT * d->kH * d->kW == 1) && d->sT == 1 && d->sH == 1 && d->sW == 1 && d->pT == 0 &&
                        d->pH == 0 && d->pW == 0;
     g.mode[a] = dense ? 0 : 1;
+    // (An XCD-contiguous block order inside each problem -- its range padded to a multiple of 8, the tiles of one split on
+    //  one XCD's L2 -- was measured: slow s4 / s5 blocks 4-9 % faster alone on the chip, the step 0.1-0.3 % slower with
+    //  three-block groups; not kept.)
     g.first[a] = first;
-    first += cfg[j].tilesM * cfg[j].tilesN * cfg[j].S;
+    g.count[a] = cfg[j].tilesM * cfg[j].tilesN * cfg[j].S;
+    first += g.count[a];
     if (cfg[j].S > 1) {
       const int e = r.n++;
       r.slabs[e] = out;
