@@ -1294,8 +1294,11 @@ class VideoTrunk(nn.Module):
                     buf = out = ops.new_act(n, c, t, hp, wp, dev)
                 stem.fwd(xin[p], out, train, saved)
             cur.append(buf)
+        if self.multi and VideoTrunk.fuse_on_fast:
+            with par.on(1):  # the lateral connection on the fast pathway's stream: off the slow pathway's chain
+                self._fuse_fwd(self.s1_fuse, cur, train, saved)
         par.join()
-        if self.multi:
+        if self.multi and not VideoTrunk.fuse_on_fast:
             self._fuse_fwd(self.s1_fuse, cur, train, saved)
         if self.debug_taps is not None:
             self.debug_taps["s1"] = [c.float().cpu() for c in cur]
@@ -1323,9 +1326,12 @@ class VideoTrunk(nn.Module):
                     else:
                         x = blk.fwd(x, None, train, saved)
                 nxt.append(x)
+            if fuse is not None and VideoTrunk.fuse_on_fast:
+                with par.on(1):
+                    self._fuse_fwd(fuse, nxt, train, saved)
             par.join(keep=cur)
             cur = nxt
-            if fuse is not None:
+            if fuse is not None and not VideoTrunk.fuse_on_fast:
                 self._fuse_fwd(fuse, cur, train, saved)
             if k == 2:
                 for p in range(P):
@@ -1433,14 +1439,18 @@ class VideoTrunk(nn.Module):
             self._backward_stage(st, k)
         if seg == "rest":
             saved, d = st["saved"], st["d"]
+            late = None
             if self.multi:
-                d = self._fuse_bwd(saved, d)
+                d, late = self._fuse_bwd(saved, d, defer=VideoTrunk.fuse_on_fast)
             par = self._fork_ctx(d[0].device)
+            d_in = list(d)
             par.fork()
             for p in reversed(range(self.num_pathways)):
                 with par.on(p):
+                    if p == 1 and late is not None:
+                        d[1] = late()
                     getattr(self.s1, f"pathway{p}_stem").bwd(saved, d[p])
-            par.join(keep=d)
+            par.join(keep=d_in)
             assert not saved, "trunk backward did not consume every saved record"
 
     def _backward_stage(self, st, k):
@@ -1453,13 +1463,16 @@ class VideoTrunk(nn.Module):
                 if self.pool1[p][0] > 1:
                     rec = saved.pop()
                     d[p] = ops.maxpool_t_bwd(d[p], rec["tpool_idx"], rec["tpool_in"], rec["kt"])
+        late = None
         if fuse is not None:
-            d = self._fuse_bwd(saved, d)
+            d, late = self._fuse_bwd(saved, d, defer=VideoTrunk.fuse_on_fast)
         par = self._fork_ctx(d[0].device)
         d_in = list(d)  # keep the incoming gradients alive until both streams are done with them
         par.fork()
         for p in reversed(range(P)):
             with par.on(p):
+                if p == 1 and late is not None:
+                    d[1] = late()  # the lateral connection's backward, on the fast pathway's stream
                 g = d[p]
                 blks = stage.blocks(p)
                 carry = {"items": [], "blocks": 0}  # grouped weight gradients waiting for their launch (this stream's)
@@ -1476,10 +1489,21 @@ class VideoTrunk(nn.Module):
         par.join(keep=d_in)
         st["d"] = d
 
-    def _fuse_bwd(self, saved, d):
+    # The lateral connections (FuseFastToSlow: conv_f2s + BN + ReLU of the FAST pathway's output, written into the slow
+    # pathway's concat buffer) run on the fast pathway's stream -- forward before the stage's join, backward behind the
+    # next fork -- instead of on the caller's stream between two stages: nothing of the slow pathway's chain waits for
+    # them but the join it waits at anyway, and their strided data gradients (55 / 31 / 20 / 20 us) leave the chain.
+    # Same launches, same bits.  VS_FUSE_ON_FAST=0: on the caller's stream.
+    fuse_on_fast = os.environ.get("VS_FUSE_ON_FAST", "1") != "0"
+
+    def _fuse_bwd(self, saved, d, defer=False):
+        """-> ([slow gradient, fast gradient], None), or with `defer` ([slow gradient, None], thunk): the thunk runs the
+        lateral unit's backward (on whatever stream is current when it is called) and returns the fast gradient."""
         d_cat, d_fast = d
         rec = saved.pop()
         cf = rec["conv"].cout
         cs = d_cat.shape[1] - cf
-        d_fast_tot, _ = _Unit.bwd(rec, ops.channel_slice(d_cat, cs, cf), dx_residual=d_fast)
-        return [ops.channel_slice(d_cat, 0, cs), d_fast_tot]
+        run = lambda: _Unit.bwd(rec, ops.channel_slice(d_cat, cs, cf), dx_residual=d_fast)[0]
+        if defer:
+            return [ops.channel_slice(d_cat, 0, cs), None], run
+        return [ops.channel_slice(d_cat, 0, cs), run()], None
