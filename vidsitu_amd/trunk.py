@@ -678,9 +678,13 @@ class ResBlock(nn.Module):
     @staticmethod
     def flush_wgrads(carry):
         if carry and carry["items"]:
-            ops.conv_wgrad_group(carry["items"])
+            items = carry["items"]
+            # (Measured and not kept: the grouped launch on the weight-gradient lane, sized for a fraction of the CUs, beside
+            #  the next blocks' kernels -- 11.20-11.28 ms against 11.05-11.16 inline: the chip has no idle share to give it.)
+            ops.conv_wgrad_group(items)
         if carry:
             carry["items"], carry["blocks"] = [], 0
+
 
     # blocks whose weight gradients share one grouped launch (VS_WGRAD_GROUP_SPAN)
     group_span = int(os.environ.get("VS_WGRAD_GROUP_SPAN", "3"))  # A/B in the step: 1 -> 2 -> 3 blocks +0.2 % each, 4 the same, 6 -0.3 %
