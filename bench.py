@@ -85,6 +85,10 @@ def _nn(a):
     return 0 if a is None or _v(a) in (None, 0) else 1
 
 
+# the weight-gradient family of the roofline (entry points vs_conv_wgrad and vs_conv_wgrad_group; the kernels named after
+# "+" run behind those calls and their PMC bytes are charged to the family)
+WGRAD_FAMILY = ("conv_wgrad (conv_wgrad_deep_group_kernel | conv_wgrad_ring_kernel | conv_wgrad_deep_kernel | "
+                "conv_wgrad_kernel, + wgrad_reduce)")
 _WAVES = {(128, 128): (2, 2), (64, 128): (1, 4), (128, 64): (2, 2), (64, 64): (2, 2),
           (256, 32): (4, 1), (256, 16): (4, 1), (256, 128): (4, 1), (128, 256): (1, 4)}
 
@@ -143,7 +147,7 @@ class EntryProbe:
                 flops = 2.0 * mo * d.Cout * d.Cin * taps
                 byts = 2.0 * (mi * d.Cin + mo * d.Cout + d.Cout * d.Cin * taps)
                 if name == "vs_conv_wgrad":
-                    return "conv_wgrad (conv_wgrad_ring_kernel | conv_wgrad_deep_kernel | conv_wgrad_kernel, + wgrad_reduce_kernel)", "mfma", flops, byts
+                    return WGRAD_FAMILY, "mfma", flops, byts
                 if name == "vs_conv_fwd" and (d.flags & 2):
                     byts += 2.0 * mo * d.Cout
                 if name == "vs_conv_dgrad_bnstats":  # + the producer's saved conv output, read by the epilogue
@@ -155,6 +159,21 @@ class EntryProbe:
                         (0.125 if ep.residual_bits else 0.0)
                     return conv_label(d, 1, bnb, bnb2), "mfma", flops, byts + extra * mi * d.Cin
                 return conv_label(d, 1 if name == "vs_conv_dgrad" else 0), "mfma", flops, byts
+            if name == "vs_conv_wgrad_group":  # several weight gradients in one launch: the sum of their algorithmic work
+                flops = byts = 0.0
+                for i in range(_v(a[1])):
+                    d = a[0][i].d
+                    taps = d.kT * d.kH * d.kW
+                    mo, mi = d.N * d.To * d.Ho * d.Wo, d.N * d.Ti * d.Hi * d.Wi
+                    flops += 2.0 * mo * d.Cout * d.Cin * taps
+                    byts += 2.0 * (mi * d.Cin + mo * d.Cout + d.Cout * d.Cin * taps)
+                return WGRAD_FAMILY, "mfma", flops, byts
+            if name == "vs_bn_apply2":  # y and the shortcut's raw output in, the block's output + its ReLU bits out
+                rows, c = _v(a[8]), _v(a[9])
+                return "bn_apply_cols_kernel", "hbm", 0.0, 2.0 * rows * c * 3 + rows * c / 8.0 * _nn(a[7])
+            if name == "vs_bn_bwd_apply2":  # dz + bits, two y in; two dy out
+                rows, c = _v(a[16]), _v(a[17])
+                return "bn_bwd_apply2_cols_kernel", "hbm", 0.0, 2.0 * rows * c * 5 + rows * c / 8.0
             if name in ("vs_stem_conv_fwd", "vs_stem_conv_wgrad"):
                 n, t, h, w, cout, kt = [_v(x) for x in a[3:9]]
                 ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
