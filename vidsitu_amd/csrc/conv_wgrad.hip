@@ -1320,14 +1320,8 @@ static bool wgg_plan(const vs_wgrad_item* it, int n, WgCfg* cfg, size_t* slab_of
   };
   long long bestS[WGG_MAX], bestR[WGG_MAX], S[WGG_MAX], R[WGG_MAX];
   double best = -1.0;
-  static const int plan_mode = [] { const char* e = getenv("VS_WGG_PLAN"); return e ? atoi(e) : 1; }();
   long long u = W / (3ll * slots);
   if (u < 16) u = 16;
-  if (plan_mode == 0) {  // (A/B: the first planner -- one candidate, ~slots blocks nominal, problems in caller order)
-    u = (W + slots - 1) / slots;
-    if (u < 16) u = 16;
-    umax = u;
-  }
   for (; u <= umax + 1; u += (u + 15) / 16) {
     splits(u, S, R);
     const double c = cost(S, R);
@@ -1346,7 +1340,7 @@ static bool wgg_plan(const vs_wgrad_item* it, int n, WgCfg* cfg, size_t* slab_of
     blocks += (long long)tiles[j] * bestS[j];
     order[j] = j;
   }
-  for (int a = 0; a < n && plan_mode != 0; ++a)
+  for (int a = 0; a < n; ++a)
     for (int b = a + 1; b < n; ++b)
       if (bestR[order[b]] > bestR[order[a]]) { const int t = order[a]; order[a] = order[b]; order[b] = t; }
   *slab_total = off;
