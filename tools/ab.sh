@@ -214,6 +214,25 @@ for rep in 1 2; do for b in 512 0; do
   VS_DIRECT_TPW_BLOCKS=$b timeout 600 python bench.py --workload feat_fwd --steps 50 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('fwd tpw_blocks $b', d['value'], d['ms_per_step'])"
 done; done
 ;;
+r5_batch_probe)
+# Round-5 batch probe: the step at 8 / 16 / 32 / 40 / 64 clips per GPU on the default plan (8 = the BASELINE config, 40 = the
+# reference's train.bs x 5 events); a least-squares line t = a + b * clips through the train rows is printed at the end.
+export TMPDIR=/tmp
+OUT=gpurun_out/r5_batch_probe; mkdir -p $OUT; : > $OUT/probe.txt
+for n in 8 16 32 40 64; do
+  for wl in sf_txenc_train feat_fwd; do
+    timeout 600 python bench.py --workload $wl --clips-per-gpu $n --steps 15 --warmup 4 --no-cpu-baseline --no-roofline --no-feat-fwd 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$wl clips $n', d['value'], d['ms_per_step'], d['config'].get('frac_of_bf16_mfma_peak'))" | tee -a $OUT/probe.txt
+  done
+done
+python - <<'PY' | tee -a gpurun_out/r5_batch_probe/probe.txt
+import numpy as np
+rows = [l.split() for l in open("gpurun_out/r5_batch_probe/probe.txt") if l.startswith("sf_txenc_train")]
+x = np.array([float(r[2]) for r in rows]); y = np.array([float(r[4]) for r in rows])
+for sel, name in ((x >= 16, "16..64"), (x >= 0, "8..64")):
+    b, a = np.polyfit(x[sel], y[sel], 1)
+    print(f"train, clips {name}: t = {a:.2f} ms + {b:.3f} ms/clip; the 8-clip step is {y[0]:.2f} ms, {y[0] - 8 * b:.2f} ms of it do not scale with the batch")
+PY
+;;
 r5_final)
 # Round-5 artefact run: full GPU test suite, smoke, both bench workloads (default flags), one-stream rocprofv3
 # kernel stats, PMC traffic and MFMA-busy passes.  Everything lands in gpurun_out/r5_final/.
