@@ -303,7 +303,7 @@ def feat_fwd_leg(dev, rank, replays=20):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, stream=side):  # the warm-up's stream: its cached scratch buffers are re-used, none is made in the graph
         step()
     g.replay()
     torch.cuda.synchronize()
@@ -676,7 +676,7 @@ def main():
             ts.capture()
         else:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, stream=side):  # (the warm-up's stream: see TrainStep.capture)
                 out = step()
             graph.replay()
             torch.cuda.synchronize()

@@ -67,6 +67,7 @@ class TrainStep:
         self.grad_fill = grad_fill
         self._accumulated = None  # learned: parameters that need a zero gradient before every backward pass
         self.graphs = None  # segment graphs + the Adam graph, or [whole-step graph]
+        self._eager_stream = None
         self.segments = self._build_segments()
 
     # ---- pieces ------------------------------------------------------------------------------
@@ -191,6 +192,8 @@ class TrainStep:
         return self.loss
 
     def step(self):
+        if self.arena.data.is_cuda and not torch.cuda.is_current_stream_capturing():
+            self._eager_stream = torch.cuda.current_stream()  # capture() records on the same stream (see there)
         if self.adam_overlap:
             return self._step_adam_overlapped()
         works = []
@@ -212,6 +215,11 @@ class TrainStep:
         # (global) capture mode treats that as an illegal call and invalidates the capture.
         mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
         inner = []  # an exception raised by the step itself: ending the aborted capture fails too, with a less useful error
+        # Capture on the stream the eager warm-up step ran on: the kernels' scratch buffers are cached per stream
+        # (ops._workspace), and on a stream of its own the capture would allocate them again INSIDE the graph -- the
+        # zero fill of the arrival-counter workspaces then replays with every step (73 us per step, measured).
+        st = getattr(self, "_eager_stream", None)
+        on = {} if st is None or st == torch.cuda.default_stream(st.device) else {"stream": st}
 
         def guarded(fn):
             try:
@@ -230,7 +238,7 @@ class TrainStep:
         try:
             if not self.use_dist:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode=mode):
+                with torch.cuda.graph(g, capture_error_mode=mode, **on):
                     guarded(self.step)
                 self.graphs = [g]
             else:
@@ -238,7 +246,7 @@ class TrainStep:
                 fns = [(lambda fn=fn, r=r: (fn(), self._pack(*r))) for fn, r in self.segments] + [self._adam]
                 for fn in fns:
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
+                    with torch.cuda.graph(g, pool=pool, capture_error_mode=mode, **on):
                         guarded(fn)
                     pool = g.pool()
                     graphs.append(g)
