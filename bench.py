@@ -664,8 +664,11 @@ def main():
     graph, used_graph = None, False
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
+    # the W untimed steps: eager ones first (allocator, plan caches, lane streams; two are enough), the rest as replays of
+    # the captured graph -- a graph's FIRST launch uploads it (a one-time ~1 ms that is not part of a step)
+    n_eager = max(1, min(args.warmup, 2)) if args.graph else max(args.warmup, 1)
     with torch.cuda.stream(side):
-        for _ in range(max(args.warmup, 1)):
+        for _ in range(n_eager):
             out = step()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
@@ -678,8 +681,6 @@ def main():
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side):  # (the warm-up's stream: see TrainStep.capture)
                 out = step()
-            graph.replay()
-            torch.cuda.synchronize()
         used_graph = True
 
     def run_once():
@@ -689,6 +690,11 @@ def main():
             graph.replay()
         else:
             step()
+
+    if used_graph:
+        for _ in range(max(args.warmup - n_eager, 1)):
+            run_once()
+        torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps, barrier + sync on both sides --------------------
     if world > 1:
