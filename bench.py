@@ -251,7 +251,7 @@ def load_pmc_traffic(workload="sf_txenc_train"):
         return {}
 
 
-def eval_parity_note(calibrated=False):
+def eval_parity_note(calibrated=False, train=False):
     """The eval path's distance to the fp32 reference at the logits, as LAST MEASURED by
     tests/test_gpu_parity_full.py (one 224^2 SlowFast-R50 clip against the fp32 oracle), read from
     profiles/parity_eval.json (the file that test writes, committed with the commit it was measured at), for the eval
@@ -269,10 +269,26 @@ def eval_parity_note(calibrated=False):
             rec = json.load(f)
     except (OSError, ValueError):
         return None
-    return {"eval_mode": mode, "logits_rel_err_vs_fp32_oracle": rec["logits_rel_err_vs_fp32_oracle"].get(mode),
+    note = {"eval_mode": mode, "logits_rel_err_vs_fp32_oracle": rec["logits_rel_err_vs_fp32_oracle"].get(mode),
+            # the tolerance is RELATIVE: the largest logit difference over the largest |logit| of the oracle (the test's
+            # head has max |logit| in the thousands, so "1e-3" is not an absolute bound)
+            "metric": "max|logit - oracle logit| / max|oracle logit|",
             "north_star": rec.get("north_star", 1e-3),
             "same_bf16_weights_both_sides": rec.get("same_bf16_weights_both_sides"),
             "measured_at_commit": rec.get("commit"), "source": rec.get("source", "") + "; not re-measured in this run"}
+    rob = rec.get("robustness")
+    if rob and calibrated:
+        # calibrated shifts over 8 evaluation clips and under a calibration / evaluation distribution shift
+        note["calibrated_shift_over_clips"] = {k: {"max": v["max"], "median": v["median"]}
+                                               for k, v in rob.get("cases", {}).items()}
+    if train:
+        # a TRAINING line times batch-statistic arithmetic: its own measured distance, beside the eval figure
+        tm = rec.get("train_mode")
+        note["train_mode"] = None if tm is None else {**tm, "metric": note["metric"]}
+        note["note"] = ("this line times the TRAINING step: `train_mode` is the distance of that arithmetic "
+                        "(batch-statistic BN, bf16 storage) from the fp32 oracle; the eval figure is the same weights' "
+                        "inference path")
+    return note
 
 
 def feat_fwd_leg(dev, rank, replays=20):
@@ -876,7 +892,7 @@ def main():
                           if train and os.environ.get("VS_BENCH_ENC_LAYERS", "6") != "6" else {}),
                        # the arithmetic of the line: bf16 operands (fp32 accumulation / statistics / optimizer); the
                        # logits' distance to the fp32 reference in that arithmetic, as last measured by the parity test
-                       "parity": eval_parity_note(False if train else calibrated_main),
+                       "parity": eval_parity_note(False if train else calibrated_main, train=train),
                        "grad_allreduce": (None if ts is None else
                                           (f"{len(ts.segments)} bucket(s), "
                                            f"{'bf16' if ts.grad_bf16 else 'fp32'} payload, "

@@ -72,6 +72,22 @@ def test_parity_numbers_come_from_the_file_the_parity_test_writes():
     assert e["bf16_calibrated_shift"] < rec["north_star"]
     assert re.fullmatch(r"[0-9a-f]{12}", rec["commit"]), "parity_eval.json carries the commit it was measured at"
     assert "calibrate_eval(mdl" in src and "canonical_b8x5_leg" in src
+    # round 6: a TRAINING line carries the train-mode distance beside the eval one, and every note names its metric (the
+    # tolerance is relative to max |logit|); the calibrated path's spread over clips / distributions rides with eval lines
+    assert rec["train_mode"]["logits_rel_err_vs_fp32_oracle"] < 2e-2 and "configs2" in rec["train_mode"]["source"]
+    cases = rec["robustness"]["cases"]
+    assert cases["calibrated_on_noise/noise"]["max"] < rec["north_star"]
+    assert cases["calibrated_on_video/video"]["median"] < rec["north_star"] < cases["uncalibrated/video"]["max"]
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    tr = bench.eval_parity_note(False, train=True)
+    assert tr["metric"].startswith("max|logit") and tr["eval_mode"] == "bf16"
+    assert tr["train_mode"]["logits_rel_err_vs_fp32_oracle"] == rec["train_mode"]["logits_rel_err_vs_fp32_oracle"]
+    assert tr["train_mode"]["metric"] == tr["metric"] and "TRAINING" in tr["note"]
+    ev = bench.eval_parity_note(True)
+    assert "train_mode" not in ev and ev["eval_mode"] == "bf16_calibrated_shift"
+    assert set(ev["calibrated_shift_over_clips"]["calibrated_on_video/video"]) == {"max", "median"}
 
 
 def test_forward_line_and_cli_surface():

@@ -122,3 +122,16 @@ def test_visible_gpus_is_bounded_by_what_the_environment_selects(monkeypatch):
     assert dist_launch.visible_gpus() == 0
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2,3,4,5,6,7,8,9")
     assert dist_launch.visible_gpus() <= n
+
+
+def test_rocr_filters_the_physical_devices_and_hip_reindexes_what_is_left():
+    """ROCR_VISIBLE_DEVICES addresses physical devices, HIP_ / CUDA_VISIBLE_DEVICES index the ROCR-filtered
+    set -- ROCR=2,3 with HIP=0,1 on an 8-GPU node is two devices, not zero."""
+    f = dist_launch._apply_visible_env
+    assert f(8, {}) == 8
+    assert f(8, {"ROCR_VISIBLE_DEVICES": "2,3", "HIP_VISIBLE_DEVICES": "0,1"}) == 2
+    assert f(8, {"ROCR_VISIBLE_DEVICES": "2,3", "HIP_VISIBLE_DEVICES": "2,3"}) == 0   # HIP indices past the ROCR set
+    assert f(8, {"ROCR_VISIBLE_DEVICES": "6,7", "CUDA_VISIBLE_DEVICES": "1"}) == 1
+    assert f(8, {"ROCR_VISIBLE_DEVICES": "0,1,2,3", "HIP_VISIBLE_DEVICES": "0,1,2", "CUDA_VISIBLE_DEVICES": "0"}) == 1
+    assert f(2, {"ROCR_VISIBLE_DEVICES": "2,3"}) == 0                                  # physical index out of range
+    assert f(8, {"HIP_VISIBLE_DEVICES": "4,5,6"}) == 3

@@ -1236,7 +1236,10 @@ static bool wgg_item_ok(const vs_conv_desc* d) {
   if (taps > 31 || Kp % 8 != 0 || d->Cout % 8 != 0 || d->x_ld % 8 != 0 || d->y_ld % 8 != 0) return false;
   if (((d->flags >> 8) & 0xf) || ((d->flags >> 16) & 7) || ((d->flags >> 24) & 0xff)) return false;  // forced plans
   const long long P = (long long)d->N * d->To * d->Ho * d->Wo;
-  return P >= 512 && (long long)d->N * d->Ti * d->Hi * d->Wi < (1ll << 31);
+  // the same 2-GiB tensor limit wg_fill_params enforces: a group declared OK must not fail inside the launch
+  const long long xb = (long long)d->N * d->Ti * d->Hi * d->Wi * d->x_ld * 2;
+  const long long db = P * d->y_ld * 2;
+  return P >= 512 && xb < (1ll << 31) && db < (1ll << 31);
 }
 
 // Splits of a group.  Every candidate "units per block" u gives each problem S_j = round(units_j / u) splits; the grid is
@@ -1322,6 +1325,9 @@ static bool wgg_plan(const vs_wgrad_item* it, int n, WgCfg* cfg, size_t* slab_of
   double best = -1.0;
   long long u = W / (3ll * slots);
   if (u < 16) u = 16;
+  // many equally long tiles (or few slots) put the first candidate past the longest problem: the loop below must still
+  // evaluate at least one plan -- start no higher than the no-split candidate u = umax (every S_j = 1)
+  if (u > umax) u = umax;
   for (; u <= umax + 1; u += (u + 15) / 16) {
     splits(u, S, R);
     const double c = cost(S, R);
@@ -1330,6 +1336,7 @@ static bool wgg_plan(const vs_wgrad_item* it, int n, WgCfg* cfg, size_t* slab_of
       for (int j = 0; j < n; ++j) { bestS[j] = S[j]; bestR[j] = R[j]; }
     }
   }
+  if (best < 0.0) return false;  // no candidate evaluated (cannot happen with the clamp above; never plan from garbage)
   size_t off = 0;
   long long blocks = 0;
   for (int j = 0; j < n; ++j) {

@@ -55,10 +55,22 @@ def visible_gpus():
     nodes = glob.glob("/dev/dri/renderD*")
     if nodes:
         n = min(n, sum(1 for d in nodes if os.access(d, os.R_OK | os.W_OK)))
-    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
-        v = os.environ.get(var)
+    return _apply_visible_env(n, os.environ)
+
+
+def _apply_visible_env(n_physical, env):
+    """Cut a physical device count down by the *_VISIBLE_DEVICES variables in the order the stack applies them:
+    ROCR_VISIBLE_DEVICES indexes the PHYSICAL devices (the HSA runtime filters first); HIP_VISIBLE_DEVICES and its alias
+    CUDA_VISIBLE_DEVICES re-index the set ROCR left.  (ROCR=2,3 with HIP=0,1 on an 8-GPU node is two devices.)"""
+    n = n_physical
+    v = env.get("ROCR_VISIBLE_DEVICES")
+    if v is not None:
+        n = min(n, _count_visible_tokens(v, n_physical))
+    n_rocr = n
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = env.get(var)
         if v is not None:
-            n = min(n, _count_visible_tokens(v, n))
+            n = min(n, _count_visible_tokens(v, n_rocr))
     return n
 
 

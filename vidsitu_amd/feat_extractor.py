@@ -99,10 +99,14 @@ def main(mdl_resume_path: str, mdl_name_used: str, is_cu: bool = False, splits=(
     `<vsitu_frm_feats>/<name>/<vseg>_feats.npy` ([E, 2304] / [E, 2048] float32) for every video of every split.
     The videos are the synthetic stand-in dataset (`SynthFrameDataset`; the 50 GB frame dataset is out of scope), so what this
     entry point pins is the flow: weights -> eval trunk on the HIP kernels -> head -> files the TxEncoder rows read back.
-    `--calibrate=N` (default 2; 0 = off): before the first split the model measures, on N videos' clips that are NOT
-    dumped (their own seed), the per-channel constants the bf16 rounding of its convolution weights adds and folds their
-    correction into the BN shifts (`SFBase.calibrate_weight_rounding`): features within 1e-3 of the fp32 reference's instead
-    of 3e-3 (tests/test_gpu_parity_full.py), at no cost per forward."""
+    `--calibrate=N` (default 2; 0 = off, the reference's behaviour: it has no such step): before the first split the
+    model measures, on the clips of the first N videos OF THE DATASET BEING EXTRACTED (the first split's loader -- the
+    evaluation distribution itself, never a stand-in: a constant measured on other data is a data-dependent bias, not a
+    correction), the per-channel constants the bf16 rounding of its convolution weights adds and folds their correction
+    into the BN shifts (`SFBase.calibrate_weight_rounding`): features within 1e-3 of the fp32 reference's instead of
+    3e-3 (tests/test_gpu_parity_full.py; spread over clips and under a calibration / evaluation distribution shift:
+    profiles/parity_eval.json), at no cost per forward.  Calibration must precede any hipGraph capture of the eval
+    forward: a captured graph keeps the fold tensors it was recorded with."""
     from . import checkpoint, synth_data
     from .extended_config import get_cfg
     from .mdl_selector import get_mdl_loss_eval
@@ -120,16 +124,19 @@ def main(mdl_resume_path: str, mdl_name_used: str, is_cu: bool = False, splits=(
         if got is None:
             raise FileNotFoundError(mdl_resume_path)
     mdl = mdl.to(torch.device("cuda")).eval()
-    if int(calibrate) > 0 and hasattr(mdl, "calibrate_weight_rounding"):
-        cal = synth_data.synth_batch(cfg, comm, bs=int(calibrate), n_ev=1, seed=cfg.synth.seed + 999_983,
-                                     device=torch.device("cuda"), dtype=torch.bfloat16)
-        n_cal = mdl.calibrate_weight_rounding(cal)
-        print(f"weight-rounding correction calibrated on {int(calibrate)} clip(s): {n_cal} convolutions")
     feat_ext, written = FeatExtract(cfg), []
     n = int(n_videos) if n_videos is not None else int(cfg.synth.num_videos)
     for si, split in enumerate(splits):
         ds = SynthFrameDataset(cfg, comm, n, n_ev=cfg.ds.vsitu.num_ev, seed=cfg.synth.seed + 1000 * si,
                                names=[f"{split}_v{i:05d}_seg_0-10" for i in range(n)])
+        if si == 0 and int(calibrate) > 0 and hasattr(mdl, "calibrate_weight_rounding"):
+            n_vid = min(int(calibrate), len(ds))
+            cal = next(iter(SimpleLoader(ds, n_vid)))
+            cal = {k: (v.to(device="cuda", dtype=torch.bfloat16) if v.is_floating_point() else v.to("cuda"))
+                   for k, v in cal.items()}
+            n_cal = mdl.calibrate_weight_rounding(cal)
+            print(f"weight-rounding correction calibrated on the first {n_vid} video(s) of split {split!r}: "
+                  f"{n_cal} convolutions")
         feat_ext.set_mdl_dl(mdl, SimpleLoader(ds, max(1, int(cfg.train.bsv))), mdl_name=mdl_name_used, split_name=split)
         written += feat_ext.forward_all()
     print(f"wrote {len(written)} feature files under {feat_ext.out_tdir}")

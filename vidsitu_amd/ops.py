@@ -1515,5 +1515,6 @@ def colsum_bf16(x, out=None):
     """Per-channel sum of a channels-last bf16 activation -> f32 [C] (conv bias gradient)."""
     n, c, t, h, w = x.shape
     out = torch.empty(c, dtype=torch.float32, device=x.device) if out is None else out
-    _lib.call("vs_colsum_bf16", _ptr(x), _ptr(out), n * t * h * w, c, act_ld(x), _stream())
+    ld = act_ld4(x) if c == 4 else act_ld(x)  # (the stems' packed C = 4 input)
+    _lib.call("vs_colsum_bf16", _ptr(x), _ptr(out), n * t * h * w, c, ld, _stream())
     return out

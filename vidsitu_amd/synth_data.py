@@ -87,6 +87,35 @@ def synth_u8_batch(cfg, comm, bs, n_ev=5, seed=1234, device="cpu", crop=None):
     }
 
 
+def synth_video_u8_batch(cfg, comm, bs, n_ev=5, seed=1234, device="cpu", crop=None):
+    """uint8 frames with the statistics of decoded video rather than of noise (the calibration-robustness test and
+    `feat_extractor`'s stand-in dataset): a spatially and temporally low-pass colour field (coarse noise, trilinear
+    upsampling: neighbouring pixels and frames are strongly correlated), per-VIDEO brightness and contrast (events of a
+    video share them, videos differ), a little sensor noise, clipped to 0..255.  Same dict as `synth_u8_batch`."""
+    import torch.nn.functional as F
+
+    sf = cfg.sf_mdl
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    t = sf.DATA.NUM_FRAMES
+    hw = crop or sf.DATA.TRAIN_CROP_SIZE
+    coarse = torch.randn(bs * n_ev, 3, max(2, t // 8), max(2, hw // 16), max(2, hw // 16), generator=g)
+    mid = torch.randn(bs * n_ev, 3, max(2, t // 4), max(2, hw // 4), max(2, hw // 4), generator=g)
+    field = (F.interpolate(coarse, size=(t, hw, hw), mode="trilinear", align_corners=False)
+             + 0.35 * F.interpolate(mid, size=(t, hw, hw), mode="trilinear", align_corners=False))
+    field = (field / field.std()).view(bs, n_ev, 3, t, hw, hw)                # unit spread: `contrast` is in grey levels
+    bright = 60.0 + 120.0 * torch.rand(bs, 1, 1, 1, 1, 1, generator=g)        # per video
+    tint = 12.0 * torch.randn(bs, 1, 3, 1, 1, 1, generator=g)                 # per video and colour channel
+    contrast = 25.0 + 55.0 * torch.rand(bs, 1, 1, 1, 1, 1, generator=g)       # per video
+    noise = 3.0 * torch.randn(bs, n_ev, 3, t, hw, hw, generator=g)
+    img = (bright + tint + contrast * field + noise).round().clamp_(0, 255).to(torch.uint8)
+    fr = img.permute(0, 1, 3, 4, 5, 2).contiguous()                           # [B, E, T, H, W, 3]
+    return {
+        "frms_ev_fast_u8": fr.to(device),
+        "vseg_idx": torch.arange(bs, dtype=torch.long, device=device),
+        "label_tensor": torch.randint(0, len(comm.vb_id_vocab), (bs, n_ev), generator=g).to(device),
+    }
+
+
 def reference_tensors(batch_u8, cfg, comm):
     """uint8 frames -> the reference's fp32 batch tensors, same operation order as
     `tensor_normalize` (`utils/video_utils.py:147-164`) and `pack_pathway_output` (:41-74)."""

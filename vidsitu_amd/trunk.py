@@ -259,9 +259,16 @@ class _Unit:
         so the means are those of the corrected path.  Host-side bookkeeping on [Cout, Cin] tensors; the activation
         means come from vs_colsum_bf16."""
         with torch.no_grad():
-            mu = ops.colsum_bf16(x) / float(ops.act_rows(x))  # [Cin]
             w = conv.weight.detach()
-            dw = (conv.w_bf16[:, : conv.cin].float() - w).sum(dim=(2, 3, 4))  # [Cout, Cin]
+            if conv.is_stem:
+                # (round 6) the stems too: decoded frames are not zero-mean per video the way N(0,1) noise is -- a video's
+                # brightness puts a channel mean of up to +-1 on the normalised input.  x = the packed C = 4 input
+                x = x[0]
+                mu = (ops.colsum_bf16(x) / float(ops.act_rows(x)))[: conv.cin]
+                dw = (w.to(torch.bfloat16).float() - w).sum(dim=(2, 3, 4))  # [Cout, 3]
+            else:
+                mu = ops.colsum_bf16(x) / float(ops.act_rows(x))  # [Cin]
+                dw = (conv.w_bf16[:, : conv.cin].float() - w).sum(dim=(2, 3, 4))  # [Cout, Cin]
             bn.wround_bias = (dw * mu.view(1, -1)).sum(dim=1)
             sc, sh = bn.fold_raw
             bn.fold = (sc, sh - sc * bn.wround_bias)
@@ -281,7 +288,7 @@ class _Unit:
         `residual_affine` = that pair: its apply pass forms the shortcut's normalised output on the fly (ops.bn_apply2,
         bitwise the two passes)."""
         if not train:
-            if _Unit.calib is not None and not conv.is_stem and conv.cin_pad == conv.cin:
+            if _Unit.calib is not None and (conv.is_stem or conv.cin_pad == conv.cin):
                 _Unit._calibrate(conv, bn, x)
             scale, shift = bn.fold
             if conv.bias is not None:  # BN(conv + b) folded: the bias joins the shift
@@ -662,18 +669,19 @@ class ResBlock(nn.Module):
         # that wins: wide, few-position blocks (slow res3 - res5 at 8 clips per GPU: 60-140 us per block instead of
         # 85-170 as three or four launches + their slab reduces; tools/wgrad_group_time.py)
         sink = [] if self._wgrad_grouped(rc, rb, ra, saved[-1] if (self.has_sc and saved) else None, dout) else None
-        try:
-            return self._bwd_units(saved, dout, chain, rc, rb, ra, sink)
-        finally:
-            if sink:
-                items = [(dy, x, c.k, c.s, c.p, c.weight.grad) for dy, x, c in sink]
-                if carry is None:
-                    ops.conv_wgrad_group(items)
-                else:
-                    carry["items"] += items
-                    carry["blocks"] += 1
-                    if carry["blocks"] >= ResBlock.group_span or len(carry["items"]) + 4 > ops.WGRAD_GROUP_MAX:
-                        ResBlock.flush_wgrads(carry)
+        # (normal path only: when a unit's backward raises, the half-filled sink is dropped with the exception -- a
+        #  grouped launch from it could only mask the original error)
+        res = self._bwd_units(saved, dout, chain, rc, rb, ra, sink)
+        if sink:
+            items = [(dy, x, c.k, c.s, c.p, c.weight.grad) for dy, x, c in sink]
+            if carry is None:
+                ops.conv_wgrad_group(items)
+            else:
+                carry["items"] += items
+                carry["blocks"] += 1
+                if carry["blocks"] >= ResBlock.group_span or len(carry["items"]) + 4 > ops.WGRAD_GROUP_MAX:
+                    ResBlock.flush_wgrads(carry)
+        return res
 
     @staticmethod
     def flush_wgrads(carry):
@@ -1183,8 +1191,9 @@ class VideoTrunk(nn.Module):
     def calibrate_weight_rounding(self, x):
         """Eval-mode bias correction for the bf16 rounding of the convolution weights (north_star: "logits within 1e-3
         of reference" on the arithmetic that is timed).  x: calibration clips, a list like forward_features' input --
-        NOT the clips that are evaluated.  One eval forward pass in which every convolution (the two Cin = 3 stems
-        excepted: normalised frames have no channel mean to speak of) measures its input's channel means and stores
+        NOT the clips that are evaluated, but clips OF THE SAME DISTRIBUTION (a calibration on other data is a bias, not a
+        correction: profiles/parity_eval.json "robustness").  One eval forward pass in which every convolution (since
+        round 6 the two Cin = 3 stems too: a video's brightness is a channel mean) measures its input's channel means and stores
         the per-channel constant its weight rounding adds (`BN3dP.wround_bias`); from then on the folded BN shift of
         every eval forward carries the correction -- no launch, byte or FLOP more per forward.  Measured on one
         224^2 SlowFast-R50 clip (tools/bias_correction_probe.py, CPU oracle: the weight-rounding error of the logits
@@ -1257,6 +1266,15 @@ class VideoTrunk(nn.Module):
         # dropped, was re-used by the slow pathway while the fast stem's wgrad was still reading
         # it: caught by test_hipgraph_two_stream_step_is_bitwise_the_one_stream_eager_step)
         par = self._fork_ctx(dev)
+        s1_buf = None
+        if self.multi:  # (the s1 concat buffer: before the fork, for the reason given at the stage loop below)
+            st0 = self.s1.pathway0_stem
+            sh0 = (tuple(inputs[0].shape) if inputs[0].dtype != torch.uint8 else
+                   (inputs[0].shape[0], 3, int(self._slow_index(inputs[0].shape[1], dev).numel()), inputs[0].shape[2],
+                    inputs[0].shape[3]))
+            ho0, wo0 = (sh0[3] + 6 - 7) // 2 + 1, (sh0[4] + 6 - 7) // 2 + 1
+            s1_buf = ops.new_act(sh0[0], st0.conv.cout + self.s1_fuse.conv_f2s.cout, sh0[2],
+                                 (ho0 + 2 - 3) // 2 + 1, (wo0 + 2 - 3) // 2 + 1, dev)
         par.fork()
         if inputs[0].dtype == torch.uint8:
             # uint8 frames [N, T, H, W, 3] (what the loader's PIL step produces): normalise, pack and
@@ -1291,8 +1309,8 @@ class VideoTrunk(nn.Module):
             c = stem.conv.cout
             with par.on(p):  # allocate on the stream that writes the buffer first
                 if self.multi and p == 0:
-                    cf = self.s1_fuse.conv_f2s.cout
-                    buf = ops.new_act(n, c + cf, t, hp, wp, dev)
+                    buf = s1_buf
+                    assert tuple(buf.shape) == (n, c + self.s1_fuse.conv_f2s.cout, t, hp, wp)
                     out = ops.channel_slice(buf, 0, c)
                 else:
                     buf = out = ops.new_act(n, c, t, hp, wp, dev)
@@ -1310,6 +1328,18 @@ class VideoTrunk(nn.Module):
             stage = getattr(self, f"s{k}")
             fuse = getattr(self, f"s{k}_fuse", None) if self.multi else None
             nxt = []
+            buf = None
+            if fuse is not None:
+                # The slow pathway's concat buffer [stage output | lateral connection] is allocated BEFORE the fork: the
+                # lateral convolution writes its slice from the fast pathway's stream, which is ordered behind the
+                # caller's stream only up to the fork.  Allocated inside the stage (round 5 and before), the buffer could
+                # land in memory an intermediate tensor of THIS stage had just been freed from on the host while its
+                # readers were still queued on the slow pathway's stream -- and the lateral write overtook them whenever
+                # the GPU ran behind the host (found in round 6: the first eval forward after a two-clip calibration pass
+                # differed from every later one; bit-identical with a synchronisation in between).
+                b0 = stage.blocks(0)[0].branch2.b
+                ys = ops.conv_out_shape(cur[0].shape, stage.couts[0], (1, 1, 1), (1, b0.s[1], b0.s[2]), (0, 0, 0))
+                buf = ops.new_act(ys[0], ys[1] + fuse.conv_f2s.cout, ys[2], ys[3], ys[4], dev)
             par.fork()
             for p in range(P):
               with par.on(p):
@@ -1317,15 +1347,8 @@ class VideoTrunk(nn.Module):
                 blocks = stage.blocks(p)
                 for i, blk in enumerate(blocks):
                     last = i == len(blocks) - 1
-                    out = None
                     if last and fuse is not None and p == 0:
-                        ys = ops.conv_out_shape(x.shape, stage.couts[0], (1, 1, 1),
-                                                (1, blk.branch2.b.s[1], blk.branch2.b.s[2]),
-                                                (0, 0, 0))
-                        cf = fuse.conv_f2s.cout
-                        buf = ops.new_act(ys[0], ys[1] + cf, ys[2], ys[3], ys[4], dev)
-                        out = ops.channel_slice(buf, 0, ys[1])
-                        blk.fwd(x, out, train, saved)
+                        blk.fwd(x, ops.channel_slice(buf, 0, ys[1]), train, saved)
                         x = buf
                     else:
                         x = blk.fwd(x, None, train, saved)
