@@ -52,6 +52,11 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvP p, HaloGeo q) {
   static_assert((D - 2) * LB + LA <= 63 && D >= 3, "vmcnt range");
 
   const int tid = threadIdx.x;
+  [[maybe_unused]] VsStamp vst;  // (diagnostic build: wave 0, a compute wave, stamps the block's phases; conv_tile.h)
+#ifdef VS_STAMP
+  for (int i_ = 0; i_ < 8; ++i_) vst.t[i_] = 0ull;
+#endif
+  VS_ST(vst, 0);
   int swz;
   {
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -112,6 +117,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvP p, HaloGeo q) {
     abase[r] = ab;
   }
   __syncthreads();
+  VS_ST(vst, 1);
 
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int taps = q.k1 * q.k2;
@@ -285,6 +291,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvP p, HaloGeo q) {
     };
     const char* Bring = smem + 2 * ABYTES;
     __builtin_amdgcn_s_barrier();  // image 0 and tile 0 landed
+    VS_ST(vst, 2);
     loadA(smem, aaddr[0], 0u, fa0);
     loadB(Bring, 0u, fb0);
     int slot = 0;
@@ -314,6 +321,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvP p, HaloGeo q) {
     }
   } else {
   __builtin_amdgcn_s_barrier();  // image 0 and tile 0 landed
+  VS_ST(vst, 2);
   load_frags(0, 0, tap_offset(), 0, fa0, fb0);
   int c = 0, tp = 0, slot = 0;
   for (int s = 0; s < nsteps; ++s) {
@@ -331,6 +339,10 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvP p, HaloGeo q) {
     __builtin_amdgcn_sched_barrier(0);
   }
   }
+  VS_ST(vst, 3);
+#ifdef VS_STAMP
+  vst.t[7] = (unsigned long long)nsteps;
+#endif
   // rows of the tile that map to no output position accumulated whatever their (clamped) image rows held:
   // zero them so that the batch-statistic partials of the epilogue see only real rows
 #pragma unroll
@@ -343,7 +355,14 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvP p, HaloGeo q) {
       }
   __builtin_amdgcn_s_barrier();  // the loaders' run-ahead copies have landed (they exit behind this barrier)
 
-  conv_tile_epilogue<BM, BN, 2, 2, BNB>(p, acc, smem, statbuf, tm, n0, [&](int row) { return orow[row]; });
+#ifdef VS_STAMP
+  VsStamp* const stp_ = &vst;
+#else
+  VsStamp* const stp_ = nullptr;
+#endif
+  conv_tile_epilogue<BM, BN, 2, 2, BNB>(p, acc, smem, statbuf, tm, n0, [&](int row) { return orow[row]; }, stp_);
+  VS_ST(vst, 6);
+  VS_ST_FLUSH(p, blockIdx.x, vst);
 }
 
 // ------------------------------ host side ------------------------------------

@@ -59,6 +59,11 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, c
   static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile");
 
   const int tid = threadIdx.x;
+  [[maybe_unused]] VsStamp vst;
+#ifdef VS_STAMP
+  for (int i_ = 0; i_ < 8; ++i_) vst.t[i_] = 0ull;
+#endif
+  VS_ST(vst, 0);
   // XCD-aware remap: blocks b, b+8, ... share an XCD (speed only); give each
   // XCD a contiguous run of tiles so neighbouring N-tiles re-read A from its L2.
   int swz;
@@ -177,14 +182,14 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, c
   // ~40-instruction integer divisions per row
   const bool small_rows = Mloc < (1 << 24);
   const float rcpW = 1.0f / (float)cW, rcpH = 1.0f / (float)cH, rcpT = 1.0f / (float)cT;
-#pragma unroll
-  for (int i = 0; i < AI; ++i) {
-    const int m = m0 + lrow + 32 * i;
-    rT[i] = rH[i] = rW[i] = -(1 << 20);
-    rbase[i] = -1;
-    roff[i] = VS_OOB;
-    vmask[i] = 0u;
-    if (MODE == 2 && kc == 0) rowpos[lrow + 32 * i] = -1;
+  // One row's state: position decode, base byte offset, bitmask of valid taps (FAST), rowpos (MODE 2).
+  auto decode_row = [&](const int m, const int slot, const bool write_rowpos, int& oT, int& oH, int& oW, long long& obase,
+                        unsigned& ooff, unsigned& omask) __attribute__((always_inline)) {
+    oT = oH = oW = -(1 << 20);
+    obase = -1;
+    ooff = VS_OOB;
+    omask = 0u;
+    if (MODE == 2 && write_rowpos) rowpos[slot] = -1;
     if (m < Mloc) {
       int rw, t1, rh, t2, rt, n;
       if (MODE == 0 && p.dense) {  // rows are consecutive positions of the gathered tensor: nothing to decode
@@ -201,25 +206,25 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, c
       rw = r0W + stW * rw;  // (identity unless the tile belongs to a stride class)
       rh = r0H + stH * rh;
       rt = r0T + stT * rt;
-      if (MODE == 2 && kc == 0)
-        rowpos[lrow + 32 * i] = ((n * p.Rt + rt) * p.Rh + rh) * p.Rw + rw;
+      if (MODE == 2 && write_rowpos)
+        rowpos[slot] = ((n * p.Rt + rt) * p.Rh + rh) * p.Rw + rw;
       if (MODE == 0) {
         const long long pos = p.dense ? (long long)m :
             ((long long)(n * p.Gt + rt * p.mulT) * p.Gh + rh * p.mulH) * p.Gw + rw * p.mulW;
-        rbase[i] = pos * p.g_ld;
-        roff[i] = (unsigned)(pos * p.g_ld * 2);
-        vmask[i] = 1u;
+        obase = pos * p.g_ld;
+        ooff = (unsigned)(pos * p.g_ld * 2);
+        omask = 1u;
       } else {
         const int ct = rt * p.mulT + p.offT, ch = rh * p.mulH + p.offH, cw = rw * p.mulW + p.offW;
-        rbase[i] = (long long)n * p.Gt * p.Gh * p.Gw;
-        rT[i] = ct;
-        rH[i] = ch;
-        rW[i] = cw;
+        obase = (long long)n * p.Gt * p.Gh * p.Gw;
+        oT = ct;
+        oH = ch;
+        oW = cw;
         if (FAST) {
           long long pos0;
-          if (MODE == 1) pos0 = rbase[i] + ((long long)ct * p.Gh + ch) * p.Gw + cw;
-          else pos0 = rbase[i] + ((long long)(ct >> p.shT) * p.Gh + (ch >> p.shH)) * p.Gw + (cw >> p.shW);
-          roff[i] = (unsigned)(pos0 * p.g_ld * 2);  // exact modulo 2^32 whenever the tap is valid
+          if (MODE == 1) pos0 = obase + ((long long)ct * p.Gh + ch) * p.Gw + cw;
+          else pos0 = obase + ((long long)(ct >> p.shT) * p.Gh + (ch >> p.shH)) * p.Gw + (cw >> p.shW);
+          ooff = (unsigned)(pos0 * p.g_ld * 2);  // exact modulo 2^32 whenever the tap is valid
           // per-axis validity first (kT + kH + kW tests), then one AND per tap
           auto axis_mask = [&](int c, int kk, int sh, int G) {
             unsigned mm = 0u;
@@ -245,10 +250,39 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, c
               mk |= (th ? mw : 0u) << tap;
               tap += p.kW;
             }
-          vmask[i] = mk;
+          omask = mk;
         }
       }
     }
+  };
+  // Round 6 (profiles/r06_launch_anatomy.txt): the eight threads that fetch the eight 16-byte units of a row all
+  // decoded that row, AI rows each -- 2.9-4.2 us of prologue in front of a 9-19 us block on the multi-tap layers
+  // (1.0 us on a pointwise one).  The gathering launches now decode ONE row per thread into an LDS table (aliased
+  // on the statistic rows, which only the epilogue uses) and every thread picks up its AI entries behind the barrier
+  // the k-table needs anyway: AI x fewer decode instructions per wave, same integers.
+  constexpr bool ROWTAB = FAST && !AOL && BM <= 256;
+  static_assert(8 * WM * BN * 4 >= BM * 8, "the row table fits the statistic rows it is aliased on");
+  const bool use_rowtab = ROWTAB && !(MODE == 0 && p.dense);
+  uint2* rowtab = (uint2*)statbuf;  // [BM] (roff, vmask)
+  if (use_rowtab) {
+    if (tid < BM) {
+      int t_, h_, w_;
+      long long b_;
+      unsigned o_, k_;
+      decode_row(m0 + tid, tid, true, t_, h_, w_, b_, o_, k_);
+      rowtab[tid] = make_uint2(o_, k_);
+    }
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {  // (filled behind the barrier below)
+      rT[i] = rH[i] = rW[i] = 0;
+      rbase[i] = -1;
+      roff[i] = VS_OOB;
+      vmask[i] = 0u;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+      decode_row(m0 + lrow + 32 * i, lrow + 32 * i, kc == 0, rT[i], rH[i], rW[i], rbase[i], roff[i], vmask[i]);
   }
   // weight rows of this thread (byte offsets; OOB beyond Ncols)
   unsigned boff[BJ];
@@ -448,7 +482,21 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, c
     kbeg = (int)((unsigned)(nk_all * ksplit) / (unsigned)p.splitK);
     nk = (int)((unsigned)(nk_all * (ksplit + 1)) / (unsigned)p.splitK) - kbeg;
   }
-  __syncthreads();  // ktab visible
+  __syncthreads();  // ktab (and the row table) visible
+  if (use_rowtab) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const uint2 e = rowtab[lrow + 32 * i];
+      roff[i] = e.x;
+      vmask[i] = e.y;
+    }
+    // (the epilogue's first statistic writes come behind the main loop's barriers: no reader of the table is left by then)
+  }
+  VS_ST(vst, 1);
+#ifdef VS_STAMP
+  vst.t[7] = (unsigned long long)nk;
+  unsigned long long vs_first = ~0ull;
+#endif
   if constexpr (NS > 0) {
     // LDS-DMA ring.  One wave-instruction copies 64 x 16 B = eight 128-byte tile rows straight
     // into LDS (destination = wave-uniform base + lane * 16, no VGPRs, no ds_write); the XOR
@@ -516,6 +564,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, c
       asm volatile("s_waitcnt vmcnt(%0)" ::"i"((D - 1) * L) : "memory");  // my part of tile kt landed
       __builtin_amdgcn_s_barrier();  // everyone's did; stage st_l (tile kt-1) is no longer read
       __builtin_amdgcn_sched_barrier(0);
+#ifdef VS_STAMP
+      { const unsigned long long now_ = vs_now(); vs_first = now_ < vs_first ? now_ : vs_first; }  // (branch-free: the first k-step's)
+#endif
       // (one straight-line body: a second, "fragment reads first" order of this step lived here behind a run-time
       //  switch until round 4 -- measured useless in round 2 (profiles/r02_ring_frags_first.txt), and its mere presence
       //  made hipcc move all 64 accumulator registers at the top of every k-step)
@@ -530,6 +581,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, c
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // run-ahead tiles (never read) before LDS reuse
     __syncthreads();
+#ifdef VS_STAMP
+    vst.t[2] = vs_first;
+#endif
   } else {
   // Software pipeline, prefetch distance 2: while tile kt is multiplied, tile kt+1 sits in one
   // register set (loaded during step kt-1, written to LDS at the end of step kt) and the loads
@@ -541,6 +595,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, c
   sstore(0, ra0, rb0);
   gload(kbeg + 1, ra1, rb1);
   __syncthreads();
+  VS_ST(vst, 2);
   int kt = 0;
   for (; kt + 2 < nk; kt += 2) {
     gload(kbeg + kt + 2, ra0, rb0);
@@ -566,6 +621,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, c
   __syncthreads();
   }
 
+  VS_ST(vst, 3);
   bool in_launch = false;
   if constexpr (NS >= 2 && !AOL) {
     if (p.splitK > 1 && p.sk_cnt != nullptr) {
@@ -650,9 +706,16 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& p, const int blk, c
   }
 
   // ---------------- epilogue ----------------
+#ifdef VS_STAMP
+  VsStamp* const stp_ = &vst;
+#else
+  VsStamp* const stp_ = nullptr;
+#endif
   conv_tile_epilogue<BM, BN, WM, WN, BNB, false, BNB2>(p, acc, smem, statbuf, tm, n0, [&](int row) {
     return (MODE == 2) ? rowpos[row] : (m0 + row < p.M ? m0 + row : -1);
-  });
+  }, stp_);
+  VS_ST(vst, 6);
+  VS_ST_FLUSH(p, blk, vst);
 }
 
 template <int BM, int BN, int WM, int WN, int MODE, bool FAST, int DBG = 0, int NS = 0, bool BNB = false,
@@ -1770,7 +1833,19 @@ static int check_desc(const vs_conv_desc* d) {
 static int fill_dgrad_params(ConvP& p, const vs_conv_desc* d);
 
 // ConvP of a forward launch (everything but the tensor pointers and byte extents); returns the kernel MODE.
+#ifdef VS_STAMP
+static unsigned long long* g_vs_stamp = nullptr;
+// diagnostic build only: every later convolution launch stamps its blocks' phases into buf[block][8] (NULL: off)
+extern "C" int vs_stamp_attach(void* buf) {
+  g_vs_stamp = (unsigned long long*)buf;
+  return VS_OK;
+}
+#endif
+
 static int fill_fwd_params(ConvP& p, const vs_conv_desc* d) {
+#ifdef VS_STAMP
+  p.stamp = g_vs_stamp;
+#endif
   p.x = p.w = nullptr;
   p.y = nullptr;
   p.scale = p.shift = nullptr;
@@ -2024,6 +2099,9 @@ extern "C" int vs_conv_fwd_bc(const void* x, const void* w_b, const vs_conv_desc
 static int fill_dgrad_params(ConvP& p, const vs_conv_desc* d) {
   const int shT = ilog2_exact(d->sT), shH = ilog2_exact(d->sH), shW = ilog2_exact(d->sW);
   if (shT < 0 || shH < 0 || shW < 0) return -1;
+#ifdef VS_STAMP
+  p.stamp = g_vs_stamp;
+#endif
   p.scale = p.shift = nullptr;
   p.stats = nullptr;
   p.bny = nullptr;

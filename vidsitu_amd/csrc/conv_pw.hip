@@ -51,6 +51,13 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(ConvP p, PwGeo g) {
   const int wm = wave / WN, wn = wave % WN;
   const int lr = lane & 15, lq = lane >> 4;
   const int kc = tid & 7, lrow = tid >> 3;
+  [[maybe_unused]] VsStamp vst;  // (diagnostic build, conv_tile.h; a persistent block: 2 = its first chunk landed, 3 / 4 / 5 = the FIRST
+                //  tile's loop / staging / stores, 7 = tiles of the block)
+#ifdef VS_STAMP
+  for (int i_ = 0; i_ < 8; ++i_) vst.t[i_] = 0ull;
+  unsigned long long vs_first = ~0ull, vs_loop = ~0ull;
+#endif
+  VS_ST(vst, 0);
 
   // block -> (XCD, weight slice, tile list): the nsl blocks of one tile list are consecutive on one XCD
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -141,6 +148,10 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(ConvP p, PwGeo g) {
     }
   };
   for (int d = 0; d < D; ++d) issue(d);
+  VS_ST(vst, 1);
+#ifdef VS_STAMP
+  vst.t[7] = (unsigned long long)ntl;
+#endif
 
   f32x4 acc[MR][NR];
   int m0c = 0;  // first row of the tile `compute` works on (AOL)
@@ -187,6 +198,9 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(ConvP p, PwGeo g) {
       if (!(g.dbg & 16)) pw_wait_vm(nwait);  // my part of this chunk (and, the first time, of the weight slice) landed
       if (!(g.dbg & 32)) __builtin_amdgcn_s_barrier();  // everyone's did; slot st_l (the previous chunk) is no longer read
       __builtin_amdgcn_sched_barrier(0);
+#ifdef VS_STAMP
+      { const unsigned long long now_ = vs_now(); vs_first = now_ < vs_first ? now_ : vs_first; }
+#endif
       if (!(g.dbg & 8)) issue(st_l);
       __builtin_amdgcn_sched_barrier(0);
       if (!(g.dbg & 4)) compute(st_c, kch);
@@ -201,11 +215,23 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(ConvP p, PwGeo g) {
       if (acc[0][0][0] == 123.456f) epi[tid] = 1;  // keep the accumulators alive
       continue;
     }
+#ifdef VS_STAMP
+    { const unsigned long long now_ = vs_now(); vs_loop = now_ < vs_loop ? now_ : vs_loop; }
+    VsStamp* const stp_ = ti == 0 ? &vst : nullptr;
+#else
+    VsStamp* const stp_ = nullptr;
+#endif
     conv_tile_epilogue<BM, BN, WM, WN, BNB, true, false, EDBG>(p, acc, epi, statbuf, tm, n0, [&](int row) {
       return (m0 + row < p.M && !(g.dbg & 1)) ? m0 + row : -1;
-    });
+    }, stp_);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // run-ahead copies (never read) before the block retires
+#ifdef VS_STAMP
+  vst.t[2] = vs_first;
+  vst.t[3] = vs_loop;
+#endif
+  VS_ST(vst, 6);
+  VS_ST_FLUSH(p, blockIdx.x, vst);
 }
 
 // ------------------------------ host side ------------------------------------

@@ -71,8 +71,40 @@ struct ConvP {
   // bit, formed on the A fragments after their LDS read.  NULL: x is used as it is.
   const float* in_scale;
   const float* in_shift;
+#ifdef VS_STAMP
+  unsigned long long* stamp;  // diagnostic build only (tools/launch_anatomy.py): [block][8] s_memrealtime stamps, or NULL
+#endif
 };
 #define VS_CONV_BNBWD (1 << 20)
+
+// ---- launch anatomy (diagnostic build, -DVS_STAMP; the shipped library holds none of this) -------------------------
+// Phase stamps of a block, read with s_memrealtime (the 100 MHz clock every CU shares, so that block starts and ends
+// line up across the chip), kept in scalar registers and stored by lane 0 of wave 0 at the very end -- no store, hence
+// no vmcnt traffic, between the phases.  Indices: 0 block start, 1 tables / descriptors ready, 2 first tile landed in
+// LDS, 3 main loop done, 4 epilogue staged, 5 last store issued, 6 block end, 7 = k-steps of the block.
+#ifdef VS_STAMP
+struct VsStamp { unsigned long long t[8]; };
+__device__ __forceinline__ unsigned long long vs_now() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define VS_ST(st, i) ((st).t[i] = vs_now())
+#define VS_STP(stp, i) do { if (stp) (stp)->t[i] = vs_now(); } while (0)
+#define VS_ST_FLUSH(p, blk, st)                                                             \
+  do {                                                                                      \
+    if (threadIdx.x == 0 && (p).stamp) {                                                    \
+      for (int i_ = 0; i_ < 8; ++i_) (p).stamp[(long long)(blk) * 8 + i_] = (st).t[i_];     \
+    }                                                                                       \
+  } while (0)
+#else
+struct VsStamp {};
+#define VS_ST(st, i) do {} while (0)
+#define VS_STP(stp, i) do {} while (0)
+#define VS_ST_FLUSH(p, blk, st) do {} while (0)
+#endif
 
 #define VS_OOB 0x80000000u  // byte offset beyond any tensor: buffer_load returns zeros
 
@@ -119,7 +151,8 @@ __device__ __forceinline__ uint4 ld_res16(const uint16_t* q) {
 
 template <int BM, int BN, int WM, int WN, bool BNB, bool RAWSYNC = false, bool TWO = false, int EDBG = 0, typename RowMap>
 __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16],
-                                                   char* smem, float* statbuf, int tm, int n0, RowMap rowm) {
+                                                   char* smem, float* statbuf, int tm, int n0, RowMap rowm,
+                                                   VsStamp* stp = nullptr) {
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MR = TM / 16, NR = TN / 16;
   const int tid = threadIdx.x;
@@ -196,6 +229,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
     }
     }
     tile_sync<RAWSYNC>();
+    VS_STP(stp, 4);
     if constexpr (BNB) {
       // copy-out + the consumer BN's backward sums: thread = one 8-channel column x (256 / CPR) row
       // lanes; the saved conv outputs of all its rows are requested before the first use
@@ -300,6 +334,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
         }
     }
     tile_sync<RAWSYNC>();
+    VS_STP(stp, 4);
     if constexpr (BNB) {
       // residual add + copy-out + the consumer BN's backward sums (ReLU mask from the unit's bit mask):
       // same thread layout as the no-residual variant above
@@ -447,6 +482,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x4 (&acc)[
     }
     }
   }
+  VS_STP(stp, 5);
   if ((p.flags & VS_CONV_STATS) && tid < BN && n0 + tid < p.Ncols) {
     float s = 0.f, q = 0.f;
 #pragma unroll
