@@ -74,14 +74,20 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvP p, HaloGeo q) {
 
   // ---- tables (every row decoded once per block) ----
   const int ipg = q.D1 * q.D2, opg = q.O1 * q.O2p;
+  // (round 6, profiles/r06_launch_anatomy.txt: this decode was ~1.0-1.2 us of every block -- six run-time integer
+  //  divisions per row; every operand is far below 2^24, so the float-reciprocal split of common.h is exact)
+  const float rcp_ipg = 1.0f / (float)ipg, rcp_D2 = 1.0f / (float)q.D2, rcp_per = 1.0f / (float)q.per,
+              rcp_opg = 1.0f / (float)opg, rcp_O2p = 1.0f / (float)q.O2p;
   for (int j = tid; j < HALO_RA_MAX; j += 512) {
     unsigned off = VS_OOB;
     if (j < q.RA) {
-      const int g = j / ipg, rem = j - g * ipg;
-      const int i1 = rem / q.D2, i2 = rem - i1 * q.D2;
+      int g, rem, i1, i2;
+      fast_divmod(j, ipg, rcp_ipg, g, rem);
+      fast_divmod(rem, q.D2, rcp_D2, i1, i2);
       const int gg = tm * q.G + g;
       if (gg < q.ngroups) {
-        const int hi = gg / q.per, lo = gg - hi * q.per;
+        int hi, lo;
+        fast_divmod(gg, q.per, rcp_per, hi, lo);
         long long pos = -1;
         if (q.kind == 0) {  // hi = clip, lo = spatial chunk
           const int t = i1 - q.p1, sp = lo * q.O2 + i2;
@@ -98,12 +104,14 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(ConvP p, HaloGeo q) {
   for (int r = tid; r < BM; r += 512) {
     int m = -1, ab = 0;
     if (r < q.rows) {
-      const int g = r / opg, rem = r - g * opg;
-      const int o1 = rem / q.O2p, o2 = rem - o1 * q.O2p;  // o2 >= O2: padding lanes of a 16-aligned line
+      int g, rem, o1, o2;  // o2 >= O2: padding lanes of a 16-aligned line
+      fast_divmod(r, opg, rcp_opg, g, rem);
+      fast_divmod(rem, q.O2p, rcp_O2p, o1, o2);
       const int gg = tm * q.G + g;
       ab = (g * q.D1 + o1) * q.D2 + o2;
       if (gg < q.ngroups && o2 < q.O2) {
-        const int hi = gg / q.per, lo = gg - hi * q.per;
+        int hi, lo;
+        fast_divmod(gg, q.per, rcp_per, hi, lo);
         if (q.kind == 0) {
           const int sp = lo * q.O2 + o2;
           if (sp < q.HW) m = (hi * q.T + o1) * q.HW + sp;
