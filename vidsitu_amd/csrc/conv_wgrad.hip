@@ -799,16 +799,58 @@ __global__ __launch_bounds__(512) void conv_wgrad_deep_kernel(WgradP p) {
 // (+ their reduces).  Same body, same summation order per problem for a given split count.
 // ---------------------------------------------------------------------------------------------
 #define WGG_MAX 20
+// Jobs (round 6, opt-in: VS_WGG_JOBS=1): a job = the output tiles of ONE position split of ONE problem -- blocks that
+// stream the same dY / x rows.  Block b runs on XCD b % 8 (round-robin dispatch); the sequence of all jobs' tiles is
+// cut into chunks of 32 (one residency round of one XCD) and chunk c is round c / 8 of XCD c % 8, so the blocks that
+// re-read a slab sit on ONE L2 at the same time instead of on eight.  With the default mapping (problem ranges back
+// to back, a split's tiles on consecutive blocks = on eight different XCDs) a grouped launch fetches 2x the bytes
+// from beyond L2 -- and takes the same time (see the switch in vs_conv_wgrad_group).
+#define WGG_JOBS 16  // table entries per XCD
 struct WgGroupP {
   int n;
   int first[WGG_MAX + 1];  // block range of problem j starts at first[j] (a multiple of 8 with the XCD order) ...
   int count[WGG_MAX];      // ... and holds count[j] blocks (the rest of the range up to first[j + 1] exits at once)
   int mode[WGG_MAX];       // 0 pointwise, 1 gather
+  int jobs;                // 1: the job table maps the blocks; 0: the problem ranges above do
+  unsigned short jobend[8];        // slots (blocks) of each XCD
+  unsigned jobtab[8][WGG_JOBS];    // first slot (9 bits) | problem (5) | split (6) | first tile (12); unused: ~0
   WgradP p[WGG_MAX];
 };
+static_assert(sizeof(WgGroupP) <= 4096, "kernel arguments");
 
 __global__ __launch_bounds__(512) void conv_wgrad_deep_group_kernel(WgGroupP g) {
   const int b = blockIdx.x;
+  if (g.jobs) {
+    const int xcd = b & 7, slot = b >> 3;
+    // (static indices into the kernel arguments only: a run-time index into the by-value struct read 8-byte entries
+    //  4 bytes off on hipcc 7.2 -- every table word is selected by a uniform compare instead)
+    unsigned e = ~0u;
+    int jend = 0;
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      const bool mine = x == xcd;
+      jend = mine ? (int)g.jobend[x] : jend;
+#pragma unroll
+      for (int i = 0; i < WGG_JOBS; ++i) {
+        const unsigned t = g.jobtab[x][i];
+        if (mine && (int)(t >> 23) <= slot) e = t;  // (unused entries: first slot 511; the last match wins)
+      }
+    }
+    if (slot >= jend) return;
+    const int j = __builtin_amdgcn_readfirstlane((int)((e >> 18) & 31));
+    const int sp = (int)((e >> 12) & 63), tile0 = (int)(e & 4095);
+    const int tile = tile0 + slot - (int)(e >> 23);
+    const int blk = __builtin_amdgcn_readfirstlane(sp * (g.p[j].tilesM * g.p[j].tilesN) + tile);
+#ifdef VS_WGG_DEBUG
+    if (j >= g.n || sp >= g.p[j].S || tile >= g.p[j].tilesM * g.p[j].tilesN) {
+      if (threadIdx.x == 0) printf("bad job: b %d xcd %d slot %d e %x j %d sp %d tile %d (n %d S %d nt %d)\n", b, xcd, slot, e, j, sp, tile, g.n, g.p[j].S, g.p[j].tilesM * g.p[j].tilesN);
+      return;
+    }
+#endif
+    if (g.mode[j] == 0) conv_wgrad_deep_body<0, true>(g.p[j], blk, g.count[j]);
+    else conv_wgrad_deep_body<1, true>(g.p[j], blk, g.count[j]);
+    return;
+  }
   int j = 0;
 #pragma unroll
   for (int i = 1; i < WGG_MAX; ++i)
@@ -1419,12 +1461,68 @@ extern "C" int vs_conv_wgrad_group(const vs_wgrad_item* items, int n, void* work
   }
   g.first[n] = first;
   for (int j = n; j < WGG_MAX; ++j) g.first[j + 1] = first;
+  // ---- jobs -> XCDs (VS_WGG_JOBS=0: the round-5 block ranges, A/B) ----
+  // All jobs' tiles in one sequence (the grid order: longest blocks first, a problem's splits one after the other, a
+  // split's tiles consecutive), cut into chunks of 32 = one residency round of one XCD (32 CUs, one 152-KiB block
+  // each); chunk c runs on XCD c % 8 as its round c / 8.  Every round of every XCD is full (the chip fills exactly as
+  // with the round-5 order) and a job is cut at most once per chunk boundary: its slabs are fetched into one L2, or
+  // two, instead of eight.
+  g.jobs = 0;
+  int grid = first;
+  {
+    // Default OFF: measured (profiles/r06_wgrad_jobs.txt) the mapping halves the launch's fabric-side bytes (443 -> 220 MB,
+    // L2 hit rate 0.30 -> 0.63) and buys no time -- neutral alone, 0.8 % SLOWER in the step: the deep body is bound by
+    // its LDS-DMA issue, not by where its operands come from.  VS_WGG_JOBS=1: on.
+    static const int jobs_on = [] { const char* e = getenv("VS_WGG_JOBS"); return e ? atoi(e) : 0; }();
+    bool fits = jobs_on != 0 && n <= 32;
+    int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int x = 0; x < 8; ++x)
+      for (int i = 0; i < WGG_JOBS; ++i) g.jobtab[x][i] = ~0u;
+    long long pos = 0;  // position in the sequence of all blocks
+    for (int a = 0; a < n && fits; ++a) {
+      const int nt = g.p[a].tilesM * g.p[a].tilesN;
+      if (nt > 4095 || g.p[a].S > 63) { fits = false; break; }
+      for (int sp = 0; sp < g.p[a].S && fits; ++sp) {
+        int t0 = 0;
+        while (t0 < nt) {  // the piece of this job inside the current chunk
+          const long long chunk = pos >> 5;
+          const int room = 32 - (int)(pos & 31), c = nt - t0 < room ? nt - t0 : room;
+          const int x = (int)(chunk & 7), slot0 = (int)(chunk >> 3) * 32 + (int)(pos & 31);
+          if (cnt[x] == WGG_JOBS || slot0 + c > 510) { fits = false; break; }
+          g.jobtab[x][cnt[x]++] = ((unsigned)slot0 << 23) | ((unsigned)a << 18) | ((unsigned)sp << 12) | (unsigned)t0;
+          t0 += c;
+          pos += c;
+        }
+      }
+    }
+    if (fits) {
+      const long long chunks = (pos + 31) >> 5;
+      int mx = 0;
+      for (int x = 0; x < 8; ++x) {
+        // slots of XCD x: its full chunks, and the sequence's tail if the last chunk is its own
+        long long sl = 0;
+        for (long long c = x; c < chunks; c += 8) sl = (c >> 3) * 32 + ((c == chunks - 1 && (pos & 31)) ? (pos & 31) : 32);
+        g.jobend[x] = (unsigned short)sl;
+        if ((int)sl > mx) mx = (int)sl;
+      }
+#ifdef VS_WGG_DEBUG
+      for (int x = 0; x < 8; ++x) {
+        fprintf(stderr, "xcd %d (%d slots):", x, (int)g.jobend[x]);
+        for (int i = 0; i < cnt[x]; ++i) fprintf(stderr, " [slot %u p %u s %u t %u]", g.jobtab[x][i] >> 23, (g.jobtab[x][i] >> 18) & 31, (g.jobtab[x][i] >> 12) & 63, g.jobtab[x][i] & 4095);
+        fprintf(stderr, "\n");
+      }
+      for (int a = 0; a < n; ++a) fprintf(stderr, "problem %d: tiles %d x %d S %d rps %d count %d\n", a, g.p[a].tilesM, g.p[a].tilesN, g.p[a].S, g.p[a].rows_per_split, g.count[a]);
+#endif
+      g.jobs = 1;
+      grid = 8 * mx;
+    }
+  }
   static std::once_flag gattr;
   std::call_once(gattr, [] {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_deep_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   const size_t smem = (size_t)WGD_NU * WGD_UNIT + 2 * WGD_TAB * sizeof(int2);
-  hipLaunchKernelGGL(conv_wgrad_deep_group_kernel, dim3(first), dim3(512), smem, (hipStream_t)stream, g);
+  hipLaunchKernelGGL(conv_wgrad_deep_group_kernel, dim3(grid), dim3(512), smem, (hipStream_t)stream, g);
   VS_CHECK_LAUNCH();
   if (r.n > 0) {
     hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3((unsigned)r.first[r.n]), dim3(256), 0, (hipStream_t)stream, r);
