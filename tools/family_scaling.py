@@ -10,14 +10,18 @@ FAM = [("conv fwd/dgrad (igemm)", r"conv_igemm_kernel|conv_igemm_aol"), ("conv h
        ("bn finalize fwd", r"^bn_finalize_kernel|bn_partials_reduce"), ("bn apply", r"bn_apply_cols|bn_apply_kernel|bn_apply_maxpool"),
        ("bn bwd reduce", r"bn_bwd_reduce"), ("bn bwd apply", r"bn_bwd_apply"), ("stems", r"stem_"), ("pools / pack", r"pool|pack_input"),
        ("adam", r"adam"), ("weight images", r"weight_transpose|cast"), ("encoder / head", r"linear|layernorm|attn|softmax|xent"),
-       ("torch / copies", r"at::|rocclr|elementwise")]
+       ("torch (in the step)", r"at::|elementwise")]
+# One-time work that is NOT part of a step (ADVICE / VERDICT r5): the ~1 000 `__amd_rocclr_copyBuffer` parameter uploads of model
+# construction and the fills of first-use workspace allocations happen once per process -- reported on a line of their own,
+# whole (not divided by the step count), and left out of the per-step sums.
+ONE_TIME = r"rocclr|FillFunctor"
 
 
 def load(path):
     fam = {}
     for r in csv.DictReader(open(path)):
         name = r["Name"]
-        key = next((f for f, pat in FAM if re.search(pat, name)), "other")
+        key = "one-time (whole run)" if re.search(ONE_TIME, name) else next((f for f, pat in FAM if re.search(pat, name)), "other")
         c, t = fam.get(key, (0, 0.0))
         fam[key] = (c + int(r["Calls"]), t + float(r["TotalDurationNs"]))
     return fam
@@ -26,6 +30,10 @@ def load(path):
 a, ca, b, cb = load(sys.argv[1]), int(sys.argv[2]), load(sys.argv[3]), int(sys.argv[4])
 print(f"{'family':34s} {'launches':>8s} {'ms/step@' + str(ca):>12s} {'ms/step@' + str(cb):>12s} {'us/clip@' + str(ca):>12s} {'us/clip@' + str(cb):>12s} {'ratio':>6s} {'excess ms@' + str(ca):>12s}")
 tot = [0.0, 0.0, 0.0]
+for key in ("one-time (whole run)",):
+    if key in a or key in b:
+        na, ta = a.get(key, (0, 0.0)); nb, tb = b.get(key, (0, 0.0))
+        print(f"# {key}: {na} launches {ta / 1e6:.3f} ms at {ca} clips, {nb} launches {tb / 1e6:.3f} ms at {cb} clips -- not in the table below")
 for key in [f for f, _ in FAM] + ["other"]:
     if key not in a and key not in b:
         continue

@@ -749,6 +749,14 @@ static void launch_bwd_fused(const float* dy, const float* relu_y, const float* 
   const int g1 = (K + 3) / 4;  // four output columns (of dx) per block
   long long g2 = ((long long)N * ((K + 3) / 4) + 255) / 256;
   if (g2 > 4096) g2 = 4096;
+  {
+    // tools only (timing experiment, GARBAGE parameter gradients): what the weight-gradient half of these launches costs
+    // the step -- the upper bound of moving it to a side stream.  Needs VS_WHATIF_OK=1 beside it.
+    static const int skip_dw = [] {
+      const char* e = getenv("VS_WHATIF_LINEAR_DW"); const char* ok = getenv("VS_WHATIF_OK");
+      return (e && atoi(e) && ok && atoi(ok)) ? 1 : 0; }();
+    if (skip_dw) g2 = 0;
+  }
   hipLaunchKernelGGL((linear_bwd_fused_kernel<8, KC, VEC>), dim3((unsigned)(g1 + g2)), dim3(256), smem, st, dy,
                      relu_y, x, wt, dx, dw, db, M, N, K, g1, (int)g2, dx_res);
 }
