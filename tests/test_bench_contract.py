@@ -1,5 +1,5 @@
 """The bench line's schema (the driver parses it): checked on the committed lines of the current round's build
-(`profiles/r05_bench_train_v2.json`, `profiles/r05_bench_feat_fwd_v2.json`, produced by `python bench.py` on an MI355X)
+(`profiles/r06_bench_train_v1.json`, `profiles/r06_bench_feat_fwd_v1.json`, produced by `python bench.py` on an MI355X)
 and on bench.py's argument surface -- no GPU needed."""
 import json
 import os
@@ -14,7 +14,7 @@ def _line(name):
 
 
 def test_train_line_has_the_contract_fields():
-    d = _line("r05_bench_train_v2.json")
+    d = _line("r06_bench_train_v1.json")
     for k in ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better",
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -56,6 +56,10 @@ def test_train_line_has_the_contract_fields():
     par = d["config"]["parity"]
     assert par["north_star"] == 1e-3 and 0 < par["logits_rel_err_vs_fp32_oracle"] < 1e-2
     assert "measured_at_commit" in par and "not re-measured in this run" in par["source"]
+    # round 6: the training line carries the TRAIN-mode distance beside the eval one, and names the metric
+    assert par["metric"].startswith("max|logit") and 0 < par["train_mode"]["logits_rel_err_vs_fp32_oracle"] < 2e-2
+    assert par["train_mode"]["metric"] == par["metric"] and "configs2" in par["train_mode"]["source"]
+    assert "calibrated_shift_over_clips" in f["parity"] and f["parity"]["metric"] == par["metric"]
 
 
 def test_parity_numbers_come_from_the_file_the_parity_test_writes():
@@ -91,7 +95,7 @@ def test_parity_numbers_come_from_the_file_the_parity_test_writes():
 
 
 def test_forward_line_and_cli_surface():
-    d = _line("r05_bench_feat_fwd_v2.json")
+    d = _line("r06_bench_feat_fwd_v1.json")
     assert d["unit"] == "clips/s" and d["value"] > 0 and "feature extractor" in d["metric"]
     assert "parity" in d["config"]  # the measured logit distance to the fp32 oracle, per eval mode
     src = open(os.path.join(ROOT, "bench.py")).read()

@@ -119,7 +119,9 @@ def test_feat_extractor_cli_from_a_trained_checkpoint_and_from_a_caffe2_pickle(d
     ck = tmp_path / "models" / "t_fx.pth"
     rc, out, err = _run(["-m", "vidsitu_amd.feat_extractor", str(ck), "trained_mini", "--n_videos=3"] + common)
     assert rc == 0 and "wrote 6 feature files" in out, out[-2000:] + err
-    assert "weight-rounding correction calibrated on 2 clip(s)" in out  # (round 5: on by default, --calibrate=0 switches it off)
+    # (round 5: on by default, --calibrate=0 switches it off; round 6: the calibration clips are the first videos of the
+    #  dataset being extracted, not a stand-in batch)
+    assert "weight-rounding correction calibrated on the first 2 video(s) of split 'valid'" in out
     files = sorted((tmp_path / "feats" / "trained_mini").glob("*_feats.npy"))
     assert len(files) == 6
     a = np.load(files[0])

@@ -32,7 +32,12 @@ def main():
             rec[key] = part
     commit = sys.argv[1] if len(sys.argv) > 1 else subprocess.run(
         ["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
-    if not rec.get("commit"):
+    import re
+
+    if not re.fullmatch(r"[0-9a-f]{12}", str(rec.get("commit", ""))):
+        # (the GPU box has no .git: the test wrote the build tag there; keep it beside the commit of the tree that ran)
+        if rec.get("commit"):
+            rec["build_tag"] = rec["commit"]
         rec["commit"] = commit
     with open(dst, "w") as f:
         json.dump(rec, f, indent=1)
