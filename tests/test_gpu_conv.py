@@ -1411,3 +1411,20 @@ def test_grouped_weight_gradients_vs_torch(dev):
     torch.cuda.synchronize()
     assert all(torch.equal(a, it[5]) or float((a - it[5]).abs().max() / a.abs().max()) < 1e-5 for a, it in zip(again, items))
     assert ops.conv_wgrad_group_ok(items * 3) and not ops.conv_wgrad_group_ok(items * 6)
+
+
+def test_grouped_weight_gradients_with_xcd_resident_jobs_opt_in(dev):
+    """Round 6: VS_WGG_JOBS=1 deals the grouped launch's tiles to the XCDs in full 32-block rounds (profiles/r06_wgrad_jobs.txt;
+    half the fabric-side bytes, no time gain -> opt-in).  The switch is read once per process, so the torch comparison above and
+    the ResBlock-level grouped test run again in a child process with the switch set: same bounds, same bitwise repeatability."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VS_WGG_JOBS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(root, "tests", "test_gpu_conv.py") + "::test_grouped_weight_gradients_vs_torch",
+                        os.path.join(root, "tests", "test_gpu_trunk.py") + "::test_grouped_weight_gradients_of_a_resblock"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
