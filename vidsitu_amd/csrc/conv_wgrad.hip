@@ -1476,8 +1476,10 @@ extern "C" int vs_conv_wgrad_group(const vs_wgrad_item* items, int n, void* work
     static const int jobs_on = [] { const char* e = getenv("VS_WGG_JOBS"); return e ? atoi(e) : 0; }();
     bool fits = jobs_on != 0 && n <= 32;
     int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int x = 0; x < 8; ++x)
+    for (int x = 0; x < 8; ++x) {
+      g.jobend[x] = 0;
       for (int i = 0; i < WGG_JOBS; ++i) g.jobtab[x][i] = ~0u;
+    }
     long long pos = 0;  // position in the sequence of all blocks
     for (int a = 0; a < n && fits; ++a) {
       const int nt = g.p[a].tilesM * g.p[a].tilesN;
