@@ -252,7 +252,8 @@ def _block_as_the_kernels_compute_it(blk, x):
 # timed step, and every parameter gradient of those launches is held against the oracle.  The test asserts that the
 # grouped entry point was taken and that no slow-pathway weight gradient went through the per-unit launch.
 @pytest.mark.parametrize("arch,depth,hw,n,stages", [("slowfast", 50, 64, 2, (2, 3, 4, 5)), ("i3d", 50, 64, 2, (2, 3, 4, 5)),
-                                                    ("slowfast", 50, 224, 1, (2, 3)), ("slowfast", 50, 224, 8, (4, 5))])
+                                                    ("slowfast", 50, 224, 1, (2, 3)), ("slowfast", 50, 224, 8, (4, 5)),
+                                                    ("slowfast", 50, 224, 8, (2, 3))])
 def test_every_resblock_fwd_bwd_matches_oracle_on_the_oracles_own_tensors(arch, depth, hw, n, stages, dev, monkeypatch):
     import copy
     import os
@@ -358,11 +359,17 @@ def test_every_resblock_fwd_bwd_matches_oracle_on_the_oracles_own_tensors(arch, 
         pending = []
     torch.set_num_threads(threads0)
     print(f"grouped weight-gradient launches (items each): {group_calls}; per-unit launches: {len(unit_calls)}")
-    if bench_batch:
+    if bench_batch and stages == (4, 5):
         # slow res4 (6 blocks: 3 + 3) and res5 (3 blocks) leave as three-block groups: 3 launches of >= 9 items, and no
         # slow-pathway convolution (Cin and Cout >= 256 here) took the per-unit path
         assert len(group_calls) >= 3 and min(group_calls) >= 9, group_calls  # measured: [9, 10, 10]
         assert not any(co >= 256 and ci >= 256 for co, ci in unit_calls), unit_calls  # (fast pathway: Cin or Cout <= 128)
+    elif bench_batch:
+        # stages 2 / 3 at the bench batch (round 6): slow res3 (inner width 128) is grouped -- blocks 3, 2, 1 as one launch of
+        # 9 items, block 0 with its shortcut as one of 4; slow res2 (inner width 64) and the fast pathway run per unit by plan
+        assert sorted(group_calls) == [4, 9], group_calls
+        slow_s3 = {(128, 512), (128, 128), (512, 128), (128, 320), (512, 320)}
+        assert not any(u in slow_s3 for u in unit_calls), unit_calls
     worst.sort(reverse=True, key=lambda r: r[0])
     print("per-block rel_l2, worst first (worst tensor | z | dx):\n" +
           "\n".join(f"  {e:.3e} {n} ({k}) | z {ez:.3e} | dx {edx:.3e}" for e, n, k, ez, edx, _ in worst))
@@ -390,7 +397,14 @@ def test_every_resblock_fwd_bwd_matches_oracle_on_the_oracles_own_tensors(arch, 
     # tables in profiles/r04_parity_blocks_korder.txt; the kernels themselves are tested against torch in both orders).  That one tensor gets
     # 7e-2 at the small crops (still far below the O(1) a wrong formula gives); everything else keeps 4e-2.
     def limit(block, tensor):
-        if hw >= 224 and not bench_batch and block.endswith("_res0") and tensor in ("branch1.weight", "branch2.a.weight"):
+        if (hw >= 224 and block.endswith("_res0") and tensor in ("branch1.weight", "branch2.a.weight")
+                and (not bench_batch or (".pathway1_" in block and stages == (2, 3)))):
+            return 1.5e-1
+        # stages 2 / 3 at the bench batch (round 6): the fast pathway's res2 blocks sum 8-channel tensors over 6.4 million
+        # positions -- every parameter gradient there is a cancellation-dominated sum of the class described above
+        # (measured: b_bn bias / weight of s2.pathway1_res1 1.0e-1 / 6.6e-2); the kernels are held to fp64 on equal
+        # operands at that size by tests/test_gpu_bn_pool.py and tests/test_gpu_conv.py
+        if bench_batch and stages == (2, 3) and block.startswith("s2.pathway1_"):
             return 1.5e-1
         # (the relaxed bound is for the ONE tensor that moved -- slow s4 res2's b_bn bias at the 64-pixel crop,
         #  4.87e-2 in profiles/r04_parity_blocks_korder.txt -- not for every BN tensor of every block)
@@ -401,6 +415,15 @@ def test_every_resblock_fwd_bwd_matches_oracle_on_the_oracles_own_tensors(arch, 
     gross = [(n, b) for n, b in gross if b]
     assert not gross, f"tensors beyond their bound (4e-2; slow s4 res2's b_bn bias at small crops 7e-2): {gross[:3]}"
     errs = sorted(r[0] for r in worst)
+    if bench_batch and stages == (2, 3):
+        # At 8 clips x 224^2 the res2 / res3 sums run over 0.4-6.4 million positions: the rounding / mask-flip floor of the
+        # per-block comparison sits at 2-4e-2 for the a-unit weight gradients (post-ReLU inputs with a large mean against
+        # zero-sum gradients).  What this case holds: every tensor within its bound above, and the GROUPED blocks (slow
+        # res3: the launches the step runs) entirely within 2e-2 (measured: 7.6e-3 .. 1.1e-2).
+        s3_slow = [(e, n) for e, n, *_ in worst if n.startswith("s3.pathway0_")]
+        assert len(s3_slow) == 4 and all(e < 2e-2 for e, _ in s3_slow), f"grouped slow res3 blocks: {s3_slow}"
+        torch.set_num_threads(threads0)
+        return
     assert errs[len(errs) // 2] < 1e-2, f"median block's worst tensor {errs[len(errs) // 2]:.3e}"
     tight = sum(1 for e in errs if e < 1e-2)
     assert tight >= 0.5 * len(errs), f"only {tight} of {len(errs)} blocks entirely within 1e-2"
@@ -410,7 +433,7 @@ def test_every_resblock_fwd_bwd_matches_oracle_on_the_oracles_own_tensors(arch, 
     #  above, now 8 x 12 544 positions -- and s4.pathway1_res3's b_bn bias 2.06e-2: 16 of 18 within 2e-2)
     frac = 0.85 if bench_batch else 0.9
     assert near >= frac * len(errs) - 1e-9, f"only {near} of {len(errs)} blocks entirely within 2e-2"
-    if bench_batch:
+    if bench_batch and stages == (4, 5):
         slow = [(e, n) for e, n, *_ in worst if ".pathway0_" in n]
         assert len(slow) == 9 and all(e < 2e-2 for e, _ in slow), f"grouped slow-pathway blocks: {slow}"
 
